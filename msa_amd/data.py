@@ -1,0 +1,101 @@
+"""Synthetic MMBertDataset batches that reproduce the reference's input contract.
+
+The reference's data path (``MMBertDataset.__getitem__`` -> ``model_utils.collate`` ->
+``model_utils.mask_tokens`` -> the packing in ``trainer.train_epoch``, REF:trainer.py:41-64) needs
+the CMU pickles and a tokenizer, neither of which exists offline.  This module builds batches with
+the same tuple structure, dtypes and quirks directly:
+
+* ``text / twv / tws``: int64 ``[B,T]``, ``[CLS]=101, tokens, [SEP]=102, PAD=0...``; the three are
+  the same sentence with independently re-drawn MLM masking (REF:trainer.py:45-47).
+* ``visual`` / ``speech``: float64 ``[B,P,D]`` features whose trailing rows are exactly 0 (padding).
+* text mask float64 with 0 at PAD (REF:model_utils.py:118-120); pair masks ``feature != 0`` with the
+  features' shape (float64 for visual, int64 for speech, REF:model_utils.py:124-133); the
+  text-with-pair masks are all ones (the ``==`` bug, REF:model_utils.py:128,136).
+* labels: -100 where not selected, 80 % of the selected inputs -> 103 (REF:model_utils.py:27-32);
+  pair-position labels are a copy of the text labels when P == T (REF:trainer.py:50,53) and -100
+  otherwise (the reference cannot express P != T through ``collate``).
+
+Determinism: numpy PCG64 only, so a (seed, shape) pair means the same batch on every box.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+PAD, CLS, SEP, MASK = 0, 101, 102, 103
+MODALITY_DIMS = {"mosi": (47, 74), "mosei": (35, 74), "ur_funny": (371, 81)}    # REF:config.py:13-17
+
+
+def _mask_tokens(rng, ids, p_mlm):
+    """REF:model_utils.py:6-39 on numpy arrays (special tokens never selected; PAD counts as
+    special because ``get_special_tokens_mask`` flags it)."""
+    special = (ids == PAD) | (ids == CLS) | (ids == SEP)
+    select = (rng.random(ids.shape) < p_mlm) & ~special
+    replace = (rng.random(ids.shape) < 0.8) & select
+    labels = np.where(select, ids, -100)
+    out = np.where(replace, MASK, ids)
+    return out.astype(np.int64), labels.astype(np.int64)
+
+
+def synthetic_batch(batch: int, text_len: int, visual_len: int, speech_len: int, *, dataset="mosei",
+                    vocab=30522, seed=1, mlm_probability=0.15, full_length=False):
+    """Returns the six keyword arguments of ``MMBertForPretraining.forward`` as CPU tensors:
+    ``dict(input_ids=..., token_type_ids=..., attention_mask=..., masked_labels=..., ap_label=...,
+    sentiment=...)``."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    vd, sd = MODALITY_DIMS[dataset]
+    B, T = batch, text_len
+    lo = min(1000, vocab - 1)
+    text = np.zeros((B, T), np.int64)
+    for b in range(B):
+        n = T - 2 if full_length else int(rng.integers(max(1, T // 2), T - 1))
+        text[b, 0] = CLS
+        text[b, 1:1 + n] = rng.integers(lo, vocab, n)
+        text[b, 1 + n] = SEP
+
+    def feats(P, D):
+        x = rng.standard_normal((B, P, D))
+        x[x == 0.0] = 1e-3
+        for b in range(B):
+            n = P if full_length else int(rng.integers(max(1, P // 2), P + 1))
+            x[b, n:] = 0.0
+        return x
+    visual, speech = feats(visual_len, vd), feats(speech_len, sd)
+
+    t_in, t_lab = _mask_tokens(rng, text, mlm_probability)
+    v_in, v_lab = _mask_tokens(rng, text, mlm_probability)
+    s_in, s_lab = _mask_tokens(rng, text, mlm_probability)
+
+    def pair_labels(lab, P):
+        if P == T:
+            return np.concatenate((lab, lab), axis=-1)                    # REF:trainer.py:50,53
+        return np.concatenate((lab, np.full((B, P), -100, np.int64)), axis=-1)
+
+    text_mask = (text != PAD).astype(np.float64)
+    tt = torch.from_numpy
+    input_ids = (tt(t_in), tt(visual), tt(speech), tt(v_in), tt(s_in))
+    token_type_ids = (
+        torch.zeros(B, T, dtype=torch.int64),
+        tt(np.concatenate((np.zeros((B, T)), np.ones((B, visual_len))), axis=1)),
+        tt(np.concatenate((np.zeros((B, T)), np.ones((B, speech_len))), axis=1)),
+    )
+    attention_mask = (
+        tt(text_mask),
+        (torch.ones(B, T, dtype=torch.float64), tt((visual != 0).astype(np.float64))),
+        (torch.ones(B, T, dtype=torch.int64), tt((speech != 0).astype(np.int64))),
+    )
+    masked_labels = (tt(t_lab), tt(pair_labels(v_lab, visual_len)), tt(pair_labels(s_lab, speech_len)))
+    ap_label = (tt(rng.integers(0, 2, B).astype(np.int64)), tt(rng.integers(0, 2, B).astype(np.int64)))
+    sentiment = tt(rng.uniform(-3, 3, B).astype(np.float32))
+    return dict(input_ids=input_ids, token_type_ids=token_type_ids, attention_mask=attention_mask,
+                masked_labels=masked_labels, ap_label=ap_label, sentiment=sentiment)
+
+
+def batch_to(batch: dict, device):
+    """Moves every tensor of a (nested-tuple) batch to ``device`` keeping dtypes, like the
+    ``.to(DEVICE)`` calls in REF:trainer.py:49-64."""
+    def mv(x):
+        if isinstance(x, tuple):
+            return tuple(mv(y) for y in x)
+        return x.to(device)
+    return {k: mv(v) for k, v in batch.items()}
