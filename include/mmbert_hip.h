@@ -1,0 +1,114 @@
+/* mmbert_hip.h -- C ABI of libmmbert_hip.so: the MI355X (gfx950) kernels behind the MMBert train step.
+ *
+ * The reference (kimkyeonghun/MSA) is pure Python and has no FFI: its hot path is the Python module
+ * API of MMBertForPretraining / MMBertModel / JointEmbeddings whose arithmetic
+ * runs inside HuggingFace BERT modules -> ATen/cuBLAS.  This header is the boundary a maintainer
+ * binds instead of those ATen calls (INTEGRATION.md shows the ctypes stubs).  Every entry point:
+ *   - is extern "C", takes plain device pointers / sizes / strides (elements) and a hipStream_t,
+ *   - returns 0, a negative value for rejected arguments, or a positive hipError_t,
+ *   - allocates nothing, synchronises nothing, keeps no state between calls (graph-capturable);
+ *     workspaces are passed in by the caller.
+ * bf16 tensors are row-major `uint16` storage; "ld*" are leading dimensions in elements.
+ * REF: = /root/reference/<file>:<line>;  HF: = transformers models/bert/modeling_bert.py (5.15.0).
+ */
+#ifndef MMBERT_HIP_H
+#define MMBERT_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ihipStream_t* mmbert_stream_t;   /* == hipStream_t */
+
+/* ---- GEMM epilogue flags (mmbert_gemm_nt.epi) ---- */
+#define MMBERT_EPI_BIAS 1      /* + bias[N] (fp32)                                             */
+#define MMBERT_EPI_GELU 2      /* out = gelu_erf(v); aux (optional) = v      HF:334-337         */
+#define MMBERT_EPI_RESID 4     /* out = dropout(v) + R                       HF:289-293,347-351 */
+#define MMBERT_EPI_GELU_BWD 8  /* out = v * gelu'(U)   (dgrad of the FFN down projection)       */
+#define MMBERT_EPI_OUT_F32 16  /* C is fp32 instead of bf16                                     */
+
+/* C[M,N] = epi(alpha * alpha_dev[0] * A[M,K] . B[N,K]^T).  Replaces nn.Linear forward (HF:175-177,
+ * 289, 334, 347, 476, 493) and, with the transposed bf16 weight copy as B, its input gradient.
+ * K % 64 == 0, N % 4 == 0.  Accepted epi: 0, 1, 1|2, 1|4, 4, 8, 16, 1|16. */
+int mmbert_gemm_nt(mmbert_stream_t stream, const void* A, int lda, const void* B, int ldb, void* C, int ldc,
+                   int M, int N, int K, int epi, const float* bias, const void* R, int ldr, void* aux, int ldaux,
+                   const void* U, int ldu, float alpha, const float* alpha_dev,
+                   uint32_t drop_stream, uint32_t drop_thr16, float drop_scale);
+
+/* W[N,K] (fp32) = (accumulate ? W : 0) + alpha * alpha_dev[0] * A[M,N]^T . B[M,K]: the weight
+ * gradient autograd computes for nn.Linear (REF:trainer.py:83).  `slab` must hold
+ * mmbert_gemm_tn_workspace() bytes (split over the token axis, reduced deterministically). */
+size_t mmbert_gemm_tn_workspace(int M, int N, int K, int* splits_out);
+int mmbert_gemm_tn(mmbert_stream_t stream, const void* A, int lda, const void* B, int ldb, float* W, int ldw,
+                   int M, int N, int K, int accumulate, float alpha, const float* alpha_dev, void* slab);
+
+/* out[n] += alpha * alpha_dev[0] * sum_m X[m][n]   (bias gradients) */
+int mmbert_colsum(mmbert_stream_t stream, const void* X, int ldx, int M, int N, float* out, float alpha, const float* alpha_dev);
+
+/* ---- dropout RNG (counter based; forward and backward regenerate the same mask) ---- */
+uint32_t mmbert_rng_stream(uint64_t seed, uint32_t site);
+uint32_t mmbert_dropout_thr16(float p);          /* keep iff 16 random bits >= thr16; 0 = no dropout */
+int mmbert_dropout_mask(mmbert_stream_t stream, uint8_t* out, size_t n, uint32_t rng_stream, uint32_t thr16);
+
+/* ---- LayerNorm (+ the reference's dropout placements) ----
+ * fwd: y[out_rows[i]] = dropout(LN(x[in_rows[i]]))              BertEmbeddings HF:104-107,
+ *      JointEmbeddings REF:MMBertEmbedding.py:69-70, BertSelfOutput/BertOutput LN HF:292,350.
+ * bwd: see rowwise.hip; dx2 = dx * (pre-LN branch dropout mask) feeds the dense layer's gradients. */
+int mmbert_ln_fwd(mmbert_stream_t stream, const void* x, int ldx, const int* in_rows, void* y, int ldy, const int* out_rows,
+                  int M, int H, const float* gamma, const float* beta, float eps, float* mean, float* rstd,
+                  uint32_t dstream, uint32_t dthr, float dscale);
+int mmbert_ln_bwd(mmbert_stream_t stream, const void* dy, int lddy, const int* dy_rows, const void* x, int ldx, const int* x_rows,
+                  const float* mean, const float* rstd, const float* gamma, int M, int H,
+                  void* dx, int lddx, const int* dx_rows, void* dx2, int lddx2, float* dgamma, float* dbeta,
+                  uint32_t post_stream, uint32_t post_thr, float post_scale,
+                  uint32_t pre_stream, uint32_t pre_thr, float pre_scale);
+
+/* ---- embeddings ----
+ * gather: out[i] = word[ids[i]] + type[tts[i]] + pos[i % T]     HF:96-102 via REF:MMBertForPretraining.py:264
+ * scatter: the matching scatter-add of the gradient (row 0 of word excluded: padding_idx, HF:58). */
+int mmbert_embed_gather(mmbert_stream_t stream, const int64_t* ids, const int64_t* tts, const float* word, const float* type,
+                        const float* pos, int n, int T, int H, int V, void* out, int ldo);
+int mmbert_embed_scatter(mmbert_stream_t stream, const int64_t* ids, const int64_t* tts, const void* d, int ldd, int n, int T, int H, int V,
+                         float* gword, float* gtype, float* gpos);
+
+/* JointEmbeddings pair projection relu(W.feat + b) written after the text rows of each sample:
+ * out[(b*(T+P) + T + p)] (REF:MMBertEmbedding.py:61-68); bwd accumulates dW, db. */
+int mmbert_pair_proj_fwd(mmbert_stream_t stream, const float* feat, int B, int P, int D, const float* W, const float* bias, int H,
+                         void* out, int ldo, int T);
+int mmbert_pair_proj_bwd(mmbert_stream_t stream, const float* feat, int B, int P, int D, const void* J, const void* dJ, int ld, int T,
+                         float* dW, float* db, int H);
+
+/* ---- attention (head dim 64) over packed variable-length sequences ----
+ * softmax(q.k^T/8 + key_bias) -> dropout -> .v   (HF:111-136); REF mask plumbing: key_bias is
+ * (1-mask)*-10000 per key token (REF:MMBertForPretraining.py:57-154,246-250).
+ * tile_seq/tile_r0 list the 64-row tiles; elem_base[s] (multiples of 4) are the dropout index bases. */
+int mmbert_attn_fwd(mmbert_stream_t stream, const void* qkv, void* ctx, float* lse, const float* key_bias, int H, int heads,
+                    const int* seq_start, const int* seq_len, const unsigned* elem_base, const int* tile_seq, const int* tile_r0, int ntiles,
+                    uint32_t dstream, uint32_t dthr, float dscale);
+int mmbert_attn_bwd(mmbert_stream_t stream, const void* qkv, const void* ctx, const void* dctx, void* dqkv, const float* lse, float* delta,
+                    const float* key_bias, int H, int heads, const int* seq_start, const int* seq_len, const unsigned* elem_base,
+                    const int* tile_seq, const int* tile_r0, int ntiles, uint32_t dstream, uint32_t dthr, float dscale);
+int mmbert_attn_dropout_mask(mmbert_stream_t stream, uint8_t* out, int S, unsigned elem_base, int head, uint32_t rng_stream, uint32_t thr16);
+
+/* ---- vocabulary cross-entropy (ignore_index -100), per-pass means ----
+ * REF:MMBertForPretraining.py:381-384 (one CrossEntropyLoss(mean) per pass).  loss_sum[s] receives the
+ * mean loss of segment s (rows seg_bounds[s]..seg_bounds[s+1]); dlogits = d(loss_sum[seg])/d(logits). */
+int mmbert_ce_fwd_bwd(mmbert_stream_t stream, const void* logits, int ldv, int V, const int64_t* labels, int M,
+                      const int* seg_bounds, int nseg, float* inv_count, float* loss_sum, float* row_loss, void* dlogits, int ldd);
+
+/* ---- optimizer: flat AdamW (REF:train.py:76-97; mode 0 = transformers-2.8 AdamW, 1 = torch.optim.AdamW) ----
+ * flags[i/256]: 0 no decay, 1 decay, 2 frozen.  n % 256 == 0.  Also refreshes the bf16 copy, and zeroes g. */
+int mmbert_adamw(mmbert_stream_t stream, float* p, float* g, float* m, float* v, void* p_bf16, const uint8_t* flags, size_t n,
+                 float lr, float beta1, float beta2, float eps, float wd, int step, float gscale, int mode, int zero_grad);
+
+int mmbert_cast_f32_bf16(mmbert_stream_t stream, const float* x, void* y, size_t n);
+int mmbert_cast_bf16_f32(mmbert_stream_t stream, const void* x, float* y, size_t n);
+/* descs: device array of {int64 src_off, int64 dst_off, int rows, cols, dst_ld, tile0} (64x64 tiles) */
+int mmbert_transpose_cast(mmbert_stream_t stream, const float* src, void* dst, const void* descs, int ndesc, int total_tiles);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MMBERT_HIP_H */

@@ -1,0 +1,65 @@
+"""ctypes binding of libmmbert_hip.so (the C ABI declared in include/mmbert_hip.h).
+
+There is NO fallback: if the shared library is absent or a symbol is missing, importing the product
+path raises.  Build it with ``python -m msa_amd.build`` (or ``__graft_entry__.build()``).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libmmbert_hip.so")
+
+P, I, F, U32, SZ, U64 = C.c_void_p, C.c_int, C.c_float, C.c_uint32, C.c_size_t, C.c_uint64
+
+# name -> (restype, argtypes); must list every symbol of include/mmbert_hip.h
+SIGNATURES = {
+    "mmbert_gemm_nt": (I, [P, P, I, P, I, P, I, I, I, I, I, P, P, I, P, I, P, I, F, P, U32, U32, F]),
+    "mmbert_gemm_tn_workspace": (SZ, [I, I, I, P]),
+    "mmbert_gemm_tn": (I, [P, P, I, P, I, P, I, I, I, I, I, F, P, P]),
+    "mmbert_colsum": (I, [P, P, I, I, I, P, F, P]),
+    "mmbert_rng_stream": (U32, [U64, U32]),
+    "mmbert_dropout_thr16": (U32, [F]),
+    "mmbert_dropout_mask": (I, [P, P, SZ, U32, U32]),
+    "mmbert_ln_fwd": (I, [P, P, I, P, P, I, P, I, I, P, P, F, P, P, U32, U32, F]),
+    "mmbert_ln_bwd": (I, [P, P, I, P, P, I, P, P, P, P, I, I, P, I, P, P, I, P, P, U32, U32, F, U32, U32, F]),
+    "mmbert_embed_gather": (I, [P, P, P, P, P, P, I, I, I, I, P, I]),
+    "mmbert_embed_scatter": (I, [P, P, P, P, I, I, I, I, I, P, P, P]),
+    "mmbert_pair_proj_fwd": (I, [P, P, I, I, I, P, P, I, P, I, I]),
+    "mmbert_pair_proj_bwd": (I, [P, P, I, I, I, P, P, I, I, P, P, I]),
+    "mmbert_attn_fwd": (I, [P, P, P, P, P, I, I, P, P, P, P, P, I, U32, U32, F]),
+    "mmbert_attn_bwd": (I, [P, P, P, P, P, P, P, P, I, I, P, P, P, P, P, I, U32, U32, F]),
+    "mmbert_attn_dropout_mask": (I, [P, P, I, C.c_uint, I, U32, U32]),
+    "mmbert_ce_fwd_bwd": (I, [P, P, I, I, P, I, P, I, P, P, P, P, I]),
+    "mmbert_adamw": (I, [P, P, P, P, P, P, P, SZ, F, F, F, F, F, I, F, I, I]),
+    "mmbert_cast_f32_bf16": (I, [P, P, P, SZ]),
+    "mmbert_cast_bf16_f32": (I, [P, P, P, SZ]),
+    "mmbert_transpose_cast": (I, [P, P, P, P, I, I]),
+}
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    """Loads the library and binds every declared symbol; raises if anything is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} not found: the MI355X kernels are not built and there is no CPU fallback. "
+            "Run `python -m msa_amd.build` (needs hipcc) first.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the symbol is missing -> loud
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(code: int, what: str) -> None:
+    if code != 0:
+        raise RuntimeError(f"{what} failed with code {code} "
+                           f"({'invalid argument' if code < 0 else 'hipError_t'})")

@@ -1,0 +1,53 @@
+"""Builds msa_amd/libmmbert_hip.so for gfx950 with hipcc (cross-compiles without a GPU).
+
+``python -m msa_amd.build`` or ``msa_amd.build.build()``.  The .so is git-ignored but travels to the
+GPU box with the repo snapshot; it is rebuilt only when a source is newer than it.
+"""
+from __future__ import annotations
+
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "libmmbert_hip.so")
+SOURCES = ["gemm.hip", "attention.hip", "rowwise.hip"]
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffast-math", "-fno-finite-math-only"]
+
+
+def needs_build() -> bool:
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.abspath(__file__)]
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force: bool = False, verbose: bool = True) -> str:
+    if not force and not needs_build():
+        return LIB
+    objs = []
+    os.makedirs(os.path.join(HERE, "_obj"), exist_ok=True)
+    procs = []
+    for s in SOURCES:
+        o = os.path.join(HERE, "_obj", s.replace(".hip", ".o"))
+        objs.append(o)
+        cmd = [HIPCC, *FLAGS, "-c", os.path.join(CSRC, s), "-o", o]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        procs.append(subprocess.Popen(cmd))
+    for p in procs:
+        if p.wait() != 0:
+            raise RuntimeError("hipcc failed")
+    cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv)
+    print(LIB)

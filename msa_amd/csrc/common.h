@@ -1,0 +1,66 @@
+// Shared device helpers for the MMBert gfx950 kernels (wave64, bf16 storage, fp32 math).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef __bf16 bf16_t;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+#define MMB_CHECK_LAUNCH() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return (int)e_; } while (0)
+
+// address-space casts for the LDS-DMA builtin
+#define GPTR(p) ((const void __attribute__((address_space(1)))*)(p))
+#define LPTR(p) ((void __attribute__((address_space(3)))*)(p))
+
+__device__ __forceinline__ float bf2f(bf16_t x) { return (float)x; }
+__device__ __forceinline__ bf16_t f2bf(float x) { return (bf16_t)x; }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Counter-based dropout RNG.  One 32-bit hash serves TWO consecutive elements (16 bits each), so
+// the keep probability is quantised to 1/65536.  stream = mix(seed, site) is computed on the host
+// (mmbert_rng_stream) and passed as a kernel argument; idx is the element's flat index in the
+// tensor the dropout acts on.  Forward and backward kernels regenerate identical masks.
+// ---------------------------------------------------------------------------------------------
+__host__ __device__ __forceinline__ uint32_t mmb_hash32(uint32_t x) {
+    x ^= x >> 16; x *= 0x85EBCA6Bu; x ^= x >> 13; x *= 0xC2B2AE35u; x ^= x >> 16;
+    return x;
+}
+__host__ __device__ __forceinline__ uint32_t mmb_pair_bits(uint32_t stream, uint32_t pair_idx) {
+    return mmb_hash32(pair_idx * 0x9E3779B1u + stream);
+}
+// keep flag of element idx (idx = 2*pair + sub)
+__host__ __device__ __forceinline__ bool mmb_keep(uint32_t stream, uint64_t idx, uint32_t thr16) {
+    uint32_t h = mmb_pair_bits(stream, (uint32_t)(idx >> 1));
+    uint32_t v = (idx & 1) ? (h >> 16) : (h & 0xFFFFu);
+    return v >= thr16;
+}
+// keep flags of 4 consecutive elements starting at an idx that is a multiple of 2
+__device__ __forceinline__ void mmb_keep4(uint32_t stream, uint64_t idx0, uint32_t thr16, bool k[4]) {
+    uint32_t p = (uint32_t)(idx0 >> 1);
+    uint32_t h0 = mmb_pair_bits(stream, p), h1 = mmb_pair_bits(stream, p + 1);
+    k[0] = (h0 & 0xFFFFu) >= thr16; k[1] = (h0 >> 16) >= thr16;
+    k[2] = (h1 & 0xFFFFu) >= thr16; k[3] = (h1 >> 16) >= thr16;
+}
+
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float gelu_erf_grad(float x) {
+    const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752f));
+    const float pdf = 0.3989422804014327f * __expf(-0.5f * x * x);
+    return cdf + x * pdf;
+}

@@ -1,0 +1,665 @@
+// HBM-bound row-wise kernels of the MMBert train step (gfx950): LayerNorm forward/backward with
+// the reference's dropout placements fused, embedding gather / scatter-add, the JointEmbeddings
+// pair projection (K = 35/74/47/371/81: far too thin for MFMA, plain FMA), vocabulary
+// cross-entropy over bf16 logits, the flat AdamW update (+ bf16 weight refresh), and the batched
+// fp32 -> bf16 transpose that maintains the dgrad weight copies.
+//
+// Conventions: one wave (64 lanes) per row, 8-byte bf16x4 accesses, fp32 statistics, row-index
+// maps (int32) where a kernel gathers or scatters rows of the packed token matrix.
+#include "common.h"
+
+#define LN_MAXV 4   // 4 chunks x 64 lanes x 4 elements = 1024 columns max
+
+// --------------------------------------------------------------------------------------------
+// LayerNorm forward: y[out_row(i)] = dropout(LN(x[in_row(i)]))   (dropout index = i*H + col)
+// --------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const bf16_t* __restrict__ x, int ldx, const int* __restrict__ in_rows,
+                                                     bf16_t* __restrict__ y, int ldy, const int* __restrict__ out_rows,
+                                                     int M, int H, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                     float eps, float* __restrict__ mean_out, float* __restrict__ rstd_out,
+                                                     uint32_t dstream, uint32_t dthr, float dscale) {
+    const int lane = threadIdx.x & 63;
+    const int wpb = blockDim.x >> 6;
+    for (int i = blockIdx.x * wpb + (threadIdx.x >> 6); i < M; i += gridDim.x * wpb) {
+        const bf16_t* xr = x + (size_t)(in_rows ? in_rows[i] : i) * ldx;
+        float v[LN_MAXV][4];
+        float s = 0.f;
+#pragma unroll
+        for (int c = 0; c < LN_MAXV; ++c) {
+            const int col = c * 256 + lane * 4;
+            if (col < H) {
+                const bf16x4 t = *(const bf16x4*)(xr + col);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { v[c][r] = bf2f(t[r]); s += v[c][r]; }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[c][r] = 0.f;
+            }
+        }
+        const float mean = wave_sum(s) / H;
+        float q = 0.f;
+#pragma unroll
+        for (int c = 0; c < LN_MAXV; ++c) {
+            const int col = c * 256 + lane * 4;
+            if (col < H) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { const float d = v[c][r] - mean; q += d * d; }
+            }
+        }
+        const float rstd = rsqrtf(wave_sum(q) / H + eps);
+        if (lane == 0) { if (mean_out) mean_out[i] = mean; if (rstd_out) rstd_out[i] = rstd; }
+        bf16_t* yr = y + (size_t)(out_rows ? out_rows[i] : i) * ldy;
+#pragma unroll
+        for (int c = 0; c < LN_MAXV; ++c) {
+            const int col = c * 256 + lane * 4;
+            if (col < H) {
+                const float4 g = *(const float4*)(gamma + col);
+                const float4 b = *(const float4*)(beta + col);
+                float o[4] = {(v[c][0] - mean) * rstd * g.x + b.x, (v[c][1] - mean) * rstd * g.y + b.y,
+                              (v[c][2] - mean) * rstd * g.z + b.z, (v[c][3] - mean) * rstd * g.w + b.w};
+                if (dthr) {
+                    bool k[4];
+                    mmb_keep4(dstream, (uint64_t)i * H + col, dthr, k);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) o[r] = k[r] ? o[r] * dscale : 0.f;
+                }
+                bf16x4 ob = {f2bf(o[0]), f2bf(o[1]), f2bf(o[2]), f2bf(o[3])};
+                *(bf16x4*)(yr + col) = ob;
+            }
+        }
+    }
+}
+
+// --------------------------------------------------------------------------------------------
+// LayerNorm backward.
+//   g  = dy[dy_row(i)] (* post-LN dropout mask, index i*H+col, when post_thr)        -- d(LN out)
+//   dx = rstd * (g*gamma - mean(g*gamma) - xhat * mean(g*gamma*xhat))
+//   dx  -> dx[dx_row(i)]                                                             -- d(LN in)
+//   dx2 -> dx * pre-LN branch dropout mask (index i*H+col) when dx2 != null          -- d(GEMM out)
+//   dgamma += sum_i g*xhat, dbeta += sum_i g   (fp32 atomics, one per column per workgroup)
+// --------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ dy, int lddy, const int* __restrict__ dy_rows,
+                                                     const bf16_t* __restrict__ x, int ldx, const int* __restrict__ x_rows,
+                                                     const float* __restrict__ mean_in, const float* __restrict__ rstd_in,
+                                                     const float* __restrict__ gamma, int M, int H,
+                                                     bf16_t* __restrict__ dx, int lddx, const int* __restrict__ dx_rows,
+                                                     bf16_t* __restrict__ dx2, int lddx2,
+                                                     float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                     uint32_t post_stream, uint32_t post_thr, float post_scale,
+                                                     uint32_t pre_stream, uint32_t pre_thr, float pre_scale) {
+    __shared__ float red[2][4][1024];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    float ag[LN_MAXV][4], ab[LN_MAXV][4];
+#pragma unroll
+    for (int c = 0; c < LN_MAXV; ++c)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { ag[c][r] = 0.f; ab[c][r] = 0.f; }
+    for (int i = blockIdx.x * 4 + w; i < M; i += gridDim.x * 4) {
+        const bf16_t* dyr = dy + (size_t)(dy_rows ? dy_rows[i] : i) * lddy;
+        const bf16_t* xr = x + (size_t)(x_rows ? x_rows[i] : i) * ldx;
+        const float mean = mean_in[i], rstd = rstd_in[i];
+        float g[LN_MAXV][4], xh[LN_MAXV][4];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int c = 0; c < LN_MAXV; ++c) {
+            const int col = c * 256 + lane * 4;
+            if (col < H) {
+                const bf16x4 d = *(const bf16x4*)(dyr + col);
+                const bf16x4 t = *(const bf16x4*)(xr + col);
+                const float4 gm = *(const float4*)(gamma + col);
+                const float gmv[4] = {gm.x, gm.y, gm.z, gm.w};
+                bool k[4] = {true, true, true, true};
+                if (post_thr) mmb_keep4(post_stream, (uint64_t)i * H + col, post_thr, k);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float dv = bf2f(d[r]);
+                    if (post_thr) dv = k[r] ? dv * post_scale : 0.f;
+                    xh[c][r] = (bf2f(t[r]) - mean) * rstd;
+                    ag[c][r] += dv * xh[c][r];
+                    ab[c][r] += dv;
+                    g[c][r] = dv * gmv[r];
+                    s1 += g[c][r]; s2 += g[c][r] * xh[c][r];
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { g[c][r] = 0.f; xh[c][r] = 0.f; }
+            }
+        }
+        s1 = wave_sum(s1) / H; s2 = wave_sum(s2) / H;
+        bf16_t* dxr = dx + (size_t)(dx_rows ? dx_rows[i] : i) * lddx;
+#pragma unroll
+        for (int c = 0; c < LN_MAXV; ++c) {
+            const int col = c * 256 + lane * 4;
+            if (col < H) {
+                float o[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[r] = rstd * (g[c][r] - s1 - xh[c][r] * s2);
+                bf16x4 ob = {f2bf(o[0]), f2bf(o[1]), f2bf(o[2]), f2bf(o[3])};
+                *(bf16x4*)(dxr + col) = ob;
+                if (dx2) {
+                    if (pre_thr) {
+                        bool k[4];
+                        mmb_keep4(pre_stream, (uint64_t)i * H + col, pre_thr, k);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) o[r] = k[r] ? o[r] * pre_scale : 0.f;
+                    }
+                    bf16x4 o2 = {f2bf(o[0]), f2bf(o[1]), f2bf(o[2]), f2bf(o[3])};
+                    *(bf16x4*)(dx2 + (size_t)i * lddx2 + col) = o2;
+                }
+            }
+        }
+    }
+    // workgroup reduction of the gamma/beta partials, then one atomic per column
+#pragma unroll
+    for (int c = 0; c < LN_MAXV; ++c)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            red[0][w][c * 256 + lane * 4 + r] = ag[c][r];
+            red[1][w][c * 256 + lane * 4 + r] = ab[c][r];
+        }
+    __syncthreads();
+    for (int col = threadIdx.x; col < H; col += 256) {
+        const float sg = red[0][0][col] + red[0][1][col] + red[0][2][col] + red[0][3][col];
+        const float sb = red[1][0][col] + red[1][1][col] + red[1][2][col] + red[1][3][col];
+        if (dgamma) atomicAdd(dgamma + col, sg);
+        if (dbeta) atomicAdd(dbeta + col, sb);
+    }
+}
+
+// --------------------------------------------------------------------------------------------
+// Embedding gather: out[i] = word[ids[i]] + type[tt[i]] + pos[i % T]      (fp32 tables -> bf16)
+// --------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void embed_gather_kernel(const int64_t* __restrict__ ids, const int64_t* __restrict__ tts,
+                                                           const float* __restrict__ word, const float* __restrict__ type,
+                                                           const float* __restrict__ pos, int n, int T, int H, int V,
+                                                           bf16_t* __restrict__ out, int ldo) {
+    const int lane = threadIdx.x & 63;
+    for (int i = blockIdx.x * 4 + (threadIdx.x >> 6); i < n; i += gridDim.x * 4) {
+        long id = ids[i]; if (id < 0 || id >= V) id = 0;
+        const long tt = tts ? (tts[i] != 0) : 0;
+        const float* wr = word + (size_t)id * H;
+        const float* tr = type + (size_t)tt * H;
+        const float* pr = pos + (size_t)(i % T) * H;
+        for (int col = lane * 4; col < H; col += 256) {
+            const float4 a = *(const float4*)(wr + col), b = *(const float4*)(tr + col), c = *(const float4*)(pr + col);
+            bf16x4 o = {f2bf(a.x + b.x + c.x), f2bf(a.y + b.y + c.y), f2bf(a.z + b.z + c.z), f2bf(a.w + b.w + c.w)};
+            *(bf16x4*)(out + (size_t)i * ldo + col) = o;
+        }
+    }
+}
+
+// scatter-add of d(embedding sum): word rows (not row 0: padding_idx), position rows, and the two
+// token-type rows (pre-reduced per workgroup, they are hit by every token).
+__global__ __launch_bounds__(256) void embed_scatter_kernel(const int64_t* __restrict__ ids, const int64_t* __restrict__ tts,
+                                                            const bf16_t* __restrict__ d, int ldd, int n, int T, int H, int V,
+                                                            float* __restrict__ gword, float* __restrict__ gtype, float* __restrict__ gpos,
+                                                            int rows_per_block) {
+    __shared__ float tsum[2][1024];
+    for (int c = threadIdx.x; c < 2 * 1024; c += 256) ((float*)tsum)[c] = 0.f;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int beg = blockIdx.x * rows_per_block, end = min(n, beg + rows_per_block);
+    float t0[LN_MAXV][4], t1[LN_MAXV][4];
+#pragma unroll
+    for (int c = 0; c < LN_MAXV; ++c)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { t0[c][r] = 0.f; t1[c][r] = 0.f; }
+    for (int i = beg + w; i < end; i += 4) {
+        const long id = ids[i];
+        const bool tt = tts ? (tts[i] != 0) : false;
+#pragma unroll
+        for (int c = 0; c < LN_MAXV; ++c) {
+            const int col = c * 256 + lane * 4;
+            if (col < H) {
+                const bf16x4 v = *(const bf16x4*)(d + (size_t)i * ldd + col);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float f = bf2f(v[r]);
+                    if (id > 0 && id < V) atomicAdd(gword + (size_t)id * H + col + r, f);
+                    atomicAdd(gpos + (size_t)(i % T) * H + col + r, f);
+                    if (tt) t1[c][r] += f; else t0[c][r] += f;
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < LN_MAXV; ++c)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int col = c * 256 + lane * 4 + r;
+            if (col < H) { atomicAdd(&tsum[0][col], t0[c][r]); atomicAdd(&tsum[1][col], t1[c][r]); }
+        }
+    __syncthreads();
+    for (int col = threadIdx.x; col < H; col += 256) {
+        if (tsum[0][col] != 0.f) atomicAdd(gtype + col, tsum[0][col]);
+        if (tsum[1][col] != 0.f) atomicAdd(gtype + H + col, tsum[1][col]);
+    }
+}
+
+// --------------------------------------------------------------------------------------------
+// JointEmbeddings pair projection: out[out_row0 + b*(T+P) + T + p] = relu(W . feat[b,p] + bias)
+// feat fp32 [B*P, D]; W fp32 [H, D] is staged transposed in LDS; one workgroup = 16 rows.
+// --------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pair_proj_fwd_kernel(const float* __restrict__ feat, int n_rows, int P, int D,
+                                                            const float* __restrict__ W, const float* __restrict__ bias, int H,
+                                                            bf16_t* __restrict__ out, int ldo, int T) {
+    extern __shared__ float sm[];            // feat tile [16][D]
+    const int row0 = blockIdx.x * 16;
+    for (int c = threadIdx.x; c < 16 * D; c += 256) {
+        const int r = row0 + c / D;
+        sm[c] = r < n_rows ? feat[(size_t)r * D + (c % D)] : 0.f;
+    }
+    __syncthreads();
+    for (int h = threadIdx.x; h < H; h += 256) {
+        float acc[16];
+        const float b = bias[h];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = b;
+        const float* wr = W + (size_t)h * D;
+        for (int k = 0; k < D; ++k) {
+            const float w = wr[k];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] += w * sm[r * D + k];
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = row0 + r;
+            if (row < n_rows) {
+                const int b_ = row / P, p_ = row % P;
+                out[(size_t)(b_ * (T + P) + T + p_) * ldo + h] = f2bf(fmaxf(acc[r], 0.f));
+            }
+        }
+    }
+}
+
+// backward: dpre = dJ * (J > 0); dW[h][k] += sum_rows dpre[row][h]*feat[row][k]; db[h] += sum dpre
+// grid: (H/64, row-chunks); each workgroup owns 64 h-columns x a chunk of rows.
+__global__ __launch_bounds__(256) void pair_proj_bwd_kernel(const float* __restrict__ feat, int n_rows, int P, int D,
+                                                            const bf16_t* __restrict__ J, const bf16_t* __restrict__ dJ, int ld, int T,
+                                                            float* __restrict__ dW, float* __restrict__ db, int H, int rows_per_block) {
+    extern __shared__ float sm[];            // [32 rows][D] feat  +  [32][64] dpre
+    float* sf = sm; float* sd = sm + 32 * D;
+    const int h0 = blockIdx.x * 64;
+    const int beg = blockIdx.y * rows_per_block, end = min(n_rows, beg + rows_per_block);
+    // thread t owns h = h0 + (t & 63) and k = (t >> 6) + 4*j
+    const int hl = threadIdx.x & 63, kq = threadIdx.x >> 6;
+    float acc[96];                            // supports D <= 384
+#pragma unroll
+    for (int j = 0; j < 96; ++j) acc[j] = 0.f;
+    float accb = 0.f;
+    for (int r0 = beg; r0 < end; r0 += 32) {
+        __syncthreads();
+        for (int c = threadIdx.x; c < 32 * D; c += 256) {
+            const int r = r0 + c / D;
+            sf[c] = r < end ? feat[(size_t)r * D + (c % D)] : 0.f;
+        }
+        for (int c = threadIdx.x; c < 32 * 64; c += 256) {
+            const int r = r0 + (c >> 6), h = h0 + (c & 63);
+            float v = 0.f;
+            if (r < end && h < H) {
+                const size_t off = (size_t)((r / P) * (T + P) + T + (r % P)) * ld + h;
+                v = bf2f(J[off]) > 0.f ? bf2f(dJ[off]) : 0.f;
+            }
+            sd[c] = v;
+        }
+        __syncthreads();
+        for (int r = 0; r < 32; ++r) {
+            const float dv = sd[r * 64 + hl];
+            if (kq == 0) accb += dv;
+#pragma unroll
+            for (int j = 0; j < 96; ++j) {
+                const int k = kq + 4 * j;
+                if (k < D) acc[j] += dv * sf[r * D + k];
+            }
+        }
+    }
+    const int h = h0 + hl;
+    if (h < H) {
+#pragma unroll
+        for (int j = 0; j < 96; ++j) {
+            const int k = kq + 4 * j;
+            if (k < D) atomicAdd(dW + (size_t)h * D + k, acc[j]);
+        }
+        if (kq == 0) atomicAdd(db + h, accb);
+    }
+}
+
+// --------------------------------------------------------------------------------------------
+// Vocabulary cross-entropy over bf16 logits [M, ldv] (first V columns valid), ignore_index -100.
+// Rows are grouped into up to 4 segments (the text / text+visual / text+speech passes): each
+// segment's loss is a mean over ITS non-ignored rows (REF get_outputs, one CrossEntropyLoss per pass).
+//   ce_count : inv_count[s] = 1/max(1,#valid rows in segment s); loss_sum[s] = 0
+//   ce_row   : one workgroup per row, whole row held in registers (<= 16 x 16 B per lane):
+//              loss_sum[seg] += (lse - logit[label]) * inv_count; dlogits = (softmax - onehot)*inv_count
+//              (0 for ignored rows and for the pad columns V..ldv)
+// --------------------------------------------------------------------------------------------
+__global__ void ce_count_kernel(const int64_t* __restrict__ labels, int M, const int* __restrict__ seg_bounds, int nseg,
+                                float* __restrict__ inv_count, float* __restrict__ loss_sum) {
+    __shared__ int cnt[4];
+    if (threadIdx.x < 4) cnt[threadIdx.x] = 0;
+    __syncthreads();
+    for (int i = threadIdx.x; i < M; i += blockDim.x) {
+        if (labels[i] != -100) {
+            int s = 0;
+            while (s + 1 < nseg && i >= seg_bounds[s + 1]) ++s;
+            atomicAdd(&cnt[s], 1);
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < nseg) {
+        inv_count[threadIdx.x] = 1.0f / (float)max(cnt[threadIdx.x], 1);
+        // torch CrossEntropyLoss(mean) over zero valid rows gives nan; the reference never hits it
+        loss_sum[threadIdx.x] = 0.f;
+    }
+}
+
+#define CE_MAXC 16
+__global__ __launch_bounds__(256) void ce_row_kernel(const bf16_t* __restrict__ logits, int ldv, int V, const int64_t* __restrict__ labels,
+                                                     const int* __restrict__ seg_bounds, int nseg, const float* __restrict__ inv_count,
+                                                     float* __restrict__ loss_sum, float* __restrict__ row_loss,
+                                                     bf16_t* __restrict__ dlogits, int ldd) {
+    __shared__ float red[4];
+    __shared__ float lab_logit;
+    const int i = blockIdx.x;
+    const int64_t lab = labels[i];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int nchunk = ldv >> 3;
+    bf16_t* drow = dlogits ? dlogits + (size_t)i * ldd : nullptr;
+    if (lab == -100 || lab < 0 || lab >= V) {
+        if (row_loss && tid == 0) row_loss[i] = 0.f;
+        if (drow) {
+            const bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+            for (int c = tid; c < nchunk; c += 256) *(bf16x8*)(drow + c * 8) = z;
+        }
+        return;
+    }
+    int s = 0;
+    while (s + 1 < nseg && i >= seg_bounds[s + 1]) ++s;
+    const float inv = inv_count[s];
+    const bf16_t* row = logits + (size_t)i * ldv;
+    bf16x8 v[CE_MAXC];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int c = 0; c < CE_MAXC; ++c) {
+        const int ch = c * 256 + tid;
+        if (ch < nchunk) {
+            v[c] = *(const bf16x8*)(row + ch * 8);
+#pragma unroll
+            for (int r = 0; r < 8; ++r) if (ch * 8 + r < V) mx = fmaxf(mx, bf2f(v[c][r]));
+        }
+    }
+    mx = wave_max(mx);
+    if (lane == 0) red[w] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    __syncthreads();
+    float se = 0.f;
+#pragma unroll
+    for (int c = 0; c < CE_MAXC; ++c) {
+        const int ch = c * 256 + tid;
+        if (ch < nchunk) {
+#pragma unroll
+            for (int r = 0; r < 8; ++r) if (ch * 8 + r < V) se += __expf(bf2f(v[c][r]) - mx);
+            if ((int)(lab >> 3) == ch) lab_logit = bf2f(v[c][lab & 7]);
+        }
+    }
+    se = wave_sum(se);
+    if (lane == 0) red[w] = se;
+    __syncthreads();
+    se = red[0] + red[1] + red[2] + red[3];
+    const float lse = mx + __logf(se);
+    if (tid == 0) {
+        const float l = lse - lab_logit;
+        if (row_loss) row_loss[i] = l;
+        atomicAdd(loss_sum + s, l * inv);
+    }
+    if (drow) {
+#pragma unroll
+        for (int c = 0; c < CE_MAXC; ++c) {
+            const int ch = c * 256 + tid;
+            if (ch < nchunk) {
+                bf16x8 o;
+#pragma unroll
+                for (int r = 0; r < 8; ++r) {
+                    const int col = ch * 8 + r;
+                    float pr = col < V ? __expf(bf2f(v[c][r]) - lse) : 0.f;
+                    if (col == (int)lab) pr -= 1.0f;
+                    o[r] = f2bf(pr * inv);
+                }
+                *(bf16x8*)(drow + ch * 8) = o;
+            }
+        }
+    }
+}
+
+// --------------------------------------------------------------------------------------------
+// Flat AdamW over the model's contiguous fp32 parameter / gradient / moment buffers.
+// flags[block of 256 elements]: 0 = no weight decay, 1 = weight decay, 2 = frozen (the
+// reference's never-differentiated parameters keep grad None and are skipped by the optimizer).
+// mode 0 = transformers-2.8 AdamW (decay after the update), 1 = torch.optim.AdamW.
+// Also writes the bf16 working copy and (optionally) zeroes the gradient: zero_grad fused.
+// --------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                                                    bf16_t* __restrict__ pb, const uint8_t* __restrict__ flags, size_t n,
+                                                    float lr, float beta1, float beta2, float eps, float wd, float bc1, float bc2,
+                                                    float gscale, int mode, int zero_grad) {
+    const size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i >= n) return;
+    const uint8_t f = flags[i >> 8];
+    float4 P = *(float4*)(p + i);
+    if (f != 2) {
+        float4 G = *(float4*)(g + i), Mm = *(float4*)(m + i), Vv = *(float4*)(v + i);
+        float pa[4] = {P.x, P.y, P.z, P.w}, ga[4] = {G.x, G.y, G.z, G.w}, ma[4] = {Mm.x, Mm.y, Mm.z, Mm.w}, va[4] = {Vv.x, Vv.y, Vv.z, Vv.w};
+        const float decay = (f == 1) ? wd : 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float gr = ga[r] * gscale;
+            if (mode == 1) pa[r] *= (1.0f - lr * decay);
+            ma[r] = beta1 * ma[r] + (1.0f - beta1) * gr;
+            va[r] = beta2 * va[r] + (1.0f - beta2) * gr * gr;
+            if (mode == 0) {
+                pa[r] -= (lr * sqrtf(bc2) / bc1) * ma[r] / (sqrtf(va[r]) + eps);
+                pa[r] -= lr * decay * pa[r];
+            } else {
+                pa[r] -= (lr / bc1) * ma[r] / (sqrtf(va[r]) / sqrtf(bc2) + eps);
+            }
+        }
+        P = make_float4(pa[0], pa[1], pa[2], pa[3]);
+        *(float4*)(p + i) = P;
+        *(float4*)(m + i) = make_float4(ma[0], ma[1], ma[2], ma[3]);
+        *(float4*)(v + i) = make_float4(va[0], va[1], va[2], va[3]);
+    }
+    if (zero_grad) *(float4*)(g + i) = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (pb) { bf16x4 o = {f2bf(P.x), f2bf(P.y), f2bf(P.z), f2bf(P.w)}; *(bf16x4*)(pb + i) = o; }
+}
+
+__global__ void cast_f32_bf16_kernel(const float* __restrict__ x, bf16_t* __restrict__ y, size_t n) {
+    for (size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n; i += (size_t)gridDim.x * blockDim.x * 4) {
+        const float4 a = *(const float4*)(x + i);
+        bf16x4 o = {f2bf(a.x), f2bf(a.y), f2bf(a.z), f2bf(a.w)};
+        *(bf16x4*)(y + i) = o;
+    }
+}
+
+__global__ void cast_bf16_f32_kernel(const bf16_t* __restrict__ x, float* __restrict__ y, size_t n) {
+    for (size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n; i += (size_t)gridDim.x * blockDim.x * 4) {
+        const bf16x4 a = *(const bf16x4*)(x + i);
+        *(float4*)(y + i) = make_float4(bf2f(a[0]), bf2f(a[1]), bf2f(a[2]), bf2f(a[3]));
+    }
+}
+
+// batched transpose-cast: for each descriptor d: dst[c][r] (bf16, ld = dst_ld) = src[r][c] (fp32 [rows, cols])
+struct TransDesc { long long src_off, dst_off; int rows, cols, dst_ld, tile0; };
+__global__ __launch_bounds__(256) void transpose_cast_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst,
+                                                             const TransDesc* __restrict__ descs, int ndesc) {
+    __shared__ float t[64][65];
+    int d = 0;
+    while (d + 1 < ndesc && (int)blockIdx.x >= descs[d + 1].tile0) ++d;
+    const TransDesc ds = descs[d];
+    const int tl = blockIdx.x - ds.tile0;
+    const int tc = (ds.cols + 63) >> 6;
+    const int r0 = (tl / tc) << 6, c0 = (tl % tc) << 6;
+    const float* s = src + ds.src_off;
+    bf16_t* o = dst + ds.dst_off;
+    for (int e = threadIdx.x; e < 4096; e += 256) {
+        const int r = e >> 6, c = e & 63;
+        t[r][c] = (r0 + r < ds.rows && c0 + c < ds.cols) ? s[(size_t)(r0 + r) * ds.cols + c0 + c] : 0.f;
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < 4096; e += 256) {
+        const int c = e >> 6, r = e & 63;
+        if (c0 + c < ds.cols && r0 + r < ds.dst_ld) o[(size_t)(c0 + c) * ds.dst_ld + r0 + r] = f2bf(r0 + r < ds.rows ? t[r][c] : 0.f);
+    }
+}
+
+// test/debug: keep mask of a dropout site as bytes (so the CPU oracle can replay the same mask)
+__global__ void dropout_mask_kernel(uint8_t* __restrict__ out, size_t n, uint32_t stream, uint32_t thr) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        out[i] = mmb_keep(stream, i, thr) ? 1 : 0;
+}
+
+static inline int grid_for(size_t work_items, int per_block, int cap = 2048) {
+    size_t b = (work_items + per_block - 1) / per_block;
+    if (b < 1) b = 1;
+    return (int)(b > (size_t)cap ? cap : b);
+}
+
+extern "C" {
+
+uint32_t mmbert_rng_stream(uint64_t seed, uint32_t site) {
+    uint32_t a = mmb_hash32((uint32_t)seed ^ 0xA511E9B3u);
+    uint32_t b = mmb_hash32((uint32_t)(seed >> 32) + 0x7F4A7C15u);
+    return mmb_hash32(a ^ (b * 0x9E3779B1u) ^ mmb_hash32(site * 0x85EBCA6Bu + 0x27D4EB2Fu));
+}
+
+uint32_t mmbert_dropout_thr16(float p) {
+    if (p <= 0.f) return 0;
+    double t = (double)p * 65536.0 + 0.5;
+    if (t > 65535.0) t = 65535.0;
+    return (uint32_t)t;
+}
+
+int mmbert_ln_fwd(hipStream_t stream, const void* x, int ldx, const int* in_rows, void* y, int ldy, const int* out_rows,
+                  int M, int H, const float* gamma, const float* beta, float eps, float* mean, float* rstd,
+                  uint32_t dstream, uint32_t dthr, float dscale) {
+    if (M <= 0) return 0;
+    if (H > LN_MAXV * 256 || (H & 3) || (ldx & 3) || (ldy & 3)) return -1;
+    hipLaunchKernelGGL(ln_fwd_kernel, dim3(grid_for(M, 4)), dim3(256), 0, stream, (const bf16_t*)x, ldx, in_rows, (bf16_t*)y, ldy, out_rows,
+                       M, H, gamma, beta, eps, mean, rstd, dstream, dthr, dscale);
+    MMB_CHECK_LAUNCH();
+    return 0;
+}
+
+int mmbert_ln_bwd(hipStream_t stream, const void* dy, int lddy, const int* dy_rows, const void* x, int ldx, const int* x_rows,
+                  const float* mean, const float* rstd, const float* gamma, int M, int H,
+                  void* dx, int lddx, const int* dx_rows, void* dx2, int lddx2, float* dgamma, float* dbeta,
+                  uint32_t post_stream, uint32_t post_thr, float post_scale,
+                  uint32_t pre_stream, uint32_t pre_thr, float pre_scale) {
+    if (M <= 0) return 0;
+    if (H > LN_MAXV * 256 || (H & 3) || (ldx & 3) || (lddy & 3) || (lddx & 3) || (lddx2 & 3)) return -1;
+    hipLaunchKernelGGL(ln_bwd_kernel, dim3(grid_for(M, 32, 512)), dim3(256), 0, stream, (const bf16_t*)dy, lddy, dy_rows, (const bf16_t*)x, ldx, x_rows,
+                       mean, rstd, gamma, M, H, (bf16_t*)dx, lddx, dx_rows, (bf16_t*)dx2, lddx2, dgamma, dbeta,
+                       post_stream, post_thr, post_scale, pre_stream, pre_thr, pre_scale);
+    MMB_CHECK_LAUNCH();
+    return 0;
+}
+
+int mmbert_embed_gather(hipStream_t stream, const int64_t* ids, const int64_t* tts, const float* word, const float* type, const float* pos,
+                        int n, int T, int H, int V, void* out, int ldo) {
+    if (n <= 0) return 0;
+    if ((H & 3) || (ldo & 3)) return -1;
+    hipLaunchKernelGGL(embed_gather_kernel, dim3(grid_for(n, 4)), dim3(256), 0, stream, ids, tts, word, type, pos, n, T, H, V, (bf16_t*)out, ldo);
+    MMB_CHECK_LAUNCH();
+    return 0;
+}
+
+int mmbert_embed_scatter(hipStream_t stream, const int64_t* ids, const int64_t* tts, const void* d, int ldd, int n, int T, int H, int V,
+                         float* gword, float* gtype, float* gpos) {
+    if (n <= 0) return 0;
+    if (H > LN_MAXV * 256 || (H & 3) || (ldd & 3)) return -1;
+    const int rows = 32;
+    hipLaunchKernelGGL(embed_scatter_kernel, dim3((n + rows - 1) / rows), dim3(256), 0, stream, ids, tts, (const bf16_t*)d, ldd, n, T, H, V, gword, gtype, gpos, rows);
+    MMB_CHECK_LAUNCH();
+    return 0;
+}
+
+int mmbert_pair_proj_fwd(hipStream_t stream, const float* feat, int B, int P, int D, const float* W, const float* bias, int H,
+                         void* out, int ldo, int T) {
+    const int n = B * P;
+    if (n <= 0) return 0;
+    if (D > 384) return -1;
+    hipLaunchKernelGGL(pair_proj_fwd_kernel, dim3((n + 15) / 16), dim3(256), 16 * D * sizeof(float), stream, feat, n, P, D, W, bias, H, (bf16_t*)out, ldo, T);
+    MMB_CHECK_LAUNCH();
+    return 0;
+}
+
+int mmbert_pair_proj_bwd(hipStream_t stream, const float* feat, int B, int P, int D, const void* J, const void* dJ, int ld, int T,
+                         float* dW, float* db, int H) {
+    const int n = B * P;
+    if (n <= 0) return 0;
+    if (D > 384) return -1;
+    const int gx = (H + 63) / 64;
+    int gy = (512 + gx - 1) / gx;
+    int rows = ((n + gy - 1) / gy + 31) / 32 * 32;
+    gy = (n + rows - 1) / rows;
+    hipLaunchKernelGGL(pair_proj_bwd_kernel, dim3(gx, gy), dim3(256), (32 * D + 32 * 64) * sizeof(float), stream, feat, n, P, D,
+                       (const bf16_t*)J, (const bf16_t*)dJ, ld, T, dW, db, H, rows);
+    MMB_CHECK_LAUNCH();
+    return 0;
+}
+
+int mmbert_ce_fwd_bwd(hipStream_t stream, const void* logits, int ldv, int V, const int64_t* labels, int M,
+                      const int* seg_bounds, int nseg, float* inv_count, float* loss_sum, float* row_loss, void* dlogits, int ldd) {
+    if (M <= 0) return 0;
+    if (nseg < 1 || nseg > 4 || (ldv & 7) || (ldd & 7) || ldv > CE_MAXC * 256 * 8 || V > ldv) return -1;
+    hipLaunchKernelGGL(ce_count_kernel, dim3(1), dim3(1024), 0, stream, labels, M, seg_bounds, nseg, inv_count, loss_sum);
+    MMB_CHECK_LAUNCH();
+    hipLaunchKernelGGL(ce_row_kernel, dim3(M), dim3(256), 0, stream, (const bf16_t*)logits, ldv, V, labels, seg_bounds, nseg, inv_count, loss_sum,
+                       row_loss, (bf16_t*)dlogits, ldd);
+    MMB_CHECK_LAUNCH();
+    return 0;
+}
+
+int mmbert_adamw(hipStream_t stream, float* p, float* g, float* m, float* v, void* p_bf16, const uint8_t* flags, size_t n,
+                 float lr, float beta1, float beta2, float eps, float wd, int step, float gscale, int mode, int zero_grad) {
+    if (n == 0) return 0;
+    if (n & 255) return -1;
+    const float bc1 = 1.0f - powf(beta1, (float)step), bc2 = 1.0f - powf(beta2, (float)step);
+    hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, stream, p, g, m, v, (bf16_t*)p_bf16, flags, n,
+                       lr, beta1, beta2, eps, wd, bc1, bc2, gscale, mode, zero_grad);
+    MMB_CHECK_LAUNCH();
+    return 0;
+}
+
+int mmbert_cast_f32_bf16(hipStream_t stream, const float* x, void* y, size_t n) {
+    if (n == 0) return 0;
+    if (n & 3) return -1;
+    hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3(grid_for(n / 4, 256, 4096)), dim3(256), 0, stream, x, (bf16_t*)y, n);
+    MMB_CHECK_LAUNCH();
+    return 0;
+}
+
+int mmbert_cast_bf16_f32(hipStream_t stream, const void* x, float* y, size_t n) {
+    if (n == 0) return 0;
+    if (n & 3) return -1;
+    hipLaunchKernelGGL(cast_bf16_f32_kernel, dim3(grid_for(n / 4, 256, 4096)), dim3(256), 0, stream, (const bf16_t*)x, y, n);
+    MMB_CHECK_LAUNCH();
+    return 0;
+}
+
+// descs: device array of {src_off, dst_off, rows, cols, dst_ld, tile0}; total_tiles = sum of 64x64 tiles
+int mmbert_transpose_cast(hipStream_t stream, const float* src, void* dst, const void* descs, int ndesc, int total_tiles) {
+    if (ndesc <= 0 || total_tiles <= 0) return 0;
+    hipLaunchKernelGGL(transpose_cast_kernel, dim3(total_tiles), dim3(256), 0, stream, src, (bf16_t*)dst, (const TransDesc*)descs, ndesc);
+    MMB_CHECK_LAUNCH();
+    return 0;
+}
+
+int mmbert_dropout_mask(hipStream_t stream, uint8_t* out, size_t n, uint32_t rng_stream, uint32_t thr16) {
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(dropout_mask_kernel, dim3(grid_for(n, 256, 4096)), dim3(256), 0, stream, out, n, rng_stream, thr16);
+    MMB_CHECK_LAUNCH();
+    return 0;
+}
+
+}  // extern "C"

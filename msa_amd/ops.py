@@ -1,0 +1,280 @@
+"""Tensor-level wrappers over the C ABI (include/mmbert_hip.h).  torch is used for device memory
+and the current stream only; every computation below is a hand-written gfx950 kernel.
+
+All tensors must live on the GPU; bf16 operands are ``torch.bfloat16``; leading dimensions are
+taken from ``stride(0)`` so row-slices of larger buffers can be passed without copies.
+"""
+from __future__ import annotations
+
+from typing import Optional, Tuple
+
+import torch
+
+from . import _lib
+
+EPI_BIAS, EPI_GELU, EPI_RESID, EPI_GELU_BWD, EPI_OUT_F32 = 1, 2, 4, 8, 16
+
+Drop = Optional[Tuple[int, int, float]]      # (rng stream, thr16, scale)
+NO_DROP = (0, 0, 1.0)
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def rng_stream(seed: int, site: int) -> int:
+    return _lib.load().mmbert_rng_stream(seed & 0xFFFFFFFFFFFFFFFF, site & 0xFFFFFFFF)
+
+
+def make_drop(p: float, seed: int, site: int) -> Tuple[int, int, float]:
+    """(stream, thr16, scale) of a dropout site; the effective drop probability is thr16/65536."""
+    if p <= 0.0:
+        return NO_DROP
+    lib = _lib.load()
+    thr = lib.mmbert_dropout_thr16(p)
+    return (rng_stream(seed, site), thr, 1.0 / (1.0 - thr / 65536.0))
+
+
+def gemm_nt(A, B, *, out=None, bias=None, gelu=False, aux=None, resid=None, gelu_bwd_u=None, alpha=1.0,
+            alpha_dev=None, drop: Drop = None, out_f32=False):
+    """out[M,N] = epi(alpha * A[M,K] @ B[N,K]^T)  (see mmbert_gemm_nt)."""
+    lib = _lib.load()
+    M, K = A.shape
+    N = B.shape[0]
+    assert B.shape[1] == K and A.stride(1) == 1 and B.stride(1) == 1
+    if out is None:
+        out = torch.empty((M, N), device=A.device, dtype=torch.float32 if out_f32 else torch.bfloat16)
+    epi = 0
+    if bias is not None:
+        epi |= EPI_BIAS
+    if gelu:
+        epi |= EPI_GELU
+    if resid is not None:
+        epi |= EPI_RESID
+    if gelu_bwd_u is not None:
+        epi |= EPI_GELU_BWD
+    if out_f32:
+        epi |= EPI_OUT_F32
+    d = drop or NO_DROP
+    _lib.check(lib.mmbert_gemm_nt(_stream(), A.data_ptr(), A.stride(0), B.data_ptr(), B.stride(0), out.data_ptr(), out.stride(0),
+                                  M, N, K, epi, _ptr(bias), _ptr(resid), resid.stride(0) if resid is not None else 0,
+                                  _ptr(aux), aux.stride(0) if aux is not None else 0,
+                                  _ptr(gelu_bwd_u), gelu_bwd_u.stride(0) if gelu_bwd_u is not None else 0,
+                                  float(alpha), _ptr(alpha_dev), d[0], d[1], d[2]), "mmbert_gemm_nt")
+    return out
+
+
+_slab_cache = {}
+
+
+def _slab(nbytes: int, device) -> Optional[torch.Tensor]:
+    if nbytes == 0:
+        return None
+    key = (device, torch.cuda.current_stream().cuda_stream)
+    t = _slab_cache.get(key)
+    if t is None or t.numel() < nbytes:
+        t = torch.empty(nbytes, device=device, dtype=torch.uint8)
+        _slab_cache[key] = t
+    return t
+
+
+def gemm_tn(A, B, W, *, accumulate=True, alpha=1.0, alpha_dev=None):
+    """W[N,K] (fp32) (+)= alpha * A[M,N]^T @ B[M,K]   (weight gradient; see mmbert_gemm_tn)."""
+    lib = _lib.load()
+    M, N = A.shape
+    K = B.shape[1]
+    assert B.shape[0] == M and W.shape == (N, K) and W.dtype == torch.float32
+    need = lib.mmbert_gemm_tn_workspace(M, N, K, None)
+    slab = _slab(need, A.device)
+    _lib.check(lib.mmbert_gemm_tn(_stream(), A.data_ptr(), A.stride(0), B.data_ptr(), B.stride(0), W.data_ptr(), W.stride(0),
+                                  M, N, K, 1 if accumulate else 0, float(alpha), _ptr(alpha_dev), _ptr(slab)), "mmbert_gemm_tn")
+    return W
+
+
+def colsum(X, out, *, alpha=1.0, alpha_dev=None):
+    lib = _lib.load()
+    M, N = X.shape
+    _lib.check(lib.mmbert_colsum(_stream(), X.data_ptr(), X.stride(0), M, N, out.data_ptr(), float(alpha), _ptr(alpha_dev)), "mmbert_colsum")
+    return out
+
+
+def dropout_mask(n: int, drop: Tuple[int, int, float], device) -> torch.Tensor:
+    lib = _lib.load()
+    out = torch.empty(n, device=device, dtype=torch.uint8)
+    _lib.check(lib.mmbert_dropout_mask(_stream(), out.data_ptr(), n, drop[0], drop[1]), "mmbert_dropout_mask")
+    return out
+
+
+def ln_fwd(x, gamma, beta, eps, *, M=None, out=None, in_rows=None, out_rows=None, drop: Drop = None, stats=True):
+    lib = _lib.load()
+    H = x.shape[1]
+    if M is None:
+        M = in_rows.numel() if in_rows is not None else x.shape[0]
+    if out is None:
+        out = torch.empty((M, H), device=x.device, dtype=torch.bfloat16)
+    mean = torch.empty(M, device=x.device, dtype=torch.float32) if stats else None
+    rstd = torch.empty(M, device=x.device, dtype=torch.float32) if stats else None
+    d = drop or NO_DROP
+    _lib.check(lib.mmbert_ln_fwd(_stream(), x.data_ptr(), x.stride(0), _ptr(in_rows), out.data_ptr(), out.stride(0), _ptr(out_rows),
+                                 M, H, gamma.data_ptr(), beta.data_ptr(), float(eps), _ptr(mean), _ptr(rstd), d[0], d[1], d[2]), "mmbert_ln_fwd")
+    return out, mean, rstd
+
+
+def ln_bwd(dy, x, mean, rstd, gamma, dgamma, dbeta, *, M=None, dx=None, dx2=None, dy_rows=None, x_rows=None, dx_rows=None,
+           post_drop: Drop = None, pre_drop: Drop = None):
+    lib = _lib.load()
+    H = x.shape[1]
+    if M is None:
+        M = mean.numel()
+    if dx is None:
+        dx = torch.empty((M, H), device=x.device, dtype=torch.bfloat16)
+    po, pr = post_drop or NO_DROP, pre_drop or NO_DROP
+    _lib.check(lib.mmbert_ln_bwd(_stream(), dy.data_ptr(), dy.stride(0), _ptr(dy_rows), x.data_ptr(), x.stride(0), _ptr(x_rows),
+                                 mean.data_ptr(), rstd.data_ptr(), gamma.data_ptr(), M, H,
+                                 dx.data_ptr(), dx.stride(0), _ptr(dx_rows), _ptr(dx2), dx2.stride(0) if dx2 is not None else 0,
+                                 _ptr(dgamma), _ptr(dbeta), po[0], po[1], po[2], pr[0], pr[1], pr[2]), "mmbert_ln_bwd")
+    return dx
+
+
+def embed_gather(ids, tts, word, type_, pos, T, out=None):
+    lib = _lib.load()
+    n = ids.numel()
+    V, H = word.shape
+    if out is None:
+        out = torch.empty((n, H), device=word.device, dtype=torch.bfloat16)
+    _lib.check(lib.mmbert_embed_gather(_stream(), ids.data_ptr(), _ptr(tts), word.data_ptr(), type_.data_ptr(), pos.data_ptr(),
+                                       n, T, H, V, out.data_ptr(), out.stride(0)), "mmbert_embed_gather")
+    return out
+
+
+def embed_scatter(ids, tts, d, T, gword, gtype, gpos):
+    lib = _lib.load()
+    n = ids.numel()
+    V, H = gword.shape
+    _lib.check(lib.mmbert_embed_scatter(_stream(), ids.data_ptr(), _ptr(tts), d.data_ptr(), d.stride(0), n, T, H, V,
+                                        gword.data_ptr(), gtype.data_ptr(), gpos.data_ptr()), "mmbert_embed_scatter")
+
+
+def pair_proj_fwd(feat, W, bias, out, T):
+    """feat fp32 [B,P,D]; writes relu(W.feat+b) into rows b*(T+P)+T+p of ``out`` (bf16 [B*(T+P), H])."""
+    lib = _lib.load()
+    B, Pn, D = feat.shape
+    H = W.shape[0]
+    _lib.check(lib.mmbert_pair_proj_fwd(_stream(), feat.data_ptr(), B, Pn, D, W.data_ptr(), bias.data_ptr(), H,
+                                        out.data_ptr(), out.stride(0), T), "mmbert_pair_proj_fwd")
+
+
+def pair_proj_bwd(feat, J, dJ, T, dW, db):
+    lib = _lib.load()
+    B, Pn, D = feat.shape
+    H = dW.shape[0]
+    assert J.stride(0) == dJ.stride(0)
+    _lib.check(lib.mmbert_pair_proj_bwd(_stream(), feat.data_ptr(), B, Pn, D, J.data_ptr(), dJ.data_ptr(), J.stride(0), T,
+                                        dW.data_ptr(), db.data_ptr(), H), "mmbert_pair_proj_bwd")
+
+
+class SeqLayout:
+    """Device-side description of the packed variable-length token matrix: ``lens[i]`` tokens per
+    sequence, sequences back to back.  Cached per shape (built on the host, no device sync)."""
+
+    def __init__(self, lens, heads, device):
+        starts, tiles_seq, tiles_r0, bases = [], [], [], []
+        s = 0
+        e = 0
+        for i, n in enumerate(lens):
+            starts.append(s)
+            s += n
+            bases.append(e)
+            e += heads * n * ((n + 3) // 4 * 4)
+            e = (e + 3) // 4 * 4
+            for r0 in range(0, n, 64):
+                tiles_seq.append(i)
+                tiles_r0.append(r0)
+        if e >= 2 ** 32:
+            raise ValueError("attention dropout index space exceeds 2^32 elements")
+        mk = lambda x, dt: torch.tensor(x, dtype=dt, device=device)
+        self.lens = list(lens)
+        self.tokens = s
+        self.heads = heads
+        self.seq_start = mk(starts, torch.int32)
+        self.seq_len = mk(list(lens), torch.int32)
+        self.elem_base = mk(bases, torch.int64).to(torch.int32)      # bit pattern of uint32
+        self.elem_base_host = bases
+        self.tile_seq = mk(tiles_seq, torch.int32)
+        self.tile_r0 = mk(tiles_r0, torch.int32)
+        self.ntiles = len(tiles_seq)
+
+
+def attn_fwd(qkv, key_bias, layout: SeqLayout, H, *, drop: Drop = None, ctx=None, lse=None):
+    lib = _lib.load()
+    M = qkv.shape[0]
+    assert qkv.shape[1] == 3 * H and qkv.is_contiguous()
+    if ctx is None:
+        ctx = torch.empty((M, H), device=qkv.device, dtype=torch.bfloat16)
+    if lse is None:
+        lse = torch.empty((M, layout.heads), device=qkv.device, dtype=torch.float32)
+    d = drop or NO_DROP
+    _lib.check(lib.mmbert_attn_fwd(_stream(), qkv.data_ptr(), ctx.data_ptr(), lse.data_ptr(), key_bias.data_ptr(), H, layout.heads,
+                                   layout.seq_start.data_ptr(), layout.seq_len.data_ptr(), layout.elem_base.data_ptr(),
+                                   layout.tile_seq.data_ptr(), layout.tile_r0.data_ptr(), layout.ntiles, d[0], d[1], d[2]), "mmbert_attn_fwd")
+    return ctx, lse
+
+
+def attn_bwd(qkv, ctx, dctx, lse, key_bias, layout: SeqLayout, H, *, drop: Drop = None, dqkv=None):
+    lib = _lib.load()
+    M = qkv.shape[0]
+    if dqkv is None:
+        dqkv = torch.empty_like(qkv)
+    delta = torch.empty((M, layout.heads), device=qkv.device, dtype=torch.float32)
+    d = drop or NO_DROP
+    assert dctx.is_contiguous() and ctx.is_contiguous()
+    _lib.check(lib.mmbert_attn_bwd(_stream(), qkv.data_ptr(), ctx.data_ptr(), dctx.data_ptr(), dqkv.data_ptr(), lse.data_ptr(), delta.data_ptr(),
+                                   key_bias.data_ptr(), H, layout.heads, layout.seq_start.data_ptr(), layout.seq_len.data_ptr(),
+                                   layout.elem_base.data_ptr(), layout.tile_seq.data_ptr(), layout.tile_r0.data_ptr(), layout.ntiles,
+                                   d[0], d[1], d[2]), "mmbert_attn_bwd")
+    return dqkv
+
+
+def attn_dropout_mask(S, elem_base, head, drop, device):
+    lib = _lib.load()
+    out = torch.empty((S, S), device=device, dtype=torch.uint8)
+    _lib.check(lib.mmbert_attn_dropout_mask(_stream(), out.data_ptr(), S, elem_base, head, drop[0], drop[1]), "mmbert_attn_dropout_mask")
+    return out
+
+
+def ce_fwd_bwd(logits, V, labels, seg_bounds, nseg, *, dlogits=None, row_loss=None):
+    """Returns (loss_mean_per_segment[nseg] fp32, inv_count[nseg]); writes dlogits when given."""
+    lib = _lib.load()
+    M = logits.shape[0]
+    inv = torch.empty(4, device=logits.device, dtype=torch.float32)
+    loss = torch.empty(4, device=logits.device, dtype=torch.float32)
+    _lib.check(lib.mmbert_ce_fwd_bwd(_stream(), logits.data_ptr(), logits.stride(0), V, labels.data_ptr(), M, seg_bounds.data_ptr(), nseg,
+                                     inv.data_ptr(), loss.data_ptr(), _ptr(row_loss), _ptr(dlogits),
+                                     dlogits.stride(0) if dlogits is not None else 0), "mmbert_ce_fwd_bwd")
+    return loss[:nseg], inv[:nseg]
+
+
+def adamw(p, g, m, v, p_bf16, flags, *, lr, beta1=0.9, beta2=0.999, eps=1e-6, wd=0.01, step=1, gscale=1.0, mode=0, zero_grad=True):
+    lib = _lib.load()
+    _lib.check(lib.mmbert_adamw(_stream(), p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), _ptr(p_bf16), flags.data_ptr(), p.numel(),
+                                float(lr), float(beta1), float(beta2), float(eps), float(wd), int(step), float(gscale), int(mode),
+                                1 if zero_grad else 0), "mmbert_adamw")
+
+
+def cast_f32_bf16(x, y):
+    _lib.check(_lib.load().mmbert_cast_f32_bf16(_stream(), x.data_ptr(), y.data_ptr(), x.numel()), "mmbert_cast_f32_bf16")
+    return y
+
+
+def cast_bf16_f32(x, y):
+    _lib.check(_lib.load().mmbert_cast_bf16_f32(_stream(), x.data_ptr(), y.data_ptr(), x.numel()), "mmbert_cast_bf16_f32")
+    return y
+
+
+def transpose_cast(src_flat, dst_flat, descs_dev, ndesc, total_tiles):
+    _lib.check(_lib.load().mmbert_transpose_cast(_stream(), src_flat.data_ptr(), dst_flat.data_ptr(), descs_dev.data_ptr(), ndesc, total_tiles),
+               "mmbert_transpose_cast")

@@ -1,0 +1,349 @@
+"""Per-kernel parity: every C-ABI entry point against a plain fp32 CPU computation of the same op on
+the same (bf16-rounded) inputs.  Tolerances: outputs are bf16 (rel 2^-8) of fp32-accumulated sums."""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda"
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale)
+
+
+def bf(x):
+    return x.to(torch.bfloat16)
+
+
+def assert_close(got, ref, rtol, atol, what=""):
+    got = got.detach().float().cpu()
+    ref = ref.detach().float().cpu()
+    err = (got - ref).abs()
+    tol = atol + rtol * ref.abs()
+    bad = err > tol
+    assert not bad.any(), f"{what}: {int(bad.sum())}/{bad.numel()} off, max err {float(err.max()):.4g} at ref {float(ref.flatten()[err.argmax()]):.4g}"
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from msa_amd import ops as o
+    return o
+
+
+# ------------------------------------------------------------------------------------------- GEMM
+def test_gemm_nt_exact_integers_asymmetric(ops):
+    """A = [I | 0] picks rows of an ASYMMETRIC integer B: catches swapped row/col fragment maps."""
+    M, N, K = 128, 256, 128
+    A = torch.zeros(M, K)
+    A[torch.arange(M), torch.arange(M) % K] = 1.0
+    B = (torch.arange(N)[:, None] * 3 + torch.arange(K)[None, :] * 7) % 61 - 30.0
+    out = ops.gemm_nt(bf(A).to(DEV), bf(B).to(DEV))
+    assert torch.equal(out.float().cpu(), (A @ B.t()))
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (200, 384, 128), (800, 768, 768), (1150, 2304, 768), (333, 512, 3072), (64, 30592, 128)])
+def test_gemm_nt_plain_and_bias(ops, M, N, K):
+    A, B, bias = bf(rnd(M, K, seed=1)), bf(rnd(N, K, seed=2, scale=0.05)), rnd(N, seed=3)
+    ref = A.float() @ B.float().t()
+    assert_close(ops.gemm_nt(A.to(DEV), B.to(DEV)), ref, 1e-2, 2e-2, "plain")
+    assert_close(ops.gemm_nt(A.to(DEV), B.to(DEV), bias=bias.to(DEV)), ref + bias, 1e-2, 2e-2, "bias")
+    assert_close(ops.gemm_nt(A.to(DEV), B.to(DEV), bias=bias.to(DEV), out_f32=True, alpha=0.5), 0.5 * ref + bias, 1e-4, 1e-3, "f32 out")
+
+
+def test_gemm_nt_strided_views_and_alpha_dev(ops):
+    M, N, K = 300, 256, 192
+    big = bf(rnd(M, 3 * K, seed=4)).to(DEV)
+    A = big[:, K:2 * K]
+    B = bf(rnd(N, K, seed=5, scale=0.1)).to(DEV)
+    ad = torch.tensor([0.25], device=DEV)
+    out = torch.zeros(M, 2 * N, device=DEV, dtype=torch.bfloat16)
+    ops.gemm_nt(A, B, out=out[:, N:], alpha=2.0, alpha_dev=ad)
+    ref = 0.5 * (A.float().cpu() @ B.float().cpu().t())
+    assert_close(out[:, N:], ref, 1e-2, 2e-2, "strided")
+    assert float(out[:, :N].abs().max()) == 0.0
+
+
+def test_gemm_nt_gelu_resid_gelubwd(ops):
+    M, N, K = 257, 512, 128
+    A, B, bias = bf(rnd(M, K, seed=6)), bf(rnd(N, K, seed=7, scale=0.1)), rnd(N, seed=8)
+    pre = A.float() @ B.float().t() + bias
+    aux = torch.empty(M, N, device=DEV, dtype=torch.bfloat16)
+    out = ops.gemm_nt(A.to(DEV), B.to(DEV), bias=bias.to(DEV), gelu=True, aux=aux)
+    assert_close(aux, pre, 1e-2, 1e-2, "pre-activation")
+    assert_close(out, torch.nn.functional.gelu(pre), 1e-2, 1e-2, "gelu")
+    R = bf(rnd(M, N, seed=9))
+    out = ops.gemm_nt(A.to(DEV), B.to(DEV), bias=bias.to(DEV), resid=R.to(DEV))
+    assert_close(out, pre + R.float(), 1e-2, 2e-2, "bias+resid")
+    out = ops.gemm_nt(A.to(DEV), B.to(DEV), resid=R.to(DEV))
+    assert_close(out, pre - bias + R.float(), 1e-2, 2e-2, "resid")
+    U = bf(rnd(M, N, seed=10))
+    u = U.float().requires_grad_(True)
+    torch.nn.functional.gelu(u).sum().backward()
+    out = ops.gemm_nt(A.to(DEV), B.to(DEV), gelu_bwd_u=U.to(DEV))
+    assert_close(out, (pre - bias) * u.grad, 1e-2, 2e-2, "gelu bwd")
+
+
+def test_gemm_nt_dropout_epilogue_matches_exported_mask(ops):
+    M, N, K = 130, 256, 64
+    A, B, bias, R = bf(rnd(M, K, seed=11)), bf(rnd(N, K, seed=12, scale=0.1)), rnd(N, seed=13), bf(rnd(M, N, seed=14))
+    drop = ops.make_drop(0.1, seed=1234, site=7)
+    out = ops.gemm_nt(A.to(DEV), B.to(DEV), bias=bias.to(DEV), resid=R.to(DEV), drop=drop)
+    mask = ops.dropout_mask(M * N, drop, DEV).view(M, N).float().cpu()
+    assert 0.88 < float(mask.mean()) < 0.92
+    ref = (A.float() @ B.float().t() + bias) * mask * drop[2] + R.float()
+    assert_close(out, ref, 1e-2, 2e-2, "dropout epilogue")
+
+
+@pytest.mark.parametrize("M,N,K", [(64, 128, 128), (300, 128, 256), (1150, 768, 768), (2000, 256, 3072), (999, 2304, 128), (1000, 2048, 64)])
+def test_gemm_tn(ops, M, N, K):
+    A, B = bf(rnd(M, N, seed=20, scale=0.1)), bf(rnd(M, K, seed=21))
+    ref = A.float().t() @ B.float()
+    W0 = rnd(N, K, seed=22)
+    W = W0.clone().to(DEV)
+    ops.gemm_tn(A.to(DEV), B.to(DEV), W, accumulate=True, alpha=0.5)
+    assert_close(W, W0 + 0.5 * ref, 2e-3, 2e-3 * math.sqrt(M), "accumulate")
+    ops.gemm_tn(A.to(DEV), B.to(DEV), W, accumulate=False)
+    assert_close(W, ref, 2e-3, 2e-3 * math.sqrt(M), "overwrite")
+
+
+def test_gemm_tn_exact_integers(ops):
+    M, N, K = 192, 128, 128
+    A = ((torch.arange(M)[:, None] * 5 + torch.arange(N)[None, :] * 3) % 7 - 3.0)
+    B = ((torch.arange(M)[:, None] * 2 + torch.arange(K)[None, :] * 11) % 5 - 2.0)
+    W = torch.zeros(N, K, device=DEV)
+    ops.gemm_tn(bf(A).to(DEV), bf(B).to(DEV), W, accumulate=False)
+    assert torch.equal(W.cpu(), A.t() @ B)
+
+
+def test_gemm_tn_tied_vocab_rows(ops):
+    """decoder weight gradient: N = V (not a multiple of 128) rows into a [V,H] fp32 table."""
+    M, V, H = 500, 2008, 128
+    A, B = bf(rnd(M, V, seed=23, scale=0.05)), bf(rnd(M, H, seed=24))
+    W = torch.zeros(V, H, device=DEV)
+    ops.gemm_tn(A.to(DEV), B.to(DEV), W, accumulate=True)
+    assert_close(W, A.float().t() @ B.float(), 2e-3, 5e-2, "vocab rows")
+
+
+def test_colsum(ops):
+    X = bf(rnd(1234, 768, seed=25))
+    out = torch.ones(768, device=DEV)
+    ops.colsum(X.to(DEV), out, alpha=2.0)
+    assert_close(out, 1.0 + 2.0 * X.float().sum(0), 1e-4, 1e-2, "colsum")
+
+
+# ------------------------------------------------------------------------------------ LayerNorm
+@pytest.mark.parametrize("M,H,eps", [(7, 128, 1e-12), (1000, 768, 1e-12), (513, 1024, 1e-5), (50, 64, 1e-5)])
+def test_ln_fwd_bwd(ops, M, H, eps):
+    x, gamma, beta, dy = bf(rnd(M, H, seed=30)), 1 + 0.1 * rnd(H, seed=31), 0.1 * rnd(H, seed=32), bf(rnd(M, H, seed=33))
+    xr = x.float().requires_grad_(True)
+    g_, b_ = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    y = torch.nn.functional.layer_norm(xr, (H,), g_, b_, eps)
+    y.backward(dy.float())
+    out, mean, rstd = ops.ln_fwd(x.to(DEV), gamma.to(DEV), beta.to(DEV), eps)
+    assert_close(out, y, 1e-2, 1e-2, "ln fwd")
+    assert_close(mean, x.float().mean(1), 1e-4, 1e-5, "mean")
+    dgamma, dbeta = torch.zeros(H, device=DEV), torch.zeros(H, device=DEV)
+    dx = ops.ln_bwd(dy.to(DEV), x.to(DEV), mean, rstd, gamma.to(DEV), dgamma, dbeta)
+    assert_close(dx, xr.grad, 1e-2, 1e-2, "ln dx")
+    assert_close(dgamma, g_.grad, 1e-3, 1e-3 * math.sqrt(M), "dgamma")
+    assert_close(dbeta, b_.grad, 1e-3, 1e-3 * math.sqrt(M), "dbeta")
+
+
+def test_ln_row_maps_and_dropouts(ops):
+    M, H, n = 40, 128, 24
+    x, gamma, beta = bf(rnd(M, H, seed=34)), 1 + 0.1 * rnd(H, seed=35), 0.1 * rnd(H, seed=36)
+    in_rows = torch.randperm(M, generator=torch.Generator().manual_seed(1))[:n].int()
+    out_rows = torch.randperm(M, generator=torch.Generator().manual_seed(2))[:n].int()
+    post = ops.make_drop(0.5, 99, 1)
+    out = torch.zeros(M, H, device=DEV, dtype=torch.bfloat16)
+    _, mean, rstd = ops.ln_fwd(x.to(DEV), gamma.to(DEV), beta.to(DEV), 1e-5, out=out, in_rows=in_rows.to(DEV), out_rows=out_rows.to(DEV), drop=post)
+    mask = ops.dropout_mask(n * H, post, DEV).view(n, H).float().cpu()
+    assert 0.45 < float(mask.mean()) < 0.55
+    xs = x.float()[in_rows.long()].requires_grad_(True)
+    y = torch.nn.functional.layer_norm(xs, (H,), gamma, beta, 1e-5) * mask * post[2]
+    ref = torch.zeros(M, H)
+    ref[out_rows.long()] = y.detach()
+    assert_close(out, ref, 1e-2, 1e-2, "mapped ln + post dropout")
+    dy = bf(rnd(M, H, seed=37))
+    y.backward(dy.float()[out_rows.long()])
+    dgamma, dbeta = torch.zeros(H, device=DEV), torch.zeros(H, device=DEV)
+    pre = ops.make_drop(0.1, 99, 2)
+    dx2 = torch.zeros(n, H, device=DEV, dtype=torch.bfloat16)
+    dx = ops.ln_bwd(dy.to(DEV), x.to(DEV), mean, rstd, gamma.to(DEV), dgamma, dbeta, M=n, dy_rows=out_rows.to(DEV), x_rows=in_rows.to(DEV),
+                    post_drop=post, dx2=dx2, pre_drop=pre)
+    assert_close(dx, xs.grad, 1e-2, 1e-2, "mapped ln bwd")
+    m2 = ops.dropout_mask(n * H, pre, DEV).view(n, H).float().cpu()
+    assert_close(dx2, xs.grad * m2 * pre[2], 1e-2, 1e-2, "branch dropout grad")
+
+
+# ------------------------------------------------------------------------------------ attention
+def ref_attention(q, k, v, bias, drop_mask=None, drop_scale=1.0):
+    w = (q @ k.transpose(-1, -2)) * 0.125 + bias[None, None, :]
+    w = torch.softmax(w, -1)
+    if drop_mask is not None:
+        w = w * drop_mask * drop_scale
+    return w @ v
+
+
+@pytest.mark.parametrize("lens,heads,p", [([50], 2, 0.0), ([64, 128], 2, 0.0), ([50, 114, 550], 2, 0.0), ([37, 200], 3, 0.1), ([1425], 1, 0.0)])
+def test_attention_fwd_bwd(ops, lens, heads, p):
+    H = heads * 64
+    M = sum(lens)
+    qkv = bf(rnd(M, 3 * H, seed=40))
+    dctx = bf(rnd(M, H, seed=41))
+    bias = torch.zeros(M)
+    gsel = torch.Generator().manual_seed(5)
+    bias[torch.rand(M, generator=gsel) < 0.2] = -10000.0
+    layout = ops.SeqLayout(lens, heads, DEV)
+    drop = ops.make_drop(p, 777, 3)
+    ctx, lse = ops.attn_fwd(qkv.to(DEV), bias.to(DEV), layout, H, drop=drop)
+    dqkv = ops.attn_bwd(qkv.to(DEV), ctx, dctx.to(DEV), lse, bias.to(DEV), layout, H, drop=drop)
+    s = 0
+    for i, n in enumerate(lens):
+        x = qkv[s:s + n].float().requires_grad_(True)
+        q, k, v = (x[:, j * H:(j + 1) * H].view(n, heads, 64).transpose(0, 1)[None] for j in range(3))
+        mask = None
+        if p > 0:
+            mask = torch.stack([ops.attn_dropout_mask(n, layout.elem_base_host[i], h, drop, DEV).float().cpu() for h in range(heads)])[None]
+            assert 0.85 < float(mask.mean()) < 0.95
+        out = ref_attention(q, k, v, bias[s:s + n], mask, drop[2])          # [1, heads, n, 64]
+        ref = out[0].transpose(0, 1).reshape(n, H)
+        ref.backward(dctx[s:s + n].float())
+        assert_close(ctx[s:s + n], ref, 2e-2, 2e-2, f"ctx seq{i}")
+        sc = (q @ k.transpose(-1, -2)) * 0.125 + bias[s:s + n][None, None, :]
+        assert_close(lse[s:s + n], torch.logsumexp(sc, -1)[0].t(), 1e-3, 2e-2, f"lse seq{i}")
+        assert_close(dqkv[s:s + n], x.grad, 3e-2, 3e-2, f"dqkv seq{i}")
+        s += n
+
+
+def test_attention_rescale_branch(ops):
+    """Force the running max to jump at a later key tile (guide rule 26): spike one key."""
+    n, heads, H = 200, 1, 64
+    qkv = bf(rnd(n, 3 * H, seed=42) * 0.3)
+    qkv[150, H:2 * H] = qkv[3, 0:H] * 40.0          # key 150 aligned with query 3 -> huge score in tile 2
+    layout = ops.SeqLayout([n], heads, DEV)
+    bias = torch.zeros(n)
+    ctx, _ = ops.attn_fwd(qkv.to(DEV), bias.to(DEV), layout, H)
+    x = qkv.float()
+    ref = ref_attention(x[None, None, :, :H], x[None, None, :, H:2 * H], x[None, None, :, 2 * H:], bias)[0, 0]
+    assert_close(ctx, ref, 2e-2, 2e-2, "rescale")
+
+
+# ------------------------------------------------------------------------- embeddings, CE, AdamW
+def test_embed_gather_scatter(ops):
+    V, H, T, n = 500, 128, 10, 60
+    word, typ, pos = rnd(V, H, seed=50), rnd(2, H, seed=51), rnd(64, H, seed=52)
+    g = torch.Generator().manual_seed(3)
+    ids = torch.randint(0, V, (n,), generator=g)
+    ids[::7] = 0
+    tts = torch.randint(0, 2, (n,), generator=g)
+    out = ops.embed_gather(ids.to(DEV), tts.to(DEV), word.to(DEV), typ.to(DEV), pos.to(DEV), T)
+    ref = word[ids] + typ[tts] + pos[torch.arange(n) % T]
+    assert_close(out, ref, 1e-2, 1e-2, "gather")
+    d = bf(rnd(n, H, seed=53))
+    gw, gt, gp = torch.zeros(V, H, device=DEV), torch.zeros(2, H, device=DEV), torch.zeros(64, H, device=DEV)
+    ops.embed_scatter(ids.to(DEV), tts.to(DEV), d.to(DEV), T, gw, gt, gp)
+    rw, rt, rp = torch.zeros(V, H), torch.zeros(2, H), torch.zeros(64, H)
+    keep = ids != 0
+    rw.index_add_(0, ids[keep], d.float()[keep])
+    rt.index_add_(0, tts, d.float())
+    rp.index_add_(0, torch.arange(n) % T, d.float())
+    assert_close(gw, rw, 1e-4, 1e-4, "word grad")
+    assert_close(gt, rt, 1e-4, 1e-3, "type grad")
+    assert_close(gp, rp, 1e-4, 1e-4, "pos grad")
+
+
+@pytest.mark.parametrize("D", [35, 74, 371])
+def test_pair_proj(ops, D):
+    B, P, T, H = 3, 21, 5, 128
+    feat, W, b = rnd(B, P, D, seed=54), rnd(H, D, seed=55, scale=0.2), rnd(H, seed=56, scale=0.1)
+    out = torch.zeros(B * (T + P), H, device=DEV, dtype=torch.bfloat16)
+    ops.pair_proj_fwd(feat.to(DEV), W.to(DEV), b.to(DEV), out, T)
+    Wr, br = W.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    y = torch.relu(feat @ Wr.t() + br)
+    o3 = out.view(B, T + P, H)
+    assert float(o3[:, :T].abs().max()) == 0.0
+    assert_close(o3[:, T:], y, 1e-2, 1e-2, "pair fwd")
+    dJ = bf(rnd(B * (T + P), H, seed=57))
+    (o3.float().cpu()[:, T:] > 0)
+    y_b = o3[:, T:].float().cpu()
+    gy = dJ.float().view(B, T + P, H)[:, T:] * (y_b > 0)
+    ((feat @ Wr.t() + br) * gy).sum().backward()        # linear part only: relu gate taken from the bf16 output
+    dW, db = torch.zeros(H, D, device=DEV), torch.zeros(H, device=DEV)
+    ops.pair_proj_bwd(feat.to(DEV), out, dJ.to(DEV), T, dW, db)
+    assert_close(dW, Wr.grad, 1e-3, 1e-3, "pair dW")
+    assert_close(db, br.grad, 1e-3, 1e-3, "pair db")
+
+
+def test_cross_entropy_segments(ops):
+    M, V, ldv = 90, 1000, 1024
+    logits = torch.zeros(M, ldv)
+    logits[:, :V] = rnd(M, V, seed=58, scale=3.0)
+    logits = bf(logits)
+    g = torch.Generator().manual_seed(4)
+    labels = torch.randint(0, V, (M,), generator=g)
+    labels[torch.rand(M, generator=g) < 0.6] = -100
+    bounds = torch.tensor([0, 20, 55, M], dtype=torch.int32)
+    dl = torch.full((M, ldv), 7.0, device=DEV, dtype=torch.bfloat16)
+    loss, inv = ops.ce_fwd_bwd(logits.to(DEV), V, labels.to(DEV), bounds.to(DEV), 3, dlogits=dl)
+    for s in range(3):
+        a, b = int(bounds[s]), int(bounds[s + 1])
+        lg = logits[a:b, :V].float().requires_grad_(True)
+        ref = torch.nn.functional.cross_entropy(lg, labels[a:b])
+        ref.backward()
+        assert_close(loss[s], ref, 2e-3, 2e-3, f"ce loss seg{s}")
+        assert_close(dl[a:b, :V], lg.grad, 2e-2, 1e-4, f"dlogits seg{s}")
+    assert float(dl[:, V:].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+def test_adamw_flat(ops, mode):
+    import sys
+    sys.path.insert(0, __file__.rsplit("/tests/", 1)[0])
+    from oracle import mmbert_oracle as O
+    n = 256 * 12
+    p, g = rnd(n, seed=60), rnd(n, seed=61, scale=0.1)
+    flags = torch.tensor([0, 1, 2] * 4, dtype=torch.uint8)
+    pr, m, v = p.clone(), torch.zeros(n), torch.zeros(n)
+    pd, gd, md, vd = p.clone().to(DEV), g.clone().to(DEV), torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+    pb = torch.empty(n, device=DEV, dtype=torch.bfloat16)
+    for step in (1, 2, 3):
+        gd.copy_(g.to(DEV) * 4.0)
+        ops.adamw(pd, gd, md, vd, pb, flags.to(DEV), lr=1e-2, wd=0.01, step=step, gscale=0.25, mode=mode, zero_grad=True)
+        for blk in range(12):
+            sl = slice(blk * 256, (blk + 1) * 256)
+            if flags[blk] == 2:
+                continue
+            O.adamw_step(pr[sl], g[sl], m[sl], v[sl], step, 1e-2, 0.01 if flags[blk] == 1 else 0.0, mode="hf" if mode == 0 else "torch")
+        assert float(gd.abs().max()) == 0.0
+    assert_close(pd, pr, 1e-5, 1e-6, "adamw params")
+    assert_close(pb, pr, 1e-2, 1e-3, "bf16 copy")
+    assert torch.equal(pd[512:768].cpu(), p[512:768])                  # frozen block untouched
+
+
+def test_transpose_cast_and_casts(ops):
+    src = rnd(5000, seed=62)
+    descs, tile0 = [], 0
+    mats = [(0, 0, 40, 50, 64), (2000, 4096, 30, 100, 32)]              # (src_off, dst_off, rows, cols, dst_ld)
+    for so, do, r, c, ld in mats:
+        descs.append([so, do, r | (c << 32), ld | (tile0 << 32)])
+        tile0 += ((r + 63) // 64) * ((c + 63) // 64)
+    import numpy as np
+    raw = np.zeros((len(mats), 4), dtype=np.int64)
+    for i, (so, do, r, c, ld) in enumerate(mats):
+        raw[i, 0], raw[i, 1] = so, do
+        raw[i, 2] = np.int64(r) | (np.int64(c) << 32)
+        raw[i, 3] = np.int64(ld) | (np.int64(sum(((a[2] + 63) // 64) * ((a[3] + 63) // 64) for a in mats[:i])) << 32)
+    dst = torch.zeros(10000, device=DEV, dtype=torch.bfloat16)
+    ops.transpose_cast(src.to(DEV), dst, torch.from_numpy(raw).to(DEV), len(mats), tile0)
+    for so, do, r, c, ld in mats:
+        ref = src[so:so + r * c].view(r, c).t()
+        got = dst[do:do + c * ld].view(c, ld).float().cpu()
+        assert_close(got[:, :r], ref, 1e-2, 1e-2, "transpose")
+    y = torch.empty(5000, device=DEV, dtype=torch.bfloat16)
+    ops.cast_f32_bf16(src[:5000].to(DEV), y)
+    assert torch.equal(y.cpu(), src.to(torch.bfloat16))
