@@ -1,0 +1,193 @@
+#!/usr/bin/env python3
+"""Headline benchmark: MMBert train-step samples/sec on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+One step = forward of the three passes (text S=50, text+visual S=550, text+speech S=550: the
+reference's ``MMBertForPretraining.forward``) in TRAIN mode (all dropouts on) + every loss +
+backward + (N>1: RCCL gradient all-reduce) + the AdamW step, on synthetic MMBertDataset-shaped
+batches already resident in HBM.  Workload = BASELINE.json configs[1]: 12 layers, d=768, 12 heads,
+T=50, A=V=500, batch 16 per GPU, bf16 MFMA compute (fp32 master weights / accumulation).
+Weak scaling: per-GPU batch is fixed, global batch = 16*N.
+
+Extra objects on the JSON line:
+  roofline     -- the dominant kernel (gemm_nt: forward projections + input gradients, 2/3 of the
+                  step's FLOPs): algorithmic FLOPs of its launches / their summed durations, both
+                  taken INSIDE the timed region with HIP events on the launch stream.
+  cpu_baseline -- the CPU oracle (oracle/mmbert_oracle.py, kind "port") timed on this box's host
+                  cores on a bounded sample: the same model/shapes at batch 2, one fwd+bwd step.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch
+
+
+def flops_per_sample(L, H, I, V, T, Pv, Pa, dv=35, ds=74):
+    """Algorithmic forward FLOPs of one sample over the three passes; train = 3x."""
+    def one(S, P, D):
+        return 2 * S * L * (4 * H * H + 2 * H * I) + 4 * S * S * H * L + 2 * S * H * H + 2 * S * H * V + 2 * P * D * H
+    return one(T, 0, 0) + one(T + Pv, Pv, dv) + one(T + Pa, Pa, ds)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=16)
+    ap.add_argument("--text", type=int, default=50)
+    ap.add_argument("--pair", type=int, default=500)
+    ap.add_argument("--layers", type=int, default=12)
+    ap.add_argument("--hidden", type=int, default=768)
+    ap.add_argument("--heads", type=int, default=12)
+    ap.add_argument("--vocab", type=int, default=30522)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--eval-dropout-off", action="store_true", help="diagnostic only: not a valid headline number")
+    a = ap.parse_args()
+
+    from msa_amd import ops, parallel
+    from msa_amd.data import synthetic_batch, batch_to
+    from msa_amd.model import MMBertConfig, MMBertForPretraining
+    from msa_amd.trainer import build_optimizer, default_args
+
+    rank, local, world = parallel.init_from_env()
+    if world != a.gpus:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {a.gpus}")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    H, L, I, V = a.hidden, a.layers, 4 * a.hidden, a.vocab
+    torch.manual_seed(0)
+    cfg = MMBertConfig(vocab_size=V, hidden_size=H, num_hidden_layers=L, num_attention_heads=a.heads, intermediate_size=I)
+    model = MMBertForPretraining(cfg)
+    model.bert.set_joint_embeddings("mosei")
+    model.set_alpha_beta(1.0, 1.0)
+    model.to(dev)
+    model.train(not a.eval_dropout_off)
+    model.manual_seed(1234 + rank)
+    model.return_scores = True            # the reference returns the six score tensors; keep them materialised
+    targs = default_args(train_batch_size=a.batch, learning_rate=5e-5)
+    opt, sched = build_optimizer(model, targs, num_train_optimization_steps=10 * (a.steps + a.warmup))
+    dp = parallel.DataParallel(model, opt) if world > 1 else None
+    pool = [batch_to(synthetic_batch(a.batch, a.text, a.pair, a.pair, vocab=V, seed=1 + i + 1000 * rank), dev) for i in range(4)]
+
+    timing = {"nt": [], "tn": [], "attn_fwd": [], "attn_bwd": []}
+    record = [False]
+
+    def wrap(name, fn, flop_fn):
+        def inner(*args, **kw):
+            if not record[0]:
+                return fn(*args, **kw)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            out = fn(*args, **kw)
+            e1.record()
+            timing[name].append((flop_fn(*args, **kw), e0, e1))
+            return out
+        return inner
+
+    if not a.no_kernel_timing:
+        ops.gemm_nt = wrap("nt", ops.gemm_nt, lambda A, B, **kw: 2.0 * A.shape[0] * A.shape[1] * B.shape[0])
+        ops.gemm_tn = wrap("tn", ops.gemm_tn, lambda A, B, W, **kw: 2.0 * A.shape[0] * A.shape[1] * B.shape[1])
+
+    def step(i):
+        out, _ = model(**pool[i % len(pool)])
+        out[0].mean().backward()
+        if dp is not None:
+            dp.finish_backward()
+        opt.step()
+        sched.step()
+        opt.zero_grad()
+        return out[0]
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+
+    for i in range(a.warmup):
+        step(i)
+    torch.cuda.synchronize()
+    barrier()
+    record[0] = not a.no_kernel_timing
+    t0 = time.perf_counter()
+    last = None
+    for i in range(a.steps):
+        last = step(a.warmup + i)
+    torch.cuda.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    record[0] = False
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(t)
+    loss = float(last)
+
+    samples = a.steps * a.batch * world
+    value = samples / elapsed
+    fps = 3.0 * flops_per_sample(L, H, I, V, a.text, a.pair, a.pair)
+    res = {
+        "metric": "train-step samples/sec", "value": round(value, 2), "unit": "samples/s", "n_gpus": world, "steps": a.steps,
+        "warmup": a.warmup, "ms_per_step": round(1e3 * elapsed / a.steps, 3), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+        "config": {"workload": f"MMBertForPretraining train step, 3 passes S={a.text}/{a.text + a.pair}/{a.text + a.pair}, "
+                               f"{L}-layer d={H} heads={a.heads} vocab={V}, T={a.text} A={a.pair} V={a.pair}, dropout on, AdamW",
+                   "per_gpu_batch": a.batch, "global_batch": a.batch * world, "parallelism": f"dp{world}",
+                   "tflop_per_sample": round(fps / 1e12, 4)},
+        "final_loss": round(loss, 4),
+        "step_mfma_frac": round(fps * value / world / 2.5e15, 4),
+    }
+    if rank == 0:
+        if not a.no_kernel_timing and timing["nt"]:
+            kern = {}
+            for k, lst in timing.items():
+                if lst:
+                    ms = sum(e0.elapsed_time(e1) for _, e0, e1 in lst)
+                    fl = sum(f for f, _, _ in lst)
+                    kern[k] = (fl, ms, len(lst))
+            fl, ms, n = kern["nt"]
+            ach = fl / (ms * 1e-3) / 1e12
+            res["roofline"] = {"bound": "mfma", "kernel": "gemm_nt_kernel (bf16 MFMA 16x16x32, all epilogues)",
+                               "achieved": round(ach, 1), "peak": 2500.0, "unit": "TFLOP/s", "frac": round(ach / 2500.0, 4),
+                               "traffic": None, "launches": n, "avg_launch_us": round(1e3 * ms / n, 2),
+                               "share_of_step_time": round(ms * 1e-3 / elapsed, 3)}
+            if "tn" in kern:
+                fl2, ms2, n2 = kern["tn"]
+                res["roofline"]["gemm_tn"] = {"achieved": round(fl2 / (ms2 * 1e-3) / 1e12, 1), "launches": n2,
+                                              "share_of_step_time": round(ms2 * 1e-3 / elapsed, 3)}
+        if world == 1 and not a.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(a, L, H, I, V)
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+def cpu_baseline(a, L, H, I, V):
+    """The CPU oracle on the host cores: same architecture and sequence shapes, batch 2 (bounded sample)."""
+    from oracle import mmbert_oracle as O
+    from msa_amd.data import synthetic_batch
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    cfg = dict(hidden=H, layers=L, heads=a.heads, intermediate=I, vocab=V, dataset="mosei", alpha=1.0, beta=1.0)
+    p = {k: v.requires_grad_(True) for k, v in O.seeded_params(cfg).items()}
+    B = 2
+    batch = synthetic_batch(B, a.text, a.pair, a.pair, vocab=V, seed=1)
+    t0 = time.perf_counter()
+    out, _ = O.pretraining_forward(p, cfg, **batch, train=True)
+    out[0].mean().backward()
+    dt = time.perf_counter() - t0
+    return {"value": round(B / dt, 4), "unit": "samples/s", "cores": cores, "kind": "port",
+            "sample": f"oracle fwd+loss+bwd (fp32, dropout on), same model and S=50/550/550 shapes, batch {B}, 1 step = {dt:.1f} s"}
+
+
+if __name__ == "__main__":
+    main()

@@ -103,6 +103,9 @@ int mmbert_ce_fwd_bwd(mmbert_stream_t stream, const void* logits, int ldv, int V
 int mmbert_adamw(mmbert_stream_t stream, float* p, float* g, float* m, float* v, void* p_bf16, const uint8_t* flags, size_t n,
                  float lr, float beta1, float beta2, float eps, float wd, int step, float gscale, int mode, int zero_grad);
 
+/* du = dy * gelu_erf'(u), contiguous bf16 (BertPredictionHeadTransform backward, HF:476-480) */
+int mmbert_gelu_bwd(mmbert_stream_t stream, const void* dy, const void* u, void* du, size_t n);
+
 int mmbert_cast_f32_bf16(mmbert_stream_t stream, const float* x, void* y, size_t n);
 int mmbert_cast_bf16_f32(mmbert_stream_t stream, const void* x, float* y, size_t n);
 /* descs: device array of {int64 src_off, int64 dst_off, int rows, cols, dst_ld, tile0} (64x64 tiles) */

@@ -33,6 +33,7 @@ SIGNATURES = {
     "mmbert_attn_dropout_mask": (I, [P, P, I, C.c_uint, I, U32, U32]),
     "mmbert_ce_fwd_bwd": (I, [P, P, I, I, P, I, P, I, P, P, P, P, I]),
     "mmbert_adamw": (I, [P, P, P, P, P, P, P, SZ, F, F, F, F, F, I, F, I, I]),
+    "mmbert_gelu_bwd": (I, [P, P, P, P, SZ]),
     "mmbert_cast_f32_bf16": (I, [P, P, P, SZ]),
     "mmbert_cast_bf16_f32": (I, [P, P, P, SZ]),
     "mmbert_transpose_cast": (I, [P, P, P, P, I, I]),

@@ -488,6 +488,17 @@ __global__ void cast_bf16_f32_kernel(const bf16_t* __restrict__ x, float* __rest
     }
 }
 
+// du = dy * gelu'(u)   (MLM head transform, HF:476-480; the encoder's FFN fuses this into its dgrad GEMM)
+__global__ void gelu_bwd_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ u, bf16_t* __restrict__ du, size_t n) {
+    for (size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n; i += (size_t)gridDim.x * blockDim.x * 4) {
+        const bf16x4 a = *(const bf16x4*)(dy + i), b = *(const bf16x4*)(u + i);
+        bf16x4 o;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[r] = f2bf(bf2f(a[r]) * gelu_erf_grad(bf2f(b[r])));
+        *(bf16x4*)(du + i) = o;
+    }
+}
+
 // batched transpose-cast: for each descriptor d: dst[c][r] (bf16, ld = dst_ld) = src[r][c] (fp32 [rows, cols])
 struct TransDesc { long long src_off, dst_off; int rows, cols, dst_ld, tile0; };
 __global__ __launch_bounds__(256) void transpose_cast_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst,
@@ -627,6 +638,14 @@ int mmbert_adamw(hipStream_t stream, float* p, float* g, float* m, float* v, voi
     const float bc1 = 1.0f - powf(beta1, (float)step), bc2 = 1.0f - powf(beta2, (float)step);
     hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, stream, p, g, m, v, (bf16_t*)p_bf16, flags, n,
                        lr, beta1, beta2, eps, wd, bc1, bc2, gscale, mode, zero_grad);
+    MMB_CHECK_LAUNCH();
+    return 0;
+}
+
+int mmbert_gelu_bwd(hipStream_t stream, const void* dy, const void* u, void* du, size_t n) {
+    if (n == 0) return 0;
+    if (n & 3) return -1;
+    hipLaunchKernelGGL(gelu_bwd_kernel, dim3(grid_for(n / 4, 256, 4096)), dim3(256), 0, stream, (const bf16_t*)dy, (const bf16_t*)u, (bf16_t*)du, n);
     MMB_CHECK_LAUNCH();
     return 0;
 }

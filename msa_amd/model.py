@@ -1,0 +1,717 @@
+"""Drop-in MI355X implementation of the reference's model API:
+
+    MMBertForPretraining(config) / .from_pretrained(path) / .bert.set_joint_embeddings(dataset) /
+    .set_alpha_beta(alpha, beta) / .forward(input_ids, token_type_ids, attention_mask,
+    masked_labels, ap_label, sentiment) -> (outputs_tuple_of_13, logits)      REF:MMBertForPretraining.py:304-449
+    MMBertModel.forward(..., joint) -> (sequence_output, pooled_output)       REF:MMBertForPretraining.py:13-285
+    MMBertPreTrainingHeads.forward(sequence_output, pooled_output, joint)     REF:MMBertForPretraining.py:287-302
+    JointEmbeddings(hidden_size, dropout_prob, dataset).forward(embs, pair)   REF:MMBertEmbedding.py:34-72
+    CPC(x_size, y_size, n_layers, activation).forward(x, y)                   REF:MMBertEmbedding.py:7-32
+
+Parameter names / shapes / state-dict keys are the reference's.  The arithmetic is NOT torch's:
+the three encoder passes (text, text+visual, text+speech) are packed into one variable-length
+token matrix and run through hand-written gfx950 kernels (msa_amd/csrc) via the C ABI in
+include/mmbert_hip.h -- bf16 MFMA GEMMs with fused epilogues, flash-style attention, fused
+LayerNorm/dropout/residual, vocabulary cross-entropy -- with fp32 master weights, fp32 gradient
+accumulation and fp32 statistics.  The <0.01 %-of-FLOPs heads on the [B,H] pooled vectors (pooler,
+gates, CPC, 2-way CE, MSE) are torch-ROCm glue in fp32.  There is no CPU path: a missing
+libmmbert_hip.so or a CPU tensor raises.
+"""
+from __future__ import annotations
+
+import json
+import os
+from typing import Optional
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import ops
+from .flat import FlatParams
+
+MODALITY_DIMS = {"mosi": (47, 74), "mosei": (35, 74), "ur_funny": (371, 81)}      # REF:config.py:13-17
+LN_EPS_JOINT = 1e-5                                                                # nn.LayerNorm default, REF:MMBertEmbedding.py:54
+MASK_NEG = -10000.0                                                                # REF:MMBertForPretraining.py:153
+
+
+class MMBertConfig:
+    """The BertConfig fields the hot path reads (any object with these attributes works, including a
+    HuggingFace BertConfig)."""
+
+    def __init__(self, vocab_size=30522, hidden_size=768, num_hidden_layers=12, num_attention_heads=12,
+                 intermediate_size=3072, max_position_embeddings=512, type_vocab_size=2,
+                 hidden_dropout_prob=0.1, attention_probs_dropout_prob=0.1, layer_norm_eps=1e-12,
+                 initializer_range=0.02, pad_token_id=0, hidden_act="gelu", is_decoder=False, **unused):
+        self.vocab_size, self.hidden_size = vocab_size, hidden_size
+        self.num_hidden_layers, self.num_attention_heads = num_hidden_layers, num_attention_heads
+        self.intermediate_size, self.max_position_embeddings = intermediate_size, max_position_embeddings
+        self.type_vocab_size = type_vocab_size
+        self.hidden_dropout_prob, self.attention_probs_dropout_prob = hidden_dropout_prob, attention_probs_dropout_prob
+        self.layer_norm_eps, self.initializer_range = layer_norm_eps, initializer_range
+        self.pad_token_id, self.hidden_act, self.is_decoder = pad_token_id, hidden_act, is_decoder
+        self.output_attentions = False
+        self.output_hidden_states = False
+
+
+# ================================================================================================
+# parameter-holder modules (names = the reference's state-dict keys)
+# ================================================================================================
+class _Box(nn.Module):
+    pass
+
+
+def _make_bert_holder(cfg) -> nn.Module:
+    H, I = cfg.hidden_size, cfg.intermediate_size
+    bert = _Box()
+    emb = _Box()
+    emb.word_embeddings = nn.Embedding(cfg.vocab_size, H, padding_idx=cfg.pad_token_id)
+    emb.position_embeddings = nn.Embedding(cfg.max_position_embeddings, H)
+    emb.token_type_embeddings = nn.Embedding(cfg.type_vocab_size, H)
+    emb.LayerNorm = nn.LayerNorm(H, eps=cfg.layer_norm_eps)
+    bert.embeddings = emb
+    enc = _Box()
+    layers = []
+    for _ in range(cfg.num_hidden_layers):
+        lay = _Box()
+        att = _Box()
+        att.self = _Box()
+        att.self.query, att.self.key, att.self.value = nn.Linear(H, H), nn.Linear(H, H), nn.Linear(H, H)
+        att.output = _Box()
+        att.output.dense = nn.Linear(H, H)
+        att.output.LayerNorm = nn.LayerNorm(H, eps=cfg.layer_norm_eps)
+        lay.attention = att
+        lay.intermediate = _Box()
+        lay.intermediate.dense = nn.Linear(H, I)
+        lay.output = _Box()
+        lay.output.dense = nn.Linear(I, H)
+        lay.output.LayerNorm = nn.LayerNorm(H, eps=cfg.layer_norm_eps)
+        layers.append(lay)
+    enc.layer = nn.ModuleList(layers)
+    bert.encoder = enc
+    bert.pooler = _Box()
+    bert.pooler.dense = nn.Linear(H, H)
+    return bert
+
+
+def _hf_init(module: nn.Module, std: float):
+    """HF ``_init_weights``: N(0, std) Linear/Embedding weights, zero biases, LayerNorm (1, 0),
+    zero padding row -- what ``init_weights()`` does at REF:MMBertForPretraining.py:22,347."""
+    for m in module.modules():
+        if isinstance(m, nn.Linear):
+            nn.init.normal_(m.weight, mean=0.0, std=std)
+            if m.bias is not None:
+                nn.init.zeros_(m.bias)
+        elif isinstance(m, nn.Embedding):
+            nn.init.normal_(m.weight, mean=0.0, std=std)
+            if m.padding_idx is not None:
+                with torch.no_grad():
+                    m.weight[m.padding_idx].zero_()
+        elif isinstance(m, nn.LayerNorm):
+            nn.init.ones_(m.weight)
+            nn.init.zeros_(m.bias)
+
+
+class CPC(nn.Module):
+    """REF:MMBertEmbedding.py:7-32 (InfoNCE with in-batch negatives); [B,H] inputs, torch fp32 glue."""
+
+    def __init__(self, x_size, y_size, n_layers=1, activation="Tanh"):
+        super().__init__()
+        self.x_size, self.y_size, self.layers = x_size, y_size, n_layers
+        self.activation = getattr(nn, activation)
+        if n_layers == 1:
+            self.net = nn.Linear(in_features=y_size, out_features=x_size)
+
+    def forward(self, x, y):
+        x_pred = self.net(y)
+        x_pred = x_pred / x_pred.norm(dim=1, keepdim=True)
+        x = x / x.norm(dim=1, keepdim=True)
+        pos = torch.sum(x * x_pred, dim=-1)
+        neg = torch.logsumexp(torch.matmul(x, x_pred.t()), dim=-1)
+        return -(pos - neg).mean()
+
+
+class JointEmbeddings(nn.Module):
+    """REF:MMBertEmbedding.py:34-72.  ``TEXTDIM`` is the hidden size (the reference hard-codes 1024,
+    config.py:12).  W_cv / W_cs exist (state-dict compatibility) and are unused."""
+
+    def __init__(self, hidden_size, dropout_prob, dataset):
+        super().__init__()
+        if dataset not in MODALITY_DIMS:
+            raise KeyError(dataset)
+        self.VISUALDIM, self.SPEECHDIM = MODALITY_DIMS[dataset]
+        H = hidden_size
+        self.W_cv = nn.Linear(self.VISUALDIM + H, H)
+        self.W_cs = nn.Linear(self.SPEECHDIM + H, H)
+        self.Wv = nn.Linear(self.VISUALDIM, H)
+        self.Ws = nn.Linear(self.SPEECHDIM, H)
+        self.LayerNorm = nn.LayerNorm(H)
+        self.dropout_prob = dropout_prob
+        self.dropout = nn.Dropout(dropout_prob)
+        self._owner = None
+
+    def which(self, pair_ids) -> str:
+        d = pair_ids.size()[-1]
+        if d == self.VISUALDIM:
+            return "Wv"
+        if d == self.SPEECHDIM:
+            return "Ws"
+        raise Exception("Wrong Dimension")                                 # REF:MMBertEmbedding.py:66
+
+    def forward(self, input_embs, pair_ids):
+        assert input_embs is not None, "You miss input_embs"
+        assert pair_ids is not None, "You miss pair_ids"
+        if self._owner is None:
+            raise RuntimeError("JointEmbeddings must be attached with MMBertModel.set_joint_embeddings()")
+        top = self._owner()
+        top._ensure_ready(input_embs.device)
+        B, T, H = input_embs.shape
+        e1 = input_embs.reshape(B * T, H).to(torch.bfloat16)
+        drop = ops.make_drop(self.dropout_prob if self.training else 0.0, top._next_seed(), 1001)
+        out = _JointFn.apply(e1, self.LayerNorm.weight, top, pair_ids.float().contiguous(), self.which(pair_ids), B, T, drop)
+        return out.view(B, -1, H).float()
+
+
+# ================================================================================================
+# autograd functions over the C-ABI kernels.  Parameter gradients are accumulated straight into the
+# flat fp32 gradient buffer (p.grad views); the ``anchor`` parameter only makes autograd call backward.
+# ================================================================================================
+class _TextEmbedFn(torch.autograd.Function):
+    """word+type+pos -> LayerNorm(1e-12) -> dropout    (HF:53-108 via REF:MMBertForPretraining.py:264)"""
+
+    @staticmethod
+    def forward(ctx, anchor, top, ids, tts, T, drop):
+        w = top._w
+        e0 = ops.embed_gather(ids, tts, w["word"], w["type"], w["pos"], T)
+        e1, mean, rstd = ops.ln_fwd(e0, w["emb_ln_g"], w["emb_ln_b"], top.config.layer_norm_eps, drop=drop)
+        ctx.top, ctx.T, ctx.drop = top, T, drop
+        ctx.save_for_backward(ids, tts, e0, mean, rstd)
+        return e1
+
+    @staticmethod
+    def backward(ctx, de1):
+        ids, tts, e0, mean, rstd = ctx.saved_tensors
+        w = ctx.top._w
+        de0 = ops.ln_bwd(de1.contiguous(), e0, mean, rstd, w["emb_ln_g"], w["g_emb_ln_g"], w["g_emb_ln_b"], post_drop=ctx.drop)
+        ops.embed_scatter(ids, tts, de0, ctx.T, w["g_word"], w["g_type"], w["g_pos"])
+        return None, None, None, None, None, None
+
+
+class _JointFn(torch.autograd.Function):
+    """cat(text_emb, relu(W.pair+b)) -> LayerNorm(1e-5) -> dropout(0.5)      (REF:MMBertEmbedding.py:57-72)"""
+
+    @staticmethod
+    def forward(ctx, e1, anchor, top, feat, which, B, T, drop):
+        w = top._w
+        H = e1.shape[1]
+        P = feat.shape[1]
+        j0 = torch.empty((B * (T + P), H), device=e1.device, dtype=torch.bfloat16)
+        j0.view(B, T + P, H)[:, :T].copy_(e1.view(B, T, H))
+        ops.pair_proj_fwd(feat, w[which + "_w"], w[which + "_b"], j0, T)
+        x, mean, rstd = ops.ln_fwd(j0, w["joint_ln_g"], w["joint_ln_b"], LN_EPS_JOINT, drop=drop)
+        ctx.top, ctx.which, ctx.B, ctx.T, ctx.drop = top, which, B, T, drop
+        ctx.save_for_backward(feat, j0, mean, rstd)
+        return x
+
+    @staticmethod
+    def backward(ctx, dx):
+        feat, j0, mean, rstd = ctx.saved_tensors
+        w, B, T = ctx.top._w, ctx.B, ctx.T
+        H = j0.shape[1]
+        dj0 = ops.ln_bwd(dx.contiguous(), j0, mean, rstd, w["joint_ln_g"], w["g_joint_ln_g"], w["g_joint_ln_b"], post_drop=ctx.drop)
+        ops.pair_proj_bwd(feat, j0, dj0, T, w["g_" + ctx.which + "_w"], w["g_" + ctx.which + "_b"])
+        de1 = dj0.view(B, -1, H)[:, :T].reshape(B * T, H)
+        return de1, None, None, None, None, None, None, None
+
+
+class _EncoderFn(torch.autograd.Function):
+    """L x BertLayer (HF:374-416) over the packed token matrix."""
+
+    @staticmethod
+    def forward(ctx, x, anchor, top, layout, key_bias, seed):
+        cfg = top.config
+        H, L = cfg.hidden_size, cfg.num_hidden_layers
+        train = top.training
+        ph = cfg.hidden_dropout_prob if train else 0.0
+        pa = cfg.attention_probs_dropout_prob if train else 0.0
+        keep = ctx.needs_input_grad[0]
+        saved = []
+        x = x.contiguous()
+        for i in range(L):
+            lw = top._lw[i]
+            d_att, d_h1, d_h2 = (ops.make_drop(pa, seed, 8 * i), ops.make_drop(ph, seed, 8 * i + 1), ops.make_drop(ph, seed, 8 * i + 2))
+            qkv = ops.gemm_nt(x, lw["Wqkv"], bias=lw["bqkv"])
+            actx, lse = ops.attn_fwd(qkv, key_bias, layout, H, drop=d_att)
+            z1 = ops.gemm_nt(actx, lw["Wo"], bias=lw["bo"], resid=x, drop=d_h1)
+            y1, m1, r1 = ops.ln_fwd(z1, lw["ln1_g"], lw["ln1_b"], cfg.layer_norm_eps, stats=keep)
+            u = torch.empty((x.shape[0], cfg.intermediate_size), device=x.device, dtype=torch.bfloat16) if keep else None
+            g = ops.gemm_nt(y1, lw["W1"], bias=lw["b1"], gelu=True, aux=u)
+            z2 = ops.gemm_nt(g, lw["W2"], bias=lw["b2"], resid=y1, drop=d_h2)
+            y2, m2, r2 = ops.ln_fwd(z2, lw["ln2_g"], lw["ln2_b"], cfg.layer_norm_eps, stats=keep)
+            if keep:
+                saved.append((x, qkv, actx, lse, z1, m1, r1, y1, u, g, z2, m2, r2, d_att, d_h1, d_h2))
+            x = y2
+        ctx.top, ctx.layout, ctx.key_bias, ctx.saved = top, layout, key_bias, saved
+        return x
+
+    @staticmethod
+    def backward(ctx, dy):
+        top, layout, key_bias = ctx.top, ctx.layout, ctx.key_bias
+        H = top.config.hidden_size
+        dy = dy.contiguous()
+        top._flat.grads_dirty = True
+        for i in reversed(range(top.config.num_hidden_layers)):
+            lw = top._lw[i]
+            x, qkv, actx, lse, z1, m1, r1, y1, u, g, z2, m2, r2, d_att, d_h1, d_h2 = ctx.saved[i]
+            ctx.saved[i] = None
+            # --- output sublayer: y2 = LN(dropout(g.W2^T + b2) + y1)
+            dz2d = torch.empty_like(dy) if d_h2[1] else None
+            dz2 = ops.ln_bwd(dy, z2, m2, r2, lw["ln2_g"], lw["g_ln2_g"], lw["g_ln2_b"], dx2=dz2d, pre_drop=d_h2)
+            if dz2d is None:
+                dz2d = dz2
+            ops.colsum(dz2d, lw["g_b2"])
+            ops.gemm_tn(dz2d, g, lw["g_W2"])
+            du = ops.gemm_nt(dz2d, lw["W2T"], gelu_bwd_u=u)
+            ops.colsum(du, lw["g_b1"])
+            ops.gemm_tn(du, y1, lw["g_W1"])
+            dy1 = ops.gemm_nt(du, lw["W1T"], resid=dz2)
+            # --- attention sublayer: y1 = LN(dropout(ctx.Wo^T + bo) + x)
+            dz1d = torch.empty_like(dy) if d_h1[1] else None
+            dz1 = ops.ln_bwd(dy1, z1, m1, r1, lw["ln1_g"], lw["g_ln1_g"], lw["g_ln1_b"], dx2=dz1d, pre_drop=d_h1)
+            if dz1d is None:
+                dz1d = dz1
+            ops.colsum(dz1d, lw["g_bo"])
+            ops.gemm_tn(dz1d, actx, lw["g_Wo"])
+            dctx = ops.gemm_nt(dz1d, lw["WoT"])
+            dqkv = ops.attn_bwd(qkv, actx, dctx, lse, key_bias, layout, H, drop=d_att)
+            ops.colsum(dqkv, lw["g_bqkv"])
+            ops.gemm_tn(dqkv, x, lw["g_Wqkv"])
+            dy = ops.gemm_nt(dqkv, lw["WqkvT"], resid=dz1)
+            top._layer_grads_done(i)
+        return dy, None, None, None, None, None
+
+
+class _MLMHeadFn(torch.autograd.Function):
+    """decoder(LN(gelu(dense(seq)))) + per-pass CrossEntropy(ignore -100)
+    (HF:466-496 via REF:MMBertForPretraining.py:293,381-384).  Returns (loss[nseg], logits or None)."""
+
+    @staticmethod
+    def forward(ctx, y, anchor, top, labels, seg_bounds_host, seg_bounds, want_scores):
+        cfg, w = top.config, top._w
+        M, H = y.shape
+        V, Vp = cfg.vocab_size, top._flat.vpad
+        keep = ctx.needs_input_grad[0]
+        y = y.contiguous()
+        pre = torch.empty_like(y) if keep else None
+        t0 = ops.gemm_nt(y, w["Wt"], bias=w["bt"], gelu=True, aux=pre)
+        t, mean, rstd = ops.ln_fwd(t0, w["mlm_ln_g"], w["mlm_ln_b"], cfg.layer_norm_eps, stats=keep)
+        logits = ops.gemm_nt(t, w["word_h"], bias=w["pred_bias"])                 # [M, Vpad] bf16
+        nseg = len(seg_bounds_host) - 1
+        dlogits = None
+        if keep:
+            dlogits = torch.empty_like(logits) if want_scores else logits          # in place unless the scores are returned
+        loss, _ = ops.ce_fwd_bwd(logits, V, labels, seg_bounds, nseg, dlogits=dlogits)
+        ctx.top, ctx.bounds = top, seg_bounds_host
+        if keep:
+            ctx.save_for_backward(y, pre, t0, mean, rstd, t, dlogits)
+        out_logits = logits if want_scores else None
+        if out_logits is not None:
+            ctx.mark_non_differentiable(out_logits)
+        return loss.clone(), out_logits
+
+    @staticmethod
+    def backward(ctx, dloss, _unused):
+        y, pre, t0, mean, rstd, t, dlogits = ctx.saved_tensors
+        w = ctx.top._w
+        dloss = dloss.contiguous().float()
+        dt = torch.empty_like(t)
+        b = ctx.bounds
+        for s in range(len(b) - 1):
+            r0, r1 = b[s], b[s + 1]
+            if r1 <= r0:
+                continue
+            gs = dloss[s:s + 1]
+            dl = dlogits[r0:r1]
+            ops.colsum(dl, w["g_pred_bias"], alpha_dev=gs)
+            ops.gemm_tn(dl, t[r0:r1], w["g_word_pad"], alpha_dev=gs)              # tied decoder weight gradient
+            ops.gemm_nt(dl, w["wordT"], out=dt[r0:r1], alpha_dev=gs)
+        dt0 = ops.ln_bwd(dt, t0, mean, rstd, w["mlm_ln_g"], w["g_mlm_ln_g"], w["g_mlm_ln_b"])
+        dpre = ops.gelu_bwd(dt0, pre)
+        ops.colsum(dpre, w["g_bt"])
+        ops.gemm_tn(dpre, y, w["g_Wt"])
+        dy = ops.gemm_nt(dpre, w["WtT"])
+        return dy, None, None, None, None, None, None
+
+
+# ================================================================================================
+# the reference's module API
+# ================================================================================================
+class _GpuModelBase(nn.Module):
+    """Shared machinery: flat storage, weight views, dropout seeds, pass packing."""
+
+    def _init_runtime(self):
+        self._flat: Optional[FlatParams] = None
+        self._seed = 0x5EED
+        self._calls = 0
+        self._plans = {}
+        self.grad_hook = None           # set by parallel.DataParallel: called as layers finish in backward
+
+    def manual_seed(self, seed: int):
+        self._seed, self._calls = int(seed), 0
+
+    def _next_seed(self) -> int:
+        self._calls += 1
+        return self._seed * 1000003 + self._calls
+
+    def _layer_grads_done(self, i: int):
+        if self.grad_hook is not None:
+            self.grad_hook(i)
+
+    def _bert(self):
+        return self.bert if hasattr(self, "bert") else self
+
+    def _ensure_ready(self, device):
+        device = torch.device(device)
+        if device.type != "cuda":
+            raise RuntimeError("msa_amd runs on MI355X only: move the model and its inputs to 'cuda' (there is no CPU path)")
+        if not hasattr(self._bert(), "jointEmbeddings"):
+            raise RuntimeError("call .bert.set_joint_embeddings(dataset) first (REF:train.py:72)")
+        p0 = next(self.parameters())
+        if p0.device != device:
+            raise RuntimeError(f"model is on {p0.device}, inputs on {device}")
+        if self._flat is None or not self._flat.owns(self):
+            self._flat = FlatParams(self, self.config, device)
+            self._build_views()
+        else:
+            self._flat.maybe_refresh()
+
+    def _build_views(self):
+        f, cfg = self._flat, self.config
+        H, I, V, L = cfg.hidden_size, cfg.intermediate_size, cfg.vocab_size, cfg.num_hidden_layers
+        pre = "bert." if hasattr(self, "bert") else ""
+        if not pre:
+            raise RuntimeError("flat storage is built from MMBertForPretraining")
+        self._lw = []
+        for i in range(L):
+            p = f"bert.encoder.layer.{i}."
+            d = {}
+            for tag, buf in (("", f.half), ("g_", f.grads)):
+                d[tag + "Wqkv"] = f.span(buf, p + "attention.self.query.weight", 3 * H * H, (3 * H, H))
+                d[tag + "Wo"] = f.span(buf, p + "attention.output.dense.weight", H * H, (H, H))
+                d[tag + "W1"] = f.span(buf, p + "intermediate.dense.weight", I * H, (I, H))
+                d[tag + "W2"] = f.span(buf, p + "output.dense.weight", H * I, (H, I))
+            for tag, buf in (("", f.params), ("g_", f.grads)):
+                d[tag + "bqkv"] = f.span(buf, p + "attention.self.query.bias", 3 * H, (3 * H,))
+                d[tag + "bo"] = f.span(buf, p + "attention.output.dense.bias", H, (H,))
+                d[tag + "b1"] = f.span(buf, p + "intermediate.dense.bias", I, (I,))
+                d[tag + "b2"] = f.span(buf, p + "output.dense.bias", H, (H,))
+                d[tag + "ln1_g"] = f.span(buf, p + "attention.output.LayerNorm.weight", H, (H,))
+                d[tag + "ln1_b"] = f.span(buf, p + "attention.output.LayerNorm.bias", H, (H,))
+                d[tag + "ln2_g"] = f.span(buf, p + "output.LayerNorm.weight", H, (H,))
+                d[tag + "ln2_b"] = f.span(buf, p + "output.LayerNorm.bias", H, (H,))
+            d["WqkvT"], d["WoT"], d["W1T"], d["W2T"] = f.tview(p + "qkv"), f.tview(p + "o"), f.tview(p + "w1"), f.tview(p + "w2")
+            self._lw.append(d)
+        w = {}
+        e = "bert.embeddings."
+        j = "bert.jointEmbeddings."
+        c = "cls.predictions."
+        vd, sd = self.bert.jointEmbeddings.VISUALDIM, self.bert.jointEmbeddings.SPEECHDIM
+        for tag, buf in (("", f.params), ("g_", f.grads)):
+            w[tag + "word"] = f.span(buf, e + "word_embeddings.weight", V * H, (V, H))
+            w[tag + "word_pad"] = f.span(buf, e + "word_embeddings.weight", f.vpad * H, (f.vpad, H))
+            w[tag + "type"] = f.span(buf, e + "token_type_embeddings.weight", cfg.type_vocab_size * H, (cfg.type_vocab_size, H))
+            w[tag + "pos"] = f.span(buf, e + "position_embeddings.weight", cfg.max_position_embeddings * H, (cfg.max_position_embeddings, H))
+            w[tag + "emb_ln_g"] = f.span(buf, e + "LayerNorm.weight", H, (H,))
+            w[tag + "emb_ln_b"] = f.span(buf, e + "LayerNorm.bias", H, (H,))
+            w[tag + "joint_ln_g"] = f.span(buf, j + "LayerNorm.weight", H, (H,))
+            w[tag + "joint_ln_b"] = f.span(buf, j + "LayerNorm.bias", H, (H,))
+            w[tag + "Wv_w"] = f.span(buf, j + "Wv.weight", H * vd, (H, vd))
+            w[tag + "Wv_b"] = f.span(buf, j + "Wv.bias", H, (H,))
+            w[tag + "Ws_w"] = f.span(buf, j + "Ws.weight", H * sd, (H, sd))
+            w[tag + "Ws_b"] = f.span(buf, j + "Ws.bias", H, (H,))
+            w[tag + "pred_bias"] = f.span(buf, c + "bias", f.vpad, (f.vpad,))
+            w[tag + "bt"] = f.span(buf, c + "transform.dense.bias", H, (H,))
+            w[tag + "mlm_ln_g"] = f.span(buf, c + "transform.LayerNorm.weight", H, (H,))
+            w[tag + "mlm_ln_b"] = f.span(buf, c + "transform.LayerNorm.bias", H, (H,))
+        w["Wt"] = f.span(f.half, c + "transform.dense.weight", H * H, (H, H))
+        w["g_Wt"] = f.span(f.grads, c + "transform.dense.weight", H * H, (H, H))
+        w["word_h"] = f.span(f.half, e + "word_embeddings.weight", f.vpad * H, (f.vpad, H))
+        w["WtT"], w["wordT"] = f.tview("transform"), f.tview("word")
+        self._w = w
+
+    # ---- pass packing --------------------------------------------------------------------------
+    def _plan(self, lens_per_pass, B, device):
+        key = (tuple(lens_per_pass), B, str(device))
+        pl = self._plans.get(key)
+        if pl is None:
+            lens, first, bounds = [], [], [0]
+            row = 0
+            for S in lens_per_pass:
+                for b in range(B):
+                    lens.append(S)
+                    first.append(row + b * S)
+                row += B * S
+                bounds.append(row)
+            pl = dict(layout=ops.SeqLayout(lens, self.config.num_attention_heads, device),
+                      first=torch.tensor(first, dtype=torch.int64, device=device),
+                      bounds=bounds, bounds_dev=torch.tensor(bounds, dtype=torch.int32, device=device))
+            self._plans[key] = pl
+        return pl
+
+    @staticmethod
+    def _key_bias(mask, joint_pair: bool, device):
+        """REF:MMBertForPretraining.py:57-154: 2-D masks as is; 3-D joint masks -> feature 0."""
+        if mask.dim() == 3:
+            m = torch.narrow(mask, 2, 0, 1).squeeze(-1) if joint_pair else mask.float().mean(2)
+        elif mask.dim() == 2:
+            m = mask
+        else:
+            raise ValueError("You have so large dimension (), Check dimension or shape ")
+        return (1.0 - m.to(device=device, dtype=torch.float32)) * MASK_NEG
+
+    def _encode(self, passes):
+        """passes: list of dict(ids[B,T], tt[B,T]|None, mask, pair[B,P,D]|None, pair_mask|None).
+        Returns (Y [tokens,H] bf16, plan, lens_per_pass)."""
+        bert = self._bert()
+        dev = passes[0]["ids"].device
+        self._ensure_ready(dev)
+        B, T = passes[0]["ids"].shape
+        cfg = self.config
+        if T > cfg.max_position_embeddings:
+            raise ValueError("text length exceeds max_position_embeddings")
+        seed = self._next_seed()
+        ids = torch.cat([p["ids"].reshape(-1).long() for p in passes])
+        tts = torch.cat([(p["tt"].reshape(-1).long() if p.get("tt") is not None else torch.zeros(B * T, dtype=torch.long, device=dev)) for p in passes])
+        w = self._w
+        p_emb = cfg.hidden_dropout_prob if self.training else 0.0
+        e1 = _TextEmbedFn.apply(bert.embeddings.LayerNorm.weight, self, ids, tts, T, ops.make_drop(p_emb, seed, 1000))
+        xs, kbs, lens = [], [], []
+        je = bert.jointEmbeddings
+        p_joint = je.dropout_prob if (self.training and je.training) else 0.0
+        for k, p in enumerate(passes):
+            e = e1[k * B * T:(k + 1) * B * T]
+            kb = self._key_bias(p["mask"], False, dev)
+            if p.get("pair") is not None:
+                which = je.which(p["pair"])
+                feat = p["pair"].to(dev).float().contiguous()
+                e = _JointFn.apply(e, je.LayerNorm.weight, self, feat, which, B, T, ops.make_drop(p_joint, seed, 1001 + k))
+                kb = torch.cat((kb, self._key_bias(p["pair_mask"], True, dev)), dim=-1)
+                lens.append(T + feat.shape[1])
+            else:
+                lens.append(T)
+            xs.append(e)
+            kbs.append(kb.reshape(-1))
+        x = torch.cat(xs) if len(xs) > 1 else xs[0]
+        key_bias = torch.cat(kbs) if len(kbs) > 1 else kbs[0]
+        plan = self._plan(lens, B, dev)
+        y = _EncoderFn.apply(x, bert.embeddings.LayerNorm.weight, self, plan["layout"], key_bias.contiguous(), seed)
+        return y, plan, lens
+
+
+class MMBertModel(_GpuModelBase):
+    """REF:MMBertForPretraining.py:13-285.  Holds embeddings / encoder / pooler (+ jointEmbeddings)."""
+
+    def __init__(self, config, _owner=None):
+        super().__init__()
+        self.config = config
+        holder = _make_bert_holder(config)
+        self.embeddings, self.encoder, self.pooler = holder.embeddings, holder.encoder, holder.pooler
+        self._init_runtime()
+        self._owner = _owner
+        _hf_init(self, config.initializer_range)
+
+    def set_joint_embeddings(self, dataset):
+        self.dataset = dataset
+        self.jointEmbeddings = JointEmbeddings(self.config.hidden_size, 0.5, dataset)      # REF:MMBertForPretraining.py:26
+        dev = self.embeddings.word_embeddings.weight.device
+        self.jointEmbeddings.to(dev)
+        top = self._owner() if self._owner is not None else None
+        if top is not None:
+            import weakref
+            self.jointEmbeddings._owner = weakref.ref(top)
+            top._flat = None
+
+    def get_input_embeddings(self):
+        return self.embeddings.word_embeddings
+
+    def set_input_embeddings(self, value):
+        self.embeddings.word_embeddings = value
+
+    def forward(self, input_ids=None, attention_mask=None, token_type_ids=None, position_ids=None, head_mask=None,
+                inputs_embeds=None, encoder_hidden_states=None, encoder_attention_mask=None, output_attentions=None,
+                output_hidden_states=None, joint=False):
+        if self._owner is None:
+            raise RuntimeError("MMBertModel runs as MMBertForPretraining.bert (it shares the flat parameter storage)")
+        top = self._owner()
+        if input_ids is not None and inputs_embeds is not None:
+            raise ValueError("You cannot specify both input_ids and inputs_embeds at the same time")
+        if input_ids is None:
+            raise ValueError("You have to specify either input_ids or inputs_embeds")
+        if joint:
+            text, pair = input_ids
+            tmask, pmask = attention_mask
+            p = dict(ids=text, tt=None, mask=tmask.to(text.device), pair=pair, pair_mask=pmask.to(text.device))   # token types forced to 0 (:223)
+        else:
+            text = input_ids
+            tmask = attention_mask if attention_mask is not None else torch.ones(text.shape, device=text.device)
+            p = dict(ids=text, tt=token_type_ids, mask=tmask)
+        y, plan, lens = top._encode([p])
+        B = text.shape[0]
+        seq = y.view(B, lens[0], -1).float()
+        pooled = torch.tanh(F.linear(seq[:, 0], self.pooler.dense.weight, self.pooler.dense.bias))     # HF:457-463
+        return (seq, pooled)
+
+
+class MMBertPreTrainingHeads(nn.Module):
+    """REF:MMBertForPretraining.py:287-302 (BertPreTrainingHeads + ``align``)."""
+
+    def __init__(self, config):
+        super().__init__()
+        H = config.hidden_size
+        pred = _Box()
+        pred.transform = _Box()
+        pred.transform.dense = nn.Linear(H, H)
+        pred.transform.LayerNorm = nn.LayerNorm(H, eps=config.layer_norm_eps)
+        pred.decoder = nn.Linear(H, config.vocab_size, bias=True)
+        pred.bias = nn.Parameter(torch.zeros(config.vocab_size))
+        pred.decoder.bias = pred.bias
+        self.predictions = pred
+        self.seq_relationship = nn.Linear(H, 2)
+        self.align = nn.Linear(H, 2)
+        self._owner = None
+
+    def forward(self, sequence_output, pooled_output, joint=False):
+        top = self._owner()
+        B, S, H = sequence_output.shape
+        y = sequence_output.reshape(B * S, H).to(torch.bfloat16)
+        top._ensure_ready(y.device)
+        labels = torch.full((B * S,), -100, dtype=torch.long, device=y.device)
+        bounds = [0, B * S]
+        _, logits = _MLMHeadFn.apply(y, self.predictions.transform.LayerNorm.weight, top, labels, bounds, torch.tensor(bounds, dtype=torch.int32, device=y.device), True)
+        scores = logits.view(B, S, -1)[:, :, :top.config.vocab_size]
+        if joint:
+            return scores, self.align(sequence_output[:, 0])
+        return scores, self.seq_relationship(pooled_output)
+
+
+class MMBertForPretraining(_GpuModelBase):
+    """REF:MMBertForPretraining.py:304-449."""
+
+    def __init__(self, config):
+        super().__init__()
+        import weakref
+        self.config = config
+        H = config.hidden_size
+        self.bert = MMBertModel(config, _owner=weakref.ref(self))
+        self.cls = MMBertPreTrainingHeads(config)
+        self.cls._owner = weakref.ref(self)
+        self.num_labels = 7
+        self.classifier1_1 = nn.Linear(H * 3, H)
+        self.classifier1_2 = nn.Linear(H, 1) if self.num_labels == 7 else nn.Linear(H, self.num_labels)
+        self.attn = nn.Linear(H * 2, H)
+        self.relu = nn.ReLU()
+        self.vt, self.vs, self.vv = nn.Linear(H, 1), nn.Linear(H, 1), nn.Linear(H, 1)
+        self.tanh, self.sigmoid = nn.Tanh(), nn.Sigmoid()
+        self.dropout = nn.Dropout(0.38)                              # never used (REF :322)
+        self.alpha, self.beta = 1, 1
+        # x_size = hidden size: the reference hard-codes 1024 (:327-344) and only runs with bert-large
+        self.cpc_zt, self.cpc_zv, self.cpc_za = (CPC(H, H, 1, "Tanh") for _ in range(3))
+        self._init_runtime()
+        self.return_scores = True
+        _hf_init(self, config.initializer_range)
+        # weight tying (HF:728-731): decoder.weight IS the word embedding, decoder.bias IS predictions.bias
+        self.cls.predictions.decoder.weight = self.bert.embeddings.word_embeddings.weight
+
+    # ---- construction helpers ------------------------------------------------------------------
+    @classmethod
+    def from_pretrained(cls, name_or_path, **kw):
+        """Loads ``config.json`` + ``pytorch_model.bin``/``model.safetensors`` from a LOCAL directory
+        (HF BertForPreTraining key names load as is).  There is no network on the target boxes."""
+        if not os.path.isdir(name_or_path):
+            raise OSError(f"{name_or_path}: from_pretrained needs a local checkpoint directory (no network access)")
+        with open(os.path.join(name_or_path, "config.json")) as fh:
+            cfg = MMBertConfig(**json.load(fh))
+        model = cls(cfg)
+        sd = None
+        st = os.path.join(name_or_path, "model.safetensors")
+        if os.path.exists(st):
+            from safetensors.torch import load_file
+            sd = load_file(st)
+        else:
+            sd = torch.load(os.path.join(name_or_path, "pytorch_model.bin"), map_location="cpu")
+        sd = {k: v for k, v in sd.items() if not k.endswith("position_ids")}
+        model.load_state_dict(sd, strict=False)
+        return model
+
+    def set_alpha_beta(self, alpha, beta):
+        self.alpha, self.beta = alpha, beta
+
+    def _apply(self, fn, *a, **k):
+        self._flat = None                       # .cuda()/.to() re-creates parameter storage: re-flatten lazily
+        return super()._apply(fn, *a, **k)
+
+    def load_state_dict(self, state_dict, strict=True, **kw):
+        sd = {k: v for k, v in state_dict.items() if not k.endswith("embeddings.position_ids")}   # transformers-4.x buffer
+        return super().load_state_dict(sd, strict=strict, **kw)
+
+    # ---- the hot path --------------------------------------------------------------------------
+    def get_bert_output(self, input_ids, attention_mask, token_type_ids, joint=False):
+        if joint:
+            assert isinstance(input_ids, tuple)
+        seq, pooled = self.bert(input_ids, attention_mask=attention_mask, token_type_ids=token_type_ids, joint=joint)
+        return self.cls(seq, pooled, joint), pooled
+
+    def forward(self, input_ids, token_type_ids, attention_mask, masked_labels, ap_label, sentiment):
+        self.outputs = ()
+        text_ids, visual, speech, twv, tws = input_ids
+        tt_t = token_type_ids[0]
+        am_t, am_v, am_s = attention_mask
+        lab_t, lab_v, lab_s = masked_labels
+        ap_v, ap_s = ap_label
+        dev = text_ids.device
+        B, T = text_ids.shape
+        passes = [dict(ids=text_ids, tt=tt_t, mask=am_t),
+                  dict(ids=twv, tt=None, mask=am_v[0].to(dev), pair=visual, pair_mask=am_v[1].to(dev)),
+                  dict(ids=tws, tt=None, mask=am_s[0].to(dev), pair=speech, pair_mask=am_s[1].to(dev))]
+        y, plan, lens = self._encode(passes)
+        H, V = self.config.hidden_size, self.config.vocab_size
+        labels = torch.cat((lab_t.reshape(-1), lab_v.reshape(-1), lab_s.reshape(-1))).to(device=dev, dtype=torch.long)
+        if labels.numel() != y.shape[0]:
+            raise ValueError("masked_labels must cover text (+ pair) positions of every pass")
+        mlm, logits = _MLMHeadFn.apply(y, self.cls.predictions.transform.LayerNorm.weight, self, labels, plan["bounds"], plan["bounds_dev"], self.return_scores)
+
+        first = y.index_select(0, plan["first"]).float()                             # [3B, H]: [CLS] rows of every sequence
+        pool = self.bert.pooler.dense
+        pooled = torch.tanh(F.linear(first, pool.weight, pool.bias))
+        pt, pv, ps = pooled[:B], pooled[B:2 * B], pooled[2 * B:]
+        with torch.no_grad():
+            t_rel = self.cls.seq_relationship(pt)                                    # computed, never in a loss (:301, App. B-9)
+        v_rel = self.cls.align(first[B:2 * B])                                       # :297-298
+        s_rel = self.cls.align(first[2 * B:])
+        v_ap = F.cross_entropy(v_rel.view(-1, 2), ap_v.to(dev).view(-1).long())
+        s_ap = F.cross_entropy(s_rel.view(-1, 2), ap_s.to(dev).view(-1).long())
+
+        def gate(x, v):                                                              # :407-409
+            return v(self.relu(self.attn(torch.cat((x, x), dim=1))))
+        pooled_cat = torch.cat((pt * gate(pt, self.vt), pv * gate(pv, self.vv), ps * gate(ps, self.vs)), dim=1)
+        temp = self.classifier1_1(pooled_cat)
+        logits_out = self.classifier1_2(temp)
+        nce = self.cpc_zt(pt, temp) + self.cpc_zv(pv, temp) + self.cpc_za(ps, temp)
+        mlm_loss = (mlm[0] + mlm[1] + mlm[2]) / 3.0                                  # :427
+        ap_loss = (v_ap + s_ap) / 2.0                                                # :428
+        if sentiment is not None:
+            if self.num_labels == 1 or self.num_labels == 7:
+                if self.num_labels == 1:
+                    logits_out = self.tanh(logits_out)
+                label_loss = F.mse_loss(logits_out.view(-1), sentiment.to(dev).view(-1).float())
+            else:
+                label_loss = F.cross_entropy(logits_out, sentiment.to(dev))
+                logits_out = torch.argmax(self.sigmoid(logits_out), dim=1)
+        joint_loss = self.alpha * mlm_loss + ap_loss + label_loss - self.beta * nce   # :443
+        scores = (None, None, None)
+        if logits is not None:
+            b = plan["bounds"]
+            scores = tuple(logits[b[k]:b[k + 1]].view(B, lens[k], -1)[:, :, :V] for k in range(3))
+        self.outputs = (joint_loss, None, None, None, ap_loss, label_loss, nce,
+                        scores[0], t_rel, scores[1], v_rel, scores[2], s_rel)
+        return self.outputs, logits_out

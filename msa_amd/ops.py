@@ -265,6 +265,14 @@ def adamw(p, g, m, v, p_bf16, flags, *, lr, beta1=0.9, beta2=0.999, eps=1e-6, wd
                                 1 if zero_grad else 0), "mmbert_adamw")
 
 
+def gelu_bwd(dy, u, du=None):
+    if du is None:
+        du = torch.empty_like(dy)
+    assert dy.is_contiguous() and u.is_contiguous() and du.is_contiguous()
+    _lib.check(_lib.load().mmbert_gelu_bwd(_stream(), dy.data_ptr(), u.data_ptr(), du.data_ptr(), dy.numel()), "mmbert_gelu_bwd")
+    return du
+
+
 def cast_f32_bf16(x, y):
     _lib.check(_lib.load().mmbert_cast_f32_bf16(_stream(), x.data_ptr(), y.data_ptr(), x.numel()), "mmbert_cast_f32_bf16")
     return y

@@ -1,0 +1,169 @@
+"""Counterpart of the reference's training loop (REF:trainer.py:13-101) and of the input producers it
+calls (REF:model_utils.py:6-143): same packing, same stepping rule, same return value.
+
+Differences, all deliberate and documented in DESIGN.md:
+* tensors are built on / moved to the GPU once per step and loss bookkeeping stays on the device
+  (the reference calls ``.item()`` >= 3x per step, REF:trainer.py:85-93: a device sync each);
+* ``quirk_step=True`` keeps ``(step+1) & gradient_accumulation_step == 0`` (REF:trainer.py:96 -- at
+  gas=1 the optimizer steps every SECOND micro-batch); ``False`` gives the intended modulo;
+* with a ``parallel.DataParallel`` wrapper the gradient exchange happens only on stepping micro-batches.
+"""
+from __future__ import annotations
+
+import types
+from typing import Optional
+
+import torch
+from torch.nn.utils.rnn import pad_sequence
+
+PAD, CLS, SEP, MASK = 0, 101, 102, 103
+
+
+def mask_tokens(inputs: torch.Tensor, args, generator: Optional[torch.Generator] = None, special_ids=(PAD, CLS, SEP), mask_id=MASK):
+    """REF:model_utils.py:6-39 on the tensor's own device: Bernoulli(mlm_probability) selection with
+    special tokens excluded (:17-23), labels -100 elsewhere (:28), 80 % of the selected positions
+    -> [MASK] (:30-32, in place like the reference); the 10 % random-token branch is commented out
+    in the reference (:34-37) and therefore absent."""
+    labels = inputs.clone()
+    prob = torch.full(labels.shape, float(args.mlm_probability), device=inputs.device)
+    special = torch.zeros_like(inputs, dtype=torch.bool)
+    for s in special_ids:
+        special |= inputs == s
+    prob.masked_fill_(special, 0.0)
+    masked = torch.bernoulli(prob, generator=generator).bool()
+    labels[~masked] = -100
+    replaced = torch.bernoulli(torch.full(labels.shape, 0.8, device=inputs.device), generator=generator).bool() & masked
+    inputs[replaced] = mask_id
+    return inputs, labels
+
+
+def collate(examples):
+    """REF:model_utils.py:51-143 output contract: (text_batch, visual_batch, speech_batch,
+    attention_batch, segments, rawData) with the reference's dtypes and quirks -- text mask 0 at
+    PAD (:118-120); pair masks ``feature != 0`` (float64 visual :124-125, int64 speech :132-133);
+    text-with-pair masks stay all ones (``==`` instead of ``=``, :128,136)."""
+    te, tl, tti, ts, twv, ve, vl, vti, vs, tws, se, sl, sti, ss, seg, raw = zip(*examples)
+    for a, b, c, d, e in zip(te, ve, se, twv, tws):
+        assert len(a) == len(b) == len(c) == len(d) == len(e)                # :92
+    sent_dtype = torch.long if torch.as_tensor(ts[0]).dtype == torch.int64 else torch.float
+    mk_sent = lambda x: torch.tensor([float(v) if sent_dtype == torch.float else int(v) for v in x], dtype=sent_dtype)
+    text = pad_sequence([torch.as_tensor(t) for t in te], batch_first=True, padding_value=0)
+    text_mask = torch.ones(text.shape, dtype=torch.float64)
+    text_mask[text == 0] = 0
+    vis = torch.as_tensor(_stack(ve))
+    vis_mask = torch.ones(vis.shape, dtype=torch.float64)
+    vis_mask[vis == 0] = 0
+    sp = torch.as_tensor(_stack(se))
+    sp_mask = torch.ones(sp.shape, dtype=torch.int64)
+    sp_mask[sp == 0] = 0
+    twv_t, tws_t = torch.as_tensor(_stack(twv)), torch.as_tensor(_stack(tws))
+    twv_mask = torch.ones(twv_t.shape, dtype=torch.float64)                 # quirk: never zeroed
+    tws_mask = torch.ones(tws_t.shape, dtype=torch.int64)
+    lab = lambda x: torch.tensor([int(v) for v in x], dtype=torch.int64)
+    text_batch = (text, lab(tl), pad_sequence(list(tti), batch_first=True, padding_value=0).long(), text_mask, mk_sent(ts))
+    visual_batch = (twv_t, vis, lab(vl), pad_sequence(list(vti), batch_first=True, padding_value=0), vis_mask, mk_sent(vs))
+    speech_batch = (tws_t, sp, lab(sl), pad_sequence(list(sti), batch_first=True, padding_value=0), sp_mask, mk_sent(ss))
+    return text_batch, visual_batch, speech_batch, (twv_mask, tws_mask), list(seg), list(raw)
+
+
+def _stack(seq):
+    import numpy as np
+    return np.stack([np.asarray(x) for x in seq])
+
+
+def pack_step_inputs(batch, args, device, generator=None):
+    """REF:trainer.py:42-64: MLM masking (re-drawn independently for text / twv / tws), label
+    duplication for the pair positions, tuple packing -- returns the model's keyword arguments."""
+    text_batch, visual_batch, speech_batch, attention_batch = batch[:4]
+    dev = torch.device(device)
+    t0, v0, s0 = text_batch[0].to(dev), visual_batch[0].to(dev), speech_batch[0].to(dev)
+    if args.mlm:
+        text_inputs, text_labels = mask_tokens(t0.clone(), args, generator)
+        twv_ids, v_labels = mask_tokens(v0.clone(), args, generator)
+        tws_ids, s_labels = mask_tokens(s0.clone(), args, generator)
+    else:
+        text_inputs, text_labels, twv_ids, v_labels, tws_ids, s_labels = t0, t0, v0, v0, s0, s0
+    v_labels = torch.cat((v_labels, v_labels), dim=-1)                       # REF:trainer.py:50 (needs P == T)
+    s_labels = torch.cat((s_labels, s_labels), dim=-1)                       # REF:trainer.py:53
+    return dict(
+        input_ids=(text_inputs, visual_batch[1].to(dev), speech_batch[1].to(dev), twv_ids, tws_ids),
+        token_type_ids=(text_batch[2].to(dev), visual_batch[3].to(dev), speech_batch[3].to(dev)),
+        attention_mask=(text_batch[3].to(dev), (attention_batch[0].to(dev), visual_batch[4].to(dev)),
+                        (attention_batch[1].to(dev), speech_batch[4].to(dev))),
+        masked_labels=(text_labels, v_labels, s_labels),
+        ap_label=(visual_batch[2].to(dev), speech_batch[2].to(dev)),
+        sentiment=text_batch[-1].to(dev),
+    )
+
+
+def should_step(step: int, gas: int, quirk: bool = True) -> bool:
+    return (((step + 1) & gas) == 0) if quirk else (((step + 1) % gas) == 0)
+
+
+def train_epoch(args, model, traindata, optimizer, scheduler, tokenizer=None, *, device="cuda", dp=None, quirk_step=True,
+                generator=None, shuffle=True, batches=None):
+    """One epoch.  ``traindata``: a Dataset of the reference's 16-tuples (collated here), or pass
+    ``batches`` = an iterable of ready model-kwargs dicts (the synthetic generator).
+    Returns the reference's 6-tuple (REF:trainer.py:101): (train_loss, text_loss, visual_loss,
+    speech_loss, ap_loss_of_the_LAST_step, label_loss) each divided by the number of steps."""
+    if batches is None:
+        from torch.utils.data import DataLoader, RandomSampler, SequentialSampler
+        sampler = RandomSampler(traindata) if shuffle else SequentialSampler(traindata)
+        loader = DataLoader(traindata, sampler=sampler, batch_size=args.train_batch_size, collate_fn=collate)
+        batches = (pack_step_inputs(b, args, device, generator) for b in loader)
+    gas = args.gradient_accumulation_step
+    model.train()
+    train_loss = torch.zeros((), device=device)
+    label_loss = torch.zeros((), device=device)
+    ap_loss = torch.zeros((), device=device)
+    n = 0
+    for step, kwargs in enumerate(batches):
+        stepping = should_step(step, gas, quirk_step)
+        ctx = dp.no_sync() if (dp is not None and not stepping) else _null()
+        with ctx:
+            outputs, _ = model(**kwargs)
+            loss = outputs[0]
+            loss.mean().backward()                                           # REF:trainer.py:83
+        train_loss += loss.detach().mean()
+        label_loss += outputs[5].detach().mean()
+        ap_loss = outputs[4].detach()
+        n += 1
+        if stepping:                                                         # REF:trainer.py:96-99
+            if dp is not None:
+                dp.finish_backward()
+            optimizer.step()
+            scheduler.step()
+            optimizer.zero_grad()
+    if n == 0:
+        return (0.0,) * 6
+    return (float(train_loss) / n, 0.0, 0.0, 0.0, float(ap_loss) / n, float(label_loss) / n)
+
+
+class _null:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False
+
+
+def default_args(**kw):
+    """The reference's argparse defaults that the loop reads (REF:train.py:24-42)."""
+    d = dict(train_batch_size=32, mlm=True, mlm_probability=0.15, gradient_accumulation_step=1, learning_rate=5e-4,
+             warmup_proportion=1.0, n_epochs=200, max_seq_length=40)
+    d.update(kw)
+    return types.SimpleNamespace(**d)
+
+
+def build_optimizer(model, args, num_train_optimization_steps, mode="hf"):
+    """REF:train.py:76-97: two parameter groups by NAME substring, AdamW, linear warm-up with
+    warmup = N and total = warmup_proportion * N."""
+    from .optim import AdamW, get_linear_schedule_with_warmup
+    no_decay = ["bias", "LayerNorm.bias", "LayerNorm.weight"]
+    named = list(model.named_parameters())
+    groups = [{"params": [p for n, p in named if not any(nd in n for nd in no_decay)], "weight_decay": 0.01},
+              {"params": [p for n, p in named if any(nd in n for nd in no_decay)], "weight_decay": 0.0}]
+    opt = AdamW(groups, lr=args.learning_rate, mode=mode)
+    sched = get_linear_schedule_with_warmup(opt, num_warmup_steps=num_train_optimization_steps,
+                                            num_training_steps=args.warmup_proportion * num_train_optimization_steps)
+    return opt, sched

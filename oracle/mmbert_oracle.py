@@ -41,8 +41,35 @@ MODALITY_DIMS = {"mosi": (47, 74), "mosei": (35, 74), "ur_funny": (371, 81)}
 # ----------------------------------------------------------------------------------------------
 # small helpers
 # ----------------------------------------------------------------------------------------------
-def _linear(x, p: Params, name: str):
-    return F.linear(x, p[name + ".weight"], p[name + ".bias"])
+_EMULATE_BF16 = False      # tolerance calibrator only: see bf16_storage_emulation()
+
+
+def _r(x):
+    """bf16 storage emulation with a straight-through gradient (identity unless the calibrator is on)."""
+    if not _EMULATE_BF16:
+        return x
+    return x + (x.to(torch.bfloat16).to(x.dtype) - x).detach()
+
+
+class bf16_storage_emulation:
+    """Context manager: round activations and GEMM weights to bf16 at the points where the HIP path
+    stores bf16 (fp32 accumulation everywhere).  NOT part of the parity pin -- the tests use it to
+    measure how far bf16 storage alone moves each loss / gradient away from the fp32 oracle, and
+    bound the HIP path's deviation by a small multiple of that (ill-conditioned head gradients)."""
+
+    def __enter__(self):
+        global _EMULATE_BF16
+        self.prev, _EMULATE_BF16 = _EMULATE_BF16, True
+
+    def __exit__(self, *a):
+        global _EMULATE_BF16
+        _EMULATE_BF16 = self.prev
+
+
+def _linear(x, p: Params, name: str, big: bool = False):
+    """``big`` marks the projections the HIP path runs as bf16 GEMMs (weights rounded in emulation)."""
+    w = _r(p[name + ".weight"]) if big else p[name + ".weight"]
+    return F.linear(x, w, p[name + ".bias"])
 
 
 def _layer_norm(x, p: Params, name: str, eps: float):
@@ -91,8 +118,8 @@ def bert_embeddings(p: Params, input_ids, token_type_ids, *, hidden_dropout=0.1,
     e = F.embedding(input_ids.long(), p["bert.embeddings.word_embeddings.weight"], padding_idx=0)
     e = e + p["bert.embeddings.token_type_embeddings.weight"][token_type_ids.long()]
     e = e + p["bert.embeddings.position_embeddings.weight"][:T][None]
-    e = _layer_norm(e, p, "bert.embeddings.LayerNorm", LN_EPS_BERT)
-    return _dropout(e, hidden_dropout, train, masks, tag + "emb")
+    e = _layer_norm(_r(e), p, "bert.embeddings.LayerNorm", LN_EPS_BERT)
+    return _r(_dropout(e, hidden_dropout, train, masks, tag + "emb"))
 
 
 def joint_embeddings(p: Params, input_embs, pair_ids, dims: Tuple[int, int], *, joint_dropout=0.5,
@@ -107,9 +134,9 @@ def joint_embeddings(p: Params, input_embs, pair_ids, dims: Tuple[int, int], *, 
         pe = F.relu(_linear(pair_ids.float(), p, "bert.jointEmbeddings.Ws"))
     else:
         raise Exception("Wrong Dimension")                      # REF:MMBertEmbedding.py:66
-    x = torch.cat((input_embs, pe), dim=1)
+    x = _r(torch.cat((input_embs, pe), dim=1))
     x = _layer_norm(x, p, "bert.jointEmbeddings.LayerNorm", LN_EPS_JOINT)
-    return _dropout(x, joint_dropout, train, masks, tag + "joint")
+    return _r(_dropout(x, joint_dropout, train, masks, tag + "joint"))
 
 
 # ----------------------------------------------------------------------------------------------
@@ -122,22 +149,22 @@ def encoder_layer(p: Params, i: int, x, ext_mask, n_heads: int, *, hidden_dropou
     pre = f"bert.encoder.layer.{i}."
     B, S, H = x.shape
     dh = H // n_heads
-    q = _linear(x, p, pre + "attention.self.query").view(B, S, n_heads, dh).transpose(1, 2)
-    k = _linear(x, p, pre + "attention.self.key").view(B, S, n_heads, dh).transpose(1, 2)
-    v = _linear(x, p, pre + "attention.self.value").view(B, S, n_heads, dh).transpose(1, 2)
+    q = _r(_linear(x, p, pre + "attention.self.query", True)).view(B, S, n_heads, dh).transpose(1, 2)
+    k = _r(_linear(x, p, pre + "attention.self.key", True)).view(B, S, n_heads, dh).transpose(1, 2)
+    v = _r(_linear(x, p, pre + "attention.self.value", True)).view(B, S, n_heads, dh).transpose(1, 2)
     w = torch.matmul(q, k.transpose(2, 3)) * (dh ** -0.5)
     if ext_mask is not None:
         w = w + ext_mask
     w = F.softmax(w, dim=-1)
     w = _dropout(w, attn_dropout, train, masks, f"{tag}l{i}.attn")
-    ctx = torch.matmul(w, v).transpose(1, 2).reshape(B, S, H)
-    a = _linear(ctx, p, pre + "attention.output.dense")
+    ctx = _r(torch.matmul(_r(w), v).transpose(1, 2).reshape(B, S, H))
+    a = _linear(ctx, p, pre + "attention.output.dense", True)
     a = _dropout(a, hidden_dropout, train, masks, f"{tag}l{i}.h1")
-    y = _layer_norm(a + x, p, pre + "attention.output.LayerNorm", LN_EPS_BERT)
-    u = F.gelu(_linear(y, p, pre + "intermediate.dense"))
-    o = _linear(u, p, pre + "output.dense")
+    y = _r(_layer_norm(_r(a + x), p, pre + "attention.output.LayerNorm", LN_EPS_BERT))
+    u = _r(F.gelu(_r(_linear(y, p, pre + "intermediate.dense", True))))
+    o = _linear(u, p, pre + "output.dense", True)
     o = _dropout(o, hidden_dropout, train, masks, f"{tag}l{i}.h2")
-    return _layer_norm(o + y, p, pre + "output.LayerNorm", LN_EPS_BERT)
+    return _r(_layer_norm(_r(o + y), p, pre + "output.LayerNorm", LN_EPS_BERT))
 
 
 def encoder(p: Params, x, ext_mask, n_layers: int, n_heads: int, *, collect=None, **kw):
@@ -183,9 +210,9 @@ def mmbert_model(p: Params, cfg: dict, input_ids, attention_mask, token_type_ids
 def mlm_scores(p: Params, seq):
     """HF:466-496: decoder(LN(gelu(dense(seq)))); decoder.weight tied to the word embeddings
     (HF:728-731), decoder.bias = cls.predictions.bias."""
-    t = F.gelu(_linear(seq, p, "cls.predictions.transform.dense"))
-    t = _layer_norm(t, p, "cls.predictions.transform.LayerNorm", LN_EPS_BERT)
-    return F.linear(t, p["bert.embeddings.word_embeddings.weight"], p["cls.predictions.bias"])
+    t = _r(F.gelu(_r(_linear(seq, p, "cls.predictions.transform.dense", True))))
+    t = _r(_layer_norm(t, p, "cls.predictions.transform.LayerNorm", LN_EPS_BERT))
+    return _r(F.linear(t, _r(p["bert.embeddings.word_embeddings.weight"]), p["cls.predictions.bias"]))
 
 
 def pretraining_heads(p: Params, seq, pooled, joint: bool):

@@ -1,0 +1,197 @@
+"""End-to-end parity of the HIP path (through the reference's module API) against the CPU oracle
+and against the golden vectors generated from the real reference.
+
+Stated tolerances (bf16 operands, fp32 accumulation): losses 3e-3 relative,
+regression logits 2e-2 absolute, MLM scores 3e-2 absolute, parameter-gradient cosine >= 0.995 and
+every parameter gradient within 4.5 % relative error (== cosine 0.999) of the oracle's, except
+ill-conditioned head gradients, which are bounded by 3x the deviation that bf16 STORAGE ALONE
+causes in the oracle itself (oracle.bf16_storage_emulation, a calibrator -- not a parity pin)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import mmbert_oracle as O
+from msa_amd.data import synthetic_batch, batch_to
+
+DEV = "cuda"
+CFG1 = dict(hidden=128, layers=2, heads=2, intermediate=512, vocab=30522, dataset="mosei", alpha=1.0, beta=1.0)
+
+
+def build(cfg, train=False, seed=0):
+    from msa_amd.model import MMBertConfig, MMBertForPretraining
+    c = MMBertConfig(vocab_size=cfg["vocab"], hidden_size=cfg["hidden"], num_hidden_layers=cfg["layers"],
+                     num_attention_heads=cfg["heads"], intermediate_size=cfg["intermediate"])
+    m = MMBertForPretraining(c)
+    m.bert.set_joint_embeddings(cfg["dataset"])
+    m.set_alpha_beta(cfg.get("alpha", 1.0), cfg.get("beta", 1.0))
+    sd = O.seeded_params(cfg, seed)
+    missing, unexpected = m.load_state_dict(sd, strict=False)
+    assert not unexpected and sorted(missing) == ["cls.predictions.decoder.bias", "cls.predictions.decoder.weight"], (missing, unexpected)
+    m = m.to(DEV)
+    m.train(train)
+    return m
+
+
+def oracle_run(cfg, batch, train=False, emulate_bf16=False):
+    p = {k: v.clone().requires_grad_(True) for k, v in O.seeded_params(cfg).items()}
+    ocfg = dict(cfg)
+    if not train:
+        ocfg.update(hidden_dropout=0.0, attn_dropout=0.0, joint_dropout=0.0)
+    if emulate_bf16:
+        with O.bf16_storage_emulation():
+            out, logits = O.pretraining_forward(p, ocfg, **batch)
+            out[0].mean().backward()
+    else:
+        out, logits = O.pretraining_forward(p, ocfg, **batch)
+        out[0].mean().backward()
+    return p, out, logits
+
+
+def rel(a, b):
+    return abs(float(a) - float(b)) / max(abs(float(b)), 1e-6)
+
+
+def check_against_oracle(cfg, B, T, Pv, Pa, seed, loss_tol=3e-3):
+    batch = synthetic_batch(B, T, Pv, Pa, dataset=cfg["dataset"], vocab=cfg["vocab"], seed=seed)
+    p, oout, ologits = oracle_run(cfg, batch)
+    pe, _, _ = oracle_run(cfg, batch, emulate_bf16=True)        # calibrator: what bf16 storage alone does to each gradient
+    m = build(cfg)
+    out, logits = m(**batch_to(batch, DEV))
+    for i, name in ((0, "joint"), (4, "ap"), (5, "label"), (6, "nce")):
+        assert rel(out[i], oout[i]) < loss_tol, (name, float(out[i]), float(oout[i]))
+    assert out[1] is None and out[2] is None and out[3] is None
+    assert float((logits.float().cpu() - ologits.detach()).abs().max()) < 2e-2
+    V = cfg["vocab"]
+    for k in (7, 9, 11):
+        assert tuple(out[k].shape) == tuple(oout[k].shape)
+        d = (out[k].float().cpu() - oout[k].detach()).abs().max()
+        assert float(d) < 3e-2, (k, float(d))
+    for k in (8, 10, 12):
+        assert float((out[k].float().cpu() - oout[k].detach()).abs().max()) < 2e-2
+    out[0].mean().backward()
+    torch.cuda.synchronize()
+    worst = (1.0, None)
+    loose = []
+    for n, q in m.named_parameters():
+        og = p[n].grad
+        g = q.grad.float().cpu()
+        if og is None or float(og.abs().sum()) == 0.0:
+            assert float(g.abs().sum()) == 0.0, f"{n}: reference has no gradient here"
+            continue
+        if "attention.self.key.bias" in n:
+            # softmax is invariant to a per-query constant: the true gradient is 0, the reference holds
+            # fp32 rounding noise (~1e-9); ours must be bf16-noise small
+            assert float(og.norm()) < 1e-6 and float(g.norm()) < 2e-3, (n, float(g.norm()))
+            continue
+        dev = float((g - og).norm() / og.norm())
+        dev_emul = float((pe[n].grad - og).norm() / og.norm())
+        # 4.5 % relative error == cosine 0.999; ill-conditioned head gradients (CPC, pooler, gates at
+        # init) are allowed 3x what bf16 storage alone does to the ORACLE's gradient
+        assert dev < max(0.045, 3.0 * dev_emul), (n, dev, dev_emul)
+        if dev > 0.045:
+            loose.append((n, round(dev, 3), round(dev_emul, 3)))
+        cos = float(torch.nn.functional.cosine_similarity(g.reshape(1, -1), og.reshape(1, -1)))
+        if cos < worst[0]:
+            worst = (cos, n)
+    print("gradients checked against the bf16-emulation calibrator instead of the 4.5% bound:", loose)
+    return m, out, worst
+
+
+def test_cfg1_matches_oracle_forward_backward():
+    m, out, worst = check_against_oracle(CFG1, 2, 50, 64, 64, seed=1)
+    print("worst gradient cosine", worst)
+
+
+def test_cfg1_matches_reference_golden(golden_dir):
+    """Direct comparison with the numbers the REAL reference produced (tests/golden/make_golden.py)."""
+    for name in ("cfg1_T50_P64", "cfg1_T50_P50"):
+        g = np.load(os.path.join(golden_dir, name + ".npz"))
+        B, T, Pv, Pa, seed = (int(x) for x in g["meta"])
+        batch = synthetic_batch(B, T, Pv, Pa, seed=seed)
+        m = build(CFG1)
+        out, logits = m(**batch_to(batch, DEV))
+        assert rel(out[0], g["joint_loss"]) < 3e-3 and rel(out[4], g["ap_loss"]) < 3e-3
+        assert rel(out[5], g["label_loss"]) < 3e-3 and rel(out[6], g["nce"]) < 3e-3
+        assert np.abs(logits.detach().float().cpu().numpy() - g["logits"]).max() < 2e-2
+        for pi, tag in enumerate("tvs"):
+            sc = out[7 + 2 * pi].detach().float().cpu()
+            assert np.abs(sc[:, :, :48].numpy() - g[f"{tag}_scores_head"]).max() < 3e-2
+            assert np.abs(torch.logsumexp(sc, -1).numpy() - g[f"{tag}_scores_lse"]).max() < 2e-2
+        out[0].mean().backward()
+        nograd = sorted(n for n, q in m.named_parameters() if float(q.grad.abs().sum()) == 0.0)
+        assert nograd == list(g["nograd"])
+        for n, q in m.named_parameters():
+            if n in nograd or "attention.self.key.bias" in n:       # key.bias: true gradient is 0 (noise only)
+                continue
+            if not n.startswith(("bert.embeddings", "bert.encoder", "bert.jointEmbeddings", "cls.predictions")):
+                continue        # ill-conditioned [B,H] head gradients: bounded by the calibrator in check_against_oracle
+            gn = float(g["gnorm/" + n])
+            assert abs(float(q.grad.norm()) - gn) < 0.03 * gn + 1e-7, n
+
+
+def test_bert_base_shapes_two_layers_match_oracle():
+    cfg = dict(hidden=768, layers=2, heads=12, intermediate=3072, vocab=30522, dataset="mosei", alpha=1.0, beta=1.0)
+    check_against_oracle(cfg, 2, 50, 500, 500, seed=5)
+
+
+def test_mosi_dims_and_unequal_pair_lengths():
+    cfg = dict(CFG1, dataset="mosi", vocab=4096, alpha=0.5, beta=0.25)
+    check_against_oracle(cfg, 3, 24, 70, 33, seed=6)
+
+
+def test_dropout_train_mode_is_seeded_and_unbiased():
+    batch = batch_to(synthetic_batch(2, 50, 64, 64, seed=1), DEV)
+    m = build(CFG1, train=True)
+    m.manual_seed(11)
+    a = float(m(**batch)[0][0])
+    b = float(m(**batch)[0][0])
+    m.manual_seed(11)
+    c = float(m(**batch)[0][0])
+    assert a == c and a != b
+    m.eval()
+    e = float(m(**batch)[0][0])
+    vals = []
+    m.train()
+    for _ in range(8):
+        vals.append(float(m(**batch)[0][0]))
+    assert all(np.isfinite(vals)) and abs(np.mean(vals) - e) < 0.15 * abs(e)
+    out, _ = m(**batch)
+    out[0].mean().backward()
+    assert all(torch.isfinite(q.grad).all() for q in m.parameters())
+
+
+def test_submodule_api_matches_oracle():
+    """MMBertModel.forward(joint) / JointEmbeddings.forward / heads via the reference's call sites."""
+    cfg = CFG1
+    batch = synthetic_batch(2, 50, 64, 64, seed=1)
+    p = O.seeded_params(cfg)
+    m = build(cfg)
+    ids, am = batch["input_ids"], batch["attention_mask"]
+    ocfg = dict(cfg, hidden_dropout=0.0, attn_dropout=0.0, joint_dropout=0.0)
+    with torch.no_grad():
+        seq, pooled = m.bert((ids[3].to(DEV), ids[1].to(DEV)), attention_mask=(am[1][0].to(DEV), am[1][1].to(DEV)), joint=True)
+        oseq, opooled = O.mmbert_model(p, ocfg, (ids[3], ids[1]), am[1], None, True)
+        assert float((seq.cpu() - oseq).abs().max()) < 6e-2 and float((pooled.cpu() - opooled).abs().max()) < 2e-2
+        seq, pooled = m.bert(ids[0].to(DEV), attention_mask=am[0].to(DEV), token_type_ids=batch["token_type_ids"][0].to(DEV))
+        oseq, opooled = O.mmbert_model(p, ocfg, ids[0], am[0], batch["token_type_ids"][0], False)
+        assert float((seq.cpu() - oseq).abs().max()) < 6e-2
+        te = torch.randn(2, 50, cfg["hidden"], generator=torch.Generator().manual_seed(3))
+        je = m.bert.jointEmbeddings(te.to(DEV), ids[2].to(DEV))
+        oje = O.joint_embeddings(p, te, ids[2], (35, 74))
+        assert float((je.cpu() - oje).abs().max()) < 5e-2
+        with pytest.raises(Exception, match="Wrong Dimension"):
+            m.bert.jointEmbeddings(te.to(DEV), torch.zeros(2, 4, 33, device=DEV))
+        with pytest.raises(ValueError):
+            m.bert(ids[0].to(DEV), attention_mask=torch.ones(2, 50, 1, 1, device=DEV))
+
+
+def test_cpu_tensors_are_rejected_loudly():
+    from msa_amd.model import MMBertConfig, MMBertForPretraining
+    m = MMBertForPretraining(MMBertConfig(vocab_size=512, hidden_size=128, num_hidden_layers=1, num_attention_heads=2, intermediate_size=256))
+    m.bert.set_joint_embeddings("mosei")
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        m(**synthetic_batch(2, 8, 8, 8, vocab=512, seed=1))
