@@ -37,12 +37,23 @@ int mmbert_gemm_nt(mmbert_stream_t stream, const void* A, int lda, const void* B
                    const void* U, int ldu, float alpha, const float* alpha_dev,
                    uint32_t drop_stream, uint32_t drop_thr16, float drop_scale);
 
-/* W[N,K] (fp32) = (accumulate ? W : 0) + alpha * alpha_dev[0] * A[M,N]^T . B[M,K]: the weight
- * gradient autograd computes for nn.Linear (REF:trainer.py:83).  `slab` must hold
- * mmbert_gemm_tn_workspace() bytes (split over the token axis, reduced deterministically). */
+/* Kernel selection for mmbert_gemm_nt: 0 = by shape (default), 1 = 128x128 tile kernel, 2 = 256x256
+ * 4-stage-ring kernel.  For tests and A/B benchmarking; results are identical up to fp32 summation order. */
+void mmbert_gemm_nt_force(int mode);
+
+/* Weight gradients autograd computes for nn.Linear (REF:trainer.py:83):
+ *   W[N,K] (fp32, contiguous: ldw == K) = (accumulate ? W : 0) + alpha * alpha_dev[0] * A[M,N]^T . B[M,K]
+ *   bias_out[N] (optional)             += alpha * alpha_dev[0] * column sums of A      (the bias gradient)
+ * The token axis may be split into fp32 slabs (deterministic reduce): `slab` must hold *_workspace() bytes.
+ * The grouped form runs up to 4 problems that share M in ONE launch (the four dense layers of an encoder
+ * layer); host arrays of length nprob. */
 size_t mmbert_gemm_tn_workspace(int M, int N, int K, int* splits_out);
 int mmbert_gemm_tn(mmbert_stream_t stream, const void* A, int lda, const void* B, int ldb, float* W, int ldw,
-                   int M, int N, int K, int accumulate, float alpha, const float* alpha_dev, void* slab);
+                   int M, int N, int K, int accumulate, float alpha, const float* alpha_dev, void* slab, float* bias_out);
+size_t mmbert_gemm_tn_grouped_workspace(int nprob, const int* N, const int* K, int M, int* splits_out);
+int mmbert_gemm_tn_grouped(mmbert_stream_t stream, int nprob, const void* const* A, const int* lda, const void* const* B, const int* ldb,
+                           float* const* W, float* const* bias, const int* N, const int* K, int M,
+                           int accumulate, float alpha, const float* alpha_dev, void* slab);
 
 /* out[n] += alpha * alpha_dev[0] * sum_m X[m][n]   (bias gradients) */
 int mmbert_colsum(mmbert_stream_t stream, const void* X, int ldx, int M, int N, float* out, float alpha, const float* alpha_dev);
@@ -61,7 +72,7 @@ int mmbert_ln_fwd(mmbert_stream_t stream, const void* x, int ldx, const int* in_
                   uint32_t dstream, uint32_t dthr, float dscale);
 int mmbert_ln_bwd(mmbert_stream_t stream, const void* dy, int lddy, const int* dy_rows, const void* x, int ldx, const int* x_rows,
                   const float* mean, const float* rstd, const float* gamma, int M, int H,
-                  void* dx, int lddx, const int* dx_rows, void* dx2, int lddx2, float* dgamma, float* dbeta,
+                  void* dx, int lddx, const int* dx_rows, void* dx2, int lddx2, float* dgamma, float* dbeta, float* dbias2,
                   uint32_t post_stream, uint32_t post_thr, float post_scale,
                   uint32_t pre_stream, uint32_t pre_thr, float pre_scale);
 

@@ -16,14 +16,17 @@ P, I, F, U32, SZ, U64 = C.c_void_p, C.c_int, C.c_float, C.c_uint32, C.c_size_t, 
 # name -> (restype, argtypes); must list every symbol of include/mmbert_hip.h
 SIGNATURES = {
     "mmbert_gemm_nt": (I, [P, P, I, P, I, P, I, I, I, I, I, P, P, I, P, I, P, I, F, P, U32, U32, F]),
+    "mmbert_gemm_nt_force": (None, [I]),
     "mmbert_gemm_tn_workspace": (SZ, [I, I, I, P]),
-    "mmbert_gemm_tn": (I, [P, P, I, P, I, P, I, I, I, I, I, F, P, P]),
+    "mmbert_gemm_tn": (I, [P, P, I, P, I, P, I, I, I, I, I, F, P, P, P]),
+    "mmbert_gemm_tn_grouped_workspace": (SZ, [I, P, P, I, P]),
+    "mmbert_gemm_tn_grouped": (I, [P, I, P, P, P, P, P, P, P, P, I, I, F, P, P]),
     "mmbert_colsum": (I, [P, P, I, I, I, P, F, P]),
     "mmbert_rng_stream": (U32, [U64, U32]),
     "mmbert_dropout_thr16": (U32, [F]),
     "mmbert_dropout_mask": (I, [P, P, SZ, U32, U32]),
     "mmbert_ln_fwd": (I, [P, P, I, P, P, I, P, I, I, P, P, F, P, P, U32, U32, F]),
-    "mmbert_ln_bwd": (I, [P, P, I, P, P, I, P, P, P, P, I, I, P, I, P, P, I, P, P, U32, U32, F, U32, U32, F]),
+    "mmbert_ln_bwd": (I, [P, P, I, P, P, I, P, P, P, P, I, I, P, I, P, P, I, P, P, P, U32, U32, F, U32, U32, F]),
     "mmbert_embed_gather": (I, [P, P, P, P, P, P, I, I, I, I, P, I]),
     "mmbert_embed_scatter": (I, [P, P, P, P, I, I, I, I, I, P, P, P]),
     "mmbert_pair_proj_fwd": (I, [P, P, I, I, I, P, P, I, P, I, I]),

@@ -14,6 +14,7 @@
 // NT reads fragments with ds_read_b128 (rows are K-contiguous).  TN needs 8 consecutive m for one
 // column, i.e. a column of the row-major LDS tile: ds_read_b64_tr_b16 (hardware transpose read).
 #include "common.h"
+#include <type_traits>
 
 #define EPI_BIAS 1
 #define EPI_GELU 2       // out = gelu(v); optional aux = v (pre-activation, bf16)
@@ -33,6 +34,45 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     // bijective "each XCD gets a contiguous chunk" remap (blocks b and b+8 share an XCD)
     const int q = nwg >> 3, r = nwg & 7, x = bid & 7, j = bid >> 3;
     return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + j;
+}
+
+// shared epilogue: v[0..3] = alpha-scaled accumulators of C[m][n..n+3]
+template <int EPI>
+__device__ __forceinline__ void epi_store(const GemmNT& p, int m, int n, float (&v)[4]) {
+    if constexpr (EPI & EPI_BIAS) {
+        const float4 b = *(const float4*)(p.bias + n);
+        v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
+    }
+    if constexpr (EPI & EPI_GELU) {
+        if (p.aux) {
+            bf16x4 u = {f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
+            *(bf16x4*)(p.aux + (size_t)m * p.ldaux + n) = u;
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
+    }
+    if constexpr (EPI & EPI_GELU_BWD) {
+        const bf16x4 u = *(const bf16x4*)(p.U + (size_t)m * p.ldu + n);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] *= gelu_erf_grad(bf2f(u[r]));
+    }
+    if constexpr (EPI & EPI_RESID) {
+        if (p.drop_thr16) {
+            bool k[4];
+            mmb_keep4(p.drop_stream, (uint64_t)m * p.N + n, p.drop_thr16, k);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = k[r] ? v[r] * p.drop_scale : 0.f;
+        }
+        const bf16x4 rr = *(const bf16x4*)(p.R + (size_t)m * p.ldr + n);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] += bf2f(rr[r]);
+    }
+    if constexpr (EPI & EPI_OUT_F32) {
+        *(float4*)((float*)p.C + (size_t)m * p.ldc + n) = make_float4(v[0], v[1], v[2], v[3]);
+    } else {
+        bf16x4 o = {f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
+        *(bf16x4*)((bf16_t*)p.C + (size_t)m * p.ldc + n) = o;
+    }
 }
 
 template <int EPI>
@@ -118,40 +158,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const GemmNT p) {
             float v[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r] * alpha;
-            if constexpr (EPI & EPI_BIAS) {
-                const float4 b = *(const float4*)(p.bias + n);
-                v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
-            }
-            if constexpr (EPI & EPI_GELU) {
-                if (p.aux) {
-                    bf16x4 u = {f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
-                    *(bf16x4*)(p.aux + (size_t)m * p.ldaux + n) = u;
-                }
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
-            }
-            if constexpr (EPI & EPI_GELU_BWD) {
-                const bf16x4 u = *(const bf16x4*)(p.U + (size_t)m * p.ldu + n);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] *= gelu_erf_grad(bf2f(u[r]));
-            }
-            if constexpr (EPI & EPI_RESID) {
-                if (p.drop_thr16) {
-                    bool k[4];
-                    mmb_keep4(p.drop_stream, (uint64_t)m * p.N + n, p.drop_thr16, k);
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] = k[r] ? v[r] * p.drop_scale : 0.f;
-                }
-                const bf16x4 rr = *(const bf16x4*)(p.R + (size_t)m * p.ldr + n);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] += bf2f(rr[r]);
-            }
-            if constexpr (EPI & EPI_OUT_F32) {
-                *(float4*)((float*)p.C + (size_t)m * p.ldc + n) = make_float4(v[0], v[1], v[2], v[3]);
-            } else {
-                bf16x4 o = {f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
-                *(bf16x4*)((bf16_t*)p.C + (size_t)m * p.ldc + n) = o;
-            }
+            epi_store<EPI>(p, m, n, v);
         }
     }
 }
@@ -171,172 +178,406 @@ static int launch_nt(hipStream_t s, const GemmNT& p) {
 }
 
 // -------------------------------------------------------------------------------------------------
-// TN: W[N,K] (+)= A[M,N]^T . B[M,K], reduction over the token axis M, optional split over M.
-// LDS tiles are [64 m][128 cols] bf16 (256-B rows), chunk-swizzled by f(row) = ((row&3)|((row>>1)&4))<<1
-// so that the 8 rows a 32-lane half touches in one ds_read_b64_tr_b16 fall on distinct bank groups.
+// NT, large shapes: 256x256 output tile, 512 threads (8 waves as 2(M) x 4(N), 128x64 per wave =
+// 8x4 MFMA tiles, 128 accumulator VGPRs), K consumed in 32-deep stages through a 4-slot LDS ring
+// (4 x 32 KiB = 128 KiB, one workgroup per CU).  Per stage and wave: 4 global_load_lds (16 B),
+// 12 ds_read_b128, 32 MFMAs.  The LDS-DMA of stages s+2..s+4 stays in flight across the (single,
+// raw) barrier of stage s behind a COUNTED s_waitcnt vmcnt(8); fragments of stage s+1 are read into
+// a second register set while the MFMAs of stage s issue.  LDS rows are 64 B (4 chunks of 16 B);
+// chunk' = chunk ^ G[(row>>2)&3], G = {0,2,3,1}, makes every ds_read_b128 lane group hit 16
+// distinct 16-byte slots (the groups mix rows {0-3,12-15} of one chunk with rows {4-11} of chunk^1).
+// Loads past the last stage re-read the last stage (clamped) into a dead slot, so the in-flight
+// count is the same in every iteration and the waits need no tail variants.
 // -------------------------------------------------------------------------------------------------
-struct GemmTN {
-    const bf16_t* A; const bf16_t* B; float* W; float* slab;
-    int M, N, K, lda, ldb, ldw, splits, rows_per_split, accumulate;
-    float alpha; const float* alpha_dev;
+template <int EPI>
+__global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(const GemmNT p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // 4 slots x [A 16K | B 16K]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+    const int tiles_n = (p.N + 255) >> 8, tiles_m = (p.M + 255) >> 8;
+    const int tile = xcd_remap(blockIdx.x, tiles_m * tiles_n);
+    const int m0 = (tile / tiles_n) << 8, n0 = (tile % tiles_n) << 8;
+    const int ns = p.K >> 5;
+    constexpr unsigned GT = 0x78;                                  // G = {0,2,3,1} packed 2 bits each: 0b01111000
+
+    // staging: a wave-instruction writes 16 rows x 64 B; wave w owns rows [32w, 32w+32) of A and of B
+    const int srow = lane >> 2;
+    const int schunk = (lane & 3) ^ ((GT >> (2 * ((srow >> 2) & 3))) & 3);
+    const bf16_t* a_src[2]; const bf16_t* b_src[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int r = wave * 32 + i * 16 + srow;
+        a_src[i] = p.A + (size_t)min(m0 + r, p.M - 1) * p.lda + schunk * 8;
+        b_src[i] = p.B + (size_t)min(n0 + r, p.N - 1) * p.ldb + schunk * 8;
+    }
+    auto stage = [&](int slot, int st) {
+        const int ko = min(st, ns - 1) * 32;
+        char* base = smem + slot * 32768 + wave * 2048;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            __builtin_amdgcn_global_load_lds(GPTR(a_src[i] + ko), LPTR(base + i * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds(GPTR(b_src[i] + ko), LPTR(base + 16384 + i * 1024), 16, 0, 0);
+        }
+    };
+
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int fr = lane & 15, fq = lane >> 4;
+    // lane-constant part of every fragment address: row fr of a 16-row block, swizzled chunk fq
+    const int lane_off = fr * 64 + ((fq ^ ((GT >> (2 * ((fr >> 2) & 3))) & 3)) << 4);
+    const char* a_rd = smem + (wr * 128) * 64 + lane_off;
+    const char* b_rd = smem + 16384 + (wc * 64) * 64 + lane_off;
+    auto load_frags = [&](int slot, bf16x8 (&af)[8], bf16x8 (&bfr)[4]) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bfr[j] = *(const bf16x8*)(b_rd + slot * 32768 + j * 1024);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) af[i] = *(const bf16x8*)(a_rd + slot * 32768 + i * 1024);
+    };
+    auto mma = [&](const bf16x8 (&af)[8], const bf16x8 (&bfr)[4]) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+    };
+
+    bf16x8 a0[8], b0[4], a1[8], b1[4];
+    stage(0, 0); stage(1, 1); stage(2, 2); stage(3, 3);
+    asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    load_frags(0, a0, b0);
+
+#define NT256_STEP(SLOT, CUR_A, CUR_B, NXT_A, NXT_B)                                  \
+    {                                                                                 \
+        /* stage s+1 landed (my loads); my ds_reads of the slot about to be restaged are complete */ \
+        __builtin_amdgcn_s_waitcnt(0x0078);   /* vmcnt(8) lgkmcnt(0): a builtin, so hipcc's own scoreboard sees it */ \
+        __builtin_amdgcn_s_barrier();                      /* ... and everyone's; slot of stage s is free */ \
+        stage(SLOT, s + 4);                                                           \
+        load_frags((SLOT + 1) & 3, NXT_A, NXT_B);                                     \
+        __builtin_amdgcn_s_setprio(1);                                                \
+        mma(CUR_A, CUR_B);                                                            \
+        __builtin_amdgcn_s_setprio(0);                                                \
+        ++s;                                                                          \
+    }
+    int s = 0;
+    while (true) {
+        NT256_STEP(0, a0, b0, a1, b1) if (s >= ns) break;
+        NT256_STEP(1, a1, b1, a0, b0) if (s >= ns) break;
+        NT256_STEP(2, a0, b0, a1, b1) if (s >= ns) break;
+        NT256_STEP(3, a1, b1, a0, b0) if (s >= ns) break;
+    }
+#undef NT256_STEP
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // drain the dummy tail stages before LDS is released
+
+    const float alpha = p.alpha * (p.alpha_dev ? *p.alpha_dev : 1.0f);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int m = m0 + wr * 128 + i * 16 + fr;
+        if (m >= p.M) continue;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n = n0 + wc * 64 + j * 16 + fq * 4;
+            if (n >= p.N) continue;
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r] * alpha;
+            epi_store<EPI>(p, m, n, v);
+        }
+    }
+}
+
+template <int EPI>
+static int launch_nt256(hipStream_t s, const GemmNT& p) {
+    const int tiles = ((p.M + 255) / 256) * ((p.N + 255) / 256);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)gemm_nt256_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(gemm_nt256_kernel<EPI>, dim3(tiles), dim3(512), 131072, s, p);
+    MMB_CHECK_LAUNCH();
+    return 0;
+}
+
+// shape dispatch: the 256^2 pipeline needs >= 4 stages of K and enough rows to fill its tiles
+static int g_nt_force = 0;   // 0 auto, 1 force 128^2, 2 force 256^2 (tests / A-B benchmarking)
+template <int EPI>
+static int dispatch_nt(hipStream_t s, const GemmNT& p) {
+    const bool big = (p.K >= 128) && (p.M >= 512) && (p.N >= 256);
+    if (g_nt_force == 2 || (g_nt_force == 0 && big)) return launch_nt256<EPI>(s, p);
+    return launch_nt<EPI>(s, p);
+}
+
+// -------------------------------------------------------------------------------------------------
+// TN (weight gradients): W_p[N_p,K_p] (+)= alpha * A_p[M,N_p]^T . B_p[M,K_p]  for up to 4 problems that
+// share the token axis M (the four dense layers of one encoder layer go out as ONE launch), optional
+// split over M into fp32 slabs reduced deterministically by tn_reduce_kernel, and optionally
+// bias_p[N_p] += alpha * colsum(A_p): the bias gradient rides on the MFMA with an all-ones A operand.
+//
+// Workgroup = 256 threads (4 waves as 2(k) x 2(n)), output tile 256(n) x 128(k); a wave owns
+// 64(k) x 128(n) = 4 x 8 MFMA tiles (the v1 64x64 wave tile was LDS-read bound: 1 transposed read per
+// MFMA; this shape needs 0.75).  The token axis is consumed in 32-row stages through a 3-slot LDS ring
+// (3 x 24 KiB, 2 workgroups per CU): stages s+1, s+2 are in flight behind a counted vmcnt(6) while
+// stage s is read with ds_read_b64_tr_b16 (both operands are needed "m-major", i.e. transposed) and
+// multiplied.  LDS rows are 512 B (A) / 256 B (B); 16-byte chunks are XOR-swizzled by
+// ((row&3)|((row>>1)&4))<<1 on the source address and on the read, so the 8 rows a 32-lane half
+// touches in one transposed read fall on 8 distinct 32-byte bank groups.
+// -------------------------------------------------------------------------------------------------
+struct TNProb { const bf16_t* A; const bf16_t* B; float* W; float* bias; int N, K, lda, ldb, tiles_k, tile0; long long slab_off; };
+struct GemmTNG {
+    TNProb pr[4];
+    float* slab; const float* alpha_dev;
+    long long slab_stride;
+    int nprob, total_tiles, M, splits, rows_per_split, accumulate;
+    float alpha;
 };
 
 __device__ __forceinline__ int tn_swz(int row) { return ((row & 3) | ((row >> 1) & 4)) << 1; }
 
-__global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const GemmTN p) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];   // [2][A 16K | B 16K]
+// ds_read_b64_tr_b16 through inline asm: behind the builtin hipcc cannot prove that the read does not
+// alias the LDS-DMA still in flight and drains vmcnt(0) in front of every stage's reads.  The asm form is
+// invisible to its scoreboard: the caller waits lgkmcnt(0) itself and fences with sched_barrier(0).
+template <int OFF>
+__device__ __forceinline__ void tr_read(s16x4& dst, unsigned lds_addr) {
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(lds_addr), "i"(OFF));
+}
+
+__global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const GemmTNG g) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // 3 slots x [A 32x256 (16 KiB) | B 32x128 (8 KiB)]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wk = wave >> 1, wn = wave & 1;
-    const int tiles_k = (p.K + 127) >> 7, tiles_n = (p.N + 127) >> 7;
-    const int tile = xcd_remap(blockIdx.x, tiles_k * tiles_n);
-    const int n0 = (tile / tiles_k) << 7, k0 = (tile % tiles_k) << 7;
+    int t = xcd_remap(blockIdx.x, g.total_tiles);
+    int pi = 0;
+#pragma unroll
+    for (int q = 1; q < 4; ++q) if (q < g.nprob && t >= g.pr[q].tile0) pi = q;
+    const bf16_t* Ap = g.pr[0].A; const bf16_t* Bp = g.pr[0].B; float* Wp = g.pr[0].W; float* biasp = g.pr[0].bias;
+    int N = g.pr[0].N, K = g.pr[0].K, lda = g.pr[0].lda, ldb = g.pr[0].ldb, tiles_k = g.pr[0].tiles_k, tile0 = g.pr[0].tile0;
+    long long slab_off = g.pr[0].slab_off;
+#pragma unroll
+    for (int q = 1; q < 4; ++q)
+        if (pi == q) { Ap = g.pr[q].A; Bp = g.pr[q].B; Wp = g.pr[q].W; biasp = g.pr[q].bias; N = g.pr[q].N; K = g.pr[q].K; lda = g.pr[q].lda;
+                       ldb = g.pr[q].ldb; tiles_k = g.pr[q].tiles_k; tile0 = g.pr[q].tile0; slab_off = g.pr[q].slab_off; }
+    t -= tile0;
+    const int n0 = (t / tiles_k) << 8, k0 = (t % tiles_k) << 7;
     const int split = blockIdx.y;
-    const int mbeg = split * p.rows_per_split;
-    const int mend = min(p.M, mbeg + p.rows_per_split);
-    const int nt = (mend - mbeg + 63) >> 6;
+    const int mbeg = split * g.rows_per_split;
+    const int mend = min(g.M, mbeg + g.rows_per_split);
+    const int ns = (mend - mbeg + 31) >> 5;                        // may be <= 0 for a trailing empty split
+    const bool do_bias = (biasp != nullptr) && (k0 == 0) && (wk == 0);
 
-    // staging: a wave-instruction covers 4 rows x 256 B; wave w issues row-groups 4w..4w+3 (16 rows)
-    const int srow = lane >> 4, sc = lane & 15;
-    auto stage = [&](int buf, int mt) {
-        char* base = smem + buf * 32768 + wave * 4096;
+    // ---- staging (LDS-DMA, lane-linear destination, swizzle on the source chunk) ----
+    // A stage tile: 32 rows x 512 B = 16 wave-instructions (2 rows each); wave w issues 4w..4w+3
+    // B stage tile: 32 rows x 256 B =  8 wave-instructions (4 rows each); wave w issues 2w, 2w+1
+    int a_row[4], a_col[4], b_row[2], b_col[2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        a_row[i] = (wave * 4 + i) * 2 + (lane >> 5);
+        a_col[i] = min(n0 + (((lane & 31) ^ tn_swz(a_row[i])) << 3), N - 8);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        b_row[i] = (wave * 2 + i) * 4 + (lane >> 4);
+        b_col[i] = min(k0 + (((lane & 15) ^ tn_swz(b_row[i])) << 3), K - 8);
+    }
+    auto stage = [&](int slot, int st) {
+        const int mb = mbeg + min(st, max(ns - 1, 0)) * 32;
+        char* base = smem + slot * 24576 + wave * 4096;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int r = (wave * 4 + i) * 4 + srow;            // row inside the 64-row tile
-            const int m = mbeg + mt * 64 + r;
-            const int mc = min(m, p.M - 1);                      // clamped; rows >= mend are zeroed by the row mask below
-            const int c = sc ^ tn_swz(r);
-            const int ca = min(n0 + c * 8, p.N - 8), cb = min(k0 + c * 8, p.K - 8);
-            __builtin_amdgcn_global_load_lds(GPTR(p.A + (size_t)mc * p.lda + ca), LPTR(base + i * 1024), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds(GPTR(p.B + (size_t)mc * p.ldb + cb), LPTR(base + 16384 + i * 1024), 16, 0, 0);
+            const int m = min(mb + a_row[i], g.M - 1);
+            __builtin_amdgcn_global_load_lds(GPTR(Ap + (size_t)m * lda + a_col[i]), LPTR(base + i * 1024), 16, 0, 0);
+        }
+        char* bb = smem + slot * 24576 + 16384 + wave * 2048;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int m = min(mb + b_row[i], g.M - 1);
+            __builtin_amdgcn_global_load_lds(GPTR(Bp + (size_t)m * ldb + b_col[i]), LPTR(bb + i * 1024), 16, 0, 0);
         }
     };
 
-    f32x4 acc[4][4];
+    f32x4 acc[4][8], accb[8];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < 8; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < 8; ++j) accb[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    const int g = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
-    auto compute = [&](int buf, int mt) {
-        const char* As = smem + buf * 32768;
-        const char* Bs = As + 16384;
-        const int mrem = (mend - mbeg) - mt * 64;                // valid rows in this tile (>0)
+    // ---- transposed-read addresses: lane (g4 = lane>>4, q = (lane>>2)&3, pp = lane&3) supplies row 8*g4+q (+4), 4 columns at 4*pp ----
+    const int g4 = lane >> 4, r0 = 8 * g4 + ((lane >> 2) & 3), pp = lane & 3;
+    const unsigned lds0 = (unsigned)(uintptr_t)LPTR(smem);
+    unsigned offA[8], offB[4];
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-            // lane supplies the address of row (kk*32 + 8g + q [+4]), columns col0 + 4*pp
-            const int r0 = kk * 32 + 8 * g + q, r1 = r0 + 4;
-            s16x4 a0[4], a1[4], b0[4], b1[4];
+    for (int j = 0; j < 8; ++j) {
+        const int col = wn * 128 + j * 16 + 4 * pp;
+        offA[j] = lds0 + r0 * 512 + ((((col >> 3) ^ tn_swz(r0)) << 4) | ((col & 4) << 1));
+    }
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int colA = wn * 64 + i * 16 + 4 * pp;       // n_out columns of the A (=dY) tile
-                const int colB = wk * 64 + i * 16 + 4 * pp;       // k_out columns of the B (=X) tile
-                const int offA0 = r0 * 256 + ((((colA >> 3) ^ tn_swz(r0)) << 4) | ((colA & 4) << 1));
-                const int offA1 = r1 * 256 + ((((colA >> 3) ^ tn_swz(r1)) << 4) | ((colA & 4) << 1));
-                const int offB0 = r0 * 256 + ((((colB >> 3) ^ tn_swz(r0)) << 4) | ((colB & 4) << 1));
-                const int offB1 = r1 * 256 + ((((colB >> 3) ^ tn_swz(r1)) << 4) | ((colB & 4) << 1));
-                a0[i] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(As + offA0));
-                a1[i] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(As + offA1));
-                b0[i] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(Bs + offB0));
-                b1[i] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(Bs + offB1));
-            }
-            // zero the m rows past the end of this split (lane holds m = kk*32 + 8g + j, j = 0..7)
-            const int mb = kk * 32 + 8 * g;
-            if (mb + 8 > mrem) {
+    for (int i = 0; i < 4; ++i) {
+        const int col = wk * 64 + i * 16 + 4 * pp;
+        offB[i] = lds0 + 16384 + r0 * 256 + ((((col >> 3) ^ tn_swz(r0)) << 4) | ((col & 4) << 1));
+    }
+    typedef __attribute__((ext_vector_type(8))) short s16x8;
+    const s16x8 ones_s = {0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80};   // bf16 1.0
+    const bf16x8 ones = __builtin_bit_cast(bf16x8, ones_s);
+
+    auto compute = [&](auto slot_c, int st) {
+        constexpr int SB = decltype(slot_c)::value * 24576;
+        s16x4 ylo[8], yhi[8], xlo[4], xhi[4];
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < 4; ++i) { tr_read<SB>(xlo[i], offB[i]); tr_read<SB + 4 * 256>(xhi[i], offB[i]); }   // rows r0 and r0+4 (same swizzle: bit 2 unused)
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        if (mb + j >= mrem) { a0[i][j] = 0; b0[i][j] = 0; }
-                        if (mb + 4 + j >= mrem) { a1[i][j] = 0; b1[i][j] = 0; }
-                    }
-            }
+        for (int j = 0; j < 8; ++j) { tr_read<SB>(ylo[j], offA[j]); tr_read<SB + 4 * 512>(yhi[j], offA[j]); }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        bf16x8 ay[8], bx[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                typedef __attribute__((ext_vector_type(8))) short s16x8;
-                const s16x8 bx = {b0[i][0], b0[i][1], b0[i][2], b0[i][3], b1[i][0], b1[i][1], b1[i][2], b1[i][3]};
+        for (int i = 0; i < 4; ++i) {
+            const s16x8 v = {xlo[i][0], xlo[i][1], xlo[i][2], xlo[i][3], xhi[i][0], xhi[i][1], xhi[i][2], xhi[i][3]};
+            bx[i] = __builtin_bit_cast(bf16x8, v);
+        }
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const s16x8 ay = {a0[j][0], a0[j][1], a0[j][2], a0[j][3], a1[j][0], a1[j][1], a1[j][2], a1[j][3]};
-                    // D[row <-> k_out (X^T as the A operand)][col <-> n_out (dY as the B operand)]
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, bx), __builtin_bit_cast(bf16x8, ay), acc[i][j], 0, 0, 0);
+        for (int j = 0; j < 8; ++j) {
+            const s16x8 v = {ylo[j][0], ylo[j][1], ylo[j][2], ylo[j][3], yhi[j][0], yhi[j][1], yhi[j][2], yhi[j][3]};
+            ay[j] = __builtin_bit_cast(bf16x8, v);
+        }
+        const int mrem = (mend - mbeg) - st * 32;                  // valid rows in this stage
+        if (mrem < 32) {                                           // wave-uniform: only the last stage of a split
+            const int mb8 = 8 * g4;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                if (mb8 + e >= mrem) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) ay[j][e] = (bf16_t)0.0f;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) bx[i][e] = (bf16_t)0.0f;
                 }
             }
         }
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 8; ++j)     // D[row <-> k_out (X^T as the A operand)][col <-> n_out (dY as the B operand)]
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bx[i], ay[j], acc[i][j], 0, 0, 0);
+        if (do_bias) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) accb[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, ay[j], accb[j], 0, 0, 0);
+        }
+        __builtin_amdgcn_s_setprio(0);
     };
 
-    if (nt > 0) {
-        stage(0, 0);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        int cur = 0;
-        for (int mt = 0; mt < nt - 1; ++mt) {
-            stage(cur ^ 1, mt + 1);
-            compute(cur, mt);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            cur ^= 1;
+    if (ns > 0) {
+        stage(0, 0); stage(1, 1);
+#define TN_STEP(SLOT)                                                                       \
+        {                                                                                   \
+            __builtin_amdgcn_s_waitcnt(0x0076);   /* vmcnt(6) lgkmcnt(0): stage s landed, my reads of stage s-1 done */ \
+            __builtin_amdgcn_s_barrier();                                                   \
+            stage((SLOT + 2) % 3, s + 2);                                                   \
+            compute(std::integral_constant<int, SLOT>{}, s);                                \
+            ++s;                                                                            \
         }
-        compute(cur, nt - 1);
+        int s = 0;
+        while (true) {
+            TN_STEP(0) if (s >= ns) break;
+            TN_STEP(1) if (s >= ns) break;
+            TN_STEP(2) if (s >= ns) break;
+        }
+#undef TN_STEP
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
 
-    const float alpha = p.alpha * (p.alpha_dev ? *p.alpha_dev : 1.0f);
+    const float alpha = g.alpha * (g.alpha_dev ? *g.alpha_dev : 1.0f);
     const int fr = lane & 15, fq = lane >> 4;
-    float* out = p.splits > 1 ? p.slab + (size_t)split * p.N * p.ldw : p.W;
-    const bool accum = (p.splits == 1) && p.accumulate;
+    float* out = g.splits > 1 ? g.slab + (size_t)split * g.slab_stride + slab_off : Wp;
+    const bool accum = (g.splits == 1) && g.accumulate;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int k = k0 + wk * 64 + i * 16 + fq * 4;
-        if (k >= p.K) continue;
+        if (k >= K) continue;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int n = n0 + wn * 64 + j * 16 + fr;
-            if (n >= p.N) continue;
-            float* dst = out + (size_t)n * p.ldw + k;
+        for (int j = 0; j < 8; ++j) {
+            const int n = n0 + wn * 128 + j * 16 + fr;
+            if (n >= N) continue;
+            float* dst = out + (size_t)n * K + k;
             float4 v = make_float4(acc[i][j][0] * alpha, acc[i][j][1] * alpha, acc[i][j][2] * alpha, acc[i][j][3] * alpha);
             if (accum) { const float4 o = *(const float4*)dst; v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
             *(float4*)dst = v;
         }
     }
+    if (do_bias && fq == 0) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int n = n0 + wn * 128 + j * 16 + fr;
+            if (n < N) atomicAdd(biasp + n, accb[j][0] * alpha);
+        }
+    }
 }
 
-// W[n][k] (+)= sum_s slab[s][n][k]
-__global__ void tn_reduce_kernel(float* __restrict__ W, const float* __restrict__ slab, int N, int K4, int ldw4, int splits, int accumulate) {
-    const size_t total = (size_t)N * K4;
-    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        const int n = (int)(i / K4), k4 = (int)(i % K4);
-        const size_t off = (size_t)n * ldw4 + k4;
-        float4 v = accumulate ? ((const float4*)W)[off] : make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int s = 0; s < splits; ++s) {
-            const float4 t = ((const float4*)slab)[(size_t)s * total + i];
+// W[i] (+)= sum_s slab[s][i] over the concatenated outputs of all problems of a launch
+struct TNReduce { float* W[4]; long long off[5]; int nprob, splits, accumulate; long long slab_stride; };
+__global__ void tn_reduce_kernel(const TNReduce r, const float* __restrict__ slab) {
+    const long long total4 = r.off[r.nprob] >> 2;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total4; i += (long long)gridDim.x * blockDim.x) {
+        const long long e = i << 2;
+        int pi = 0;
+#pragma unroll
+        for (int q = 1; q < 4; ++q) if (q < r.nprob && e >= r.off[q]) pi = q;
+        float* W = r.W[0]; long long o = r.off[0];
+#pragma unroll
+        for (int q = 1; q < 4; ++q) if (pi == q) { W = r.W[q]; o = r.off[q]; }
+        float4* dst = (float4*)(W + (e - o));
+        float4 v = r.accumulate ? *dst : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int s = 0; s < r.splits; ++s) {
+            const float4 t = *(const float4*)(slab + (size_t)s * r.slab_stride + e);
             v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
         }
-        ((float4*)W)[off] = v;
+        *dst = v;
     }
 }
 
-// column sums: out[n] += alpha * sum_m X[m][n]   (bias gradients); grid (N/256 x row-splits)
-__global__ void colsum_kernel(const bf16_t* __restrict__ X, int M, int N, int ldx, float* __restrict__ out, float alpha, const float* alpha_dev, int rows_per_block) {
-    const int n = (blockIdx.x * 64 + (threadIdx.x & 63)) * 4;
-    const int sub = threadIdx.x >> 6;                                  // 4 waves take interleaved rows
+// column sums: out[n] += alpha * sum_m X[m][n]   (bias gradients).  grid (ceil(N/512), row chunks);
+// a lane owns 8 columns (16-byte loads), the 4 waves take interleaved rows, one atomic per column per workgroup.
+__global__ __launch_bounds__(256) void colsum_kernel(const bf16_t* __restrict__ X, int M, int N, int ldx, float* __restrict__ out, float alpha, const float* alpha_dev, int rows_per_block) {
+    const int lane = threadIdx.x & 63, sub = threadIdx.x >> 6;
+    const int n = (blockIdx.x * 64 + lane) * 8;
     const int mbeg = blockIdx.y * rows_per_block, mend = min(M, mbeg + rows_per_block);
-    float s[4] = {0.f, 0.f, 0.f, 0.f};
+    float s[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) s[r] = 0.f;
     if (n < N) {
-        for (int m = mbeg + sub; m < mend; m += 4) {
-            const bf16x4 v = *(const bf16x4*)(X + (size_t)m * ldx + n);
-            s[0] += bf2f(v[0]); s[1] += bf2f(v[1]); s[2] += bf2f(v[2]); s[3] += bf2f(v[3]);
+        int m = mbeg + sub;
+        for (; m + 12 < mend; m += 16) {                              // 4 independent 16-byte loads in flight
+            bf16x8 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = *(const bf16x8*)(X + (size_t)(m + 4 * u) * ldx + n);
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int r = 0; r < 8; ++r) s[r] += bf2f(v[u][r]);
+        }
+        for (; m < mend; m += 4) {
+            const bf16x8 v = *(const bf16x8*)(X + (size_t)m * ldx + n);
+#pragma unroll
+            for (int r = 0; r < 8; ++r) s[r] += bf2f(v[r]);
         }
     }
-    __shared__ float red[4][64][4];
-    for (int r = 0; r < 4; ++r) red[sub][threadIdx.x & 63][r] = s[r];
+    __shared__ float red[4][64][9];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) red[sub][lane][r] = s[r];
     __syncthreads();
     if (sub == 0 && n < N) {
         const float a = alpha * (alpha_dev ? *alpha_dev : 1.0f);
-        for (int r = 0; r < 4; ++r) {
-            const float t = red[0][threadIdx.x][r] + red[1][threadIdx.x][r] + red[2][threadIdx.x][r] + red[3][threadIdx.x][r];
-            atomicAdd(out + n + r, t * a);
-        }
+#pragma unroll
+        for (int r = 0; r < 8; ++r)
+            atomicAdd(out + n + r, (red[0][lane][r] + red[1][lane][r] + red[2][lane][r] + red[3][lane][r]) * a);
     }
 }
 
@@ -354,67 +595,105 @@ int mmbert_gemm_nt(hipStream_t stream, const void* A, int lda, const void* B, in
     p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.ldr = ldr; p.ldaux = ldaux; p.ldu = ldu;
     p.alpha = alpha; p.drop_stream = drop_stream; p.drop_thr16 = drop_thr16; p.drop_scale = drop_scale;
     switch (epi) {
-        case 0: return launch_nt<0>(stream, p);
-        case EPI_BIAS: return launch_nt<EPI_BIAS>(stream, p);
-        case EPI_BIAS | EPI_GELU: return launch_nt<EPI_BIAS | EPI_GELU>(stream, p);
-        case EPI_BIAS | EPI_RESID: return launch_nt<EPI_BIAS | EPI_RESID>(stream, p);
-        case EPI_RESID: return launch_nt<EPI_RESID>(stream, p);
-        case EPI_GELU_BWD: return launch_nt<EPI_GELU_BWD>(stream, p);
-        case EPI_OUT_F32: return launch_nt<EPI_OUT_F32>(stream, p);
-        case EPI_BIAS | EPI_OUT_F32: return launch_nt<EPI_BIAS | EPI_OUT_F32>(stream, p);
+        case 0: return dispatch_nt<0>(stream, p);
+        case EPI_BIAS: return dispatch_nt<EPI_BIAS>(stream, p);
+        case EPI_BIAS | EPI_GELU: return dispatch_nt<EPI_BIAS | EPI_GELU>(stream, p);
+        case EPI_BIAS | EPI_RESID: return dispatch_nt<EPI_BIAS | EPI_RESID>(stream, p);
+        case EPI_RESID: return dispatch_nt<EPI_RESID>(stream, p);
+        case EPI_GELU_BWD: return dispatch_nt<EPI_GELU_BWD>(stream, p);
+        case EPI_OUT_F32: return dispatch_nt<EPI_OUT_F32>(stream, p);
+        case EPI_BIAS | EPI_OUT_F32: return dispatch_nt<EPI_BIAS | EPI_OUT_F32>(stream, p);
         default: return -2;
     }
 }
 
-// returns the slab size in bytes the caller must provide for (M,N,K); 0 when no split is used
-size_t mmbert_gemm_tn_workspace(int M, int N, int K, int* splits_out) {
-    const int tiles = ((N + 127) / 128) * ((K + 127) / 128);
+// test / benchmarking hook: 0 = automatic shape dispatch, 1 = always the 128^2 kernel, 2 = always the 256^2 kernel
+void mmbert_gemm_nt_force(int mode) { g_nt_force = mode; }
+
+static int tn_plan(int nprob, const int* N, const int* K, int M, int* splits_out, int* tiles_out) {
+    int tiles = 0;
+    for (int i = 0; i < nprob; ++i) tiles += ((N[i] + 255) / 256) * ((K[i] + 127) / 128);
     int splits = 1;
     if (tiles < 512) splits = (512 + tiles - 1) / tiles;
-    const int max_splits = (M + 255) / 256;
+    const int max_splits = (M + 511) / 512;
     if (splits > max_splits) splits = max_splits;
     if (splits < 1) splits = 1;
-    if (splits_out) *splits_out = splits;
-    return splits > 1 ? (size_t)splits * N * K * sizeof(float) : 0;
+    *splits_out = splits; *tiles_out = tiles;
+    return 0;
 }
 
-int mmbert_gemm_tn(hipStream_t stream, const void* A, int lda, const void* B, int ldb, float* W, int ldw,
-                   int M, int N, int K, int accumulate, float alpha, const float* alpha_dev, void* slab) {
-    if (M <= 0 || N <= 0 || K <= 0) return 0;
-    if ((N & 7) || (K & 7) || (lda & 7) || (ldb & 7) || (ldw & 3) || N < 8 || K < 8) return -1;
-    int splits;
-    const size_t need = mmbert_gemm_tn_workspace(M, N, K, &splits);
-    if (need && !slab) return -3;
-    GemmTN p;
-    p.A = (const bf16_t*)A; p.B = (const bf16_t*)B; p.W = W; p.slab = (float*)slab;
-    p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.splits = splits;
-    p.ldw = splits > 1 ? K : ldw;
-    p.rows_per_split = (((M + splits - 1) / splits) + 63) / 64 * 64;
-    p.accumulate = accumulate; p.alpha = alpha; p.alpha_dev = alpha_dev;
+// slab bytes the caller must provide for a grouped launch (0 when the token axis is not split)
+size_t mmbert_gemm_tn_grouped_workspace(int nprob, const int* N, const int* K, int M, int* splits_out) {
+    int splits, tiles;
+    tn_plan(nprob, N, K, M, &splits, &tiles);
+    if (splits_out) *splits_out = splits;
+    if (splits == 1) return 0;
+    size_t elems = 0;
+    for (int i = 0; i < nprob; ++i) elems += (size_t)N[i] * K[i];
+    return (size_t)splits * elems * sizeof(float);
+}
+
+size_t mmbert_gemm_tn_workspace(int M, int N, int K, int* splits_out) {
+    return mmbert_gemm_tn_grouped_workspace(1, &N, &K, M, splits_out);
+}
+
+// up to 4 problems sharing M:  W_i[N_i,K_i] (+)= alpha * A_i^T . B_i ;  bias_i[N_i] += alpha * colsum(A_i) (bias_i may be null)
+int mmbert_gemm_tn_grouped(hipStream_t stream, int nprob, const void* const* A, const int* lda, const void* const* B, const int* ldb,
+                           float* const* W, float* const* bias, const int* N, const int* K, int M,
+                           int accumulate, float alpha, const float* alpha_dev, void* slab) {
+    if (nprob <= 0 || M <= 0) return 0;
+    if (nprob > 4) return -1;
+    GemmTNG g;
+    int splits, tiles;
+    tn_plan(nprob, N, K, M, &splits, &tiles);
+    long long off = 0;
+    int tile0 = 0;
+    TNReduce r;
+    for (int i = 0; i < nprob; ++i) {
+        if ((N[i] & 7) || (K[i] & 7) || (lda[i] & 7) || (ldb[i] & 7) || N[i] < 8 || K[i] < 8) return -1;
+        TNProb& q = g.pr[i];
+        q.A = (const bf16_t*)A[i]; q.B = (const bf16_t*)B[i]; q.W = W[i]; q.bias = bias ? bias[i] : nullptr;
+        q.N = N[i]; q.K = K[i]; q.lda = lda[i]; q.ldb = ldb[i];
+        q.tiles_k = (K[i] + 127) / 128; q.tile0 = tile0; q.slab_off = off;
+        r.W[i] = W[i]; r.off[i] = off;
+        tile0 += ((N[i] + 255) / 256) * q.tiles_k;
+        off += (long long)N[i] * K[i];
+    }
+    for (int i = nprob; i < 4; ++i) { g.pr[i] = g.pr[0]; g.pr[i].tile0 = 0x7fffffff; r.W[i] = nullptr; }
+    for (int i = nprob; i < 5; ++i) r.off[i] = off;
+    if (splits > 1 && !slab) return -3;
+    g.slab = (float*)slab; g.alpha_dev = alpha_dev; g.slab_stride = off; g.nprob = nprob; g.total_tiles = tiles; g.M = M;
+    g.splits = splits; g.rows_per_split = (((M + splits - 1) / splits) + 31) / 32 * 32; g.accumulate = accumulate; g.alpha = alpha;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)gemm_tn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+        hipError_t e = hipFuncSetAttribute((const void*)gemm_tn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 73728);
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
-    const int tiles = ((N + 127) / 128) * ((K + 127) / 128);
-    hipLaunchKernelGGL(gemm_tn_kernel, dim3(tiles, splits), dim3(256), 65536, stream, p);
+    hipLaunchKernelGGL(gemm_tn_kernel, dim3(tiles, splits), dim3(256), 73728, stream, g);
     MMB_CHECK_LAUNCH();
     if (splits > 1) {
-        const size_t total = (size_t)N * (K / 4);
-        const int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
-        hipLaunchKernelGGL(tn_reduce_kernel, dim3(blocks), dim3(256), 0, stream, W, (const float*)slab, N, K / 4, ldw / 4, splits, accumulate);
+        r.nprob = nprob; r.splits = splits; r.accumulate = accumulate; r.slab_stride = off;
+        const long long total4 = off / 4;
+        const int blocks = (int)((total4 + 255) / 256 < 4096 ? (total4 + 255) / 256 : 4096);
+        hipLaunchKernelGGL(tn_reduce_kernel, dim3(blocks), dim3(256), 0, stream, r, (const float*)slab);
         MMB_CHECK_LAUNCH();
     }
     return 0;
 }
 
+int mmbert_gemm_tn(hipStream_t stream, const void* A, int lda, const void* B, int ldb, float* W, int ldw,
+                   int M, int N, int K, int accumulate, float alpha, const float* alpha_dev, void* slab, float* bias_out) {
+    if (ldw != K) return -1;                 // weight-gradient tensors are contiguous
+    return mmbert_gemm_tn_grouped(stream, 1, &A, &lda, &B, &ldb, &W, &bias_out, &N, &K, M, accumulate, alpha, alpha_dev, slab);
+}
+
 int mmbert_colsum(hipStream_t stream, const void* X, int ldx, int M, int N, float* out, float alpha, const float* alpha_dev) {
     if (M <= 0 || N <= 0) return 0;
-    if ((N & 3) || (ldx & 3)) return -1;
-    const int gx = (N / 4 + 63) / 64;
-    int gy = (1024 + gx - 1) / gx;
-    int rows = (M + gy - 1) / gy; if (rows < 16) rows = 16;
+    if ((N & 7) || (ldx & 7)) return -1;
+    const int gx = (N / 8 + 63) / 64;
+    int gy = (2048 + gx - 1) / gx;
+    int rows = (M + gy - 1) / gy; if (rows < 32) rows = 32;
     gy = (M + rows - 1) / rows;
     hipLaunchKernelGGL(colsum_kernel, dim3(gx, gy), dim3(256), 0, stream, (const bf16_t*)X, M, N, ldx, out, alpha, alpha_dev, rows);
     MMB_CHECK_LAUNCH();

@@ -84,16 +84,16 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
                                                      const float* __restrict__ gamma, int M, int H,
                                                      bf16_t* __restrict__ dx, int lddx, const int* __restrict__ dx_rows,
                                                      bf16_t* __restrict__ dx2, int lddx2,
-                                                     float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                     float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ dbias2,
                                                      uint32_t post_stream, uint32_t post_thr, float post_scale,
                                                      uint32_t pre_stream, uint32_t pre_thr, float pre_scale) {
     __shared__ float red[2][4][1024];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    float ag[LN_MAXV][4], ab[LN_MAXV][4];
+    float ag[LN_MAXV][4], ab[LN_MAXV][4], ad[LN_MAXV][4];
 #pragma unroll
     for (int c = 0; c < LN_MAXV; ++c)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { ag[c][r] = 0.f; ab[c][r] = 0.f; }
+        for (int r = 0; r < 4; ++r) { ag[c][r] = 0.f; ab[c][r] = 0.f; ad[c][r] = 0.f; }
     for (int i = blockIdx.x * 4 + w; i < M; i += gridDim.x * 4) {
         const bf16_t* dyr = dy + (size_t)(dy_rows ? dy_rows[i] : i) * lddy;
         const bf16_t* xr = x + (size_t)(x_rows ? x_rows[i] : i) * ldx;
@@ -146,6 +146,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
                     bf16x4 o2 = {f2bf(o[0]), f2bf(o[1]), f2bf(o[2]), f2bf(o[3])};
                     *(bf16x4*)(dx2 + (size_t)i * lddx2 + col) = o2;
                 }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) ad[c][r] += o[r];       // column sums of the dense layer's output gradient = its bias gradient
             }
         }
     }
@@ -163,6 +165,16 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
         const float sb = red[1][0][col] + red[1][1][col] + red[1][2][col] + red[1][3][col];
         if (dgamma) atomicAdd(dgamma + col, sg);
         if (dbeta) atomicAdd(dbeta + col, sb);
+    }
+    if (dbias2) {
+        __syncthreads();
+#pragma unroll
+        for (int c = 0; c < LN_MAXV; ++c)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) red[0][w][c * 256 + lane * 4 + r] = ad[c][r];
+        __syncthreads();
+        for (int col = threadIdx.x; col < H; col += 256)
+            atomicAdd(dbias2 + col, red[0][0][col] + red[0][1][col] + red[0][2][col] + red[0][3][col]);
     }
 }
 
@@ -274,6 +286,7 @@ __global__ __launch_bounds__(256) void pair_proj_fwd_kernel(const float* __restr
 
 // backward: dpre = dJ * (J > 0); dW[h][k] += sum_rows dpre[row][h]*feat[row][k]; db[h] += sum dpre
 // grid: (H/64, row-chunks); each workgroup owns 64 h-columns x a chunk of rows.
+template <int NJ>      // NJ*4 >= D: 12 (D<=48), 24 (D<=96), 96 (D<=384)
 __global__ __launch_bounds__(256) void pair_proj_bwd_kernel(const float* __restrict__ feat, int n_rows, int P, int D,
                                                             const bf16_t* __restrict__ J, const bf16_t* __restrict__ dJ, int ld, int T,
                                                             float* __restrict__ dW, float* __restrict__ db, int H, int rows_per_block) {
@@ -283,9 +296,9 @@ __global__ __launch_bounds__(256) void pair_proj_bwd_kernel(const float* __restr
     const int beg = blockIdx.y * rows_per_block, end = min(n_rows, beg + rows_per_block);
     // thread t owns h = h0 + (t & 63) and k = (t >> 6) + 4*j
     const int hl = threadIdx.x & 63, kq = threadIdx.x >> 6;
-    float acc[96];                            // supports D <= 384
+    float acc[NJ];
 #pragma unroll
-    for (int j = 0; j < 96; ++j) acc[j] = 0.f;
+    for (int j = 0; j < NJ; ++j) acc[j] = 0.f;
     float accb = 0.f;
     for (int r0 = beg; r0 < end; r0 += 32) {
         __syncthreads();
@@ -307,7 +320,7 @@ __global__ __launch_bounds__(256) void pair_proj_bwd_kernel(const float* __restr
             const float dv = sd[r * 64 + hl];
             if (kq == 0) accb += dv;
 #pragma unroll
-            for (int j = 0; j < 96; ++j) {
+            for (int j = 0; j < NJ; ++j) {
                 const int k = kq + 4 * j;
                 if (k < D) acc[j] += dv * sf[r * D + k];
             }
@@ -316,7 +329,7 @@ __global__ __launch_bounds__(256) void pair_proj_bwd_kernel(const float* __restr
     const int h = h0 + hl;
     if (h < H) {
 #pragma unroll
-        for (int j = 0; j < 96; ++j) {
+        for (int j = 0; j < NJ; ++j) {
             const int k = kq + 4 * j;
             if (k < D) atomicAdd(dW + (size_t)h * D + k, acc[j]);
         }
@@ -563,13 +576,13 @@ int mmbert_ln_fwd(hipStream_t stream, const void* x, int ldx, const int* in_rows
 
 int mmbert_ln_bwd(hipStream_t stream, const void* dy, int lddy, const int* dy_rows, const void* x, int ldx, const int* x_rows,
                   const float* mean, const float* rstd, const float* gamma, int M, int H,
-                  void* dx, int lddx, const int* dx_rows, void* dx2, int lddx2, float* dgamma, float* dbeta,
+                  void* dx, int lddx, const int* dx_rows, void* dx2, int lddx2, float* dgamma, float* dbeta, float* dbias2,
                   uint32_t post_stream, uint32_t post_thr, float post_scale,
                   uint32_t pre_stream, uint32_t pre_thr, float pre_scale) {
     if (M <= 0) return 0;
     if (H > LN_MAXV * 256 || (H & 3) || (ldx & 3) || (lddy & 3) || (lddx & 3) || (lddx2 & 3)) return -1;
     hipLaunchKernelGGL(ln_bwd_kernel, dim3(grid_for(M, 32, 512)), dim3(256), 0, stream, (const bf16_t*)dy, lddy, dy_rows, (const bf16_t*)x, ldx, x_rows,
-                       mean, rstd, gamma, M, H, (bf16_t*)dx, lddx, dx_rows, (bf16_t*)dx2, lddx2, dgamma, dbeta,
+                       mean, rstd, gamma, M, H, (bf16_t*)dx, lddx, dx_rows, (bf16_t*)dx2, lddx2, dgamma, dbeta, dbias2,
                        post_stream, post_thr, post_scale, pre_stream, pre_thr, pre_scale);
     MMB_CHECK_LAUNCH();
     return 0;
@@ -613,8 +626,13 @@ int mmbert_pair_proj_bwd(hipStream_t stream, const float* feat, int B, int P, in
     int gy = (512 + gx - 1) / gx;
     int rows = ((n + gy - 1) / gy + 31) / 32 * 32;
     gy = (n + rows - 1) / rows;
-    hipLaunchKernelGGL(pair_proj_bwd_kernel, dim3(gx, gy), dim3(256), (32 * D + 32 * 64) * sizeof(float), stream, feat, n, P, D,
-                       (const bf16_t*)J, (const bf16_t*)dJ, ld, T, dW, db, H, rows);
+    const size_t lds = (32 * D + 32 * 64) * sizeof(float);
+    if (D <= 48)
+        hipLaunchKernelGGL(pair_proj_bwd_kernel<12>, dim3(gx, gy), dim3(256), lds, stream, feat, n, P, D, (const bf16_t*)J, (const bf16_t*)dJ, ld, T, dW, db, H, rows);
+    else if (D <= 96)
+        hipLaunchKernelGGL(pair_proj_bwd_kernel<24>, dim3(gx, gy), dim3(256), lds, stream, feat, n, P, D, (const bf16_t*)J, (const bf16_t*)dJ, ld, T, dW, db, H, rows);
+    else
+        hipLaunchKernelGGL(pair_proj_bwd_kernel<96>, dim3(gx, gy), dim3(256), lds, stream, feat, n, P, D, (const bf16_t*)J, (const bf16_t*)dJ, ld, T, dW, db, H, rows);
     MMB_CHECK_LAUNCH();
     return 0;
 }

@@ -264,29 +264,24 @@ class _EncoderFn(torch.autograd.Function):
             lw = top._lw[i]
             x, qkv, actx, lse, z1, m1, r1, y1, u, g, z2, m2, r2, d_att, d_h1, d_h2 = ctx.saved[i]
             ctx.saved[i] = None
-            # --- output sublayer: y2 = LN(dropout(g.W2^T + b2) + y1)
+            # --- output sublayer: y2 = LN(dropout(g.W2^T + b2) + y1)      (b2 / bo gradients come out of ln_bwd)
             dz2d = torch.empty_like(dy) if d_h2[1] else None
-            dz2 = ops.ln_bwd(dy, z2, m2, r2, lw["ln2_g"], lw["g_ln2_g"], lw["g_ln2_b"], dx2=dz2d, pre_drop=d_h2)
+            dz2 = ops.ln_bwd(dy, z2, m2, r2, lw["ln2_g"], lw["g_ln2_g"], lw["g_ln2_b"], dx2=dz2d, pre_drop=d_h2, dbias2=lw["g_b2"])
             if dz2d is None:
                 dz2d = dz2
-            ops.colsum(dz2d, lw["g_b2"])
-            ops.gemm_tn(dz2d, g, lw["g_W2"])
             du = ops.gemm_nt(dz2d, lw["W2T"], gelu_bwd_u=u)
-            ops.colsum(du, lw["g_b1"])
-            ops.gemm_tn(du, y1, lw["g_W1"])
             dy1 = ops.gemm_nt(du, lw["W1T"], resid=dz2)
             # --- attention sublayer: y1 = LN(dropout(ctx.Wo^T + bo) + x)
             dz1d = torch.empty_like(dy) if d_h1[1] else None
-            dz1 = ops.ln_bwd(dy1, z1, m1, r1, lw["ln1_g"], lw["g_ln1_g"], lw["g_ln1_b"], dx2=dz1d, pre_drop=d_h1)
+            dz1 = ops.ln_bwd(dy1, z1, m1, r1, lw["ln1_g"], lw["g_ln1_g"], lw["g_ln1_b"], dx2=dz1d, pre_drop=d_h1, dbias2=lw["g_bo"])
             if dz1d is None:
                 dz1d = dz1
-            ops.colsum(dz1d, lw["g_bo"])
-            ops.gemm_tn(dz1d, actx, lw["g_Wo"])
             dctx = ops.gemm_nt(dz1d, lw["WoT"])
             dqkv = ops.attn_bwd(qkv, actx, dctx, lse, key_bias, layout, H, drop=d_att)
-            ops.colsum(dqkv, lw["g_bqkv"])
-            ops.gemm_tn(dqkv, x, lw["g_Wqkv"])
             dy = ops.gemm_nt(dqkv, lw["WqkvT"], resid=dz1)
+            # --- all four weight gradients (+ b1, bqkv gradients on the ones-operand MFMA) of the layer in ONE launch
+            ops.gemm_tn_grouped([(du, y1, lw["g_W1"], lw["g_b1"]), (dz2d, g, lw["g_W2"], None),
+                                 (dqkv, x, lw["g_Wqkv"], lw["g_bqkv"]), (dz1d, actx, lw["g_Wo"], None)])
             top._layer_grads_done(i)
         return dy, None, None, None, None, None
 
@@ -332,13 +327,11 @@ class _MLMHeadFn(torch.autograd.Function):
                 continue
             gs = dloss[s:s + 1]
             dl = dlogits[r0:r1]
-            ops.colsum(dl, w["g_pred_bias"], alpha_dev=gs)
-            ops.gemm_tn(dl, t[r0:r1], w["g_word_pad"], alpha_dev=gs)              # tied decoder weight gradient
+            ops.gemm_tn(dl, t[r0:r1], w["g_word_pad"], alpha_dev=gs, bias_out=w["g_pred_bias"])   # tied decoder weight + bias gradient
             ops.gemm_nt(dl, w["wordT"], out=dt[r0:r1], alpha_dev=gs)
         dt0 = ops.ln_bwd(dt, t0, mean, rstd, w["mlm_ln_g"], w["g_mlm_ln_g"], w["g_mlm_ln_b"])
         dpre = ops.gelu_bwd(dt0, pre)
-        ops.colsum(dpre, w["g_bt"])
-        ops.gemm_tn(dpre, y, w["g_Wt"])
+        ops.gemm_tn(dpre, y, w["g_Wt"], bias_out=w["g_bt"])
         dy = ops.gemm_nt(dpre, w["WtT"])
         return dy, None, None, None, None, None, None
 

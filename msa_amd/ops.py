@@ -6,6 +6,7 @@ taken from ``stride(0)`` so row-slices of larger buffers can be passed without c
 """
 from __future__ import annotations
 
+import ctypes
 from typing import Optional, Tuple
 
 import torch
@@ -82,17 +83,39 @@ def _slab(nbytes: int, device) -> Optional[torch.Tensor]:
     return t
 
 
-def gemm_tn(A, B, W, *, accumulate=True, alpha=1.0, alpha_dev=None):
-    """W[N,K] (fp32) (+)= alpha * A[M,N]^T @ B[M,K]   (weight gradient; see mmbert_gemm_tn)."""
+def gemm_tn(A, B, W, *, accumulate=True, alpha=1.0, alpha_dev=None, bias_out=None):
+    """W[N,K] (fp32) (+)= alpha * A[M,N]^T @ B[M,K]; bias_out[N] += alpha * colsum(A)  (see mmbert_gemm_tn)."""
     lib = _lib.load()
     M, N = A.shape
     K = B.shape[1]
-    assert B.shape[0] == M and W.shape == (N, K) and W.dtype == torch.float32
+    assert B.shape[0] == M and W.shape == (N, K) and W.dtype == torch.float32 and W.is_contiguous()
     need = lib.mmbert_gemm_tn_workspace(M, N, K, None)
     slab = _slab(need, A.device)
     _lib.check(lib.mmbert_gemm_tn(_stream(), A.data_ptr(), A.stride(0), B.data_ptr(), B.stride(0), W.data_ptr(), W.stride(0),
-                                  M, N, K, 1 if accumulate else 0, float(alpha), _ptr(alpha_dev), _ptr(slab)), "mmbert_gemm_tn")
+                                  M, N, K, 1 if accumulate else 0, float(alpha), _ptr(alpha_dev), _ptr(slab), _ptr(bias_out)), "mmbert_gemm_tn")
     return W
+
+
+_PtrArr = {n: (ctypes.c_void_p * n) for n in range(1, 5)}
+_IntArr = {n: (ctypes.c_int * n) for n in range(1, 5)}
+
+
+def gemm_tn_grouped(problems, *, accumulate=True, alpha=1.0):
+    """problems: up to 4 tuples (A[M,N] bf16, B[M,K] bf16, W[N,K] fp32, bias[N] fp32 or None) sharing M:
+    one launch computes every W (+)= A^T @ B and bias += colsum(A)  (see mmbert_gemm_tn_grouped)."""
+    lib = _lib.load()
+    n = len(problems)
+    M = problems[0][0].shape[0]
+    PA, IA = _PtrArr[n], _IntArr[n]
+    Ns = IA(*[p[0].shape[1] for p in problems])
+    Ks = IA(*[p[1].shape[1] for p in problems])
+    need = lib.mmbert_gemm_tn_grouped_workspace(n, Ns, Ks, M, None)
+    slab = _slab(need, problems[0][0].device)
+    _lib.check(lib.mmbert_gemm_tn_grouped(
+        _stream(), n, PA(*[p[0].data_ptr() for p in problems]), IA(*[p[0].stride(0) for p in problems]),
+        PA(*[p[1].data_ptr() for p in problems]), IA(*[p[1].stride(0) for p in problems]),
+        PA(*[p[2].data_ptr() for p in problems]), PA(*[(p[3].data_ptr() if p[3] is not None else None) for p in problems]),
+        Ns, Ks, M, 1 if accumulate else 0, float(alpha), None, _ptr(slab)), "mmbert_gemm_tn_grouped")
 
 
 def colsum(X, out, *, alpha=1.0, alpha_dev=None):
@@ -125,7 +148,7 @@ def ln_fwd(x, gamma, beta, eps, *, M=None, out=None, in_rows=None, out_rows=None
 
 
 def ln_bwd(dy, x, mean, rstd, gamma, dgamma, dbeta, *, M=None, dx=None, dx2=None, dy_rows=None, x_rows=None, dx_rows=None,
-           post_drop: Drop = None, pre_drop: Drop = None):
+           post_drop: Drop = None, pre_drop: Drop = None, dbias2=None):
     lib = _lib.load()
     H = x.shape[1]
     if M is None:
@@ -136,7 +159,7 @@ def ln_bwd(dy, x, mean, rstd, gamma, dgamma, dbeta, *, M=None, dx=None, dx2=None
     _lib.check(lib.mmbert_ln_bwd(_stream(), dy.data_ptr(), dy.stride(0), _ptr(dy_rows), x.data_ptr(), x.stride(0), _ptr(x_rows),
                                  mean.data_ptr(), rstd.data_ptr(), gamma.data_ptr(), M, H,
                                  dx.data_ptr(), dx.stride(0), _ptr(dx_rows), _ptr(dx2), dx2.stride(0) if dx2 is not None else 0,
-                                 _ptr(dgamma), _ptr(dbeta), po[0], po[1], po[2], pr[0], pr[1], pr[2]), "mmbert_ln_bwd")
+                                 _ptr(dgamma), _ptr(dbeta), _ptr(dbias2), po[0], po[1], po[2], pr[0], pr[1], pr[2]), "mmbert_ln_bwd")
     return dx
 
 

@@ -54,6 +54,44 @@ def test_gemm_nt_plain_and_bias(ops, M, N, K):
     assert_close(ops.gemm_nt(A.to(DEV), B.to(DEV), bias=bias.to(DEV), out_f32=True, alpha=0.5), 0.5 * ref + bias, 1e-4, 1e-3, "f32 out")
 
 
+@pytest.mark.parametrize("mode", [1, 2])
+@pytest.mark.parametrize("M,N,K", [(256, 256, 128), (700, 768, 768), (1150, 2304, 768), (520, 768, 3072), (2048, 30592, 128), (513, 260, 160)])
+def test_gemm_nt_both_kernels_all_epilogues(ops, mode, M, N, K):
+    """The 128^2 and the 256^2 (4-stage ring) kernels, forced, on ragged shapes: M, N not tile multiples, K = 32*odd."""
+    from msa_amd import _lib
+    lib = _lib.load()
+    lib.mmbert_gemm_nt_force(mode)
+    try:
+        if K % 64:
+            pytest.skip("both kernels take K % 64 == 0 through the C ABI")
+        A, B, bias, R, U = bf(rnd(M, K, seed=1)), bf(rnd(N, K, seed=2, scale=0.05)), rnd(N, seed=3), bf(rnd(M, N, seed=4)), bf(rnd(M, N, seed=5))
+        ref = A.float() @ B.float().t()
+        Ad, Bd = A.to(DEV), B.to(DEV)
+        assert_close(ops.gemm_nt(Ad, Bd), ref, 1e-2, 2e-2, "plain")
+        assert_close(ops.gemm_nt(Ad, Bd, bias=bias.to(DEV)), ref + bias, 1e-2, 2e-2, "bias")
+        assert_close(ops.gemm_nt(Ad, Bd, bias=bias.to(DEV), gelu=True), torch.nn.functional.gelu(ref + bias), 1e-2, 2e-2, "gelu")
+        assert_close(ops.gemm_nt(Ad, Bd, bias=bias.to(DEV), resid=R.to(DEV)), ref + bias + R.float(), 1e-2, 2e-2, "resid")
+        u = U.float().requires_grad_(True)
+        torch.nn.functional.gelu(u).sum().backward()
+        assert_close(ops.gemm_nt(Ad, Bd, gelu_bwd_u=U.to(DEV)), ref * u.grad, 1e-2, 2e-2, "gelu bwd")
+    finally:
+        lib.mmbert_gemm_nt_force(0)
+
+
+def test_gemm_nt256_exact_integers(ops):
+    from msa_amd import _lib
+    lib = _lib.load()
+    lib.mmbert_gemm_nt_force(2)
+    try:
+        M, N, K = 384, 512, 256
+        A = ((torch.arange(M)[:, None] * 5 + torch.arange(K)[None, :] * 3) % 7 - 3.0)
+        B = ((torch.arange(N)[:, None] * 2 + torch.arange(K)[None, :] * 11) % 5 - 2.0)
+        out = ops.gemm_nt(bf(A).to(DEV), bf(B).to(DEV), out_f32=True)
+        assert torch.equal(out.cpu(), A @ B.t())
+    finally:
+        lib.mmbert_gemm_nt_force(0)
+
+
 def test_gemm_nt_strided_views_and_alpha_dev(ops):
     M, N, K = 300, 256, 192
     big = bf(rnd(M, 3 * K, seed=4)).to(DEV)
@@ -108,6 +146,27 @@ def test_gemm_tn(ops, M, N, K):
     assert_close(W, W0 + 0.5 * ref, 2e-3, 2e-3 * math.sqrt(M), "accumulate")
     ops.gemm_tn(A.to(DEV), B.to(DEV), W, accumulate=False)
     assert_close(W, ref, 2e-3, 2e-3 * math.sqrt(M), "overwrite")
+
+
+def test_gemm_tn_fused_bias_and_grouped(ops):
+    M = 1700
+    probs, refs = [], []
+    for i, (N, K) in enumerate([(3072, 768), (768, 3072), (2304, 768), (768, 768)]):
+        A, B = bf(rnd(M, N, seed=70 + i, scale=0.1)), bf(rnd(M, K, seed=80 + i))
+        W0, b0 = rnd(N, K, seed=90 + i), rnd(N, seed=95 + i)
+        bias = b0.clone().to(DEV) if i % 2 == 0 else None
+        probs.append((A.to(DEV), B.to(DEV), W0.clone().to(DEV), bias))
+        refs.append((W0 + A.float().t() @ B.float(), (b0 + A.float().sum(0)) if bias is not None else None))
+    ops.gemm_tn_grouped(probs)
+    for (A, B, W, bias), (rw, rb) in zip(probs, refs):
+        assert_close(W, rw, 2e-3, 2e-3 * math.sqrt(M), "grouped W")
+        if bias is not None:
+            assert_close(bias, rb, 2e-3, 2e-2, "grouped bias")
+    A, B = bf(rnd(999, 520, seed=60, scale=0.1)), bf(rnd(999, 136, seed=61))
+    W, bias = torch.zeros(520, 136, device=DEV), torch.ones(520, device=DEV)
+    ops.gemm_tn(A.to(DEV), B.to(DEV), W, accumulate=False, alpha=0.5, bias_out=bias)
+    assert_close(W, 0.5 * (A.float().t() @ B.float()), 2e-3, 5e-2, "single W")
+    assert_close(bias, 1.0 + 0.5 * A.float().sum(0), 2e-3, 2e-2, "single bias")
 
 
 def test_gemm_tn_exact_integers(ops):
@@ -173,11 +232,13 @@ def test_ln_row_maps_and_dropouts(ops):
     dgamma, dbeta = torch.zeros(H, device=DEV), torch.zeros(H, device=DEV)
     pre = ops.make_drop(0.1, 99, 2)
     dx2 = torch.zeros(n, H, device=DEV, dtype=torch.bfloat16)
+    dbias2 = torch.zeros(H, device=DEV)
     dx = ops.ln_bwd(dy.to(DEV), x.to(DEV), mean, rstd, gamma.to(DEV), dgamma, dbeta, M=n, dy_rows=out_rows.to(DEV), x_rows=in_rows.to(DEV),
-                    post_drop=post, dx2=dx2, pre_drop=pre)
+                    post_drop=post, dx2=dx2, pre_drop=pre, dbias2=dbias2)
     assert_close(dx, xs.grad, 1e-2, 1e-2, "mapped ln bwd")
     m2 = ops.dropout_mask(n * H, pre, DEV).view(n, H).float().cpu()
     assert_close(dx2, xs.grad * m2 * pre[2], 1e-2, 1e-2, "branch dropout grad")
+    assert_close(dbias2, (xs.grad * m2 * pre[2]).sum(0), 1e-3, 1e-3, "fused bias gradient")
 
 
 # ------------------------------------------------------------------------------------ attention

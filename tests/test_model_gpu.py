@@ -151,7 +151,8 @@ def test_dropout_train_mode_is_seeded_and_unbiased():
     b = float(m(**batch)[0][0])
     m.manual_seed(11)
     c = float(m(**batch)[0][0])
-    assert a == c and a != b
+    # same seed -> same masks (the CE loss sum uses fp32 atomics, so allow last-bit differences)
+    assert abs(a - c) < 1e-5 * abs(a) and abs(a - b) > 1e-4 * abs(a)
     m.eval()
     e = float(m(**batch)[0][0])
     vals = []
