@@ -104,10 +104,13 @@ int mmbert_attn_bwd(mmbert_stream_t stream, const void* qkv, const void* ctx, co
 int mmbert_attn_dropout_mask(mmbert_stream_t stream, uint8_t* out, int S, unsigned elem_base, int head, uint32_t rng_stream, uint32_t thr16);
 
 /* ---- vocabulary cross-entropy (ignore_index -100), per-pass means ----
- * REF:MMBertForPretraining.py:381-384 (one CrossEntropyLoss(mean) per pass).  loss_sum[s] receives the
- * mean loss of segment s (rows seg_bounds[s]..seg_bounds[s+1]); dlogits = d(loss_sum[seg])/d(logits). */
-int mmbert_ce_fwd_bwd(mmbert_stream_t stream, const void* logits, int ldv, int V, const int64_t* labels, int M,
-                      const int* seg_bounds, int nseg, float* inv_count, float* loss_sum, float* row_loss, void* dlogits, int ldd);
+ * REF:MMBertForPretraining.py:381-384 (one CrossEntropyLoss(mean) per pass).  Segment s = rows
+ * seg_bounds[s]..seg_bounds[s+1].  fwd: loss_sum[s] = mean loss of segment s, row_lse[i] = logsumexp(row i),
+ * inv_count[s] = 1/#valid rows.  bwd: dlogits = d(sum_s gscale[s]*loss_sum[s])/d(logits) (may alias logits). */
+int mmbert_ce_fwd(mmbert_stream_t stream, const void* logits, int ldv, int V, const int64_t* labels, int M,
+                  const int* seg_bounds, int nseg, float* inv_count, float* loss_sum, float* row_lse);
+int mmbert_ce_bwd(mmbert_stream_t stream, const void* logits, int ldv, int V, const int64_t* labels, int M,
+                  const int* seg_bounds, int nseg, const float* inv_count, const float* gscale, const float* row_lse, void* dlogits, int ldd);
 
 /* ---- optimizer: flat AdamW (REF:train.py:76-97; mode 0 = transformers-2.8 AdamW, 1 = torch.optim.AdamW) ----
  * flags[i/256]: 0 no decay, 1 decay, 2 frozen.  n % 256 == 0.  Also refreshes the bf16 copy, and zeroes g. */

@@ -34,7 +34,8 @@ SIGNATURES = {
     "mmbert_attn_fwd": (I, [P, P, P, P, P, I, I, P, P, P, P, P, I, U32, U32, F]),
     "mmbert_attn_bwd": (I, [P, P, P, P, P, P, P, P, I, I, P, P, P, P, P, I, U32, U32, F]),
     "mmbert_attn_dropout_mask": (I, [P, P, I, C.c_uint, I, U32, U32]),
-    "mmbert_ce_fwd_bwd": (I, [P, P, I, I, P, I, P, I, P, P, P, P, I]),
+    "mmbert_ce_fwd": (I, [P, P, I, I, P, I, P, I, P, P, P]),
+    "mmbert_ce_bwd": (I, [P, P, I, I, P, I, P, I, P, P, P, P, I]),
     "mmbert_adamw": (I, [P, P, P, P, P, P, P, SZ, F, F, F, F, F, I, F, I, I]),
     "mmbert_gelu_bwd": (I, [P, P, P, P, SZ]),
     "mmbert_cast_f32_bf16": (I, [P, P, P, SZ]),

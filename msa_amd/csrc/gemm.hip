@@ -75,6 +75,53 @@ __device__ __forceinline__ void epi_store(const GemmNT& p, int m, int n, float (
     }
 }
 
+// 8-wide epilogue on row-contiguous data: v[0..7] = alpha-scaled C[m][n..n+7] (n % 8 == 0), 16-byte accesses
+template <int EPI>
+__device__ __forceinline__ void epi_store8(const GemmNT& p, int m, int n, float (&v)[8]) {
+    if constexpr (EPI & EPI_BIAS) {
+        const float4 b0 = *(const float4*)(p.bias + n), b1 = *(const float4*)(p.bias + n + 4);
+        v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w; v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
+    }
+    if constexpr (EPI & EPI_GELU) {
+        if (p.aux) {
+            bf16x8 u;
+#pragma unroll
+            for (int r = 0; r < 8; ++r) u[r] = f2bf(v[r]);
+            *(bf16x8*)(p.aux + (size_t)m * p.ldaux + n) = u;
+        }
+#pragma unroll
+        for (int r = 0; r < 8; ++r) v[r] = gelu_erf(v[r]);
+    }
+    if constexpr (EPI & EPI_GELU_BWD) {
+        const bf16x8 u = *(const bf16x8*)(p.U + (size_t)m * p.ldu + n);
+#pragma unroll
+        for (int r = 0; r < 8; ++r) v[r] *= gelu_erf_grad(bf2f(u[r]));
+    }
+    if constexpr (EPI & EPI_RESID) {
+        if (p.drop_thr16) {
+            bool k0[4], k1[4];
+            const uint64_t idx = (uint64_t)m * p.N + n;
+            mmb_keep4(p.drop_stream, idx, p.drop_thr16, k0);
+            mmb_keep4(p.drop_stream, idx + 4, p.drop_thr16, k1);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { v[r] = k0[r] ? v[r] * p.drop_scale : 0.f; v[4 + r] = k1[r] ? v[4 + r] * p.drop_scale : 0.f; }
+        }
+        const bf16x8 rr = *(const bf16x8*)(p.R + (size_t)m * p.ldr + n);
+#pragma unroll
+        for (int r = 0; r < 8; ++r) v[r] += bf2f(rr[r]);
+    }
+    if constexpr (EPI & EPI_OUT_F32) {
+        float* c = (float*)p.C + (size_t)m * p.ldc + n;
+        *(float4*)c = make_float4(v[0], v[1], v[2], v[3]);
+        *(float4*)(c + 4) = make_float4(v[4], v[5], v[6], v[7]);
+    } else {
+        bf16x8 o;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) o[r] = f2bf(v[r]);
+        *(bf16x8*)((bf16_t*)p.C + (size_t)m * p.ldc + n) = o;
+    }
+}
+
 template <int EPI>
 __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const GemmNT p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];   // [2][A 16K | B 16K]
@@ -188,6 +235,12 @@ static int launch_nt(hipStream_t s, const GemmNT& p) {
 // distinct 16-byte slots (the groups mix rows {0-3,12-15} of one chunk with rows {4-11} of chunk^1).
 // Loads past the last stage re-read the last stage (clamped) into a dead slot, so the in-flight
 // count is the same in every iteration and the waits need no tail variants.
+// Epilogue: accumulators -> LDS (fp32, wave-private 16 KiB, 64 rows at a time) -> 8 consecutive columns
+// per lane -> fused math -> 16-byte global accesses (8 full 128-B lines per store instruction; the direct
+// 8-byte fragment-shaped stores were store-issue bound: 27 us vs 19 us per tile round).
+// Tried and rejected (round 1, same-process A/B, tools/bench_gemm.py): a 256x128-tile / 256-thread /
+// 3-slot-ring variant with two workgroups per CU (to overlap one's epilogue with the other's K loop):
+// deep-K shapes fell from ~1080 to ~850 TF/s and the K=768 shapes did not improve.
 // -------------------------------------------------------------------------------------------------
 template <int EPI>
 __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(const GemmNT p) {
@@ -272,22 +325,37 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(const GemmNT p) {
         NT256_STEP(3, a1, b1, a0, b0) if (s >= ns) break;
     }
 #undef NT256_STEP
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // drain the dummy tail stages before LDS is released
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // drain the dummy tail stages before LDS is reused
+    __builtin_amdgcn_s_barrier();                            // every wave is done with the ring
 
     const float alpha = p.alpha * (p.alpha_dev ? *p.alpha_dev : 1.0f);
+    char* wl = smem + wave * 16384;                          // [64 rows][64 fp32] = 256-B rows, 16-B chunks XOR (row & 15)
+    const int er = lane >> 3, ec = lane & 7;                 // read-back: 8 rows per pass, lane owns columns 8*ec .. 8*ec+7
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int m = m0 + wr * 128 + i * 16 + fr;
-        if (m >= p.M) continue;
+    for (int half = 0; half < 2; ++half) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int n = n0 + wc * 64 + j * 16 + fq * 4;
-            if (n >= p.N) continue;
-            float v[4];
+        for (int i = 0; i < 4; ++i) {
+            const int row = i * 16 + fr;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r] * alpha;
-            epi_store<EPI>(p, m, n, v);
+            for (int j = 0; j < 4; ++j) {
+                const f32x4 a4 = acc[half * 4 + i][j];
+                *(float4*)(wl + row * 256 + (((j * 4 + fq) ^ (row & 15)) << 4)) = make_float4(a4[0] * alpha, a4[1] * alpha, a4[2] * alpha, a4[3] * alpha);
+            }
         }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // wave-private region: no barrier needed
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int row = it * 8 + er;
+            const float4 lo = *(const float4*)(wl + row * 256 + (((2 * ec) ^ (row & 15)) << 4));
+            const float4 hi = *(const float4*)(wl + row * 256 + (((2 * ec + 1) ^ (row & 15)) << 4));
+            const int m = m0 + wr * 128 + half * 64 + row;
+            const int n = n0 + wc * 64 + ec * 8;
+            if (m < p.M && n < p.N) {
+                float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+                epi_store8<EPI>(p, m, n, v);
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // reads done before the next half overwrites the region
     }
 }
 
@@ -309,8 +377,8 @@ static int launch_nt256(hipStream_t s, const GemmNT& p) {
 static int g_nt_force = 0;   // 0 auto, 1 force 128^2, 2 force 256^2 (tests / A-B benchmarking)
 template <int EPI>
 static int dispatch_nt(hipStream_t s, const GemmNT& p) {
-    const bool big = (p.K >= 128) && (p.M >= 512) && (p.N >= 256);
-    if (g_nt_force == 2 || (g_nt_force == 0 && big)) return launch_nt256<EPI>(s, p);
+    const bool big = (p.K >= 128) && (p.M >= 512) && (p.N >= 256) && !(p.N & 7) && !(p.ldc & 7) && !(p.ldr & 7) && !(p.ldaux & 7) && !(p.ldu & 7);
+    if ((g_nt_force == 2 && !(p.N & 7)) || (g_nt_force == 0 && big)) return launch_nt256<EPI>(s, p);
     return launch_nt<EPI>(s, p);
 }
 

@@ -342,9 +342,9 @@ __global__ __launch_bounds__(256) void pair_proj_bwd_kernel(const float* __restr
 // Rows are grouped into up to 4 segments (the text / text+visual / text+speech passes): each
 // segment's loss is a mean over ITS non-ignored rows (REF get_outputs, one CrossEntropyLoss per pass).
 //   ce_count : inv_count[s] = 1/max(1,#valid rows in segment s); loss_sum[s] = 0
-//   ce_row   : one workgroup per row, whole row held in registers (<= 16 x 16 B per lane):
-//              loss_sum[seg] += (lse - logit[label]) * inv_count; dlogits = (softmax - onehot)*inv_count
-//              (0 for ignored rows and for the pad columns V..ldv)
+//   ce_row<0>: forward  (loss per segment, per-row logsumexp kept for backward)
+//   ce_row<1>: backward (dlogits, the upstream gradient of each segment's loss folded in, so the two
+//              vocabulary GEMMs of backward run once over all rows instead of once per pass)
 // --------------------------------------------------------------------------------------------
 __global__ void ce_count_kernel(const int64_t* __restrict__ labels, int M, const int* __restrict__ seg_bounds, int nseg,
                                 float* __restrict__ inv_count, float* __restrict__ loss_sum) {
@@ -367,9 +367,15 @@ __global__ void ce_count_kernel(const int64_t* __restrict__ labels, int M, const
 }
 
 #define CE_MAXC 16
+// One workgroup per row, the row held in registers (<= 16 x 16 B per lane).
+//   MODE 0 (forward): row_lse[i] = logsumexp(row); loss_sum[seg] += (lse - logit[label]) * inv_count[seg]
+//   MODE 1 (backward): dlogits = (exp(logit - row_lse) - onehot) * inv_count[seg] * gscale[seg]
+//                      (0 for ignored rows and for the pad columns V..ldv); gscale = upstream d(loss)/d(loss_seg)
+// Ignored rows (label -100) are never read.
+template <int MODE>
 __global__ __launch_bounds__(256) void ce_row_kernel(const bf16_t* __restrict__ logits, int ldv, int V, const int64_t* __restrict__ labels,
                                                      const int* __restrict__ seg_bounds, int nseg, const float* __restrict__ inv_count,
-                                                     float* __restrict__ loss_sum, float* __restrict__ row_loss,
+                                                     float* __restrict__ loss_sum, float* __restrict__ row_lse, const float* __restrict__ gscale,
                                                      bf16_t* __restrict__ dlogits, int ldd) {
     __shared__ float red[4];
     __shared__ float lab_logit;
@@ -377,10 +383,10 @@ __global__ __launch_bounds__(256) void ce_row_kernel(const bf16_t* __restrict__ 
     const int64_t lab = labels[i];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int nchunk = ldv >> 3;
-    bf16_t* drow = dlogits ? dlogits + (size_t)i * ldd : nullptr;
     if (lab == -100 || lab < 0 || lab >= V) {
-        if (row_loss && tid == 0) row_loss[i] = 0.f;
-        if (drow) {
+        if (MODE == 0) { if (tid == 0) row_lse[i] = 0.f; }
+        else {
+            bf16_t* drow = dlogits + (size_t)i * ldd;
             const bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
             for (int c = tid; c < nchunk; c += 256) *(bf16x8*)(drow + c * 8) = z;
         }
@@ -388,45 +394,50 @@ __global__ __launch_bounds__(256) void ce_row_kernel(const bf16_t* __restrict__ 
     }
     int s = 0;
     while (s + 1 < nseg && i >= seg_bounds[s + 1]) ++s;
-    const float inv = inv_count[s];
     const bf16_t* row = logits + (size_t)i * ldv;
     bf16x8 v[CE_MAXC];
-    float mx = -INFINITY;
 #pragma unroll
     for (int c = 0; c < CE_MAXC; ++c) {
         const int ch = c * 256 + tid;
-        if (ch < nchunk) {
-            v[c] = *(const bf16x8*)(row + ch * 8);
+        if (ch < nchunk) v[c] = *(const bf16x8*)(row + ch * 8);
+    }
+    if (MODE == 0) {
+        float mx = -INFINITY;
 #pragma unroll
-            for (int r = 0; r < 8; ++r) if (ch * 8 + r < V) mx = fmaxf(mx, bf2f(v[c][r]));
+        for (int c = 0; c < CE_MAXC; ++c) {
+            const int ch = c * 256 + tid;
+            if (ch < nchunk) {
+#pragma unroll
+                for (int r = 0; r < 8; ++r) if (ch * 8 + r < V) mx = fmaxf(mx, bf2f(v[c][r]));
+            }
         }
-    }
-    mx = wave_max(mx);
-    if (lane == 0) red[w] = mx;
-    __syncthreads();
-    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
-    __syncthreads();
-    float se = 0.f;
+        mx = wave_max(mx);
+        if (lane == 0) red[w] = mx;
+        __syncthreads();
+        mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+        __syncthreads();
+        float se = 0.f;
 #pragma unroll
-    for (int c = 0; c < CE_MAXC; ++c) {
-        const int ch = c * 256 + tid;
-        if (ch < nchunk) {
+        for (int c = 0; c < CE_MAXC; ++c) {
+            const int ch = c * 256 + tid;
+            if (ch < nchunk) {
 #pragma unroll
-            for (int r = 0; r < 8; ++r) if (ch * 8 + r < V) se += __expf(bf2f(v[c][r]) - mx);
-            if ((int)(lab >> 3) == ch) lab_logit = bf2f(v[c][lab & 7]);
+                for (int r = 0; r < 8; ++r) if (ch * 8 + r < V) se += __expf(bf2f(v[c][r]) - mx);
+                if ((int)(lab >> 3) == ch) lab_logit = bf2f(v[c][lab & 7]);
+            }
         }
-    }
-    se = wave_sum(se);
-    if (lane == 0) red[w] = se;
-    __syncthreads();
-    se = red[0] + red[1] + red[2] + red[3];
-    const float lse = mx + __logf(se);
-    if (tid == 0) {
-        const float l = lse - lab_logit;
-        if (row_loss) row_loss[i] = l;
-        atomicAdd(loss_sum + s, l * inv);
-    }
-    if (drow) {
+        se = wave_sum(se);
+        if (lane == 0) red[w] = se;
+        __syncthreads();
+        if (tid == 0) {
+            const float lse = mx + __logf(red[0] + red[1] + red[2] + red[3]);
+            row_lse[i] = lse;
+            atomicAdd(loss_sum + s, (lse - lab_logit) * inv_count[s]);
+        }
+    } else {
+        const float lse = row_lse[i];
+        const float scale = inv_count[s] * gscale[s];
+        bf16_t* drow = dlogits + (size_t)i * ldd;
 #pragma unroll
         for (int c = 0; c < CE_MAXC; ++c) {
             const int ch = c * 256 + tid;
@@ -437,7 +448,7 @@ __global__ __launch_bounds__(256) void ce_row_kernel(const bf16_t* __restrict__ 
                     const int col = ch * 8 + r;
                     float pr = col < V ? __expf(bf2f(v[c][r]) - lse) : 0.f;
                     if (col == (int)lab) pr -= 1.0f;
-                    o[r] = f2bf(pr * inv);
+                    o[r] = f2bf(pr * scale);
                 }
                 *(bf16x8*)(drow + ch * 8) = o;
             }
@@ -637,14 +648,24 @@ int mmbert_pair_proj_bwd(hipStream_t stream, const float* feat, int B, int P, in
     return 0;
 }
 
-int mmbert_ce_fwd_bwd(hipStream_t stream, const void* logits, int ldv, int V, const int64_t* labels, int M,
-                      const int* seg_bounds, int nseg, float* inv_count, float* loss_sum, float* row_loss, void* dlogits, int ldd) {
+int mmbert_ce_fwd(hipStream_t stream, const void* logits, int ldv, int V, const int64_t* labels, int M,
+                  const int* seg_bounds, int nseg, float* inv_count, float* loss_sum, float* row_lse) {
     if (M <= 0) return 0;
-    if (nseg < 1 || nseg > 4 || (ldv & 7) || (ldd & 7) || ldv > CE_MAXC * 256 * 8 || V > ldv) return -1;
+    if (nseg < 1 || nseg > 4 || (ldv & 7) || ldv > CE_MAXC * 256 * 8 || V > ldv) return -1;
     hipLaunchKernelGGL(ce_count_kernel, dim3(1), dim3(1024), 0, stream, labels, M, seg_bounds, nseg, inv_count, loss_sum);
     MMB_CHECK_LAUNCH();
-    hipLaunchKernelGGL(ce_row_kernel, dim3(M), dim3(256), 0, stream, (const bf16_t*)logits, ldv, V, labels, seg_bounds, nseg, inv_count, loss_sum,
-                       row_loss, (bf16_t*)dlogits, ldd);
+    hipLaunchKernelGGL(ce_row_kernel<0>, dim3(M), dim3(256), 0, stream, (const bf16_t*)logits, ldv, V, labels, seg_bounds, nseg, inv_count, loss_sum,
+                       row_lse, (const float*)nullptr, (bf16_t*)nullptr, 0);
+    MMB_CHECK_LAUNCH();
+    return 0;
+}
+
+int mmbert_ce_bwd(hipStream_t stream, const void* logits, int ldv, int V, const int64_t* labels, int M,
+                  const int* seg_bounds, int nseg, const float* inv_count, const float* gscale, const float* row_lse, void* dlogits, int ldd) {
+    if (M <= 0) return 0;
+    if (nseg < 1 || nseg > 4 || (ldv & 7) || (ldd & 7) || ldv > CE_MAXC * 256 * 8 || V > ldv) return -1;
+    hipLaunchKernelGGL(ce_row_kernel<1>, dim3(M), dim3(256), 0, stream, (const bf16_t*)logits, ldv, V, labels, seg_bounds, nseg, inv_count,
+                       (float*)nullptr, (float*)row_lse, gscale, (bf16_t*)dlogits, ldd);
     MMB_CHECK_LAUNCH();
     return 0;
 }

@@ -302,13 +302,10 @@ class _MLMHeadFn(torch.autograd.Function):
         t, mean, rstd = ops.ln_fwd(t0, w["mlm_ln_g"], w["mlm_ln_b"], cfg.layer_norm_eps, stats=keep)
         logits = ops.gemm_nt(t, w["word_h"], bias=w["pred_bias"])                 # [M, Vpad] bf16
         nseg = len(seg_bounds_host) - 1
-        dlogits = None
+        loss, inv, lse = ops.ce_fwd(logits, V, labels, seg_bounds, nseg)
+        ctx.top, ctx.nseg, ctx.keep_logits = top, nseg, want_scores
         if keep:
-            dlogits = torch.empty_like(logits) if want_scores else logits          # in place unless the scores are returned
-        loss, _ = ops.ce_fwd_bwd(logits, V, labels, seg_bounds, nseg, dlogits=dlogits)
-        ctx.top, ctx.bounds = top, seg_bounds_host
-        if keep:
-            ctx.save_for_backward(y, pre, t0, mean, rstd, t, dlogits)
+            ctx.save_for_backward(y, pre, t0, mean, rstd, t, logits, labels, seg_bounds, inv, lse)
         out_logits = logits if want_scores else None
         if out_logits is not None:
             ctx.mark_non_differentiable(out_logits)
@@ -316,19 +313,15 @@ class _MLMHeadFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dloss, _unused):
-        y, pre, t0, mean, rstd, t, dlogits = ctx.saved_tensors
+        y, pre, t0, mean, rstd, t, logits, labels, seg_bounds, inv, lse = ctx.saved_tensors
         w = ctx.top._w
-        dloss = dloss.contiguous().float()
-        dt = torch.empty_like(t)
-        b = ctx.bounds
-        for s in range(len(b) - 1):
-            r0, r1 = b[s], b[s + 1]
-            if r1 <= r0:
-                continue
-            gs = dloss[s:s + 1]
-            dl = dlogits[r0:r1]
-            ops.gemm_tn(dl, t[r0:r1], w["g_word_pad"], alpha_dev=gs, bias_out=w["g_pred_bias"])   # tied decoder weight + bias gradient
-            ops.gemm_nt(dl, w["wordT"], out=dt[r0:r1], alpha_dev=gs)
+        V = ctx.top.config.vocab_size
+        gs = dloss.contiguous().float()
+        # dlogits with the per-pass upstream gradients folded in; in place unless the scores were handed to the caller
+        dl = torch.empty_like(logits) if ctx.keep_logits else logits
+        ops.ce_bwd(logits, V, labels, seg_bounds, ctx.nseg, inv, gs, lse, dl)
+        ops.gemm_tn(dl, t, w["g_word_pad"], bias_out=w["g_pred_bias"])          # tied decoder weight + prediction bias gradient
+        dt = ops.gemm_nt(dl, w["wordT"])
         dt0 = ops.ln_bwd(dt, t0, mean, rstd, w["mlm_ln_g"], w["g_mlm_ln_g"], w["g_mlm_ln_b"])
         dpre = ops.gelu_bwd(dt0, pre)
         ops.gemm_tn(dpre, y, w["g_Wt"], bias_out=w["g_bt"])

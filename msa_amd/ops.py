@@ -269,16 +269,25 @@ def attn_dropout_mask(S, elem_base, head, drop, device):
     return out
 
 
-def ce_fwd_bwd(logits, V, labels, seg_bounds, nseg, *, dlogits=None, row_loss=None):
-    """Returns (loss_mean_per_segment[nseg] fp32, inv_count[nseg]); writes dlogits when given."""
+def ce_fwd(logits, V, labels, seg_bounds, nseg):
+    """Returns (loss_mean_per_segment[nseg], inv_count[4], row_lse[M])  (see mmbert_ce_fwd)."""
     lib = _lib.load()
     M = logits.shape[0]
     inv = torch.empty(4, device=logits.device, dtype=torch.float32)
     loss = torch.empty(4, device=logits.device, dtype=torch.float32)
-    _lib.check(lib.mmbert_ce_fwd_bwd(_stream(), logits.data_ptr(), logits.stride(0), V, labels.data_ptr(), M, seg_bounds.data_ptr(), nseg,
-                                     inv.data_ptr(), loss.data_ptr(), _ptr(row_loss), _ptr(dlogits),
-                                     dlogits.stride(0) if dlogits is not None else 0), "mmbert_ce_fwd_bwd")
-    return loss[:nseg], inv[:nseg]
+    lse = torch.empty(M, device=logits.device, dtype=torch.float32)
+    _lib.check(lib.mmbert_ce_fwd(_stream(), logits.data_ptr(), logits.stride(0), V, labels.data_ptr(), M, seg_bounds.data_ptr(), nseg,
+                                 inv.data_ptr(), loss.data_ptr(), lse.data_ptr()), "mmbert_ce_fwd")
+    return loss[:nseg], inv, lse
+
+
+def ce_bwd(logits, V, labels, seg_bounds, nseg, inv, gscale, lse, dlogits):
+    """dlogits (may be ``logits`` itself) = d(sum_s gscale[s] * loss_s) / d(logits)  (see mmbert_ce_bwd)."""
+    lib = _lib.load()
+    M = logits.shape[0]
+    _lib.check(lib.mmbert_ce_bwd(_stream(), logits.data_ptr(), logits.stride(0), V, labels.data_ptr(), M, seg_bounds.data_ptr(), nseg,
+                                 inv.data_ptr(), gscale.data_ptr(), lse.data_ptr(), dlogits.data_ptr(), dlogits.stride(0)), "mmbert_ce_bwd")
+    return dlogits
 
 
 def adamw(p, g, m, v, p_bf16, flags, *, lr, beta1=0.9, beta2=0.999, eps=1e-6, wd=0.01, step=1, gscale=1.0, mode=0, zero_grad=True):

@@ -349,16 +349,24 @@ def test_cross_entropy_segments(ops):
     labels = torch.randint(0, V, (M,), generator=g)
     labels[torch.rand(M, generator=g) < 0.6] = -100
     bounds = torch.tensor([0, 20, 55, M], dtype=torch.int32)
+    g = torch.tensor([0.5, 2.0, -1.0])
+    loss, inv, lse = ops.ce_fwd(logits.to(DEV), V, labels.to(DEV), bounds.to(DEV), 3)
     dl = torch.full((M, ldv), 7.0, device=DEV, dtype=torch.bfloat16)
-    loss, inv = ops.ce_fwd_bwd(logits.to(DEV), V, labels.to(DEV), bounds.to(DEV), 3, dlogits=dl)
+    ops.ce_bwd(logits.to(DEV), V, labels.to(DEV), bounds.to(DEV), 3, inv, g.to(DEV), lse, dl)
     for s in range(3):
         a, b = int(bounds[s]), int(bounds[s + 1])
         lg = logits[a:b, :V].float().requires_grad_(True)
         ref = torch.nn.functional.cross_entropy(lg, labels[a:b])
-        ref.backward()
+        (ref * g[s]).backward()
         assert_close(loss[s], ref, 2e-3, 2e-3, f"ce loss seg{s}")
         assert_close(dl[a:b, :V], lg.grad, 2e-2, 1e-4, f"dlogits seg{s}")
+        valid = labels[a:b] != -100
+        assert_close(lse[a:b][valid.to(DEV)], torch.logsumexp(lg.detach(), -1)[valid], 1e-4, 1e-3, "row lse")
     assert float(dl[:, V:].abs().max()) == 0.0
+    # in-place form (dlogits aliases logits)
+    lg_dev = logits.to(DEV).clone()
+    ops.ce_bwd(lg_dev, V, labels.to(DEV), bounds.to(DEV), 3, inv, g.to(DEV), lse, lg_dev)
+    assert torch.equal(lg_dev, dl)
 
 
 @pytest.mark.parametrize("mode", [0, 1])
