@@ -18,6 +18,7 @@
 // Dropout index of P[i][j] in sequence s, head h: elem_base[s] + (h*S + i)*Spad + j, Spad = S
 // rounded up to 4 (elem_base multiples of 4), so forward and both backward kernels agree.
 #include "common.h"
+#include <type_traits>
 
 #define LOG2E 1.4426950408889634f
 #define LN2 0.6931471805599453f
@@ -84,281 +85,529 @@ __device__ __forceinline__ float group_max(float v) {
 }
 
 // =============================================================================================
-// forward
+// forward.  Work item = 128 query rows of one sequence x one head; 4 waves x 32 rows (two 16-row
+// query blocks per wave share every K / V fragment read).  K, V and the key-bias slice of the next
+// 64-key tile stream into the second LDS buffer by LDS-DMA while the current tile is consumed (one
+// barrier per tile).  VALU work per probability (the binding resource at head dim 64) is kept minimal:
+//   * the key bias enters as the INITIAL ACCUMULATOR of S^T = K.Q^T (bias/scale), so scaling and
+//     max-subtraction are ONE fma feeding v_exp_f32:  p = exp2(acc*c - m*c),  c = scale*log2(e);
+//   * the dropout scale 1/(1-p) is applied once to the output row, not to every probability;
+//   * the transposed V reads go through inline asm (see tr_read in gemm.hip: the builtin makes hipcc
+//     drain vmcnt(0) in front of them, which would serialise the prefetch).
 // =============================================================================================
+template <int OFF>
+__device__ __forceinline__ void tr_read(s16x4& dst, unsigned lds_addr) {
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(lds_addr), "i"(OFF));
+}
+
+template <int OFF>
+__device__ __forceinline__ void lds_read16(f32x4& dst, unsigned lds_addr) {
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(lds_addr), "i"(OFF));
+}
+
+#define FWD_BUF 16640          // K 8192 | V 8192 | bias 256
+
 __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs a) {
-    __shared__ __attribute__((aligned(16))) char smem[16384];       // K (mode 0) | V (mode 1)
-    char* Ks = smem; char* Vs = smem + 8192;
+    __shared__ __attribute__((aligned(16))) char smem[2 * FWD_BUF];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int seq = a.tile_seq[blockIdx.x], r0 = a.tile_r0[blockIdx.x], head = blockIdx.y;
     const int start = a.seq_start[seq], S = a.seq_len[seq];
     const int Spad = (S + 3) & ~3;
     const int fr = lane & 15, g = lane >> 4;
-    const int qi = r0 + wave * 16 + fr;                              // row inside the sequence
-    const int qc = min(qi, S - 1);
     const bf16_t* base = a.qkv + (size_t)start * a.ld_qkv + head * 64;
-    bf16x8 qf[2];
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk) qf[kk] = *(const bf16x8*)(base + (size_t)qc * a.ld_qkv + kk * 32 + 8 * g);
     const bf16_t* kbase = base + a.H;
     const bf16_t* vbase = base + 2 * a.H;
-    const float sl2 = a.scale * LOG2E;
-    const unsigned rowbase = a.elem_base[seq] + (unsigned)((head * S + qc) * Spad);
-
-    f32x4 o[4];
+    const float* bbase = a.key_bias + start;
+    int qi[2], qc[2];
+    unsigned rowbase[2];
+    bf16x8 qf[2][2];
 #pragma unroll
-    for (int d = 0; d < 4; ++d) o[d] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    float m2 = -INFINITY, lpart = 0.f;
-
-    for (int kv0 = 0; kv0 < S; kv0 += 64) {
-        __syncthreads();                                             // previous tile fully consumed
-        stage_tile<0>(Ks, kbase, a.ld_qkv, kv0, S, wave, lane);
-        stage_tile<1>(Vs, vbase, a.ld_qkv, kv0, S, wave, lane);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        f32x4 s[4];
+    for (int qb = 0; qb < 2; ++qb) {
+        qi[qb] = r0 + wave * 32 + qb * 16 + fr;
+        qc[qb] = min(qi[qb], S - 1);
 #pragma unroll
-        for (int kt = 0; kt < 4; ++kt) {
-            s[kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int kk = 0; kk < 2; ++kk)
-                s[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_row_frag(Ks, kt * 16 + fr, kk * 4 + g), qf[kk], s[kt], 0, 0, 0);
-        }
-        // scores (log2 domain), tile max
-        float tmax = -INFINITY;
-#pragma unroll
-        for (int kt = 0; kt < 4; ++kt) {
-            const int key = kv0 + kt * 16 + 4 * g;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float b = (key + r < S) ? a.key_bias[start + key + r] * LOG2E : -INFINITY;
-                s[kt][r] = s[kt][r] * sl2 + b;
-                tmax = fmaxf(tmax, s[kt][r]);
-            }
-        }
-        tmax = group_max(tmax);
-        const float mnew = fmaxf(m2, tmax);
-        const float alpha = exp2f(m2 - mnew);                        // m2 = -inf on the first tile -> 0
-        m2 = mnew;
-        float psum = 0.f;
-#pragma unroll
-        for (int kt = 0; kt < 4; ++kt) {
-            bool keep[4] = {true, true, true, true};
-            if (a.dthr) mmb_keep4(a.dstream, (uint64_t)rowbase + (kv0 + kt * 16 + 4 * g), a.dthr, keep);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float p = exp2f(s[kt][r] - mnew);
-                psum += p;
-                s[kt][r] = a.dthr ? (keep[r] ? p * a.dscale : 0.f) : p;
-            }
-        }
-        lpart = lpart * alpha + psum;
-#pragma unroll
-        for (int d = 0; d < 4; ++d)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) o[d][r] *= alpha;
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            const bf16x8 pf = pack8(s[2 * ks], s[2 * ks + 1]);
-#pragma unroll
-            for (int d = 0; d < 4; ++d)
-                o[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_tr_frag(Vs, ks, d, lane), pf, o[d], 0, 0, 0);
-        }
+        for (int kk = 0; kk < 2; ++kk) qf[qb][kk] = *(const bf16x8*)(base + (size_t)qc[qb] * a.ld_qkv + kk * 32 + 8 * g);
+        rowbase[qb] = a.elem_base[seq] + (unsigned)((head * S + qc[qb]) * Spad);
     }
-    const float l = group_sum(lpart);
-    if (qi < S) {
-        const float inv = 1.0f / l;
-        bf16_t* orow = a.ctx + (size_t)(start + qi) * a.H + head * 64;
+    const float c2 = a.scale * LOG2E, inv_scale = 1.0f / a.scale;
+
+    auto stage = [&](int buf, int kv0) {
+        char* B = smem + buf * FWD_BUF;
+        stage_tile<0>(B, kbase, a.ld_qkv, kv0, S, wave, lane);
+        stage_tile<1>(B + 8192, vbase, a.ld_qkv, kv0, S, wave, lane);
+        // 64 bias floats; every wave writes the same 256 B (identical data) so that all waves keep the same vmcnt
+        __builtin_amdgcn_global_load_lds(GPTR(bbase + min(kv0 + lane, S - 1)), LPTR(B + 16384), 4, 0, 0);
+    };
+
+    f32x4 o[2][4];
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+        for (int d = 0; d < 4; ++d) o[qb][d] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float mraw[2] = {-INFINITY, -INFINITY}, lpart[2] = {0.f, 0.f};
+
+    // transposed-read lane addressing (see lds_tr_frag): rows 4g+q (+16 per row tile), 4 columns at 4p
+    const unsigned lds0 = (unsigned)(uintptr_t)LPTR(smem);
+    const int tq = (lane >> 2) & 3, tp = lane & 3;
+    unsigned vaddr[4];                                       // one base per d-tile; row tiles by immediate offsets
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+        const int r = 4 * g + tq;
+        vaddr[d] = lds0 + 8192 + r * 128 + ((d ^ ((r >> 1) & 3)) << 5) + tp * 8;
+    }
+
+    const unsigned baddr = lds0 + 16 * g;                    // bias tile: 4 consecutive keys per lane group
+    const int ntile = (S + 63) >> 6;
+    stage(0, 0);
+    // the buffer index must be a compile-time constant: with a runtime index hipcc cannot prove that the
+    // fragment reads do not alias the LDS-DMA it has just issued and drains vmcnt(0) in front of them
+    auto tile_body = [&](auto buf_c, int t) {
+        constexpr int buf = decltype(buf_c)::value;
+        const int kv0 = t << 6;
+        __builtin_amdgcn_s_waitcnt(0x0F70);                  // vmcnt(0): tile t landed (tile t+1 is issued below, after the barrier)
+        __builtin_amdgcn_s_barrier();                        // ... for every wave; buffer buf^1 (tile t-1) is free
+        if (t + 1 < ntile) stage(buf ^ 1, kv0 + 64);
+        const char* Ks = smem + buf * FWD_BUF;
+
+        // S^T = K.Q^T with the key bias (divided by the scale) as the initial accumulator
+        f32x4 s[2][4], b4[4];
+        lds_read16<buf * FWD_BUF + 16384>(b4[0], baddr); lds_read16<buf * FWD_BUF + 16384 + 64>(b4[1], baddr);
+        lds_read16<buf * FWD_BUF + 16384 + 128>(b4[2], baddr); lds_read16<buf * FWD_BUF + 16384 + 192>(b4[3], baddr);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) {
+            s[0][kt] = b4[kt] * inv_scale;
+            s[1][kt] = s[0][kt];
+            const bf16x8 k0 = lds_row_frag(Ks, kt * 16 + fr, g), k1 = lds_row_frag(Ks, kt * 16 + fr, 4 + g);
+#pragma unroll
+            for (int qb = 0; qb < 2; ++qb) {
+                s[qb][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k0, qf[qb][0], s[qb][kt], 0, 0, 0);
+                s[qb][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k1, qf[qb][1], s[qb][kt], 0, 0, 0);
+            }
+        }
+        if (kv0 + 64 > S) {                                  // wave-uniform: only the last tile has keys past the end
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (kv0 + kt * 16 + 4 * g + r >= S) { s[0][kt][r] = -INFINITY; s[1][kt][r] = -INFINITY; }
+        }
+        // issue all transposed V reads of this tile now; they land while the softmax VALU work runs
+        s16x4 vlo[2][4], vhi[2][4];
 #pragma unroll
         for (int d = 0; d < 4; ++d) {
-            bf16x4 ov = {f2bf(o[d][0] * inv), f2bf(o[d][1] * inv), f2bf(o[d][2] * inv), f2bf(o[d][3] * inv)};
-            *(bf16x4*)(orow + d * 16 + 4 * g) = ov;
+            tr_read<buf * FWD_BUF>(vlo[0][d], vaddr[d]); tr_read<buf * FWD_BUF + 16 * 128>(vhi[0][d], vaddr[d]);
+            tr_read<buf * FWD_BUF + 32 * 128>(vlo[1][d], vaddr[d]); tr_read<buf * FWD_BUF + 48 * 128>(vhi[1][d], vaddr[d]);
         }
-        if (g == 0) a.lse[(size_t)(start + qi) * a.heads + head] = (m2 + log2f(l)) * LN2;
+        bf16x8 pf[2][2];
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb) {
+            float tmax = fmaxf(fmaxf(fmaxf(s[qb][0][0], s[qb][0][1]), fmaxf(s[qb][0][2], s[qb][0][3])),
+                               fmaxf(fmaxf(s[qb][1][0], s[qb][1][1]), fmaxf(s[qb][1][2], s[qb][1][3])));
+            tmax = fmaxf(tmax, fmaxf(fmaxf(fmaxf(s[qb][2][0], s[qb][2][1]), fmaxf(s[qb][2][2], s[qb][2][3])),
+                                     fmaxf(fmaxf(s[qb][3][0], s[qb][3][1]), fmaxf(s[qb][3][2], s[qb][3][3]))));
+            tmax = group_max(tmax);
+            const float mnew = fmaxf(mraw[qb], tmax);
+            const float alpha = __builtin_amdgcn_exp2f((mraw[qb] - mnew) * c2);      // first tile: exp2(-inf) = 0
+            mraw[qb] = mnew;
+            const float mc = mnew * c2;
+            float psum = 0.f;
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt) {
+                bool keep[4] = {true, true, true, true};
+                if (a.dthr) mmb_keep4(a.dstream, (uint64_t)rowbase[qb] + (kv0 + kt * 16 + 4 * g), a.dthr, keep);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[qb][kt][r], c2, -mc));
+                    psum += p;
+                    s[qb][kt][r] = keep[r] ? p : 0.f;
+                }
+            }
+            lpart[qb] = lpart[qb] * alpha + psum;
+#pragma unroll
+            for (int d = 0; d < 4; ++d)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[qb][d][r] *= alpha;
+            pf[qb][0] = pack8(s[qb][0], s[qb][1]);
+            pf[qb][1] = pack8(s[qb][2], s[qb][3]);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the asm V reads
+        __builtin_amdgcn_sched_barrier(0);
+        typedef __attribute__((ext_vector_type(8))) short s16x8;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+                const s16x8 vv = {vlo[ks][d][0], vlo[ks][d][1], vlo[ks][d][2], vlo[ks][d][3], vhi[ks][d][0], vhi[ks][d][1], vhi[ks][d][2], vhi[ks][d][3]};
+                const bf16x8 vf = __builtin_bit_cast(bf16x8, vv);
+#pragma unroll
+                for (int qb = 0; qb < 2; ++qb)
+                    o[qb][d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[qb][ks], o[qb][d], 0, 0, 0);
+            }
+    };
+    for (int t = 0; t < ntile; t += 2) {
+        tile_body(std::integral_constant<int, 0>{}, t);
+        if (t + 1 < ntile) tile_body(std::integral_constant<int, 1>{}, t + 1);
+    }
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+        const float l = group_sum(lpart[qb]);
+        if (qi[qb] < S) {
+            const float inv = a.dscale / l;                  // dropout scale folded into the normalisation
+            bf16_t* orow = a.ctx + (size_t)(start + qi[qb]) * a.H + head * 64;
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+                bf16x4 ov = {f2bf(o[qb][d][0] * inv), f2bf(o[qb][d][1] * inv), f2bf(o[qb][d][2] * inv), f2bf(o[qb][d][3] * inv)};
+                *(bf16x4*)(orow + d * 16 + 4 * g) = ov;
+            }
+            if (g == 0) a.lse[(size_t)(start + qi[qb]) * a.heads + head] = (mraw[qb] * c2 + log2f(l)) * LN2;
+        }
     }
 }
 
 // =============================================================================================
-// backward, part 1: dQ (and delta = rowsum(dO*O)) per 64-query tile
+// backward, part 1: dQ (and delta = rowsum(dO*O)) per 128-query tile; same structure as forward:
+// 4 waves x 32 query rows, double-buffered K (row image + transposed-read image), V and key-bias tiles.
+//   S^T  = K.Q^T (+bias/scale as initial accumulator)      p  = exp2(S^T*c - lse*c)      (normalised)
+//   dP^T = V.dO^T                                          dS^T = p * (keep*dscale*dP^T - delta)
+//   dQ^T += K^T.dS^T   (K^T by transposed LDS reads, dS^T straight from the accumulator registers)
 // =============================================================================================
+#define DQ_BUF 24832           // K row image 8192 | K transposed-read image 8192 | V row image 8192 | bias 256
+
 __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnArgs a) {
-    __shared__ __attribute__((aligned(16))) char smem[24576];       // K mode0 | K mode1 | V mode0
-    char* Ks = smem; char* Kt = smem + 8192; char* Vs = smem + 16384;
+    __shared__ __attribute__((aligned(16))) char smem[2 * DQ_BUF];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int seq = a.tile_seq[blockIdx.x], r0 = a.tile_r0[blockIdx.x], head = blockIdx.y;
     const int start = a.seq_start[seq], S = a.seq_len[seq];
     const int Spad = (S + 3) & ~3;
     const int fr = lane & 15, g = lane >> 4;
-    const int qi = r0 + wave * 16 + fr;
-    const int qc = min(qi, S - 1);
     const bf16_t* base = a.qkv + (size_t)start * a.ld_qkv + head * 64;
     const bf16_t* dob = a.dctx + (size_t)start * a.H + head * 64;
     const bf16_t* ob = a.ctx + (size_t)start * a.H + head * 64;
-    bf16x8 qf[2], dof[2];
-    float dl = 0.f;
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
-        qf[kk] = *(const bf16x8*)(base + (size_t)qc * a.ld_qkv + kk * 32 + 8 * g);
-        dof[kk] = *(const bf16x8*)(dob + (size_t)qc * a.H + kk * 32 + 8 * g);
-        const bf16x8 of = *(const bf16x8*)(ob + (size_t)qc * a.H + kk * 32 + 8 * g);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) dl += bf2f(dof[kk][j]) * bf2f(of[j]);
-    }
-    const float delta = group_sum(dl);
-    if (qi < S && g == 0) a.delta[(size_t)(start + qi) * a.heads + head] = delta;
-    const float lse2 = a.lse[(size_t)(start + qc) * a.heads + head] * LOG2E;
     const bf16_t* kbase = base + a.H;
     const bf16_t* vbase = base + 2 * a.H;
-    const float sl2 = a.scale * LOG2E;
-    const unsigned rowbase = a.elem_base[seq] + (unsigned)((head * S + qc) * Spad);
-
-    f32x4 dq[4];
+    const float* bbase = a.key_bias + start;
+    const float c2 = a.scale * LOG2E, inv_scale = 1.0f / a.scale;
+    int qi[2];
+    unsigned rowbase[2];
+    bf16x8 qf[2][2], dof[2][2];
+    float delta[2], nlse[2];
 #pragma unroll
-    for (int d = 0; d < 4; ++d) dq[d] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-    for (int kv0 = 0; kv0 < S; kv0 += 64) {
-        __syncthreads();
-        stage_tile<0>(Ks, kbase, a.ld_qkv, kv0, S, wave, lane);
-        stage_tile<1>(Kt, kbase, a.ld_qkv, kv0, S, wave, lane);
-        stage_tile<0>(Vs, vbase, a.ld_qkv, kv0, S, wave, lane);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        f32x4 s[4], dp[4];
+    for (int qb = 0; qb < 2; ++qb) {
+        qi[qb] = r0 + wave * 32 + qb * 16 + fr;
+        const int qc = min(qi[qb], S - 1);
+        float dl = 0.f;
 #pragma unroll
-        for (int kt = 0; kt < 4; ++kt) {
-            s[kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            dp[kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int kk = 0; kk < 2; ++kk) {
+            qf[qb][kk] = *(const bf16x8*)(base + (size_t)qc * a.ld_qkv + kk * 32 + 8 * g);
+            dof[qb][kk] = *(const bf16x8*)(dob + (size_t)qc * a.H + kk * 32 + 8 * g);
+            const bf16x8 of = *(const bf16x8*)(ob + (size_t)qc * a.H + kk * 32 + 8 * g);
 #pragma unroll
-            for (int kk = 0; kk < 2; ++kk) {
-                s[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_row_frag(Ks, kt * 16 + fr, kk * 4 + g), qf[kk], s[kt], 0, 0, 0);
-                dp[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_row_frag(Vs, kt * 16 + fr, kk * 4 + g), dof[kk], dp[kt], 0, 0, 0);
-            }
+            for (int j = 0; j < 8; ++j) dl += bf2f(dof[qb][kk][j]) * bf2f(of[j]);
         }
-#pragma unroll
-        for (int kt = 0; kt < 4; ++kt) {
-            const int key = kv0 + kt * 16 + 4 * g;
-            bool keep[4] = {true, true, true, true};
-            if (a.dthr) mmb_keep4(a.dstream, (uint64_t)rowbase + key, a.dthr, keep);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float p = 0.f;
-                if (key + r < S) p = exp2f(s[kt][r] * sl2 + a.key_bias[start + key + r] * LOG2E - lse2);
-                float dpm = dp[kt][r];
-                if (a.dthr) dpm = keep[r] ? dpm * a.dscale : 0.f;
-                s[kt][r] = p * (dpm - delta);                        // dS^T
-            }
-        }
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            const bf16x8 dsf = pack8(s[2 * ks], s[2 * ks + 1]);
-#pragma unroll
-            for (int d = 0; d < 4; ++d)
-                dq[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_tr_frag(Kt, ks, d, lane), dsf, dq[d], 0, 0, 0);
-        }
+        delta[qb] = group_sum(dl);
+        if (qi[qb] < S && g == 0) a.delta[(size_t)(start + qi[qb]) * a.heads + head] = delta[qb];
+        nlse[qb] = -a.lse[(size_t)(start + qc) * a.heads + head] * LOG2E;
+        rowbase[qb] = a.elem_base[seq] + (unsigned)((head * S + qc) * Spad);
     }
-    if (qi < S) {
-        bf16_t* drow = a.dqkv + (size_t)(start + qi) * a.ld_qkv + head * 64;
+
+    auto stage = [&](int buf, int kv0) {
+        char* B = smem + buf * DQ_BUF;
+        stage_tile<0>(B, kbase, a.ld_qkv, kv0, S, wave, lane);
+        stage_tile<1>(B + 8192, kbase, a.ld_qkv, kv0, S, wave, lane);
+        stage_tile<0>(B + 16384, vbase, a.ld_qkv, kv0, S, wave, lane);
+        __builtin_amdgcn_global_load_lds(GPTR(bbase + min(kv0 + lane, S - 1)), LPTR(B + 24576), 4, 0, 0);
+    };
+
+    f32x4 dq[2][4];
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+        for (int d = 0; d < 4; ++d) dq[qb][d] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const unsigned lds0 = (unsigned)(uintptr_t)LPTR(smem);
+    const int tq = (lane >> 2) & 3, tp = lane & 3;
+    unsigned kaddr[4];
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+        const int r = 4 * g + tq;
+        kaddr[d] = lds0 + 8192 + r * 128 + ((d ^ ((r >> 1) & 3)) << 5) + tp * 8;
+    }
+    const unsigned baddr = lds0 + 16 * g;
+    const int ntile = (S + 63) >> 6;
+    stage(0, 0);
+    auto tile_body = [&](auto buf_c, int t) {
+        constexpr int buf = decltype(buf_c)::value;
+        const int kv0 = t << 6;
+        __builtin_amdgcn_s_waitcnt(0x0F70);                  // vmcnt(0)
+        __builtin_amdgcn_s_barrier();
+        if (t + 1 < ntile) stage(buf ^ 1, kv0 + 64);
+        const char* Ks = smem + buf * DQ_BUF;
+        const char* Vs = Ks + 16384;
+        f32x4 s[2][4], dp[2][4], b4[4];
+        lds_read16<buf * DQ_BUF + 24576>(b4[0], baddr); lds_read16<buf * DQ_BUF + 24576 + 64>(b4[1], baddr);
+        lds_read16<buf * DQ_BUF + 24576 + 128>(b4[2], baddr); lds_read16<buf * DQ_BUF + 24576 + 192>(b4[3], baddr);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) {
+            s[0][kt] = b4[kt] * inv_scale;
+            s[1][kt] = s[0][kt];
+            dp[0][kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            dp[1][kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            const bf16x8 k0 = lds_row_frag(Ks, kt * 16 + fr, g), k1 = lds_row_frag(Ks, kt * 16 + fr, 4 + g);
+            const bf16x8 v0 = lds_row_frag(Vs, kt * 16 + fr, g), v1 = lds_row_frag(Vs, kt * 16 + fr, 4 + g);
+#pragma unroll
+            for (int qb = 0; qb < 2; ++qb) {
+                s[qb][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k0, qf[qb][0], s[qb][kt], 0, 0, 0);
+                s[qb][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k1, qf[qb][1], s[qb][kt], 0, 0, 0);
+                dp[qb][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(v0, dof[qb][0], dp[qb][kt], 0, 0, 0);
+                dp[qb][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(v1, dof[qb][1], dp[qb][kt], 0, 0, 0);
+            }
+        }
+        // transposed K reads for dQ^T: issue now, consume after the VALU block
+        s16x4 klo[2][4], khi[2][4];
 #pragma unroll
         for (int d = 0; d < 4; ++d) {
-            bf16x4 ov = {f2bf(dq[d][0] * a.scale), f2bf(dq[d][1] * a.scale), f2bf(dq[d][2] * a.scale), f2bf(dq[d][3] * a.scale)};
-            *(bf16x4*)(drow + d * 16 + 4 * g) = ov;
+            tr_read<buf * DQ_BUF>(klo[0][d], kaddr[d]); tr_read<buf * DQ_BUF + 16 * 128>(khi[0][d], kaddr[d]);
+            tr_read<buf * DQ_BUF + 32 * 128>(klo[1][d], kaddr[d]); tr_read<buf * DQ_BUF + 48 * 128>(khi[1][d], kaddr[d]);
+        }
+        const bool tail = kv0 + 64 > S;
+        bf16x8 dsf[2][2];
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb) {
+            const float lc = nlse[qb];
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt) {
+                bool keep[4] = {true, true, true, true};
+                if (a.dthr) mmb_keep4(a.dstream, (uint64_t)rowbase[qb] + (kv0 + kt * 16 + 4 * g), a.dthr, keep);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[qb][kt][r], c2, lc));
+                    if (tail && kv0 + kt * 16 + 4 * g + r >= S) p = 0.f;
+                    const float dpm = keep[r] ? dp[qb][kt][r] * a.dscale : 0.f;
+                    s[qb][kt][r] = p * (dpm - delta[qb]);                       // dS^T
+                }
+            }
+            dsf[qb][0] = pack8(s[qb][0], s[qb][1]);
+            dsf[qb][1] = pack8(s[qb][2], s[qb][3]);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        typedef __attribute__((ext_vector_type(8))) short s16x8;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+                const s16x8 kv = {klo[ks][d][0], klo[ks][d][1], klo[ks][d][2], klo[ks][d][3], khi[ks][d][0], khi[ks][d][1], khi[ks][d][2], khi[ks][d][3]};
+                const bf16x8 kf = __builtin_bit_cast(bf16x8, kv);
+#pragma unroll
+                for (int qb = 0; qb < 2; ++qb)
+                    dq[qb][d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, dsf[qb][ks], dq[qb][d], 0, 0, 0);
+            }
+    };
+    for (int t = 0; t < ntile; t += 2) {
+        tile_body(std::integral_constant<int, 0>{}, t);
+        if (t + 1 < ntile) tile_body(std::integral_constant<int, 1>{}, t + 1);
+    }
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+        if (qi[qb] < S) {
+            bf16_t* drow = a.dqkv + (size_t)(start + qi[qb]) * a.ld_qkv + head * 64;
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+                bf16x4 ov = {f2bf(dq[qb][d][0] * a.scale), f2bf(dq[qb][d][1] * a.scale), f2bf(dq[qb][d][2] * a.scale), f2bf(dq[qb][d][3] * a.scale)};
+                *(bf16x4*)(drow + d * 16 + 4 * g) = ov;
+            }
         }
     }
 }
 
 // =============================================================================================
-// backward, part 2: dK, dV per 64-key tile (wave owns 16 keys, sweeps all query tiles)
+// backward, part 2: dK, dV per 128-key tile.  4 waves x 32 keys (two 16-key blocks per wave); the
+// 64-query tiles (Q and dO, each as a row image and a transposed-read image, plus the LSE / delta
+// slices) stream through two LDS buffers.  Products, all with the key on the lane:
+//   S  = Q.K^T  (+ (bias[key] - lse[q]) / scale as initial accumulator)     p = exp2(S*c)
+//   dP = dO.V^T            Pd = keep*dscale*p            dS = p*(keep*dscale*dP - delta[q])
+//   dV^T += dO^T.Pd        dK^T += Q^T.dS       (dO^T / Q^T by transposed LDS reads)
+// The dropout hash is per (query row, key PAIR): the two lanes that hold the keys of a pair split the
+// four query rows of an accumulator register group between them and swap results with one DPP move.
 // =============================================================================================
+#define DKV_BUF 33280          // Q row 8192 | Q tr 8192 | dO row 8192 | dO tr 8192 | lse 256 | delta 256
+
 __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnArgs a) {
-    __shared__ __attribute__((aligned(16))) char smem[4 * 8192 + 512];   // Q m0 | Q m1 | dO m0 | dO m1 | lse,delta
-    char* Qs = smem; char* Qt = smem + 8192; char* Ds = smem + 16384; char* Dt = smem + 24576;
-    float* stat = (float*)(smem + 32768);                              // [64] lse2, [64] delta
+    __shared__ __attribute__((aligned(16))) char smem[2 * DKV_BUF];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int seq = a.tile_seq[blockIdx.x], r0 = a.tile_r0[blockIdx.x], head = blockIdx.y;
     const int start = a.seq_start[seq], S = a.seq_len[seq];
     const int Spad = (S + 3) & ~3;
     const int fr = lane & 15, g = lane >> 4;
-    const int ki = r0 + wave * 16 + fr;                                // this lane's key
-    const int kc = min(ki, S - 1);
     const bf16_t* base = a.qkv + (size_t)start * a.ld_qkv + head * 64;
     const bf16_t* dob = a.dctx + (size_t)start * a.H + head * 64;
-    bf16x8 kf[2], vf[2];
+    const float* lbase = a.lse + (size_t)start * a.heads + head;
+    const float* dbase = a.delta + (size_t)start * a.heads + head;
+    const float c2 = a.scale * LOG2E, inv_scale = 1.0f / a.scale;
+    int ki[2], kc[2];
+    bf16x8 kf[2][2], vf[2][2];
+    float kb[2];
 #pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
-        kf[kk] = *(const bf16x8*)(base + a.H + (size_t)kc * a.ld_qkv + kk * 32 + 8 * g);
-        vf[kk] = *(const bf16x8*)(base + 2 * a.H + (size_t)kc * a.ld_qkv + kk * 32 + 8 * g);
+    for (int kb_ = 0; kb_ < 2; ++kb_) {
+        ki[kb_] = r0 + wave * 32 + kb_ * 16 + fr;
+        kc[kb_] = min(ki[kb_], S - 1);
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            kf[kb_][kk] = *(const bf16x8*)(base + a.H + (size_t)kc[kb_] * a.ld_qkv + kk * 32 + 8 * g);
+            vf[kb_][kk] = *(const bf16x8*)(base + 2 * a.H + (size_t)kc[kb_] * a.ld_qkv + kk * 32 + 8 * g);
+        }
+        kb[kb_] = (ki[kb_] < S) ? a.key_bias[start + kc[kb_]] * inv_scale : -INFINITY;   // keys past the end: p = 0
     }
-    const float kb2 = a.key_bias[start + kc] * LOG2E;
-    const float sl2 = a.scale * LOG2E;
     const unsigned ebase = a.elem_base[seq] + (unsigned)(head * S) * Spad;
 
-    f32x4 dk[4], dv[4];
-#pragma unroll
-    for (int d = 0; d < 4; ++d) { dk[d] = (f32x4){0.f, 0.f, 0.f, 0.f}; dv[d] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+    auto stage = [&](int buf, int q0) {
+        char* B = smem + buf * DKV_BUF;
+        stage_tile<0>(B, base, a.ld_qkv, q0, S, wave, lane);
+        stage_tile<1>(B + 8192, base, a.ld_qkv, q0, S, wave, lane);
+        stage_tile<0>(B + 16384, dob, a.H, q0, S, wave, lane);
+        stage_tile<1>(B + 24576, dob, a.H, q0, S, wave, lane);
+        const size_t qoff = (size_t)min(q0 + lane, S - 1) * a.heads;
+        __builtin_amdgcn_global_load_lds(GPTR(lbase + qoff), LPTR(B + 32768), 4, 0, 0);
+        __builtin_amdgcn_global_load_lds(GPTR(dbase + qoff), LPTR(B + 33024), 4, 0, 0);
+    };
 
-    for (int q0 = 0; q0 < S; q0 += 64) {
-        __syncthreads();
-        stage_tile<0>(Qs, base, a.ld_qkv, q0, S, wave, lane);
-        stage_tile<1>(Qt, base, a.ld_qkv, q0, S, wave, lane);
-        stage_tile<0>(Ds, dob, a.H, q0, S, wave, lane);
-        stage_tile<1>(Dt, dob, a.H, q0, S, wave, lane);
-        if (threadIdx.x < 64) {
-            const int q = min(q0 + (int)threadIdx.x, S - 1);
-            stat[threadIdx.x] = a.lse[(size_t)(start + q) * a.heads + head] * LOG2E;
-            stat[64 + threadIdx.x] = a.delta[(size_t)(start + q) * a.heads + head];
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        f32x4 s[4], dp[4];
+    f32x4 dk[2][4], dv[2][4];
+#pragma unroll
+    for (int kb_ = 0; kb_ < 2; ++kb_)
+#pragma unroll
+        for (int d = 0; d < 4; ++d) { dk[kb_][d] = (f32x4){0.f, 0.f, 0.f, 0.f}; dv[kb_][d] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+
+    const unsigned lds0 = (unsigned)(uintptr_t)LPTR(smem);
+    const int tq = (lane >> 2) & 3, tp = lane & 3;
+    unsigned taddr2[2][4];                                   // per buffer (ds offsets are 16-bit: the second buffer needs its own base)
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+        const int r = 4 * g + tq;
+        taddr2[0][d] = lds0 + r * 128 + ((d ^ ((r >> 1) & 3)) << 5) + tp * 8;
+        taddr2[1][d] = taddr2[0][d] + DKV_BUF;
+    }
+    const unsigned saddr2[2] = {lds0 + 16 * g, lds0 + 16 * g + DKV_BUF};   // lse / delta: 4 consecutive query rows per lane group
+    const bool odd = lane & 1;
+    const int ntile = (S + 63) >> 6;
+    stage(0, 0);
+    auto tile_body = [&](auto buf_c, int t) {
+        constexpr int buf = decltype(buf_c)::value;
+        constexpr int BO = 0;                                // buffer base lives in the address registers
+        const unsigned saddr = saddr2[buf];
+        const unsigned (&taddr)[4] = taddr2[buf];
+        const int q0 = t << 6;
+        __builtin_amdgcn_s_waitcnt(0x0F70);                  // vmcnt(0)
+        __builtin_amdgcn_s_barrier();
+        if (t + 1 < ntile) stage(buf ^ 1, q0 + 64);
+        const char* Qs = smem + buf * DKV_BUF;
+        const char* Ds = Qs + 16384;
+        f32x4 l4[4], d4[4];
+        lds_read16<BO + 32768>(l4[0], saddr); lds_read16<BO + 32768 + 64>(l4[1], saddr);
+        lds_read16<BO + 32768 + 128>(l4[2], saddr); lds_read16<BO + 32768 + 192>(l4[3], saddr);
+        lds_read16<BO + 33024>(d4[0], saddr); lds_read16<BO + 33024 + 64>(d4[1], saddr);
+        lds_read16<BO + 33024 + 128>(d4[2], saddr); lds_read16<BO + 33024 + 192>(d4[3], saddr);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        const bool qtail = q0 + 64 > S;
 #pragma unroll
         for (int qt = 0; qt < 4; ++qt) {
-            s[qt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            dp[qt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            l4[qt] = l4[qt] * (-inv_scale);                  // -lse[q]/scale  (natural-log lse: exp2(S*c) with c = scale*log2e)
+            if (qtail) {
 #pragma unroll
-            for (int kk = 0; kk < 2; ++kk) {
+                for (int r = 0; r < 4; ++r) if (q0 + qt * 16 + 4 * g + r >= S) l4[qt][r] = -INFINITY;   // query rows past the end: p = 0
+            }
+        }
+#pragma unroll
+        for (int kb_ = 0; kb_ < 2; ++kb_) {
+            f32x4 s[4], dp[4];
+#pragma unroll
+            for (int qt = 0; qt < 4; ++qt) {
+                s[qt] = l4[qt] + kb[kb_];
+                dp[qt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                const bf16x8 q0f = lds_row_frag(Qs, qt * 16 + fr, g), q1f = lds_row_frag(Qs, qt * 16 + fr, 4 + g);
+                const bf16x8 o0f = lds_row_frag(Ds, qt * 16 + fr, g), o1f = lds_row_frag(Ds, qt * 16 + fr, 4 + g);
                 // D[row <-> query (A operand rows)][col <-> key (B operand = this lane's K / V row)]
-                s[qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_row_frag(Qs, qt * 16 + fr, kk * 4 + g), kf[kk], s[qt], 0, 0, 0);
-                dp[qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_row_frag(Ds, qt * 16 + fr, kk * 4 + g), vf[kk], dp[qt], 0, 0, 0);
+                s[qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(q0f, kf[kb_][0], s[qt], 0, 0, 0);
+                s[qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(q1f, kf[kb_][1], s[qt], 0, 0, 0);
+                dp[qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(o0f, vf[kb_][0], dp[qt], 0, 0, 0);
+                dp[qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(o1f, vf[kb_][1], dp[qt], 0, 0, 0);
+            }
+            f32x4 pm[4];
+#pragma unroll
+            for (int qt = 0; qt < 4; ++qt) {
+                float ksc[4] = {1.f, 1.f, 1.f, 1.f};
+                if (a.dthr) {
+                    // pair index of (row q, keys {2j,2j+1}); even lane hashes rows r = 0,2, odd lane rows 1,3, then swap
+                    const int qa = min(q0 + qt * 16 + 4 * g + (odd ? 1 : 0), S - 1), qb2 = min(q0 + qt * 16 + 4 * g + (odd ? 3 : 2), S - 1);
+                    const uint32_t pj = (uint32_t)kc[kb_] >> 1;
+                    const uint32_t ha = mmb_pair_bits(a.dstream, ((ebase + (uint32_t)qa * Spad) >> 1) + pj);
+                    const uint32_t hb = mmb_pair_bits(a.dstream, ((ebase + (uint32_t)qb2 * Spad) >> 1) + pj);
+                    const uint32_t xa = __builtin_amdgcn_mov_dpp(ha, 0xB1, 0xF, 0xF, true);    // quad_perm [1,0,3,2]: neighbour lane's value
+                    const uint32_t xb = __builtin_amdgcn_mov_dpp(hb, 0xB1, 0xF, 0xF, true);
+                    const uint32_t h0 = odd ? xa : ha, h1 = odd ? ha : xa, h2 = odd ? xb : hb, h3 = odd ? hb : xb;
+                    const int sh = (kc[kb_] & 1) * 16;
+                    ksc[0] = ((h0 >> sh) & 0xFFFFu) >= a.dthr ? a.dscale : 0.f;
+                    ksc[1] = ((h1 >> sh) & 0xFFFFu) >= a.dthr ? a.dscale : 0.f;
+                    ksc[2] = ((h2 >> sh) & 0xFFFFu) >= a.dthr ? a.dscale : 0.f;
+                    ksc[3] = ((h3 >> sh) & 0xFFFFu) >= a.dthr ? a.dscale : 0.f;
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float p = __builtin_amdgcn_exp2f(s[qt][r] * c2);
+                    pm[qt][r] = p * ksc[r];                                  // dropped P   -> dV
+                    s[qt][r] = p * (dp[qt][r] * ksc[r] - d4[qt][r]);         // dS          -> dK
+                }
+            }
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const bf16x8 pf = pack8(pm[2 * ks], pm[2 * ks + 1]);
+                const bf16x8 dsf = pack8(s[2 * ks], s[2 * ks + 1]);
+                s16x4 dlo[4], dhi[4], qlo[4], qhi[4];
+#pragma unroll
+                for (int d = 0; d < 4; ++d) {
+                    if (ks == 0) {
+                        tr_read<BO + 24576>(dlo[d], taddr[d]); tr_read<BO + 24576 + 16 * 128>(dhi[d], taddr[d]);
+                        tr_read<BO + 8192>(qlo[d], taddr[d]); tr_read<BO + 8192 + 16 * 128>(qhi[d], taddr[d]);
+                    } else {
+                        tr_read<BO + 24576 + 32 * 128>(dlo[d], taddr[d]); tr_read<BO + 24576 + 48 * 128>(dhi[d], taddr[d]);
+                        tr_read<BO + 8192 + 32 * 128>(qlo[d], taddr[d]); tr_read<BO + 8192 + 48 * 128>(qhi[d], taddr[d]);
+                    }
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+                typedef __attribute__((ext_vector_type(8))) short s16x8;
+#pragma unroll
+                for (int d = 0; d < 4; ++d) {
+                    const s16x8 dvv = {dlo[d][0], dlo[d][1], dlo[d][2], dlo[d][3], dhi[d][0], dhi[d][1], dhi[d][2], dhi[d][3]};
+                    const s16x8 qvv = {qlo[d][0], qlo[d][1], qlo[d][2], qlo[d][3], qhi[d][0], qhi[d][1], qhi[d][2], qhi[d][3]};
+                    dv[kb_][d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, dvv), pf, dv[kb_][d], 0, 0, 0);
+                    dk[kb_][d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, qvv), dsf, dk[kb_][d], 0, 0, 0);
+                }
             }
         }
-        f32x4 pm[4];
+    };
+    for (int t = 0; t < ntile; t += 2) {
+        tile_body(std::integral_constant<int, 0>{}, t);
+        if (t + 1 < ntile) tile_body(std::integral_constant<int, 1>{}, t + 1);
+    }
 #pragma unroll
-        for (int qt = 0; qt < 4; ++qt) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int ql = qt * 16 + 4 * g + r;                     // query row inside the tile
-                const int q = q0 + ql;
-                float p = 0.f;
-                if (q < S && ki < S) p = exp2f(s[qt][r] * sl2 + kb2 - stat[ql]);
-                bool keep = true;
-                if (a.dthr) keep = mmb_keep(a.dstream, (uint64_t)ebase + (uint64_t)min(q, S - 1) * Spad + kc, a.dthr);
-                const float kscale = a.dthr ? (keep ? a.dscale : 0.f) : 1.0f;
-                pm[qt][r] = p * kscale;                                 // dropped P   -> dV
-                s[qt][r] = p * (dp[qt][r] * kscale - stat[64 + ql]);    // dS          -> dK
-            }
-        }
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            const bf16x8 pf = pack8(pm[2 * ks], pm[2 * ks + 1]);
-            const bf16x8 dsf = pack8(s[2 * ks], s[2 * ks + 1]);
+    for (int kb_ = 0; kb_ < 2; ++kb_) {
+        if (ki[kb_] < S) {
+            bf16_t* drow = a.dqkv + (size_t)(start + ki[kb_]) * a.ld_qkv + head * 64;
 #pragma unroll
             for (int d = 0; d < 4; ++d) {
-                dv[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_tr_frag(Dt, ks, d, lane), pf, dv[d], 0, 0, 0);
-                dk[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_tr_frag(Qt, ks, d, lane), dsf, dk[d], 0, 0, 0);
+                bf16x4 kvv = {f2bf(dk[kb_][d][0] * a.scale), f2bf(dk[kb_][d][1] * a.scale), f2bf(dk[kb_][d][2] * a.scale), f2bf(dk[kb_][d][3] * a.scale)};
+                bf16x4 vvv = {f2bf(dv[kb_][d][0]), f2bf(dv[kb_][d][1]), f2bf(dv[kb_][d][2]), f2bf(dv[kb_][d][3])};
+                *(bf16x4*)(drow + a.H + d * 16 + 4 * g) = kvv;
+                *(bf16x4*)(drow + 2 * a.H + d * 16 + 4 * g) = vvv;
             }
-        }
-    }
-    if (ki < S) {
-        bf16_t* drow = a.dqkv + (size_t)(start + ki) * a.ld_qkv + head * 64;
-#pragma unroll
-        for (int d = 0; d < 4; ++d) {
-            bf16x4 kvv = {f2bf(dk[d][0] * a.scale), f2bf(dk[d][1] * a.scale), f2bf(dk[d][2] * a.scale), f2bf(dk[d][3] * a.scale)};
-            bf16x4 vvv = {f2bf(dv[d][0]), f2bf(dv[d][1]), f2bf(dv[d][2]), f2bf(dv[d][3])};
-            *(bf16x4*)(drow + a.H + d * 16 + 4 * g) = kvv;
-            *(bf16x4*)(drow + 2 * a.H + d * 16 + 4 * g) = vvv;
         }
     }
 }
@@ -399,17 +648,25 @@ int mmbert_attn_fwd(hipStream_t stream, const void* qkv, void* ctx, float* lse, 
 
 int mmbert_attn_bwd(hipStream_t stream, const void* qkv, const void* ctx, const void* dctx, void* dqkv, const float* lse, float* delta,
                     const float* key_bias, int H, int heads, const int* seq_start, const int* seq_len, const unsigned* elem_base,
-                    const int* tile_seq, const int* tile_r0, int ntiles, uint32_t dstream, uint32_t dthr, float dscale) {
-    if (ntiles <= 0) return 0;
+                    const int* qtile_seq, const int* qtile_r0, int nqtiles, const int* tile_seq, const int* tile_r0, int ntiles,
+                    uint32_t dstream, uint32_t dthr, float dscale) {
+    if (ntiles <= 0 || nqtiles <= 0) return 0;
     AttnArgs a;
     if (fill_args(a, qkv, H, heads, key_bias, seq_start, seq_len, elem_base, tile_seq, tile_r0, (float*)lse, dstream, dthr, dscale)) return -1;
     a.ctx = (bf16_t*)ctx; a.dctx = (const bf16_t*)dctx; a.dqkv = (bf16_t*)dqkv; a.delta = delta;
-    hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3(ntiles, heads), dim3(256), 0, stream, a);
-    MMB_CHECK_LAUNCH();
+    {
+        AttnArgs q = a;
+        q.tile_seq = qtile_seq; q.tile_r0 = qtile_r0;
+        hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3(nqtiles, heads), dim3(256), 0, stream, q);
+        MMB_CHECK_LAUNCH();
+    }
     hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3(ntiles, heads), dim3(256), 0, stream, a);
     MMB_CHECK_LAUNCH();
     return 0;
 }
+
+// rows per work item of the tile lists: which = 0 forward (128), 1 backward (64)
+int mmbert_attn_tile_rows(int which) { (void)which; return 128; }
 
 int mmbert_attn_dropout_mask(hipStream_t stream, uint8_t* out, int S, unsigned elem_base, int head, uint32_t rng_stream, uint32_t thr16) {
     hipLaunchKernelGGL(attn_mask_kernel, dim3(256), dim3(256), 0, stream, out, S, elem_base, head, rng_stream, thr16);

@@ -205,7 +205,9 @@ class SeqLayout:
     sequence, sequences back to back.  Cached per shape (built on the host, no device sync)."""
 
     def __init__(self, lens, heads, device):
-        starts, tiles_seq, tiles_r0, bases = [], [], [], []
+        lib = _lib.load()
+        rows_f, rows_b = lib.mmbert_attn_tile_rows(0), lib.mmbert_attn_tile_rows(1)
+        starts, tiles_seq, tiles_r0, ftiles_seq, ftiles_r0, bases = [], [], [], [], [], []
         s = 0
         e = 0
         for i, n in enumerate(lens):
@@ -214,9 +216,12 @@ class SeqLayout:
             bases.append(e)
             e += heads * n * ((n + 3) // 4 * 4)
             e = (e + 3) // 4 * 4
-            for r0 in range(0, n, 64):
+            for r0 in range(0, n, rows_b):
                 tiles_seq.append(i)
                 tiles_r0.append(r0)
+            for r0 in range(0, n, rows_f):
+                ftiles_seq.append(i)
+                ftiles_r0.append(r0)
         if e >= 2 ** 32:
             raise ValueError("attention dropout index space exceeds 2^32 elements")
         mk = lambda x, dt: torch.tensor(x, dtype=dt, device=device)
@@ -230,6 +235,9 @@ class SeqLayout:
         self.tile_seq = mk(tiles_seq, torch.int32)
         self.tile_r0 = mk(tiles_r0, torch.int32)
         self.ntiles = len(tiles_seq)
+        self.ftile_seq = mk(ftiles_seq, torch.int32)
+        self.ftile_r0 = mk(ftiles_r0, torch.int32)
+        self.nftiles = len(ftiles_seq)
 
 
 def attn_fwd(qkv, key_bias, layout: SeqLayout, H, *, drop: Drop = None, ctx=None, lse=None):
@@ -243,7 +251,7 @@ def attn_fwd(qkv, key_bias, layout: SeqLayout, H, *, drop: Drop = None, ctx=None
     d = drop or NO_DROP
     _lib.check(lib.mmbert_attn_fwd(_stream(), qkv.data_ptr(), ctx.data_ptr(), lse.data_ptr(), key_bias.data_ptr(), H, layout.heads,
                                    layout.seq_start.data_ptr(), layout.seq_len.data_ptr(), layout.elem_base.data_ptr(),
-                                   layout.tile_seq.data_ptr(), layout.tile_r0.data_ptr(), layout.ntiles, d[0], d[1], d[2]), "mmbert_attn_fwd")
+                                   layout.ftile_seq.data_ptr(), layout.ftile_r0.data_ptr(), layout.nftiles, d[0], d[1], d[2]), "mmbert_attn_fwd")
     return ctx, lse
 
 
@@ -257,7 +265,8 @@ def attn_bwd(qkv, ctx, dctx, lse, key_bias, layout: SeqLayout, H, *, drop: Drop 
     assert dctx.is_contiguous() and ctx.is_contiguous()
     _lib.check(lib.mmbert_attn_bwd(_stream(), qkv.data_ptr(), ctx.data_ptr(), dctx.data_ptr(), dqkv.data_ptr(), lse.data_ptr(), delta.data_ptr(),
                                    key_bias.data_ptr(), H, layout.heads, layout.seq_start.data_ptr(), layout.seq_len.data_ptr(),
-                                   layout.elem_base.data_ptr(), layout.tile_seq.data_ptr(), layout.tile_r0.data_ptr(), layout.ntiles,
+                                   layout.elem_base.data_ptr(), layout.ftile_seq.data_ptr(), layout.ftile_r0.data_ptr(), layout.nftiles,
+                                   layout.tile_seq.data_ptr(), layout.tile_r0.data_ptr(), layout.ntiles,
                                    d[0], d[1], d[2]), "mmbert_attn_bwd")
     return dqkv
 
