@@ -16,7 +16,7 @@ Extra objects on the JSON line:
                   step's FLOPs): algorithmic FLOPs of its launches / their summed durations, both
                   taken INSIDE the timed region with HIP events on the launch stream.
   cpu_baseline -- the CPU oracle (oracle/mmbert_oracle.py, kind "port") timed on this box's host
-                  cores on a bounded sample: the same model/shapes at batch 2, one fwd+bwd step.
+                  cores on a bounded sample: the same model/shapes at batch 4, one fwd+bwd step (~10 s on the box's 16-CPU quota).
 """
 import argparse
 import json
@@ -51,6 +51,7 @@ def main():
     ap.add_argument("--vocab", type=int, default=30522)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--overlap-wgrad", action="store_true", help="weight-gradient GEMMs on a side stream (measured slower)")
     ap.add_argument("--eval-dropout-off", action="store_true", help="diagnostic only: not a valid headline number")
     a = ap.parse_args()
 
@@ -74,6 +75,7 @@ def main():
     model.to(dev)
     model.train(not a.eval_dropout_off)
     model.manual_seed(1234 + rank)
+    model.overlap_wgrad = a.overlap_wgrad
     model.return_scores = True            # the reference returns the six score tensors; keep them materialised
     targs = default_args(train_batch_size=a.batch, learning_rate=5e-5)
     opt, sched = build_optimizer(model, targs, num_train_optimization_steps=10 * (a.steps + a.warmup))
@@ -98,6 +100,10 @@ def main():
     if not a.no_kernel_timing:
         ops.gemm_nt = wrap("nt", ops.gemm_nt, lambda A, B, **kw: 2.0 * A.shape[0] * A.shape[1] * B.shape[0])
         ops.gemm_tn = wrap("tn", ops.gemm_tn, lambda A, B, W, **kw: 2.0 * A.shape[0] * A.shape[1] * B.shape[1])
+        ops.gemm_tn_grouped = wrap("tn", ops.gemm_tn_grouped, lambda probs, **kw: sum(2.0 * p[0].shape[0] * p[0].shape[1] * p[1].shape[1] for p in probs))
+        attn_fl = lambda lay: sum(4.0 * n * n * 64 * lay.heads for n in lay.lens)
+        ops.attn_fwd = wrap("attn_fwd", ops.attn_fwd, lambda qkv, kb, lay, H, **kw: attn_fl(lay))
+        ops.attn_bwd = wrap("attn_bwd", ops.attn_bwd, lambda qkv, c, d, l, kb, lay, H, **kw: 2.5 * attn_fl(lay))
 
     def step(i):
         out, _ = model(**pool[i % len(pool)])
@@ -156,14 +162,15 @@ def main():
                     kern[k] = (fl, ms, len(lst))
             fl, ms, n = kern["nt"]
             ach = fl / (ms * 1e-3) / 1e12
-            res["roofline"] = {"bound": "mfma", "kernel": "gemm_nt_kernel (bf16 MFMA 16x16x32, all epilogues)",
+            res["roofline"] = {"bound": "mfma", "kernel": "gemm_nt256_kernel (bf16 MFMA 16x16x32, 256x256 tile, 4-stage LDS-DMA ring; all epilogues)",
                                "achieved": round(ach, 1), "peak": 2500.0, "unit": "TFLOP/s", "frac": round(ach / 2500.0, 4),
                                "traffic": None, "launches": n, "avg_launch_us": round(1e3 * ms / n, 2),
                                "share_of_step_time": round(ms * 1e-3 / elapsed, 3)}
-            if "tn" in kern:
-                fl2, ms2, n2 = kern["tn"]
-                res["roofline"]["gemm_tn"] = {"achieved": round(fl2 / (ms2 * 1e-3) / 1e12, 1), "launches": n2,
-                                              "share_of_step_time": round(ms2 * 1e-3 / elapsed, 3)}
+            for k in ("tn", "attn_fwd", "attn_bwd"):
+                if k in kern:
+                    fl2, ms2, n2 = kern[k]
+                    res["roofline"]["gemm_tn" if k == "tn" else k] = {"achieved": round(fl2 / (ms2 * 1e-3) / 1e12, 1), "launches": n2,
+                                                                      "share_of_step_time": round(ms2 * 1e-3 / elapsed, 3)}
         if world == 1 and not a.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(a, L, H, I, V)
         print(json.dumps(res), flush=True)
@@ -171,15 +178,28 @@ def main():
         torch.distributed.destroy_process_group()
 
 
+def usable_cores(cap=32):
+    """Threads for the CPU baseline: the cgroup CPU quota if there is one, else the affinity mask, capped at 32
+    (256 torch threads on the GPU box's 256-core host took 429 s for the same step that needs 12 s on 8 cores)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, int(int(q) / int(per))))
+    except Exception:
+        pass
+    return max(1, min(n, cap))
+
+
 def cpu_baseline(a, L, H, I, V):
     """The CPU oracle on the host cores: same architecture and sequence shapes, batch 2 (bounded sample)."""
     from oracle import mmbert_oracle as O
     from msa_amd.data import synthetic_batch
-    cores = os.cpu_count() or 1
+    cores = usable_cores()
     torch.set_num_threads(cores)
     cfg = dict(hidden=H, layers=L, heads=a.heads, intermediate=I, vocab=V, dataset="mosei", alpha=1.0, beta=1.0)
     p = {k: v.requires_grad_(True) for k, v in O.seeded_params(cfg).items()}
-    B = 2
+    B = 4
     batch = synthetic_batch(B, a.text, a.pair, a.pair, vocab=V, seed=1)
     t0 = time.perf_counter()
     out, _ = O.pretraining_forward(p, cfg, **batch, train=True)

@@ -74,7 +74,9 @@ int mmbert_ln_bwd(mmbert_stream_t stream, const void* dy, int lddy, const int* d
                   const float* mean, const float* rstd, const float* gamma, int M, int H,
                   void* dx, int lddx, const int* dx_rows, void* dx2, int lddx2, float* dgamma, float* dbeta, float* dbias2,
                   uint32_t post_stream, uint32_t post_thr, float post_scale,
-                  uint32_t pre_stream, uint32_t pre_thr, float pre_scale);
+                  uint32_t pre_stream, uint32_t pre_thr, float pre_scale,
+                  float* partial_ws /* mmbert_ln_bwd_workspace() floats, or NULL: contended atomics */);
+size_t mmbert_ln_bwd_workspace(int M, int H);
 
 /* ---- embeddings ----
  * gather: out[i] = word[ids[i]] + type[tts[i]] + pos[i % T]     HF:96-102 via REF:MMBertForPretraining.py:264

@@ -85,6 +85,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
                                                      bf16_t* __restrict__ dx, int lddx, const int* __restrict__ dx_rows,
                                                      bf16_t* __restrict__ dx2, int lddx2,
                                                      float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ dbias2,
+                                                     float* __restrict__ partial,
                                                      uint32_t post_stream, uint32_t post_thr, float post_scale,
                                                      uint32_t pre_stream, uint32_t pre_thr, float pre_scale) {
     __shared__ float red[2][4][1024];
@@ -163,8 +164,10 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
     for (int col = threadIdx.x; col < H; col += 256) {
         const float sg = red[0][0][col] + red[0][1][col] + red[0][2][col] + red[0][3][col];
         const float sb = red[1][0][col] + red[1][1][col] + red[1][2][col] + red[1][3][col];
-        if (dgamma) atomicAdd(dgamma + col, sg);
-        if (dbeta) atomicAdd(dbeta + col, sb);
+        // every workgroup adding into the same 3*H addresses is contention-bound (~0.09 TB/s): with a
+        // workspace the partials are stored plainly and summed by ln_bwd_reduce_kernel
+        if (partial) { partial[((size_t)blockIdx.x * 3 + 0) * H + col] = sg; partial[((size_t)blockIdx.x * 3 + 1) * H + col] = sb; }
+        else { if (dgamma) atomicAdd(dgamma + col, sg); if (dbeta) atomicAdd(dbeta + col, sb); }
     }
     if (dbias2) {
         __syncthreads();
@@ -173,9 +176,32 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
 #pragma unroll
             for (int r = 0; r < 4; ++r) red[0][w][c * 256 + lane * 4 + r] = ad[c][r];
         __syncthreads();
-        for (int col = threadIdx.x; col < H; col += 256)
-            atomicAdd(dbias2 + col, red[0][0][col] + red[0][1][col] + red[0][2][col] + red[0][3][col]);
+        for (int col = threadIdx.x; col < H; col += 256) {
+            const float sd = red[0][0][col] + red[0][1][col] + red[0][2][col] + red[0][3][col];
+            if (partial) partial[((size_t)blockIdx.x * 3 + 2) * H + col] = sd;
+            else atomicAdd(dbias2 + col, sd);
+        }
     }
+}
+
+// out_k[col] += sum_b partial[b][k][col]  for k = 0 (dgamma), 1 (dbeta), 2 (dbias2, optional).
+// grid (ceil(H/64), 3, 16): a workgroup = 64 columns x 4 interleaved row groups over 1/16 of the partials,
+// LDS-reduced, then ONE atomic per column per workgroup (16 adders per address: no contention to speak of).
+__global__ __launch_bounds__(256) void ln_bwd_reduce_kernel(const float* __restrict__ partial, int nblocks, int H, float* __restrict__ dgamma,
+                                                            float* __restrict__ dbeta, float* __restrict__ dbias2) {
+    __shared__ float red[4][64];
+    const int col = blockIdx.x * 64 + (threadIdx.x & 63), sub = threadIdx.x >> 6;
+    const int k = blockIdx.y;
+    float* out = k == 0 ? dgamma : (k == 1 ? dbeta : dbias2);
+    if (out == nullptr) return;
+    const int per = (nblocks + gridDim.z - 1) / gridDim.z;
+    const int b0 = blockIdx.z * per, b1 = min(nblocks, b0 + per);
+    float s = 0.f;
+    if (col < H)
+        for (int b = b0 + sub; b < b1; b += 4) s += partial[((size_t)b * 3 + k) * H + col];
+    red[sub][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (sub == 0 && col < H) atomicAdd(out + col, red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
 
 // --------------------------------------------------------------------------------------------
@@ -589,15 +615,23 @@ int mmbert_ln_bwd(hipStream_t stream, const void* dy, int lddy, const int* dy_ro
                   const float* mean, const float* rstd, const float* gamma, int M, int H,
                   void* dx, int lddx, const int* dx_rows, void* dx2, int lddx2, float* dgamma, float* dbeta, float* dbias2,
                   uint32_t post_stream, uint32_t post_thr, float post_scale,
-                  uint32_t pre_stream, uint32_t pre_thr, float pre_scale) {
+                  uint32_t pre_stream, uint32_t pre_thr, float pre_scale, float* partial_ws) {
     if (M <= 0) return 0;
     if (H > LN_MAXV * 256 || (H & 3) || (ldx & 3) || (lddy & 3) || (lddx & 3) || (lddx2 & 3)) return -1;
-    hipLaunchKernelGGL(ln_bwd_kernel, dim3(grid_for(M, 32, 512)), dim3(256), 0, stream, (const bf16_t*)dy, lddy, dy_rows, (const bf16_t*)x, ldx, x_rows,
-                       mean, rstd, gamma, M, H, (bf16_t*)dx, lddx, dx_rows, (bf16_t*)dx2, lddx2, dgamma, dbeta, dbias2,
+    const int nblocks = grid_for(M, 16, 1024);
+    hipLaunchKernelGGL(ln_bwd_kernel, dim3(nblocks), dim3(256), 0, stream, (const bf16_t*)dy, lddy, dy_rows, (const bf16_t*)x, ldx, x_rows,
+                       mean, rstd, gamma, M, H, (bf16_t*)dx, lddx, dx_rows, (bf16_t*)dx2, lddx2, dgamma, dbeta, dbias2, partial_ws,
                        post_stream, post_thr, post_scale, pre_stream, pre_thr, pre_scale);
     MMB_CHECK_LAUNCH();
+    if (partial_ws) {
+        hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3((H + 63) / 64, 3, 16), dim3(256), 0, stream, (const float*)partial_ws, nblocks, H, dgamma, dbeta, dbias2);
+        MMB_CHECK_LAUNCH();
+    }
     return 0;
 }
+
+// floats the caller must provide as partial_ws for mmbert_ln_bwd (0 = use the atomic path)
+size_t mmbert_ln_bwd_workspace(int M, int H) { return (size_t)grid_for(M, 16, 1024) * 3 * H; }
 
 int mmbert_embed_gather(hipStream_t stream, const int64_t* ids, const int64_t* tts, const float* word, const float* type, const float* pos,
                         int n, int T, int H, int V, void* out, int ldo) {

@@ -279,10 +279,26 @@ class _EncoderFn(torch.autograd.Function):
             dctx = ops.gemm_nt(dz1d, lw["WoT"])
             dqkv = ops.attn_bwd(qkv, actx, dctx, lse, key_bias, layout, H, drop=d_att)
             dy = ops.gemm_nt(dqkv, lw["WqkvT"], resid=dz1)
-            # --- all four weight gradients (+ b1, bqkv gradients on the ones-operand MFMA) of the layer in ONE launch
-            ops.gemm_tn_grouped([(du, y1, lw["g_W1"], lw["g_b1"]), (dz2d, g, lw["g_W2"], None),
-                                 (dqkv, x, lw["g_Wqkv"], lw["g_bqkv"]), (dz1d, actx, lw["g_Wo"], None)])
+            # --- all four weight gradients (+ b1, bqkv gradients on the ones-operand MFMA) of the layer in ONE launch.
+            # They are off the critical path of backward; model.overlap_wgrad = True moves them to a side stream (measured: a loss).
+            probs = [(du, y1, lw["g_W1"], lw["g_b1"]), (dz2d, g, lw["g_W2"], None),
+                     (dqkv, x, lw["g_Wqkv"], lw["g_bqkv"]), (dz1d, actx, lw["g_Wo"], None)]
+            side = top._wgrad_stream()
+            if side is None:
+                ops.gemm_tn_grouped(probs)
+            else:
+                main = torch.cuda.current_stream()
+                side.wait_stream(main)
+                with torch.cuda.stream(side):
+                    ops.gemm_tn_grouped(probs)
+                for t in (du, y1, dz2d, g, dqkv, x, dz1d, actx):
+                    t.record_stream(side)                  # the caching allocator must not hand these out while the side stream reads them
+                if top.grad_hook is not None:
+                    main.wait_stream(side)                 # DP: the layer's gradient slice is final only after its wgrad
             top._layer_grads_done(i)
+        side = top._wgrad_stream()
+        if side is not None:
+            torch.cuda.current_stream().wait_stream(side)     # optimizer / all-reduce tail see complete gradients
         return dy, None, None, None, None, None
 
 
@@ -341,6 +357,18 @@ class _GpuModelBase(nn.Module):
         self._calls = 0
         self._plans = {}
         self.grad_hook = None           # set by parallel.DataParallel: called as layers finish in backward
+
+    def _wgrad_stream(self):
+        """Side stream for the weight-gradient GEMMs (None = run them in line, the default); see _EncoderFn.backward.
+        Measured on MI355X (round 1, same box, bench.py): 572 samples/s with the side stream vs 606 in line -- the TN
+        GEMM's two 72-KiB workgroups per CU leave no LDS for attention workgroups to co-reside, and capping it at one
+        workgroup per CU (padded LDS request) does not help either (577).  Kept as an opt-in switch only."""
+        if not getattr(self, "overlap_wgrad", False):
+            return None
+        s = getattr(self, "_side_stream", None)
+        if s is None:
+            s = self._side_stream = torch.cuda.Stream()
+        return s
 
     def manual_seed(self, seed: int):
         self._seed, self._calls = int(seed), 0

@@ -83,6 +83,18 @@ def _slab(nbytes: int, device) -> Optional[torch.Tensor]:
     return t
 
 
+_ws_cache = {}
+
+
+def _ws_f32(nfloats: int, device) -> torch.Tensor:
+    key = (device, torch.cuda.current_stream().cuda_stream)
+    t = _ws_cache.get(key)
+    if t is None or t.numel() < nfloats:
+        t = torch.empty(max(nfloats, 1), device=device, dtype=torch.float32)
+        _ws_cache[key] = t
+    return t
+
+
 def gemm_tn(A, B, W, *, accumulate=True, alpha=1.0, alpha_dev=None, bias_out=None):
     """W[N,K] (fp32) (+)= alpha * A[M,N]^T @ B[M,K]; bias_out[N] += alpha * colsum(A)  (see mmbert_gemm_tn)."""
     lib = _lib.load()
@@ -156,10 +168,11 @@ def ln_bwd(dy, x, mean, rstd, gamma, dgamma, dbeta, *, M=None, dx=None, dx2=None
     if dx is None:
         dx = torch.empty((M, H), device=x.device, dtype=torch.bfloat16)
     po, pr = post_drop or NO_DROP, pre_drop or NO_DROP
+    ws = _ws_f32(lib.mmbert_ln_bwd_workspace(M, H), x.device)
     _lib.check(lib.mmbert_ln_bwd(_stream(), dy.data_ptr(), dy.stride(0), _ptr(dy_rows), x.data_ptr(), x.stride(0), _ptr(x_rows),
                                  mean.data_ptr(), rstd.data_ptr(), gamma.data_ptr(), M, H,
                                  dx.data_ptr(), dx.stride(0), _ptr(dx_rows), _ptr(dx2), dx2.stride(0) if dx2 is not None else 0,
-                                 _ptr(dgamma), _ptr(dbeta), _ptr(dbias2), po[0], po[1], po[2], pr[0], pr[1], pr[2]), "mmbert_ln_bwd")
+                                 _ptr(dgamma), _ptr(dbeta), _ptr(dbias2), po[0], po[1], po[2], pr[0], pr[1], pr[2], ws.data_ptr()), "mmbert_ln_bwd")
     return dx
 
 
