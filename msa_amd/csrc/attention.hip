@@ -95,9 +95,22 @@ __device__ __forceinline__ float group_max(float v) {
 //   * the transposed V reads go through inline asm (see tr_read in gemm.hip: the builtin makes hipcc
 //     drain vmcnt(0) in front of them, which would serialise the prefetch).
 // =============================================================================================
+typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 template <int OFF>
-__device__ __forceinline__ void tr_read(s16x4& dst, unsigned lds_addr) {
+__device__ __forceinline__ void tr_read(u32x2& dst, unsigned lds_addr) {
     asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(lds_addr), "i"(OFF));
+}
+// two transposed reads (rows r.. and r+16..) -> one 8-element MFMA operand; dword moves only
+__device__ __forceinline__ bf16x8 frag_of(const u32x2 lo, const u32x2 hi) {
+    const u32x4 v = {lo[0], lo[1], hi[0], hi[1]};
+    return __builtin_bit_cast(bf16x8, v);
+}
+// row maximum helpers: plain v_max3_f32 (hipcc otherwise inserts a canonicalising v_max per fmaxf operand)
+__device__ __forceinline__ float max3f(float a, float b, float c) {
+    float r;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
 }
 
 template <int OFF>
@@ -107,7 +120,8 @@ __device__ __forceinline__ void lds_read16(f32x4& dst, unsigned lds_addr) {
 
 #define FWD_BUF 16640          // K 8192 | V 8192 | bias 256
 
-__global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs a) {
+template <bool DROP>
+__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnArgs a) {
     __shared__ __attribute__((aligned(16))) char smem[2 * FWD_BUF];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -195,7 +209,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs a) {
                     if (kv0 + kt * 16 + 4 * g + r >= S) { s[0][kt][r] = -INFINITY; s[1][kt][r] = -INFINITY; }
         }
         // issue all transposed V reads of this tile now; they land while the softmax VALU work runs
-        s16x4 vlo[2][4], vhi[2][4];
+        u32x2 vlo[2][4], vhi[2][4];
 #pragma unroll
         for (int d = 0; d < 4; ++d) {
             tr_read<buf * FWD_BUF>(vlo[0][d], vaddr[d]); tr_read<buf * FWD_BUF + 16 * 128>(vhi[0][d], vaddr[d]);
@@ -204,12 +218,13 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs a) {
         bf16x8 pf[2][2];
 #pragma unroll
         for (int qb = 0; qb < 2; ++qb) {
-            float tmax = fmaxf(fmaxf(fmaxf(s[qb][0][0], s[qb][0][1]), fmaxf(s[qb][0][2], s[qb][0][3])),
-                               fmaxf(fmaxf(s[qb][1][0], s[qb][1][1]), fmaxf(s[qb][1][2], s[qb][1][3])));
-            tmax = fmaxf(tmax, fmaxf(fmaxf(fmaxf(s[qb][2][0], s[qb][2][1]), fmaxf(s[qb][2][2], s[qb][2][3])),
-                                     fmaxf(fmaxf(s[qb][3][0], s[qb][3][1]), fmaxf(s[qb][3][2], s[qb][3][3]))));
+            float tmax = max3f(s[qb][0][0], s[qb][0][1], s[qb][0][2]);
+            tmax = max3f(tmax, s[qb][0][3], s[qb][1][0]); tmax = max3f(tmax, s[qb][1][1], s[qb][1][2]);
+            tmax = max3f(tmax, s[qb][1][3], s[qb][2][0]); tmax = max3f(tmax, s[qb][2][1], s[qb][2][2]);
+            tmax = max3f(tmax, s[qb][2][3], s[qb][3][0]); tmax = max3f(tmax, s[qb][3][1], s[qb][3][2]);
+            tmax = max3f(tmax, s[qb][3][3], mraw[qb]);       // running maximum folded in
             tmax = group_max(tmax);
-            const float mnew = fmaxf(mraw[qb], tmax);
+            const float mnew = tmax;                         // already >= mraw
             const float alpha = __builtin_amdgcn_exp2f((mraw[qb] - mnew) * c2);      // first tile: exp2(-inf) = 0
             mraw[qb] = mnew;
             const float mc = mnew * c2;
@@ -217,7 +232,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs a) {
 #pragma unroll
             for (int kt = 0; kt < 4; ++kt) {
                 bool keep[4] = {true, true, true, true};
-                if (a.dthr) mmb_keep4(a.dstream, (uint64_t)rowbase[qb] + (kv0 + kt * 16 + 4 * g), a.dthr, keep);
+                if constexpr (DROP) mmb_keep4(a.dstream, (uint64_t)rowbase[qb] + (kv0 + kt * 16 + 4 * g), a.dthr, keep);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[qb][kt][r], c2, -mc));
@@ -240,8 +255,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs a) {
         for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
             for (int d = 0; d < 4; ++d) {
-                const s16x8 vv = {vlo[ks][d][0], vlo[ks][d][1], vlo[ks][d][2], vlo[ks][d][3], vhi[ks][d][0], vhi[ks][d][1], vhi[ks][d][2], vhi[ks][d][3]};
-                const bf16x8 vf = __builtin_bit_cast(bf16x8, vv);
+                const bf16x8 vf = frag_of(vlo[ks][d], vhi[ks][d]);
 #pragma unroll
                 for (int qb = 0; qb < 2; ++qb)
                     o[qb][d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[qb][ks], o[qb][d], 0, 0, 0);
@@ -276,7 +290,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs a) {
 // =============================================================================================
 #define DQ_BUF 24832           // K row image 8192 | K transposed-read image 8192 | V row image 8192 | bias 256
 
-__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnArgs a) {
+template <bool DROP>
+__global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnArgs a) {
     __shared__ __attribute__((aligned(16))) char smem[2 * DQ_BUF];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -369,7 +384,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnArgs a) {
             }
         }
         // transposed K reads for dQ^T: issue now, consume after the VALU block
-        s16x4 klo[2][4], khi[2][4];
+        u32x2 klo[2][4], khi[2][4];
 #pragma unroll
         for (int d = 0; d < 4; ++d) {
             tr_read<buf * DQ_BUF>(klo[0][d], kaddr[d]); tr_read<buf * DQ_BUF + 16 * 128>(khi[0][d], kaddr[d]);
@@ -383,7 +398,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnArgs a) {
 #pragma unroll
             for (int kt = 0; kt < 4; ++kt) {
                 bool keep[4] = {true, true, true, true};
-                if (a.dthr) mmb_keep4(a.dstream, (uint64_t)rowbase[qb] + (kv0 + kt * 16 + 4 * g), a.dthr, keep);
+                if constexpr (DROP) mmb_keep4(a.dstream, (uint64_t)rowbase[qb] + (kv0 + kt * 16 + 4 * g), a.dthr, keep);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[qb][kt][r], c2, lc));
@@ -402,8 +417,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnArgs a) {
         for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
             for (int d = 0; d < 4; ++d) {
-                const s16x8 kv = {klo[ks][d][0], klo[ks][d][1], klo[ks][d][2], klo[ks][d][3], khi[ks][d][0], khi[ks][d][1], khi[ks][d][2], khi[ks][d][3]};
-                const bf16x8 kf = __builtin_bit_cast(bf16x8, kv);
+                const bf16x8 kf = frag_of(klo[ks][d], khi[ks][d]);
 #pragma unroll
                 for (int qb = 0; qb < 2; ++qb)
                     dq[qb][d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, dsf[qb][ks], dq[qb][d], 0, 0, 0);
@@ -438,7 +452,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnArgs a) {
 // =============================================================================================
 #define DKV_BUF 33280          // Q row 8192 | Q tr 8192 | dO row 8192 | dO tr 8192 | lse 256 | delta 256
 
-__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnArgs a) {
+template <bool DROP>
+__global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnArgs a) {
     __shared__ __attribute__((aligned(16))) char smem[2 * DKV_BUF];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -543,7 +558,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnArgs a) {
 #pragma unroll
             for (int qt = 0; qt < 4; ++qt) {
                 float ksc[4] = {1.f, 1.f, 1.f, 1.f};
-                if (a.dthr) {
+                if constexpr (DROP) {
                     // pair index of (row q, keys {2j,2j+1}); even lane hashes rows r = 0,2, odd lane rows 1,3, then swap
                     const int qa = min(q0 + qt * 16 + 4 * g + (odd ? 1 : 0), S - 1), qb2 = min(q0 + qt * 16 + 4 * g + (odd ? 3 : 2), S - 1);
                     const uint32_t pj = (uint32_t)kc[kb_] >> 1;
@@ -569,7 +584,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnArgs a) {
             for (int ks = 0; ks < 2; ++ks) {
                 const bf16x8 pf = pack8(pm[2 * ks], pm[2 * ks + 1]);
                 const bf16x8 dsf = pack8(s[2 * ks], s[2 * ks + 1]);
-                s16x4 dlo[4], dhi[4], qlo[4], qhi[4];
+                u32x2 dlo[4], dhi[4], qlo[4], qhi[4];
 #pragma unroll
                 for (int d = 0; d < 4; ++d) {
                     if (ks == 0) {
@@ -585,10 +600,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnArgs a) {
                 typedef __attribute__((ext_vector_type(8))) short s16x8;
 #pragma unroll
                 for (int d = 0; d < 4; ++d) {
-                    const s16x8 dvv = {dlo[d][0], dlo[d][1], dlo[d][2], dlo[d][3], dhi[d][0], dhi[d][1], dhi[d][2], dhi[d][3]};
-                    const s16x8 qvv = {qlo[d][0], qlo[d][1], qlo[d][2], qlo[d][3], qhi[d][0], qhi[d][1], qhi[d][2], qhi[d][3]};
-                    dv[kb_][d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, dvv), pf, dv[kb_][d], 0, 0, 0);
-                    dk[kb_][d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, qvv), dsf, dk[kb_][d], 0, 0, 0);
+                    dv[kb_][d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_of(dlo[d], dhi[d]), pf, dv[kb_][d], 0, 0, 0);
+                    dk[kb_][d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_of(qlo[d], qhi[d]), dsf, dk[kb_][d], 0, 0, 0);
                 }
             }
         }
@@ -641,7 +654,8 @@ int mmbert_attn_fwd(hipStream_t stream, const void* qkv, void* ctx, float* lse, 
     AttnArgs a;
     if (fill_args(a, qkv, H, heads, key_bias, seq_start, seq_len, elem_base, tile_seq, tile_r0, lse, dstream, dthr, dscale)) return -1;
     a.ctx = (bf16_t*)ctx;
-    hipLaunchKernelGGL(attn_fwd_kernel, dim3(ntiles, heads), dim3(256), 0, stream, a);
+    if (dthr) hipLaunchKernelGGL(attn_fwd_kernel<true>, dim3(ntiles, heads), dim3(256), 0, stream, a);
+    else hipLaunchKernelGGL(attn_fwd_kernel<false>, dim3(ntiles, heads), dim3(256), 0, stream, a);
     MMB_CHECK_LAUNCH();
     return 0;
 }
@@ -657,10 +671,12 @@ int mmbert_attn_bwd(hipStream_t stream, const void* qkv, const void* ctx, const 
     {
         AttnArgs q = a;
         q.tile_seq = qtile_seq; q.tile_r0 = qtile_r0;
-        hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3(nqtiles, heads), dim3(256), 0, stream, q);
+        if (dthr) hipLaunchKernelGGL(attn_bwd_dq_kernel<true>, dim3(nqtiles, heads), dim3(256), 0, stream, q);
+        else hipLaunchKernelGGL(attn_bwd_dq_kernel<false>, dim3(nqtiles, heads), dim3(256), 0, stream, q);
         MMB_CHECK_LAUNCH();
     }
-    hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3(ntiles, heads), dim3(256), 0, stream, a);
+    if (dthr) hipLaunchKernelGGL(attn_bwd_dkv_kernel<true>, dim3(ntiles, heads), dim3(256), 0, stream, a);
+    else hipLaunchKernelGGL(attn_bwd_dkv_kernel<false>, dim3(ntiles, heads), dim3(256), 0, stream, a);
     MMB_CHECK_LAUNCH();
     return 0;
 }

@@ -411,8 +411,10 @@ __device__ __forceinline__ int tn_swz(int row) { return ((row & 3) | ((row >> 1)
 // ds_read_b64_tr_b16 through inline asm: behind the builtin hipcc cannot prove that the read does not
 // alias the LDS-DMA still in flight and drains vmcnt(0) in front of every stage's reads.  The asm form is
 // invisible to its scoreboard: the caller waits lgkmcnt(0) itself and fences with sched_barrier(0).
+typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 template <int OFF>
-__device__ __forceinline__ void tr_read(s16x4& dst, unsigned lds_addr) {
+__device__ __forceinline__ void tr_read(u32x2& dst, unsigned lds_addr) {
     asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(lds_addr), "i"(OFF));
 }
 
@@ -498,7 +500,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const GemmTNG g) {
 
     auto compute = [&](auto slot_c, int st) {
         constexpr int SB = decltype(slot_c)::value * 24576;
-        s16x4 ylo[8], yhi[8], xlo[4], xhi[4];
+        u32x2 ylo[8], yhi[8], xlo[4], xhi[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) { tr_read<SB>(xlo[i], offB[i]); tr_read<SB + 4 * 256>(xhi[i], offB[i]); }   // rows r0 and r0+4 (same swizzle: bit 2 unused)
 #pragma unroll
@@ -507,15 +509,9 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const GemmTNG g) {
         __builtin_amdgcn_sched_barrier(0);
         bf16x8 ay[8], bx[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const s16x8 v = {xlo[i][0], xlo[i][1], xlo[i][2], xlo[i][3], xhi[i][0], xhi[i][1], xhi[i][2], xhi[i][3]};
-            bx[i] = __builtin_bit_cast(bf16x8, v);
-        }
+        for (int i = 0; i < 4; ++i) { const u32x4 v = {xlo[i][0], xlo[i][1], xhi[i][0], xhi[i][1]}; bx[i] = __builtin_bit_cast(bf16x8, v); }
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const s16x8 v = {ylo[j][0], ylo[j][1], ylo[j][2], ylo[j][3], yhi[j][0], yhi[j][1], yhi[j][2], yhi[j][3]};
-            ay[j] = __builtin_bit_cast(bf16x8, v);
-        }
+        for (int j = 0; j < 8; ++j) { const u32x4 v = {ylo[j][0], ylo[j][1], yhi[j][0], yhi[j][1]}; ay[j] = __builtin_bit_cast(bf16x8, v); }
         const int mrem = (mend - mbeg) - st * 32;                  // valid rows in this stage
         if (mrem < 32) {                                           // wave-uniform: only the last stage of a split
             const int mb8 = 8 * g4;
