@@ -96,14 +96,16 @@ int mmbert_pair_proj_bwd(mmbert_stream_t stream, const float* feat, int B, int P
 /* ---- attention (head dim 64) over packed variable-length sequences ----
  * softmax(q.k^T/8 + key_bias) -> dropout -> .v   (HF:111-136); REF mask plumbing: key_bias is
  * (1-mask)*-10000 per key token (REF:MMBertForPretraining.py:57-154,246-250).
+ * key_bias is PADDED per sequence: sequence s owns entries bias_start[s] .. bias_start[s] + ceil128(len) - 1, and the
+ * entries past its length must be <= -1e30 (they stand for "no such key"; the kernels carry no range logic).
  * tile_seq/tile_r0 list the row tiles (sequence id, first row) of mmbert_attn_tile_rows() rows each, one
  * list for forward and one for backward; elem_base[s] (multiples of 4) are the dropout index bases. */
 int mmbert_attn_tile_rows(int which);   /* rows per entry of the tile lists: which = 0 forward, 1 backward */
-int mmbert_attn_fwd(mmbert_stream_t stream, const void* qkv, void* ctx, float* lse, const float* key_bias, int H, int heads,
+int mmbert_attn_fwd(mmbert_stream_t stream, const void* qkv, void* ctx, float* lse, const float* key_bias, const int* bias_start, int H, int heads,
                     const int* seq_start, const int* seq_len, const unsigned* elem_base, const int* tile_seq, const int* tile_r0, int ntiles,
                     uint32_t dstream, uint32_t dthr, float dscale);
 int mmbert_attn_bwd(mmbert_stream_t stream, const void* qkv, const void* ctx, const void* dctx, void* dqkv, const float* lse, float* delta,
-                    const float* key_bias, int H, int heads, const int* seq_start, const int* seq_len, const unsigned* elem_base,
+                    const float* key_bias, const int* bias_start, int H, int heads, const int* seq_start, const int* seq_len, const unsigned* elem_base,
                     const int* qtile_seq, const int* qtile_r0, int nqtiles,      /* query tiles: mmbert_attn_tile_rows(0) rows */
                     const int* tile_seq, const int* tile_r0, int ntiles,         /* key tiles:   mmbert_attn_tile_rows(1) rows */
                     uint32_t dstream, uint32_t dthr, float dscale);

@@ -33,8 +33,8 @@ SIGNATURES = {
     "mmbert_pair_proj_fwd": (I, [P, P, I, I, I, P, P, I, P, I, I]),
     "mmbert_pair_proj_bwd": (I, [P, P, I, I, I, P, P, I, I, P, P, I]),
     "mmbert_attn_tile_rows": (I, [I]),
-    "mmbert_attn_fwd": (I, [P, P, P, P, P, I, I, P, P, P, P, P, I, U32, U32, F]),
-    "mmbert_attn_bwd": (I, [P, P, P, P, P, P, P, P, I, I, P, P, P, P, P, I, P, P, I, U32, U32, F]),
+    "mmbert_attn_fwd": (I, [P, P, P, P, P, P, I, I, P, P, P, P, P, I, U32, U32, F]),
+    "mmbert_attn_bwd": (I, [P, P, P, P, P, P, P, P, P, I, I, P, P, P, P, P, I, P, P, I, U32, U32, F]),
     "mmbert_attn_dropout_mask": (I, [P, P, I, C.c_uint, I, U32, U32]),
     "mmbert_ce_fwd": (I, [P, P, I, I, P, I, P, I, P, P, P]),
     "mmbert_ce_bwd": (I, [P, P, I, I, P, I, P, I, P, P, P, P, I]),

@@ -30,7 +30,8 @@ struct AttnArgs {
     bf16_t* dqkv;            // bwd out   [tokens, 3H]
     float* lse;              // [tokens, heads]
     float* delta;            // [tokens, heads]
-    const float* key_bias;   // [tokens]
+    const float* key_bias;   // per sequence, padded: bias_start[s] + key, entries past the sequence length <= -1e30 (ceil128(S) entries)
+    const int* bias_start;
     const int* seq_start; const int* seq_len; const unsigned* elem_base;
     const int* tile_seq; const int* tile_r0;
     int H, heads;
@@ -99,23 +100,41 @@ typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 template <int OFF>
 __device__ __forceinline__ void tr_read(u32x2& dst, unsigned lds_addr) {
-    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(lds_addr), "i"(OFF));
+    // "memory": the read must stay behind the s_waitcnt / s_barrier that publish the LDS-DMA data (without it hipcc
+    // hoisted these reads above the barrier: stale LDS -> NaN)
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(lds_addr), "i"(OFF) : "memory");
 }
 // two transposed reads (rows r.. and r+16..) -> one 8-element MFMA operand; dword moves only
 __device__ __forceinline__ bf16x8 frag_of(const u32x2 lo, const u32x2 hi) {
     const u32x4 v = {lo[0], lo[1], hi[0], hi[1]};
     return __builtin_bit_cast(bf16x8, v);
 }
-// row maximum helpers: plain v_max3_f32 (hipcc otherwise inserts a canonicalising v_max per fmaxf operand)
-__device__ __forceinline__ float max3f(float a, float b, float c) {
+// Row maximum of 16 MFMA results and the running maximum as ONE asm block of v_max3_f32 (hipcc otherwise adds a
+// canonicalising v_max per fmaxf operand).  The inputs are MFMA result registers and hipcc pads NO hazards for
+// inline asm (an XDL result needs 12 wait states before a VALU reads it): the block therefore opens with s_nop 15.
+// Without it the asm read stale registers whenever it was scheduled right behind the MFMAs: rare wrong maxima ->
+// exp2 overflow -> NaN rows, run-to-run different.
+__device__ __forceinline__ float rowmax16(const f32x4 a, const f32x4 b, const f32x4 c, const f32x4 d, float m) {
     float r;
-    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    asm("s_nop 15\n\t"
+        "v_max3_f32 %0, %1, %2, %3\n\t"
+        "v_max3_f32 %0, %0, %4, %5\n\t"
+        "v_max3_f32 %0, %0, %6, %7\n\t"
+        "v_max3_f32 %0, %0, %8, %9\n\t"
+        "v_max3_f32 %0, %0, %10, %11\n\t"
+        "v_max3_f32 %0, %0, %12, %13\n\t"
+        "v_max3_f32 %0, %0, %14, %15\n\t"
+        "v_max3_f32 %0, %0, %16, %17"
+        : "=&v"(r)
+        : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(b[0]), "v"(b[1]), "v"(b[2]), "v"(b[3]),
+          "v"(c[0]), "v"(c[1]), "v"(c[2]), "v"(c[3]), "v"(d[0]), "v"(d[1]), "v"(d[2]), "v"(d[3]), "v"(m));
     return r;
 }
 
+
 template <int OFF>
 __device__ __forceinline__ void lds_read16(f32x4& dst, unsigned lds_addr) {
-    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(lds_addr), "i"(OFF));
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(lds_addr), "i"(OFF) : "memory");
 }
 
 #define FWD_BUF 16640          // K 8192 | V 8192 | bias 256
@@ -132,7 +151,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnArgs a) {
     const bf16_t* base = a.qkv + (size_t)start * a.ld_qkv + head * 64;
     const bf16_t* kbase = base + a.H;
     const bf16_t* vbase = base + 2 * a.H;
-    const float* bbase = a.key_bias + start;
+    const float* bbase = a.key_bias + a.bias_start[seq];
     int qi[2], qc[2];
     unsigned rowbase[2];
     bf16x8 qf[2][2];
@@ -150,8 +169,9 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnArgs a) {
         char* B = smem + buf * FWD_BUF;
         stage_tile<0>(B, kbase, a.ld_qkv, kv0, S, wave, lane);
         stage_tile<1>(B + 8192, vbase, a.ld_qkv, kv0, S, wave, lane);
-        // 64 bias floats; every wave writes the same 256 B (identical data) so that all waves keep the same vmcnt
-        __builtin_amdgcn_global_load_lds(GPTR(bbase + min(kv0 + lane, S - 1)), LPTR(B + 16384), 4, 0, 0);
+        // 64 bias floats (padded array: keys past the end read -1e30 -> p = 0, no per-tile range logic);
+        // every wave writes the same 256 B (identical data) so that all waves keep the same vmcnt
+        __builtin_amdgcn_global_load_lds(GPTR(bbase + kv0 + lane), LPTR(B + 16384), 4, 0, 0);
     };
 
     f32x4 o[2][4];
@@ -201,13 +221,6 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnArgs a) {
                 s[qb][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k1, qf[qb][1], s[qb][kt], 0, 0, 0);
             }
         }
-        if (kv0 + 64 > S) {                                  // wave-uniform: only the last tile has keys past the end
-#pragma unroll
-            for (int kt = 0; kt < 4; ++kt)
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    if (kv0 + kt * 16 + 4 * g + r >= S) { s[0][kt][r] = -INFINITY; s[1][kt][r] = -INFINITY; }
-        }
         // issue all transposed V reads of this tile now; they land while the softmax VALU work runs
         u32x2 vlo[2][4], vhi[2][4];
 #pragma unroll
@@ -218,14 +231,11 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnArgs a) {
         bf16x8 pf[2][2];
 #pragma unroll
         for (int qb = 0; qb < 2; ++qb) {
-            float tmax = max3f(s[qb][0][0], s[qb][0][1], s[qb][0][2]);
-            tmax = max3f(tmax, s[qb][0][3], s[qb][1][0]); tmax = max3f(tmax, s[qb][1][1], s[qb][1][2]);
-            tmax = max3f(tmax, s[qb][1][3], s[qb][2][0]); tmax = max3f(tmax, s[qb][2][1], s[qb][2][2]);
-            tmax = max3f(tmax, s[qb][2][3], s[qb][3][0]); tmax = max3f(tmax, s[qb][3][1], s[qb][3][2]);
-            tmax = max3f(tmax, s[qb][3][3], mraw[qb]);       // running maximum folded in
+            float tmax = rowmax16(s[qb][0], s[qb][1], s[qb][2], s[qb][3], mraw[qb]);   // running maximum folded in
             tmax = group_max(tmax);
             const float mnew = tmax;                         // already >= mraw
-            const float alpha = __builtin_amdgcn_exp2f((mraw[qb] - mnew) * c2);      // first tile: exp2(-inf) = 0
+            const bool grew = __ballot(mnew > mraw[qb]) != 0ull;                     // wave-uniform: did any row's maximum grow?
+            const float alpha = grew ? __builtin_amdgcn_exp2f((mraw[qb] - mnew) * c2) : 1.0f;   // first tile: exp2(-inf) = 0
             mraw[qb] = mnew;
             const float mc = mnew * c2;
             float psum = 0.f;
@@ -240,11 +250,14 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnArgs a) {
                     s[qb][kt][r] = keep[r] ? p : 0.f;
                 }
             }
-            lpart[qb] = lpart[qb] * alpha + psum;
+            if (grew) {                                      // steady state (maximum unchanged): no rescale pass
+                lpart[qb] *= alpha;
 #pragma unroll
-            for (int d = 0; d < 4; ++d)
+                for (int d = 0; d < 4; ++d)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) o[qb][d][r] *= alpha;
+                    for (int r = 0; r < 4; ++r) o[qb][d][r] *= alpha;
+            }
+            lpart[qb] += psum;
             pf[qb][0] = pack8(s[qb][0], s[qb][1]);
             pf[qb][1] = pack8(s[qb][2], s[qb][3]);
         }
@@ -304,7 +317,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnArgs a) {
     const bf16_t* ob = a.ctx + (size_t)start * a.H + head * 64;
     const bf16_t* kbase = base + a.H;
     const bf16_t* vbase = base + 2 * a.H;
-    const float* bbase = a.key_bias + start;
+    const float* bbase = a.key_bias + a.bias_start[seq];
     const float c2 = a.scale * LOG2E, inv_scale = 1.0f / a.scale;
     int qi[2];
     unsigned rowbase[2];
@@ -334,7 +347,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnArgs a) {
         stage_tile<0>(B, kbase, a.ld_qkv, kv0, S, wave, lane);
         stage_tile<1>(B + 8192, kbase, a.ld_qkv, kv0, S, wave, lane);
         stage_tile<0>(B + 16384, vbase, a.ld_qkv, kv0, S, wave, lane);
-        __builtin_amdgcn_global_load_lds(GPTR(bbase + min(kv0 + lane, S - 1)), LPTR(B + 24576), 4, 0, 0);
+        __builtin_amdgcn_global_load_lds(GPTR(bbase + kv0 + lane), LPTR(B + 24576), 4, 0, 0);
     };
 
     f32x4 dq[2][4];
@@ -390,7 +403,6 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnArgs a) {
             tr_read<buf * DQ_BUF>(klo[0][d], kaddr[d]); tr_read<buf * DQ_BUF + 16 * 128>(khi[0][d], kaddr[d]);
             tr_read<buf * DQ_BUF + 32 * 128>(klo[1][d], kaddr[d]); tr_read<buf * DQ_BUF + 48 * 128>(khi[1][d], kaddr[d]);
         }
-        const bool tail = kv0 + 64 > S;
         bf16x8 dsf[2][2];
 #pragma unroll
         for (int qb = 0; qb < 2; ++qb) {
@@ -401,8 +413,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnArgs a) {
                 if constexpr (DROP) mmb_keep4(a.dstream, (uint64_t)rowbase[qb] + (kv0 + kt * 16 + 4 * g), a.dthr, keep);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[qb][kt][r], c2, lc));
-                    if (tail && kv0 + kt * 16 + 4 * g + r >= S) p = 0.f;
+                    const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[qb][kt][r], c2, lc));   // keys past the end: bias -1e30 -> 0
                     const float dpm = keep[r] ? dp[qb][kt][r] * a.dscale : 0.f;
                     s[qb][kt][r] = p * (dpm - delta[qb]);                       // dS^T
                 }
@@ -478,7 +489,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnArgs a) 
             kf[kb_][kk] = *(const bf16x8*)(base + a.H + (size_t)kc[kb_] * a.ld_qkv + kk * 32 + 8 * g);
             vf[kb_][kk] = *(const bf16x8*)(base + 2 * a.H + (size_t)kc[kb_] * a.ld_qkv + kk * 32 + 8 * g);
         }
-        kb[kb_] = (ki[kb_] < S) ? a.key_bias[start + kc[kb_]] * inv_scale : -INFINITY;   // keys past the end: p = 0
+        kb[kb_] = a.key_bias[a.bias_start[seq] + ki[kb_]] * inv_scale;    // padded array: keys past the end read -1e30 -> p = 0
     }
     const unsigned ebase = a.elem_base[seq] + (unsigned)(head * S) * Spad;
 
@@ -636,23 +647,23 @@ __global__ void attn_mask_kernel(uint8_t* out, int S, unsigned elem_base, int he
 
 extern "C" {
 
-static int fill_args(AttnArgs& a, const void* qkv, int H, int heads, const float* key_bias, const int* seq_start, const int* seq_len,
+static int fill_args(AttnArgs& a, const void* qkv, int H, int heads, const float* key_bias, const int* bias_start, const int* seq_start, const int* seq_len,
                      const unsigned* elem_base, const int* tile_seq, const int* tile_r0, float* lse,
                      uint32_t dstream, uint32_t dthr, float dscale) {
     if (heads <= 0 || H != heads * 64) return -1;      // head dim 64 only
-    a.qkv = (const bf16_t*)qkv; a.ld_qkv = 3 * H; a.H = H; a.heads = heads; a.key_bias = key_bias;
+    a.qkv = (const bf16_t*)qkv; a.ld_qkv = 3 * H; a.H = H; a.heads = heads; a.key_bias = key_bias; a.bias_start = bias_start;
     a.seq_start = seq_start; a.seq_len = seq_len; a.elem_base = elem_base; a.tile_seq = tile_seq; a.tile_r0 = tile_r0;
     a.lse = lse; a.scale = 0.125f; a.dstream = dstream; a.dthr = dthr; a.dscale = dscale;
     a.ctx = nullptr; a.dctx = nullptr; a.dqkv = nullptr; a.delta = nullptr;
     return 0;
 }
 
-int mmbert_attn_fwd(hipStream_t stream, const void* qkv, void* ctx, float* lse, const float* key_bias, int H, int heads,
+int mmbert_attn_fwd(hipStream_t stream, const void* qkv, void* ctx, float* lse, const float* key_bias, const int* bias_start, int H, int heads,
                     const int* seq_start, const int* seq_len, const unsigned* elem_base, const int* tile_seq, const int* tile_r0, int ntiles,
                     uint32_t dstream, uint32_t dthr, float dscale) {
     if (ntiles <= 0) return 0;
     AttnArgs a;
-    if (fill_args(a, qkv, H, heads, key_bias, seq_start, seq_len, elem_base, tile_seq, tile_r0, lse, dstream, dthr, dscale)) return -1;
+    if (fill_args(a, qkv, H, heads, key_bias, bias_start, seq_start, seq_len, elem_base, tile_seq, tile_r0, lse, dstream, dthr, dscale)) return -1;
     a.ctx = (bf16_t*)ctx;
     if (dthr) hipLaunchKernelGGL(attn_fwd_kernel<true>, dim3(ntiles, heads), dim3(256), 0, stream, a);
     else hipLaunchKernelGGL(attn_fwd_kernel<false>, dim3(ntiles, heads), dim3(256), 0, stream, a);
@@ -661,12 +672,12 @@ int mmbert_attn_fwd(hipStream_t stream, const void* qkv, void* ctx, float* lse, 
 }
 
 int mmbert_attn_bwd(hipStream_t stream, const void* qkv, const void* ctx, const void* dctx, void* dqkv, const float* lse, float* delta,
-                    const float* key_bias, int H, int heads, const int* seq_start, const int* seq_len, const unsigned* elem_base,
+                    const float* key_bias, const int* bias_start, int H, int heads, const int* seq_start, const int* seq_len, const unsigned* elem_base,
                     const int* qtile_seq, const int* qtile_r0, int nqtiles, const int* tile_seq, const int* tile_r0, int ntiles,
                     uint32_t dstream, uint32_t dthr, float dscale) {
     if (ntiles <= 0 || nqtiles <= 0) return 0;
     AttnArgs a;
-    if (fill_args(a, qkv, H, heads, key_bias, seq_start, seq_len, elem_base, tile_seq, tile_r0, (float*)lse, dstream, dthr, dscale)) return -1;
+    if (fill_args(a, qkv, H, heads, key_bias, bias_start, seq_start, seq_len, elem_base, tile_seq, tile_r0, (float*)lse, dstream, dthr, dscale)) return -1;
     a.ctx = (bf16_t*)ctx; a.dctx = (const bf16_t*)dctx; a.dqkv = (bf16_t*)dqkv; a.delta = delta;
     {
         AttnArgs q = a;

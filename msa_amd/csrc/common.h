@@ -41,8 +41,14 @@ __host__ __device__ __forceinline__ uint32_t mmb_hash32(uint32_t x) {
     x ^= x >> 16; x *= 0x85EBCA6Bu; x ^= x >> 13; x *= 0xC2B2AE35u; x ^= x >> 16;
     return x;
 }
+// dropout bits of an element pair: Weyl sequence (pair_idx * golden ratio + stream) through ONE xorshift-multiply-
+// xorshift round.  The full two-multiply finaliser (mmb_hash32, still used to derive streams) costs ~9 VALU ops per
+// pair and was 38 % of the attention kernels' VALU work; this is 5, and Bernoulli sampling at 16-bit granularity
+// does not need full avalanche (tests check keep rates and forward/backward mask identity).
 __host__ __device__ __forceinline__ uint32_t mmb_pair_bits(uint32_t stream, uint32_t pair_idx) {
-    return mmb_hash32(pair_idx * 0x9E3779B1u + stream);
+    uint32_t x = pair_idx * 0x9E3779B1u + stream;
+    x ^= x >> 15; x *= 0x2C1B3C6Du; x ^= x >> 16;
+    return x;
 }
 // keep flag of element idx (idx = 2*pair + sub)
 __host__ __device__ __forceinline__ bool mmb_keep(uint32_t stream, uint64_t idx, uint32_t thr16) {

@@ -415,7 +415,9 @@ typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 template <int OFF>
 __device__ __forceinline__ void tr_read(u32x2& dst, unsigned lds_addr) {
-    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(lds_addr), "i"(OFF));
+    // "memory": the read must stay behind the s_waitcnt / s_barrier that publish the LDS-DMA data (without it hipcc
+    // hoisted these reads above the barrier: stale LDS -> NaN)
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(lds_addr), "i"(OFF) : "memory");
 }
 
 __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const GemmTNG g) {

@@ -518,7 +518,8 @@ class _GpuModelBase(nn.Module):
         x = torch.cat(xs) if len(xs) > 1 else xs[0]
         key_bias = torch.cat(kbs) if len(kbs) > 1 else kbs[0]
         plan = self._plan(lens, B, dev)
-        y = _EncoderFn.apply(x, bert.embeddings.LayerNorm.weight, self, plan["layout"], key_bias.contiguous(), seed)
+        key_bias = ops.pad_key_bias(key_bias, plan["layout"])        # per-sequence padded layout, -1e30 = "no such key"
+        y = _EncoderFn.apply(x, bert.embeddings.LayerNorm.weight, self, plan["layout"], key_bias, seed)
         return y, plan, lens
 
 

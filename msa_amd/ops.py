@@ -213,6 +213,9 @@ def pair_proj_bwd(feat, J, dJ, T, dW, db):
                                         dW.data_ptr(), db.data_ptr(), H), "mmbert_pair_proj_bwd")
 
 
+NO_KEY = -1.0e30        # key-bias value of the padding slots ("no such key")
+
+
 class SeqLayout:
     """Device-side description of the packed variable-length token matrix: ``lens[i]`` tokens per
     sequence, sequences back to back.  Cached per shape (built on the host, no device sync)."""
@@ -221,9 +224,14 @@ class SeqLayout:
         lib = _lib.load()
         rows_f, rows_b = lib.mmbert_attn_tile_rows(0), lib.mmbert_attn_tile_rows(1)
         starts, tiles_seq, tiles_r0, ftiles_seq, ftiles_r0, bases = [], [], [], [], [], []
+        bstarts, bidx = [], []
         s = 0
         e = 0
+        bp = 0
         for i, n in enumerate(lens):
+            bstarts.append(bp)
+            bidx.extend(range(bp, bp + n))
+            bp += (n + 127) // 128 * 128
             starts.append(s)
             s += n
             bases.append(e)
@@ -248,21 +256,34 @@ class SeqLayout:
         self.tile_seq = mk(tiles_seq, torch.int32)
         self.tile_r0 = mk(tiles_r0, torch.int32)
         self.ntiles = len(tiles_seq)
+        self.bias_start = mk(bstarts, torch.int32)        # padded key-bias layout (ceil128 entries per sequence)
+        self.bias_index = mk(bidx, torch.int64)           # token -> slot of the padded array
+        self.bias_len = bp
         self.ftile_seq = mk(ftiles_seq, torch.int32)
         self.ftile_r0 = mk(ftiles_r0, torch.int32)
         self.nftiles = len(ftiles_seq)
 
 
+def pad_key_bias(key_bias, layout: "SeqLayout"):
+    """[tokens] additive key bias -> the padded per-sequence layout the attention kernels read."""
+    out = torch.full((layout.bias_len,), NO_KEY, device=key_bias.device, dtype=torch.float32)
+    out.index_copy_(0, layout.bias_index, key_bias.float())
+    return out
+
+
 def attn_fwd(qkv, key_bias, layout: SeqLayout, H, *, drop: Drop = None, ctx=None, lse=None):
+    """``key_bias``: padded layout (pad_key_bias); a [tokens] vector is padded on the fly."""
     lib = _lib.load()
     M = qkv.shape[0]
+    if key_bias.numel() != layout.bias_len or layout.bias_len == M:
+        key_bias = pad_key_bias(key_bias, layout) if key_bias.numel() == M else key_bias
     assert qkv.shape[1] == 3 * H and qkv.is_contiguous()
     if ctx is None:
         ctx = torch.empty((M, H), device=qkv.device, dtype=torch.bfloat16)
     if lse is None:
         lse = torch.empty((M, layout.heads), device=qkv.device, dtype=torch.float32)
     d = drop or NO_DROP
-    _lib.check(lib.mmbert_attn_fwd(_stream(), qkv.data_ptr(), ctx.data_ptr(), lse.data_ptr(), key_bias.data_ptr(), H, layout.heads,
+    _lib.check(lib.mmbert_attn_fwd(_stream(), qkv.data_ptr(), ctx.data_ptr(), lse.data_ptr(), key_bias.data_ptr(), layout.bias_start.data_ptr(), H, layout.heads,
                                    layout.seq_start.data_ptr(), layout.seq_len.data_ptr(), layout.elem_base.data_ptr(),
                                    layout.ftile_seq.data_ptr(), layout.ftile_r0.data_ptr(), layout.nftiles, d[0], d[1], d[2]), "mmbert_attn_fwd")
     return ctx, lse
@@ -275,9 +296,11 @@ def attn_bwd(qkv, ctx, dctx, lse, key_bias, layout: SeqLayout, H, *, drop: Drop 
         dqkv = torch.empty_like(qkv)
     delta = torch.empty((M, layout.heads), device=qkv.device, dtype=torch.float32)
     d = drop or NO_DROP
+    if key_bias.numel() != layout.bias_len or layout.bias_len == M:
+        key_bias = pad_key_bias(key_bias, layout) if key_bias.numel() == M else key_bias
     assert dctx.is_contiguous() and ctx.is_contiguous()
     _lib.check(lib.mmbert_attn_bwd(_stream(), qkv.data_ptr(), ctx.data_ptr(), dctx.data_ptr(), dqkv.data_ptr(), lse.data_ptr(), delta.data_ptr(),
-                                   key_bias.data_ptr(), H, layout.heads, layout.seq_start.data_ptr(), layout.seq_len.data_ptr(),
+                                   key_bias.data_ptr(), layout.bias_start.data_ptr(), H, layout.heads, layout.seq_start.data_ptr(), layout.seq_len.data_ptr(),
                                    layout.elem_base.data_ptr(), layout.ftile_seq.data_ptr(), layout.ftile_r0.data_ptr(), layout.nftiles,
                                    layout.tile_seq.data_ptr(), layout.tile_r0.data_ptr(), layout.ntiles,
                                    d[0], d[1], d[2]), "mmbert_attn_bwd")
