@@ -37,8 +37,9 @@ int mmbert_gemm_nt(mmbert_stream_t stream, const void* A, int lda, const void* B
                    const void* U, int ldu, float alpha, const float* alpha_dev,
                    uint32_t drop_stream, uint32_t drop_thr16, float drop_scale);
 
-/* Kernel selection for mmbert_gemm_nt: 0 = by shape (default), 1 = 128x128 tile kernel, 2 = 256x256
- * 4-stage-ring kernel.  For tests and A/B benchmarking; results are identical up to fp32 summation order. */
+/* Kernel selection for mmbert_gemm_nt: 0 = by shape (default), 1 = 128x128 tile kernel, 2 = 4-stage-ring kernel
+ * with the tile height (256 or 224 rows) chosen by tile-round count, 3 = ring kernel 256x256, 4 = ring kernel
+ * 224x256.  For tests and A/B benchmarking; results are identical up to fp32 summation order. */
 void mmbert_gemm_nt_force(int mode);
 
 /* Weight gradients autograd computes for nn.Linear (REF:trainer.py:83):

@@ -62,6 +62,9 @@ def load() -> C.CDLL:
         fn = getattr(lib, name)          # AttributeError if the symbol is missing -> loud
         fn.restype = res
         fn.argtypes = args
+    mode = os.environ.get("MMBERT_NT_MODE")          # A/B benchmarking only: kernel selection of mmbert_gemm_nt
+    if mode:
+        lib.mmbert_gemm_nt_force(int(mode))
     _lib = lib
     return lib
 

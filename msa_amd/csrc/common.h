@@ -74,8 +74,11 @@ __device__ __forceinline__ float fast_erf(float x) {
     return copysignf(e, x);
 }
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + fast_erf(x * 0.70710678118654752f)); }
+// d/dx gelu = Phi(x) + x phi(x); erf(x/sqrt2) and phi share exp(-x^2/2): one exp and one rcp per element
 __device__ __forceinline__ float gelu_erf_grad(float x) {
-    const float cdf = 0.5f * (1.0f + fast_erf(x * 0.70710678118654752f));
-    const float pdf = 0.3989422804014327f * __expf(-0.5f * x * x);
-    return cdf + x * pdf;
+    const float e = __expf(-0.5f * x * x);
+    const float t = __frcp_rn(1.0f + 0.3275911f * 0.70710678118654752f * fabsf(x));
+    const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+    const float half_erf = copysignf(0.5f - 0.5f * poly * e, x);
+    return 0.5f + half_erf + x * (0.3989422804014327f * e);
 }

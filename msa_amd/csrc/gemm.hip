@@ -242,15 +242,34 @@ static int launch_nt(hipStream_t s, const GemmNT& p) {
 // 3-slot-ring variant with two workgroups per CU (to overlap one's epilogue with the other's K loop):
 // deep-K shapes fell from ~1080 to ~850 TF/s and the K=768 shapes did not improve.
 // -------------------------------------------------------------------------------------------------
-template <int EPI>
+// Diagnostic build only (-DMMB_STAMPS, tools/stamp_gemm.py): s_memtime stamps at the phase boundaries of the ring
+// kernel, kept in SGPRs and stored once at the end to a buffer nothing else reads.  No stamp exists in the product build.
+#ifdef MMB_STAMPS
+__device__ unsigned long long* g_stamps = nullptr;
+#define MMB_STAMP(var) { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var) :: "memory"); __builtin_amdgcn_sched_barrier(0); }
+#else
+#define MMB_STAMP(var)
+#endif
+
+// MI = 16-row MFMA blocks per wave along M: 8 (256-row tile) or 7 (224-row tile).  The 224-row variant exists for
+// tile-round quantisation only: at M = 18400 the 256-row tiling leaves every launch at 84 % of a whole number of
+// rounds over 256 CUs (216 / 648 / 864 tiles), the 224-row tiling at 97 % (249 / 747 / 996).  Staging is identical
+// (256 A rows are loaded; rows past the tile are never read), only the MFMA count and the epilogue shrink.
+template <int EPI, int MI>
 __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(const GemmNT p) {
+    constexpr int BM = 32 * MI;
+#ifdef MMB_STAMPS
+    unsigned long long st0 = 0, st1 = 0, st2 = 0, st3 = 0, rt0 = 0, rt3 = 0;
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rt0) :: "memory");
+    MMB_STAMP(st0)
+#endif
     extern __shared__ __attribute__((aligned(16))) char smem[];   // 4 slots x [A 16K | B 16K]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 2, wc = wave & 3;
-    const int tiles_n = (p.N + 255) >> 8, tiles_m = (p.M + 255) >> 8;
+    const int tiles_n = (p.N + 255) >> 8, tiles_m = (p.M + BM - 1) / BM;
     const int tile = xcd_remap(blockIdx.x, tiles_m * tiles_n);
-    const int m0 = (tile / tiles_n) << 8, n0 = (tile % tiles_n) << 8;
+    const int m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) << 8;
     const int ns = p.K >> 5;
     constexpr unsigned GT = 0x78;                                  // G = {0,2,3,1} packed 2 bits each: 0b01111000
 
@@ -274,35 +293,36 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(const GemmNT p) {
         }
     };
 
-    f32x4 acc[8][4];
+    f32x4 acc[MI][4];
 #pragma unroll
-    for (int i = 0; i < 8; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     const int fr = lane & 15, fq = lane >> 4;
     // lane-constant part of every fragment address: row fr of a 16-row block, swizzled chunk fq
     const int lane_off = fr * 64 + ((fq ^ ((GT >> (2 * ((fr >> 2) & 3))) & 3)) << 4);
-    const char* a_rd = smem + (wr * 128) * 64 + lane_off;
+    const char* a_rd = smem + (wr * MI * 16) * 64 + lane_off;
     const char* b_rd = smem + 16384 + (wc * 64) * 64 + lane_off;
-    auto load_frags = [&](int slot, bf16x8 (&af)[8], bf16x8 (&bfr)[4]) {
+    auto load_frags = [&](int slot, bf16x8 (&af)[MI], bf16x8 (&bfr)[4]) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) bfr[j] = *(const bf16x8*)(b_rd + slot * 32768 + j * 1024);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) af[i] = *(const bf16x8*)(a_rd + slot * 32768 + i * 1024);
+        for (int i = 0; i < MI; ++i) af[i] = *(const bf16x8*)(a_rd + slot * 32768 + i * 1024);
     };
-    auto mma = [&](const bf16x8 (&af)[8], const bf16x8 (&bfr)[4]) {
+    auto mma = [&](const bf16x8 (&af)[MI], const bf16x8 (&bfr)[4]) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i)
+        for (int i = 0; i < MI; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j)
                 acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
     };
 
-    bf16x8 a0[8], b0[4], a1[8], b1[4];
+    bf16x8 a0[MI], b0[4], a1[MI], b1[4];
     stage(0, 0); stage(1, 1); stage(2, 2); stage(3, 3);
     asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
     __builtin_amdgcn_s_barrier();
+    MMB_STAMP(st1)
     load_frags(0, a0, b0);
 
 #define NT256_STEP(SLOT, CUR_A, CUR_B, NXT_A, NXT_B)                                  \
@@ -327,14 +347,17 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(const GemmNT p) {
 #undef NT256_STEP
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // drain the dummy tail stages before LDS is reused
     __builtin_amdgcn_s_barrier();                            // every wave is done with the ring
+    MMB_STAMP(st2)
 
     const float alpha = p.alpha * (p.alpha_dev ? *p.alpha_dev : 1.0f);
     char* wl = smem + wave * 16384;                          // [64 rows][64 fp32] = 256-B rows, 16-B chunks XOR (row & 15)
     const int er = lane >> 3, ec = lane & 7;                 // read-back: 8 rows per pass, lane owns columns 8*ec .. 8*ec+7
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
+        const int nblk = half == 0 ? 4 : MI - 4;             // 16-row blocks in this half (compile-time after unrolling)
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
+            if (i >= nblk) continue;
             const int row = i * 16 + fr;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -345,10 +368,11 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(const GemmNT p) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // wave-private region: no barrier needed
 #pragma unroll
         for (int it = 0; it < 8; ++it) {
+            if (it >= 2 * nblk) continue;
             const int row = it * 8 + er;
             const float4 lo = *(const float4*)(wl + row * 256 + (((2 * ec) ^ (row & 15)) << 4));
             const float4 hi = *(const float4*)(wl + row * 256 + (((2 * ec + 1) ^ (row & 15)) << 4));
-            const int m = m0 + wr * 128 + half * 64 + row;
+            const int m = m0 + wr * (MI * 16) + half * 64 + row;
             const int n = n0 + wc * 64 + ec * 8;
             if (m < p.M && n < p.N) {
                 float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
@@ -357,28 +381,367 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(const GemmNT p) {
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // reads done before the next half overwrites the region
     }
+#ifdef MMB_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // stores acknowledged
+    MMB_STAMP(st3)
+    if (g_stamps && lane == 0) {
+        asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rt3) :: "memory");
+        unsigned long long* o = g_stamps + ((size_t)blockIdx.x * 8 + wave) * 6;
+        o[0] = st0; o[1] = st1; o[2] = st2; o[3] = st3; o[4] = rt0; o[5] = rt3;
+    }
+#endif
 }
 
-template <int EPI>
-static int launch_nt256(hipStream_t s, const GemmNT& p) {
-    const int tiles = ((p.M + 255) / 256) * ((p.N + 255) / 256);
+static int g_nt_force = 0;   // 0 auto, 1 force 128^2, 2 force the 256-wide kernels (tests / A-B benchmarking)
+static int g_nt_bm = 0;      // 0 auto, 256 / 224 forced (A-B benchmarking)
+static int g_nt_persist = 1;  // persistent stream kernel where eligible (0: launch-per-tile ring kernel)
+static int device_cus() {
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 256;
+        cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }
+    return cus;
+}
+
+// -------------------------------------------------------------------------------------------------
+// NT, persistent form of the ring kernel (the default for large shapes with K % 128 == 0).
+// Stamps of the launch-per-tile kernel above (tools/stamp_gemm.py, M = 18400) showed a workgroup outside its
+// K loop for 26-49 % of its life at K = 768: ~5 k clk from start to the first stage landing, 5-25 k clk of
+// epilogue with nothing in flight.  Here one workgroup per CU walks tiles v = b, b + G, b + 2G, ...; the
+// stages of ALL its tiles form one stream through the 4-slot ring (stream stage g sits in slot g & 3, is
+// issued at step g - 4), so the first four stages of the next tile are issued by the last four K steps of the
+// current one and land under its epilogue.  The epilogue works in a fifth 32 KiB LDS region (160 KiB in all):
+// per wave 16 rows x 64 fp32 at a time through inline-asm ds_write/ds_read (hipcc drains vmcnt(0) in front
+// of a plain LDS access while LDS-DMA is in flight), residual / GELU-input rows prefetched into the dead
+// fragment registers before the first block is transposed, 16 consecutive columns per lane -> 2 x 16-byte
+// global accesses per array.
+// vmcnt bookkeeping across a tile boundary: vector memory operations retire in issue order, and the
+// epilogue's loads and stores are issued BEHIND the next tile's stages 0-3.  Waiting for stage 0 therefore
+// allows 12 + E outstanding operations and the first three K steps allow 8 + E, E = a LOWER bound of the
+// epilogue's operation count (its stores; interior tiles issue them unconditionally, edge tiles use E = 0):
+// a bound that is too low only waits longer.  Steady state is the ring kernel's vmcnt(8).
+// -------------------------------------------------------------------------------------------------
+__host__ __device__ constexpr int mmb_waitcnt(int vm, int lgkm) { return (vm & 15) | ((vm >> 4) << 14) | 0x70 | (lgkm << 8); }
+
+template <int OFF>
+__device__ __forceinline__ void lds_write16(uint32_t lds_addr, const f32x4& v) {
+    asm volatile("ds_write_b128 %0, %1 offset:%2\n\ts_nop 1" :: "v"(lds_addr), "v"(v), "i"(OFF) : "memory");
+}
+template <int OFF>
+__device__ __forceinline__ void lds_read16f(f32x4& dst, uint32_t lds_addr) {
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(lds_addr), "i"(OFF) : "memory");
+}
+
+template <int EPI, int MI>
+__global__ __launch_bounds__(512, 2) void gemm_ntp_kernel(const GemmNT p) {
+#if __HIP_DEVICE_COMPILE__   // the host pass only needs the launch stub (the body uses device-only builtins)
+    constexpr int BM = 32 * MI;
+    constexpr int EST = MI * ((EPI & EPI_OUT_F32) ? 4 : 2) * ((EPI & EPI_GELU) ? 2 : 1);   // stores per wave per interior tile
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // 4 slots x [A 16K | B 16K] | 8 x 4 KiB epilogue scratch
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+    const int tiles_n = (p.N + 255) >> 8, tiles_m = (p.M + BM - 1) / BM;
+    const int ntiles = tiles_m * tiles_n, G = gridDim.x;
+    const int ns = p.K >> 5;                                       // multiple of 4 (dispatch)
+    constexpr unsigned GT = 0x78;
+
+    // ---- load cursor: runs 4 stages ahead of the MFMAs, crosses tile boundaries ----
+    struct Src { uint32_t a[2], b[2]; };
+    auto set_src = [&](int v, Src& o) {
+        int l = lane;
+        asm volatile("" : "+v"(l));                               // recomputed per call, nothing kept alive across the K loop
+        const int srow = l >> 2;
+        const uint32_t schunk = (l & 3) ^ ((GT >> (2 * ((srow >> 2) & 3))) & 3);
+        const int t = xcd_remap(v, ntiles);
+        const int tm0 = (t / tiles_n) * BM, tn0 = (t % tiles_n) << 8;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int r = wave * 32 + i * 16 + srow;
+            o.a[i] = ((uint32_t)min(tm0 + r, p.M - 1) * (uint32_t)p.lda + schunk * 8u) * 2u;
+            o.b[i] = ((uint32_t)min(tn0 + r, p.N - 1) * (uint32_t)p.ldb + schunk * 8u) * 2u;
+        }
+    };
+    Src cur, nxt;
+    set_src(blockIdx.x, cur);
+    nxt = cur;
+    // buffer addressing: descriptor (SGPRs) + 32-bit per-lane offset + scalar K offset -- no 64-bit VALU address
+    // arithmetic and no hoisted 64-bit per-lane pointers (the global_load_lds form spilled registers here)
+    const auto rsA = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, (int)((uint32_t)p.M * (uint32_t)p.lda * 2u), 0x00020000);
+    const auto rsB = __builtin_amdgcn_make_buffer_rsrc((void*)p.B, 0, (int)((uint32_t)p.N * (uint32_t)p.ldb * 2u), 0x00020000);
+    auto issue = [&](int slot, const Src& o, uint32_t kb) {      // kb: byte offset along K (wave-uniform)
+        char* base = smem + slot * 32768 + wave * 2048;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, LPTR(base + i * 1024), 16, o.a[i], kb, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, LPTR(base + 16384 + i * 1024), 16, o.b[i], kb, 0, 0);
+        }
+    };
+
+    const int fr = lane & 15, fq = lane >> 4;
+    const int lane_off = fr * 64 + ((fq ^ ((GT >> (2 * ((fr >> 2) & 3))) & 3)) << 4);
+    // 32-bit LDS addresses; ds offsets are 16-bit, so slots 2 and 3 read through a second pair of bases (opaque, or
+    // hipcc materialises one address register per fragment read of those slots and keeps them all alive)
+    typedef const __attribute__((address_space(3))) char* lds_cptr;
+    typedef const __attribute__((address_space(3))) bf16x8* lds_frag;
+    const lds_cptr a_rd = (lds_cptr)LPTR(smem) + (wr * MI * 16) * 64 + lane_off;
+    const lds_cptr b_rd = (lds_cptr)LPTR(smem) + 16384 + (wc * 64) * 64 + lane_off;
+    lds_cptr a_rd_hi = a_rd + 65536, b_rd_hi = b_rd + 65536;
+    asm volatile("" : "+v"(a_rd_hi), "+v"(b_rd_hi));
+    auto load_frags = [&](int slot, bf16x8 (&af)[MI], bf16x8 (&bfr)[4]) {
+        const lds_cptr ab = slot < 2 ? a_rd : a_rd_hi;
+        const lds_cptr bb = slot < 2 ? b_rd : b_rd_hi;
+        const int so = (slot & 1) * 32768;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bfr[j] = *(lds_frag)(bb + so + j * 1024);
+#pragma unroll
+        for (int i = 0; i < MI; ++i) af[i] = *(lds_frag)(ab + so + i * 1024);
+    };
+    f32x4 acc[MI][4];
+    auto mma = [&](const bf16x8 (&af)[MI], const bf16x8 (&bfr)[4]) {
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+    };
+    auto mma_first = [&](const bf16x8 (&af)[MI], const bf16x8 (&bfr)[4]) {     // C = 0: no accumulator clearing pass
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+    };
+
+    const float alpha = p.alpha * (p.alpha_dev ? *p.alpha_dev : 1.0f);
+
+    bf16x8 a0[MI], b0[4], a1[MI], b1[4];
+    issue(0, cur, 0); issue(1, cur, 64); issue(2, cur, 128); issue(3, cur, 192);
+    bool early = false;          // the previous tile's epilogue stores sit behind this tile's first stages in vmcnt order
+
+#define NTP_STEP(SLOT, CUR_A, CUR_B, NXT_A, NXT_B, MMA, WEARLY, LOADNEXT, SRC, KB)        \
+    {                                                                                     \
+        if (WEARLY) __builtin_amdgcn_s_waitcnt(mmb_waitcnt(8 + EST, 0));                  \
+        else __builtin_amdgcn_s_waitcnt(mmb_waitcnt(8, 0));                               \
+        __builtin_amdgcn_s_barrier();                                                     \
+        issue(SLOT, SRC, KB);                                                             \
+        if (LOADNEXT) load_frags((SLOT + 1) & 3, NXT_A, NXT_B);                           \
+        __builtin_amdgcn_s_setprio(1);                                                    \
+        MMA(CUR_A, CUR_B);                                                                \
+        __builtin_amdgcn_s_setprio(0);                                                    \
+    }
+
+    for (int v = blockIdx.x; v < ntiles; v += G) {
+        const int tile = xcd_remap(v, ntiles);
+        const int m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) << 8;
+        // K steps 0-3 issue stages 4-7 of this tile (ns >= 8).  `early` only selects the wait immediate (a scalar branch
+        // around one s_waitcnt); two full copies of the steps made hipcc spill accumulator tuples at the join
+        if (early) __builtin_amdgcn_s_waitcnt(mmb_waitcnt(12 + EST, 0));
+        else __builtin_amdgcn_s_waitcnt(mmb_waitcnt(12, 0));
+        __builtin_amdgcn_s_barrier();
+        load_frags(0, a0, b0);
+        NTP_STEP(0, a0, b0, a1, b1, mma_first, early, true, cur, 256)
+        NTP_STEP(1, a1, b1, a0, b0, mma, early, true, cur, 320)
+        NTP_STEP(2, a0, b0, a1, b1, mma, early, true, cur, 384)
+        NTP_STEP(3, a1, b1, a0, b0, mma, false, true, cur, 448)
+        for (int s = 4; s < ns - 4; s += 4) {
+            const uint32_t kb = (uint32_t)(s + 4) * 64u;
+            NTP_STEP(0, a0, b0, a1, b1, mma, false, true, cur, kb)
+            NTP_STEP(1, a1, b1, a0, b0, mma, false, true, cur, kb + 64)
+            NTP_STEP(2, a0, b0, a1, b1, mma, false, true, cur, kb + 128)
+            NTP_STEP(3, a1, b1, a0, b0, mma, false, true, cur, kb + 192)
+        }
+        // the last four K steps issue stages 0-3 of the workgroup's next tile
+        if (v + G < ntiles) set_src(v + G, nxt);                  // past the last tile: dead re-reads of the same stages
+        NTP_STEP(0, a0, b0, a1, b1, mma, false, true, nxt, 0)
+        NTP_STEP(1, a1, b1, a0, b0, mma, false, true, nxt, 64)
+        NTP_STEP(2, a0, b0, a1, b1, mma, false, true, nxt, 128)
+        NTP_STEP(3, a1, b1, a0, b0, mma, false, false, nxt, 192)
+        cur = nxt;
+
+        // ---- epilogue of this tile; the next tile's stages 0-3 are in flight / landed in the ring ----
+        // every per-lane epilogue address is derived from an opaque copy of the lane id, so that hipcc recomputes them
+        // here (a dozen VALU operations) instead of keeping ~20 loop-invariant registers alive across the K loop: there
+        // they spill, and a scratch reload is a vmcnt(0) drain of the stages in flight
+        // ... and every epilogue parameter is re-read (s_load) from an opaque copy of the kernel-argument pointer: kept in
+        // SGPRs across the K loop they overflow the scalar file into VGPR lanes, and from there into scratch
+        auto kp = __builtin_amdgcn_kernarg_segment_ptr();
+        asm volatile("" : "+s"(kp));
+        const __attribute__((address_space(4))) GemmNT& q = *(const __attribute__((address_space(4))) GemmNT*)kp;
+        int elane = lane;
+        asm volatile("" : "+v"(elane));
+        const int efr = elane & 15, efq = elane >> 4;
+        const uint32_t scratch = (uint32_t)(size_t)LPTR(smem) + 131072u + wave * 4096u;
+        // scratch rows are 256 B (64 fp32); 16-byte chunk c of row r sits at chunk c ^ r
+        const uint32_t wr_addr = scratch + efr * 256;                 // + ((4j + fq) ^ fr) * 16 per j
+        const int er = elane >> 2, eq = elane & 3;                    // read-back: row er, columns 16 eq .. 16 eq + 15
+        const uint32_t rd_addr = scratch + er * 256;
+        const bool interior = (m0 + BM <= q.M) && (n0 + 256 <= q.N);
+        const int mrow = m0 + wr * (MI * 16) + er;                   // + 16 i
+        const int ncol = n0 + wc * 64 + eq * 16;
+        const bool ncol_ok = ncol < q.N;                              // N % 8 == 0 and 16-column groups: check both halves below
+        // residual / GELU-input rows: prefetched PRE blocks ahead of their use (all MI blocks at once do not fit the
+        // register file next to the accumulators; a scratch reload would drain vmcnt)
+        constexpr int PRE = 3;
+        bf16x8 pre[MI][2];
+        auto load_pre = [&](int i) {
+            if constexpr (EPI & (EPI_RESID | EPI_GELU_BWD)) {
+                const bf16_t* src = (EPI & EPI_RESID) ? q.R : q.U;
+                const int ld = (EPI & EPI_RESID) ? q.ldr : q.ldu;
+                const int m = mrow + 16 * i;
+                // unconditional, clamped in-bounds (a half that is out of range is never stored): no branches, and
+                // nothing conditionally defined that hipcc would carry around the tile loop
+                const bf16_t* rp = src + (size_t)min(m, q.M - 1) * ld;
+                asm volatile("" : "+v"(rp));                        // pins the load behind the previous block's asm LDS traffic
+                pre[i][0] = *(const bf16x8*)(rp + min(ncol, q.N - 8));
+                pre[i][1] = *(const bf16x8*)(rp + min(ncol + 8, q.N - 8));
+            }
+        };
+#pragma unroll
+        for (int i = 0; i < PRE; ++i) load_pre(i);
+        float bias[16];
+        if constexpr (EPI & EPI_BIAS) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (interior || ncol + 4 * c + 4 <= q.N) b4 = *(const float4*)(q.bias + ncol + 4 * c);
+                bias[4 * c] = b4.x; bias[4 * c + 1] = b4.y; bias[4 * c + 2] = b4.z; bias[4 * c + 3] = b4.w;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+            if (i + PRE < MI) load_pre(i + PRE);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const f32x4 a4 = acc[i][j];
+                const f32x4 sc = {a4[0] * alpha, a4[1] * alpha, a4[2] * alpha, a4[3] * alpha};
+                lds_write16<0>(wr_addr + ((((j << 2) | efq) ^ efr) << 4), sc);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // wave-private scratch: no barrier
+            f32x4 q4[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) lds_read16f<0>(q4[c], rd_addr + ((((eq << 2) | c) ^ er) << 4));
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(q4[0]), "+v"(q4[1]), "+v"(q4[2]), "+v"(q4[3]) :: "memory");
+            const int m = mrow + 16 * i;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int n = ncol + 8 * h;
+                float vv[8] = {q4[2 * h][0], q4[2 * h][1], q4[2 * h][2], q4[2 * h][3], q4[2 * h + 1][0], q4[2 * h + 1][1], q4[2 * h + 1][2], q4[2 * h + 1][3]};
+                if constexpr (EPI & EPI_BIAS) {
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) vv[r] += bias[8 * h + r];
+                }
+                const bool ok = interior || (m < q.M && n + 8 <= q.N);
+                if constexpr (EPI & EPI_GELU) {
+                    if (q.aux) {
+                        bf16x8 u;
+#pragma unroll
+                        for (int r = 0; r < 8; ++r) u[r] = f2bf(vv[r]);
+                        if (ok) *(bf16x8*)(q.aux + (size_t)m * q.ldaux + n) = u;
+                    }
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) vv[r] = gelu_erf(vv[r]);
+                }
+                if constexpr (EPI & EPI_GELU_BWD) {
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) vv[r] *= gelu_erf_grad(bf2f(pre[i][h][r]));
+                }
+                if constexpr (EPI & EPI_RESID) {
+                    if (q.drop_thr16) {
+                        bool k0[4], k1[4];
+                        const uint64_t idx = (uint64_t)m * q.N + n;
+                        mmb_keep4(q.drop_stream, idx, q.drop_thr16, k0);
+                        mmb_keep4(q.drop_stream, idx + 4, q.drop_thr16, k1);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) { vv[r] = k0[r] ? vv[r] * q.drop_scale : 0.f; vv[4 + r] = k1[r] ? vv[4 + r] * q.drop_scale : 0.f; }
+                    }
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) vv[r] += bf2f(pre[i][h][r]);
+                }
+                if constexpr (EPI & EPI_OUT_F32) {
+                    float* c = (float*)q.C + (size_t)m * q.ldc + n;
+                    if (ok) {
+                        *(float4*)c = make_float4(vv[0], vv[1], vv[2], vv[3]);
+                        *(float4*)(c + 4) = make_float4(vv[4], vv[5], vv[6], vv[7]);
+                    }
+                } else {
+                    bf16x8 o;
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) o[r] = f2bf(vv[r]);
+                    if (ok) *(bf16x8*)((bf16_t*)q.C + (size_t)m * q.ldc + n) = o;
+                }
+            }
+        }
+        (void)ncol_ok;
+        early = interior && !((EPI & EPI_GELU) && !q.aux);
+    }
+#undef NTP_STEP
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // the dead tail stages
+#endif
+}
+
+template <int EPI, int MI>
+static int launch_ntp_mi(hipStream_t s, const GemmNT& p) {
+    constexpr int BM = 32 * MI;
+    const int tiles = ((p.M + BM - 1) / BM) * ((p.N + 255) / 256);
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)gemm_nt256_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+        hipError_t e = hipFuncSetAttribute((const void*)gemm_ntp_kernel<EPI, MI>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
-    hipLaunchKernelGGL(gemm_nt256_kernel<EPI>, dim3(tiles), dim3(512), 131072, s, p);
+    const int cus = device_cus();
+    hipLaunchKernelGGL((gemm_ntp_kernel<EPI, MI>), dim3(tiles < cus ? tiles : cus), dim3(512), 163840, s, p);
     MMB_CHECK_LAUNCH();
     return 0;
 }
 
+static bool ntp_eligible(const GemmNT& p) {
+    return !(p.K & 127) && p.K >= 256 && (long long)p.M * p.lda < (1ll << 31) && (long long)p.N * p.ldb < (1ll << 31);
+}
+
+template <int EPI, int MI>
+static int launch_nt256_mi(hipStream_t s, const GemmNT& p) {
+    constexpr int BM = 32 * MI;
+    const int tiles = ((p.M + BM - 1) / BM) * ((p.N + 255) / 256);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)gemm_nt256_kernel<EPI, MI>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((gemm_nt256_kernel<EPI, MI>), dim3(tiles), dim3(512), 131072, s, p);
+    MMB_CHECK_LAUNCH();
+    return 0;
+}
+
+template <int EPI>
+static int launch_nt256(hipStream_t s, const GemmNT& p) {
+    // Measured cost model (tools/stamp_gemm.py, tools/bench_gemm.py): a K step costs the same ~1270 clk for the 224- and
+    // the 256-row tile (LDS-bound), so what counts is the number of tile rounds over the CUs; the shorter tile also has
+    // the shorter epilogue.  224 rows unless that takes more rounds.  The persistent stream kernel (224-row form: the only
+    // one that fits the register file without spills) hides every prologue but the first and has the leaner epilogue
+    // (operand prefetch, 32-byte runs per lane): it won or tied on every shape of the step, single-round ones included.
+    const int cus = device_cus(), tn = (p.N + 255) / 256;
+    const int r256 = (((p.M + 255) / 256) * tn + cus - 1) / cus;
+    const int r224 = (((p.M + 223) / 224) * tn + cus - 1) / cus;
+    const bool can_persist = g_nt_persist && ntp_eligible(p);
+    if (g_nt_bm == 0) {
+        if (can_persist) return launch_ntp_mi<EPI, 7>(s, p);
+        return r224 <= r256 ? launch_nt256_mi<EPI, 7>(s, p) : launch_nt256_mi<EPI, 8>(s, p);
+    }
+    if (can_persist && g_nt_force == 2 && g_nt_persist == 2) return g_nt_bm == 224 ? launch_ntp_mi<EPI, 7>(s, p) : launch_ntp_mi<EPI, 8>(s, p);
+    return g_nt_bm == 224 ? launch_nt256_mi<EPI, 7>(s, p) : launch_nt256_mi<EPI, 8>(s, p);
+}
+
 // shape dispatch: the 256^2 pipeline needs >= 4 stages of K and enough rows to fill its tiles
-static int g_nt_force = 0;   // 0 auto, 1 force 128^2, 2 force 256^2 (tests / A-B benchmarking)
 template <int EPI>
 static int dispatch_nt(hipStream_t s, const GemmNT& p) {
     const bool big = (p.K >= 128) && (p.M >= 512) && (p.N >= 256) && !(p.N & 7) && !(p.ldc & 7) && !(p.ldr & 7) && !(p.ldaux & 7) && !(p.ldu & 7);
-    if ((g_nt_force == 2 && !(p.N & 7)) || (g_nt_force == 0 && big)) return launch_nt256<EPI>(s, p);
+    if ((g_nt_force >= 2 && !(p.N & 7)) || (g_nt_force == 0 && big)) return launch_nt256<EPI>(s, p);
     return launch_nt<EPI>(s, p);
 }
 
@@ -674,7 +1037,18 @@ int mmbert_gemm_nt(hipStream_t stream, const void* A, int lda, const void* B, in
 }
 
 // test / benchmarking hook: 0 = automatic shape dispatch, 1 = always the 128^2 kernel, 2 = always the 256^2 kernel
-void mmbert_gemm_nt_force(int mode) { g_nt_force = mode; }
+#ifdef MMB_STAMPS
+int mmbert_debug_set_stamps(void* buf) {
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), &buf, sizeof(buf));
+}
+#endif
+void mmbert_gemm_nt_force(int mode) {
+    // 0 auto | 1 128^2 | ring kernel, one launch slot per tile: 2 (tile height auto), 3 (256x256), 4 (224x256)
+    // | persistent stream kernel: 5 (tile height auto), 6 (256x256), 7 (224x256)
+    g_nt_force = mode >= 2 ? 2 : mode;
+    g_nt_bm = (mode == 3 || mode == 6) ? 256 : (mode == 4 || mode == 7) ? 224 : 0;
+    g_nt_persist = (mode >= 2 && mode <= 4) ? 0 : (mode >= 6 ? 2 : 1);      // 2: forced persistent tile height
+}
 
 static int tn_plan(int nprob, const int* N, const int* K, int M, int* splits_out, int* tiles_out) {
     int tiles = 0;

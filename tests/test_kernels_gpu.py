@@ -54,10 +54,10 @@ def test_gemm_nt_plain_and_bias(ops, M, N, K):
     assert_close(ops.gemm_nt(A.to(DEV), B.to(DEV), bias=bias.to(DEV), out_f32=True, alpha=0.5), 0.5 * ref + bias, 1e-4, 1e-3, "f32 out")
 
 
-@pytest.mark.parametrize("mode", [1, 2])
+@pytest.mark.parametrize("mode", [1, 3, 4, 6, 7])
 @pytest.mark.parametrize("M,N,K", [(256, 256, 128), (700, 768, 768), (1150, 2304, 768), (520, 768, 3072), (2048, 30592, 128), (513, 260, 160)])
 def test_gemm_nt_both_kernels_all_epilogues(ops, mode, M, N, K):
-    """The 128^2 and the 256^2 (4-stage ring) kernels, forced, on ragged shapes: M, N not tile multiples, K = 32*odd."""
+    """The 128^2 and the 256x256 / 224x256 (4-stage ring) kernels, forced, on ragged shapes: M, N not tile multiples, K = 32*odd."""
     from msa_amd import _lib
     lib = _lib.load()
     lib.mmbert_gemm_nt_force(mode)
@@ -78,12 +78,13 @@ def test_gemm_nt_both_kernels_all_epilogues(ops, mode, M, N, K):
         lib.mmbert_gemm_nt_force(0)
 
 
-def test_gemm_nt256_exact_integers(ops):
+@pytest.mark.parametrize("mode,M", [(3, 384), (4, 384), (4, 450), (2, 18400 // 8), (6, 384), (7, 450), (7, 18400), (6, 18400), (5, 5000)])
+def test_gemm_nt256_exact_integers(ops, mode, M):
     from msa_amd import _lib
     lib = _lib.load()
-    lib.mmbert_gemm_nt_force(2)
+    lib.mmbert_gemm_nt_force(mode)
     try:
-        M, N, K = 384, 512, 256
+        N, K = 512, 256
         A = ((torch.arange(M)[:, None] * 5 + torch.arange(K)[None, :] * 3) % 7 - 3.0)
         B = ((torch.arange(N)[:, None] * 2 + torch.arange(K)[None, :] * 11) % 5 - 2.0)
         out = ops.gemm_nt(bf(A).to(DEV), bf(B).to(DEV), out_f32=True)

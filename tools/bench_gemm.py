@@ -12,6 +12,8 @@ shapes = [("qkv", M, 2304, 768, "bias"), ("o", M, 768, 768, "resid"), ("w1", M, 
           ("dgelu", M, 3072, 768, "gelu_bwd"), ("dy1", M, 768, 3072, "resid0"), ("dx", M, 768, 2304, "resid0"), ("dctx", M, 768, 768, "plain"),
           ("vocab", M, 30592, 768, "bias"), ("dvocab", M, 768, 30592, "plain")]
 rounds = int(os.environ.get("ROUNDS", 5))
+MODES = [int(x) for x in os.environ.get("MODES", "3,4").split(",")]
+NAMES = {0: "default", 1: "128sq", 2: "ring auto", 3: "ring256", 4: "ring224", 5: "pers auto", 6: "pers256", 7: "pers224"}
 for name, m, n, k, epi in shapes:
     A = torch.randn(m, k, device=dev).bfloat16(); B = (torch.randn(n, k, device=dev) * 0.05).bfloat16()
     bias = torch.randn(n, device=dev); R = torch.randn(m, n, device=dev).bfloat16(); U = torch.randn(m, n, device=dev).bfloat16()
@@ -23,12 +25,12 @@ for name, m, n, k, epi in shapes:
     elif epi == "gelu": kw.update(bias=bias, gelu=True, aux=aux)
     elif epi == "gelu_bwd": kw.update(gelu_bwd_u=U)
     res = {}
-    for mode in (1, 2):
+    for mode in MODES:
         lib.mmbert_gemm_nt_force(mode)
         for _ in range(2): ops.gemm_nt(A, B, **kw)
-    ts = {1: [], 2: []}
+    ts = {m_: [] for m_ in MODES}
     for r in range(rounds):
-        for mode in (1, 2):
+        for mode in MODES:
             lib.mmbert_gemm_nt_force(mode)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
@@ -37,8 +39,8 @@ for name, m, n, k, epi in shapes:
             ts[mode].append(e0.elapsed_time(e1) / 5)
     fl = 2.0 * m * n * k
     s = f"{name:7s} M={m} N={n} K={k} {epi:9s}"
-    for mode in (1, 2):
+    for mode in MODES:
         t = sorted(ts[mode])[len(ts[mode]) // 2]
-        s += f" | k{128*mode}: {t*1e3:7.1f} us {fl/t/1e9:7.1f} TF"
+        s += f" | {NAMES[mode]}: {t*1e3:7.1f} us {fl/t/1e9:7.1f} TF"
     print(s, flush=True)
 lib.mmbert_gemm_nt_force(0)
