@@ -41,6 +41,8 @@ int mmbert_gemm_nt(mmbert_stream_t stream, const void* A, int lda, const void* B
  * with the tile height (256 or 224 rows) chosen by tile-round count, 3 = ring kernel 256x256, 4 = ring kernel
  * 224x256.  For tests and A/B benchmarking; results are identical up to fp32 summation order. */
 void mmbert_gemm_nt_force(int mode);
+/* Split count of the token axis in mmbert_gemm_tn / _grouped: 0 = by shape (default), > 0 forced.  A/B benchmarking. */
+void mmbert_gemm_tn_force_splits(int splits);
 
 /* Weight gradients autograd computes for nn.Linear (REF:trainer.py:83):
  *   W[N,K] (fp32, contiguous: ldw == K) = (accumulate ? W : 0) + alpha * alpha_dev[0] * A[M,N]^T . B[M,K]

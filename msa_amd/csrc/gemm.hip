@@ -521,6 +521,10 @@ __global__ __launch_bounds__(512, 2) void gemm_ntp_kernel(const GemmNT p) {
     bf16x8 a0[MI], b0[4], a1[MI], b1[4];
     issue(0, cur, 0); issue(1, cur, 64); issue(2, cur, 128); issue(3, cur, 192);
     bool early = false;          // the previous tile's epilogue stores sit behind this tile's first stages in vmcnt order
+#ifdef MMB_STAMPS
+    unsigned long long sa = 0, sb = 0, sc_ = 0, sd = 0, t_wait = 0, t_loop = 0, t_epi = 0, rt0 = 0, rt3 = 0, ntile = 0;
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rt0) :: "memory");
+#endif
 
 #define NTP_STEP(SLOT, CUR_A, CUR_B, NXT_A, NXT_B, MMA, WEARLY, LOADNEXT, SRC, KB)        \
     {                                                                                     \
@@ -539,9 +543,11 @@ __global__ __launch_bounds__(512, 2) void gemm_ntp_kernel(const GemmNT p) {
         const int m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) << 8;
         // K steps 0-3 issue stages 4-7 of this tile (ns >= 8).  `early` only selects the wait immediate (a scalar branch
         // around one s_waitcnt); two full copies of the steps made hipcc spill accumulator tuples at the join
+        MMB_STAMP(sa)
         if (early) __builtin_amdgcn_s_waitcnt(mmb_waitcnt(12 + EST, 0));
         else __builtin_amdgcn_s_waitcnt(mmb_waitcnt(12, 0));
         __builtin_amdgcn_s_barrier();
+        MMB_STAMP(sb)
         load_frags(0, a0, b0);
         NTP_STEP(0, a0, b0, a1, b1, mma_first, early, true, cur, 256)
         NTP_STEP(1, a1, b1, a0, b0, mma, early, true, cur, 320)
@@ -561,6 +567,7 @@ __global__ __launch_bounds__(512, 2) void gemm_ntp_kernel(const GemmNT p) {
         NTP_STEP(2, a0, b0, a1, b1, mma, false, true, nxt, 128)
         NTP_STEP(3, a1, b1, a0, b0, mma, false, false, nxt, 192)
         cur = nxt;
+        MMB_STAMP(sc_)
 
         // ---- epilogue of this tile; the next tile's stages 0-3 are in flight / landed in the ring ----
         // every per-lane epilogue address is derived from an opaque copy of the lane id, so that hipcc recomputes them
@@ -611,20 +618,42 @@ __global__ __launch_bounds__(512, 2) void gemm_ntp_kernel(const GemmNT p) {
                 bias[4 * c] = b4.x; bias[4 * c + 1] = b4.y; bias[4 * c + 2] = b4.z; bias[4 * c + 3] = b4.w;
             }
         }
+        // Transposition through the wave-private scratch, software-pipelined: a wave's DS instructions execute in issue
+        // order, so block i + 1 is written (and its read-back issued) right behind the read-back of block i with no wait
+        // in between; only the consumer of block i waits, with a COUNTED lgkmcnt that leaves those 8 younger DS
+        // operations in flight (compiler-issued scalar loads in flight only make that wait stricter).
+        uint32_t wa[4], ra[4];
 #pragma unroll
-        for (int i = 0; i < MI; ++i) {
-            if (i + PRE < MI) load_pre(i + PRE);
+        for (int j = 0; j < 4; ++j) {
+            wa[j] = wr_addr + ((((j << 2) | efq) ^ efr) << 4);
+            ra[j] = rd_addr + ((((eq << 2) | j) ^ er) << 4);
+        }
+        auto wr_block = [&](int i) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const f32x4 a4 = acc[i][j];
                 const f32x4 sc = {a4[0] * alpha, a4[1] * alpha, a4[2] * alpha, a4[3] * alpha};
-                lds_write16<0>(wr_addr + ((((j << 2) | efq) ^ efr) << 4), sc);
+                lds_write16<0>(wa[j], sc);
             }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // wave-private scratch: no barrier
-            f32x4 q4[4];
+        };
+        auto rd_block = [&](f32x4 (&d)[4]) {
 #pragma unroll
-            for (int c = 0; c < 4; ++c) lds_read16f<0>(q4[c], rd_addr + ((((eq << 2) | c) ^ er) << 4));
-            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(q4[0]), "+v"(q4[1]), "+v"(q4[2]), "+v"(q4[3]) :: "memory");
+            for (int c = 0; c < 4; ++c) lds_read16f<0>(d[c], ra[c]);
+        };
+        f32x4 qbuf[2][4];
+        wr_block(0);
+        rd_block(qbuf[0]);
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+            if (i + PRE < MI) load_pre(i + PRE);
+            f32x4 (&q4)[4] = qbuf[i & 1];
+            if (i + 1 < MI) {
+                wr_block(i + 1);
+                rd_block(qbuf[(i + 1) & 1]);
+                asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(q4[0]), "+v"(q4[1]), "+v"(q4[2]), "+v"(q4[3]) :: "memory");
+            } else {
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(q4[0]), "+v"(q4[1]), "+v"(q4[2]), "+v"(q4[3]) :: "memory");
+            }
             const int m = mrow + 16 * i;
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
@@ -676,10 +705,21 @@ __global__ __launch_bounds__(512, 2) void gemm_ntp_kernel(const GemmNT p) {
             }
         }
         (void)ncol_ok;
+#ifdef MMB_STAMPS
+        MMB_STAMP(sd)
+        t_wait += sb - sa; t_loop += sc_ - sb; t_epi += sd - sc_; ++ntile;
+#endif
         early = interior && !((EPI & EPI_GELU) && !q.aux);
     }
 #undef NTP_STEP
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // the dead tail stages
+#ifdef MMB_STAMPS
+    if (g_stamps && lane == 0) {
+        asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rt3) :: "memory");
+        unsigned long long* o = g_stamps + ((size_t)blockIdx.x * 8 + wave) * 6;
+        o[0] = t_wait; o[1] = t_loop; o[2] = t_epi; o[3] = ntile; o[4] = rt0; o[5] = rt3;
+    }
+#endif
 #endif
 }
 
@@ -1050,12 +1090,37 @@ void mmbert_gemm_nt_force(int mode) {
     g_nt_persist = (mode >= 2 && mode <= 4) ? 0 : (mode >= 6 ? 2 : 1);      // 2: forced persistent tile height
 }
 
+static int g_tn_splits = 0;   // 0 = by shape; > 0 forces the split count of the token axis (A/B benchmarking)
+void mmbert_gemm_tn_force_splits(int splits) { g_tn_splits = splits; }
+
 static int tn_plan(int nprob, const int* N, const int* K, int M, int* splits_out, int* tiles_out) {
     int tiles = 0;
-    for (int i = 0; i < nprob; ++i) tiles += ((N[i] + 255) / 256) * ((K[i] + 127) / 128);
-    int splits = 1;
-    if (tiles < 512) splits = (512 + tiles - 1) / tiles;
+    double elems = 0;
+    for (int i = 0; i < nprob; ++i) { tiles += ((N[i] + 255) / 256) * ((K[i] + 127) / 128); elems += (double)N[i] * K[i]; }
+    // Split count of the token axis, by a cost model fitted to tools/bench_tn.py (M = 18400, one layer's group: 1 -> 358,
+    // 2 -> 290, 3 -> 310, 4 -> 294, 5 -> 321, 7 -> ~305 us).  Two workgroups share a CU; a workgroup streams a token row
+    // in ~31 ns when it shares and in ~0.6 of that when it has the CU alone, plus ~6 us per workgroup outside its loop; a
+    // launch of W workgroups costs (full rounds of 2 x CUs + 1 for a remainder over one per CU, 0.6 for a smaller one)
+    // workgroup times; every extra slab costs a write and a read of the weights' fp32 image (mostly L2 / MALL hits).
+    // The smallest split count within 3 % of the best modelled cost wins (fewer slabs = less workspace traffic).
+    const int slots = 2 * device_cus();
     const int max_splits = (M + 511) / 512;
+    double cost[9];
+    double best_cost = 1e300;
+    int top = 1;
+    for (int sp = 1; sp <= 8 && sp <= (max_splits < 1 ? 1 : max_splits); ++sp) {
+        const long long wgs = (long long)tiles * sp;
+        const long long full = wgs / slots, rem = wgs % slots;
+        const double rows = (double)((M + sp - 1) / sp);
+        cost[sp] = (rows * 30.9e-9 + 6e-6) * ((double)full + (rem > slots / 2 ? 1.0 : rem > 0 ? 0.6 : 0.0)) + (sp - 1) * elems * 8.0 / 9.4e12;
+        if (cost[sp] < best_cost) best_cost = cost[sp];
+        top = sp;
+    }
+    int best = 1;
+    for (int sp = 1; sp <= top; ++sp)
+        if (cost[sp] <= 1.03 * best_cost) { best = sp; break; }
+    int splits = best;
+    if (g_tn_splits > 0) splits = g_tn_splits;
     if (splits > max_splits) splits = max_splits;
     if (splits < 1) splits = 1;
     *splits_out = splits; *tiles_out = tiles;

@@ -66,9 +66,19 @@ for name, m, n, k, epi in shapes:
     used = st[:, 0, 0] != 0
     st = st[used]
     w0 = st[:, 0, :]                      # wave 0 of each workgroup
+    rt0, rt3 = w0[:, 4], w0[:, 5]                      # 100 MHz constant clock, chip-wide
+    if mode == 0 or mode >= 5:                         # persistent kernel: per-workgroup sums over its tiles
+        nt_ = w0[:, 3].astype(np.float64)
+        span_us = (rt3.max() - rt0.min()) / 100.0
+        life_us = (rt3 - rt0) / 100.0
+        tot = (w0[:, 0] + w0[:, 1] + w0[:, 2]).astype(np.float64)
+        print(f"{name:6s} N={n:5d} K={k:5d} {epi:8s} wgs={len(w0):4d} tiles/wg {nt_.mean():4.2f} kernel {e0.elapsed_time(e1)*1e3:7.1f} us, span {span_us:7.1f} us | "
+              f"per-tile clk: stage-0 wait {(w0[:,0]/nt_).mean():6.0f}  K-loop {(w0[:,1]/nt_).mean():7.0f}  epilogue {(w0[:,2]/nt_).mean():6.0f} | "
+              f"shares {w0[:,0].sum()/tot.sum():.2f}/{w0[:,1].sum()/tot.sum():.2f}/{w0[:,2].sum()/tot.sum():.2f} | clock {tot.sum()/life_us.sum():5.0f} MHz (stamped part) | "
+              f"WG life mean {life_us.mean():6.1f} max {life_us.max():6.1f} us", flush=True)
+        continue
     pro, loop, epi_c = (w0[:, 1] - w0[:, 0]), (w0[:, 2] - w0[:, 1]), (w0[:, 3] - w0[:, 2])
     life = (w0[:, 3] - w0[:, 0])
-    rt0, rt3 = w0[:, 4], w0[:, 5]                      # 100 MHz constant clock, chip-wide
     span_us = (rt3.max() - rt0.min()) / 100.0
     life_us = (rt3 - rt0) / 100.0
     mhz = life.sum() / life_us.sum()
