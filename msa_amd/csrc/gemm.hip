@@ -246,6 +246,13 @@ static int launch_nt(hipStream_t s, const GemmNT& p) {
 // kernel, kept in SGPRs and stored once at the end to a buffer nothing else reads.  No stamp exists in the product build.
 #ifdef MMB_STAMPS
 __device__ unsigned long long* g_stamps = nullptr;
+// timing-only experiments (bit mask; outputs are wrong by construction): 1 zero-record descriptors (LDS-DMA loads dropped by
+// the range check: instruction stream and waits stay, memory traffic goes), 32 whole-cache-line source pattern (8 rows x 128 B
+// per load instruction instead of 16 x 64 B).  Round-1 findings with these and with per-part ablations of the K step (MFMAs,
+// fragment reads, LDS-DMA issue switched off one at a time): the step costs ~1180-1300 clk whether or not the MFMAs run and
+// whether or not the loads touch memory -- ISSUING 32 sixteen-byte-per-lane vector loads per CU and step is the floor
+// (~37 clk per wave instruction, LDS-DMA and register loads alike, = 27-32 B/clk/CU), just above the 1024 clk of the MFMAs.
+__device__ int g_nt_dbg = 0;
 #define MMB_STAMP(var) { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var) :: "memory"); __builtin_amdgcn_sched_barrier(0); }
 #else
 #define MMB_STAMP(var)
@@ -463,6 +470,13 @@ __global__ __launch_bounds__(512, 2) void gemm_ntp_kernel(const GemmNT p) {
             const int r = wave * 32 + i * 16 + srow;
             o.a[i] = ((uint32_t)min(tm0 + r, p.M - 1) * (uint32_t)p.lda + schunk * 8u) * 2u;
             o.b[i] = ((uint32_t)min(tn0 + r, p.N - 1) * (uint32_t)p.ldb + schunk * 8u) * 2u;
+#ifdef MMB_STAMPS
+            if (g_nt_dbg & 32) {
+                const int r8 = wave * 32 + i * 8 + (l >> 3);
+                o.a[i] = ((uint32_t)min(tm0 + r8, p.M - 1) * (uint32_t)p.lda + (l & 7) * 8u) * 2u;
+                o.b[i] = ((uint32_t)min(tn0 + r8, p.N - 1) * (uint32_t)p.ldb + (l & 7) * 8u) * 2u;
+            }
+#endif
         }
     };
     Src cur, nxt;
@@ -470,8 +484,14 @@ __global__ __launch_bounds__(512, 2) void gemm_ntp_kernel(const GemmNT p) {
     nxt = cur;
     // buffer addressing: descriptor (SGPRs) + 32-bit per-lane offset + scalar K offset -- no 64-bit VALU address
     // arithmetic and no hoisted 64-bit per-lane pointers (the global_load_lds form spilled registers here)
-    const auto rsA = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, (int)((uint32_t)p.M * (uint32_t)p.lda * 2u), 0x00020000);
-    const auto rsB = __builtin_amdgcn_make_buffer_rsrc((void*)p.B, 0, (int)((uint32_t)p.N * (uint32_t)p.ldb * 2u), 0x00020000);
+#ifdef MMB_STAMPS
+    const int dbg_bits = __builtin_amdgcn_readfirstlane(g_nt_dbg);
+    const uint32_t recA = (dbg_bits & 1) ? 0u : (uint32_t)p.M * (uint32_t)p.lda * 2u, recB = (dbg_bits & 1) ? 0u : (uint32_t)p.N * (uint32_t)p.ldb * 2u;
+#else
+    const uint32_t recA = (uint32_t)p.M * (uint32_t)p.lda * 2u, recB = (uint32_t)p.N * (uint32_t)p.ldb * 2u;
+#endif
+    const auto rsA = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, (int)recA, 0x00020000);
+    const auto rsB = __builtin_amdgcn_make_buffer_rsrc((void*)p.B, 0, (int)recB, 0x00020000);
     auto issue = [&](int slot, const Src& o, uint32_t kb) {      // kb: byte offset along K (wave-uniform)
         char* base = smem + slot * 32768 + wave * 2048;
 #pragma unroll
@@ -1080,6 +1100,9 @@ int mmbert_gemm_nt(hipStream_t stream, const void* A, int lda, const void* B, in
 #ifdef MMB_STAMPS
 int mmbert_debug_set_stamps(void* buf) {
     return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), &buf, sizeof(buf));
+}
+int mmbert_debug_set_nt_dbg(int v) {
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_nt_dbg), &v, sizeof(v));
 }
 #endif
 void mmbert_gemm_nt_force(int mode) {

@@ -44,6 +44,11 @@ shapes = [("qkv", M, 2304, 768, "bias"), ("o", M, 768, 768, "resid"), ("w1", M, 
           ("dgelu", M, 3072, 768, "gelu_bwd"), ("dx", M, 768, 2304, "resid0"), ("dctx", M, 768, 768, "plain"), ("vocab", M, 30592, 768, "bias")]
 buf = torch.zeros(16384 * 8 * 6, device=dev, dtype=torch.int64)
 assert lib.mmbert_debug_set_stamps(buf.data_ptr()) == 0
+if os.environ.get("DBG"):
+    lib.mmbert_debug_set_nt_dbg.restype = ctypes.c_int
+    lib.mmbert_debug_set_nt_dbg.argtypes = [ctypes.c_int]
+    assert lib.mmbert_debug_set_nt_dbg(int(os.environ["DBG"])) == 0
+    print("timing-only experiment", os.environ["DBG"], "(outputs are wrong by construction)")
 lib.mmbert_gemm_nt_force(mode)
 for name, m, n, k, epi in shapes:
     A = torch.randn(m, k, device=dev).bfloat16(); B = (torch.randn(n, k, device=dev) * 0.05).bfloat16()
