@@ -162,7 +162,7 @@ def main():
                     kern[k] = (fl, ms, len(lst))
             fl, ms, n = kern["nt"]
             ach = fl / (ms * 1e-3) / 1e12
-            res["roofline"] = {"bound": "mfma", "kernel": "gemm_nt256_kernel (bf16 MFMA 16x16x32, 256x256 tile, 4-stage LDS-DMA ring; all epilogues)",
+            res["roofline"] = {"bound": "mfma", "kernel": "gemm_ntp_kernel (bf16 MFMA 16x16x32, persistent 224x256-tile stream through a 4-slot LDS-DMA ring; all epilogues)",
                                "achieved": round(ach, 1), "peak": 2500.0, "unit": "TFLOP/s", "frac": round(ach / 2500.0, 4),
                                "traffic": None, "launches": n, "avg_launch_us": round(1e3 * ms / n, 2),
                                "share_of_step_time": round(ms * 1e-3 / elapsed, 3)}

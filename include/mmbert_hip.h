@@ -94,7 +94,8 @@ int mmbert_embed_scatter(mmbert_stream_t stream, const int64_t* ids, const int64
 int mmbert_pair_proj_fwd(mmbert_stream_t stream, const float* feat, int B, int P, int D, const float* W, const float* bias, int H,
                          void* out, int ldo, int T);
 int mmbert_pair_proj_bwd(mmbert_stream_t stream, const float* feat, int B, int P, int D, const void* J, const void* dJ, int ld, int T,
-                         float* dW, float* db, int H);
+                         float* dW, float* db, int H, void* workspace /* mmbert_pair_proj_bwd_workspace() bytes */);
+size_t mmbert_pair_proj_bwd_workspace(int B, int P, int D, int H);
 
 /* ---- attention (head dim 64) over packed variable-length sequences ----
  * softmax(q.k^T/8 + key_bias) -> dropout -> .v   (HF:111-136); REF mask plumbing: key_bias is

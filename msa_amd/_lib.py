@@ -32,7 +32,8 @@ SIGNATURES = {
     "mmbert_embed_gather": (I, [P, P, P, P, P, P, I, I, I, I, P, I]),
     "mmbert_embed_scatter": (I, [P, P, P, P, I, I, I, I, I, P, P, P]),
     "mmbert_pair_proj_fwd": (I, [P, P, I, I, I, P, P, I, P, I, I]),
-    "mmbert_pair_proj_bwd": (I, [P, P, I, I, I, P, P, I, I, P, P, I]),
+    "mmbert_pair_proj_bwd": (I, [P, P, I, I, I, P, P, I, I, P, P, I, P]),
+    "mmbert_pair_proj_bwd_workspace": (SZ, [I, I, I, I]),
     "mmbert_attn_tile_rows": (I, [I]),
     "mmbert_attn_fwd": (I, [P, P, P, P, P, P, I, I, P, P, P, P, P, I, U32, U32, F]),
     "mmbert_attn_bwd": (I, [P, P, P, P, P, P, P, P, P, I, I, P, P, P, P, P, I, P, P, I, U32, U32, F]),

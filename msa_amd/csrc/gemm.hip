@@ -811,12 +811,14 @@ static int dispatch_nt(hipStream_t s, const GemmNT& p) {
 // split over M into fp32 slabs reduced deterministically by tn_reduce_kernel, and optionally
 // bias_p[N_p] += alpha * colsum(A_p): the bias gradient rides on the MFMA with an all-ones A operand.
 //
-// Workgroup = 256 threads (4 waves as 2(k) x 2(n)), output tile 256(n) x 128(k); a wave owns
-// 64(k) x 128(n) = 4 x 8 MFMA tiles (the v1 64x64 wave tile was LDS-read bound: 1 transposed read per
-// MFMA; this shape needs 0.75).  The token axis is consumed in 32-row stages through a 3-slot LDS ring
-// (3 x 24 KiB, 2 workgroups per CU): stages s+1, s+2 are in flight behind a counted vmcnt(6) while
-// stage s is read with ds_read_b64_tr_b16 (both operands are needed "m-major", i.e. transposed) and
-// multiplied.  LDS rows are 512 B (A) / 256 B (B); 16-byte chunks are XOR-swizzled by
+// Workgroup = 512 threads (8 waves as 4(k) x 2(n)), output tile 256(n) x 256(k), one workgroup per CU; a wave owns
+// 64(k) x 128(n) = 4 x 8 MFMA tiles.  The token axis is consumed in 32-row stages through a 4-slot LDS ring
+// (A slots at 0, B slots at 64 KiB, 16 KiB each): stages s+1, s+2 are in flight behind a counted vmcnt(8) while
+// stage s is read with ds_read_b64_tr_b16 (both operands are needed "m-major", i.e. transposed) and multiplied.
+// Why 256 x 256: a CU issues a 16-byte-per-lane vector load every ~37 clk at best (see g_nt_dbg above).  The former
+// 256(n) x 128(k) tile (4 waves, two workgroups per CU) needed 48 loads for the MFMA work of 1024 clk -> ~1780 clk,
+// load-issue bound at ~58 % of the MFMA rate (measured ~54 %); this tile needs 32 (~1180 clk), like the NT kernel.
+// LDS rows are 512 B; 16-byte chunks are XOR-swizzled by
 // ((row&3)|((row>>1)&4))<<1 on the source address and on the read, so the 8 rows a 32-lane half
 // touches in one transposed read fall on 8 distinct 32-byte bank groups.
 // -------------------------------------------------------------------------------------------------
@@ -843,11 +845,11 @@ __device__ __forceinline__ void tr_read(u32x2& dst, unsigned lds_addr) {
     asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(lds_addr), "i"(OFF) : "memory");
 }
 
-__global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const GemmTNG g) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];   // 3 slots x [A 32x256 (16 KiB) | B 32x128 (8 KiB)]
+__global__ __launch_bounds__(512, 2) void gemm_tn_kernel(const GemmTNG g) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // A: 4 slots x 32x256 (16 KiB) at 0 | B: 4 slots x 32x256 at 64 KiB
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wk = wave >> 1, wn = wave & 1;
+    const int wk = wave >> 1, wn = wave & 1;                       // 8 waves as 4(k) x 2(n): a wave owns 64(k) x 128(n)
     int t = xcd_remap(blockIdx.x, g.total_tiles);
     int pi = 0;
 #pragma unroll
@@ -860,7 +862,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const GemmTNG g) {
         if (pi == q) { Ap = g.pr[q].A; Bp = g.pr[q].B; Wp = g.pr[q].W; biasp = g.pr[q].bias; N = g.pr[q].N; K = g.pr[q].K; lda = g.pr[q].lda;
                        ldb = g.pr[q].ldb; tiles_k = g.pr[q].tiles_k; tile0 = g.pr[q].tile0; slab_off = g.pr[q].slab_off; }
     t -= tile0;
-    const int n0 = (t / tiles_k) << 8, k0 = (t % tiles_k) << 7;
+    const int n0 = (t / tiles_k) << 8, k0 = (t % tiles_k) << 8;
     const int split = blockIdx.y;
     const int mbeg = split * g.rows_per_split;
     const int mend = min(g.M, mbeg + g.rows_per_split);
@@ -868,33 +870,34 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const GemmTNG g) {
     const bool do_bias = (biasp != nullptr) && (k0 == 0) && (wk == 0);
 
     // ---- staging (LDS-DMA, lane-linear destination, swizzle on the source chunk) ----
-    // A stage tile: 32 rows x 512 B = 16 wave-instructions (2 rows each); wave w issues 4w..4w+3
-    // B stage tile: 32 rows x 256 B =  8 wave-instructions (4 rows each); wave w issues 2w, 2w+1
-    int a_row[4], a_col[4], b_row[2], b_col[2];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        a_row[i] = (wave * 4 + i) * 2 + (lane >> 5);
-        a_col[i] = min(n0 + (((lane & 31) ^ tn_swz(a_row[i])) << 3), N - 8);
-    }
+    // A and B stage tiles: 32 rows x 512 B = 16 wave-instructions each (2 rows per instruction); wave w issues 2w, 2w+1
+    int s_row[2], a_col[2], b_col[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-        b_row[i] = (wave * 2 + i) * 4 + (lane >> 4);
-        b_col[i] = min(k0 + (((lane & 15) ^ tn_swz(b_row[i])) << 3), K - 8);
+        s_row[i] = (wave * 2 + i) * 2 + (lane >> 5);
+        a_col[i] = min(n0 + (((lane & 31) ^ tn_swz(s_row[i])) << 3), N - 8);
+        b_col[i] = min(k0 + (((lane & 31) ^ tn_swz(s_row[i])) << 3), K - 8);
     }
+    // buffer addressing (descriptor + constant per-lane offset + scalar row-block offset): no per-stage 64-bit VALU address
+    // arithmetic; token rows past M read as zeros through the range check
+    const auto rsA = __builtin_amdgcn_make_buffer_rsrc((void*)Ap, 0, (int)((uint32_t)g.M * (uint32_t)lda * 2u), 0x00020000);
+    const auto rsB = __builtin_amdgcn_make_buffer_rsrc((void*)Bp, 0, (int)((uint32_t)g.M * (uint32_t)ldb * 2u), 0x00020000);
+    uint32_t a_off[2], b_off[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        a_off[i] = ((uint32_t)s_row[i] * (uint32_t)lda + (uint32_t)a_col[i]) * 2u;
+        b_off[i] = ((uint32_t)s_row[i] * (uint32_t)ldb + (uint32_t)b_col[i]) * 2u;
+    }
+    // one of the wave's four loads of a stage (q = 0..3: A rows 0, B rows 0, A rows 1, B rows 1)
+    auto stage_one = [&](int slot, int st, int q) {
+        const uint32_t mb = (uint32_t)(mbeg + min(st, max(ns - 1, 0)) * 32);
+        char* base = smem + slot * 16384 + wave * 2048 + (q >> 1) * 1024;
+        if (q & 1) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, LPTR(base + 65536), 16, b_off[q >> 1], mb * (uint32_t)ldb * 2u, 0, 0);
+        else       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, LPTR(base), 16, a_off[q >> 1], mb * (uint32_t)lda * 2u, 0, 0);
+    };
     auto stage = [&](int slot, int st) {
-        const int mb = mbeg + min(st, max(ns - 1, 0)) * 32;
-        char* base = smem + slot * 24576 + wave * 4096;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int m = min(mb + a_row[i], g.M - 1);
-            __builtin_amdgcn_global_load_lds(GPTR(Ap + (size_t)m * lda + a_col[i]), LPTR(base + i * 1024), 16, 0, 0);
-        }
-        char* bb = smem + slot * 24576 + 16384 + wave * 2048;
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int m = min(mb + b_row[i], g.M - 1);
-            __builtin_amdgcn_global_load_lds(GPTR(Bp + (size_t)m * ldb + b_col[i]), LPTR(bb + i * 1024), 16, 0, 0);
-        }
+        for (int q = 0; q < 4; ++q) stage_one(slot, st, q);
     };
 
     f32x4 acc[4][8], accb[8];
@@ -917,19 +920,21 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const GemmTNG g) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int col = wk * 64 + i * 16 + 4 * pp;
-        offB[i] = lds0 + 16384 + r0 * 256 + ((((col >> 3) ^ tn_swz(r0)) << 4) | ((col & 4) << 1));
+        offB[i] = lds0 + 65536 + r0 * 512 + ((((col >> 3) ^ tn_swz(r0)) << 4) | ((col & 4) << 1));
     }
     typedef __attribute__((ext_vector_type(8))) short s16x8;
     const s16x8 ones_s = {0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80};   // bf16 1.0
     const bf16x8 ones = __builtin_bit_cast(bf16x8, ones_s);
 
-    auto compute = [&](auto slot_c, int st) {
-        constexpr int SB = decltype(slot_c)::value * 24576;
-        u32x2 ylo[8], yhi[8], xlo[4], xhi[4];
+    u32x2 ylo[8], yhi[8], xlo[4], xhi[4];
+    auto reads = [&](auto slot_c) {
+        constexpr int SB = decltype(slot_c)::value * 16384;        // both regions: slot pitch 16 KiB, every ds offset < 64 KiB
 #pragma unroll
-        for (int i = 0; i < 4; ++i) { tr_read<SB>(xlo[i], offB[i]); tr_read<SB + 4 * 256>(xhi[i], offB[i]); }   // rows r0 and r0+4 (same swizzle: bit 2 unused)
+        for (int i = 0; i < 4; ++i) { tr_read<SB>(xlo[i], offB[i]); tr_read<SB + 4 * 512>(xhi[i], offB[i]); }   // rows r0 and r0+4 (same swizzle: bit 2 unused)
 #pragma unroll
         for (int j = 0; j < 8; ++j) { tr_read<SB>(ylo[j], offA[j]); tr_read<SB + 4 * 512>(yhi[j], offA[j]); }
+    };
+    auto mma = [&](int st, int nslot) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
         bf16x8 ay[8], bx[4];
@@ -952,10 +957,13 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const GemmTNG g) {
         }
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < 4; ++i) {
+            stage_one(nslot, st + 3, i);    // the four LDS-DMA loads of stage s + 3, spread between the MFMA groups: a burst
+                                            // of loads in front of the MFMAs stalls the wave on the (saturated) load issue queue
 #pragma unroll
             for (int j = 0; j < 8; ++j)     // D[row <-> k_out (X^T as the A operand)][col <-> n_out (dY as the B operand)]
                 acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bx[i], ay[j], acc[i][j], 0, 0, 0);
+        }
         if (do_bias) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) accb[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, ay[j], accb[j], 0, 0, 0);
@@ -963,14 +971,32 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const GemmTNG g) {
         __builtin_amdgcn_s_setprio(0);
     };
 
+    // Two wave groups (waves 0-3 and 4-7: one wave of each per SIMD) run half a stage apart: the second group takes one extra
+    // barrier up front, so its k-th barrier meets the first group's (k + 1)-th, and each stage is { transposed reads, wait
+    // for this wave's loads of stage s + 1 ; barrier X ; LDS-DMA of stage s + 3, MFMAs ; barrier Y }: one group's MFMAs run
+    // under the other's reads (in lockstep the fragment reads and their latency sat in front of every wave's MFMAs: 1680 clk
+    // per stage against ~1200 of load issue).
+    //  RAW: every wave has waited for its part of stage s + 1 before its X(s); group 0 reads stage s + 1 behind its Y(s),
+    //       which pairs with group 1's X(s); group 1 behind its Y(s), which pairs with group 0's X(s + 1).
+    //  WAR: stage s + 3 overwrites stage s - 1, whose reads a wave completes (lgkmcnt(0)) before its Y(s - 1); the issue
+    //       sits behind X(s), which pairs with the other group's Y(s - 1) (group 0) or Y(s) (group 1).
+#ifdef MMB_STAMPS
+    unsigned long long ts0 = 0, ts1 = 0, tr0 = 0, tr1 = 0;
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tr0) :: "memory");
+    MMB_STAMP(ts0)
+#endif
     if (ns > 0) {
-        stage(0, 0); stage(1, 1);
+        stage(0, 0); stage(1, 1); stage(2, 2);
+        __builtin_amdgcn_s_waitcnt(0x0F78);                        // vmcnt(8): stage 0 (this wave's part)
+        __builtin_amdgcn_s_barrier();
+        if (wave >= 4) __builtin_amdgcn_s_barrier();               // stagger
 #define TN_STEP(SLOT)                                                                       \
         {                                                                                   \
-            __builtin_amdgcn_s_waitcnt(0x0076);   /* vmcnt(6) lgkmcnt(0): stage s landed, my reads of stage s-1 done */ \
+            reads(std::integral_constant<int, SLOT>{});                                     \
+            __builtin_amdgcn_s_waitcnt(0x0F74);   /* vmcnt(4): this wave's part of stage s + 1 has landed */ \
             __builtin_amdgcn_s_barrier();                                                   \
-            stage((SLOT + 2) % 3, s + 2);                                                   \
-            compute(std::integral_constant<int, SLOT>{}, s);                                \
+            mma(s, (SLOT + 3) & 3);                                                         \
+            __builtin_amdgcn_s_barrier();                                                   \
             ++s;                                                                            \
         }
         int s = 0;
@@ -978,10 +1004,15 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const GemmTNG g) {
             TN_STEP(0) if (s >= ns) break;
             TN_STEP(1) if (s >= ns) break;
             TN_STEP(2) if (s >= ns) break;
+            TN_STEP(3) if (s >= ns) break;
         }
 #undef TN_STEP
+        if (wave < 4) __builtin_amdgcn_s_barrier();                // balances the stagger barrier
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
+#ifdef MMB_STAMPS
+    MMB_STAMP(ts1)
+#endif
 
     const float alpha = g.alpha * (g.alpha_dev ? *g.alpha_dev : 1.0f);
     const int fr = lane & 15, fq = lane >> 4;
@@ -1008,6 +1039,16 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const GemmTNG g) {
             if (n < N) atomicAdd(biasp + n, accb[j][0] * alpha);
         }
     }
+#ifdef MMB_STAMPS
+    if (g_stamps && tid == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tr1) :: "memory");
+        unsigned long long te;
+        MMB_STAMP(te)
+        unsigned long long* o = g_stamps + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x)) * 6;
+        o[0] = ts1 - ts0; o[1] = (unsigned long long)ns; o[2] = te - ts1; o[3] = 1; o[4] = tr0; o[5] = tr1;
+    }
+#endif
 }
 
 // W[i] (+)= sum_s slab[s][i] over the concatenated outputs of all problems of a launch
@@ -1119,23 +1160,22 @@ void mmbert_gemm_tn_force_splits(int splits) { g_tn_splits = splits; }
 static int tn_plan(int nprob, const int* N, const int* K, int M, int* splits_out, int* tiles_out) {
     int tiles = 0;
     double elems = 0;
-    for (int i = 0; i < nprob; ++i) { tiles += ((N[i] + 255) / 256) * ((K[i] + 127) / 128); elems += (double)N[i] * K[i]; }
-    // Split count of the token axis, by a cost model fitted to tools/bench_tn.py (M = 18400, one layer's group: 1 -> 358,
-    // 2 -> 290, 3 -> 310, 4 -> 294, 5 -> 321, 7 -> ~305 us).  Two workgroups share a CU; a workgroup streams a token row
-    // in ~31 ns when it shares and in ~0.6 of that when it has the CU alone, plus ~6 us per workgroup outside its loop; a
-    // launch of W workgroups costs (full rounds of 2 x CUs + 1 for a remainder over one per CU, 0.6 for a smaller one)
-    // workgroup times; every extra slab costs a write and a read of the weights' fp32 image (mostly L2 / MALL hits).
-    // The smallest split count within 3 % of the best modelled cost wins (fewer slabs = less workspace traffic).
-    const int slots = 2 * device_cus();
+    for (int i = 0; i < nprob; ++i) { tiles += ((N[i] + 255) / 256) * ((K[i] + 255) / 256); elems += (double)N[i] * K[i]; }
+    // Split count of the token axis by a cost model (one 256x256-tile workgroup per CU): a launch of W workgroups costs
+    // ceil(W / CUs) workgroup times, a workgroup streams a token row in ~T_ROW and spends ~T_FIX outside its loop; every extra
+    // slab costs a write and a read of the weights' fp32 image (mostly L2 / MALL hits).  Constants fitted with
+    // tools/bench_tn.py at M = 18400.  The smallest split count within 3 % of the best modelled cost wins.
+    constexpr double T_ROW = 21e-9, T_FIX = 8e-6;
+    const int slots = device_cus();
     const int max_splits = (M + 511) / 512;
     double cost[9];
     double best_cost = 1e300;
     int top = 1;
     for (int sp = 1; sp <= 8 && sp <= (max_splits < 1 ? 1 : max_splits); ++sp) {
         const long long wgs = (long long)tiles * sp;
-        const long long full = wgs / slots, rem = wgs % slots;
+        const long long rounds = (wgs + slots - 1) / slots;
         const double rows = (double)((M + sp - 1) / sp);
-        cost[sp] = (rows * 30.9e-9 + 6e-6) * ((double)full + (rem > slots / 2 ? 1.0 : rem > 0 ? 0.6 : 0.0)) + (sp - 1) * elems * 8.0 / 9.4e12;
+        cost[sp] = (rows * T_ROW + T_FIX) * (double)rounds + (sp - 1) * elems * 8.0 / 9.4e12;
         if (cost[sp] < best_cost) best_cost = cost[sp];
         top = sp;
     }
@@ -1182,7 +1222,7 @@ int mmbert_gemm_tn_grouped(hipStream_t stream, int nprob, const void* const* A, 
         TNProb& q = g.pr[i];
         q.A = (const bf16_t*)A[i]; q.B = (const bf16_t*)B[i]; q.W = W[i]; q.bias = bias ? bias[i] : nullptr;
         q.N = N[i]; q.K = K[i]; q.lda = lda[i]; q.ldb = ldb[i];
-        q.tiles_k = (K[i] + 127) / 128; q.tile0 = tile0; q.slab_off = off;
+        q.tiles_k = (K[i] + 255) / 256; q.tile0 = tile0; q.slab_off = off;
         r.W[i] = W[i]; r.off[i] = off;
         tile0 += ((N[i] + 255) / 256) * q.tiles_k;
         off += (long long)N[i] * K[i];
@@ -1194,11 +1234,11 @@ int mmbert_gemm_tn_grouped(hipStream_t stream, int nprob, const void* const* A, 
     g.splits = splits; g.rows_per_split = (((M + splits - 1) / splits) + 31) / 32 * 32; g.accumulate = accumulate; g.alpha = alpha;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)gemm_tn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 73728);
+        hipError_t e = hipFuncSetAttribute((const void*)gemm_tn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
-    hipLaunchKernelGGL(gemm_tn_kernel, dim3(tiles, splits), dim3(256), 73728, stream, g);
+    hipLaunchKernelGGL(gemm_tn_kernel, dim3(tiles, splits), dim3(512), 131072, stream, g);
     MMB_CHECK_LAUNCH();
     if (splits > 1) {
         r.nprob = nprob; r.splits = splits; r.accumulate = accumulate; r.slab_stride = off;

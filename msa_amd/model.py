@@ -320,6 +320,7 @@ class _MLMHeadFn(torch.autograd.Function):
         nseg = len(seg_bounds_host) - 1
         loss, inv, lse = ops.ce_fwd(logits, V, labels, seg_bounds, nseg)
         ctx.top, ctx.nseg, ctx.keep_logits = top, nseg, want_scores
+        ctx.set_materialize_grads(False)      # or autograd zero-fills a [tokens, vocab] gradient for the returned scores
         if keep:
             ctx.save_for_backward(y, pre, t0, mean, rstd, t, logits, labels, seg_bounds, inv, lse)
         out_logits = logits if want_scores else None
@@ -332,6 +333,8 @@ class _MLMHeadFn(torch.autograd.Function):
         y, pre, t0, mean, rstd, t, logits, labels, seg_bounds, inv, lse = ctx.saved_tensors
         w = ctx.top._w
         V = ctx.top.config.vocab_size
+        if dloss is None:
+            return None, None, None, None, None, None, None
         gs = dloss.contiguous().float()
         # dlogits with the per-pass upstream gradients folded in; in place unless the scores were handed to the caller
         dl = torch.empty_like(logits) if ctx.keep_logits else logits

@@ -209,8 +209,9 @@ def pair_proj_bwd(feat, J, dJ, T, dW, db):
     B, Pn, D = feat.shape
     H = dW.shape[0]
     assert J.stride(0) == dJ.stride(0)
+    ws = _ws_f32((lib.mmbert_pair_proj_bwd_workspace(B, Pn, D, H) + 3) // 4, feat.device)
     _lib.check(lib.mmbert_pair_proj_bwd(_stream(), feat.data_ptr(), B, Pn, D, J.data_ptr(), dJ.data_ptr(), J.stride(0), T,
-                                        dW.data_ptr(), db.data_ptr(), H), "mmbert_pair_proj_bwd")
+                                        dW.data_ptr(), db.data_ptr(), H, ws.data_ptr()), "mmbert_pair_proj_bwd")
 
 
 NO_KEY = -1.0e30        # key-bias value of the padding slots ("no such key")
