@@ -17,6 +17,7 @@
 //
 // Dropout index of P[i][j] in sequence s, head h: elem_base[s] + (h*S + i)*Spad + j, Spad = S
 // rounded up to 4 (elem_base multiples of 4), so forward and both backward kernels agree.
+#include <cstdlib>
 #include "common.h"
 #include <type_traits>
 
@@ -160,10 +161,15 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnArgs a) {
         qi[qb] = r0 + wave * 32 + qb * 16 + fr;
         qc[qb] = min(qi[qb], S - 1);
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) qf[qb][kk] = *(const bf16x8*)(base + (size_t)qc[qb] * a.ld_qkv + kk * 32 + 8 * g);
+        for (int kk = 0; kk < 2; ++kk) {
+            qf[qb][kk] = *(const bf16x8*)(base + (size_t)qc[qb] * a.ld_qkv + kk * 32 + 8 * g);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) qf[qb][kk][j] = f2bf(bf2f(qf[qb][kk][j]) * a.scale);   // 1/8: exact in bf16; the accumulator is q.k/8
+        }
         rowbase[qb] = a.elem_base[seq] + (unsigned)((head * S + qc[qb]) * Spad);
     }
-    const float c2 = a.scale * LOG2E, inv_scale = 1.0f / a.scale;
+    const float c2 = LOG2E;                                  // scores leave the MFMA already scaled (Q carries the 1/8)
+    const uint32_t thr_pk = mmb_thr_packed(a.dthr);
 
     auto stage = [&](int buf, int kv0) {
         char* B = smem + buf * FWD_BUF;
@@ -179,7 +185,13 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnArgs a) {
     for (int qb = 0; qb < 2; ++qb)
 #pragma unroll
         for (int d = 0; d < 4; ++d) o[qb][d] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    float mraw[2] = {-INFINITY, -INFINITY}, lpart[2] = {0.f, 0.f};
+    float mraw[2] = {-INFINITY, -INFINITY};
+    // softmax denominators on the MFMA: ones(16 x keys) . P^T gives, in every accumulator row, the sum over the 32 keys of a
+    // k-slice for this lane's query column -- of the bf16 probabilities the P.V product uses, before dropout.  Replaces one
+    // v_add_f32 per score and the cross-lane sum at the end by 4 MFMAs per tile.
+    f32x4 lacc[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
+    typedef __attribute__((ext_vector_type(8))) short ones_s16x8;
+    const bf16x8 ones = __builtin_bit_cast(bf16x8, (ones_s16x8){0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80});
 
     // transposed-read lane addressing (see lds_tr_frag): rows 4g+q (+16 per row tile), 4 columns at 4p
     const unsigned lds0 = (unsigned)(uintptr_t)LPTR(smem);
@@ -212,7 +224,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnArgs a) {
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int kt = 0; kt < 4; ++kt) {
-            s[0][kt] = b4[kt] * inv_scale;
+            s[0][kt] = b4[kt];
             s[1][kt] = s[0][kt];
             const bf16x8 k0 = lds_row_frag(Ks, kt * 16 + fr, g), k1 = lds_row_frag(Ks, kt * 16 + fr, 4 + g);
 #pragma unroll
@@ -238,28 +250,39 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnArgs a) {
             const float alpha = grew ? __builtin_amdgcn_exp2f((mraw[qb] - mnew) * c2) : 1.0f;   // first tile: exp2(-inf) = 0
             mraw[qb] = mnew;
             const float mc = mnew * c2;
-            float psum = 0.f;
 #pragma unroll
             for (int kt = 0; kt < 4; ++kt) {
-                bool keep[4] = {true, true, true, true};
-                if constexpr (DROP) mmb_keep4(a.dstream, (uint64_t)rowbase[qb] + (kv0 + kt * 16 + 4 * g), a.dthr, keep);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[qb][kt][r], c2, -mc));
-                    psum += p;
-                    s[qb][kt][r] = keep[r] ? p : 0.f;
+                    s[qb][kt][r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[qb][kt][r], c2, -mc));
                 }
             }
             if (grew) {                                      // steady state (maximum unchanged): no rescale pass
-                lpart[qb] *= alpha;
+                lacc[qb] = lacc[qb] * alpha;
 #pragma unroll
                 for (int d = 0; d < 4; ++d)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) o[qb][d][r] *= alpha;
             }
-            lpart[qb] += psum;
             pf[qb][0] = pack8(s[qb][0], s[qb][1]);
             pf[qb][1] = pack8(s[qb][2], s[qb][3]);
+            lacc[qb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, pf[qb][0], lacc[qb], 0, 0, 0);
+            lacc[qb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, pf[qb][1], lacc[qb], 0, 0, 0);
+            if constexpr (DROP) {
+                // dropout on the PACKED bf16 probabilities: dword (kt, pair) holds keys kv0 + 16 kt + 4 g + 2 pair (+1), the
+                // element pair of one hash word; 2 VALU operations build the mask of both halves (see mmb_drop_mask2)
+                const uint32_t pair0 = (rowbase[qb] + (uint32_t)(kv0 + 4 * g)) >> 1;
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    u32x4 w = __builtin_bit_cast(u32x4, pf[qb][ks]);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const uint32_t h = mmb_pair_bits(a.dstream, pair0 + (uint32_t)((2 * ks + (j >> 1)) * 8 + (j & 1)));
+                        w[j] &= ~mmb_drop_mask2(h, thr_pk);
+                    }
+                    pf[qb][ks] = __builtin_bit_cast(bf16x8, w);
+                }
+            }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the asm V reads
         __builtin_amdgcn_sched_barrier(0);
@@ -280,7 +303,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnArgs a) {
     }
 #pragma unroll
     for (int qb = 0; qb < 2; ++qb) {
-        const float l = group_sum(lpart[qb]);
+        const float l = lacc[qb][0];
         if (qi[qb] < S) {
             const float inv = a.dscale / l;                  // dropout scale folded into the normalisation
             bf16_t* orow = a.ctx + (size_t)(start + qi[qb]) * a.H + head * 64;
@@ -492,6 +515,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnArgs a) 
         kb[kb_] = a.key_bias[a.bias_start[seq] + ki[kb_]] * inv_scale;    // padded array: keys past the end read -1e30 -> p = 0
     }
     const unsigned ebase = a.elem_base[seq] + (unsigned)(head * S) * Spad;
+    // dropout hash seed of (row 4g + (lane & 1), this lane's key pair of key block 0); the other rows / key block are
+    // wave-uniform offsets away (keys past the end hash out of range: their p is 0 through the -1e30 bias)
+    const uint32_t hseed = (((ebase + (uint32_t)(4 * g + (lane & 1)) * (uint32_t)Spad) >> 1) + ((uint32_t)ki[0] >> 1)) * MMB_WEYL + a.dstream;
 
     auto stage = [&](int buf, int q0) {
         char* B = smem + buf * DKV_BUF;
@@ -570,19 +596,20 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnArgs a) 
             for (int qt = 0; qt < 4; ++qt) {
                 float ksc[4] = {1.f, 1.f, 1.f, 1.f};
                 if constexpr (DROP) {
-                    // pair index of (row q, keys {2j,2j+1}); even lane hashes rows r = 0,2, odd lane rows 1,3, then swap
-                    const int qa = min(q0 + qt * 16 + 4 * g + (odd ? 1 : 0), S - 1), qb2 = min(q0 + qt * 16 + 4 * g + (odd ? 3 : 2), S - 1);
-                    const uint32_t pj = (uint32_t)kc[kb_] >> 1;
-                    const uint32_t ha = mmb_pair_bits(a.dstream, ((ebase + (uint32_t)qa * Spad) >> 1) + pj);
-                    const uint32_t hb = mmb_pair_bits(a.dstream, ((ebase + (uint32_t)qb2 * Spad) >> 1) + pj);
+                    // pair index of (row q, keys {2j,2j+1}); even lane hashes rows r = 0,2, odd lane rows 1,3, then swap.  The
+                    // seed is linear in the row: per-lane part hseed[][] (set up once), wave-uniform part by scalar arithmetic
+                    // (rows past the sequence end hash whatever they hash: their contributions are zero anyway)
+                    const uint32_t sv = ((uint32_t)(q0 + qt * 16) * ((uint32_t)Spad >> 1) + (uint32_t)kb_ * 8u) * MMB_WEYL;
+                    const uint32_t ha = mmb_pair_mix(hseed + sv);
+                    const uint32_t hb = mmb_pair_mix(hseed + sv + (uint32_t)Spad * MMB_WEYL);      // rows + 2
                     const uint32_t xa = __builtin_amdgcn_mov_dpp(ha, 0xB1, 0xF, 0xF, true);    // quad_perm [1,0,3,2]: neighbour lane's value
                     const uint32_t xb = __builtin_amdgcn_mov_dpp(hb, 0xB1, 0xF, 0xF, true);
                     const uint32_t h0 = odd ? xa : ha, h1 = odd ? ha : xa, h2 = odd ? xb : hb, h3 = odd ? hb : xb;
                     const int sh = (kc[kb_] & 1) * 16;
-                    ksc[0] = ((h0 >> sh) & 0xFFFFu) >= a.dthr ? a.dscale : 0.f;
-                    ksc[1] = ((h1 >> sh) & 0xFFFFu) >= a.dthr ? a.dscale : 0.f;
-                    ksc[2] = ((h2 >> sh) & 0xFFFFu) >= a.dthr ? a.dscale : 0.f;
-                    ksc[3] = ((h3 >> sh) & 0xFFFFu) >= a.dthr ? a.dscale : 0.f;
+                    ksc[0] = mmb_keep16((h0 >> sh) & 0xFFFFu, a.dthr) ? a.dscale : 0.f;
+                    ksc[1] = mmb_keep16((h1 >> sh) & 0xFFFFu, a.dthr) ? a.dscale : 0.f;
+                    ksc[2] = mmb_keep16((h2 >> sh) & 0xFFFFu, a.dthr) ? a.dscale : 0.f;
+                    ksc[3] = mmb_keep16((h3 >> sh) & 0xFFFFu, a.dthr) ? a.dscale : 0.f;
                 }
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
@@ -665,8 +692,9 @@ int mmbert_attn_fwd(hipStream_t stream, const void* qkv, void* ctx, float* lse, 
     AttnArgs a;
     if (fill_args(a, qkv, H, heads, key_bias, bias_start, seq_start, seq_len, elem_base, tile_seq, tile_r0, lse, dstream, dthr, dscale)) return -1;
     a.ctx = (bf16_t*)ctx;
-    if (dthr) hipLaunchKernelGGL(attn_fwd_kernel<true>, dim3(ntiles, heads), dim3(256), 0, stream, a);
-    else hipLaunchKernelGGL(attn_fwd_kernel<false>, dim3(ntiles, heads), dim3(256), 0, stream, a);
+    static const int extra_lds = getenv("MMBERT_ATTN_EXTRA_LDS") ? atoi(getenv("MMBERT_ATTN_EXTRA_LDS")) : 0;   // occupancy experiments
+    if (dthr) hipLaunchKernelGGL(attn_fwd_kernel<true>, dim3(ntiles, heads), dim3(256), extra_lds, stream, a);
+    else hipLaunchKernelGGL(attn_fwd_kernel<false>, dim3(ntiles, heads), dim3(256), extra_lds, stream, a);
     MMB_CHECK_LAUNCH();
     return 0;
 }
