@@ -341,9 +341,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnArgs a) {
     const bf16_t* kbase = base + a.H;
     const bf16_t* vbase = base + 2 * a.H;
     const float* bbase = a.key_bias + a.bias_start[seq];
-    const float c2 = a.scale * LOG2E, inv_scale = 1.0f / a.scale;
+    const float c2 = LOG2E;                                  // scores leave the MFMA already scaled (Q carries the 1/8)
     int qi[2];
-    unsigned rowbase[2];
+    uint32_t hseed[2];                                       // dropout hash seed of (row, keys 4g..) -- linear in the key offset
     bf16x8 qf[2][2], dof[2][2];
     float delta[2], nlse[2];
 #pragma unroll
@@ -354,6 +354,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnArgs a) {
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
             qf[qb][kk] = *(const bf16x8*)(base + (size_t)qc * a.ld_qkv + kk * 32 + 8 * g);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) qf[qb][kk][j] = f2bf(bf2f(qf[qb][kk][j]) * a.scale);   // 1/8: exact in bf16
             dof[qb][kk] = *(const bf16x8*)(dob + (size_t)qc * a.H + kk * 32 + 8 * g);
             const bf16x8 of = *(const bf16x8*)(ob + (size_t)qc * a.H + kk * 32 + 8 * g);
 #pragma unroll
@@ -362,7 +364,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnArgs a) {
         delta[qb] = group_sum(dl);
         if (qi[qb] < S && g == 0) a.delta[(size_t)(start + qi[qb]) * a.heads + head] = delta[qb];
         nlse[qb] = -a.lse[(size_t)(start + qc) * a.heads + head] * LOG2E;
-        rowbase[qb] = a.elem_base[seq] + (unsigned)((head * S + qc) * Spad);
+        hseed[qb] = ((a.elem_base[seq] + (unsigned)((head * S + qc) * Spad) + 4u * (unsigned)g) >> 1) * MMB_WEYL + a.dstream;
     }
 
     auto stage = [&](int buf, int kv0) {
@@ -405,7 +407,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnArgs a) {
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int kt = 0; kt < 4; ++kt) {
-            s[0][kt] = b4[kt] * inv_scale;
+            s[0][kt] = b4[kt];
             s[1][kt] = s[0][kt];
             dp[0][kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
             dp[1][kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -433,7 +435,12 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnArgs a) {
 #pragma unroll
             for (int kt = 0; kt < 4; ++kt) {
                 bool keep[4] = {true, true, true, true};
-                if constexpr (DROP) mmb_keep4(a.dstream, (uint64_t)rowbase[qb] + (kv0 + kt * 16 + 4 * g), a.dthr, keep);
+                if constexpr (DROP) {
+                    const uint32_t sv = (uint32_t)((kv0 >> 1) + kt * 8) * MMB_WEYL;          // wave-uniform
+                    const uint32_t h0 = mmb_pair_mix(hseed[qb] + sv), h1 = mmb_pair_mix(hseed[qb] + sv + MMB_WEYL);
+                    keep[0] = mmb_keep16(h0 & 0xFFFFu, a.dthr); keep[1] = mmb_keep16(h0 >> 16, a.dthr);
+                    keep[2] = mmb_keep16(h1 & 0xFFFFu, a.dthr); keep[3] = mmb_keep16(h1 >> 16, a.dthr);
+                }
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[qb][kt][r], c2, lc));   // keys past the end: bias -1e30 -> 0
