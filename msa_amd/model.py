@@ -709,12 +709,25 @@ class MMBertForPretraining(_GpuModelBase):
         v_ap = F.cross_entropy(v_rel.view(-1, 2), ap_v.to(dev).view(-1).long())
         s_ap = F.cross_entropy(s_rel.view(-1, 2), ap_s.to(dev).view(-1).long())
 
-        def gate(x, v):                                                              # :407-409
-            return v(self.relu(self.attn(torch.cat((x, x), dim=1))))
-        pooled_cat = torch.cat((pt * gate(pt, self.vt), pv * gate(pv, self.vv), ps * gate(ps, self.vs)), dim=1)
+        # The three gates (:407-409, v(relu(attn(cat(x, x))))), the gated concat and the three CPC terms (REF:MMBertEmbedding.py:21-32)
+        # are evaluated BATCHED over the modality axis: same arithmetic as the per-modality module calls of the reference,
+        # a third of the [B,H]-sized kernel launches (each costs ~3 us of device time whatever its size).
+        P3 = pooled.view(3, B, H)                                                     # pt, pv, ps
+        a3 = self.relu(self.attn(torch.cat((pooled, pooled), dim=1))).view(3, B, H)
+        Vw = torch.cat((self.vt.weight, self.vv.weight, self.vs.weight), dim=0)      # [3, H]
+        Vb = torch.cat((self.vt.bias, self.vv.bias, self.vs.bias))                   # [3]
+        g3 = (a3 * Vw[:, None, :]).sum(-1) + Vb[:, None]                             # [3, B]
+        pooled_cat = (P3 * g3[:, :, None]).transpose(0, 1).reshape(B, 3 * H)
         temp = self.classifier1_1(pooled_cat)
         logits_out = self.classifier1_2(temp)
-        nce = self.cpc_zt(pt, temp) + self.cpc_zv(pv, temp) + self.cpc_za(ps, temp)
+        Wc = torch.stack((self.cpc_zt.net.weight, self.cpc_zv.net.weight, self.cpc_za.net.weight))   # [3, H, H]
+        bc = torch.stack((self.cpc_zt.net.bias, self.cpc_zv.net.bias, self.cpc_za.net.bias))[:, None, :]
+        x_pred = torch.baddbmm(bc, temp.expand(3, B, H), Wc.transpose(1, 2))
+        x_pred = x_pred / x_pred.norm(dim=2, keepdim=True)
+        Xn = P3 / P3.norm(dim=2, keepdim=True)
+        pos = torch.sum(Xn * x_pred, dim=-1)
+        neg = torch.logsumexp(torch.bmm(Xn, x_pred.transpose(1, 2)), dim=-1)
+        nce = -(pos - neg).mean(dim=1).sum()
         mlm_loss = (mlm[0] + mlm[1] + mlm[2]) / 3.0                                  # :427
         ap_loss = (v_ap + s_ap) / 2.0                                                # :428
         if sentiment is not None:
