@@ -162,9 +162,10 @@ def main():
                     kern[k] = (fl, ms, len(lst))
             fl, ms, n = kern["nt"]
             ach = fl / (ms * 1e-3) / 1e12
+            traffic, traffic_src = pmc_traffic_per_launch("gemm_ntp_kernel")
             res["roofline"] = {"bound": "mfma", "kernel": "gemm_ntp_kernel (bf16 MFMA 16x16x32, persistent 224x256-tile stream through a 4-slot LDS-DMA ring; all epilogues)",
                                "achieved": round(ach, 1), "peak": 2500.0, "unit": "TFLOP/s", "frac": round(ach / 2500.0, 4),
-                               "traffic": None, "launches": n, "avg_launch_us": round(1e3 * ms / n, 2),
+                               "traffic": traffic, "traffic_source": traffic_src, "launches": n, "avg_launch_us": round(1e3 * ms / n, 2),
                                "share_of_step_time": round(ms * 1e-3 / elapsed, 3)}
             for k in ("tn", "attn_fwd", "attn_bwd"):
                 if k in kern:
@@ -176,6 +177,23 @@ def main():
         print(json.dumps(res), flush=True)
     if world > 1:
         torch.distributed.destroy_process_group()
+
+
+def pmc_traffic_per_launch(kernel_substr):
+    """HBM/fabric bytes per launch of the dominant kernel family from the committed PMC summary (two separate rocprofv3 --pmc
+    passes over this same bench command, FETCH_SIZE doubled as the gfx950 correction asks: tools/pmc_traffic.py).  Counters
+    cannot be collected from inside the timed run, so this is the measured figure of record, or None if the file is absent."""
+    path = os.path.join(ROOT, "profiles", "r1_pmc_hbm_traffic.csv")
+    try:
+        import csv
+        rows = [r for r in csv.DictReader(l for l in open(path) if not l.startswith("#")) if kernel_substr in r["kernel"]]
+        n = sum(int(r["launches"]) for r in rows)
+        if not n:
+            return None, None
+        mb = sum(float(r["total_MB"]) * int(r["launches"]) for r in rows) / n
+        return round(mb * 1e6), "profiles/r1_pmc_hbm_traffic.csv (mean over %d launches, read x2-corrected + written)" % n
+    except Exception:
+        return None, None
 
 
 def usable_cores(cap=32):
