@@ -37,6 +37,12 @@ int mmbert_gemm_nt(mmbert_stream_t stream, const void* A, int lda, const void* B
                    const void* U, int ldu, float alpha, const float* alpha_dev,
                    uint32_t drop_stream, uint32_t drop_thr16, float drop_scale);
 
+/* Split-K form of the plain product (C bf16 = A . B^T) for long K with few output tiles: fp32 partial slabs in the
+ * caller's workspace (mmbert_gemm_nt_splitk_workspace() bytes), reduced deterministically. */
+int mmbert_gemm_nt_splitk(mmbert_stream_t stream, const void* A, int lda, const void* B, int ldb, void* C, int ldc,
+                          int M, int N, int K, void* workspace);
+size_t mmbert_gemm_nt_splitk_workspace(int M, int N, int K);
+
 /* Kernel selection for mmbert_gemm_nt: 0 = by shape (default), 1 = 128x128 tile kernel, 2 = 4-stage-ring kernel
  * with the tile height (256 or 224 rows) chosen by tile-round count, 3 = ring kernel 256x256, 4 = ring kernel
  * 224x256.  For tests and A/B benchmarking; results are identical up to fp32 summation order. */
@@ -122,7 +128,11 @@ int mmbert_attn_dropout_mask(mmbert_stream_t stream, uint8_t* out, int S, unsign
 int mmbert_ce_fwd(mmbert_stream_t stream, const void* logits, int ldv, int V, const int64_t* labels, int M,
                   const int* seg_bounds, int nseg, float* inv_count, float* loss_sum, float* row_lse);
 int mmbert_ce_bwd(mmbert_stream_t stream, const void* logits, int ldv, int V, const int64_t* labels, int M,
-                  const int* seg_bounds, int nseg, const float* inv_count, const float* gscale, const float* row_lse, void* dlogits, int ldd);
+                  const int* seg_bounds, int nseg, const float* inv_count, const float* gscale, const float* row_lse, void* dlogits, int ldd,
+                  const int* rows /* NULL: all M rows; else a row list: dlogits row j = gradient of row rows[j] */, int nrows);
+/* idx[0..count) = the rows with a label in [0, V), ascending; every other row of the CE gradient is exactly zero (ignore_index),
+ * so the head's backward may run on this list alone.  idx has room for M entries; count is one int on the device. */
+int mmbert_active_rows(mmbert_stream_t stream, const int64_t* labels, int M, int V, int* idx, int* count);
 
 /* ---- optimizer: flat AdamW (REF:train.py:76-97; mode 0 = transformers-2.8 AdamW, 1 = torch.optim.AdamW) ----
  * flags[i/256]: 0 no decay, 1 decay, 2 frozen.  n % 256 == 0.  Also refreshes the bf16 copy, and zeroes g. */

@@ -17,6 +17,8 @@ P, I, F, U32, SZ, U64 = C.c_void_p, C.c_int, C.c_float, C.c_uint32, C.c_size_t, 
 SIGNATURES = {
     "mmbert_gemm_nt": (I, [P, P, I, P, I, P, I, I, I, I, I, P, P, I, P, I, P, I, F, P, U32, U32, F]),
     "mmbert_gemm_nt_force": (None, [I]),
+    "mmbert_gemm_nt_splitk": (I, [P, P, I, P, I, P, I, I, I, I, P]),
+    "mmbert_gemm_nt_splitk_workspace": (SZ, [I, I, I]),
     "mmbert_gemm_tn_force_splits": (None, [I]),
     "mmbert_gemm_tn_workspace": (SZ, [I, I, I, P]),
     "mmbert_gemm_tn": (I, [P, P, I, P, I, P, I, I, I, I, I, F, P, P, P]),
@@ -39,7 +41,8 @@ SIGNATURES = {
     "mmbert_attn_bwd": (I, [P, P, P, P, P, P, P, P, P, I, I, P, P, P, P, P, I, P, P, I, U32, U32, F]),
     "mmbert_attn_dropout_mask": (I, [P, P, I, C.c_uint, I, U32, U32]),
     "mmbert_ce_fwd": (I, [P, P, I, I, P, I, P, I, P, P, P]),
-    "mmbert_ce_bwd": (I, [P, P, I, I, P, I, P, I, P, P, P, P, I]),
+    "mmbert_ce_bwd": (I, [P, P, I, I, P, I, P, I, P, P, P, P, I, P, I]),
+    "mmbert_active_rows": (I, [P, P, I, I, P, P]),
     "mmbert_adamw": (I, [P, P, P, P, P, P, P, SZ, F, F, F, F, F, I, F, I, I]),
     "mmbert_gelu_bwd": (I, [P, P, P, P, SZ]),
     "mmbert_cast_f32_bf16": (I, [P, P, P, SZ]),

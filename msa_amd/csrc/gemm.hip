@@ -28,6 +28,7 @@ struct GemmNT {
     int M, N, K, lda, ldb, ldc, ldr, ldaux, ldu;
     float alpha;
     uint32_t drop_stream, drop_thr16; float drop_scale;
+    int kt_per_split; long long split_stride;     // gemm_nt_kernel only: split-K over blockIdx.z into fp32 slabs (0 = no split)
 };
 
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
@@ -131,7 +132,9 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const GemmNT p) {
     const int tiles_n = (p.N + 127) >> 7, tiles_m = (p.M + 127) >> 7;
     const int tile = xcd_remap(blockIdx.x, tiles_m * tiles_n);
     const int m0 = (tile / tiles_n) << 7, n0 = (tile % tiles_n) << 7;
-    const int nt = p.K >> 6;
+    // split-K (long K, few output tiles): workgroup z takes K tiles [kt0, kt1) and writes fp32 partial sums to slab z
+    const int kt0 = p.kt_per_split ? (int)blockIdx.z * p.kt_per_split : 0;
+    const int kt1 = p.kt_per_split ? min(p.K >> 6, kt0 + p.kt_per_split) : (p.K >> 6);
 
     // staging: wave w issues chunks 4w..4w+3 of A and of B; a chunk = 8 rows x 128 B = 1 KiB
     const int srow = lane >> 3, schunk = (lane & 7) ^ srow;     // source chunk pre-swizzled
@@ -179,11 +182,11 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const GemmNT p) {
         }
     };
 
-    stage(0, 0);
+    stage(0, kt0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     int cur = 0;
-    for (int kt = 0; kt < nt - 1; ++kt) {
+    for (int kt = kt0; kt < kt1 - 1; ++kt) {
         stage(cur ^ 1, kt + 1);
         compute(cur);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -205,6 +208,12 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const GemmNT p) {
             float v[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r] * alpha;
+            if constexpr (EPI == EPI_OUT_F32) {
+                if (p.kt_per_split) {
+                    *(float4*)((float*)p.C + (size_t)blockIdx.z * p.split_stride + (size_t)m * p.ldc + n) = make_float4(v[0], v[1], v[2], v[3]);
+                    continue;
+                }
+            }
             epi_store<EPI>(p, m, n, v);
         }
     }
@@ -1113,6 +1122,53 @@ __global__ __launch_bounds__(256) void colsum_kernel(const bf16_t* __restrict__ 
 
 extern "C" {
 
+// C (bf16) = sum over the split-K slabs
+__global__ void nt_splitk_reduce_kernel(const float* __restrict__ slabs, int splits, long long stride, int M, int N, bf16_t* __restrict__ C, int ldc) {
+    const long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (i >= (long long)M * N) return;
+    float4 a = *(const float4*)(slabs + i);
+    for (int z = 1; z < splits; ++z) { const float4 b = *(const float4*)(slabs + z * stride + i); a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; }
+    const int m = (int)(i / N), n = (int)(i - (long long)m * N);
+    bf16x4 o = {f2bf(a.x), f2bf(a.y), f2bf(a.z), f2bf(a.w)};
+    *(bf16x4*)(C + (size_t)m * ldc + n) = o;
+}
+
+// Split-K form for long-K products with few output tiles (the MLM head's compact dlogits . E^T: M ~ 360, K = 30592):
+// C[M,N] (bf16) = A[M,K] . B[N,K]^T through fp32 slabs (deterministic).  workspace >= mmbert_gemm_nt_splitk_workspace() bytes.
+static int nt_splitk_plan(int M, int N, int K) {
+    const int tiles = ((M + 127) / 128) * ((N + 127) / 128), kt = K >> 6;
+    int splits = (2 * device_cus() + tiles - 1) / tiles;          // ~2 workgroups per CU
+    if (splits > kt / 4) splits = kt / 4;                          // at least 4 K tiles per workgroup
+    if (splits < 1) splits = 1;
+    return splits;
+}
+size_t mmbert_gemm_nt_splitk_workspace(int M, int N, int K) { return (size_t)nt_splitk_plan(M, N, K) * M * N * sizeof(float); }
+
+int mmbert_gemm_nt_splitk(hipStream_t stream, const void* A, int lda, const void* B, int ldb, void* C, int ldc,
+                          int M, int N, int K, void* workspace) {
+    if (M <= 0 || N <= 0) return 0;
+    if (K <= 0 || (K & 63) || (N & 3) || (lda & 7) || (ldb & 7) || (ldc & 3) || !workspace) return -1;
+    GemmNT p = {};
+    p.A = (const bf16_t*)A; p.B = (const bf16_t*)B; p.C = workspace; p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = N;
+    p.alpha = 1.0f;
+    const int splits = nt_splitk_plan(M, N, K), kt = K >> 6;
+    p.kt_per_split = (kt + splits - 1) / splits;
+    p.split_stride = (long long)M * N;
+    const int zs = (kt + p.kt_per_split - 1) / p.kt_per_split;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)gemm_nt_kernel<EPI_OUT_F32>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(gemm_nt_kernel<EPI_OUT_F32>, dim3(((M + 127) / 128) * ((N + 127) / 128), 1, zs), dim3(256), 65536, stream, p);
+    MMB_CHECK_LAUNCH();
+    const long long n4 = ((long long)M * N + 3) / 4;
+    hipLaunchKernelGGL(nt_splitk_reduce_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, stream, (const float*)workspace, zs, p.split_stride, M, N, (bf16_t*)C, ldc);
+    MMB_CHECK_LAUNCH();
+    return 0;
+}
+
 int mmbert_gemm_nt(hipStream_t stream, const void* A, int lda, const void* B, int ldb, void* C, int ldc,
                    int M, int N, int K, int epi, const float* bias, const void* R, int ldr, void* aux, int ldaux,
                    const void* U, int ldu, float alpha, const float* alpha_dev,
@@ -1124,6 +1180,7 @@ int mmbert_gemm_nt(hipStream_t stream, const void* A, int lda, const void* B, in
     p.aux = (bf16_t*)aux; p.U = (const bf16_t*)U; p.alpha_dev = alpha_dev;
     p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.ldr = ldr; p.ldaux = ldaux; p.ldu = ldu;
     p.alpha = alpha; p.drop_stream = drop_stream; p.drop_thr16 = drop_thr16; p.drop_scale = drop_scale;
+    p.kt_per_split = 0; p.split_stride = 0;
     switch (epi) {
         case 0: return dispatch_nt<0>(stream, p);
         case EPI_BIAS: return dispatch_nt<EPI_BIAS>(stream, p);

@@ -360,6 +360,32 @@ __global__ void pair_fold_kernel(const float* __restrict__ wtmp, int H, int D, i
 //   ce_row<1>: backward (dlogits, the upstream gradient of each segment's loss folded in, so the two
 //              vocabulary GEMMs of backward run once over all rows instead of once per pass)
 // --------------------------------------------------------------------------------------------
+// Compact list of the rows that carry a label (0 <= label < V), in row order, plus their count: one workgroup, block scan.
+// The MLM head's backward runs on these rows only: every other row of dlogits is exactly zero (ignore_index), so the two
+// vocabulary-sized products, LayerNorm', GELU' and the transform products of backward need ~2 % of the rows.
+__global__ __launch_bounds__(1024) void active_rows_kernel(const int64_t* __restrict__ labels, int M, int V, int* __restrict__ idx, int* __restrict__ count) {
+    __shared__ int wsum[16];
+    __shared__ int base;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    if (tid == 0) base = 0;
+    __syncthreads();
+    for (int i0 = 0; i0 < M; i0 += 1024) {
+        const int i = i0 + tid;
+        const bool act = i < M && labels[i] >= 0 && labels[i] < V;
+        const unsigned long long bal = __ballot(act);
+        const int before = __popcll(bal & ((1ull << lane) - 1ull));
+        if (lane == 0) wsum[w] = __popcll(bal);
+        __syncthreads();
+        int off = base;
+        for (int q = 0; q < w; ++q) off += wsum[q];
+        if (act) idx[off + before] = i;
+        __syncthreads();
+        if (tid == 0) { int t = 0; for (int q = 0; q < 16; ++q) t += wsum[q]; base += t; }
+        __syncthreads();
+    }
+    if (tid == 0) *count = base;
+}
+
 __global__ void ce_count_kernel(const int64_t* __restrict__ labels, int M, const int* __restrict__ seg_bounds, int nseg,
                                 float* __restrict__ inv_count, float* __restrict__ loss_sum) {
     __shared__ int cnt[4];
@@ -390,17 +416,17 @@ template <int MODE>
 __global__ __launch_bounds__(256) void ce_row_kernel(const bf16_t* __restrict__ logits, int ldv, int V, const int64_t* __restrict__ labels,
                                                      const int* __restrict__ seg_bounds, int nseg, const float* __restrict__ inv_count,
                                                      float* __restrict__ loss_sum, float* __restrict__ row_lse, const float* __restrict__ gscale,
-                                                     bf16_t* __restrict__ dlogits, int ldd) {
+                                                     bf16_t* __restrict__ dlogits, int ldd, const int* __restrict__ rows) {
     __shared__ float red[4];
     __shared__ float lab_logit;
-    const int i = blockIdx.x;
+    const int i = rows ? rows[blockIdx.x] : blockIdx.x;        // backward over a compact row list: output row = blockIdx.x
     const int64_t lab = labels[i];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int nchunk = ldv >> 3;
     if (lab == -100 || lab < 0 || lab >= V) {
         if (MODE == 0) { if (tid == 0) row_lse[i] = 0.f; }
         else {
-            bf16_t* drow = dlogits + (size_t)i * ldd;
+            bf16_t* drow = dlogits + (size_t)(rows ? blockIdx.x : i) * ldd;
             const bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
             for (int c = tid; c < nchunk; c += 256) *(bf16x8*)(drow + c * 8) = z;
         }
@@ -451,7 +477,7 @@ __global__ __launch_bounds__(256) void ce_row_kernel(const bf16_t* __restrict__ 
     } else {
         const float lse = row_lse[i];
         const float scale = inv_count[s] * gscale[s];
-        bf16_t* drow = dlogits + (size_t)i * ldd;
+        bf16_t* drow = dlogits + (size_t)(rows ? blockIdx.x : i) * ldd;
 #pragma unroll
         for (int c = 0; c < CE_MAXC; ++c) {
             const int ch = c * 256 + tid;
@@ -692,17 +718,25 @@ int mmbert_ce_fwd(hipStream_t stream, const void* logits, int ldv, int V, const 
     hipLaunchKernelGGL(ce_count_kernel, dim3(1), dim3(1024), 0, stream, labels, M, seg_bounds, nseg, inv_count, loss_sum);
     MMB_CHECK_LAUNCH();
     hipLaunchKernelGGL(ce_row_kernel<0>, dim3(M), dim3(256), 0, stream, (const bf16_t*)logits, ldv, V, labels, seg_bounds, nseg, inv_count, loss_sum,
-                       row_lse, (const float*)nullptr, (bf16_t*)nullptr, 0);
+                       row_lse, (const float*)nullptr, (bf16_t*)nullptr, 0, (const int*)nullptr);
     MMB_CHECK_LAUNCH();
     return 0;
 }
 
 int mmbert_ce_bwd(hipStream_t stream, const void* logits, int ldv, int V, const int64_t* labels, int M,
-                  const int* seg_bounds, int nseg, const float* inv_count, const float* gscale, const float* row_lse, void* dlogits, int ldd) {
-    if (M <= 0) return 0;
+                  const int* seg_bounds, int nseg, const float* inv_count, const float* gscale, const float* row_lse, void* dlogits, int ldd,
+                  const int* rows, int nrows) {
+    if (M <= 0 || (rows && nrows <= 0)) return 0;
     if (nseg < 1 || nseg > 4 || (ldv & 7) || (ldd & 7) || ldv > CE_MAXC * 256 * 8 || V > ldv) return -1;
-    hipLaunchKernelGGL(ce_row_kernel<1>, dim3(M), dim3(256), 0, stream, (const bf16_t*)logits, ldv, V, labels, seg_bounds, nseg, inv_count,
-                       (float*)nullptr, (float*)row_lse, gscale, (bf16_t*)dlogits, ldd);
+    hipLaunchKernelGGL(ce_row_kernel<1>, dim3(rows ? nrows : M), dim3(256), 0, stream, (const bf16_t*)logits, ldv, V, labels, seg_bounds, nseg, inv_count,
+                       (float*)nullptr, (float*)row_lse, gscale, (bf16_t*)dlogits, ldd, rows);
+    MMB_CHECK_LAUNCH();
+    return 0;
+}
+
+int mmbert_active_rows(hipStream_t stream, const int64_t* labels, int M, int V, int* idx, int* count) {
+    if (M < 0) return -1;
+    hipLaunchKernelGGL(active_rows_kernel, dim3(1), dim3(1024), 0, stream, labels, M, V, idx, count);
     MMB_CHECK_LAUNCH();
     return 0;
 }

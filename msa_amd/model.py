@@ -321,6 +321,17 @@ class _MLMHeadFn(torch.autograd.Function):
         loss, inv, lse = ops.ce_fwd(logits, V, labels, seg_bounds, nseg)
         ctx.top, ctx.nseg, ctx.keep_logits = top, nseg, want_scores
         ctx.set_materialize_grads(False)      # or autograd zero-fills a [tokens, vocab] gradient for the returned scores
+        ctx.rows = None
+        if keep and getattr(top, "sparse_mlm_backward", True):
+            # Rows without a label have an exactly-zero CE gradient (ignore_index): backward needs the labelled rows only
+            # (~2 % of the packed tokens).  Their list is built on the device now; the COUNT travels to a pinned host word
+            # by an async copy that is a whole forward pass old when backward asks for it (no pipeline drain).
+            idx, cnt = ops.active_rows(labels, V)
+            host = torch.empty(1, dtype=torch.int32, pin_memory=True)
+            host.copy_(cnt, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+            ctx.rows = (idx, host, ev)
         if keep:
             ctx.save_for_backward(y, pre, t0, mean, rstd, t, logits, labels, seg_bounds, inv, lse)
         out_logits = logits if want_scores else None
@@ -336,7 +347,28 @@ class _MLMHeadFn(torch.autograd.Function):
         if dloss is None:
             return None, None, None, None, None, None, None
         gs = dloss.contiguous().float()
-        # dlogits with the per-pass upstream gradients folded in; in place unless the scores were handed to the caller
+        M = y.shape[0]
+        if ctx.rows is not None:
+            idx_all, host, ev = ctx.rows
+            ev.synchronize()
+            n = int(host[0])
+            if 2 * n <= M:
+                dy = torch.zeros_like(y)
+                if n == 0:
+                    return dy, None, None, None, None, None, None
+                idx = idx_all[:n]
+                sel = idx.long()
+                dl = torch.empty((n, logits.shape[1]), device=y.device, dtype=torch.bfloat16)
+                ops.ce_bwd(logits, V, labels, seg_bounds, ctx.nseg, inv, gs, lse, dl, rows=idx)
+                t_c, t0_c, pre_c, y_c = (x.index_select(0, sel) for x in (t, t0, pre, y))
+                ops.gemm_tn(dl, t_c, w["g_word_pad"], bias_out=w["g_pred_bias"])
+                dt = ops.gemm_nt_splitk(dl, w["wordT"])                     # K = vocabulary, a few hundred rows: split-K
+                dt0 = ops.ln_bwd(dt, t0_c, mean.index_select(0, sel), rstd.index_select(0, sel), w["mlm_ln_g"], w["g_mlm_ln_g"], w["g_mlm_ln_b"])
+                dpre = ops.gelu_bwd(dt0, pre_c)
+                ops.gemm_tn(dpre, y_c, w["g_Wt"], bias_out=w["g_bt"])
+                dy.index_copy_(0, sel, ops.gemm_nt(dpre, w["WtT"]))
+                return dy, None, None, None, None, None, None
+        # dense path: dlogits with the per-pass upstream gradients folded in; in place unless the scores were handed to the caller
         dl = torch.empty_like(logits) if ctx.keep_logits else logits
         ops.ce_bwd(logits, V, labels, seg_bounds, ctx.nseg, inv, gs, lse, dl)
         ops.gemm_tn(dl, t, w["g_word_pad"], bias_out=w["g_pred_bias"])          # tied decoder weight + prediction bias gradient

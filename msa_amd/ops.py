@@ -95,6 +95,19 @@ def _ws_f32(nfloats: int, device) -> torch.Tensor:
     return t
 
 
+def gemm_nt_splitk(A, B, out=None):
+    """out[M,N] (bf16) = A[M,K] @ B[N,K]^T for long K and few output tiles (see mmbert_gemm_nt_splitk)."""
+    lib = _lib.load()
+    M, K = A.shape
+    N = B.shape[0]
+    if out is None:
+        out = torch.empty((M, N), device=A.device, dtype=torch.bfloat16)
+    ws = _ws_f32((lib.mmbert_gemm_nt_splitk_workspace(M, N, K) + 3) // 4, A.device)
+    _lib.check(lib.mmbert_gemm_nt_splitk(_stream(), A.data_ptr(), A.stride(0), B.data_ptr(), B.stride(0), out.data_ptr(), out.stride(0),
+                                         M, N, K, ws.data_ptr()), "mmbert_gemm_nt_splitk")
+    return out
+
+
 def gemm_tn(A, B, W, *, accumulate=True, alpha=1.0, alpha_dev=None, bias_out=None):
     """W[N,K] (fp32) (+)= alpha * A[M,N]^T @ B[M,K]; bias_out[N] += alpha * colsum(A)  (see mmbert_gemm_tn)."""
     lib = _lib.load()
@@ -327,13 +340,25 @@ def ce_fwd(logits, V, labels, seg_bounds, nseg):
     return loss[:nseg], inv, lse
 
 
-def ce_bwd(logits, V, labels, seg_bounds, nseg, inv, gscale, lse, dlogits):
-    """dlogits (may be ``logits`` itself) = d(sum_s gscale[s] * loss_s) / d(logits)  (see mmbert_ce_bwd)."""
+def ce_bwd(logits, V, labels, seg_bounds, nseg, inv, gscale, lse, dlogits, rows=None):
+    """dlogits (may be ``logits`` itself) = d(sum_s gscale[s] * loss_s) / d(logits)  (see mmbert_ce_bwd).
+    ``rows`` (int32 row list): compact output, dlogits[j] = gradient of row rows[j]."""
     lib = _lib.load()
     M = logits.shape[0]
     _lib.check(lib.mmbert_ce_bwd(_stream(), logits.data_ptr(), logits.stride(0), V, labels.data_ptr(), M, seg_bounds.data_ptr(), nseg,
-                                 inv.data_ptr(), gscale.data_ptr(), lse.data_ptr(), dlogits.data_ptr(), dlogits.stride(0)), "mmbert_ce_bwd")
+                                 inv.data_ptr(), gscale.data_ptr(), lse.data_ptr(), dlogits.data_ptr(), dlogits.stride(0),
+                                 _ptr(rows), 0 if rows is None else rows.numel()), "mmbert_ce_bwd")
     return dlogits
+
+
+def active_rows(labels, V):
+    """(idx int32 [M], count int32 [1]) on the device: rows with a label in [0, V), ascending (see mmbert_active_rows)."""
+    lib = _lib.load()
+    M = labels.numel()
+    idx = torch.empty(max(M, 1), device=labels.device, dtype=torch.int32)
+    count = torch.empty(1, device=labels.device, dtype=torch.int32)
+    _lib.check(lib.mmbert_active_rows(_stream(), labels.data_ptr(), M, V, idx.data_ptr(), count.data_ptr()), "mmbert_active_rows")
+    return idx, count
 
 
 def adamw(p, g, m, v, p_bf16, flags, *, lr, beta1=0.9, beta2=0.999, eps=1e-6, wd=0.01, step=1, gscale=1.0, mode=0, zero_grad=True):

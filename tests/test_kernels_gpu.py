@@ -93,6 +93,15 @@ def test_gemm_nt256_exact_integers(ops, mode, M):
         lib.mmbert_gemm_nt_force(0)
 
 
+@pytest.mark.parametrize("M,N,K", [(300, 256, 4096), (77, 768, 30592), (130, 132, 1024)])
+def test_gemm_nt_splitk(ops, M, N, K):
+    A, B = bf(rnd(M, K, seed=15, scale=0.1)), bf(rnd(N, K, seed=16, scale=0.1))
+    out = ops.gemm_nt_splitk(A.to(DEV), B.to(DEV))
+    assert_close(out, A.float() @ B.float().t(), 1e-2, 2e-2, "split-K")
+    again = ops.gemm_nt_splitk(A.to(DEV), B.to(DEV))
+    assert torch.equal(out, again)                                   # slabs + ordered reduction: reproducible
+
+
 def test_gemm_nt_strided_views_and_alpha_dev(ops):
     M, N, K = 300, 256, 192
     big = bf(rnd(M, 3 * K, seed=4)).to(DEV)

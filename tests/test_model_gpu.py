@@ -165,6 +165,27 @@ def test_dropout_train_mode_is_seeded_and_unbiased():
     assert all(torch.isfinite(q.grad).all() for q in m.parameters())
 
 
+def test_sparse_mlm_backward_equals_dense_backward():
+    """The MLM head's backward over the labelled rows only (default) against the dense backward over all rows: the
+    CE gradient of an unlabelled row is exactly zero, so every parameter gradient must agree up to fp32 summation order."""
+    batch = batch_to(synthetic_batch(2, 50, 64, 64, seed=3), DEV)
+    grads = []
+    for sparse in (True, False):
+        m = build(CFG1)
+        m.sparse_mlm_backward = sparse
+        out, _ = m(**batch)
+        out[0].mean().backward()
+        torch.cuda.synchronize()
+        grads.append({n: q.grad.float().clone() for n, q in m.named_parameters()})
+    for n in grads[0]:
+        a, b = grads[0][n], grads[1][n]
+        scale = float(b.abs().max()) + 1e-12
+        assert float((a - b).abs().max()) <= 2e-3 * scale + 1e-9, (n, float((a - b).abs().max()), scale)
+    lab = batch["masked_labels"]
+    n_act = sum(int((x != -100).sum()) for x in lab)
+    assert 0 < n_act < sum(x.numel() for x in lab) // 2          # the sparse path was really taken
+
+
 def test_submodule_api_matches_oracle():
     """MMBertModel.forward(joint) / JointEmbeddings.forward / heads via the reference's call sites."""
     cfg = CFG1
