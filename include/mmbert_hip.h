@@ -47,6 +47,9 @@ size_t mmbert_gemm_nt_splitk_workspace(int M, int N, int K);
  * with the tile height (256 or 224 rows) chosen by tile-round count, 3 = ring kernel 256x256, 4 = ring kernel
  * 224x256.  For tests and A/B benchmarking; results are identical up to fp32 summation order. */
 void mmbert_gemm_nt_force(int mode);
+/* Persistent NT kernel: draw tiles from a device-side queue instead of the static b, b+G, ... schedule.  For processes whose
+ * GEMMs share the GPU's CUs with concurrently running kernels of another stream (data-parallel training: RCCL). */
+void mmbert_gemm_nt_dynamic(int on);
 /* Split count of the token axis in mmbert_gemm_tn / _grouped: 0 = by shape (default), > 0 forced.  A/B benchmarking. */
 void mmbert_gemm_tn_force_splits(int splits);
 

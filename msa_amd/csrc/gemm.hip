@@ -29,6 +29,7 @@ struct GemmNT {
     float alpha;
     uint32_t drop_stream, drop_thr16; float drop_scale;
     int kt_per_split; long long split_stride;     // gemm_nt_kernel only: split-K over blockIdx.z into fp32 slabs (0 = no split)
+    int* tile_counter; int* tile_counter_next;    // gemm_ntp_kernel only: dynamic tile queue (null = static b, b+G, ...)
 };
 
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
@@ -410,6 +411,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(const GemmNT p) {
 
 static int g_nt_force = 0;   // 0 auto, 1 force 128^2, 2 force the 256-wide kernels (tests / A-B benchmarking)
 static int g_nt_bm = 0;      // 0 auto, 256 / 224 forced (A-B benchmarking)
+static int g_nt_dynamic = 0;  // dynamic tile queue in the persistent kernel: mmbert_gemm_nt_dynamic(1), used when other kernels share the CUs
 static int g_nt_persist = 1;  // persistent stream kernel where eligible (0: launch-per-tile ring kernel)
 static int device_cus() {
     static int cus = 0;
@@ -547,6 +549,11 @@ __global__ __launch_bounds__(512, 2) void gemm_ntp_kernel(const GemmNT p) {
 
     const float alpha = p.alpha * (p.alpha_dev ? *p.alpha_dev : 1.0f);
 
+    int first_fetch = 0;
+    if (p.tile_counter && tid == 0) {
+        if (blockIdx.x == 0) *p.tile_counter_next = 0;               // the NEXT launch's queue (launches are stream-ordered)
+        first_fetch = G + atomicAdd(p.tile_counter, 1);              // issued ahead of the prologue loads, parked behind them
+    }
     bf16x8 a0[MI], b0[4], a1[MI], b1[4];
     issue(0, cur, 0); issue(1, cur, 64); issue(2, cur, 128); issue(3, cur, 192);
     bool early = false;          // the previous tile's epilogue stores sit behind this tile's first stages in vmcnt order
@@ -567,9 +574,21 @@ __global__ __launch_bounds__(512, 2) void gemm_ntp_kernel(const GemmNT p) {
         __builtin_amdgcn_s_setprio(0);                                                    \
     }
 
-    for (int v = blockIdx.x; v < ntiles; v += G) {
+    // Tile queue.  A workgroup's first tile is its block index; further tiles come from a device counter (G + fetch-and-add)
+    // when the launch has more tiles than workgroups -- so that workgroups which start late (CUs held by another stream's
+    // kernels, e.g. RCCL channels during the gradient all-reduce) do not leave their whole static share for a second wave.
+    // One lane fetches the tile AFTER the next one at the start of an epilogue (at kernel start for the second tile), when
+    // registers are free and the latency has the whole epilogue to hide in, and parks it in a word of the (then idle)
+    // epilogue scratch; every wave picks it up after K step 3 of the next tile, several barriers later.
+    auto vq_write = [&](int value) {
+        const uint32_t vq_addr = (uint32_t)(size_t)LPTR(smem) + 131072u;
+        asm volatile("ds_write_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" :: "v"(vq_addr), "v"(value) : "memory");
+    };
+    if (p.tile_counter && tid == 0) vq_write(first_fetch);
+    for (int v = blockIdx.x, vn = 0; v < ntiles; v = vn) {
         const int tile = xcd_remap(v, ntiles);
         const int m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) << 8;
+
         // K steps 0-3 issue stages 4-7 of this tile (ns >= 8).  `early` only selects the wait immediate (a scalar branch
         // around one s_waitcnt); two full copies of the steps made hipcc spill accumulator tuples at the join
         MMB_STAMP(sa)
@@ -582,6 +601,14 @@ __global__ __launch_bounds__(512, 2) void gemm_ntp_kernel(const GemmNT p) {
         NTP_STEP(1, a1, b1, a0, b0, mma, early, true, cur, 320)
         NTP_STEP(2, a0, b0, a1, b1, mma, early, true, cur, 384)
         NTP_STEP(3, a1, b1, a0, b0, mma, false, true, cur, 448)
+        if (p.tile_counter) {
+            int q;
+            const uint32_t vq_addr = (uint32_t)(size_t)LPTR(smem) + 131072u;
+            asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(q) : "v"(vq_addr) : "memory");
+            vn = __builtin_amdgcn_readfirstlane(q);
+        } else {
+            vn = v + G;
+        }
         for (int s = 4; s < ns - 4; s += 4) {
             const uint32_t kb = (uint32_t)(s + 4) * 64u;
             NTP_STEP(0, a0, b0, a1, b1, mma, false, true, cur, kb)
@@ -590,7 +617,7 @@ __global__ __launch_bounds__(512, 2) void gemm_ntp_kernel(const GemmNT p) {
             NTP_STEP(3, a1, b1, a0, b0, mma, false, true, cur, kb + 192)
         }
         // the last four K steps issue stages 0-3 of the workgroup's next tile
-        if (v + G < ntiles) set_src(v + G, nxt);                  // past the last tile: dead re-reads of the same stages
+        if (vn < ntiles) set_src(vn, nxt);                        // past the last tile: dead re-reads of the same stages
         NTP_STEP(0, a0, b0, a1, b1, mma, false, true, nxt, 0)
         NTP_STEP(1, a1, b1, a0, b0, mma, false, true, nxt, 64)
         NTP_STEP(2, a0, b0, a1, b1, mma, false, true, nxt, 128)
@@ -607,6 +634,9 @@ __global__ __launch_bounds__(512, 2) void gemm_ntp_kernel(const GemmNT p) {
         auto kp = __builtin_amdgcn_kernarg_segment_ptr();
         asm volatile("" : "+s"(kp));
         const __attribute__((address_space(4))) GemmNT& q = *(const __attribute__((address_space(4))) GemmNT*)kp;
+        int fetched = 0;
+        const bool fetcher = q.tile_counter && tid == 0 && vn < ntiles;     // the tile after the next one (if there is a next one)
+        if (fetcher) fetched = G + atomicAdd(q.tile_counter, 1);
         int elane = lane;
         asm volatile("" : "+v"(elane));
         const int efr = elane & 15, efq = elane >> 4;
@@ -734,6 +764,7 @@ __global__ __launch_bounds__(512, 2) void gemm_ntp_kernel(const GemmNT p) {
             }
         }
         (void)ncol_ok;
+        if (fetcher) vq_write(fetched);                              // wave 0's scratch is idle again
 #ifdef MMB_STAMPS
         MMB_STAMP(sd)
         t_wait += sb - sa; t_loop += sc_ - sb; t_epi += sd - sc_; ++ntile;
@@ -763,7 +794,26 @@ static int launch_ntp_mi(hipStream_t s, const GemmNT& p) {
         attr_set = true;
     }
     const int cus = device_cus();
-    hipLaunchKernelGGL((gemm_ntp_kernel<EPI, MI>), dim3(tiles < cus ? tiles : cus), dim3(512), 163840, s, p);
+    GemmNT q = p;
+    q.tile_counter = q.tile_counter_next = nullptr;
+    if (tiles > cus) {
+        // two counters used alternately: launch k draws from ctr[k & 1] and zeroes ctr[(k + 1) & 1] for its successor.  Valid
+        // for launches that are ordered on ONE stream (the forward / backward pass); a launch on another stream gets the
+        // static schedule.  8 bytes of device memory owned by the library, allocated once.
+        static int* ctr = nullptr;
+        static hipStream_t ctr_stream = nullptr;
+        static unsigned launches = 0;
+        if (!ctr) {
+            if (hipMalloc((void**)&ctr, 2 * sizeof(int)) == hipSuccess && hipMemset(ctr, 0, 2 * sizeof(int)) == hipSuccess) ctr_stream = s;
+            else ctr = nullptr;
+        }
+        if (ctr && s == ctr_stream && g_nt_dynamic) {
+            q.tile_counter = ctr + (launches & 1);
+            q.tile_counter_next = ctr + ((launches + 1) & 1);
+            ++launches;
+        }
+    }
+    hipLaunchKernelGGL((gemm_ntp_kernel<EPI, MI>), dim3(tiles < cus ? tiles : cus), dim3(512), 163840, s, q);
     MMB_CHECK_LAUNCH();
     return 0;
 }
@@ -1180,7 +1230,7 @@ int mmbert_gemm_nt(hipStream_t stream, const void* A, int lda, const void* B, in
     p.aux = (bf16_t*)aux; p.U = (const bf16_t*)U; p.alpha_dev = alpha_dev;
     p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.ldr = ldr; p.ldaux = ldaux; p.ldu = ldu;
     p.alpha = alpha; p.drop_stream = drop_stream; p.drop_thr16 = drop_thr16; p.drop_scale = drop_scale;
-    p.kt_per_split = 0; p.split_stride = 0;
+    p.kt_per_split = 0; p.split_stride = 0; p.tile_counter = p.tile_counter_next = nullptr;
     switch (epi) {
         case 0: return dispatch_nt<0>(stream, p);
         case EPI_BIAS: return dispatch_nt<EPI_BIAS>(stream, p);
@@ -1203,6 +1253,9 @@ int mmbert_debug_set_nt_dbg(int v) {
     return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_nt_dbg), &v, sizeof(v));
 }
 #endif
+// Dynamic tile queue of the persistent NT kernel (off by default: on a GPU of its own the static schedule is ~0.4 % faster;
+// on when kernels of another stream -- RCCL during the overlapped gradient all-reduce -- hold CUs, see gemm_ntp_kernel).
+void mmbert_gemm_nt_dynamic(int on) { g_nt_dynamic = on ? 1 : 0; }
 void mmbert_gemm_nt_force(int mode) {
     // 0 auto | 1 128^2 | ring kernel, one launch slot per tile: 2 (tile height auto), 3 (256x256), 4 (224x256)
     // | persistent stream kernel: 5 (tile height auto), 6 (256x256), 7 (224x256)
