@@ -453,7 +453,19 @@ __device__ __forceinline__ void lds_read16f(f32x4& dst, uint32_t lds_addr) {
     asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(lds_addr), "i"(OFF) : "memory");
 }
 
-template <int EPI, int MI>
+// STAG selects the K-step schedule:
+//  false: one barrier per step, fragments of step s+1 read into a second register set under the MFMAs of step s (96 fragment
+//         VGPRs; with 8 row blocks per wave that spills, so this form runs the 224-row tile);
+//  true : two wave groups (the two M halves: one wave of each per SIMD) half a step apart -- the second group takes one extra
+//         barrier up front, so its k-th barrier meets the first group's (k+1)-th -- and a step = two phases of <= 16 MFMAs,
+//         phase = { LDS reads of its operands (phase b: + wait for this wave's part of stage s+1, issue stage s+3) ; barrier ;
+//         MFMAs ; barrier }: one group's MFMAs run under the other's reads, fragments are single-buffered (32 VGPRs) and the
+//         256-row tile fits.  Measured per step: 1286 clk (false, 224 rows) vs ~1300 (true, 256 rows = 14 % more work).
+//         RAW: a wave waits for ITS part of stage s+1 in phase b of step s, before that phase's first barrier; every reader
+//              of stage s+1 (phase a of step s+1, either group) has passed a barrier that pairs with or follows it.
+//         WAR: stage s+3 goes into the slot of stage s-1, whose last reads (phase b of step s-1) completed before their
+//              MFMAs, i.e. before that phase's second barrier in BOTH groups; phase b of step s lies behind it for both.
+template <int EPI, int MI, bool STAG>
 __global__ __launch_bounds__(512, 2) void gemm_ntp_kernel(const GemmNT p) {
 #if __HIP_DEVICE_COMPILE__   // the host pass only needs the launch stub (the body uses device-only builtins)
     constexpr int BM = 32 * MI;
@@ -547,6 +559,21 @@ __global__ __launch_bounds__(512, 2) void gemm_ntp_kernel(const GemmNT p) {
                 acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
     };
 
+    bf16x8 sf_a[4], sf_b[4];                                       // STAG: single-buffered fragments
+    auto load_b1 = [&](int slot) {
+        const lds_cptr bb = slot < 2 ? b_rd : b_rd_hi;
+        const int so = (slot & 1) * 32768;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) sf_b[j] = *(lds_frag)(bb + so + j * 1024);
+    };
+    auto load_a1 = [&](int slot, int i0, int n) {                  // row blocks i0 .. i0 + n - 1 -> sf_a[0 .. n - 1]
+        const lds_cptr ab = slot < 2 ? a_rd : a_rd_hi;
+        const int so = (slot & 1) * 32768;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (i < n) sf_a[i] = *(lds_frag)(ab + so + (i0 + i) * 1024);
+    };
+
     const float alpha = p.alpha * (p.alpha_dev ? *p.alpha_dev : 1.0f);
 
     int first_fetch = 0;
@@ -555,7 +582,14 @@ __global__ __launch_bounds__(512, 2) void gemm_ntp_kernel(const GemmNT p) {
         first_fetch = G + atomicAdd(p.tile_counter, 1);              // issued ahead of the prologue loads, parked behind them
     }
     bf16x8 a0[MI], b0[4], a1[MI], b1[4];
-    issue(0, cur, 0); issue(1, cur, 64); issue(2, cur, 128); issue(3, cur, 192);
+    if constexpr (STAG) {
+        issue(0, cur, 0); issue(1, cur, 64); issue(2, cur, 128);
+        __builtin_amdgcn_s_waitcnt(mmb_waitcnt(8, 15));            // this wave's part of stage 0
+        __builtin_amdgcn_s_barrier();
+        if (wr == 1) __builtin_amdgcn_s_barrier();                 // the stagger; balanced by the other group at the end
+    } else {
+        issue(0, cur, 0); issue(1, cur, 64); issue(2, cur, 128); issue(3, cur, 192);
+    }
     bool early = false;          // the previous tile's epilogue stores sit behind this tile's first stages in vmcnt order
 #ifdef MMB_STAMPS
     unsigned long long sa = 0, sb = 0, sc_ = 0, sd = 0, t_wait = 0, t_loop = 0, t_epi = 0, rt0 = 0, rt3 = 0, ntile = 0;
@@ -572,6 +606,34 @@ __global__ __launch_bounds__(512, 2) void gemm_ntp_kernel(const GemmNT p) {
         __builtin_amdgcn_s_setprio(1);                                                    \
         MMA(CUR_A, CUR_B);                                                                \
         __builtin_amdgcn_s_setprio(0);                                                    \
+    }
+
+#define NT3_STEP(SLOT, FIRST, WEARLY, SRC, KB)                                                \
+    {                                                                                         \
+        load_b1(SLOT);                                                                        \
+        load_a1(SLOT, 0, 4);                                                                  \
+        __builtin_amdgcn_s_barrier();                                                         \
+        __builtin_amdgcn_sched_barrier(0);                                                    \
+        __builtin_amdgcn_s_setprio(1);                                                        \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i)                                         \
+            _Pragma("unroll") for (int j = 0; j < 4; ++j)                                     \
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(sf_b[j], sf_a[i], (FIRST) ? (f32x4){0.f, 0.f, 0.f, 0.f} : acc[i][j], 0, 0, 0); \
+        __builtin_amdgcn_s_setprio(0);                                                        \
+        __builtin_amdgcn_s_barrier();                                                         \
+        __builtin_amdgcn_sched_barrier(0);                                                    \
+        load_a1(SLOT, 4, MI - 4);                                                             \
+        if (WEARLY) __builtin_amdgcn_s_waitcnt(mmb_waitcnt(4 + EST, 15));                     \
+        else __builtin_amdgcn_s_waitcnt(mmb_waitcnt(4, 15));                                  \
+        issue((SLOT + 3) & 3, SRC, KB);                                                       \
+        __builtin_amdgcn_s_barrier();                                                         \
+        __builtin_amdgcn_sched_barrier(0);                                                    \
+        __builtin_amdgcn_s_setprio(1);                                                        \
+        _Pragma("unroll") for (int i = 4; i < MI; ++i)                                        \
+            _Pragma("unroll") for (int j = 0; j < 4; ++j)                                     \
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(sf_b[j], sf_a[i - 4], (FIRST) ? (f32x4){0.f, 0.f, 0.f, 0.f} : acc[i][j], 0, 0, 0); \
+        __builtin_amdgcn_s_setprio(0);                                                        \
+        __builtin_amdgcn_s_barrier();                                                         \
+        __builtin_amdgcn_sched_barrier(0);                                                    \
     }
 
     // Tile queue.  A workgroup's first tile is its block index; further tiles come from a device counter (G + fetch-and-add)
@@ -591,37 +653,65 @@ __global__ __launch_bounds__(512, 2) void gemm_ntp_kernel(const GemmNT p) {
 
         // K steps 0-3 issue stages 4-7 of this tile (ns >= 8).  `early` only selects the wait immediate (a scalar branch
         // around one s_waitcnt); two full copies of the steps made hipcc spill accumulator tuples at the join
-        MMB_STAMP(sa)
-        if (early) __builtin_amdgcn_s_waitcnt(mmb_waitcnt(12 + EST, 0));
-        else __builtin_amdgcn_s_waitcnt(mmb_waitcnt(12, 0));
-        __builtin_amdgcn_s_barrier();
-        MMB_STAMP(sb)
-        load_frags(0, a0, b0);
-        NTP_STEP(0, a0, b0, a1, b1, mma_first, early, true, cur, 256)
-        NTP_STEP(1, a1, b1, a0, b0, mma, early, true, cur, 320)
-        NTP_STEP(2, a0, b0, a1, b1, mma, early, true, cur, 384)
-        NTP_STEP(3, a1, b1, a0, b0, mma, false, true, cur, 448)
-        if (p.tile_counter) {
-            int q;
-            const uint32_t vq_addr = (uint32_t)(size_t)LPTR(smem) + 131072u;
-            asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(q) : "v"(vq_addr) : "memory");
-            vn = __builtin_amdgcn_readfirstlane(q);
+        const uint32_t kbytes = (uint32_t)p.K * 2u;
+        auto read_queue = [&]() {
+            if (p.tile_counter) {
+                int q;
+                const uint32_t vq_addr = (uint32_t)(size_t)LPTR(smem) + 131072u;
+                asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(q) : "v"(vq_addr) : "memory");
+                vn = __builtin_amdgcn_readfirstlane(q);
+            } else {
+                vn = v + G;
+            }
+        };
+        if constexpr (STAG) {
+            MMB_STAMP(sa)
+            MMB_STAMP(sb)
+            // K steps 0-3 bring in stages 3-6 of this tile (ns >= 8); the epilogue's stores sit behind the next tile's stages 0-2
+            NT3_STEP(0, true, early, cur, 192)
+            NT3_STEP(1, false, early, cur, 256)
+            NT3_STEP(2, false, false, cur, 320)
+            NT3_STEP(3, false, false, cur, 384)
+            read_queue();
+            for (int s = 4; s < ns - 4; s += 4) {
+                const uint32_t kb = (uint32_t)(s + 3) * 64u;
+                NT3_STEP(0, false, false, cur, kb)
+                NT3_STEP(1, false, false, cur, kb + 64)
+                NT3_STEP(2, false, false, cur, kb + 128)
+                NT3_STEP(3, false, false, cur, kb + 192)
+            }
+            // the last four K steps bring in the last stage of this tile and stages 0-2 of the workgroup's next tile
+            if (vn < ntiles) set_src(vn, nxt);                    // past the last tile: dead re-reads of the same stages
+            NT3_STEP(0, false, false, cur, kbytes - 64)
+            NT3_STEP(1, false, false, nxt, 0)
+            NT3_STEP(2, false, false, nxt, 64)
+            NT3_STEP(3, false, false, nxt, 128)
         } else {
-            vn = v + G;
+            MMB_STAMP(sa)
+            if (early) __builtin_amdgcn_s_waitcnt(mmb_waitcnt(12 + EST, 0));
+            else __builtin_amdgcn_s_waitcnt(mmb_waitcnt(12, 0));
+            __builtin_amdgcn_s_barrier();
+            MMB_STAMP(sb)
+            load_frags(0, a0, b0);
+            NTP_STEP(0, a0, b0, a1, b1, mma_first, early, true, cur, 256)
+            NTP_STEP(1, a1, b1, a0, b0, mma, early, true, cur, 320)
+            NTP_STEP(2, a0, b0, a1, b1, mma, early, true, cur, 384)
+            NTP_STEP(3, a1, b1, a0, b0, mma, false, true, cur, 448)
+            read_queue();
+            for (int s = 4; s < ns - 4; s += 4) {
+                const uint32_t kb = (uint32_t)(s + 4) * 64u;
+                NTP_STEP(0, a0, b0, a1, b1, mma, false, true, cur, kb)
+                NTP_STEP(1, a1, b1, a0, b0, mma, false, true, cur, kb + 64)
+                NTP_STEP(2, a0, b0, a1, b1, mma, false, true, cur, kb + 128)
+                NTP_STEP(3, a1, b1, a0, b0, mma, false, true, cur, kb + 192)
+            }
+            // the last four K steps issue stages 0-3 of the workgroup's next tile
+            if (vn < ntiles) set_src(vn, nxt);                        // past the last tile: dead re-reads of the same stages
+            NTP_STEP(0, a0, b0, a1, b1, mma, false, true, nxt, 0)
+            NTP_STEP(1, a1, b1, a0, b0, mma, false, true, nxt, 64)
+            NTP_STEP(2, a0, b0, a1, b1, mma, false, true, nxt, 128)
+            NTP_STEP(3, a1, b1, a0, b0, mma, false, false, nxt, 192)
         }
-        for (int s = 4; s < ns - 4; s += 4) {
-            const uint32_t kb = (uint32_t)(s + 4) * 64u;
-            NTP_STEP(0, a0, b0, a1, b1, mma, false, true, cur, kb)
-            NTP_STEP(1, a1, b1, a0, b0, mma, false, true, cur, kb + 64)
-            NTP_STEP(2, a0, b0, a1, b1, mma, false, true, cur, kb + 128)
-            NTP_STEP(3, a1, b1, a0, b0, mma, false, true, cur, kb + 192)
-        }
-        // the last four K steps issue stages 0-3 of the workgroup's next tile
-        if (vn < ntiles) set_src(vn, nxt);                        // past the last tile: dead re-reads of the same stages
-        NTP_STEP(0, a0, b0, a1, b1, mma, false, true, nxt, 0)
-        NTP_STEP(1, a1, b1, a0, b0, mma, false, true, nxt, 64)
-        NTP_STEP(2, a0, b0, a1, b1, mma, false, true, nxt, 128)
-        NTP_STEP(3, a1, b1, a0, b0, mma, false, false, nxt, 192)
         cur = nxt;
         MMB_STAMP(sc_)
 
@@ -772,6 +862,8 @@ __global__ __launch_bounds__(512, 2) void gemm_ntp_kernel(const GemmNT p) {
         early = interior && !((EPI & EPI_GELU) && !q.aux);
     }
 #undef NTP_STEP
+#undef NT3_STEP
+    if constexpr (STAG) { if (wr == 0) __builtin_amdgcn_s_barrier(); }   // balances the stagger barrier of the other group
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // the dead tail stages
 #ifdef MMB_STAMPS
     if (g_stamps && lane == 0) {
@@ -789,7 +881,7 @@ static int launch_ntp_mi(hipStream_t s, const GemmNT& p) {
     const int tiles = ((p.M + BM - 1) / BM) * ((p.N + 255) / 256);
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)gemm_ntp_kernel<EPI, MI>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
+        hipError_t e = hipFuncSetAttribute((const void*)gemm_ntp_kernel<EPI, MI, MI == 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
@@ -813,7 +905,7 @@ static int launch_ntp_mi(hipStream_t s, const GemmNT& p) {
             ++launches;
         }
     }
-    hipLaunchKernelGGL((gemm_ntp_kernel<EPI, MI>), dim3(tiles < cus ? tiles : cus), dim3(512), 163840, s, q);
+    hipLaunchKernelGGL((gemm_ntp_kernel<EPI, MI, MI == 8>), dim3(tiles < cus ? tiles : cus), dim3(512), 163840, s, q);
     MMB_CHECK_LAUNCH();
     return 0;
 }
@@ -849,6 +941,8 @@ static int launch_nt256(hipStream_t s, const GemmNT& p) {
     const int r224 = (((p.M + 223) / 224) * tn + cus - 1) / cus;
     const bool can_persist = g_nt_persist && ntp_eligible(p);
     if (g_nt_bm == 0) {
+        // default: the 224-row form.  The 256-row staggered form (mode 6) wins 1-7 % on single-round and very wide shapes in
+        // isolation (tools/bench_gemm.py) but not in the train step (same box, bench.py: 797 vs 805 samples/s): not the default.
         if (can_persist) return launch_ntp_mi<EPI, 7>(s, p);
         return r224 <= r256 ? launch_nt256_mi<EPI, 7>(s, p) : launch_nt256_mi<EPI, 8>(s, p);
     }
