@@ -576,6 +576,23 @@ __global__ __launch_bounds__(256) void transpose_cast_kernel(const float* __rest
     const int r0 = (tl / tc) << 6, c0 = (tl % tc) << 6;
     const float* s = src + ds.src_off;
     bf16_t* o = dst + ds.dst_off;
+    const bool full = r0 + 64 <= ds.rows && c0 + 64 <= ds.cols && r0 + 64 <= ds.dst_ld && !(ds.cols & 3) && !(ds.dst_ld & 7) && !(ds.src_off & 3) && !(ds.dst_off & 7);
+    if (full) {                                  // interior tile: 16-byte reads along a source row, 16-byte writes along a destination row
+        for (int e = threadIdx.x; e < 1024; e += 256) {
+            const int r = e >> 4, c = (e & 15) << 2;
+            const float4 v = *(const float4*)(s + (size_t)(r0 + r) * ds.cols + c0 + c);
+            t[r][c] = v.x; t[r][c + 1] = v.y; t[r][c + 2] = v.z; t[r][c + 3] = v.w;
+        }
+        __syncthreads();
+        for (int e = threadIdx.x; e < 512; e += 256) {
+            const int c = e >> 3, r = (e & 7) << 3;
+            bf16x8 ov;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) ov[j] = f2bf(t[r + j][c]);
+            *(bf16x8*)(o + (size_t)(c0 + c) * ds.dst_ld + r0 + r) = ov;
+        }
+        return;
+    }
     for (int e = threadIdx.x; e < 4096; e += 256) {
         const int r = e >> 6, c = e & 63;
         t[r][c] = (r0 + r < ds.rows && c0 + c < ds.cols) ? s[(size_t)(r0 + r) * ds.cols + c0 + c] : 0.f;
