@@ -147,6 +147,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnArgs a) {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int seq = a.tile_seq[blockIdx.x], r0 = a.tile_r0[blockIdx.x], head = blockIdx.y;
     const int start = a.seq_start[seq], S = a.seq_len[seq];
+    const bool wave_active = r0 + wave * 32 < S;             // (128-row tiles: S = 550 leaves waves 2, 3 of the fifth tile without rows)
     const int Spad = (S + 3) & ~3;
     const int fr = lane & 15, g = lane >> 4;
     const bf16_t* base = a.qkv + (size_t)start * a.ld_qkv + head * 64;
@@ -214,6 +215,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnArgs a) {
         __builtin_amdgcn_s_waitcnt(0x0F70);                  // vmcnt(0): tile t landed (tile t+1 is issued below, after the barrier)
         __builtin_amdgcn_s_barrier();                        // ... for every wave; buffer buf^1 (tile t-1) is free
         if (t + 1 < ntile) stage(buf ^ 1, kv0 + 64);
+        if (!wave_active) return;                            // a wave whose 32 rows lie past the sequence end only helps staging
         const char* Ks = smem + buf * FWD_BUF;
 
         // S^T = K.Q^T with the key bias (divided by the scale) as the initial accumulator
@@ -333,6 +335,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnArgs a) {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int seq = a.tile_seq[blockIdx.x], r0 = a.tile_r0[blockIdx.x], head = blockIdx.y;
     const int start = a.seq_start[seq], S = a.seq_len[seq];
+    const bool wave_active = r0 + wave * 32 < S;             // (128-row tiles: S = 550 leaves waves 2, 3 of the fifth tile without rows)
     const int Spad = (S + 3) & ~3;
     const int fr = lane & 15, g = lane >> 4;
     const bf16_t* base = a.qkv + (size_t)start * a.ld_qkv + head * 64;
@@ -398,6 +401,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnArgs a) {
         __builtin_amdgcn_s_waitcnt(0x0F70);                  // vmcnt(0)
         __builtin_amdgcn_s_barrier();
         if (t + 1 < ntile) stage(buf ^ 1, kv0 + 64);
+        if (!wave_active) return;                            // a wave whose 32 rows lie past the sequence end only helps staging
         const char* Ks = smem + buf * DQ_BUF;
         const char* Vs = Ks + 16384;
         f32x4 s[2][4], dp[2][4], b4[4];
@@ -500,6 +504,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnArgs a) 
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int seq = a.tile_seq[blockIdx.x], r0 = a.tile_r0[blockIdx.x], head = blockIdx.y;
     const int start = a.seq_start[seq], S = a.seq_len[seq];
+    const bool wave_active = r0 + wave * 32 < S;             // (128-row tiles: S = 550 leaves waves 2, 3 of the fifth tile without rows)
     const int Spad = (S + 3) & ~3;
     const int fr = lane & 15, g = lane >> 4;
     const bf16_t* base = a.qkv + (size_t)start * a.ld_qkv + head * 64;
@@ -565,6 +570,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnArgs a) 
         __builtin_amdgcn_s_waitcnt(0x0F70);                  // vmcnt(0)
         __builtin_amdgcn_s_barrier();
         if (t + 1 < ntile) stage(buf ^ 1, q0 + 64);
+        if (!wave_active) return;                            // a wave whose 32 keys lie past the sequence end only helps staging
         const char* Qs = smem + buf * DKV_BUF;
         const char* Ds = Qs + 16384;
         f32x4 l4[4], d4[4];
