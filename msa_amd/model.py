@@ -644,6 +644,83 @@ class MMBertPreTrainingHeads(nn.Module):
         return scores, self.seq_relationship(pooled_output)
 
 
+class _HeadsFn(torch.autograd.Function):
+    """heads_loss = ap_loss + label_loss - beta * nce and the auxiliary outputs from the [CLS] rows, with a hand-written
+    backward: dense products through torch (hipBLASLt), everything between them in csrc/heads.hip.  Same arithmetic as
+    MMBertForPretraining._heads (the eager form, kept as the reference for tests and for configurations this path does not
+    cover); ~35 launches instead of ~250.  Parameter gradients are accumulated straight into ``p.grad`` (views of the flat
+    gradient buffer); the auxiliary outputs are values (non-differentiable)."""
+
+    @staticmethod
+    def forward(ctx, first, top, ap, sent):
+        B, H = first.shape[0] // 3, first.shape[1]
+        pool, al, sr, at = top.bert.pooler.dense, top.cls.align, top.cls.seq_relationship, top.attn
+        vs3 = (top.vt, top.vv, top.vs)
+        c1, c2 = top.classifier1_1, top.classifier1_2
+        qs = (top.cpc_zt.net, top.cpc_zv.net, top.cpc_za.net)
+        first = first.contiguous()
+        P = torch.addmm(pool.bias, first, pool.weight.t()).tanh_()
+        t_rel = torch.addmm(sr.bias, P[:B], sr.weight.t())
+        rel = torch.addmm(al.bias, first[B:], al.weight.t())                         # [2B, 2]: visual rows, speech rows
+        Apre = torch.addmm(at.bias, P, at.weight[:, :H].t())                         # attn(cat(x, x)) = x (W1 + W2)^T + b
+        Apre.addmm_(P, at.weight[:, H:].t())
+        g, Cc = ops.heads_gate_fwd(P, Apre, [v.weight for v in vs3], [v.bias for v in vs3], B)
+        T = torch.addmm(c1.bias, Cc, c1.weight.t())
+        lo = torch.addmm(c2.bias, T, c2.weight.t())                                  # [B, 1]
+        XP = torch.empty((3, B, H), device=first.device, dtype=torch.float32)
+        for m in range(3):
+            torch.addmm(qs[m].bias, T, qs[m].weight.t(), out=XP[m])
+        tanh_lo = top.num_labels == 1
+        out4, seeds = ops.heads_loss_fwd(P, XP, rel, ap, lo, sent, B, top.beta, tanh_lo)
+        ctx.top, ctx.B = top, B
+        ctx.save_for_backward(first, P, Apre, g, Cc, T, seeds)
+        logits_out = torch.tanh(lo) if tanh_lo else lo
+        ctx.mark_non_differentiable(t_rel, rel, logits_out)
+        ctx.set_materialize_grads(False)
+        aux = out4[:3].clone()
+        ctx.mark_non_differentiable(aux)
+        return out4[3].clone(), aux, logits_out, t_rel, rel
+
+    @staticmethod
+    def backward(ctx, d, *_unused):
+        if d is None:
+            return None, None, None, None
+        first, P, Apre, g, Cc, T, seeds = ctx.saved_tensors
+        top, B = ctx.top, ctx.B
+        H = P.shape[1]
+        pool, al, at = top.bert.pooler.dense, top.cls.align, top.attn
+        vs3 = (top.vt, top.vv, top.vs)
+        c1, c2 = top.classifier1_1, top.classifier1_2
+        qs = (top.cpc_zt.net, top.cpc_zv.net, top.cpc_za.net)
+        n = 3 * B * H
+        seeds = seeds.clone()                                                        # backward may run twice (retain_graph)
+        ops.heads_scale(seeds, d.reshape(1).float().contiguous())
+        dXP, dPc = seeds[:n].view(3, B, H), seeds[n:2 * n].view(3 * B, H)
+        dlo, drel = seeds[2 * n:2 * n + B].view(B, 1), seeds[2 * n + B:].view(2 * B, 2)
+        for m in range(3):
+            qs[m].weight.grad.addmm_(dXP[m].t(), T)
+        dT = torch.mm(dXP[0], qs[0].weight)
+        dT.addmm_(dXP[1], qs[1].weight)
+        dT.addmm_(dXP[2], qs[2].weight)
+        dT.addmm_(dlo, c2.weight)
+        c2.weight.grad.addmm_(dlo.t(), T)
+        dC = torch.mm(dT, c1.weight)
+        c1.weight.grad.addmm_(dT.t(), Cc)
+        dP, dA = ops.heads_gate_bwd(dC, P, Apre, g, [v.weight for v in vs3], dPc, B, [v.weight.grad for v in vs3], [v.bias.grad for v in vs3])
+        dP.addmm_(dA, at.weight[:, :H])
+        dP.addmm_(dA, at.weight[:, H:])
+        at.weight.grad[:, :H].addmm_(dA.t(), P)
+        at.weight.grad[:, H:].addmm_(dA.t(), P)
+        dpre = ops.heads_tanh_bwd(dP, P)
+        dfirst = torch.mm(dpre, pool.weight)
+        dfirst[B:].addmm_(drel, al.weight)
+        pool.weight.grad.addmm_(dpre.t(), first)
+        al.weight.grad.addmm_(drel.t(), first[B:])
+        ops.heads_colsum([(dXP[0], qs[0].bias.grad), (dXP[1], qs[1].bias.grad), (dXP[2], qs[2].bias.grad), (dT, c1.bias.grad),
+                          (dlo, c2.bias.grad), (dA, at.bias.grad), (dpre, pool.bias.grad), (drel, al.bias.grad)])
+        return dfirst, None, None, None
+
+
 class MMBertForPretraining(_GpuModelBase):
     """REF:MMBertForPretraining.py:304-449."""
 
@@ -668,6 +745,9 @@ class MMBertForPretraining(_GpuModelBase):
         self.cpc_zt, self.cpc_zv, self.cpc_za = (CPC(H, H, 1, "Tanh") for _ in range(3))
         self._init_runtime()
         self.return_scores = True
+        # heads through _HeadsFn (hand-written backward, csrc/heads.hip); False = the eager autograd form (_heads), in which
+        # ap_loss / label_loss / nce and the relationship scores stay differentiable outputs
+        self.fused_heads = os.environ.get("MMBERT_FUSED_HEADS", "1") != "0"
         _hf_init(self, config.initializer_range)
         # weight tying (HF:728-731): decoder.weight IS the word embedding, decoder.bias IS predictions.bias
         self.cls.predictions.decoder.weight = self.bert.embeddings.word_embeddings.weight
@@ -778,11 +858,18 @@ class MMBertForPretraining(_GpuModelBase):
 
         first = y.index_select(0, plan["first"]).float()                             # [3B, H]: [CLS] rows of every sequence
         mlm_loss = (mlm[0] + mlm[1] + mlm[2]) / 3.0                                  # :427
-        # (a captured hipGraph of this [B,H]-sized glue -- forward and backward, ~200 dependent launches -- was built and
-        # measured in round 1: 818-821 vs 808-822 samples/s eager on the same box; the device time of the tiny kernels, not
-        # their dispatch, is the cost, so the plain eager form stays)
-        heads_loss, ap_loss, label_loss, nce, logits_out, t_rel, v_rel, s_rel = self._heads(first, ap_v.to(dev), ap_s.to(dev),
-                                                                                          None if sentiment is None else sentiment.to(dev))
+        # (a captured hipGraph of the eager [B,H]-sized glue -- forward and backward, ~200 dependent launches -- was built and
+        # measured in round 1: no gain; the device time of the tiny kernels, not their dispatch, is the cost)
+        fused = (self.fused_heads and sentiment is not None and first.is_cuda and self.num_labels in (1, 7)
+                 and all(q.grad is not None for q in (self.attn.weight, self.vt.weight, self.classifier1_1.weight)))
+        if fused:
+            ap = torch.cat((ap_v.to(dev).view(-1), ap_s.to(dev).view(-1))).long()
+            heads_loss, aux, logits_out, t_rel, rel = _HeadsFn.apply(first, self, ap, sentiment.to(dev).view(-1).float())
+            ap_loss, label_loss, nce = aux[0], aux[1], aux[2]
+            v_rel, s_rel = rel[:B], rel[B:]
+        else:
+            heads_loss, ap_loss, label_loss, nce, logits_out, t_rel, v_rel, s_rel = self._heads(first, ap_v.to(dev), ap_s.to(dev),
+                                                                                              None if sentiment is None else sentiment.to(dev))
         joint_loss = self.alpha * mlm_loss + heads_loss                              # :443
         scores = (None, None, None)
         if logits is not None:

@@ -121,8 +121,8 @@ def gemm_tn(A, B, W, *, accumulate=True, alpha=1.0, alpha_dev=None, bias_out=Non
     return W
 
 
-_PtrArr = {n: (ctypes.c_void_p * n) for n in range(1, 5)}
-_IntArr = {n: (ctypes.c_int * n) for n in range(1, 5)}
+_PtrArr = {n: (ctypes.c_void_p * n) for n in range(1, 11)}
+_IntArr = {n: (ctypes.c_int * n) for n in range(1, 11)}
 
 
 def gemm_tn_grouped(problems, *, accumulate=True, alpha=1.0):
@@ -389,3 +389,59 @@ def cast_bf16_f32(x, y):
 def transpose_cast(src_flat, dst_flat, descs_dev, ndesc, total_tiles):
     _lib.check(_lib.load().mmbert_transpose_cast(_stream(), src_flat.data_ptr(), dst_flat.data_ptr(), descs_dev.data_ptr(), ndesc, total_tiles),
                "mmbert_transpose_cast")
+
+
+# ------------------------------------------------------------------------------------ pretraining heads (csrc/heads.hip)
+def _ptr3(ts):
+    return _PtrArr[3](*[t.data_ptr() for t in ts])
+
+
+def heads_gate_fwd(P, Apre, vws, vbs, B):
+    H = P.shape[1]
+    g = torch.empty(3 * B, device=P.device, dtype=torch.float32)
+    Cc = torch.empty((B, 3 * H), device=P.device, dtype=torch.float32)
+    _lib.check(_lib.load().mmbert_heads_gate_fwd(_stream(), P.data_ptr(), Apre.data_ptr(), _ptr3(vws), _ptr3(vbs), B, H, g.data_ptr(), Cc.data_ptr()),
+               "mmbert_heads_gate_fwd")
+    return g, Cc
+
+
+def heads_loss_fwd(P, XP, rel, ap, lo, sent, B, beta, tanh_lo):
+    """returns (out4, seeds) with seeds = [dXP (3BH) | dPc (3BH) | dlo (B) | drel (4B)] for an upstream gradient of 1."""
+    H = P.shape[1]
+    n = 3 * B * H
+    seeds = torch.empty(2 * n + 5 * B, device=P.device, dtype=torch.float32)
+    out4 = torch.empty(4, device=P.device, dtype=torch.float32)
+    part = torch.empty(3, device=P.device, dtype=torch.float32)
+    base = seeds.data_ptr()
+    _lib.check(_lib.load().mmbert_heads_loss_fwd(_stream(), P.data_ptr(), XP.data_ptr(), rel.data_ptr(), ap.data_ptr(), lo.data_ptr(), sent.data_ptr(),
+                                                 B, H, float(beta), int(tanh_lo), out4.data_ptr(), base, base + 4 * n, base + 4 * (2 * n + B), base + 4 * 2 * n,
+                                                 part.data_ptr()), "mmbert_heads_loss_fwd")
+    return out4, seeds
+
+
+def heads_scale(x, s):
+    _lib.check(_lib.load().mmbert_heads_scale(_stream(), x.data_ptr(), x.numel(), s.data_ptr()), "mmbert_heads_scale")
+
+
+def heads_gate_bwd(dC, P, Apre, g, vws, dPc, B, gvws, gvbs):
+    H = P.shape[1]
+    dP = torch.empty_like(P)
+    dA = torch.empty_like(P)
+    _lib.check(_lib.load().mmbert_heads_gate_bwd(_stream(), dC.data_ptr(), P.data_ptr(), Apre.data_ptr(), g.data_ptr(), _ptr3(vws), dPc.data_ptr(), B, H,
+                                                 dP.data_ptr(), dA.data_ptr(), _ptr3(gvws), _ptr3(gvbs)), "mmbert_heads_gate_bwd")
+    return dP, dA
+
+
+def heads_tanh_bwd(dP, P):
+    dpre = torch.empty_like(P)
+    _lib.check(_lib.load().mmbert_heads_tanh_bwd(_stream(), dP.data_ptr(), P.data_ptr(), dpre.data_ptr(), P.numel()), "mmbert_heads_tanh_bwd")
+    return dpre
+
+
+def heads_colsum(pairs):
+    """pairs: list of (src [rows, cols] fp32 with unit column stride, dst [cols] fp32): dst += column sums, one launch."""
+    n = len(pairs)
+    PA, IA = _PtrArr[n], _IntArr[n]
+    _lib.check(_lib.load().mmbert_heads_colsum(_stream(), n, PA(*[s.data_ptr() for s, _ in pairs]), PA(*[d.data_ptr() for _, d in pairs]),
+                                               IA(*[s.shape[0] for s, _ in pairs]), IA(*[s.shape[1] for s, _ in pairs]),
+                                               IA(*[s.stride(0) for s, _ in pairs])), "mmbert_heads_colsum")

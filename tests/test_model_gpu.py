@@ -186,6 +186,37 @@ def test_sparse_mlm_backward_equals_dense_backward():
     assert 0 < n_act < sum(x.numel() for x in lab) // 2          # the sparse path was really taken
 
 
+@pytest.mark.parametrize("num_labels", [7, 1])
+def test_fused_heads_equal_eager_heads(num_labels):
+    """_HeadsFn (hand-written backward, csrc/heads.hip) against the eager autograd form of the same arithmetic (_heads):
+    losses, returned scores and EVERY parameter gradient (fp32 on both sides: 1e-4 relative to the largest entry)."""
+    batch = batch_to(synthetic_batch(4, 50, 64, 64, seed=9), DEV)
+    res = []
+    for fused in (True, False):
+        m = build(CFG1)
+        m.num_labels = num_labels
+        m.fused_heads = fused
+        m.set_alpha_beta(0.7, 1.3)
+        out, logits_out = m(**batch)
+        out[0].mean().backward()
+        torch.cuda.synchronize()
+        res.append((out, logits_out, {n: q.grad.float().clone() for n, q in m.named_parameters()}))
+    (o1, l1, g1), (o2, l2, g2) = res
+    for i in (0, 4, 5, 6):
+        assert rel(o1[i], o2[i]) < 1e-5, (i, float(o1[i]), float(o2[i]))
+    for i in (8, 10, 12):
+        assert float((o1[i] - o2[i]).abs().max()) < 1e-5
+    assert float((l1 - l2).abs().max()) < 1e-5
+    for n in g1:
+        if "attention.self.key.bias" in n:                  # true gradient 0: both sides hold rounding noise
+            continue
+        scale = float(g2[n].abs().max()) + 1e-12
+        err = float((g1[n] - g2[n]).abs().max())
+        # 3e-7 absolute: the CPC / classifier gradients at initialisation are differences of nearly equal 1e-3-sized terms
+        # (norm ~1e-6, see DESIGN numerics): their last digits depend on the summation order on BOTH sides
+        assert err <= 1e-4 * scale + 3e-7, f"{n}: err {err:.3e} scale {scale:.3e}"
+
+
 def test_submodule_api_matches_oracle():
     """MMBertModel.forward(joint) / JointEmbeddings.forward / heads via the reference's call sites."""
     cfg = CFG1

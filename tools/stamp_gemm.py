@@ -19,7 +19,7 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffast-math", "
 if "--build" in sys.argv:
     os.makedirs(OUT, exist_ok=True)
     objs = []
-    for f in ("gemm", "attention", "rowwise"):
+    for f in ("gemm", "attention", "rowwise", "heads"):
         o = os.path.join(OUT, f + ".o")
         subprocess.check_call(["/opt/rocm/bin/hipcc", *FLAGS, "-DMMB_STAMPS", "-c", os.path.join(ROOT, "msa_amd", "csrc", f + ".hip"), "-o", o])
         objs.append(o)
