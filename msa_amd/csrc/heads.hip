@@ -37,65 +37,95 @@ __global__ __launch_bounds__(256) void heads_gate_fwd_kernel(const float* __rest
     for (int k = threadIdx.x; k < H; k += 256) C[(size_t)b * 3 * H + (size_t)m * H + k] = P[(size_t)row * H + k] * gv;
 }
 
-// Losses and backward seeds (for an upstream gradient of 1; backward scales them).  grid = 3 (one workgroup per modality).
-//   out[0] ap_loss, out[1] label_loss, out[2] nce, out[3] heads_loss      (workgroup 0 writes 0, 1, 3 after the others' nce parts)
-//   seeds: dXP [3,B,H], dPc [3,B,H] (the CPC part of dP), dlo [B], drel [2B,2]
-// nce parts are written per modality to nce_part[3]; the host-visible sums are formed by heads_loss_finish_kernel.
+// CPC terms and their backward seeds (for an upstream gradient of 1; backward scales them).  grid = 3: one workgroup per
+// modality, everything for its [B,H] pair of arrays in LDS (rows padded by one float: column reads of different rows hit
+// different banks), B <= 16, H <= 1024, 256 threads.
+//   nce_part[m] = mean_b (logsumexp_b' S[b][b'] - S[b][b]),  S = Xn XPn^T,  Xn = P_m/|.|, XPn = XP_m/|.|
+//   dS[b][b'] = (-beta/B) (softmax_b'(S[b])[b'] - delta);  dXn = dS XPn, dXPn = dS^T Xn;  through y = x/|x|: dx = (dy - y<y,dy>)/|x|
+//   dPc [3,B,H] = d loss / d P (CPC part), dXP [3,B,H] = d loss / d XP
 __global__ __launch_bounds__(256) void heads_loss_fwd_kernel(const float* __restrict__ P, const float* __restrict__ XP, int B, int H, float beta,
                                                              float* __restrict__ dXP, float* __restrict__ dPc, float* __restrict__ nce_part) {
-    extern __shared__ float sm[];                       // Xn [B][H] | XPn [B][H] | S [B][B] | n1 [B] | n2 [B]
-    __shared__ float red[4];
-    const int m = blockIdx.x, tid = threadIdx.x;
-    float* Xn = sm; float* XPn = sm + (size_t)B * H; float* S = XPn + (size_t)B * H; float* n1 = S + B * B; float* n2 = n1 + B;
+    extern __shared__ float sm[];                       // Xn [16][HP] | XPn [16][HP] | dS [16][16] | n1 [16] | n2 [16] | red [32][4]
+    const int HP = H + 1;
+    const int m = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    float* Xn = sm; float* XPn = sm + 16 * HP; float* dS = XPn + 16 * HP; float* n1 = dS + 256; float* n2 = n1 + 16; float* red = n2 + 16;
     const float* Pm = P + (size_t)m * B * H; const float* XPm = XP + (size_t)m * B * H;
-    for (int b = 0; b < B; ++b) {
-        float a = 0.f, c = 0.f;
-        for (int k = tid; k < H; k += 256) { const float x = Pm[(size_t)b * H + k], y = XPm[(size_t)b * H + k]; a += x * x; c += y * y; }
-        a = block_sum_256(a, red); c = block_sum_256(c, red);
-        if (tid == 0) { n2[b] = sqrtf(a); n1[b] = sqrtf(c); }
+    const int r = tid >> 4, q = tid & 15;               // 16 threads per row
+    // rows into LDS + norms (16-lane shuffles: a row's 16 threads sit in one wave)
+    float sa = 0.f, sc = 0.f;
+    for (int k = q; k < H; k += 16) {
+        const float x = r < B ? Pm[(size_t)r * H + k] : 0.f, y = r < B ? XPm[(size_t)r * H + k] : 0.f;
+        Xn[r * HP + k] = x; XPn[r * HP + k] = y;
+        sa += x * x; sc += y * y;
     }
+#pragma unroll
+    for (int o = 8; o >= 1; o >>= 1) { sa += __shfl_xor(sa, o, 64); sc += __shfl_xor(sc, o, 64); }
+    const float nx = sqrtf(sa), ny = sqrtf(sc);
+    if (q == 0) { n2[r] = nx; n1[r] = ny; }
+    const float ix = r < B ? 1.f / nx : 0.f, iy = r < B ? 1.f / ny : 0.f;
+    for (int k = q; k < H; k += 16) { Xn[r * HP + k] *= ix; XPn[r * HP + k] *= iy; }
     __syncthreads();
-    for (int e = tid; e < B * H; e += 256) { const int b = e / H; Xn[e] = Pm[e] / n2[b]; XPn[e] = XPm[e] / n1[b]; }
+    // S[b = r][c = q]
+    float sv = 0.f;
+    for (int k = 0; k < H; ++k) sv += Xn[r * HP + k] * XPn[q * HP + k];
+    const bool valid = r < B && q < B;
+    float mx = valid ? sv : -INFINITY;
+#pragma unroll
+    for (int o = 8; o >= 1; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    float e = valid ? expf(sv - mx) : 0.f, se = e;
+#pragma unroll
+    for (int o = 8; o >= 1; o >>= 1) se += __shfl_xor(se, o, 64);
+    const float neg = mx + logf(se);
+    const float w = -beta / (float)B;
+    dS[r * 16 + q] = valid ? w * (e / se - (q == r ? 1.f : 0.f)) : 0.f;
+    float part = (valid && q == r) ? (neg - sv) / (float)B : 0.f;
+    part = wave_sum(part);
+    if (lane == 0) red[wv] = part;
     __syncthreads();
-    for (int e = tid; e < B * B; e += 256) {            // S[b][b'] = <Xn[b], XPn[b']>
-        const int b = e / B, c = e - b * B;
-        float s = 0.f;
-        for (int k = 0; k < H; ++k) s += Xn[(size_t)b * H + k] * XPn[(size_t)c * H + k];
-        S[e] = s;
-    }
+    if (tid == 0) nce_part[m] = red[0] + red[1] + red[2] + red[3];
     __syncthreads();
-    // per row b: neg = logsumexp_b' S[b][b'], pos = S[b][b]; dS_eff[b][b'] = w * (softmax[b][b'] - delta), w = -beta / B (upstream 1)
-    float part = 0.f;
-    if (tid < B) {
-        const int b = tid;
-        float mx = -INFINITY;
-        for (int c = 0; c < B; ++c) mx = fmaxf(mx, S[b * B + c]);
-        float se = 0.f;
-        for (int c = 0; c < B; ++c) se += expf(S[b * B + c] - mx);
-        const float neg = mx + logf(se), pos = S[b * B + b];
-        part = (neg - pos) / (float)B;
-        const float w = -beta / (float)B;
-        for (int c = 0; c < B; ++c) S[b * B + c] = w * (expf(S[b * B + c] - neg) - (c == b ? 1.f : 0.f));
-    }
-    part = block_sum_256(part, red);
-    if (tid == 0) nce_part[m] = part;
-    __syncthreads();
-    // dXn[b] = sum_b' dS[b][b'] XPn[b'];  dXPn[b'] = sum_b dS[b][b'] Xn[b];  then through y = x/|x|: dx = (dy - y <y, dy>) / |x|
-    for (int b = 0; b < B; ++b) {
-        float dotx = 0.f, doty = 0.f;
-        float dxn[4], dyn[4];                           // H <= 1024: up to 4 columns per thread
-        int q = 0;
-        for (int k = tid; k < H; k += 256, ++q) {
-            float a = 0.f, c = 0.f;
-            for (int j = 0; j < B; ++j) { a += S[b * B + j] * XPn[(size_t)j * H + k]; c += S[j * B + b] * Xn[(size_t)j * H + k]; }
-            dxn[q] = a; dyn[q] = c;
-            dotx += a * Xn[(size_t)b * H + k]; doty += c * XPn[(size_t)b * H + k];
+    // gradients: thread owns columns k = tid + 256 i
+    float av[4][16], cv[4][16], dx[16], dy[16];
+#pragma unroll
+    for (int b = 0; b < 16; ++b) { dx[b] = 0.f; dy[b] = 0.f; }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int k = tid + 256 * i;
+        if (k < H) {
+            float x[16], y[16];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) { x[j] = Xn[j * HP + k]; y[j] = XPn[j * HP + k]; }
+#pragma unroll
+            for (int b = 0; b < 16; ++b) {
+                float a = 0.f, c = 0.f;
+#pragma unroll
+                for (int j = 0; j < 16; ++j) { a += dS[b * 16 + j] * y[j]; c += dS[j * 16 + b] * x[j]; }
+                av[i][b] = a; cv[i][b] = c;
+                dx[b] += a * x[b]; dy[b] += c * y[b];
+            }
         }
-        dotx = block_sum_256(dotx, red); doty = block_sum_256(doty, red);
-        q = 0;
-        for (int k = tid; k < H; k += 256, ++q) {
-            dPc[((size_t)m * B + b) * H + k] = (dxn[q] - Xn[(size_t)b * H + k] * dotx) / n2[b];
-            dXP[((size_t)m * B + b) * H + k] = (dyn[q] - XPn[(size_t)b * H + k] * doty) / n1[b];
+    }
+    // <y, dy> per row: 32 block-wide sums (wave shuffles, then 4 partials each through LDS)
+    __syncthreads();
+#pragma unroll
+    for (int b = 0; b < 16; ++b) {
+        const float u = wave_sum(dx[b]), v = wave_sum(dy[b]);
+        if (lane == 0) { red[b * 4 + wv] = u; red[(16 + b) * 4 + wv] = v; }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int k = tid + 256 * i;
+        if (k < H) {
+#pragma unroll
+            for (int b = 0; b < 16; ++b) {
+                if (b < B) {
+                    const float dotx = red[b * 4] + red[b * 4 + 1] + red[b * 4 + 2] + red[b * 4 + 3];
+                    const float doty = red[(16 + b) * 4] + red[(16 + b) * 4 + 1] + red[(16 + b) * 4 + 2] + red[(16 + b) * 4 + 3];
+                    dPc[((size_t)m * B + b) * H + k] = (av[i][b] - Xn[b * HP + k] * dotx) / n2[b];
+                    dXP[((size_t)m * B + b) * H + k] = (cv[i][b] - XPn[b * HP + k] * doty) / n1[b];
+                }
+            }
         }
     }
 }
@@ -138,39 +168,29 @@ __global__ void heads_scale_kernel(float* __restrict__ x, size_t n, const float*
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) x[i] *= f;
 }
 
-// gate backward; one workgroup per modality, rows in turn (deterministic sums over b).
-//   dC [B,3H], P, Apre [3B,H], g [3B], vw [3,H], dPc [3B,H] (CPC part)  ->
-//   dP [3B,H] = dC_m * g + dPc;  dApre [3B,H] = dg * v_m * (Apre > 0), dg[m,b] = <dC[b, mH:], P[m,b]>;
-//   gvw[m] += sum_b dg * relu(Apre[m,b]);  gvb[m] += sum_b dg
+// gate backward; one workgroup per (m, b) row:
+//   dC [B,3H], P, Apre [3B,H], g [3B], vw (3 pointers), dPc [3B,H] (CPC part)  ->
+//   dg[m,b] = <dC[b, mH:], P[m,b]>;  dP [3B,H] = dC_m * g + dPc;  dApre [3B,H] = dg * v_m * (Apre > 0);
+//   E [3B,H] = dg * relu(Apre)   (its column sums over b are the gradient of v_m: heads_colsum)
 __global__ __launch_bounds__(256) void heads_gate_bwd_kernel(const float* __restrict__ dC, const float* __restrict__ P, const float* __restrict__ Apre,
                                                              const float* __restrict__ g, const GateW w, const float* __restrict__ dPc,
-                                                             int B, int H, float* __restrict__ dP, float* __restrict__ dApre) {
+                                                             int B, int H, float* __restrict__ dP, float* __restrict__ dApre,
+                                                             float* __restrict__ E, float* __restrict__ dg_out) {
     __shared__ float red[4];
-    const int m = blockIdx.x, tid = threadIdx.x;
+    const int row = blockIdx.x, m = row / B, b = row - m * B, tid = threadIdx.x;
     const float* vw = m == 0 ? w.vw[0] : (m == 1 ? w.vw[1] : w.vw[2]);
-    float* gvw = m == 0 ? w.gvw[0] : (m == 1 ? w.gvw[1] : w.gvw[2]);
-    float* gvb = m == 0 ? w.gvb[0] : (m == 1 ? w.gvb[1] : w.gvb[2]);
-    float accv[4] = {0.f, 0.f, 0.f, 0.f};
-    float accb = 0.f;
-    for (int b = 0; b < B; ++b) {
-        const size_t row = (size_t)m * B + b;
-        const float* dc = dC + (size_t)b * 3 * H + (size_t)m * H;
-        float s = 0.f;
-        for (int k = tid; k < H; k += 256) s += dc[k] * P[row * H + k];
-        const float dg = block_sum_256(s, red);
-        const float gv = g[row];
-        int q = 0;
-        for (int k = tid; k < H; k += 256, ++q) {
-            dP[row * H + k] = dc[k] * gv + dPc[row * H + k];
-            const float a = Apre[row * H + k];
-            dApre[row * H + k] = a > 0.f ? dg * vw[k] : 0.f;
-            accv[q] += dg * fmaxf(a, 0.f);
-        }
-        accb += dg;
+    const float* dc = dC + (size_t)b * 3 * H + (size_t)m * H;
+    float s = 0.f;
+    for (int k = tid; k < H; k += 256) s += dc[k] * P[(size_t)row * H + k];
+    const float dg = block_sum_256(s, red);
+    const float gv = g[row];
+    if (tid == 0) dg_out[row] = dg;
+    for (int k = tid; k < H; k += 256) {
+        dP[(size_t)row * H + k] = dc[k] * gv + dPc[(size_t)row * H + k];
+        const float a = Apre[(size_t)row * H + k];
+        dApre[(size_t)row * H + k] = a > 0.f ? dg * vw[k] : 0.f;
+        E[(size_t)row * H + k] = dg * fmaxf(a, 0.f);
     }
-    int q = 0;
-    for (int k = tid; k < H; k += 256, ++q) gvw[k] += accv[q];
-    if (tid == 0) gvb[0] += accb;
 }
 
 // dpre = dP * (1 - P^2)
@@ -181,9 +201,9 @@ __global__ void heads_tanh_bwd_kernel(const float* __restrict__ dP, const float*
     }
 }
 
-// bias gradients: dst[c] += sum_r src[r][c] for up to 10 (src, rows, cols, dst) segments in one launch; grid.y = segment
+// bias (and gate-vector) gradients: dst[c] += sum_r src[r][c] for up to 16 (src, rows, cols, dst) segments in one launch; grid.y = segment
 struct ColsumSeg { const float* src; float* dst; int rows, cols, ld; };
-struct ColsumArgs { ColsumSeg s[10]; };
+struct ColsumArgs { ColsumSeg s[16]; };
 __global__ void heads_colsum_kernel(const ColsumArgs a) {
     const ColsumSeg s = a.s[blockIdx.y];
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
@@ -207,8 +227,8 @@ int mmbert_heads_gate_fwd(hipStream_t stream, const float* P, const float* Apre,
 int mmbert_heads_loss_fwd(hipStream_t stream, const float* P, const float* XP, const float* rel, const int64_t* ap, const float* lo, const float* sent,
                           int B, int H, float beta, int tanh_lo, float* out4, float* dXP, float* dPc, float* drel, float* dlo, float* nce_part) {
     if (B <= 0) return 0;
-    if (H > 1024 || B > 64) return -1;
-    const size_t lds = ((size_t)2 * B * H + (size_t)B * B + 2 * B) * sizeof(float);
+    if (H > 1024 || B > 16) return -1;
+    const size_t lds = ((size_t)2 * 16 * (H + 1) + 256 + 32 + 128) * sizeof(float);
     if (lds > 160 * 1024 - 256) return -1;                   // the kernel also has a few static LDS words
     static size_t attr_bytes = 0;
     if (lds > attr_bytes) {
@@ -231,12 +251,11 @@ int mmbert_heads_scale(hipStream_t stream, float* x, size_t n, const float* s) {
 }
 
 int mmbert_heads_gate_bwd(hipStream_t stream, const float* dC, const float* P, const float* Apre, const float* g, const float* const* vw3, const float* dPc,
-                          int B, int H, float* dP, float* dApre, float* const* gvw3, float* const* gvb3) {
+                          int B, int H, float* dP, float* dApre, float* E, float* dg) {
     if (B <= 0) return 0;
-    if (H > 1024) return -1;
     GateW w = {};
-    for (int i = 0; i < 3; ++i) { w.vw[i] = vw3[i]; w.gvw[i] = gvw3[i]; w.gvb[i] = gvb3[i]; }
-    hipLaunchKernelGGL(heads_gate_bwd_kernel, dim3(3), dim3(256), 0, stream, dC, P, Apre, g, w, dPc, B, H, dP, dApre);
+    for (int i = 0; i < 3; ++i) w.vw[i] = vw3[i];
+    hipLaunchKernelGGL(heads_gate_bwd_kernel, dim3(3 * B), dim3(256), 0, stream, dC, P, Apre, g, w, dPc, B, H, dP, dApre, E, dg);
     MMB_CHECK_LAUNCH();
     return 0;
 }
@@ -248,10 +267,10 @@ int mmbert_heads_tanh_bwd(hipStream_t stream, const float* dP, const float* P, f
     return 0;
 }
 
-// nseg <= 10 segments: dst_i[c] += column sums of src_i [rows_i, cols_i] (row pitch ld_i)
+// nseg <= 16 segments: dst_i[c] += column sums of src_i [rows_i, cols_i] (row pitch ld_i)
 int mmbert_heads_colsum(hipStream_t stream, int nseg, const float* const* src, float* const* dst, const int* rows, const int* cols, const int* ld) {
     if (nseg <= 0) return 0;
-    if (nseg > 10) return -1;
+    if (nseg > 16) return -1;
     ColsumArgs a;
     int maxc = 0;
     for (int i = 0; i < nseg; ++i) { a.s[i].src = src[i]; a.s[i].dst = dst[i]; a.s[i].rows = rows[i]; a.s[i].cols = cols[i]; a.s[i].ld = ld[i]; if (cols[i] > maxc) maxc = cols[i]; }

@@ -706,7 +706,7 @@ class _HeadsFn(torch.autograd.Function):
         c2.weight.grad.addmm_(dlo.t(), T)
         dC = torch.mm(dT, c1.weight)
         c1.weight.grad.addmm_(dT.t(), Cc)
-        dP, dA = ops.heads_gate_bwd(dC, P, Apre, g, [v.weight for v in vs3], dPc, B, [v.weight.grad for v in vs3], [v.bias.grad for v in vs3])
+        dP, dA, E, dg = ops.heads_gate_bwd(dC, P, Apre, g, [v.weight for v in vs3], dPc, B)
         dP.addmm_(dA, at.weight[:, :H])
         dP.addmm_(dA, at.weight[:, H:])
         at.weight.grad[:, :H].addmm_(dA.t(), P)
@@ -716,8 +716,10 @@ class _HeadsFn(torch.autograd.Function):
         dfirst[B:].addmm_(drel, al.weight)
         pool.weight.grad.addmm_(dpre.t(), first)
         al.weight.grad.addmm_(drel.t(), first[B:])
+        E3, dg3 = E.view(3, B, H), dg.view(3, B, 1)
         ops.heads_colsum([(dXP[0], qs[0].bias.grad), (dXP[1], qs[1].bias.grad), (dXP[2], qs[2].bias.grad), (dT, c1.bias.grad),
-                          (dlo, c2.bias.grad), (dA, at.bias.grad), (dpre, pool.bias.grad), (drel, al.bias.grad)])
+                          (dlo, c2.bias.grad), (dA, at.bias.grad), (dpre, pool.bias.grad), (drel, al.bias.grad)]
+                         + [(E3[m], vs3[m].weight.grad) for m in range(3)] + [(dg3[m], vs3[m].bias.grad) for m in range(3)])
         return dfirst, None, None, None
 
 

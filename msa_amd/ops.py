@@ -121,8 +121,8 @@ def gemm_tn(A, B, W, *, accumulate=True, alpha=1.0, alpha_dev=None, bias_out=Non
     return W
 
 
-_PtrArr = {n: (ctypes.c_void_p * n) for n in range(1, 11)}
-_IntArr = {n: (ctypes.c_int * n) for n in range(1, 11)}
+_PtrArr = {n: (ctypes.c_void_p * n) for n in range(1, 17)}
+_IntArr = {n: (ctypes.c_int * n) for n in range(1, 17)}
 
 
 def gemm_tn_grouped(problems, *, accumulate=True, alpha=1.0):
@@ -423,13 +423,14 @@ def heads_scale(x, s):
     _lib.check(_lib.load().mmbert_heads_scale(_stream(), x.data_ptr(), x.numel(), s.data_ptr()), "mmbert_heads_scale")
 
 
-def heads_gate_bwd(dC, P, Apre, g, vws, dPc, B, gvws, gvbs):
+def heads_gate_bwd(dC, P, Apre, g, vws, dPc, B):
+    """returns dP, dApre, E (= dg * relu(Apre)) [3B,H] and dg [3B]."""
     H = P.shape[1]
-    dP = torch.empty_like(P)
-    dA = torch.empty_like(P)
+    dP, dA, E = torch.empty_like(P), torch.empty_like(P), torch.empty_like(P)
+    dg = torch.empty(3 * B, device=P.device, dtype=torch.float32)
     _lib.check(_lib.load().mmbert_heads_gate_bwd(_stream(), dC.data_ptr(), P.data_ptr(), Apre.data_ptr(), g.data_ptr(), _ptr3(vws), dPc.data_ptr(), B, H,
-                                                 dP.data_ptr(), dA.data_ptr(), _ptr3(gvws), _ptr3(gvbs)), "mmbert_heads_gate_bwd")
-    return dP, dA
+                                                 dP.data_ptr(), dA.data_ptr(), E.data_ptr(), dg.data_ptr()), "mmbert_heads_gate_bwd")
+    return dP, dA, E, dg
 
 
 def heads_tanh_bwd(dP, P):
