@@ -167,3 +167,137 @@ def build_optimizer(model, args, num_train_optimization_steps, mode="hf"):
     sched = get_linear_schedule_with_warmup(opt, num_warmup_steps=num_train_optimization_steps,
                                             num_training_steps=args.warmup_proportion * num_train_optimization_steps)
     return opt, sched
+
+
+# ================================================================================================
+# evaluation, metrics, epoch loop (REF:trainer.py:103-290)
+# ================================================================================================
+def eval_epoch(args, model, valdata, tokenizer=None, *, device="cuda", generator=None, batches=None):
+    """REF:trainer.py:103-199.  The model in eval mode under ``no_grad``; MLM masking is applied at evaluation too
+    when ``args.mlm`` (the reference does); shuffled order (RandomSampler) like the reference.  Returns its 8-tuple
+    (dev_loss, text_loss, visual_loss, speech_loss, ap_loss, label_loss, preds, labels), every loss divided by the number
+    of steps -- ``text/visual/speech_loss`` are 0 because the model returns ``None`` for them, and ``ap_loss`` is the LAST
+    step's value divided by the number of steps (REF:trainer.py:199 divides the loop variable, not a sum)."""
+    import numpy as np
+    if batches is None:
+        from torch.utils.data import DataLoader, RandomSampler
+        loader = DataLoader(valdata, sampler=RandomSampler(valdata), batch_size=args.val_batch_size, collate_fn=collate)
+        batches = (pack_step_inputs(b, args, device, generator) for b in loader)
+    model.eval()
+    dev_loss = torch.zeros((), device=device)
+    label_loss = torch.zeros((), device=device)
+    ap_loss = torch.zeros((), device=device)
+    preds, labels = [], []
+    n = 0
+    with torch.no_grad():
+        for kwargs in batches:
+            outputs, logits = model(**kwargs)
+            dev_loss += outputs[0].mean()
+            label_loss += outputs[5].mean()
+            ap_loss = outputs[4]
+            preds.append(logits.detach().float())
+            labels.append(kwargs["sentiment"].detach())
+            n += 1
+    if n == 0:
+        return (0.0,) * 6 + (np.zeros((0,)), np.zeros((0,)))
+    preds = torch.cat(preds).cpu().numpy()                          # one device->host transfer per epoch, not per step
+    labels = torch.cat(labels).cpu().numpy()
+    return (float(dev_loss) / n, 0.0, 0.0, 0.0, float(ap_loss) / n, float(label_loss) / n, preds, labels)
+
+
+def _weighted_f1(y_true, y_pred):
+    """F1 per class weighted by the class's support in ``y_true`` (sklearn ``f1_score(average="weighted")``)."""
+    import numpy as np
+    y_true, y_pred = np.asarray(y_true).reshape(-1), np.asarray(y_pred).reshape(-1)
+    total, score = y_true.size, 0.0
+    for c in np.unique(np.concatenate((y_true, y_pred))):
+        tp = float(np.sum((y_pred == c) & (y_true == c)))
+        fp = float(np.sum((y_pred == c) & (y_true != c)))
+        fn = float(np.sum((y_pred != c) & (y_true == c)))
+        f1 = 2 * tp / (2 * tp + fp + fn) if (2 * tp + fp + fn) > 0 else 0.0
+        score += f1 * float(np.sum(y_true == c)) / max(total, 1)
+    return score
+
+
+def test_CE_score_model(preds, y_test):
+    """REF:trainer.py:201-215 (classification heads): (accuracy, mean absolute error, weighted F1) of class predictions."""
+    import numpy as np
+    preds, y_test = np.asarray(preds), np.asarray(y_test)
+    mae = float(np.mean(np.absolute(preds - y_test)))
+    return float(np.mean(preds.reshape(-1) == y_test.reshape(-1))), mae, _weighted_f1(y_test, preds)
+
+
+def test_MSE_score_model(preds, y_test, use_zero=False):
+    """REF:trainer.py:217-228 (regression heads, num_labels 1 / 7): MAE of the raw scores, then accuracy and weighted F1 of
+    the sign (>= 0) -- note the broadcasting of the reference: ``preds`` is [N,1], ``y_test`` [N], so its MAE is the mean over
+    the [N,N] difference table; kept (callers compare epochs with it), documented here."""
+    import numpy as np
+    preds, y_test = np.asarray(preds), np.asarray(y_test)
+    mae = float(np.mean(np.absolute(preds - y_test)))
+    p, y = (preds >= 0), (y_test >= 0)
+    if p.ndim == 2 and y.ndim == 1:                                  # sklearn flattens a [N,1] prediction column
+        p = p.reshape(-1)
+    return float(np.mean(p == y)), mae, _weighted_f1(y, p)
+
+test_CE_score_model.__test__ = False                                # names start with "test_": not pytest cases
+test_MSE_score_model.__test__ = False
+
+
+def make_date_dir(path):
+    """REF:utils.py:35-50: ``path/<YYYYMMDD>-NN`` with the first unused NN, created."""
+    import datetime
+    import os
+    os.makedirs(path, exist_ok=True)
+    stamp = datetime.datetime.now().strftime("%Y%m%d")
+    i = 0
+    while os.path.exists(os.path.join(path, f"{stamp}-{i:02d}")):
+        i += 1
+    out = os.path.join(path, f"{stamp}-{i:02d}")
+    os.mkdir(out)
+    return out
+
+
+def train(args, model, train_dataset, val_dataset, test_dataset, optimizer, scheduler, tokenizer=None, logger=None, *, device="cuda",
+          dp=None, save_root="./model_save", numpy_root="./numpy_save", patience_limit=25, epoch_batches=None):
+    """REF:trainer.py:230-290: per epoch train -> validate -> test; the state dict is saved (``model_<epoch>.pt``, the
+    reference's checkpoint format = its state-dict keys) whenever the TEST accuracy improves; after ``patience_limit`` epochs
+    without improvement the best predictions / targets go to ``predict.npy`` / ``target.npy`` and the loop stops.
+    ``epoch_batches``: optional callable ``(split, epoch) -> iterable of model kwargs`` replacing the datasets (synthetic data).
+    Returns a dict with the best epoch's numbers and the per-epoch history."""
+    import os
+    import numpy as np
+    log = logger.info if logger is not None else (lambda *a, **k: None)
+    save_dir = make_date_dir(save_root)
+    log("Model save path: {}".format(save_dir))
+    score = test_MSE_score_model if getattr(args, "num_labels", 7) in (1, 7) else test_CE_score_model
+    best = dict(epoch=-1, acc=0.0, loss=float("inf"), mae=None, f_score=None, preds=None, labels=None, path=None)
+    history = []
+    patience = 0
+    rank0 = dp is None or torch.distributed.get_rank() == 0
+    for epoch in range(int(args.n_epochs)):
+        patience += 1
+        tb = epoch_batches("train", epoch) if epoch_batches else None
+        tr = train_epoch(args, model, train_dataset, optimizer, scheduler, tokenizer, device=device, dp=dp, batches=tb)
+        log("[Train Epoch {}] Joint Loss : {} AP Loss : {} Label Loss : {}".format(epoch + 1, tr[0], tr[4], tr[5]))
+        va = eval_epoch(args, model, val_dataset, tokenizer, device=device, batches=epoch_batches("val", epoch) if epoch_batches else None)
+        log("[Val Epoch {}] Joint Loss : {} AP Loss : {} Label Loss : {}".format(epoch + 1, va[0], va[4], va[5]))
+        te = eval_epoch(args, model, test_dataset, tokenizer, device=device, batches=epoch_batches("test", epoch) if epoch_batches else None)
+        acc, mae, f_score = score(te[6], te[7])
+        log("[Epoch {}] Test_ACC : {}, Test_MAE : {}, Test_F_Score: {}".format(epoch + 1, acc, mae, f_score))
+        history.append(dict(epoch=epoch + 1, train_loss=tr[0], valid_loss=va[0], test_acc=acc, test_mae=mae, test_f_score=f_score))
+        if acc > best["acc"]:
+            path = os.path.join(save_dir, "model_" + str(epoch + 1) + ".pt")
+            if rank0:
+                torch.save(model.state_dict(), path)
+            best.update(epoch=epoch, acc=acc, loss=va[0], mae=mae, f_score=f_score, preds=te[6], labels=te[7], path=path)
+            patience = 0
+        if patience == patience_limit:
+            if rank0 and best["preds"] is not None:
+                out = make_date_dir(numpy_root)
+                np.save(os.path.join(out, "predict.npy"), best["preds"])
+                np.save(os.path.join(out, "target.npy"), best["labels"])
+            break
+    log("[Best Epoch {}] Best_ACC : {}, Best_MAE : {}, Best_F_Score: {}".format(best["epoch"] + 1, best["acc"], best["mae"], best["f_score"]))
+    best["history"] = history
+    best["save_dir"] = save_dir
+    return best

@@ -129,3 +129,29 @@ def test_grad_bucketer_world2_gloo():
         assert p.exitcode == 0
     assert res["sum_ok"] and res["nosync_ok"] and res["order_checked"]
     assert res["calls"] == 2, res          # slices merged into >=300-element buckets: [0,350) and [350,900); tail in finish()
+
+
+def test_score_functions_match_their_definitions():
+    """REF:trainer.py:201-228 restated: accuracy / MAE / support-weighted F1 (checked against scikit-learn when present)."""
+    rng = np.random.default_rng(0)
+    p, y = rng.integers(0, 5, 200), rng.integers(0, 5, 200)
+    acc, mae, f1 = T.test_CE_score_model(p, y)
+    assert abs(acc - float(np.mean(p == y))) < 1e-12 and abs(mae - float(np.mean(np.abs(p - y)))) < 1e-12
+    pr, yr = rng.normal(size=(50, 1)), rng.normal(size=50)
+    acc2, mae2, f12 = T.test_MSE_score_model(pr, yr)
+    assert abs(acc2 - float(np.mean((pr.reshape(-1) >= 0) == (yr >= 0)))) < 1e-12
+    assert abs(mae2 - float(np.mean(np.abs(pr - yr)))) < 1e-12          # the reference's [N,1] - [N] broadcast, kept
+    try:
+        from sklearn.metrics import f1_score
+    except Exception:
+        return
+    assert abs(f1 - f1_score(y, p, average="weighted")) < 1e-12
+    assert abs(f12 - f1_score(yr >= 0, pr.reshape(-1) >= 0, average="weighted")) < 1e-12
+    # hand-checked tiny case: classes {0,1}; y = 0,0,1,1  p = 0,1,1,1 -> F1(0) = 2/3 (support 2), F1(1) = 4/5 (support 2)
+    assert abs(T._weighted_f1([0, 0, 1, 1], [0, 1, 1, 1]) - (2 / 3 + 4 / 5) / 2) < 1e-12
+
+
+def test_make_date_dir_counts_up(tmp_path):
+    a = T.make_date_dir(str(tmp_path / "model_save"))
+    b = T.make_date_dir(str(tmp_path / "model_save"))
+    assert a != b and os.path.isdir(a) and os.path.isdir(b) and a.endswith("-00") and b.endswith("-01")

@@ -156,3 +156,35 @@ def test_data_parallel_two_ranks_equals_mean_of_single_rank_grads():
     got, ref = res["grads"], total.cpu()
     err = float((got - ref).norm() / ref.norm())
     assert err < 2e-3, err               # same kernels, same data: only fp32 atomic-order noise
+
+
+def test_eval_epoch_and_train_loop_save_rule(tmp_path):
+    """eval_epoch (no_grad, MLM masking at eval, the reference's 8-tuple), the epoch loop's
+    best-on-test-accuracy checkpoint (a state dict with the reference's keys that loads back) and the early stop."""
+    from msa_amd import trainer as T
+    from msa_amd.trainer import build_optimizer, default_args
+    m = build(dropout=0.1)
+    m.manual_seed(3)
+    args = default_args(train_batch_size=4, val_batch_size=4, learning_rate=1e-3, n_epochs=4, num_labels=7)
+    opt, sched = build_optimizer(m, args, num_train_optimization_steps=16)
+
+    def batches(split, epoch):
+        base = {"train": 100, "val": 200, "test": 300}[split]
+        return [batch_to(synthetic_batch(4, 50, 50, 50, vocab=CFG["vocab"], seed=base + i), DEV) for i in range(2)]
+
+    ev = T.eval_epoch(args, m, None, batches=batches("val", 0))
+    assert len(ev) == 8 and np.isfinite(ev[0]) and ev[1] == ev[2] == ev[3] == 0.0 and ev[6].shape == (8, 1) and ev[7].shape == (8,)
+    assert not m.training
+    before = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    best = T.train(args, m, None, None, None, opt, sched, epoch_batches=batches, save_root=str(tmp_path / "model_save"),
+                   numpy_root=str(tmp_path / "numpy_save"), patience_limit=2)
+    assert len(best["history"]) >= 1 and all(np.isfinite(h["train_loss"]) and np.isfinite(h["valid_loss"]) for h in best["history"])
+    assert any(float((m.state_dict()[k].float() - before[k].float()).abs().max()) > 0 for k in before)        # it trained
+    if best["path"] is not None:
+        sd = torch.load(best["path"], map_location="cpu")
+        assert set(sd.keys()) == set(m.state_dict().keys())
+        m2 = build()
+        m2.load_state_dict(sd)
+    if len(best["history"]) < int(args.n_epochs):                    # stopped early: the prediction dump exists
+        dumps = list((tmp_path / "numpy_save").glob("*/predict.npy"))
+        assert len(dumps) == 1
