@@ -431,11 +431,17 @@ static int device_cus() {
 // epilogue with nothing in flight.  Here one workgroup per CU walks tiles v = b, b + G, b + 2G, ...; the
 // stages of ALL its tiles form one stream through the 4-slot ring (stream stage g sits in slot g & 3, is
 // issued at step g - 4), so the first four stages of the next tile are issued by the last four K steps of the
-// current one and land under its epilogue.  The epilogue works in a fifth 32 KiB LDS region (160 KiB in all):
-// per wave 16 rows x 64 fp32 at a time through inline-asm ds_write/ds_read (hipcc drains vmcnt(0) in front
-// of a plain LDS access while LDS-DMA is in flight), residual / GELU-input rows prefetched into the dead
-// fragment registers before the first block is transposed, 16 consecutive columns per lane -> 2 x 16-byte
-// global accesses per array.
+// current one and land under its epilogue.
+// Epilogue: straight from the accumulators.  The MFMA runs with the operands swapped (B fragment first), so a lane holds
+// 4 consecutive COLUMNS of one output row per 16x16 block, and the B fragment rows are read in a permuted order (b_rd) so
+// that the four column blocks of a wave give each lane 2 x 8 consecutive columns: 16-byte stores, 64 B contiguous per row
+// and instruction, no LDS transposition (the round-1 form went through a fifth 32 KiB LDS region: +2 k clk per tile).
+// What the epilogue costs is vector-memory ISSUE, like the K loop: ~47 clk per 1 KiB store instruction per CU (stores
+// switched off in the stamped build: vocabulary GEMM 1083 -> 886 us), plus, for GELU / GELU' / dropout, VALU work
+// (common.h: single-transcendental GELU forms).  Anything the epilogue LOADS into registers returns only after the next
+// tile's 16 stage loads issued ahead of it (in-order retirement, ~5 k clk): the bias row therefore arrives by a small
+// LDS-DMA issued in K step 3 and is read with DS instructions; scale, bias and the dropout decision are applied in place
+// to all accumulators (phase 1) before the first residual / GELU-input row is consumed (phase 2).
 // vmcnt bookkeeping across a tile boundary: vector memory operations retire in issue order, and the
 // epilogue's loads and stores are issued BEHIND the next tile's stages 0-3.  Waiting for stage 0 therefore
 // allows 12 + E outstanding operations and the first three K steps allow 8 + E, E = a LOWER bound of the
@@ -444,10 +450,6 @@ static int device_cus() {
 // -------------------------------------------------------------------------------------------------
 __host__ __device__ constexpr int mmb_waitcnt(int vm, int lgkm) { return (vm & 15) | ((vm >> 4) << 14) | 0x70 | (lgkm << 8); }
 
-template <int OFF>
-__device__ __forceinline__ void lds_write16(uint32_t lds_addr, const f32x4& v) {
-    asm volatile("ds_write_b128 %0, %1 offset:%2\n\ts_nop 1" :: "v"(lds_addr), "v"(v), "i"(OFF) : "memory");
-}
 template <int OFF>
 __device__ __forceinline__ void lds_read16f(f32x4& dst, uint32_t lds_addr) {
     asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(lds_addr), "i"(OFF) : "memory");
@@ -470,7 +472,7 @@ __global__ __launch_bounds__(512, 2) void gemm_ntp_kernel(const GemmNT p) {
 #if __HIP_DEVICE_COMPILE__   // the host pass only needs the launch stub (the body uses device-only builtins)
     constexpr int BM = 32 * MI;
     constexpr int EST = MI * ((EPI & EPI_OUT_F32) ? 4 : 2) * ((EPI & EPI_GELU) ? 2 : 1);   // stores per wave per interior tile
-    extern __shared__ __attribute__((aligned(16))) char smem[];   // 4 slots x [A 16K | B 16K] | 8 x 4 KiB epilogue scratch
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // 4 slots x [A 16K | B 16K] | tile-queue word | 8 x 256 B bias rows
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 2, wc = wave & 3;
@@ -491,8 +493,11 @@ __global__ __launch_bounds__(512, 2) void gemm_ntp_kernel(const GemmNT p) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int r = wave * 32 + i * 16 + srow;
+            // B rows are read in the permuted order of b_rd below (a fragment's 16 lanes read rows 8(fr>>2) + (fr&3) + const),
+            // so their chunk swizzle is keyed on row bits 3-4 instead of 2-3
+            const uint32_t schunk_b = (l & 3) ^ ((GT >> (2 * ((2 * i + (srow >> 3)) & 3))) & 3);
             o.a[i] = ((uint32_t)min(tm0 + r, p.M - 1) * (uint32_t)p.lda + schunk * 8u) * 2u;
-            o.b[i] = ((uint32_t)min(tn0 + r, p.N - 1) * (uint32_t)p.ldb + schunk * 8u) * 2u;
+            o.b[i] = ((uint32_t)min(tn0 + r, p.N - 1) * (uint32_t)p.ldb + schunk_b * 8u) * 2u;
 #ifdef MMB_STAMPS
             if (g_nt_dbg & 32) {
                 const int r8 = wave * 32 + i * 8 + (l >> 3);
@@ -531,7 +536,13 @@ __global__ __launch_bounds__(512, 2) void gemm_ntp_kernel(const GemmNT p) {
     typedef const __attribute__((address_space(3))) char* lds_cptr;
     typedef const __attribute__((address_space(3))) bf16x8* lds_frag;
     const lds_cptr a_rd = (lds_cptr)LPTR(smem) + (wr * MI * 16) * 64 + lane_off;
-    const lds_cptr b_rd = (lds_cptr)LPTR(smem) + 16384 + (wc * 64) * 64 + lane_off;
+    // Output columns are assigned to MFMA rows so that a lane ends up with 2 x 8 CONSECUTIVE columns of one output row and the
+    // epilogue stores straight from the accumulators (no LDS transposition): MFMA row i of column block j (acc[.][j], this lane
+    // holds i = 4 fq .. 4 fq + 3) is column 32 (j >> 1) + 8 (i >> 2) + 4 (j & 1) + (i & 3) of the wave's 64, i.e. the lane holds
+    // columns 8 fq .. 8 fq + 7 in acc[.][0..1] and 32 + 8 fq .. + 7 in acc[.][2..3].  Only the B fragment rows change:
+    const int lane_off_b = (8 * (fr >> 2) + (fr & 3)) * 64 + ((fq ^ ((GT >> (2 * (fr >> 2))) & 3)) << 4);
+    const lds_cptr b_rd = (lds_cptr)LPTR(smem) + 16384 + (wc * 64) * 64 + lane_off_b;
+#define NTP_BOFF(j) ((((j) >> 1) * 32 + ((j) & 1) * 4) * 64)
     lds_cptr a_rd_hi = a_rd + 65536, b_rd_hi = b_rd + 65536;
     asm volatile("" : "+v"(a_rd_hi), "+v"(b_rd_hi));
     auto load_frags = [&](int slot, bf16x8 (&af)[MI], bf16x8 (&bfr)[4]) {
@@ -539,7 +550,7 @@ __global__ __launch_bounds__(512, 2) void gemm_ntp_kernel(const GemmNT p) {
         const lds_cptr bb = slot < 2 ? b_rd : b_rd_hi;
         const int so = (slot & 1) * 32768;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) bfr[j] = *(lds_frag)(bb + so + j * 1024);
+        for (int j = 0; j < 4; ++j) bfr[j] = *(lds_frag)(bb + so + NTP_BOFF(j));
 #pragma unroll
         for (int i = 0; i < MI; ++i) af[i] = *(lds_frag)(ab + so + i * 1024);
     };
@@ -564,7 +575,7 @@ __global__ __launch_bounds__(512, 2) void gemm_ntp_kernel(const GemmNT p) {
         const lds_cptr bb = slot < 2 ? b_rd : b_rd_hi;
         const int so = (slot & 1) * 32768;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) sf_b[j] = *(lds_frag)(bb + so + j * 1024);
+        for (int j = 0; j < 4; ++j) sf_b[j] = *(lds_frag)(bb + so + NTP_BOFF(j));
     };
     auto load_a1 = [&](int slot, int i0, int n) {                  // row blocks i0 .. i0 + n - 1 -> sf_a[0 .. n - 1]
         const lds_cptr ab = slot < 2 ? a_rd : a_rd_hi;
@@ -640,11 +651,25 @@ __global__ __launch_bounds__(512, 2) void gemm_ntp_kernel(const GemmNT p) {
     // when the launch has more tiles than workgroups -- so that workgroups which start late (CUs held by another stream's
     // kernels, e.g. RCCL channels during the gradient all-reduce) do not leave their whole static share for a second wave.
     // One lane fetches the tile AFTER the next one at the start of an epilogue (at kernel start for the second tile), when
-    // registers are free and the latency has the whole epilogue to hide in, and parks it in a word of the (then idle)
-    // epilogue scratch; every wave picks it up after K step 3 of the next tile, several barriers later.
+    // registers are free and the latency has the whole epilogue to hide in, and parks it in an LDS word behind
+    // the ring; every wave picks it up after K step 3 of the next tile, several barriers later.
     auto vq_write = [&](int value) {
         const uint32_t vq_addr = (uint32_t)(size_t)LPTR(smem) + 131072u;
         asm volatile("ds_write_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" :: "v"(vq_addr), "v"(value) : "memory");
+    };
+    // Bias row of a wave's 64 columns: one 4-byte-per-lane LDS-DMA per tile into a wave-private 256 B of LDS, issued in K
+    // step 3 -- ahead of the next tile's stages in vmcnt order, so the epilogue reads it (DS, lgkmcnt) without having to
+    // wait for those stages the way a register load issued in the epilogue would (vector memory retires in issue order)
+    auto fetch_bias = [&](int n0) {
+        if constexpr (EPI & EPI_BIAS) {
+            int l = lane;
+            asm volatile("" : "+v"(l));
+            auto kpb = __builtin_amdgcn_kernarg_segment_ptr();
+            asm volatile("" : "+s"(kpb));
+            const __attribute__((address_space(4))) GemmNT& qb = *(const __attribute__((address_space(4))) GemmNT*)kpb;
+            const auto rsBias = __builtin_amdgcn_make_buffer_rsrc((void*)qb.bias, 0, qb.N * 4, 0x00020000);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsBias, LPTR(smem + 132096 + wave * 256), 4, l * 4, (n0 + wc * 64) * 4, 0, 0);
+        }
     };
     if (p.tile_counter && tid == 0) vq_write(first_fetch);
     for (int v = blockIdx.x, vn = 0; v < ntiles; v = vn) {
@@ -673,6 +698,7 @@ __global__ __launch_bounds__(512, 2) void gemm_ntp_kernel(const GemmNT p) {
             NT3_STEP(2, false, false, cur, 320)
             NT3_STEP(3, false, false, cur, 384)
             read_queue();
+            fetch_bias(n0);
             for (int s = 4; s < ns - 4; s += 4) {
                 const uint32_t kb = (uint32_t)(s + 3) * 64u;
                 NT3_STEP(0, false, false, cur, kb)
@@ -698,6 +724,7 @@ __global__ __launch_bounds__(512, 2) void gemm_ntp_kernel(const GemmNT p) {
             NTP_STEP(2, a0, b0, a1, b1, mma, early, true, cur, 384)
             NTP_STEP(3, a1, b1, a0, b0, mma, false, true, cur, 448)
             read_queue();
+            fetch_bias(n0);
             for (int s = 4; s < ns - 4; s += 4) {
                 const uint32_t kb = (uint32_t)(s + 4) * 64u;
                 NTP_STEP(0, a0, b0, a1, b1, mma, false, true, cur, kb)
@@ -730,17 +757,10 @@ __global__ __launch_bounds__(512, 2) void gemm_ntp_kernel(const GemmNT p) {
         int elane = lane;
         asm volatile("" : "+v"(elane));
         const int efr = elane & 15, efq = elane >> 4;
-        const uint32_t scratch = (uint32_t)(size_t)LPTR(smem) + 131072u + wave * 4096u;
-        // scratch rows are 256 B (64 fp32); 16-byte chunk c of row r sits at chunk c ^ r
-        const uint32_t wr_addr = scratch + efr * 256;                 // + ((4j + fq) ^ fr) * 16 per j
-        const int er = elane >> 2, eq = elane & 3;                    // read-back: row er, columns 16 eq .. 16 eq + 15
-        const uint32_t rd_addr = scratch + er * 256;
         const bool interior = (m0 + BM <= q.M) && (n0 + 256 <= q.N);
-        const int mrow = m0 + wr * (MI * 16) + er;                   // + 16 i
-        const int ncol = n0 + wc * 64 + eq * 16;
-        const bool ncol_ok = ncol < q.N;                              // N % 8 == 0 and 16-column groups: check both halves below
-        // residual / GELU-input rows: prefetched PRE blocks ahead of their use (all MI blocks at once do not fit the
-        // register file next to the accumulators; a scratch reload would drain vmcnt)
+        const int mrow = m0 + wr * (MI * 16) + efr;                  // + 16 i
+        const int ncol = n0 + wc * 64 + efq * 8;                     // 8 columns here (acc[.][0..1]) and 8 at + 32 (acc[.][2..3])
+        // residual / GELU-input rows: prefetched PRE row blocks ahead of their use
         constexpr int PRE = 3;
         bf16x8 pre[MI][2];
         auto load_pre = [&](int i) {
@@ -751,68 +771,75 @@ __global__ __launch_bounds__(512, 2) void gemm_ntp_kernel(const GemmNT p) {
                 // unconditional, clamped in-bounds (a half that is out of range is never stored): no branches, and
                 // nothing conditionally defined that hipcc would carry around the tile loop
                 const bf16_t* rp = src + (size_t)min(m, q.M - 1) * ld;
-                asm volatile("" : "+v"(rp));                        // pins the load behind the previous block's asm LDS traffic
                 pre[i][0] = *(const bf16x8*)(rp + min(ncol, q.N - 8));
-                pre[i][1] = *(const bf16x8*)(rp + min(ncol + 8, q.N - 8));
+                pre[i][1] = *(const bf16x8*)(rp + min(ncol + 32, q.N - 8));
             }
         };
 #pragma unroll
         for (int i = 0; i < PRE; ++i) load_pre(i);
         float bias[16];
         if constexpr (EPI & EPI_BIAS) {
+            const uint32_t baddr = (uint32_t)(size_t)LPTR(smem) + 132096u + wave * 256u + efq * 32u;
+            f32x4 b4[4];
+            lds_read16f<0>(b4[0], baddr); lds_read16f<16>(b4[1], baddr); lds_read16f<128>(b4[2], baddr); lds_read16f<144>(b4[3], baddr);
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(b4[0]), "+v"(b4[1]), "+v"(b4[2]), "+v"(b4[3]) :: "memory");
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (interior || ncol + 4 * c + 4 <= q.N) b4 = *(const float4*)(q.bias + ncol + 4 * c);
-                bias[4 * c] = b4.x; bias[4 * c + 1] = b4.y; bias[4 * c + 2] = b4.z; bias[4 * c + 3] = b4.w;
+            for (int c = 0; c < 4; ++c)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) bias[4 * c + r] = b4[c][r];
+        }
+        // phase 1, needs no global data (the first residual / GELU-input rows are still queued behind the next tile's stages):
+        // scale, bias and the dropout decision, in place in the accumulators
+        // (epilogue scalars are copied out of the kernel-argument segment ONCE: read through `q` inside a select, hipcc turns
+        // every select into a divergent branch around an s_load)
+        const uint32_t dthr = (EPI & EPI_RESID) ? q.drop_thr16 : 0u;
+        const uint32_t dthr_s = dthr - 32768u;                       // the signed-compare form of mmb_keep16
+        const float dscale = (EPI & EPI_RESID) ? q.drop_scale : 1.0f;
+        // dropout seeds are linear in the element index (common.h): pair(m, n) = m * N/2 + n/2 (mod 2^32), so one multiply per
+        // lane and wave-uniform increments per row block / column pair
+        const uint32_t halfN = (uint32_t)q.N >> 1;
+        const uint32_t seed0 = (EPI & EPI_RESID) ? ((uint32_t)mrow * halfN + ((uint32_t)ncol >> 1)) * MMB_WEYL + q.drop_stream : 0u;
+        const uint32_t seed_row = 16u * halfN * MMB_WEYL;
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+#pragma unroll
+                for (int r = 0; r < 8; ++r) {
+                    float v = acc[i][2 * h + (r >> 2)][r & 3] * alpha;
+                    if constexpr (EPI & EPI_BIAS) v += bias[8 * h + r];
+                    acc[i][2 * h + (r >> 2)][r & 3] = v;
+                }
+                if constexpr (EPI & EPI_RESID) {
+                    if (dthr) {
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {                // element pair k of the 8 columns: elements 2k, 2k + 1
+                            const uint32_t hb = mmb_pair_mix(seed0 + (uint32_t)i * seed_row + (uint32_t)(16 * h + k) * MMB_WEYL);
+                            f32x4& a4 = acc[i][2 * h + (k >> 1)];
+                            const bool keep0 = (int16_t)(uint16_t)(hb & 0xFFFFu) >= (int16_t)(uint16_t)dthr_s;
+                            const bool keep1 = (int16_t)(uint16_t)(hb >> 16) >= (int16_t)(uint16_t)dthr_s;
+                            a4[(2 * k) & 3] = keep0 ? a4[(2 * k) & 3] * dscale : 0.f;
+                            a4[(2 * k + 1) & 3] = keep1 ? a4[(2 * k + 1) & 3] * dscale : 0.f;
+                        }
+                    }
+                }
             }
         }
-        // Transposition through the wave-private scratch, software-pipelined: a wave's DS instructions execute in issue
-        // order, so block i + 1 is written (and its read-back issued) right behind the read-back of block i with no wait
-        // in between; only the consumer of block i waits, with a COUNTED lgkmcnt that leaves those 8 younger DS
-        // operations in flight (compiler-issued scalar loads in flight only make that wait stricter).
-        uint32_t wa[4], ra[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            wa[j] = wr_addr + ((((j << 2) | efq) ^ efr) << 4);
-            ra[j] = rd_addr + ((((eq << 2) | j) ^ er) << 4);
-        }
-        auto wr_block = [&](int i) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const f32x4 a4 = acc[i][j];
-                const f32x4 sc = {a4[0] * alpha, a4[1] * alpha, a4[2] * alpha, a4[3] * alpha};
-                lds_write16<0>(wa[j], sc);
-            }
-        };
-        auto rd_block = [&](f32x4 (&d)[4]) {
-#pragma unroll
-            for (int c = 0; c < 4; ++c) lds_read16f<0>(d[c], ra[c]);
-        };
-        f32x4 qbuf[2][4];
-        wr_block(0);
-        rd_block(qbuf[0]);
 #pragma unroll
         for (int i = 0; i < MI; ++i) {
             if (i + PRE < MI) load_pre(i + PRE);
-            f32x4 (&q4)[4] = qbuf[i & 1];
-            if (i + 1 < MI) {
-                wr_block(i + 1);
-                rd_block(qbuf[(i + 1) & 1]);
-                asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(q4[0]), "+v"(q4[1]), "+v"(q4[2]), "+v"(q4[3]) :: "memory");
-            } else {
-                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(q4[0]), "+v"(q4[1]), "+v"(q4[2]), "+v"(q4[3]) :: "memory");
-            }
             const int m = mrow + 16 * i;
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
-                const int n = ncol + 8 * h;
-                float vv[8] = {q4[2 * h][0], q4[2 * h][1], q4[2 * h][2], q4[2 * h][3], q4[2 * h + 1][0], q4[2 * h + 1][1], q4[2 * h + 1][2], q4[2 * h + 1][3]};
-                if constexpr (EPI & EPI_BIAS) {
+                const int n = ncol + 32 * h;
+                float vv[8];
 #pragma unroll
-                    for (int r = 0; r < 8; ++r) vv[r] += bias[8 * h + r];
-                }
+                for (int r = 0; r < 8; ++r) vv[r] = acc[i][2 * h + (r >> 2)][r & 3];
+#ifdef MMB_STAMPS
+                const bool ok = (interior || (m < q.M && n + 8 <= q.N)) && !(g_nt_dbg & 64);     // 64: timing without the stores
+#else
                 const bool ok = interior || (m < q.M && n + 8 <= q.N);
+#endif
                 if constexpr (EPI & EPI_GELU) {
                     if (q.aux) {
                         bf16x8 u;
@@ -828,14 +855,6 @@ __global__ __launch_bounds__(512, 2) void gemm_ntp_kernel(const GemmNT p) {
                     for (int r = 0; r < 8; ++r) vv[r] *= gelu_erf_grad(bf2f(pre[i][h][r]));
                 }
                 if constexpr (EPI & EPI_RESID) {
-                    if (q.drop_thr16) {
-                        bool k0[4], k1[4];
-                        const uint64_t idx = (uint64_t)m * q.N + n;
-                        mmb_keep4(q.drop_stream, idx, q.drop_thr16, k0);
-                        mmb_keep4(q.drop_stream, idx + 4, q.drop_thr16, k1);
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) { vv[r] = k0[r] ? vv[r] * q.drop_scale : 0.f; vv[4 + r] = k1[r] ? vv[4 + r] * q.drop_scale : 0.f; }
-                    }
 #pragma unroll
                     for (int r = 0; r < 8; ++r) vv[r] += bf2f(pre[i][h][r]);
                 }
@@ -853,8 +872,7 @@ __global__ __launch_bounds__(512, 2) void gemm_ntp_kernel(const GemmNT p) {
                 }
             }
         }
-        (void)ncol_ok;
-        if (fetcher) vq_write(fetched);                              // wave 0's scratch is idle again
+        if (fetcher) vq_write(fetched);
 #ifdef MMB_STAMPS
         MMB_STAMP(sd)
         t_wait += sb - sa; t_loop += sc_ - sb; t_epi += sd - sc_; ++ntile;
@@ -863,6 +881,7 @@ __global__ __launch_bounds__(512, 2) void gemm_ntp_kernel(const GemmNT p) {
     }
 #undef NTP_STEP
 #undef NT3_STEP
+#undef NTP_BOFF
     if constexpr (STAG) { if (wr == 0) __builtin_amdgcn_s_barrier(); }   // balances the stagger barrier of the other group
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // the dead tail stages
 #ifdef MMB_STAMPS
@@ -875,13 +894,14 @@ __global__ __launch_bounds__(512, 2) void gemm_ntp_kernel(const GemmNT p) {
 #endif
 }
 
+constexpr int NTP_LDS_BYTES = 131072 + 1024 + 8 * 256;      // ring | tile-queue word (padded) | bias rows
 template <int EPI, int MI>
 static int launch_ntp_mi(hipStream_t s, const GemmNT& p) {
     constexpr int BM = 32 * MI;
     const int tiles = ((p.M + BM - 1) / BM) * ((p.N + 255) / 256);
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)gemm_ntp_kernel<EPI, MI, MI == 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
+        hipError_t e = hipFuncSetAttribute((const void*)gemm_ntp_kernel<EPI, MI, MI == 8>, hipFuncAttributeMaxDynamicSharedMemorySize, NTP_LDS_BYTES);
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
@@ -905,7 +925,7 @@ static int launch_ntp_mi(hipStream_t s, const GemmNT& p) {
             ++launches;
         }
     }
-    hipLaunchKernelGGL((gemm_ntp_kernel<EPI, MI, MI == 8>), dim3(tiles < cus ? tiles : cus), dim3(512), 163840, s, q);
+    hipLaunchKernelGGL((gemm_ntp_kernel<EPI, MI, MI == 8>), dim3(tiles < cus ? tiles : cus), dim3(512), NTP_LDS_BYTES, s, q);
     MMB_CHECK_LAUNCH();
     return 0;
 }

@@ -115,6 +115,33 @@ def test_gemm_nt_strided_views_and_alpha_dev(ops):
     assert float(out[:, :N].abs().max()) == 0.0
 
 
+def test_gelu_and_its_derivative_on_a_dense_grid(ops):
+    """The single-transcendental GELU / GELU' of csrc/common.h against torch's erf form on every bf16 value of [-14, 14]
+    (plus +-100, +-1e4): the only error left is the bf16 rounding of the result (half an ulp = 2^-9 relative) plus the
+    approximation floor (5.7e-7 / 4.1e-6 absolute).  GELU is reached through the persistent GEMM's epilogue (K = 256,
+    A = [x | 0], B = [I | 0] -> the product is x exactly), GELU' through mmbert_gelu_bwd with dy = 1."""
+    xs = torch.arange(-32768, 32768, dtype=torch.int32).to(torch.int16).view(torch.bfloat16).float()
+    xs = xs[torch.isfinite(xs) & (xs.abs() <= 14.0)]
+    xs = torch.cat([xs, torch.tensor([100.0, -100.0, 1e4, -1e4])])
+    xs = torch.cat([xs, torch.zeros(-xs.numel() % 256)])                      # whole rows of 256 (kernels take multiples of 8)
+    n = xs.numel()
+    x64 = xs.double()
+    gelu = (0.5 * x64 * (1.0 + torch.erf(x64 / math.sqrt(2.0))))
+    grad = 0.5 * (1.0 + torch.erf(x64 / math.sqrt(2.0))) + x64 * torch.exp(-0.5 * x64 * x64) / math.sqrt(2.0 * math.pi)
+    # derivative
+    u = bf(xs).to(DEV).contiguous()
+    du = ops.gelu_bwd(torch.ones_like(u), u)
+    assert_close(du, grad, 2.0 ** -8, 5e-6, "gelu'")
+    # forward, through the GEMM epilogue: one grid value per output element
+    M = (n + 255) // 256
+    X = torch.zeros(M * 256)
+    X[:n] = xs
+    ref = torch.zeros(M * 256, dtype=torch.float64)
+    ref[:n] = gelu
+    got = ops.gemm_nt(bf(X.view(M, 256)).to(DEV), bf(torch.eye(256)).to(DEV), gelu=True, bias=torch.zeros(256, device=DEV))
+    assert_close(got.reshape(-1), ref, 2.0 ** -8, 1e-6, "gelu")
+
+
 def test_gemm_nt_gelu_resid_gelubwd(ops):
     M, N, K = 257, 512, 128
     A, B, bias = bf(rnd(M, K, seed=6)), bf(rnd(N, K, seed=7, scale=0.1)), rnd(N, seed=8)

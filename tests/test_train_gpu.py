@@ -1,6 +1,7 @@
 """GPU tests of the training loop: the golden four-micro-batch trajectory of the REAL reference's
 trainer.train_epoch (G8), the fused AdamW through the model, and 2-rank data parallelism."""
 import os
+import socket
 
 import numpy as np
 import pytest
@@ -134,7 +135,9 @@ def _dp_worker(rank, world, port, q):
 def test_data_parallel_two_ranks_equals_mean_of_single_rank_grads():
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29800 + os.getpid() % 100
+    with socket.socket() as sk:                                           # a free port, not a guess: reruns on one box must not collide
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
     procs = [ctx.Process(target=_dp_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
