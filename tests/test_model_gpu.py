@@ -143,6 +143,37 @@ def test_mosi_dims_and_unequal_pair_lengths():
     check_against_oracle(cfg, 3, 24, 70, 33, seed=6)
 
 
+def test_long_fusion_stress_and_ur_funny_dims_match_oracle():
+    """BASELINE configs[3] shape class (A = V = 1375: S = 1425 per joint pass, attention tiles far past one LDS tile) at a
+    width the CPU oracle finishes in seconds, with the UR-FUNNY feature widths (371 / 81: odd, not multiples of 8)."""
+    cfg = dict(hidden=256, layers=1, heads=4, intermediate=1024, vocab=2048, dataset="ur_funny", alpha=1.0, beta=1.0)
+    check_against_oracle(cfg, 2, 50, 1375, 1375, seed=9)
+
+
+def test_full_size_long_fusion_step_is_finite_and_seeded():
+    """BASELINE configs[3] at full size (12-layer d=768, T=50, A=V=1375, batch 4, train mode): too large for the CPU oracle,
+    so the size-independent properties: finite losses, finite gradients on every parameter the reference differentiates,
+    and the same seed -> the same loss bit for bit."""
+    cfg = dict(hidden=768, layers=12, heads=12, intermediate=3072, vocab=30522, dataset="mosei", alpha=1.0, beta=1.0)
+    batch = batch_to(synthetic_batch(4, 50, 1375, 1375, seed=21), DEV)
+    m = build(cfg, train=True)
+    m.manual_seed(5)
+    out, logits = m(**batch)
+    a = float(out[0])
+    out[0].mean().backward()
+    torch.cuda.synchronize()
+    assert all(np.isfinite(float(out[i])) for i in (0, 4, 5, 6)) and bool(torch.isfinite(logits).all())
+    assert tuple(out[9].shape) == (4, 1425, cfg["vocab"])
+    nz = 0
+    for n, q in m.named_parameters():
+        assert bool(torch.isfinite(q.grad).all()), n
+        nz += int(float(q.grad.abs().sum()) > 0.0)
+    assert nz >= len(list(m.named_parameters())) - 6            # the six parameters the reference never differentiates
+    m.zero_grad()
+    m.manual_seed(5)
+    assert float(m(**batch)[0][0]) == a
+
+
 def test_dropout_train_mode_is_seeded_and_unbiased():
     batch = batch_to(synthetic_batch(2, 50, 64, 64, seed=1), DEV)
     m = build(CFG1, train=True)
