@@ -51,12 +51,13 @@ def main():
     ap.add_argument("--vocab", type=int, default=30522)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--no-fused", action="store_true", help="skip the secondary fused-sequence (S = T+V+A) measurement")
     ap.add_argument("--overlap-wgrad", action="store_true", help="weight-gradient GEMMs on a side stream (measured slower)")
     ap.add_argument("--eval-dropout-off", action="store_true", help="diagnostic only: not a valid headline number")
     a = ap.parse_args()
 
     from msa_amd import ops, parallel
-    from msa_amd.data import synthetic_batch, batch_to
+    from msa_amd.data import synthetic_batch, batch_to, to_fused
     from msa_amd.model import MMBertConfig, MMBertForPretraining
     from msa_amd.trainer import build_optimizer, default_args
 
@@ -138,6 +139,42 @@ def main():
         elapsed = float(t)
     loss = float(last)
 
+    # Secondary: the same train step on the fused single sequence text | visual | speech (S = T + V + A = 1050), the shape
+    # BASELINE.json's metric name quotes.  The reference never builds that sequence (its step is the three passes above), so
+    # this is a declared extension (model.forward_fused, checked against oracle.fused_forward) and never the headline value.
+    fused = None
+    if not a.no_fused:
+        fpool = [to_fused(b) for b in pool]
+
+        def fstep(i):
+            out, _ = model.forward_fused(**fpool[i % len(fpool)])
+            out[0].mean().backward()
+            if dp is not None:
+                dp.finish_backward()
+            opt.step()
+            sched.step()
+            opt.zero_grad()
+
+        for i in range(min(a.warmup, 3) + 1):
+            fstep(i)
+        torch.cuda.synchronize()
+        barrier()
+        tf0 = time.perf_counter()
+        for i in range(a.steps):
+            fstep(i)
+        torch.cuda.synchronize()
+        barrier()
+        felapsed = time.perf_counter() - tf0
+        if world > 1:
+            t = torch.tensor([felapsed], device=dev, dtype=torch.float64)
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+            felapsed = float(t)
+        S = a.text + 2 * a.pair
+        ffl = 3.0 * (2 * S * L * (4 * H * H + 2 * H * I) + 4 * S * S * H * L + 2 * S * H * H + 2 * S * H * V + 2 * a.pair * (35 + 74) * H)
+        fused = {"value": round(a.steps * a.batch * world / felapsed, 2), "unit": "samples/s", "ms_per_step": round(1e3 * felapsed / a.steps, 3),
+                 "seq_len": S, "tflop_per_sample": round(ffl / 1e12, 4),
+                 "note": "declared extension (one pass over text|visual|speech; not in the reference, no reference parity): model.forward_fused"}
+
     samples = a.steps * a.batch * world
     value = samples / elapsed
     fps = 3.0 * flops_per_sample(L, H, I, V, a.text, a.pair, a.pair)
@@ -157,6 +194,8 @@ def main():
         "final_loss": round(loss, 4),
         "step_mfma_frac": round(fps_exec * value / world / 2.5e15, 4),
     }
+    if fused is not None:
+        res["fused1050"] = fused
     if rank == 0:
         if not a.no_kernel_timing and timing["nt"]:
             kern = {}

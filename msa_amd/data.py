@@ -99,3 +99,17 @@ def batch_to(batch: dict, device):
             return tuple(mv(y) for y in x)
         return x.to(device)
     return {k: mv(v) for k, v in batch.items()}
+
+
+def to_fused(batch: dict) -> dict:
+    """The keyword arguments of ``MMBertForPretraining.forward_fused`` (text | visual | speech in ONE sequence; a declared
+    extension, see its docstring) from a three-pass batch: the text pass's ids / mask / labels, both feature blocks and
+    their masks, -100 labels on the pair positions."""
+    text_ids, visual, speech, _twv, _tws = batch["input_ids"]
+    am_t, am_v, am_s = batch["attention_mask"]
+    lab_t = batch["masked_labels"][0]
+    B = text_ids.shape[0]
+    pad = torch.full((B, visual.shape[1] + speech.shape[1]), -100, dtype=lab_t.dtype, device=lab_t.device)
+    return dict(input_ids=(text_ids, visual, speech), token_type_ids=batch["token_type_ids"][0],
+                attention_mask=(am_t, am_v[1], am_s[1]), masked_labels=torch.cat((lab_t, pad), dim=1),
+                ap_label=batch["ap_label"], sentiment=batch["sentiment"])

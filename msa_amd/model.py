@@ -198,28 +198,37 @@ class _TextEmbedFn(torch.autograd.Function):
 
 
 class _JointFn(torch.autograd.Function):
-    """cat(text_emb, relu(W.pair+b)) -> LayerNorm(1e-5) -> dropout(0.5)      (REF:MMBertEmbedding.py:57-72)"""
+    """cat(text_emb, relu(W.pair+b)) -> LayerNorm(1e-5) -> dropout(0.5)      (REF:MMBertEmbedding.py:57-72)
+    ``feats`` / ``whichs`` are tuples: one modality in the reference's joint passes; both (text | visual | speech in ONE
+    sequence) in the fused-sequence extension (forward_fused)."""
 
     @staticmethod
-    def forward(ctx, e1, anchor, top, feat, which, B, T, drop):
+    def forward(ctx, e1, anchor, top, feats, whichs, B, T, drop):
         w = top._w
         H = e1.shape[1]
-        P = feat.shape[1]
-        j0 = torch.empty((B * (T + P), H), device=e1.device, dtype=torch.bfloat16)
-        j0.view(B, T + P, H)[:, :T].copy_(e1.view(B, T, H))
-        ops.pair_proj_fwd(feat, w[which + "_w"], w[which + "_b"], j0, T)
+        S = T + sum(f.shape[1] for f in feats)
+        j0 = torch.empty((B * S, H), device=e1.device, dtype=torch.bfloat16)
+        j0.view(B, S, H)[:, :T].copy_(e1.view(B, T, H))
+        off = T
+        for feat, which in zip(feats, whichs):
+            ops.pair_proj_fwd(feat, w[which + "_w"], w[which + "_b"], j0, T, seq_len=S, offset=off)
+            off += feat.shape[1]
         x, mean, rstd = ops.ln_fwd(j0, w["joint_ln_g"], w["joint_ln_b"], LN_EPS_JOINT, drop=drop)
-        ctx.top, ctx.which, ctx.B, ctx.T, ctx.drop = top, which, B, T, drop
-        ctx.save_for_backward(feat, j0, mean, rstd)
+        ctx.top, ctx.whichs, ctx.B, ctx.T, ctx.drop, ctx.nf = top, whichs, B, T, drop, len(feats)
+        ctx.save_for_backward(j0, mean, rstd, *feats)
         return x
 
     @staticmethod
     def backward(ctx, dx):
-        feat, j0, mean, rstd = ctx.saved_tensors
+        j0, mean, rstd, *feats = ctx.saved_tensors
         w, B, T = ctx.top._w, ctx.B, ctx.T
         H = j0.shape[1]
+        S = j0.shape[0] // B
         dj0 = ops.ln_bwd(dx.contiguous(), j0, mean, rstd, w["joint_ln_g"], w["g_joint_ln_g"], w["g_joint_ln_b"], post_drop=ctx.drop)
-        ops.pair_proj_bwd(feat, j0, dj0, T, w["g_" + ctx.which + "_w"], w["g_" + ctx.which + "_b"])
+        off = T
+        for feat, which in zip(feats, ctx.whichs):
+            ops.pair_proj_bwd(feat, j0, dj0, T, w["g_" + which + "_w"], w["g_" + which + "_b"], seq_len=S, offset=off)
+            off += feat.shape[1]
         de1 = dj0.view(B, -1, H)[:, :T].reshape(B * T, H)
         return de1, None, None, None, None, None, None, None
 
@@ -541,11 +550,13 @@ class _GpuModelBase(nn.Module):
             e = e1[k * B * T:(k + 1) * B * T]
             kb = self._key_bias(p["mask"], False, dev)
             if p.get("pair") is not None:
-                which = je.which(p["pair"])
-                feat = p["pair"].to(dev).float().contiguous()
-                e = _JointFn.apply(e, je.LayerNorm.weight, self, feat, which, B, T, ops.make_drop(p_joint, seed, 1001 + k))
-                kb = torch.cat((kb, self._key_bias(p["pair_mask"], True, dev)), dim=-1)
-                lens.append(T + feat.shape[1])
+                pairs = p["pair"] if isinstance(p["pair"], (tuple, list)) else (p["pair"],)
+                pmasks = p["pair_mask"] if isinstance(p["pair_mask"], (tuple, list)) else (p["pair_mask"],)
+                whichs = tuple(je.which(f) for f in pairs)
+                feats = tuple(f.to(dev).float().contiguous() for f in pairs)
+                e = _JointFn.apply(e, je.LayerNorm.weight, self, feats, whichs, B, T, ops.make_drop(p_joint, seed, 1001 + k))
+                kb = torch.cat((kb, *(self._key_bias(pm.to(dev), True, dev) for pm in pmasks)), dim=-1)
+                lens.append(T + sum(f.shape[1] for f in feats))
             else:
                 lens.append(T)
             xs.append(e)
@@ -839,6 +850,18 @@ class MMBertForPretraining(_GpuModelBase):
         heads_loss = ap_loss + label_loss - self.beta * nce
         return heads_loss, ap_loss, label_loss, nce, logits_out, t_rel, v_rel, s_rel
 
+    def _run_heads(self, first, ap_v, ap_s, sentiment, dev, B):
+        """The heads on the [3B, H] [CLS] rows: the fused kernels (csrc/heads.hip) where they apply, else the eager form.
+        (A captured hipGraph of the eager [B,H]-sized glue -- forward and backward, ~200 dependent launches -- was built and
+        measured in round 1: no gain; the device time of the tiny kernels, not their dispatch, is the cost.)"""
+        fused = (self.fused_heads and sentiment is not None and first.is_cuda and self.num_labels in (1, 7)
+                 and all(q.grad is not None for q in (self.attn.weight, self.vt.weight, self.classifier1_1.weight)))
+        if fused:
+            ap = torch.cat((ap_v.to(dev).view(-1), ap_s.to(dev).view(-1))).long()
+            heads_loss, aux, logits_out, t_rel, rel = _HeadsFn.apply(first, self, ap, sentiment.to(dev).view(-1).float())
+            return heads_loss, aux[0], aux[1], aux[2], logits_out, t_rel, rel[:B], rel[B:]
+        return self._heads(first, ap_v.to(dev), ap_s.to(dev), None if sentiment is None else sentiment.to(dev))
+
     def forward(self, input_ids, token_type_ids, attention_mask, masked_labels, ap_label, sentiment):
         self.outputs = ()
         text_ids, visual, speech, twv, tws = input_ids
@@ -860,18 +883,7 @@ class MMBertForPretraining(_GpuModelBase):
 
         first = y.index_select(0, plan["first"]).float()                             # [3B, H]: [CLS] rows of every sequence
         mlm_loss = (mlm[0] + mlm[1] + mlm[2]) / 3.0                                  # :427
-        # (a captured hipGraph of the eager [B,H]-sized glue -- forward and backward, ~200 dependent launches -- was built and
-        # measured in round 1: no gain; the device time of the tiny kernels, not their dispatch, is the cost)
-        fused = (self.fused_heads and sentiment is not None and first.is_cuda and self.num_labels in (1, 7)
-                 and all(q.grad is not None for q in (self.attn.weight, self.vt.weight, self.classifier1_1.weight)))
-        if fused:
-            ap = torch.cat((ap_v.to(dev).view(-1), ap_s.to(dev).view(-1))).long()
-            heads_loss, aux, logits_out, t_rel, rel = _HeadsFn.apply(first, self, ap, sentiment.to(dev).view(-1).float())
-            ap_loss, label_loss, nce = aux[0], aux[1], aux[2]
-            v_rel, s_rel = rel[:B], rel[B:]
-        else:
-            heads_loss, ap_loss, label_loss, nce, logits_out, t_rel, v_rel, s_rel = self._heads(first, ap_v.to(dev), ap_s.to(dev),
-                                                                                              None if sentiment is None else sentiment.to(dev))
+        heads_loss, ap_loss, label_loss, nce, logits_out, t_rel, v_rel, s_rel = self._run_heads(first, ap_v, ap_s, sentiment, dev, B)
         joint_loss = self.alpha * mlm_loss + heads_loss                              # :443
         scores = (None, None, None)
         if logits is not None:
@@ -879,4 +891,35 @@ class MMBertForPretraining(_GpuModelBase):
             scores = tuple(logits[b[k]:b[k + 1]].view(B, lens[k], -1)[:, :, :V] for k in range(3))
         self.outputs = (joint_loss, None, None, None, ap_loss, label_loss, nce,
                         scores[0], t_rel, scores[1], v_rel, scores[2], s_rel)
+        return self.outputs, logits_out
+
+    def forward_fused(self, input_ids, token_type_ids, attention_mask, masked_labels, ap_label, sentiment):
+        """DECLARED EXTENSION, not in the reference (SURVEY S8(d) mode ``fused1050``; BASELINE.json quotes its metric on a "fused
+        seq_len~1050" sequence that the reference never builds): text | visual | speech in ONE sequence of T + V + A tokens --
+        JointEmbeddings applied to both projected modalities at once (cat -> LayerNorm -> dropout, REF:MMBertEmbedding.py:57-72
+        extended by the second ``cat`` operand), ONE encoder pass, and the reference's objective (REF:MMBertForPretraining.py:
+        392-449) evaluated with that pass standing in for all three: MLM over the fused sequence, alignment loss of its [CLS]
+        row against both pair labels, fusion head / CPC with the one pooled vector in the three modality slots.
+
+        input_ids=(text_ids[B,T], visual[B,V,Dv], speech[B,A,Ds]); token_type_ids: text's [B,T] or None;
+        attention_mask=(text_mask[B,T], visual_mask[B,V,Dv], speech_mask[B,A,Ds]); masked_labels [B, T+V+A] (-100 = ignore).
+        Returns ((joint_loss, None, None, None, ap_loss, label_loss, nce, scores[B,S,V] | None, rel[B,2]), logits[B,1]).
+        Checked against oracle.fused_forward (the same extension of the CPU restatement)."""
+        text_ids, visual, speech = input_ids
+        am_t, am_v, am_s = attention_mask
+        ap_v, ap_s = ap_label
+        dev = text_ids.device
+        B, T = text_ids.shape
+        passes = [dict(ids=text_ids, tt=token_type_ids, mask=am_t, pair=(visual, speech), pair_mask=(am_v, am_s))]
+        y, plan, lens = self._encode(passes)
+        V = self.config.vocab_size
+        labels = masked_labels.reshape(-1).to(device=dev, dtype=torch.long)
+        if labels.numel() != y.shape[0]:
+            raise ValueError("masked_labels must cover the text and both pair blocks")
+        mlm, logits = _MLMHeadFn.apply(y, self.cls.predictions.transform.LayerNorm.weight, self, labels, plan["bounds"], plan["bounds_dev"], self.return_scores)
+        first = y.index_select(0, plan["first"].repeat(3)).float()                   # the one [CLS] row in the t / v / s slots
+        heads_loss, ap_loss, label_loss, nce, logits_out, _t_rel, v_rel, _s_rel = self._run_heads(first, ap_v, ap_s, sentiment, dev, B)
+        joint_loss = self.alpha * mlm[0] + heads_loss
+        scores = None if logits is None else logits.view(B, lens[0], -1)[:, :, :V]
+        self.outputs = (joint_loss, None, None, None, ap_loss, label_loss, nce, scores, v_rel)
         return self.outputs, logits_out

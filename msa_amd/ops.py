@@ -208,22 +208,35 @@ def embed_scatter(ids, tts, d, T, gword, gtype, gpos):
                                         gword.data_ptr(), gtype.data_ptr(), gpos.data_ptr()), "mmbert_embed_scatter")
 
 
-def pair_proj_fwd(feat, W, bias, out, T):
-    """feat fp32 [B,P,D]; writes relu(W.feat+b) into rows b*(T+P)+T+p of ``out`` (bf16 [B*(T+P), H])."""
+def _pair_rows(T, Pn, ld, seq_len, offset):
+    """The kernels address the pair rows of sample b as ``b*(T+P) + T + p``.  A pair block at ``offset`` inside sequences
+    of ``seq_len`` rows (several modalities in one sequence) is the same pattern with T' = seq_len - P seen from a base
+    pointer moved by ``offset - T'`` rows: returns (T', byte shift for bf16 rows of ``ld`` elements)."""
+    if seq_len is None:
+        return T, 0
+    Tp = seq_len - Pn
+    return Tp, (offset - Tp) * ld * 2
+
+
+def pair_proj_fwd(feat, W, bias, out, T, *, seq_len=None, offset=None):
+    """feat fp32 [B,P,D]; writes relu(W.feat+b) into rows b*(T+P)+T+p of ``out`` (bf16 [B*(T+P), H]); with ``seq_len`` /
+    ``offset``: into rows b*seq_len + offset + p."""
     lib = _lib.load()
     B, Pn, D = feat.shape
     H = W.shape[0]
+    Tp, shift = _pair_rows(T, Pn, out.stride(0), seq_len, offset)
     _lib.check(lib.mmbert_pair_proj_fwd(_stream(), feat.data_ptr(), B, Pn, D, W.data_ptr(), bias.data_ptr(), H,
-                                        out.data_ptr(), out.stride(0), T), "mmbert_pair_proj_fwd")
+                                        out.data_ptr() + shift, out.stride(0), Tp), "mmbert_pair_proj_fwd")
 
 
-def pair_proj_bwd(feat, J, dJ, T, dW, db):
+def pair_proj_bwd(feat, J, dJ, T, dW, db, *, seq_len=None, offset=None):
     lib = _lib.load()
     B, Pn, D = feat.shape
     H = dW.shape[0]
     assert J.stride(0) == dJ.stride(0)
+    Tp, shift = _pair_rows(T, Pn, J.stride(0), seq_len, offset)
     ws = _ws_f32((lib.mmbert_pair_proj_bwd_workspace(B, Pn, D, H) + 3) // 4, feat.device)
-    _lib.check(lib.mmbert_pair_proj_bwd(_stream(), feat.data_ptr(), B, Pn, D, J.data_ptr(), dJ.data_ptr(), J.stride(0), T,
+    _lib.check(lib.mmbert_pair_proj_bwd(_stream(), feat.data_ptr(), B, Pn, D, J.data_ptr() + shift, dJ.data_ptr() + shift, J.stride(0), Tp,
                                         dW.data_ptr(), db.data_ptr(), H, ws.data_ptr()), "mmbert_pair_proj_bwd")
 
 

@@ -278,6 +278,47 @@ def pretraining_forward(p: Params, cfg: dict, input_ids, token_type_ids, attenti
     return outputs, logits
 
 
+def fused_forward(p: Params, cfg: dict, input_ids, token_type_ids, attention_mask, masked_labels, ap_label, sentiment, *,
+                  train=False, masks=None):
+    """NOT IN THE REFERENCE -- the declared fused-sequence extension (SURVEY S8(d) ``fused1050``), restated here only so that
+    the HIP path's ``forward_fused`` has a CPU checker: text | visual | speech in one sequence (JointEmbeddings' ``cat`` with
+    both projected modalities, REF:MMBertEmbedding.py:61-70), one encoder pass, and the objective of
+    REF:MMBertForPretraining.py:392-449 with that pass in all three modality slots.  Parity for this function is pinned by
+    nothing in the reference (there is nothing to pin it to); it reuses the pinned building blocks above."""
+    text_ids, visual, speech = input_ids
+    am_t, am_v, am_s = attention_mask
+    ap_v, ap_s = ap_label
+    hd, ad = cfg.get("hidden_dropout", 0.1), cfg.get("attn_dropout", 0.1)
+    tt = token_type_ids if token_type_ids is not None else torch.zeros_like(text_ids, dtype=torch.long)
+    x = bert_embeddings(p, text_ids, tt, hidden_dropout=hd, train=train, masks=masks, tag="f.")
+    pv = F.relu(_linear(visual.float(), p, "bert.jointEmbeddings.Wv"))
+    ps = F.relu(_linear(speech.float(), p, "bert.jointEmbeddings.Ws"))
+    x = _r(torch.cat((x, pv, ps), dim=1))
+    x = _layer_norm(x, p, "bert.jointEmbeddings.LayerNorm", LN_EPS_JOINT)
+    x = _r(_dropout(x, cfg.get("joint_dropout", 0.5), train, masks, "f.joint"))
+    ext = torch.cat((extended_attention_mask(am_t, True), extended_attention_mask(am_v, True), extended_attention_mask(am_s, True)), dim=-1)
+    seq = encoder(p, x, ext, cfg["layers"], cfg["heads"], hidden_dropout=hd, attn_dropout=ad, train=train, masks=masks, tag="f.")
+    pooled1 = torch.tanh(_linear(seq[:, 0], p, "bert.pooler.dense"))
+    scores = mlm_scores(p, seq)
+    rel = _linear(seq[:, 0], p, "cls.align")
+    V = scores.shape[-1]
+    mlm = F.cross_entropy(scores.view(-1, V), masked_labels.view(-1).long())
+    ap = (F.cross_entropy(rel.view(-1, 2), ap_v.view(-1).long()) + F.cross_entropy(rel.view(-1, 2), ap_s.view(-1).long())) / 2.0
+
+    def gate(xx, vname):
+        a = F.relu(_linear(torch.cat((xx, xx), dim=1), p, "attn"))
+        return _linear(a, p, vname)
+    pooled = torch.cat((pooled1 * gate(pooled1, "vt"), pooled1 * gate(pooled1, "vv"), pooled1 * gate(pooled1, "vs")), dim=1)
+    temp = _linear(pooled, p, "classifier1_1")
+    logits = _linear(temp, p, "classifier1_2")
+    nce = cpc(p, "cpc_zt", pooled1, temp) + cpc(p, "cpc_zv", pooled1, temp) + cpc(p, "cpc_za", pooled1, temp)
+    if cfg.get("num_labels", 7) == 1:
+        logits = torch.tanh(logits)
+    label = F.mse_loss(logits.view(-1), sentiment.view(-1).float())
+    joint_loss = cfg.get("alpha", 1.0) * mlm + ap + label - cfg.get("beta", 1.0) * nce
+    return (joint_loss, None, None, None, ap, label, nce, scores, rel), logits
+
+
 # ----------------------------------------------------------------------------------------------
 # parameter construction (shapes + init of the reference flow, used by tests and cpu_baseline)
 # ----------------------------------------------------------------------------------------------

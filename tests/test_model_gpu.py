@@ -15,7 +15,7 @@ import torch
 pytestmark = pytest.mark.gpu
 
 from oracle import mmbert_oracle as O
-from msa_amd.data import synthetic_batch, batch_to
+from msa_amd.data import synthetic_batch, batch_to, to_fused
 
 DEV = "cuda"
 CFG1 = dict(hidden=128, layers=2, heads=2, intermediate=512, vocab=30522, dataset="mosei", alpha=1.0, beta=1.0)
@@ -172,6 +172,42 @@ def test_full_size_long_fusion_step_is_finite_and_seeded():
     m.zero_grad()
     m.manual_seed(5)
     assert float(m(**batch)[0][0]) == a
+
+
+def test_fused_sequence_extension_matches_its_oracle():
+    """forward_fused (text | visual | speech in ONE sequence: a declared extension, BASELINE's "fused seq_len~1050" shape class)
+    against oracle.fused_forward, the same extension of the CPU restatement: losses, regression logits, MLM scores, and the
+    gradients of every embedding / encoder / MLM-head parameter; unequal block lengths (the two pair blocks sit at different
+    offsets of every sequence)."""
+    cfg = dict(CFG1, vocab=4096)
+    batch = to_fused(synthetic_batch(3, 24, 70, 33, dataset=cfg["dataset"], vocab=cfg["vocab"], seed=12))
+    p = {k: v.clone().requires_grad_(True) for k, v in O.seeded_params(cfg).items()}
+    ocfg = dict(cfg, hidden_dropout=0.0, attn_dropout=0.0, joint_dropout=0.0)
+    oout, ologits = O.fused_forward(p, ocfg, **batch)
+    oout[0].mean().backward()
+    m = build(cfg)
+    out, logits = m.forward_fused(**batch_to(batch, DEV))
+    for i, name in ((0, "joint"), (4, "ap"), (5, "label"), (6, "nce")):
+        assert rel(out[i].detach(), oout[i].detach()) < 3e-3, (name, float(out[i]), float(oout[i]))
+    assert float((logits.float().cpu() - ologits.detach()).abs().max()) < 2e-2
+    assert tuple(out[7].shape) == tuple(oout[7].shape) == (3, 24 + 70 + 33, cfg["vocab"])
+    assert float((out[7].float().cpu() - oout[7].detach()).abs().max()) < 3e-2
+    assert float((out[8].float().cpu() - oout[8].detach()).abs().max()) < 2e-2
+    out[0].mean().backward()
+    torch.cuda.synchronize()
+    checked = 0
+    for n, q in m.named_parameters():
+        og = p[n].grad
+        if og is None or float(og.abs().sum()) == 0.0 or "attention.self.key.bias" in n:
+            continue
+        if not n.startswith(("bert.embeddings", "bert.encoder", "bert.jointEmbeddings", "cls.predictions")):
+            continue            # [B,H]-sized head gradients: ill-conditioned at init, bounded in check_against_oracle's calibrated form
+        dev_ = float((q.grad.float().cpu() - og).norm() / og.norm())
+        assert dev_ < 0.045, (n, dev_)
+        checked += 1
+    assert checked > 30
+    # both projection matrices received a gradient (each pair block found its rows)
+    assert float(m.bert.jointEmbeddings.Wv.weight.grad.abs().sum()) > 0 and float(m.bert.jointEmbeddings.Ws.weight.grad.abs().sum()) > 0
 
 
 def test_dropout_train_mode_is_seeded_and_unbiased():
