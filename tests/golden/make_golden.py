@@ -44,6 +44,7 @@ import MMBertForPretraining as M                    # noqa: E402
 
 from oracle import mmbert_oracle as O               # noqa: E402
 from msa_amd.data import synthetic_batch            # noqa: E402
+from tests.golden.dataset_features import synthetic_features   # noqa: E402
 
 OUT = os.path.dirname(os.path.abspath(__file__))
 torch.set_num_threads(8)
@@ -205,6 +206,41 @@ def gen_collate():
     print("collate ok")
 
 
+def gen_dataset():
+    """MMBertDataset.__getitem__ (REF:MMBertDataset.py:194-202) and collate of three of its items under a seeded
+    `random`, for every (dataset, task, num_labels) rule of sentiment_selection."""
+    import random
+    import MMBertDataset as refds
+    import model_utils
+    refds.cudas = torch.device("cpu")
+    d = {}
+    cases = [("mosei", "sentiment", 1), ("mosei", "sentiment", 7), ("mosei", "sentiment", 2), ("mosei", "happy", 2),
+             ("mosei", "sad", 6), ("mosi", "sentiment", 1), ("mosi", "sentiment", 2), ("ur_funny", "sentiment", 2)]
+    for ci, (ds_name, task, nl) in enumerate(cases):
+        feats = synthetic_features(dataset=ds_name, seed=11 + ci)
+        ds = refds.MMBertDataset(None, feats, ds_name, task, nl)
+        random.seed(100 + ci)
+        tag = f"c{ci}"
+        d[tag + "/meta"] = np.array([ds_name, task, str(nl)])
+        for i in range(len(ds)):
+            item = ds[i]
+            for f, v in enumerate(item[:14]):
+                a = np.asarray(v.detach().numpy() if torch.is_tensor(v) else v)
+                d[f"{tag}/item{i}/f{f}"] = a[:, :4] if f in (5, 10) else a          # pair features: 4 columns identify the source item
+                if torch.is_tensor(v):
+                    d[f"{tag}/item{i}/f{f}_dtype"] = np.array(str(v.dtype))
+        random.seed(200 + ci)
+        text_b, vis_b, sp_b, att_b, seg, raw = model_utils.collate([ds[i] for i in (0, 3, 4, 2)])
+        for gname, grp in (("text", text_b), ("visual", vis_b), ("speech", sp_b), ("attention", att_b)):
+            for i, t in enumerate(grp):
+                a = np_(t)
+                d[f"{tag}/batch/{gname}{i}"] = a[..., :4] if a.ndim == 3 else a       # feature tensors / their masks: 4 columns
+                d[f"{tag}/batch/{gname}{i}_dtype"] = np.array(str(t.dtype))
+        d[f"{tag}/batch/seg"] = np.array(seg)
+    np.savez_compressed(os.path.join(OUT, "dataset.npz"), **d)
+    print("dataset ok", len(d), "arrays")
+
+
 def gen_train(cfg):
     """G8: four micro-batches through REF trainer.train_epoch (dropout 0, mlm off so that no torch
     RNG enters the arithmetic), torch.optim.AdamW(eps=1e-6) + linear warm-up.  Pins the
@@ -276,6 +312,9 @@ def gen_train(cfg):
 
 
 if __name__ == "__main__":
+    if sys.argv[1:] == ["dataset"]:                 # only the MMBertDataset fixture (the others are unchanged)
+        gen_dataset()
+        sys.exit(0)
     gen_units(CFG1)
     gen_collate()
     gen_full("cfg1_T50_P64", CFG1, 2, 50, 64, 64, seed=1)
@@ -283,6 +322,7 @@ if __name__ == "__main__":
     gen_full("h64_L1_T16_P24x40", dict(CFG1, hidden=64, layers=1, heads=4, intermediate=128, vocab=2048,
                                        alpha=0.7, beta=0.3), 3, 16, 24, 40, seed=3)
     gen_train(dict(CFG1, vocab=4096))
+    gen_dataset()
     for f in sorted(os.listdir(OUT)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(OUT, f)) // 1024, "KiB")

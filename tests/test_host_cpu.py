@@ -155,3 +155,84 @@ def test_make_date_dir_counts_up(tmp_path):
     a = T.make_date_dir(str(tmp_path / "model_save"))
     b = T.make_date_dir(str(tmp_path / "model_save"))
     assert a != b and os.path.isdir(a) and os.path.isdir(b) and a.endswith("-00") and b.endswith("-01")
+
+
+# ------------------------------------------------------------------------------- MMBertDataset / device batch builder
+def _np(v):
+    return np.asarray(v.detach().numpy() if torch.is_tensor(v) else v)
+
+
+def test_dataset_items_and_batches_match_the_reference(golden_dir):
+    """msa_amd.dataset.MMBertDataset against the REAL reference class (tests/golden/make_golden.py:gen_dataset) on the same
+    synthetic items under the same seeded `random`: every field of every item (values, dtypes, the label-1-for-the-true-pair
+    quirk, the self-paired last item), every sentiment rule, then collate() of four items -- and the device batch builder's
+    batch for the same indices from the same `random` state (fp32 features, otherwise identical)."""
+    import random
+    from tests.golden.dataset_features import synthetic_features
+    from msa_amd.dataset import MMBertDataset, DeviceBatchBuilder
+    g = np.load(os.path.join(golden_dir, "dataset.npz"))
+    ncases = len({k.split("/")[0] for k in g.files})
+    assert ncases == 8
+    for ci in range(ncases):
+        tag = f"c{ci}"
+        ds_name, task, nl = (str(x) for x in g[tag + "/meta"])
+        feats = synthetic_features(dataset=ds_name, seed=11 + ci)
+        ds = MMBertDataset(None, feats, ds_name, task, int(nl))
+        random.seed(100 + ci)
+        paired = 0
+        for i in range(len(ds)):
+            item = ds[i]
+            assert len(item) == 16 and item[14] == "seg%d" % i
+            for f, v in enumerate(item[:14]):
+                a = _np(v)
+                a = a[:, :4] if f in (5, 10) else a
+                ref = g[f"{tag}/item{i}/f{f}"]
+                assert a.shape == ref.shape and np.array_equal(a, ref), (tag, i, f)
+                if torch.is_tensor(v):
+                    assert str(v.dtype) == str(g[f"{tag}/item{i}/f{f}_dtype"]), (tag, i, f, v.dtype)
+            paired += int(item[6]) + int(item[11])
+        assert int(ds[len(ds) - 1][6]) == 1                        # last item: always its own pair, label 1
+        # collate of the build's items == collate of the reference's items
+        random.seed(200 + ci)
+        idx = (0, 3, 4, 2)
+        batch = T.collate([ds[i] for i in idx])
+        random.seed(200 + ci)
+        dbatch = DeviceBatchBuilder(ds, "cpu").batch(idx)
+        for which, bt in (("collate", batch), ("device builder", dbatch)):
+            for gname, grp in (("text", bt[0]), ("visual", bt[1]), ("speech", bt[2]), ("attention", bt[3])):
+                for i, t in enumerate(grp):
+                    ref = g[f"{tag}/batch/{gname}{i}"]
+                    a = _np(t)
+                    a = a[..., :4] if a.ndim == 3 else a
+                    is_feature = gname in ("visual", "speech") and i == 1
+                    if which == "device builder" and is_feature:
+                        assert t.dtype == torch.float32 and np.array_equal(a, ref.astype(np.float32)), (tag, gname, i)
+                    else:
+                        assert np.array_equal(a, ref), (which, tag, gname, i)
+                        assert str(t.dtype) == str(g[f"{tag}/batch/{gname}{i}_dtype"]), (which, tag, gname, i, t.dtype)
+            assert list(bt[4]) == [str(x) for x in g[f"{tag}/batch/seg"]]
+
+
+def test_device_batch_feeds_pack_step_inputs():
+    """The builder's batch goes through the trainer's packing unchanged (labels duplicated for the pair positions when
+    P == T, REF:trainer.py:50,53) and yields the model's six keyword arguments."""
+    from tests.golden.dataset_features import synthetic_features
+    from msa_amd.dataset import MMBertDataset, DeviceBatchBuilder
+    ds = MMBertDataset(None, synthetic_features(n_items=6, L=10, seed=3), "mosei", "sentiment", 1)
+    b = DeviceBatchBuilder(ds, "cpu").batch([1, 4, 5])
+    args = T.default_args(mlm=True, mlm_probability=0.3)
+    kw = T.pack_step_inputs(b, args, "cpu", generator=torch.Generator().manual_seed(0))
+    assert set(kw) == {"input_ids", "token_type_ids", "attention_mask", "masked_labels", "ap_label", "sentiment"}
+    assert kw["input_ids"][1].shape == (3, 10, 35) and kw["input_ids"][2].shape == (3, 10, 74)
+    assert kw["masked_labels"][1].shape == (3, 20) and kw["sentiment"].dtype == torch.float32
+    # an epoch: every item exactly once over the rank shards, same permutation on every rank, short last batch kept
+    bld = DeviceBatchBuilder(ds, "cpu")
+    seen = []
+    for rank in range(2):
+        orig, got = bld.batch, []
+        bld.batch = lambda idx, _o=orig, _g=got: (_g.extend(idx), _o(idx))[1]
+        sizes = [kw["input_ids"][0].shape[0] for kw in bld.epoch(args, batch_size=2, generator=torch.Generator().manual_seed(9), rank=rank, world=2)]
+        bld.batch = orig
+        assert sizes == [2, 1]
+        seen += got
+    assert sorted(seen) == list(range(6))
