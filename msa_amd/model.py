@@ -168,7 +168,7 @@ class JointEmbeddings(nn.Module):
         B, T, H = input_embs.shape
         e1 = input_embs.reshape(B * T, H).to(torch.bfloat16)
         drop = ops.make_drop(self.dropout_prob if self.training else 0.0, top._next_seed(), 1001)
-        out = _JointFn.apply(e1, self.LayerNorm.weight, top, pair_ids.float().contiguous(), self.which(pair_ids), B, T, drop)
+        out = _JointFn.apply(e1, self.LayerNorm.weight, top, (pair_ids.float().contiguous(),), (self.which(pair_ids),), B, T, drop)
         return out.view(B, -1, H).float()
 
 

@@ -58,11 +58,14 @@ def rel(a, b):
 def check_against_oracle(cfg, B, T, Pv, Pa, seed, loss_tol=3e-3):
     batch = synthetic_batch(B, T, Pv, Pa, dataset=cfg["dataset"], vocab=cfg["vocab"], seed=seed)
     p, oout, ologits = oracle_run(cfg, batch)
-    pe, _, _ = oracle_run(cfg, batch, emulate_bf16=True)        # calibrator: what bf16 storage alone does to each gradient
+    pe, eout, _ = oracle_run(cfg, batch, emulate_bf16=True)     # calibrator: what bf16 storage alone does to each loss / gradient
     m = build(cfg)
     out, logits = m(**batch_to(batch, DEV))
     for i, name in ((0, "joint"), (4, "ap"), (5, "label"), (6, "nce")):
-        assert rel(out[i], oout[i]) < loss_tol, (name, float(out[i]), float(oout[i]))
+        # 3e-3 relative, or 3x the deviation bf16 STORAGE alone causes in the oracle where that is larger (the 2-way alignment
+        # CE of a 2-sample batch at H = 1024 moves by 1.9e-3 under storage rounding alone)
+        tol = max(loss_tol, 3.0 * rel(eout[i].detach(), oout[i].detach()))
+        assert rel(out[i].detach(), oout[i].detach()) < tol, (name, float(out[i]), float(oout[i]), tol)
     assert out[1] is None and out[2] is None and out[3] is None
     assert float((logits.float().cpu() - ologits.detach()).abs().max()) < 2e-2
     V = cfg["vocab"]
@@ -136,6 +139,13 @@ def test_cfg1_matches_reference_golden(golden_dir):
 def test_bert_base_shapes_two_layers_match_oracle():
     cfg = dict(hidden=768, layers=2, heads=12, intermediate=3072, vocab=30522, dataset="mosei", alpha=1.0, beta=1.0)
     check_against_oracle(cfg, 2, 50, 500, 500, seed=5)
+
+
+def test_bert_large_width_matches_oracle():
+    """The reference's own default width (TEXTDIM = 1024, CPC x_size 1024: REF:config.py:12, REF:MMBertForPretraining.py:327-344
+    -- bert-large: 16 heads, I = 4096), two layers."""
+    cfg = dict(hidden=1024, layers=2, heads=16, intermediate=4096, vocab=8192, dataset="mosei", alpha=1.0, beta=1.0)
+    check_against_oracle(cfg, 2, 50, 96, 80, seed=8)
 
 
 def test_mosi_dims_and_unequal_pair_lengths():
