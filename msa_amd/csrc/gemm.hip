@@ -962,7 +962,9 @@ static int launch_nt256(hipStream_t s, const GemmNT& p) {
     const bool can_persist = g_nt_persist && ntp_eligible(p);
     if (g_nt_bm == 0) {
         // default: the 224-row form.  The 256-row staggered form (mode 6) wins 1-7 % on single-round and very wide shapes in
-        // isolation (tools/bench_gemm.py) but not in the train step (same box, bench.py: 797 vs 805 samples/s): not the default.
+        // isolation (tools/bench_gemm.py MODES=6,7; after the epilogue rewrite: N = 768 shapes -4..-6 %, vocabulary -6 %, QKV
+        // equal, GELU epilogues +8..9 %) but not in the train step, neither everywhere (797 vs 805 samples/s) nor chosen per
+        // launch by rounds x relative tile time (815 vs 820, two alternating runs on one box): not the default.
         if (can_persist) return launch_ntp_mi<EPI, 7>(s, p);
         return r224 <= r256 ? launch_nt256_mi<EPI, 7>(s, p) : launch_nt256_mi<EPI, 8>(s, p);
     }
