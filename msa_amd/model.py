@@ -311,12 +311,26 @@ class _EncoderFn(torch.autograd.Function):
         return dy, None, None, None, None, None
 
 
+def mlm_active_rows(labels, vocab):
+    """(row list on the device, its COUNT in a pinned host word, event): which packed rows carry an MLM label.  The count
+    travels by an async copy; issue this as EARLY in the forward pass as the labels exist -- the sparse MLM backward
+    synchronises on the event, and a copy issued at the end of forward would make the host wait at the start of every
+    backward until the GPU has finished the whole forward pass (measured: no throughput difference on one GPU, where the
+    host is far ahead anyway; kept early so that nothing depends on that)."""
+    idx, cnt = ops.active_rows(labels, vocab)
+    host = torch.empty(1, dtype=torch.int32, pin_memory=True)
+    host.copy_(cnt, non_blocking=True)
+    ev = torch.cuda.Event()
+    ev.record()
+    return idx, host, ev
+
+
 class _MLMHeadFn(torch.autograd.Function):
     """decoder(LN(gelu(dense(seq)))) + per-pass CrossEntropy(ignore -100)
     (HF:466-496 via REF:MMBertForPretraining.py:293,381-384).  Returns (loss[nseg], logits or None)."""
 
     @staticmethod
-    def forward(ctx, y, anchor, top, labels, seg_bounds_host, seg_bounds, want_scores):
+    def forward(ctx, y, anchor, top, labels, seg_bounds_host, seg_bounds, want_scores, rows=None):
         cfg, w = top.config, top._w
         M, H = y.shape
         V, Vp = cfg.vocab_size, top._flat.vpad
@@ -330,17 +344,12 @@ class _MLMHeadFn(torch.autograd.Function):
         loss, inv, lse = ops.ce_fwd(logits, V, labels, seg_bounds, nseg)
         ctx.top, ctx.nseg, ctx.keep_logits = top, nseg, want_scores
         ctx.set_materialize_grads(False)      # or autograd zero-fills a [tokens, vocab] gradient for the returned scores
+        # Rows without a label have an exactly-zero CE gradient (ignore_index): backward needs the labelled rows only (~2 % of
+        # the packed tokens).  ``rows`` = (device row list, pinned host count, event), normally made by mlm_active_rows() at
+        # the START of the forward pass, so that the count is on the host long before backward asks for it.
         ctx.rows = None
         if keep and getattr(top, "sparse_mlm_backward", True):
-            # Rows without a label have an exactly-zero CE gradient (ignore_index): backward needs the labelled rows only
-            # (~2 % of the packed tokens).  Their list is built on the device now; the COUNT travels to a pinned host word
-            # by an async copy that is a whole forward pass old when backward asks for it (no pipeline drain).
-            idx, cnt = ops.active_rows(labels, V)
-            host = torch.empty(1, dtype=torch.int32, pin_memory=True)
-            host.copy_(cnt, non_blocking=True)
-            ev = torch.cuda.Event()
-            ev.record()
-            ctx.rows = (idx, host, ev)
+            ctx.rows = rows if rows is not None else mlm_active_rows(labels, V)
         if keep:
             ctx.save_for_backward(y, pre, t0, mean, rstd, t, logits, labels, seg_bounds, inv, lse)
         out_logits = logits if want_scores else None
@@ -354,7 +363,7 @@ class _MLMHeadFn(torch.autograd.Function):
         w = ctx.top._w
         V = ctx.top.config.vocab_size
         if dloss is None:
-            return None, None, None, None, None, None, None
+            return None, None, None, None, None, None, None, None
         gs = dloss.contiguous().float()
         M = y.shape[0]
         if ctx.rows is not None:
@@ -364,7 +373,7 @@ class _MLMHeadFn(torch.autograd.Function):
             if 2 * n <= M:
                 dy = torch.zeros_like(y)
                 if n == 0:
-                    return dy, None, None, None, None, None, None
+                    return dy, None, None, None, None, None, None, None
                 idx = idx_all[:n]
                 sel = idx.long()
                 dl = torch.empty((n, logits.shape[1]), device=y.device, dtype=torch.bfloat16)
@@ -376,7 +385,7 @@ class _MLMHeadFn(torch.autograd.Function):
                 dpre = ops.gelu_bwd(dt0, pre_c)
                 ops.gemm_tn(dpre, y_c, w["g_Wt"], bias_out=w["g_bt"])
                 dy.index_copy_(0, sel, ops.gemm_nt(dpre, w["WtT"]))
-                return dy, None, None, None, None, None, None
+                return dy, None, None, None, None, None, None, None
         # dense path: dlogits with the per-pass upstream gradients folded in; in place unless the scores were handed to the caller
         dl = torch.empty_like(logits) if ctx.keep_logits else logits
         ops.ce_bwd(logits, V, labels, seg_bounds, ctx.nseg, inv, gs, lse, dl)
@@ -386,7 +395,7 @@ class _MLMHeadFn(torch.autograd.Function):
         dpre = ops.gelu_bwd(dt0, pre)
         ops.gemm_tn(dpre, y, w["g_Wt"], bias_out=w["g_bt"])
         dy = ops.gemm_nt(dpre, w["WtT"])
-        return dy, None, None, None, None, None, None
+        return dy, None, None, None, None, None, None, None
 
 
 # ================================================================================================
@@ -874,12 +883,13 @@ class MMBertForPretraining(_GpuModelBase):
         passes = [dict(ids=text_ids, tt=tt_t, mask=am_t),
                   dict(ids=twv, tt=None, mask=am_v[0].to(dev), pair=visual, pair_mask=am_v[1].to(dev)),
                   dict(ids=tws, tt=None, mask=am_s[0].to(dev), pair=speech, pair_mask=am_s[1].to(dev))]
-        y, plan, lens = self._encode(passes)
         H, V = self.config.hidden_size, self.config.vocab_size
         labels = torch.cat((lab_t.reshape(-1), lab_v.reshape(-1), lab_s.reshape(-1))).to(device=dev, dtype=torch.long)
+        rows = mlm_active_rows(labels, V) if (torch.is_grad_enabled() and getattr(self, "sparse_mlm_backward", True) and labels.is_cuda) else None
+        y, plan, lens = self._encode(passes)
         if labels.numel() != y.shape[0]:
             raise ValueError("masked_labels must cover text (+ pair) positions of every pass")
-        mlm, logits = _MLMHeadFn.apply(y, self.cls.predictions.transform.LayerNorm.weight, self, labels, plan["bounds"], plan["bounds_dev"], self.return_scores)
+        mlm, logits = _MLMHeadFn.apply(y, self.cls.predictions.transform.LayerNorm.weight, self, labels, plan["bounds"], plan["bounds_dev"], self.return_scores, rows)
 
         first = y.index_select(0, plan["first"]).float()                             # [3B, H]: [CLS] rows of every sequence
         mlm_loss = (mlm[0] + mlm[1] + mlm[2]) / 3.0                                  # :427
@@ -911,12 +921,13 @@ class MMBertForPretraining(_GpuModelBase):
         dev = text_ids.device
         B, T = text_ids.shape
         passes = [dict(ids=text_ids, tt=token_type_ids, mask=am_t, pair=(visual, speech), pair_mask=(am_v, am_s))]
-        y, plan, lens = self._encode(passes)
         V = self.config.vocab_size
         labels = masked_labels.reshape(-1).to(device=dev, dtype=torch.long)
+        rows = mlm_active_rows(labels, V) if (torch.is_grad_enabled() and getattr(self, "sparse_mlm_backward", True) and labels.is_cuda) else None
+        y, plan, lens = self._encode(passes)
         if labels.numel() != y.shape[0]:
             raise ValueError("masked_labels must cover the text and both pair blocks")
-        mlm, logits = _MLMHeadFn.apply(y, self.cls.predictions.transform.LayerNorm.weight, self, labels, plan["bounds"], plan["bounds_dev"], self.return_scores)
+        mlm, logits = _MLMHeadFn.apply(y, self.cls.predictions.transform.LayerNorm.weight, self, labels, plan["bounds"], plan["bounds_dev"], self.return_scores, rows)
         first = y.index_select(0, plan["first"].repeat(3)).float()                   # the one [CLS] row in the t / v / s slots
         heads_loss, ap_loss, label_loss, nce, logits_out, _t_rel, v_rel, _s_rel = self._run_heads(first, ap_v, ap_s, sentiment, dev, B)
         joint_loss = self.alpha * mlm[0] + heads_loss
