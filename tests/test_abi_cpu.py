@@ -50,3 +50,15 @@ def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         _lib.load()
+
+
+def test_torch_operator_namespace_registers_without_a_gpu():
+    """msa_amd.torch_ops defines torch.ops.mmbert.* (schemas + CUDA / AutogradCUDA kernels); on a CPU tensor an operator
+    raises instead of falling back."""
+    import pytest
+    import torch
+    import msa_amd.torch_ops  # noqa: F401
+    for n in ("linear", "linear_pre", "linear_bwd", "layer_norm", "layer_norm_fwd", "layer_norm_bwd", "attention", "attention_fwd", "attention_bwd"):
+        assert hasattr(torch.ops.mmbert, n), n
+    with pytest.raises((NotImplementedError, RuntimeError)):
+        torch.ops.mmbert.layer_norm(torch.zeros(4, 64), torch.ones(64), torch.zeros(64), 1e-5)
