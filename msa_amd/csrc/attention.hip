@@ -33,6 +33,7 @@ struct AttnArgs {
     float* delta;            // [tokens, heads]
     const float* key_bias;   // per sequence, padded: bias_start[s] + key, entries past the sequence length <= -1e30 (ceil128(S) entries)
     const int* bias_start;
+    const int* kv_len;       // optional, per sequence: the keys at and past kv_len[s] are all masked out (bias <= -10000: attn_kv_len_kernel)
     const int* seq_start; const int* seq_len; const unsigned* elem_base;
     const int* tile_seq; const int* tile_r0;
     int H, heads;
@@ -205,7 +206,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnArgs a) {
     }
 
     const unsigned baddr = lds0 + 16 * g;                    // bias tile: 4 consecutive keys per lane group
-    const int ntile = (S + 63) >> 6;
+    const int ntile = ((a.kv_len ? min(S, a.kv_len[seq]) : S) + 63) >> 6;   // trailing masked-out keys contribute exact zeros: their tiles are skipped
     stage(0, 0);
     // the buffer index must be a compile-time constant: with a runtime index hipcc cannot prove that the
     // fragment reads do not alias the LDS-DMA it has just issued and drains vmcnt(0) in front of them
@@ -393,7 +394,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnArgs a) {
         kaddr[d] = lds0 + 8192 + r * 128 + ((d ^ ((r >> 1) & 3)) << 5) + tp * 8;
     }
     const unsigned baddr = lds0 + 16 * g;
-    const int ntile = (S + 63) >> 6;
+    const int ntile = ((a.kv_len ? min(S, a.kv_len[seq]) : S) + 63) >> 6;   // trailing masked-out keys contribute exact zeros: their tiles are skipped
     stage(0, 0);
     auto tile_body = [&](auto buf_c, int t) {
         constexpr int buf = decltype(buf_c)::value;
@@ -504,7 +505,25 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnArgs a) 
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int seq = a.tile_seq[blockIdx.x], r0 = a.tile_r0[blockIdx.x], head = blockIdx.y;
     const int start = a.seq_start[seq], S = a.seq_len[seq];
-    const bool wave_active = r0 + wave * 32 < S;             // (128-row tiles: S = 550 leaves waves 2, 3 of the fifth tile without rows)
+    // keys at and past Skv are all masked out: p = exp(s - 10000 - lse) underflows to exactly 0, so dK = dV = 0 for them.  A wave
+    // whose 32 keys lie there computes nothing (its zero accumulators are stored at the end); a tile that lies there entirely
+    // stores its zeros and leaves before any staging.
+    const int Skv = a.kv_len ? min(S, a.kv_len[seq]) : S;
+    if (r0 >= Skv) {
+        const int fr_ = lane & 15, g_ = lane >> 4;
+#pragma unroll
+        for (int kb_ = 0; kb_ < 2; ++kb_) {
+            const int k = r0 + wave * 32 + kb_ * 16 + fr_;
+            if (k < S) {
+                bf16_t* drow = a.dqkv + (size_t)(a.seq_start[seq] + k) * a.ld_qkv + head * 64;
+                const bf16x4 z = {(bf16_t)0.0f, (bf16_t)0.0f, (bf16_t)0.0f, (bf16_t)0.0f};
+#pragma unroll
+                for (int d = 0; d < 4; ++d) { *(bf16x4*)(drow + a.H + d * 16 + 4 * g_) = z; *(bf16x4*)(drow + 2 * a.H + d * 16 + 4 * g_) = z; }
+            }
+        }
+        return;
+    }
+    const bool wave_active = r0 + wave * 32 < Skv;           // (also: S = 550 leaves waves 2, 3 of the fifth 128-row tile without rows)
     const int Spad = (S + 3) & ~3;
     const int fr = lane & 15, g = lane >> 4;
     const bf16_t* base = a.qkv + (size_t)start * a.ld_qkv + head * 64;
@@ -685,25 +704,43 @@ __global__ void attn_mask_kernel(uint8_t* out, int S, unsigned elem_base, int he
     }
 }
 
+// Effective key count per sequence: 1 + the last key whose additive bias is above -10000 (the reference's value for a masked
+// key, REF:MMBertForPretraining.py:152-153: (1 - mask) * -10000).  Behind it every key is masked out, its probability
+// exp(s - 10000 - max) underflows to exactly 0 in fp32 (as it does in the reference's fp32 softmax) as long as one key of the
+// row is NOT masked, so the attention kernels skip those key tiles / key blocks and the result is unchanged bit for bit.
+// A sequence with no unmasked key keeps its full length (softmax over equally biased keys is NOT zero).
+__global__ void attn_kv_len_kernel(const float* __restrict__ key_bias, const int* __restrict__ bias_start, const int* __restrict__ seq_len, int nseq, int* __restrict__ out) {
+    const int s = blockIdx.x;
+    if (s >= nseq) return;
+    const int S = seq_len[s];
+    const float* b = key_bias + bias_start[s];
+    int last = -1;
+    for (int k = threadIdx.x; k < S; k += 64)
+        if (b[k] > -10000.0f) last = k;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) last = max(last, __shfl_xor(last, o, 64));
+    if (threadIdx.x == 0) out[s] = last < 0 ? S : last + 1;
+}
+
 extern "C" {
 
 static int fill_args(AttnArgs& a, const void* qkv, int H, int heads, const float* key_bias, const int* bias_start, const int* seq_start, const int* seq_len,
                      const unsigned* elem_base, const int* tile_seq, const int* tile_r0, float* lse,
-                     uint32_t dstream, uint32_t dthr, float dscale) {
+                     uint32_t dstream, uint32_t dthr, float dscale, const int* kv_len) {
     if (heads <= 0 || H != heads * 64) return -1;      // head dim 64 only
     a.qkv = (const bf16_t*)qkv; a.ld_qkv = 3 * H; a.H = H; a.heads = heads; a.key_bias = key_bias; a.bias_start = bias_start;
     a.seq_start = seq_start; a.seq_len = seq_len; a.elem_base = elem_base; a.tile_seq = tile_seq; a.tile_r0 = tile_r0;
     a.lse = lse; a.scale = 0.125f; a.dstream = dstream; a.dthr = dthr; a.dscale = dscale;
-    a.ctx = nullptr; a.dctx = nullptr; a.dqkv = nullptr; a.delta = nullptr;
+    a.ctx = nullptr; a.dctx = nullptr; a.dqkv = nullptr; a.delta = nullptr; a.kv_len = kv_len;
     return 0;
 }
 
 int mmbert_attn_fwd(hipStream_t stream, const void* qkv, void* ctx, float* lse, const float* key_bias, const int* bias_start, int H, int heads,
                     const int* seq_start, const int* seq_len, const unsigned* elem_base, const int* tile_seq, const int* tile_r0, int ntiles,
-                    uint32_t dstream, uint32_t dthr, float dscale) {
+                    uint32_t dstream, uint32_t dthr, float dscale, const int* kv_len) {
     if (ntiles <= 0) return 0;
     AttnArgs a;
-    if (fill_args(a, qkv, H, heads, key_bias, bias_start, seq_start, seq_len, elem_base, tile_seq, tile_r0, lse, dstream, dthr, dscale)) return -1;
+    if (fill_args(a, qkv, H, heads, key_bias, bias_start, seq_start, seq_len, elem_base, tile_seq, tile_r0, lse, dstream, dthr, dscale, kv_len)) return -1;
     a.ctx = (bf16_t*)ctx;
     static const int extra_lds = getenv("MMBERT_ATTN_EXTRA_LDS") ? atoi(getenv("MMBERT_ATTN_EXTRA_LDS")) : 0;   // occupancy experiments
     if (dthr) hipLaunchKernelGGL(attn_fwd_kernel<true>, dim3(ntiles, heads), dim3(256), extra_lds, stream, a);
@@ -715,10 +752,10 @@ int mmbert_attn_fwd(hipStream_t stream, const void* qkv, void* ctx, float* lse, 
 int mmbert_attn_bwd(hipStream_t stream, const void* qkv, const void* ctx, const void* dctx, void* dqkv, const float* lse, float* delta,
                     const float* key_bias, const int* bias_start, int H, int heads, const int* seq_start, const int* seq_len, const unsigned* elem_base,
                     const int* qtile_seq, const int* qtile_r0, int nqtiles, const int* tile_seq, const int* tile_r0, int ntiles,
-                    uint32_t dstream, uint32_t dthr, float dscale) {
+                    uint32_t dstream, uint32_t dthr, float dscale, const int* kv_len) {
     if (ntiles <= 0 || nqtiles <= 0) return 0;
     AttnArgs a;
-    if (fill_args(a, qkv, H, heads, key_bias, bias_start, seq_start, seq_len, elem_base, tile_seq, tile_r0, (float*)lse, dstream, dthr, dscale)) return -1;
+    if (fill_args(a, qkv, H, heads, key_bias, bias_start, seq_start, seq_len, elem_base, tile_seq, tile_r0, (float*)lse, dstream, dthr, dscale, kv_len)) return -1;
     a.ctx = (bf16_t*)ctx; a.dctx = (const bf16_t*)dctx; a.dqkv = (bf16_t*)dqkv; a.delta = delta;
     {
         AttnArgs q = a;
@@ -729,6 +766,13 @@ int mmbert_attn_bwd(hipStream_t stream, const void* qkv, const void* ctx, const 
     }
     if (dthr) hipLaunchKernelGGL(attn_bwd_dkv_kernel<true>, dim3(ntiles, heads), dim3(256), 0, stream, a);
     else hipLaunchKernelGGL(attn_bwd_dkv_kernel<false>, dim3(ntiles, heads), dim3(256), 0, stream, a);
+    MMB_CHECK_LAUNCH();
+    return 0;
+}
+
+int mmbert_attn_kv_len(hipStream_t stream, const float* key_bias, const int* bias_start, const int* seq_len, int nseq, int* kv_len) {
+    if (nseq <= 0) return 0;
+    hipLaunchKernelGGL(attn_kv_len_kernel, dim3(nseq), dim3(64), 0, stream, key_bias, bias_start, seq_len, nseq, kv_len);
     MMB_CHECK_LAUNCH();
     return 0;
 }

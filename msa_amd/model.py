@@ -237,7 +237,7 @@ class _EncoderFn(torch.autograd.Function):
     """L x BertLayer (HF:374-416) over the packed token matrix."""
 
     @staticmethod
-    def forward(ctx, x, anchor, top, layout, key_bias, seed):
+    def forward(ctx, x, anchor, top, layout, key_bias, seed, kv_len=None):
         cfg = top.config
         H, L = cfg.hidden_size, cfg.num_hidden_layers
         train = top.training
@@ -250,7 +250,7 @@ class _EncoderFn(torch.autograd.Function):
             lw = top._lw[i]
             d_att, d_h1, d_h2 = (ops.make_drop(pa, seed, 8 * i), ops.make_drop(ph, seed, 8 * i + 1), ops.make_drop(ph, seed, 8 * i + 2))
             qkv = ops.gemm_nt(x, lw["Wqkv"], bias=lw["bqkv"])
-            actx, lse = ops.attn_fwd(qkv, key_bias, layout, H, drop=d_att)
+            actx, lse = ops.attn_fwd(qkv, key_bias, layout, H, drop=d_att, kv_len=kv_len)
             z1 = ops.gemm_nt(actx, lw["Wo"], bias=lw["bo"], resid=x, drop=d_h1)
             y1, m1, r1 = ops.ln_fwd(z1, lw["ln1_g"], lw["ln1_b"], cfg.layer_norm_eps, stats=keep)
             u = torch.empty((x.shape[0], cfg.intermediate_size), device=x.device, dtype=torch.bfloat16) if keep else None
@@ -260,7 +260,7 @@ class _EncoderFn(torch.autograd.Function):
             if keep:
                 saved.append((x, qkv, actx, lse, z1, m1, r1, y1, u, g, z2, m2, r2, d_att, d_h1, d_h2))
             x = y2
-        ctx.top, ctx.layout, ctx.key_bias, ctx.saved = top, layout, key_bias, saved
+        ctx.top, ctx.layout, ctx.key_bias, ctx.saved, ctx.kv_len = top, layout, key_bias, saved, kv_len
         return x
 
     @staticmethod
@@ -286,7 +286,7 @@ class _EncoderFn(torch.autograd.Function):
             if dz1d is None:
                 dz1d = dz1
             dctx = ops.gemm_nt(dz1d, lw["WoT"])
-            dqkv = ops.attn_bwd(qkv, actx, dctx, lse, key_bias, layout, H, drop=d_att)
+            dqkv = ops.attn_bwd(qkv, actx, dctx, lse, key_bias, layout, H, drop=d_att, kv_len=ctx.kv_len)
             dy = ops.gemm_nt(dqkv, lw["WqkvT"], resid=dz1)
             # --- all four weight gradients (+ b1, bqkv gradients on the ones-operand MFMA) of the layer in ONE launch.
             # They are off the critical path of backward; model.overlap_wgrad = True moves them to a side stream (measured: a loss).
@@ -308,7 +308,7 @@ class _EncoderFn(torch.autograd.Function):
         side = top._wgrad_stream()
         if side is not None:
             torch.cuda.current_stream().wait_stream(side)     # optimizer / all-reduce tail see complete gradients
-        return dy, None, None, None, None, None
+        return dy, None, None, None, None, None, None
 
 
 def mlm_active_rows(labels, vocab):
@@ -574,7 +574,9 @@ class _GpuModelBase(nn.Module):
         key_bias = torch.cat(kbs) if len(kbs) > 1 else kbs[0]
         plan = self._plan(lens, B, dev)
         key_bias = ops.pad_key_bias(key_bias, plan["layout"])        # per-sequence padded layout, -1e30 = "no such key"
-        y = _EncoderFn.apply(x, bert.embeddings.LayerNorm.weight, self, plan["layout"], key_bias, seed)
+        # padded pair rows are masked-out keys at the tail of every joint sequence: the attention kernels skip them (exact)
+        kv_len = ops.attn_kv_len(key_bias, plan["layout"]) if getattr(self, "skip_masked_keys", True) else None
+        y = _EncoderFn.apply(x, bert.embeddings.LayerNorm.weight, self, plan["layout"], key_bias, seed, kv_len)
         return y, plan, lens
 
 

@@ -298,7 +298,17 @@ def pad_key_bias(key_bias, layout: "SeqLayout"):
     return out
 
 
-def attn_fwd(qkv, key_bias, layout: SeqLayout, H, *, drop: Drop = None, ctx=None, lse=None):
+def attn_kv_len(key_bias_padded, layout: SeqLayout):
+    """int32 [sequences]: per sequence the count of leading keys behind which every key is masked out (see
+    mmbert_attn_kv_len); pass it to attn_fwd / attn_bwd as ``kv_len`` and they skip those keys (exact)."""
+    assert key_bias_padded.numel() == layout.bias_len and key_bias_padded.dtype == torch.float32
+    out = torch.empty(layout.seq_len.numel(), device=key_bias_padded.device, dtype=torch.int32)
+    _lib.check(_lib.load().mmbert_attn_kv_len(_stream(), key_bias_padded.data_ptr(), layout.bias_start.data_ptr(), layout.seq_len.data_ptr(),
+                                              out.numel(), out.data_ptr()), "mmbert_attn_kv_len")
+    return out
+
+
+def attn_fwd(qkv, key_bias, layout: SeqLayout, H, *, drop: Drop = None, ctx=None, lse=None, kv_len=None):
     """``key_bias``: padded layout (pad_key_bias); a [tokens] vector is padded on the fly."""
     lib = _lib.load()
     M = qkv.shape[0]
@@ -312,11 +322,11 @@ def attn_fwd(qkv, key_bias, layout: SeqLayout, H, *, drop: Drop = None, ctx=None
     d = drop or NO_DROP
     _lib.check(lib.mmbert_attn_fwd(_stream(), qkv.data_ptr(), ctx.data_ptr(), lse.data_ptr(), key_bias.data_ptr(), layout.bias_start.data_ptr(), H, layout.heads,
                                    layout.seq_start.data_ptr(), layout.seq_len.data_ptr(), layout.elem_base.data_ptr(),
-                                   layout.ftile_seq.data_ptr(), layout.ftile_r0.data_ptr(), layout.nftiles, d[0], d[1], d[2]), "mmbert_attn_fwd")
+                                   layout.ftile_seq.data_ptr(), layout.ftile_r0.data_ptr(), layout.nftiles, d[0], d[1], d[2], _ptr(kv_len)), "mmbert_attn_fwd")
     return ctx, lse
 
 
-def attn_bwd(qkv, ctx, dctx, lse, key_bias, layout: SeqLayout, H, *, drop: Drop = None, dqkv=None):
+def attn_bwd(qkv, ctx, dctx, lse, key_bias, layout: SeqLayout, H, *, drop: Drop = None, dqkv=None, kv_len=None):
     lib = _lib.load()
     M = qkv.shape[0]
     if dqkv is None:
@@ -330,7 +340,7 @@ def attn_bwd(qkv, ctx, dctx, lse, key_bias, layout: SeqLayout, H, *, drop: Drop 
                                    key_bias.data_ptr(), layout.bias_start.data_ptr(), H, layout.heads, layout.seq_start.data_ptr(), layout.seq_len.data_ptr(),
                                    layout.elem_base.data_ptr(), layout.ftile_seq.data_ptr(), layout.ftile_r0.data_ptr(), layout.nftiles,
                                    layout.tile_seq.data_ptr(), layout.tile_r0.data_ptr(), layout.ntiles,
-                                   d[0], d[1], d[2]), "mmbert_attn_bwd")
+                                   d[0], d[1], d[2], _ptr(kv_len)), "mmbert_attn_bwd")
     return dqkv
 
 

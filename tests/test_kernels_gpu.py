@@ -344,6 +344,46 @@ def test_attention_is_bitwise_reproducible_and_finite(ops, lens, p):
             assert all(torch.equal(a, b) for a, b in zip(first, cur))
 
 
+@pytest.mark.parametrize("p", [0.0, 0.1])
+def test_attention_skips_trailing_masked_keys_exactly(ops, p):
+    """Keys masked with the reference's -10000 at the tail of a sequence (padded pair rows) have probability exactly 0 in
+    fp32, so the kernels may skip their tiles: context, LSE and all three gradients must be BIT-identical with and without
+    ``kv_len`` -- also with masked keys in the middle, with a fully masked sequence (kv_len = S: nothing skipped, softmax over
+    equally biased keys is uniform) and with a tail that ends inside a tile."""
+    lens, heads, H = [550, 300, 50, 200, 130], 2, 128
+    tails = [230, 100, 0, 200, 2]                      # masked keys at the end of each sequence (sequence 3: every key)
+    M = sum(lens)
+    qkv = bf(rnd(M, 3 * H, seed=51)).to(DEV)
+    dctx = bf(rnd(M, H, seed=52)).to(DEV)
+    bias = torch.zeros(M)
+    bias[torch.rand(M, generator=torch.Generator().manual_seed(53)) < 0.1] = -10000.0
+    s = 0
+    for n, t in zip(lens, tails):
+        if t:
+            bias[s + n - t:s + n] = -10000.0
+        bias[s] = 0.0 if t < n else -10000.0           # keep key 0 of the other sequences valid
+        s += n
+    layout = ops.SeqLayout(lens, heads, DEV)
+    kb = ops.pad_key_bias(bias.to(DEV), layout)
+    kv = ops.attn_kv_len(kb, layout)
+    want = []
+    s = 0
+    for n, t in zip(lens, tails):
+        valid = (bias[s:s + n] > -10000.0).nonzero()
+        want.append(n if valid.numel() == 0 else int(valid.max()) + 1)
+        s += n
+    assert kv.cpu().tolist() == want and want[0] <= 320 and want[3] == 200
+    drop = ops.make_drop(p, 99, 3)
+    ctx0, lse0 = ops.attn_fwd(qkv, kb, layout, H, drop=drop)
+    d0 = ops.attn_bwd(qkv, ctx0, dctx, lse0, kb, layout, H, drop=drop)
+    ctx1, lse1 = ops.attn_fwd(qkv, kb, layout, H, drop=drop, kv_len=kv)
+    d1 = ops.attn_bwd(qkv, ctx1, dctx, lse1, kb, layout, H, drop=drop, kv_len=kv)
+    assert torch.equal(ctx0, ctx1) and torch.equal(lse0, lse1) and torch.equal(d0, d1)
+    assert bool(torch.isfinite(d1.float()).all())
+    # the gradients of fully masked trailing keys are exact zeros
+    assert float(d1[320:550, H:].abs().max()) == 0.0
+
+
 def test_attention_rescale_branch(ops):
     """Force the running max to jump at a later key tile (guide rule 26): spike one key."""
     n, heads, H = 200, 1, 64
