@@ -55,6 +55,7 @@ def main():
     ap.add_argument("--overlap-wgrad", action="store_true", help="weight-gradient GEMMs on a side stream (measured slower)")
     ap.add_argument("--eval-dropout-off", action="store_true", help="diagnostic only: not a valid headline number")
     ap.add_argument("--no-skip-masked-keys", action="store_true", help="A/B: attention also visits the key tiles that are entirely masked out")
+    ap.add_argument("--no-skip-padded-backward", action="store_true", help="A/B: backward also runs on the rows whose gradients are exactly zero")
     a = ap.parse_args()
 
     from msa_amd import ops, parallel
@@ -79,6 +80,7 @@ def main():
     model.manual_seed(1234 + rank)
     model.overlap_wgrad = a.overlap_wgrad
     model.skip_masked_keys = not a.no_skip_masked_keys
+    model.skip_padded_backward = not a.no_skip_padded_backward
     model.return_scores = True            # the reference returns the six score tensors; keep them materialised
     targs = default_args(train_batch_size=a.batch, learning_rate=5e-5)
     opt, sched = build_optimizer(model, targs, num_train_optimization_steps=10 * (a.steps + a.warmup))

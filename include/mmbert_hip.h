@@ -115,17 +115,23 @@ size_t mmbert_pair_proj_bwd_workspace(int B, int P, int D, int H);
  * list for forward and one for backward; elem_base[s] (multiples of 4) are the dropout index bases.
  * kv_len (may be null): per sequence, the count of leading keys behind which EVERY key is masked out (bias <= -10000, the
  * reference's value for a masked key); mmbert_attn_kv_len derives it from the padded key bias.  Those trailing keys have
- * probability exactly 0 in fp32 -- in the reference's softmax too --, so the kernels skip their tiles: same result. */
+ * probability exactly 0 in fp32 -- in the reference's softmax too --, so the kernels skip their tiles: same result.
+ * Split ("valid-first") layout, optional: the rows of a sequence need not be contiguous for the QUERY side -- tile t reads
+ * its queries (and writes their outputs) at packed row tile_qshift[t] + (index in the sequence), for indices below
+ * tile_qend[t]; keys/values stay at seq_start[s] + index.  bwd with split != 0 (needs kv_len): a sequence owns only its first
+ * kv_len[s] rows at seq_start[s], and only those queries carry a gradient (model.py packs the masked-out rows of all
+ * sequences behind the others and runs backward on the leading rows only). */
 int mmbert_attn_tile_rows(int which);   /* rows per entry of the tile lists: which = 0 forward, 1 backward */
 int mmbert_attn_kv_len(mmbert_stream_t stream, const float* key_bias, const int* bias_start, const int* seq_len, int nseq, int* kv_len);
 int mmbert_attn_fwd(mmbert_stream_t stream, const void* qkv, void* ctx, float* lse, const float* key_bias, const int* bias_start, int H, int heads,
                     const int* seq_start, const int* seq_len, const unsigned* elem_base, const int* tile_seq, const int* tile_r0, int ntiles,
-                    uint32_t dstream, uint32_t dthr, float dscale, const int* kv_len);
+                    uint32_t dstream, uint32_t dthr, float dscale, const int* kv_len, const int* tile_qshift, const int* tile_qend);
 int mmbert_attn_bwd(mmbert_stream_t stream, const void* qkv, const void* ctx, const void* dctx, void* dqkv, const float* lse, float* delta,
                     const float* key_bias, const int* bias_start, int H, int heads, const int* seq_start, const int* seq_len, const unsigned* elem_base,
                     const int* qtile_seq, const int* qtile_r0, int nqtiles,      /* query tiles: mmbert_attn_tile_rows(0) rows */
                     const int* tile_seq, const int* tile_r0, int ntiles,         /* key tiles:   mmbert_attn_tile_rows(1) rows */
-                    uint32_t dstream, uint32_t dthr, float dscale, const int* kv_len);
+                    uint32_t dstream, uint32_t dthr, float dscale, const int* kv_len,
+                    const int* qtile_qshift, const int* qtile_qend, int split);
 int mmbert_attn_dropout_mask(mmbert_stream_t stream, uint8_t* out, int S, unsigned elem_base, int head, uint32_t rng_stream, uint32_t thr16);
 
 /* ---- vocabulary cross-entropy (ignore_index -100), per-pass means ----

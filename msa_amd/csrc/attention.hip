@@ -36,6 +36,9 @@ struct AttnArgs {
     const int* kv_len;       // optional, per sequence: the keys at and past kv_len[s] are all masked out (bias <= -10000: attn_kv_len_kernel)
     const int* seq_start; const int* seq_len; const unsigned* elem_base;
     const int* tile_seq; const int* tile_r0;
+    // split (valid-first) layout, all optional: the QUERY rows of tile t sit at packed row tile_qshift[t] + (index in the sequence)
+    // and end at index tile_qend[t]; split != 0: a sequence owns only its first kv_len[s] rows at seq_start[s] (dK/dV kernel)
+    const int* tile_qshift; const int* tile_qend; int split;
     int H, heads;
     float scale;
     uint32_t dstream, dthr; float dscale;
@@ -148,10 +151,14 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnArgs a) {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int seq = a.tile_seq[blockIdx.x], r0 = a.tile_r0[blockIdx.x], head = blockIdx.y;
     const int start = a.seq_start[seq], S = a.seq_len[seq];
-    const bool wave_active = r0 + wave * 32 < S;             // (128-row tiles: S = 550 leaves waves 2, 3 of the fifth tile without rows)
+    const int qshift = a.tile_qshift ? a.tile_qshift[blockIdx.x] : start;     // packed row of query index 0
+    const int Sq = a.tile_qend ? a.tile_qend[blockIdx.x] : S;                 // query indices of this tile end here
+    const int Skv = a.kv_len ? min(S, a.kv_len[seq]) : S;                     // keys at and past Skv are all masked out
+    const bool wave_active = r0 + wave * 32 < Sq;            // (128-row tiles: S = 550 leaves waves 2, 3 of the fifth tile without rows)
     const int Spad = (S + 3) & ~3;
     const int fr = lane & 15, g = lane >> 4;
     const bf16_t* base = a.qkv + (size_t)start * a.ld_qkv + head * 64;
+    const bf16_t* qbase = a.qkv + (size_t)qshift * a.ld_qkv + head * 64;
     const bf16_t* kbase = base + a.H;
     const bf16_t* vbase = base + 2 * a.H;
     const float* bbase = a.key_bias + a.bias_start[seq];
@@ -161,10 +168,10 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnArgs a) {
 #pragma unroll
     for (int qb = 0; qb < 2; ++qb) {
         qi[qb] = r0 + wave * 32 + qb * 16 + fr;
-        qc[qb] = min(qi[qb], S - 1);
+        qc[qb] = min(qi[qb], Sq - 1);
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
-            qf[qb][kk] = *(const bf16x8*)(base + (size_t)qc[qb] * a.ld_qkv + kk * 32 + 8 * g);
+            qf[qb][kk] = *(const bf16x8*)(qbase + (size_t)qc[qb] * a.ld_qkv + kk * 32 + 8 * g);
 #pragma unroll
             for (int j = 0; j < 8; ++j) qf[qb][kk][j] = f2bf(bf2f(qf[qb][kk][j]) * a.scale);   // 1/8: exact in bf16; the accumulator is q.k/8
         }
@@ -175,8 +182,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnArgs a) {
 
     auto stage = [&](int buf, int kv0) {
         char* B = smem + buf * FWD_BUF;
-        stage_tile<0>(B, kbase, a.ld_qkv, kv0, S, wave, lane);
-        stage_tile<1>(B + 8192, vbase, a.ld_qkv, kv0, S, wave, lane);
+        stage_tile<0>(B, kbase, a.ld_qkv, kv0, Skv, wave, lane);
+        stage_tile<1>(B + 8192, vbase, a.ld_qkv, kv0, Skv, wave, lane);
         // 64 bias floats (padded array: keys past the end read -1e30 -> p = 0, no per-tile range logic);
         // every wave writes the same 256 B (identical data) so that all waves keep the same vmcnt
         __builtin_amdgcn_global_load_lds(GPTR(bbase + kv0 + lane), LPTR(B + 16384), 4, 0, 0);
@@ -206,7 +213,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnArgs a) {
     }
 
     const unsigned baddr = lds0 + 16 * g;                    // bias tile: 4 consecutive keys per lane group
-    const int ntile = ((a.kv_len ? min(S, a.kv_len[seq]) : S) + 63) >> 6;   // trailing masked-out keys contribute exact zeros: their tiles are skipped
+    const int ntile = (Skv + 63) >> 6;                       // trailing masked-out keys contribute exact zeros: their tiles are skipped
     stage(0, 0);
     // the buffer index must be a compile-time constant: with a runtime index hipcc cannot prove that the
     // fragment reads do not alias the LDS-DMA it has just issued and drains vmcnt(0) in front of them
@@ -307,15 +314,15 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnArgs a) {
 #pragma unroll
     for (int qb = 0; qb < 2; ++qb) {
         const float l = lacc[qb][0];
-        if (qi[qb] < S) {
+        if (qi[qb] < Sq) {
             const float inv = a.dscale / l;                  // dropout scale folded into the normalisation
-            bf16_t* orow = a.ctx + (size_t)(start + qi[qb]) * a.H + head * 64;
+            bf16_t* orow = a.ctx + (size_t)(qshift + qi[qb]) * a.H + head * 64;
 #pragma unroll
             for (int d = 0; d < 4; ++d) {
                 bf16x4 ov = {f2bf(o[qb][d][0] * inv), f2bf(o[qb][d][1] * inv), f2bf(o[qb][d][2] * inv), f2bf(o[qb][d][3] * inv)};
                 *(bf16x4*)(orow + d * 16 + 4 * g) = ov;
             }
-            if (g == 0) a.lse[(size_t)(start + qi[qb]) * a.heads + head] = (mraw[qb] * c2 + log2f(l)) * LN2;
+            if (g == 0) a.lse[(size_t)(qshift + qi[qb]) * a.heads + head] = (mraw[qb] * c2 + log2f(l)) * LN2;
         }
     }
 }
@@ -336,12 +343,16 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnArgs a) {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int seq = a.tile_seq[blockIdx.x], r0 = a.tile_r0[blockIdx.x], head = blockIdx.y;
     const int start = a.seq_start[seq], S = a.seq_len[seq];
-    const bool wave_active = r0 + wave * 32 < S;             // (128-row tiles: S = 550 leaves waves 2, 3 of the fifth tile without rows)
+    const int qshift = a.tile_qshift ? a.tile_qshift[blockIdx.x] : start;
+    const int Sq = a.tile_qend ? a.tile_qend[blockIdx.x] : S;
+    const int Skv = a.kv_len ? min(S, a.kv_len[seq]) : S;
+    const bool wave_active = r0 + wave * 32 < Sq;            // (128-row tiles: S = 550 leaves waves 2, 3 of the fifth tile without rows)
     const int Spad = (S + 3) & ~3;
     const int fr = lane & 15, g = lane >> 4;
     const bf16_t* base = a.qkv + (size_t)start * a.ld_qkv + head * 64;
-    const bf16_t* dob = a.dctx + (size_t)start * a.H + head * 64;
-    const bf16_t* ob = a.ctx + (size_t)start * a.H + head * 64;
+    const bf16_t* qbase = a.qkv + (size_t)qshift * a.ld_qkv + head * 64;
+    const bf16_t* dob = a.dctx + (size_t)qshift * a.H + head * 64;
+    const bf16_t* ob = a.ctx + (size_t)qshift * a.H + head * 64;
     const bf16_t* kbase = base + a.H;
     const bf16_t* vbase = base + 2 * a.H;
     const float* bbase = a.key_bias + a.bias_start[seq];
@@ -353,11 +364,11 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnArgs a) {
 #pragma unroll
     for (int qb = 0; qb < 2; ++qb) {
         qi[qb] = r0 + wave * 32 + qb * 16 + fr;
-        const int qc = min(qi[qb], S - 1);
+        const int qc = min(qi[qb], Sq - 1);
         float dl = 0.f;
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
-            qf[qb][kk] = *(const bf16x8*)(base + (size_t)qc * a.ld_qkv + kk * 32 + 8 * g);
+            qf[qb][kk] = *(const bf16x8*)(qbase + (size_t)qc * a.ld_qkv + kk * 32 + 8 * g);
 #pragma unroll
             for (int j = 0; j < 8; ++j) qf[qb][kk][j] = f2bf(bf2f(qf[qb][kk][j]) * a.scale);   // 1/8: exact in bf16
             dof[qb][kk] = *(const bf16x8*)(dob + (size_t)qc * a.H + kk * 32 + 8 * g);
@@ -366,16 +377,16 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnArgs a) {
             for (int j = 0; j < 8; ++j) dl += bf2f(dof[qb][kk][j]) * bf2f(of[j]);
         }
         delta[qb] = group_sum(dl);
-        if (qi[qb] < S && g == 0) a.delta[(size_t)(start + qi[qb]) * a.heads + head] = delta[qb];
-        nlse[qb] = -a.lse[(size_t)(start + qc) * a.heads + head] * LOG2E;
+        if (qi[qb] < Sq && g == 0) a.delta[(size_t)(qshift + qi[qb]) * a.heads + head] = delta[qb];
+        nlse[qb] = -a.lse[(size_t)(qshift + qc) * a.heads + head] * LOG2E;
         hseed[qb] = ((a.elem_base[seq] + (unsigned)((head * S + qc) * Spad) + 4u * (unsigned)g) >> 1) * MMB_WEYL + a.dstream;
     }
 
     auto stage = [&](int buf, int kv0) {
         char* B = smem + buf * DQ_BUF;
-        stage_tile<0>(B, kbase, a.ld_qkv, kv0, S, wave, lane);
-        stage_tile<1>(B + 8192, kbase, a.ld_qkv, kv0, S, wave, lane);
-        stage_tile<0>(B + 16384, vbase, a.ld_qkv, kv0, S, wave, lane);
+        stage_tile<0>(B, kbase, a.ld_qkv, kv0, Skv, wave, lane);
+        stage_tile<1>(B + 8192, kbase, a.ld_qkv, kv0, Skv, wave, lane);
+        stage_tile<0>(B + 16384, vbase, a.ld_qkv, kv0, Skv, wave, lane);
         __builtin_amdgcn_global_load_lds(GPTR(bbase + kv0 + lane), LPTR(B + 24576), 4, 0, 0);
     };
 
@@ -394,7 +405,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnArgs a) {
         kaddr[d] = lds0 + 8192 + r * 128 + ((d ^ ((r >> 1) & 3)) << 5) + tp * 8;
     }
     const unsigned baddr = lds0 + 16 * g;
-    const int ntile = ((a.kv_len ? min(S, a.kv_len[seq]) : S) + 63) >> 6;   // trailing masked-out keys contribute exact zeros: their tiles are skipped
+    const int ntile = (Skv + 63) >> 6;
     stage(0, 0);
     auto tile_body = [&](auto buf_c, int t) {
         constexpr int buf = decltype(buf_c)::value;
@@ -475,8 +486,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnArgs a) {
     }
 #pragma unroll
     for (int qb = 0; qb < 2; ++qb) {
-        if (qi[qb] < S) {
-            bf16_t* drow = a.dqkv + (size_t)(start + qi[qb]) * a.ld_qkv + head * 64;
+        if (qi[qb] < Sq) {
+            bf16_t* drow = a.dqkv + (size_t)(qshift + qi[qb]) * a.ld_qkv + head * 64;
 #pragma unroll
             for (int d = 0; d < 4; ++d) {
                 bf16x4 ov = {f2bf(dq[qb][d][0] * a.scale), f2bf(dq[qb][d][1] * a.scale), f2bf(dq[qb][d][2] * a.scale), f2bf(dq[qb][d][3] * a.scale)};
@@ -509,12 +520,14 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnArgs a) 
     // whose 32 keys lie there computes nothing (its zero accumulators are stored at the end); a tile that lies there entirely
     // stores its zeros and leaves before any staging.
     const int Skv = a.kv_len ? min(S, a.kv_len[seq]) : S;
+    // split layout: the sequence owns only its first Skv rows here, and only those queries can have a gradient
+    const int Sq = a.split ? Skv : S, Skw = a.split ? Skv : S;
     if (r0 >= Skv) {
         const int fr_ = lane & 15, g_ = lane >> 4;
 #pragma unroll
         for (int kb_ = 0; kb_ < 2; ++kb_) {
             const int k = r0 + wave * 32 + kb_ * 16 + fr_;
-            if (k < S) {
+            if (k < Skw) {
                 bf16_t* drow = a.dqkv + (size_t)(a.seq_start[seq] + k) * a.ld_qkv + head * 64;
                 const bf16x4 z = {(bf16_t)0.0f, (bf16_t)0.0f, (bf16_t)0.0f, (bf16_t)0.0f};
 #pragma unroll
@@ -537,7 +550,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnArgs a) 
 #pragma unroll
     for (int kb_ = 0; kb_ < 2; ++kb_) {
         ki[kb_] = r0 + wave * 32 + kb_ * 16 + fr;
-        kc[kb_] = min(ki[kb_], S - 1);
+        kc[kb_] = min(ki[kb_], Skv - 1);
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
             kf[kb_][kk] = *(const bf16x8*)(base + a.H + (size_t)kc[kb_] * a.ld_qkv + kk * 32 + 8 * g);
@@ -552,11 +565,11 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnArgs a) 
 
     auto stage = [&](int buf, int q0) {
         char* B = smem + buf * DKV_BUF;
-        stage_tile<0>(B, base, a.ld_qkv, q0, S, wave, lane);
-        stage_tile<1>(B + 8192, base, a.ld_qkv, q0, S, wave, lane);
-        stage_tile<0>(B + 16384, dob, a.H, q0, S, wave, lane);
-        stage_tile<1>(B + 24576, dob, a.H, q0, S, wave, lane);
-        const size_t qoff = (size_t)min(q0 + lane, S - 1) * a.heads;
+        stage_tile<0>(B, base, a.ld_qkv, q0, Sq, wave, lane);
+        stage_tile<1>(B + 8192, base, a.ld_qkv, q0, Sq, wave, lane);
+        stage_tile<0>(B + 16384, dob, a.H, q0, Sq, wave, lane);
+        stage_tile<1>(B + 24576, dob, a.H, q0, Sq, wave, lane);
+        const size_t qoff = (size_t)min(q0 + lane, Sq - 1) * a.heads;
         __builtin_amdgcn_global_load_lds(GPTR(lbase + qoff), LPTR(B + 32768), 4, 0, 0);
         __builtin_amdgcn_global_load_lds(GPTR(dbase + qoff), LPTR(B + 33024), 4, 0, 0);
     };
@@ -578,7 +591,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnArgs a) 
     }
     const unsigned saddr2[2] = {lds0 + 16 * g, lds0 + 16 * g + DKV_BUF};   // lse / delta: 4 consecutive query rows per lane group
     const bool odd = lane & 1;
-    const int ntile = (S + 63) >> 6;
+    const int ntile = (Sq + 63) >> 6;
     stage(0, 0);
     auto tile_body = [&](auto buf_c, int t) {
         constexpr int buf = decltype(buf_c)::value;
@@ -599,13 +612,13 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnArgs a) 
         lds_read16<BO + 33024 + 128>(d4[2], saddr); lds_read16<BO + 33024 + 192>(d4[3], saddr);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
-        const bool qtail = q0 + 64 > S;
+        const bool qtail = q0 + 64 > Sq;
 #pragma unroll
         for (int qt = 0; qt < 4; ++qt) {
             l4[qt] = l4[qt] * (-inv_scale);                  // -lse[q]/scale  (natural-log lse: exp2(S*c) with c = scale*log2e)
             if (qtail) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) if (q0 + qt * 16 + 4 * g + r >= S) l4[qt][r] = -INFINITY;   // query rows past the end: p = 0
+                for (int r = 0; r < 4; ++r) if (q0 + qt * 16 + 4 * g + r >= Sq) l4[qt][r] = -INFINITY;   // query rows past the end: p = 0
             }
         }
 #pragma unroll
@@ -682,7 +695,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnArgs a) 
     }
 #pragma unroll
     for (int kb_ = 0; kb_ < 2; ++kb_) {
-        if (ki[kb_] < S) {
+        if (ki[kb_] < Skw) {
             bf16_t* drow = a.dqkv + (size_t)(start + ki[kb_]) * a.ld_qkv + head * 64;
 #pragma unroll
             for (int d = 0; d < 4; ++d) {
@@ -732,16 +745,18 @@ static int fill_args(AttnArgs& a, const void* qkv, int H, int heads, const float
     a.seq_start = seq_start; a.seq_len = seq_len; a.elem_base = elem_base; a.tile_seq = tile_seq; a.tile_r0 = tile_r0;
     a.lse = lse; a.scale = 0.125f; a.dstream = dstream; a.dthr = dthr; a.dscale = dscale;
     a.ctx = nullptr; a.dctx = nullptr; a.dqkv = nullptr; a.delta = nullptr; a.kv_len = kv_len;
+    a.tile_qshift = nullptr; a.tile_qend = nullptr; a.split = 0;
     return 0;
 }
 
 int mmbert_attn_fwd(hipStream_t stream, const void* qkv, void* ctx, float* lse, const float* key_bias, const int* bias_start, int H, int heads,
                     const int* seq_start, const int* seq_len, const unsigned* elem_base, const int* tile_seq, const int* tile_r0, int ntiles,
-                    uint32_t dstream, uint32_t dthr, float dscale, const int* kv_len) {
+                    uint32_t dstream, uint32_t dthr, float dscale, const int* kv_len, const int* tile_qshift, const int* tile_qend) {
     if (ntiles <= 0) return 0;
+    if ((tile_qshift == nullptr) != (tile_qend == nullptr)) return -1;
     AttnArgs a;
     if (fill_args(a, qkv, H, heads, key_bias, bias_start, seq_start, seq_len, elem_base, tile_seq, tile_r0, lse, dstream, dthr, dscale, kv_len)) return -1;
-    a.ctx = (bf16_t*)ctx;
+    a.ctx = (bf16_t*)ctx; a.tile_qshift = tile_qshift; a.tile_qend = tile_qend;
     static const int extra_lds = getenv("MMBERT_ATTN_EXTRA_LDS") ? atoi(getenv("MMBERT_ATTN_EXTRA_LDS")) : 0;   // occupancy experiments
     if (dthr) hipLaunchKernelGGL(attn_fwd_kernel<true>, dim3(ntiles, heads), dim3(256), extra_lds, stream, a);
     else hipLaunchKernelGGL(attn_fwd_kernel<false>, dim3(ntiles, heads), dim3(256), extra_lds, stream, a);
@@ -752,18 +767,20 @@ int mmbert_attn_fwd(hipStream_t stream, const void* qkv, void* ctx, float* lse, 
 int mmbert_attn_bwd(hipStream_t stream, const void* qkv, const void* ctx, const void* dctx, void* dqkv, const float* lse, float* delta,
                     const float* key_bias, const int* bias_start, int H, int heads, const int* seq_start, const int* seq_len, const unsigned* elem_base,
                     const int* qtile_seq, const int* qtile_r0, int nqtiles, const int* tile_seq, const int* tile_r0, int ntiles,
-                    uint32_t dstream, uint32_t dthr, float dscale, const int* kv_len) {
+                    uint32_t dstream, uint32_t dthr, float dscale, const int* kv_len, const int* qtile_qshift, const int* qtile_qend, int split) {
     if (ntiles <= 0 || nqtiles <= 0) return 0;
+    if ((qtile_qshift == nullptr) != (qtile_qend == nullptr) || (split && !kv_len)) return -1;
     AttnArgs a;
     if (fill_args(a, qkv, H, heads, key_bias, bias_start, seq_start, seq_len, elem_base, tile_seq, tile_r0, (float*)lse, dstream, dthr, dscale, kv_len)) return -1;
     a.ctx = (bf16_t*)ctx; a.dctx = (const bf16_t*)dctx; a.dqkv = (bf16_t*)dqkv; a.delta = delta;
     {
         AttnArgs q = a;
-        q.tile_seq = qtile_seq; q.tile_r0 = qtile_r0;
+        q.tile_seq = qtile_seq; q.tile_r0 = qtile_r0; q.tile_qshift = qtile_qshift; q.tile_qend = qtile_qend;
         if (dthr) hipLaunchKernelGGL(attn_bwd_dq_kernel<true>, dim3(nqtiles, heads), dim3(256), 0, stream, q);
         else hipLaunchKernelGGL(attn_bwd_dq_kernel<false>, dim3(nqtiles, heads), dim3(256), 0, stream, q);
         MMB_CHECK_LAUNCH();
     }
+    a.split = split;
     if (dthr) hipLaunchKernelGGL(attn_bwd_dkv_kernel<true>, dim3(ntiles, heads), dim3(256), 0, stream, a);
     else hipLaunchKernelGGL(attn_bwd_dkv_kernel<false>, dim3(ntiles, heads), dim3(256), 0, stream, a);
     MMB_CHECK_LAUNCH();

@@ -269,10 +269,19 @@ class _EncoderFn(torch.autograd.Function):
         H = top.config.hidden_size
         dy = dy.contiguous()
         top._flat.grads_dirty = True
+        # split (valid-first) layout: the rows behind rows_a have exactly-zero gradients in every layer (see _encode), so the
+        # whole backward -- dgrads, weight gradients, LayerNorm', attention -- runs on the leading rows_a rows only
+        M_all = dy.shape[0]
+        ra = layout.rows_a if getattr(layout, "split", False) else M_all
+        if ra < M_all:
+            dy = dy[:ra]
         for i in reversed(range(top.config.num_hidden_layers)):
             lw = top._lw[i]
-            x, qkv, actx, lse, z1, m1, r1, y1, u, g, z2, m2, r2, d_att, d_h1, d_h2 = ctx.saved[i]
+            saved_i = ctx.saved[i]
             ctx.saved[i] = None
+            if ra < M_all:
+                saved_i = tuple(t[:ra] if torch.is_tensor(t) else t for t in saved_i)
+            x, qkv, actx, lse, z1, m1, r1, y1, u, g, z2, m2, r2, d_att, d_h1, d_h2 = saved_i
             # --- output sublayer: y2 = LN(dropout(g.W2^T + b2) + y1)      (b2 / bo gradients come out of ln_bwd)
             dz2d = torch.empty_like(dy) if d_h2[1] else None
             dz2 = ops.ln_bwd(dy, z2, m2, r2, lw["ln2_g"], lw["g_ln2_g"], lw["g_ln2_b"], dx2=dz2d, pre_drop=d_h2, dbias2=lw["g_b2"])
@@ -308,6 +317,10 @@ class _EncoderFn(torch.autograd.Function):
         side = top._wgrad_stream()
         if side is not None:
             torch.cuda.current_stream().wait_stream(side)     # optimizer / all-reduce tail see complete gradients
+        if ra < M_all:
+            full = dy.new_zeros((M_all, dy.shape[1]))
+            full[:ra] = dy
+            dy = full
         return dy, None, None, None, None, None, None
 
 
@@ -519,9 +532,10 @@ class _GpuModelBase(nn.Module):
                     first.append(row + b * S)
                 row += B * S
                 bounds.append(row)
-            pl = dict(layout=ops.SeqLayout(lens, self.config.num_attention_heads, device),
-                      first=torch.tensor(first, dtype=torch.int64, device=device),
-                      bounds=bounds, bounds_dev=torch.tensor(bounds, dtype=torch.int32, device=device))
+            lay = ops.SeqLayout(lens, self.config.num_attention_heads, device)
+            pl = dict(layout=lay, first=torch.tensor(first, dtype=torch.int64, device=device),
+                      bounds=bounds, bounds_dev=torch.tensor(bounds, dtype=torch.int32, device=device),
+                      row_seq=torch.from_numpy(lay._row_seq).to(device), row_pos=torch.from_numpy(lay._row_pos).to(device))
             self._plans[key] = pl
         return pl
 
@@ -536,7 +550,7 @@ class _GpuModelBase(nn.Module):
             raise ValueError("You have so large dimension (), Check dimension or shape ")
         return (1.0 - m.to(device=device, dtype=torch.float32)) * MASK_NEG
 
-    def _encode(self, passes):
+    def _encode(self, passes, labels=None):
         """passes: list of dict(ids[B,T], tt[B,T]|None, mask, pair[B,P,D]|None, pair_mask|None).
         Returns (Y [tokens,H] bf16, plan, lens_per_pass)."""
         bert = self._bert()
@@ -576,8 +590,34 @@ class _GpuModelBase(nn.Module):
         key_bias = ops.pad_key_bias(key_bias, plan["layout"])        # per-sequence padded layout, -1e30 = "no such key"
         # padded pair rows are masked-out keys at the tail of every joint sequence: the attention kernels skip them (exact)
         kv_len = ops.attn_kv_len(key_bias, plan["layout"]) if getattr(self, "skip_masked_keys", True) else None
-        y = _EncoderFn.apply(x, bert.embeddings.LayerNorm.weight, self, plan["layout"], key_bias, seed, kv_len)
+        split = self._split_layout(plan, kv_len, labels) if kv_len is not None else None
+        if split is None:
+            y = _EncoderFn.apply(x, bert.embeddings.LayerNorm.weight, self, plan["layout"], key_bias, seed, kv_len)
+        else:
+            y = _EncoderFn.apply(x.index_select(0, split.perm), bert.embeddings.LayerNorm.weight, self, split, key_bias, seed, None)
+            y = y.index_select(0, split.inv)
         return y, plan, lens
+
+    def _split_layout(self, plan, kv_len, labels):
+        """Backward on the unmasked rows only.  A row behind its sequence's last unmasked key (a padded pair row; a [PAD] row of
+        the text pass) that carries no MLM label has an exactly-zero gradient at the encoder output (the heads read [CLS] rows,
+        the MLM loss ignores it), nothing flows into it through attention (as a key its probability is exactly 0, so dK = dV = 0;
+        as a query dO = 0 gives dS = 0), and every other operator is row-wise -- by induction its gradient is zero in every layer
+        and it adds nothing to any weight gradient.  Forward still computes those rows (the reference returns their prediction
+        scores); they are packed BEHIND all other rows (ops.SplitLayout) so that backward is the same kernels on a shorter
+        matrix.  Needs the lengths on the host: one small blocking copy per step.  Returns None when it does not apply
+        (no labels given -- the caller may then put a gradient anywhere --, a label on such a row, or under 3 % to save)."""
+        if labels is None or not torch.is_grad_enabled() or not getattr(self, "skip_padded_backward", True):
+            return None
+        lay = plan["layout"]
+        bad = ((labels != -100) & (plan["row_pos"] >= kv_len.long().index_select(0, plan["row_seq"]))).sum().to(torch.int32).view(1)
+        host = torch.cat((kv_len, bad)).cpu()                            # the one host sync of the step
+        if int(host[-1]) != 0:
+            return None
+        valid = host[:-1].numpy()
+        if int(valid.sum()) > 0.97 * lay.tokens:
+            return None
+        return ops.SplitLayout(lay, valid, kv_len.device)
 
 
 class MMBertModel(_GpuModelBase):
@@ -888,9 +928,9 @@ class MMBertForPretraining(_GpuModelBase):
         H, V = self.config.hidden_size, self.config.vocab_size
         labels = torch.cat((lab_t.reshape(-1), lab_v.reshape(-1), lab_s.reshape(-1))).to(device=dev, dtype=torch.long)
         rows = mlm_active_rows(labels, V) if (torch.is_grad_enabled() and getattr(self, "sparse_mlm_backward", True) and labels.is_cuda) else None
-        y, plan, lens = self._encode(passes)
-        if labels.numel() != y.shape[0]:
+        if labels.numel() != B * (T + (T + visual.shape[1]) + (T + speech.shape[1])):
             raise ValueError("masked_labels must cover text (+ pair) positions of every pass")
+        y, plan, lens = self._encode(passes, labels)
         mlm, logits = _MLMHeadFn.apply(y, self.cls.predictions.transform.LayerNorm.weight, self, labels, plan["bounds"], plan["bounds_dev"], self.return_scores, rows)
 
         first = y.index_select(0, plan["first"]).float()                             # [3B, H]: [CLS] rows of every sequence
@@ -926,9 +966,9 @@ class MMBertForPretraining(_GpuModelBase):
         V = self.config.vocab_size
         labels = masked_labels.reshape(-1).to(device=dev, dtype=torch.long)
         rows = mlm_active_rows(labels, V) if (torch.is_grad_enabled() and getattr(self, "sparse_mlm_backward", True) and labels.is_cuda) else None
-        y, plan, lens = self._encode(passes)
-        if labels.numel() != y.shape[0]:
+        if labels.numel() != B * (T + visual.shape[1] + speech.shape[1]):
             raise ValueError("masked_labels must cover the text and both pair blocks")
+        y, plan, lens = self._encode(passes, labels)
         mlm, logits = _MLMHeadFn.apply(y, self.cls.predictions.transform.LayerNorm.weight, self, labels, plan["bounds"], plan["bounds_dev"], self.return_scores, rows)
         first = y.index_select(0, plan["first"].repeat(3)).float()                   # the one [CLS] row in the t / v / s slots
         heads_loss, ap_loss, label_loss, nce, logits_out, _t_rel, v_rel, _s_rel = self._run_heads(first, ap_v, ap_s, sentiment, dev, B)

@@ -9,6 +9,7 @@ from __future__ import annotations
 import ctypes
 from typing import Optional, Tuple
 
+import numpy as np
 import torch
 
 from . import _lib
@@ -289,6 +290,55 @@ class SeqLayout:
         self.ftile_seq = mk(ftiles_seq, torch.int32)
         self.ftile_r0 = mk(ftiles_r0, torch.int32)
         self.nftiles = len(ftiles_seq)
+        self._rows_f = rows_f
+        self._row_seq = np.repeat(np.arange(len(lens)), lens)                      # host: sequence of every packed row
+        self._row_pos = np.concatenate([np.arange(n) for n in lens]) if len(lens) else np.zeros(0, np.int64)
+
+
+class SplitLayout:
+    """"Valid-first" packing of the same sequences: the first ``valid[s]`` rows of every sequence back to back (region A,
+    ``rows_a`` rows in all), then the remaining (masked-out) rows of all sequences (region B).  Keys/values of a sequence are its
+    region-A rows; forward visits the queries of both regions, backward only region A -- rows whose keys are masked out and
+    that carry no label have exactly-zero gradients everywhere (model._encode).  ``perm[new] = old`` row, ``inv[old] = new``.
+    Dropout indices, key-bias slots and ``seq_len`` stay those of the ORIGINAL sequences, so masks do not depend on the packing.
+    Built per batch on the host (numpy) and shipped in one copy."""
+
+    def __init__(self, base: SeqLayout, valid, device):
+        lens = np.asarray(base.lens, dtype=np.int64)
+        v = np.minimum(np.asarray(valid, dtype=np.int64), lens)
+        pad = lens - v
+        start_a = np.concatenate(([0], np.cumsum(v)[:-1]))
+        self.rows_a = int(v.sum())
+        start_b = self.rows_a + np.concatenate(([0], np.cumsum(pad)[:-1]))
+        rs, rp = base._row_seq, base._row_pos
+        is_valid = rp < v[rs]
+        inv = np.where(is_valid, start_a[rs] + rp, start_b[rs] + rp - v[rs])
+        perm = np.empty_like(inv)
+        perm[inv] = np.arange(inv.size)
+        rows = base._rows_f
+        f_seq, f_r0, f_sh, f_end, q_seq, q_r0, q_sh, q_end = [], [], [], [], [], [], [], []
+        for i in range(len(lens)):
+            vi, n, a0, b0 = int(v[i]), int(lens[i]), int(start_a[i]), int(start_b[i])
+            for r0 in range(0, vi, rows):
+                f_seq.append(i); f_r0.append(r0); f_sh.append(a0); f_end.append(vi)
+            na = len(f_seq)
+            q_seq.extend(f_seq[na - (vi + rows - 1) // rows:]); q_r0.extend(f_r0[na - (vi + rows - 1) // rows:])
+            q_sh.extend(f_sh[na - (vi + rows - 1) // rows:]); q_end.extend(f_end[na - (vi + rows - 1) // rows:])
+            for r0 in range(vi, n, rows):
+                f_seq.append(i); f_r0.append(r0); f_sh.append(b0 - vi); f_end.append(n)
+        nf, nq, ns = len(f_seq), len(q_seq), len(lens)
+        ints = np.concatenate([np.asarray(x, dtype=np.int32) for x in (f_seq, f_r0, f_sh, f_end, q_seq, q_r0, q_sh, q_end, start_a, v)])
+        dev_i = torch.from_numpy(ints).to(device, non_blocking=True)
+        dev_p = torch.from_numpy(np.concatenate((perm, inv))).to(device, non_blocking=True)
+        cut = np.cumsum([0, nf, nf, nf, nf, nq, nq, nq, nq, ns, ns])
+        part = [dev_i[cut[k]:cut[k + 1]] for k in range(10)]
+        (self.ftile_seq, self.ftile_r0, self.ftile_qshift, self.ftile_qend, self.tile_seq, self.tile_r0, self.qtile_qshift,
+         self.qtile_qend, self.seq_start, self.kv_len) = part
+        self.nftiles, self.ntiles = nf, nq
+        self.perm, self.inv = dev_p[:inv.size], dev_p[inv.size:]
+        self.base, self.heads, self.tokens, self.lens = base, base.heads, base.tokens, base.lens
+        self.seq_len, self.elem_base, self.bias_start, self.bias_len = base.seq_len, base.elem_base, base.bias_start, base.bias_len
+        self.split = True
 
 
 def pad_key_bias(key_bias, layout: "SeqLayout"):
@@ -315,6 +365,8 @@ def attn_fwd(qkv, key_bias, layout: SeqLayout, H, *, drop: Drop = None, ctx=None
     if key_bias.numel() != layout.bias_len or layout.bias_len == M:
         key_bias = pad_key_bias(key_bias, layout) if key_bias.numel() == M else key_bias
     assert qkv.shape[1] == 3 * H and qkv.is_contiguous()
+    if getattr(layout, "split", False):
+        kv_len = layout.kv_len                           # keys of a sequence = its region-A rows
     if ctx is None:
         ctx = torch.empty((M, H), device=qkv.device, dtype=torch.bfloat16)
     if lse is None:
@@ -322,7 +374,8 @@ def attn_fwd(qkv, key_bias, layout: SeqLayout, H, *, drop: Drop = None, ctx=None
     d = drop or NO_DROP
     _lib.check(lib.mmbert_attn_fwd(_stream(), qkv.data_ptr(), ctx.data_ptr(), lse.data_ptr(), key_bias.data_ptr(), layout.bias_start.data_ptr(), H, layout.heads,
                                    layout.seq_start.data_ptr(), layout.seq_len.data_ptr(), layout.elem_base.data_ptr(),
-                                   layout.ftile_seq.data_ptr(), layout.ftile_r0.data_ptr(), layout.nftiles, d[0], d[1], d[2], _ptr(kv_len)), "mmbert_attn_fwd")
+                                   layout.ftile_seq.data_ptr(), layout.ftile_r0.data_ptr(), layout.nftiles, d[0], d[1], d[2], _ptr(kv_len),
+                                   _ptr(getattr(layout, "ftile_qshift", None)), _ptr(getattr(layout, "ftile_qend", None))), "mmbert_attn_fwd")
     return ctx, lse
 
 
@@ -336,11 +389,18 @@ def attn_bwd(qkv, ctx, dctx, lse, key_bias, layout: SeqLayout, H, *, drop: Drop 
     if key_bias.numel() != layout.bias_len or layout.bias_len == M:
         key_bias = pad_key_bias(key_bias, layout) if key_bias.numel() == M else key_bias
     assert dctx.is_contiguous() and ctx.is_contiguous()
+    split = getattr(layout, "split", False)
+    if split:                      # backward covers region A only: its query tiles double as the key tiles (same 128-row grid)
+        q_seq, q_r0, nq = layout.tile_seq, layout.tile_r0, layout.ntiles
+        kv_len = layout.kv_len
+    else:
+        q_seq, q_r0, nq = layout.ftile_seq, layout.ftile_r0, layout.nftiles
     _lib.check(lib.mmbert_attn_bwd(_stream(), qkv.data_ptr(), ctx.data_ptr(), dctx.data_ptr(), dqkv.data_ptr(), lse.data_ptr(), delta.data_ptr(),
                                    key_bias.data_ptr(), layout.bias_start.data_ptr(), H, layout.heads, layout.seq_start.data_ptr(), layout.seq_len.data_ptr(),
-                                   layout.elem_base.data_ptr(), layout.ftile_seq.data_ptr(), layout.ftile_r0.data_ptr(), layout.nftiles,
+                                   layout.elem_base.data_ptr(), q_seq.data_ptr(), q_r0.data_ptr(), nq,
                                    layout.tile_seq.data_ptr(), layout.tile_r0.data_ptr(), layout.ntiles,
-                                   d[0], d[1], d[2], _ptr(kv_len)), "mmbert_attn_bwd")
+                                   d[0], d[1], d[2], _ptr(kv_len), _ptr(getattr(layout, "qtile_qshift", None)), _ptr(getattr(layout, "qtile_qend", None)),
+                                   1 if split else 0), "mmbert_attn_bwd")
     return dqkv
 
 

@@ -220,6 +220,50 @@ def test_fused_sequence_extension_matches_its_oracle():
     assert float(m.bert.jointEmbeddings.Wv.weight.grad.abs().sum()) > 0 and float(m.bert.jointEmbeddings.Ws.weight.grad.abs().sum()) > 0
 
 
+def test_backward_on_unmasked_rows_only_equals_full_backward():
+    """The valid-first packing (ops.SplitLayout): rows behind a sequence's last unmasked key and without a label have zero
+    gradients in every layer, so backward runs on the other rows only.  Same model, same batch (heavy padding: pair lengths
+    from half to full), dropout off: losses and scores identical, every parameter gradient equal to the full backward up to
+    fp32 summation order; a label placed on a padded row switches the short cut off (and the gradients still agree)."""
+    cfg = dict(hidden=256, layers=2, heads=4, intermediate=1024, vocab=4096, dataset="mosei", alpha=1.0, beta=1.0)
+    batch = synthetic_batch(4, 24, 200, 130, dataset="mosei", vocab=cfg["vocab"], seed=31)
+    dbatch = batch_to(batch, DEV)
+    res = {}
+    for skip in (True, False):
+        m = build(cfg)
+        m.skip_padded_backward = skip
+        seen = []
+        orig = m._split_layout
+        m._split_layout = lambda *a, _o=orig, _s=seen: (_s.append(_o(*a)), _s[-1])[1]
+        out, logits = m(**dbatch)
+        out[0].mean().backward()
+        torch.cuda.synchronize()
+        assert (seen[0] is not None) == skip
+        if skip:
+            assert seen[0].rows_a < 0.9 * seen[0].tokens                 # a real saving on this batch
+        res[skip] = (out, logits, {n: q.grad.detach().float().clone() for n, q in m.named_parameters()})
+    (oa, la, ga), (ob, lb, gb) = res[True], res[False]
+    for i in (0, 4, 5, 6):
+        assert abs(float(oa[i]) - float(ob[i])) <= 1e-6 * abs(float(ob[i]))
+    for k in (7, 9, 11):
+        assert torch.equal(oa[k], ob[k])                                    # forward is the same arithmetic row by row
+    for n in ga:
+        scale = float(gb[n].abs().max())
+        assert float((ga[n] - gb[n]).abs().max()) <= 2e-3 * scale + 1e-7, n
+    # a label on a padded pair row: the zero-gradient argument no longer holds -> full backward
+    m = build(cfg)
+    lab_v = batch["masked_labels"][1].clone()
+    lab_v[:, -1] = 1234
+    b2 = dict(batch, masked_labels=(batch["masked_labels"][0], lab_v, batch["masked_labels"][2]))
+    assert m._split_layout.__self__ is m
+    seen = []
+    orig = m._split_layout
+    m._split_layout = lambda *a, _o=orig, _s=seen: (_s.append(_o(*a)), _s[-1])[1]
+    out, _ = m(**batch_to(b2, DEV))
+    out[0].mean().backward()
+    assert seen == [None] and all(bool(torch.isfinite(q.grad).all()) for q in m.parameters())
+
+
 def test_dropout_train_mode_is_seeded_and_unbiased():
     batch = batch_to(synthetic_batch(2, 50, 64, 64, seed=1), DEV)
     m = build(CFG1, train=True)
