@@ -965,7 +965,11 @@ static int launch_nt256(hipStream_t s, const GemmNT& p) {
         // isolation (tools/bench_gemm.py MODES=6,7; after the epilogue rewrite: N = 768 shapes -4..-6 %, vocabulary -6 %, QKV
         // equal, GELU epilogues +8..9 %) but not in the train step, neither everywhere (797 vs 805 samples/s) nor chosen per
         // launch by rounds x relative tile time (815 vs 820, two alternating runs on one box): not the default.
-        if (can_persist) return launch_ntp_mi<EPI, 7>(s, p);
+        // ... except where the taller tile saves whole ROUNDS over the CUs (static tile shares: a launch costs ceil(tiles / CUs)
+        // tile times): backward runs on a data-dependent row count (model.py, SplitLayout), e.g. 14 400 rows x N = 3072 is 780
+        // tiles = 4 rounds at 224 rows but 684 = 3 rounds at 256.  A 256-row tile is priced at 1.1 of a 224-row one.
+        static const bool tall_ok = !(getenv("MMBERT_NT_TALL") && atoi(getenv("MMBERT_NT_TALL")) == 0);     // A/B switch
+        if (can_persist) return (tall_ok && (float)r256 * 1.1f < (float)r224) ? launch_ntp_mi<EPI, 8>(s, p) : launch_ntp_mi<EPI, 7>(s, p);
         return r224 <= r256 ? launch_nt256_mi<EPI, 7>(s, p) : launch_nt256_mi<EPI, 8>(s, p);
     }
     if (can_persist && g_nt_force == 2 && g_nt_persist == 2) return g_nt_bm == 224 ? launch_ntp_mi<EPI, 7>(s, p) : launch_ntp_mi<EPI, 8>(s, p);
