@@ -30,11 +30,17 @@ sys.path.insert(0, ROOT)
 import torch
 
 
+def flop_parts(L, H, I, V, T, Pv, Pa, dv=35, ds=74):
+    """Algorithmic forward FLOPs of one sample over the three passes, by component."""
+    def one(S, P, D):
+        return dict(proj=2 * S * L * (4 * H * H + 2 * H * I), attn=4 * S * S * H * L, head=2 * S * H * H + 2 * S * H * V, joint=2 * P * D * H)
+    parts = [one(T, 0, 0), one(T + Pv, Pv, dv), one(T + Pa, Pa, ds)]
+    return {k: sum(p[k] for p in parts) for k in parts[0]}
+
+
 def flops_per_sample(L, H, I, V, T, Pv, Pa, dv=35, ds=74):
     """Algorithmic forward FLOPs of one sample over the three passes; train = 3x."""
-    def one(S, P, D):
-        return 2 * S * L * (4 * H * H + 2 * H * I) + 4 * S * S * H * L + 2 * S * H * H + 2 * S * H * V + 2 * P * D * H
-    return one(T, 0, 0) + one(T + Pv, Pv, dv) + one(T + Pa, Pa, ds)
+    return sum(flop_parts(L, H, I, V, T, Pv, Pa, dv, ds).values())
 
 
 def main():
@@ -106,12 +112,21 @@ def main():
         ops.gemm_nt = wrap("nt", ops.gemm_nt, lambda A, B, **kw: 2.0 * A.shape[0] * A.shape[1] * B.shape[0])
         ops.gemm_tn = wrap("tn", ops.gemm_tn, lambda A, B, W, **kw: 2.0 * A.shape[0] * A.shape[1] * B.shape[1])
         ops.gemm_tn_grouped = wrap("tn", ops.gemm_tn_grouped, lambda probs, **kw: sum(2.0 * p[0].shape[0] * p[0].shape[1] * p[1].shape[1] for p in probs))
-        attn_fl = lambda lay: sum(4.0 * n * n * 64 * lay.heads for n in lay.lens)
-        ops.attn_fwd = wrap("attn_fwd", ops.attn_fwd, lambda qkv, kb, lay, H, **kw: attn_fl(lay))
-        ops.attn_bwd = wrap("attn_bwd", ops.attn_bwd, lambda qkv, c, d, l, kb, lay, H, **kw: 2.5 * attn_fl(lay))
+        # executed attention FLOPs: with the valid-first packing forward visits all queries x the unmasked keys, backward the
+        # unmasked rows only (lay.valid_host); otherwise the full S x S
+        def attn_fl(lay, bwd):
+            v = getattr(lay, "valid_host", None)
+            if v is None:
+                return sum(4.0 * n * n * 64 * lay.heads for n in lay.lens)
+            return sum(4.0 * (k if bwd else n) * k * 64 * lay.heads for n, k in zip(lay.lens, v))
+        ops.attn_fwd = wrap("attn_fwd", ops.attn_fwd, lambda qkv, kb, lay, H, **kw: attn_fl(lay, False))
+        ops.attn_bwd = wrap("attn_bwd", ops.attn_bwd, lambda qkv, c, d, l, kb, lay, H, **kw: 2.5 * attn_fl(lay, True))
+
+    row_frac = []
 
     def step(i):
         out, _ = model(**pool[i % len(pool)])
+        row_frac.append(getattr(model, "last_backward_row_fraction", 1.0))
         out[0].mean().backward()
         if dp is not None:
             dp.finish_backward()
@@ -185,7 +200,12 @@ def main():
     # the MLM head's backward runs on the labelled rows only (their CE gradient is the only non-zero one; ~2 % of the
     # rows with 15 % masking of the text tokens): FLOPs actually executed = dense count - the skipped backward products
     tokens = a.text + 2 * (a.text + a.pair)
-    fps_exec = fps - 2.0 * (2.0 * tokens * H * V + 2.0 * tokens * H * H) * (1.0 - 0.15 * 3 * a.text / tokens)
+    # ... and the rest of backward runs on the rows that can have a gradient (valid-first packing): f = their share,
+    # measured per step; attention forward skips the masked-out key tiles (~ the same share of its keys)
+    f = sum(row_frac[-a.steps:]) / max(1, len(row_frac[-a.steps:]))
+    fp = flop_parts(L, H, I, V, a.text, a.pair, a.pair)
+    head_bwd = 2.0 * fp["head"] * (0.15 * 3 * a.text / tokens)
+    fps_exec = (fp["proj"] + fp["attn"] * f + fp["head"] + fp["joint"]) + 2.0 * (fp["proj"] * f + fp["attn"] * f * f + fp["joint"] * f) + head_bwd
     res = {
         "metric": "train-step samples/sec", "value": round(value, 2), "unit": "samples/s", "n_gpus": world, "steps": a.steps,
         "warmup": a.warmup, "ms_per_step": round(1e3 * elapsed / a.steps, 3), "higher_is_better": True, "scaling": "weak",
@@ -194,7 +214,9 @@ def main():
                                f"{L}-layer d={H} heads={a.heads} vocab={V}, T={a.text} A={a.pair} V={a.pair}, dropout on, AdamW",
                    "per_gpu_batch": a.batch, "global_batch": a.batch * world, "parallelism": f"dp{world}",
                    "tflop_per_sample": round(fps / 1e12, 4), "tflop_per_sample_executed": round(fps_exec / 1e12, 4),
-                   "mlm_backward": "labelled rows only (exact: unlabelled rows have zero CE gradient)"},
+                   "mlm_backward": "labelled rows only (exact: unlabelled rows have zero CE gradient)",
+                   "backward_row_fraction": round(f, 4),
+                   "backward_rows": "rows behind a sequence's last unmasked key and without a label have zero gradients in every layer: backward skips them (exact)"},
         "final_loss": round(loss, 4),
         "step_mfma_frac": round(fps_exec * value / world / 2.5e15, 4),
     }

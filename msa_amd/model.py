@@ -607,6 +607,7 @@ class _GpuModelBase(nn.Module):
         scores); they are packed BEHIND all other rows (ops.SplitLayout) so that backward is the same kernels on a shorter
         matrix.  Needs the lengths on the host: one small blocking copy per step.  Returns None when it does not apply
         (no labels given -- the caller may then put a gradient anywhere --, a label on such a row, or under 3 % to save)."""
+        self.last_backward_row_fraction = 1.0                            # (bookkeeping for bench.py: share of rows backward visits)
         if labels is None or not torch.is_grad_enabled() or not getattr(self, "skip_padded_backward", True):
             return None
         lay = plan["layout"]
@@ -617,6 +618,7 @@ class _GpuModelBase(nn.Module):
         valid = host[:-1].numpy()
         if int(valid.sum()) > 0.97 * lay.tokens:
             return None
+        self.last_backward_row_fraction = float(valid.sum()) / lay.tokens
         return ops.SplitLayout(lay, valid, kv_len.device)
 
 

@@ -309,6 +309,7 @@ class SplitLayout:
         pad = lens - v
         start_a = np.concatenate(([0], np.cumsum(v)[:-1]))
         self.rows_a = int(v.sum())
+        self.valid_host = [int(x) for x in v]
         start_b = self.rows_a + np.concatenate(([0], np.cumsum(pad)[:-1]))
         rs, rp = base._row_seq, base._row_pos
         is_valid = rp < v[rs]
