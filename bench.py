@@ -62,6 +62,7 @@ def main():
     ap.add_argument("--eval-dropout-off", action="store_true", help="diagnostic only: not a valid headline number")
     ap.add_argument("--no-skip-masked-keys", action="store_true", help="A/B: attention also visits the key tiles that are entirely masked out")
     ap.add_argument("--no-skip-padded-backward", action="store_true", help="A/B: backward also runs on the rows whose gradients are exactly zero")
+    ap.add_argument("--no-sparse-top-layer", action="store_true", help="A/B: dense backward of the top encoder layer")
     a = ap.parse_args()
 
     from msa_amd import ops, parallel
@@ -87,6 +88,7 @@ def main():
     model.overlap_wgrad = a.overlap_wgrad
     model.skip_masked_keys = not a.no_skip_masked_keys
     model.skip_padded_backward = not a.no_skip_padded_backward
+    model.sparse_top_layer_backward = not a.no_sparse_top_layer
     model.return_scores = True            # the reference returns the six score tensors; keep them materialised
     targs = default_args(train_batch_size=a.batch, learning_rate=5e-5)
     opt, sched = build_optimizer(model, targs, num_train_optimization_steps=10 * (a.steps + a.warmup))

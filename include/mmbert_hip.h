@@ -78,7 +78,8 @@ int mmbert_dropout_mask(mmbert_stream_t stream, uint8_t* out, size_t n, uint32_t
 /* ---- LayerNorm (+ the reference's dropout placements) ----
  * fwd: y[out_rows[i]] = dropout(LN(x[in_rows[i]]))              BertEmbeddings HF:104-107,
  *      JointEmbeddings REF:MMBertEmbedding.py:69-70, BertSelfOutput/BertOutput LN HF:292,350.
- * bwd: see rowwise.hip; dx2 = dx * (pre-LN branch dropout mask) feeds the dense layer's gradients. */
+ * bwd: see rowwise.hip; dx2 = dx * (pre-LN branch dropout mask) feeds the dense layer's gradients.  The dropout masks are
+ *      functions of (row, column): drop_rows[i] (may be null: i) names the row of the forward pass that compact row i stands for. */
 int mmbert_ln_fwd(mmbert_stream_t stream, const void* x, int ldx, const int* in_rows, void* y, int ldy, const int* out_rows,
                   int M, int H, const float* gamma, const float* beta, float eps, float* mean, float* rstd,
                   uint32_t dstream, uint32_t dthr, float dscale);
@@ -87,7 +88,7 @@ int mmbert_ln_bwd(mmbert_stream_t stream, const void* dy, int lddy, const int* d
                   void* dx, int lddx, const int* dx_rows, void* dx2, int lddx2, float* dgamma, float* dbeta, float* dbias2,
                   uint32_t post_stream, uint32_t post_thr, float post_scale,
                   uint32_t pre_stream, uint32_t pre_thr, float pre_scale,
-                  float* partial_ws /* mmbert_ln_bwd_workspace() floats, or NULL: contended atomics */);
+                  float* partial_ws /* mmbert_ln_bwd_workspace() floats, or NULL: contended atomics */, const int* drop_rows);
 size_t mmbert_ln_bwd_workspace(int M, int H);
 
 /* ---- embeddings ----

@@ -93,7 +93,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
                                                      float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ dbias2,
                                                      float* __restrict__ partial,
                                                      uint32_t post_stream, uint32_t post_thr, float post_scale,
-                                                     uint32_t pre_stream, uint32_t pre_thr, float pre_scale) {
+                                                     uint32_t pre_stream, uint32_t pre_thr, float pre_scale,
+                                                     const int* __restrict__ drop_rows) {
     __shared__ float red[2][4][1024];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     float ag[LN_MAXV][4], ab[LN_MAXV][4], ad[LN_MAXV][4];
@@ -105,6 +106,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
         const bf16_t* dyr = dy + (size_t)(dy_rows ? dy_rows[i] : i) * lddy;
         const bf16_t* xr = x + (size_t)(x_rows ? x_rows[i] : i) * ldx;
         const float mean = mean_in[i], rstd = rstd_in[i];
+        const uint64_t di = drop_rows ? (uint64_t)drop_rows[i] : (uint64_t)i;      // the row the dropout masks were drawn for
         float g[LN_MAXV][4], xh[LN_MAXV][4];
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
@@ -116,7 +118,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
                 const float4 gm = *(const float4*)(gamma + col);
                 const float gmv[4] = {gm.x, gm.y, gm.z, gm.w};
                 bool k[4] = {true, true, true, true};
-                if (post_thr) mmb_keep4(post_stream, (uint64_t)i * H + col, post_thr, k);
+                if (post_thr) mmb_keep4(post_stream, di * H + col, post_thr, k);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     float dv = bf2f(d[r]);
@@ -146,7 +148,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
                 if (dx2) {
                     if (pre_thr) {
                         bool k[4];
-                        mmb_keep4(pre_stream, (uint64_t)i * H + col, pre_thr, k);
+                        mmb_keep4(pre_stream, di * H + col, pre_thr, k);
 #pragma unroll
                         for (int r = 0; r < 4; ++r) o[r] = k[r] ? o[r] * pre_scale : 0.f;
                     }
@@ -646,13 +648,13 @@ int mmbert_ln_bwd(hipStream_t stream, const void* dy, int lddy, const int* dy_ro
                   const float* mean, const float* rstd, const float* gamma, int M, int H,
                   void* dx, int lddx, const int* dx_rows, void* dx2, int lddx2, float* dgamma, float* dbeta, float* dbias2,
                   uint32_t post_stream, uint32_t post_thr, float post_scale,
-                  uint32_t pre_stream, uint32_t pre_thr, float pre_scale, float* partial_ws) {
+                  uint32_t pre_stream, uint32_t pre_thr, float pre_scale, float* partial_ws, const int* drop_rows) {
     if (M <= 0) return 0;
     if (H > LN_MAXV * 256 || (H & 3) || (ldx & 3) || (lddy & 3) || (lddx & 3) || (lddx2 & 3)) return -1;
     const int nblocks = grid_for(M, 16, 1024);
     hipLaunchKernelGGL(ln_bwd_kernel, dim3(nblocks), dim3(256), 0, stream, (const bf16_t*)dy, lddy, dy_rows, (const bf16_t*)x, ldx, x_rows,
                        mean, rstd, gamma, M, H, (bf16_t*)dx, lddx, dx_rows, (bf16_t*)dx2, lddx2, dgamma, dbeta, dbias2, partial_ws,
-                       post_stream, post_thr, post_scale, pre_stream, pre_thr, pre_scale);
+                       post_stream, post_thr, post_scale, pre_stream, pre_thr, pre_scale, drop_rows);
     MMB_CHECK_LAUNCH();
     if (partial_ws) {
         hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3((H + 63) / 64, 3, 16), dim3(256), 0, stream, (const float*)partial_ws, nblocks, H, dgamma, dbeta, dbias2);

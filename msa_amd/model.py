@@ -237,7 +237,7 @@ class _EncoderFn(torch.autograd.Function):
     """L x BertLayer (HF:374-416) over the packed token matrix."""
 
     @staticmethod
-    def forward(ctx, x, anchor, top, layout, key_bias, seed, kv_len=None):
+    def forward(ctx, x, anchor, top, layout, key_bias, seed, kv_len=None, top_rows=None):
         cfg = top.config
         H, L = cfg.hidden_size, cfg.num_hidden_layers
         train = top.training
@@ -260,7 +260,7 @@ class _EncoderFn(torch.autograd.Function):
             if keep:
                 saved.append((x, qkv, actx, lse, z1, m1, r1, y1, u, g, z2, m2, r2, d_att, d_h1, d_h2))
             x = y2
-        ctx.top, ctx.layout, ctx.key_bias, ctx.saved, ctx.kv_len = top, layout, key_bias, saved, kv_len
+        ctx.top, ctx.layout, ctx.key_bias, ctx.saved, ctx.kv_len, ctx.top_rows = top, layout, key_bias, saved, kv_len, top_rows
         return x
 
     @staticmethod
@@ -282,6 +282,12 @@ class _EncoderFn(torch.autograd.Function):
             if ra < M_all:
                 saved_i = tuple(t[:ra] if torch.is_tensor(t) else t for t in saved_i)
             x, qkv, actx, lse, z1, m1, r1, y1, u, g, z2, m2, r2, d_att, d_h1, d_h2 = saved_i
+            if i == top.config.num_hidden_layers - 1 and ctx.top_rows is not None:
+                R = _EncoderFn._sparse_rows(ctx.top_rows, layout, ra)
+                if R is not None:
+                    dy = _EncoderFn._last_layer_sparse(top, lw, layout, key_bias, ctx.kv_len, saved_i, dy, R, H, ra)
+                    top._layer_grads_done(i)
+                    continue
             # --- output sublayer: y2 = LN(dropout(g.W2^T + b2) + y1)      (b2 / bo gradients come out of ln_bwd)
             dz2d = torch.empty_like(dy) if d_h2[1] else None
             dz2 = ops.ln_bwd(dy, z2, m2, r2, lw["ln2_g"], lw["g_ln2_g"], lw["g_ln2_b"], dx2=dz2d, pre_drop=d_h2, dbias2=lw["g_b2"])
@@ -321,7 +327,55 @@ class _EncoderFn(torch.autograd.Function):
             full = dy.new_zeros((M_all, dy.shape[1]))
             full[:ra] = dy
             dy = full
-        return dy, None, None, None, None, None, None
+        return dy, None, None, None, None, None, None, None
+
+    @staticmethod
+    def _sparse_rows(top_rows, layout, ra):
+        """The rows of the LAST layer's output that have a gradient: the MLM-labelled rows and the [CLS] rows (everything else
+        feeds nothing but the returned scores).  (device int64 list in the encoder's packed order) or None if not worth it."""
+        (idx, host, ev), first = top_rows
+        ev.synchronize()                                          # (long complete: the MLM head's backward ran before this)
+        n = int(host[0])
+        r = n + first.numel()
+        if 4 * r > ra:
+            return None
+        R = torch.cat((idx[:n].long(), first))
+        if getattr(layout, "split", False):
+            R = layout.inv.index_select(0, R)
+        return R
+
+    @staticmethod
+    def _last_layer_sparse(top, lw, layout, key_bias, kv_len, saved_i, dy, R, H, ra):
+        """Backward of the top encoder layer when only the rows R of its output carry a gradient: the output sublayer (LayerNorm',
+        FFN-down and FFN-up input gradients, their weight gradients), LayerNorm' and the output projection of the attention
+        sublayer run on those rows only (gathered operands, the dropout masks of the ORIGINAL rows); attention's backward is
+        dense again (every unmasked key receives a gradient), as is everything below."""
+        cfg = top.config
+        x, qkv, actx, lse, z1, m1, r1, y1, u, g, z2, m2, r2, d_att, d_h1, d_h2 = saved_i
+        R32 = R.int()
+        sel = lambda t: t.index_select(0, R)
+        dy_c = sel(dy)
+        dz2d_c = torch.empty_like(dy_c) if d_h2[1] else None
+        dz2_c = ops.ln_bwd(dy_c, z2, sel(m2), sel(r2), lw["ln2_g"], lw["g_ln2_g"], lw["g_ln2_b"], x_rows=R32, dx2=dz2d_c, pre_drop=d_h2,
+                           dbias2=lw["g_b2"], drop_rows=R32)
+        if dz2d_c is None:
+            dz2d_c = dz2_c
+        du_c = ops.gemm_nt(dz2d_c, lw["W2T"], gelu_bwd_u=sel(u))
+        dy1_c = ops.gemm_nt(du_c, lw["W1T"], resid=dz2_c)
+        dz1d_c = torch.empty_like(dy_c) if d_h1[1] else None
+        dz1_c = ops.ln_bwd(dy1_c, z1, sel(m1), sel(r1), lw["ln1_g"], lw["g_ln1_g"], lw["g_ln1_b"], x_rows=R32, dx2=dz1d_c, pre_drop=d_h1,
+                           dbias2=lw["g_bo"], drop_rows=R32)
+        if dz1d_c is None:
+            dz1d_c = dz1_c
+        dctx = torch.zeros((ra, H), device=dy.device, dtype=torch.bfloat16)
+        dctx.index_copy_(0, R, ops.gemm_nt(dz1d_c, lw["WoT"]))
+        dqkv = ops.attn_bwd(qkv, actx, dctx, lse, key_bias, layout, H, drop=d_att, kv_len=kv_len)
+        dz1 = torch.zeros((ra, H), device=dy.device, dtype=torch.bfloat16)
+        dz1.index_copy_(0, R, dz1_c)
+        out = ops.gemm_nt(dqkv, lw["WqkvT"], resid=dz1)
+        ops.gemm_tn_grouped([(du_c, sel(y1), lw["g_W1"], lw["g_b1"]), (dz2d_c, sel(g), lw["g_W2"], None), (dz1d_c, sel(actx), lw["g_Wo"], None)])
+        ops.gemm_tn_grouped([(dqkv, x, lw["g_Wqkv"], lw["g_bqkv"])])
+        return out
 
 
 def mlm_active_rows(labels, vocab):
@@ -550,7 +604,7 @@ class _GpuModelBase(nn.Module):
             raise ValueError("You have so large dimension (), Check dimension or shape ")
         return (1.0 - m.to(device=device, dtype=torch.float32)) * MASK_NEG
 
-    def _encode(self, passes, labels=None):
+    def _encode(self, passes, labels=None, rows=None):
         """passes: list of dict(ids[B,T], tt[B,T]|None, mask, pair[B,P,D]|None, pair_mask|None).
         Returns (Y [tokens,H] bf16, plan, lens_per_pass)."""
         bert = self._bert()
@@ -591,10 +645,13 @@ class _GpuModelBase(nn.Module):
         # padded pair rows are masked-out keys at the tail of every joint sequence: the attention kernels skip them (exact)
         kv_len = ops.attn_kv_len(key_bias, plan["layout"]) if getattr(self, "skip_masked_keys", True) else None
         split = self._split_layout(plan, kv_len, labels) if kv_len is not None else None
+        # rows of the top layer's output that can have a gradient (MLM-labelled rows + the [CLS] rows the heads read): known
+        # when the caller is forward() / forward_fused() -- only they guarantee that nothing else is differentiated
+        top_rows = (rows, plan["first"]) if (rows is not None and getattr(self, "sparse_top_layer_backward", True)) else None
         if split is None:
-            y = _EncoderFn.apply(x, bert.embeddings.LayerNorm.weight, self, plan["layout"], key_bias, seed, kv_len)
+            y = _EncoderFn.apply(x, bert.embeddings.LayerNorm.weight, self, plan["layout"], key_bias, seed, kv_len, top_rows)
         else:
-            y = _EncoderFn.apply(x.index_select(0, split.perm), bert.embeddings.LayerNorm.weight, self, split, key_bias, seed, None)
+            y = _EncoderFn.apply(x.index_select(0, split.perm), bert.embeddings.LayerNorm.weight, self, split, key_bias, seed, None, top_rows)
             y = y.index_select(0, split.inv)
         return y, plan, lens
 
@@ -932,7 +989,7 @@ class MMBertForPretraining(_GpuModelBase):
         rows = mlm_active_rows(labels, V) if (torch.is_grad_enabled() and getattr(self, "sparse_mlm_backward", True) and labels.is_cuda) else None
         if labels.numel() != B * (T + (T + visual.shape[1]) + (T + speech.shape[1])):
             raise ValueError("masked_labels must cover text (+ pair) positions of every pass")
-        y, plan, lens = self._encode(passes, labels)
+        y, plan, lens = self._encode(passes, labels, rows)
         mlm, logits = _MLMHeadFn.apply(y, self.cls.predictions.transform.LayerNorm.weight, self, labels, plan["bounds"], plan["bounds_dev"], self.return_scores, rows)
 
         first = y.index_select(0, plan["first"]).float()                             # [3B, H]: [CLS] rows of every sequence
@@ -970,7 +1027,7 @@ class MMBertForPretraining(_GpuModelBase):
         rows = mlm_active_rows(labels, V) if (torch.is_grad_enabled() and getattr(self, "sparse_mlm_backward", True) and labels.is_cuda) else None
         if labels.numel() != B * (T + visual.shape[1] + speech.shape[1]):
             raise ValueError("masked_labels must cover the text and both pair blocks")
-        y, plan, lens = self._encode(passes, labels)
+        y, plan, lens = self._encode(passes, labels, rows)
         mlm, logits = _MLMHeadFn.apply(y, self.cls.predictions.transform.LayerNorm.weight, self, labels, plan["bounds"], plan["bounds_dev"], self.return_scores, rows)
         first = y.index_select(0, plan["first"].repeat(3)).float()                   # the one [CLS] row in the t / v / s slots
         heads_loss, ap_loss, label_loss, nce, logits_out, _t_rel, v_rel, _s_rel = self._run_heads(first, ap_v, ap_s, sentiment, dev, B)

@@ -174,7 +174,7 @@ def ln_fwd(x, gamma, beta, eps, *, M=None, out=None, in_rows=None, out_rows=None
 
 
 def ln_bwd(dy, x, mean, rstd, gamma, dgamma, dbeta, *, M=None, dx=None, dx2=None, dy_rows=None, x_rows=None, dx_rows=None,
-           post_drop: Drop = None, pre_drop: Drop = None, dbias2=None):
+           post_drop: Drop = None, pre_drop: Drop = None, dbias2=None, drop_rows=None):
     lib = _lib.load()
     H = x.shape[1]
     if M is None:
@@ -186,7 +186,7 @@ def ln_bwd(dy, x, mean, rstd, gamma, dgamma, dbeta, *, M=None, dx=None, dx2=None
     _lib.check(lib.mmbert_ln_bwd(_stream(), dy.data_ptr(), dy.stride(0), _ptr(dy_rows), x.data_ptr(), x.stride(0), _ptr(x_rows),
                                  mean.data_ptr(), rstd.data_ptr(), gamma.data_ptr(), M, H,
                                  dx.data_ptr(), dx.stride(0), _ptr(dx_rows), _ptr(dx2), dx2.stride(0) if dx2 is not None else 0,
-                                 _ptr(dgamma), _ptr(dbeta), _ptr(dbias2), po[0], po[1], po[2], pr[0], pr[1], pr[2], ws.data_ptr()), "mmbert_ln_bwd")
+                                 _ptr(dgamma), _ptr(dbeta), _ptr(dbias2), po[0], po[1], po[2], pr[0], pr[1], pr[2], ws.data_ptr(), _ptr(drop_rows)), "mmbert_ln_bwd")
     return dx
 
 

@@ -264,6 +264,37 @@ def test_backward_on_unmasked_rows_only_equals_full_backward():
     assert seen == [None] and all(bool(torch.isfinite(q.grad).all()) for q in m.parameters())
 
 
+@pytest.mark.parametrize("train", [False, True])
+def test_sparse_backward_of_the_top_layer_equals_dense(train):
+    """Only the MLM-labelled rows and the [CLS] rows of the top encoder layer's output have a gradient, so its output sublayer,
+    LayerNorms and output projection run their backward on those rows only.  Against the dense backward of the same model on
+    the same batch -- also in TRAIN mode with the same seed (the compact rows must regenerate the dropout masks of their
+    original rows): every parameter gradient equal up to fp32 summation order."""
+    cfg = dict(hidden=256, layers=2, heads=4, intermediate=1024, vocab=4096, dataset="mosei", alpha=1.0, beta=1.0)
+    dbatch = batch_to(synthetic_batch(4, 24, 120, 90, dataset="mosei", vocab=cfg["vocab"], seed=33), DEV)
+    res = {}
+    for sparse in (True, False):
+        m = build(cfg, train=train)
+        m.sparse_top_layer_backward = sparse
+        m.manual_seed(17)
+        from msa_amd import model as MM
+        calls, orig = [], MM._EncoderFn._last_layer_sparse
+        MM._EncoderFn._last_layer_sparse = staticmethod(lambda *a, _o=orig, _c=calls: (_c.append(1), _o(*a))[1])
+        try:
+            out, _ = m(**dbatch)
+            out[0].mean().backward()
+        finally:
+            MM._EncoderFn._last_layer_sparse = staticmethod(orig)
+        torch.cuda.synchronize()
+        assert len(calls) == (1 if sparse else 0)                        # the short cut really ran (once: the top layer)
+        res[sparse] = (float(out[0]), {n: q.grad.detach().float().clone() for n, q in m.named_parameters()})
+    assert res[True][0] == res[False][0]
+    for n in res[True][1]:
+        a, b = res[True][1][n], res[False][1][n]
+        scale = float(b.abs().max())
+        assert float((a - b).abs().max()) <= 2e-3 * scale + 1e-7, (n, float((a - b).abs().max()), scale)
+
+
 def test_dropout_train_mode_is_seeded_and_unbiased():
     batch = batch_to(synthetic_batch(2, 50, 64, 64, seed=1), DEV)
     m = build(CFG1, train=True)
