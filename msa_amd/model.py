@@ -615,36 +615,43 @@ class _GpuModelBase(nn.Module):
         if T > cfg.max_position_embeddings:
             raise ValueError("text length exceeds max_position_embeddings")
         seed = self._next_seed()
-        ids = torch.cat([p["ids"].reshape(-1).long() for p in passes])
-        tts = torch.cat([(p["tt"].reshape(-1).long() if p.get("tt") is not None else torch.zeros(B * T, dtype=torch.long, device=dev)) for p in passes])
-        w = self._w
-        p_emb = cfg.hidden_dropout_prob if self.training else 0.0
-        e1 = _TextEmbedFn.apply(bert.embeddings.LayerNorm.weight, self, ids, tts, T, ops.make_drop(p_emb, seed, 1000))
-        xs, kbs, lens = [], [], []
         je = bert.jointEmbeddings
-        p_joint = je.dropout_prob if (self.training and je.training) else 0.0
-        for k, p in enumerate(passes):
-            e = e1[k * B * T:(k + 1) * B * T]
+        # ---- masks first: key bias, per-sequence unmasked lengths, and the request for those lengths on the host (an async
+        # copy; the embedding kernels below keep the GPU busy while it travels and the host packs the layout)
+        kbs, lens, pair_info = [], [], []
+        for p in passes:
             kb = self._key_bias(p["mask"], False, dev)
             if p.get("pair") is not None:
                 pairs = p["pair"] if isinstance(p["pair"], (tuple, list)) else (p["pair"],)
                 pmasks = p["pair_mask"] if isinstance(p["pair_mask"], (tuple, list)) else (p["pair_mask"],)
-                whichs = tuple(je.which(f) for f in pairs)
-                feats = tuple(f.to(dev).float().contiguous() for f in pairs)
-                e = _JointFn.apply(e, je.LayerNorm.weight, self, feats, whichs, B, T, ops.make_drop(p_joint, seed, 1001 + k))
                 kb = torch.cat((kb, *(self._key_bias(pm.to(dev), True, dev) for pm in pmasks)), dim=-1)
-                lens.append(T + sum(f.shape[1] for f in feats))
+                lens.append(T + sum(f.shape[1] for f in pairs))
+                pair_info.append((pairs, tuple(je.which(f) for f in pairs)))
             else:
                 lens.append(T)
-            xs.append(e)
+                pair_info.append(None)
             kbs.append(kb.reshape(-1))
-        x = torch.cat(xs) if len(xs) > 1 else xs[0]
         key_bias = torch.cat(kbs) if len(kbs) > 1 else kbs[0]
         plan = self._plan(lens, B, dev)
         key_bias = ops.pad_key_bias(key_bias, plan["layout"])        # per-sequence padded layout, -1e30 = "no such key"
         # padded pair rows are masked-out keys at the tail of every joint sequence: the attention kernels skip them (exact)
         kv_len = ops.attn_kv_len(key_bias, plan["layout"]) if getattr(self, "skip_masked_keys", True) else None
-        split = self._split_layout(plan, kv_len, labels) if kv_len is not None else None
+        pending = self._request_lengths(plan, kv_len, labels) if kv_len is not None else None
+        # ---- embeddings
+        ids = torch.cat([p["ids"].reshape(-1).long() for p in passes])
+        tts = torch.cat([(p["tt"].reshape(-1).long() if p.get("tt") is not None else torch.zeros(B * T, dtype=torch.long, device=dev)) for p in passes])
+        p_emb = cfg.hidden_dropout_prob if self.training else 0.0
+        e1 = _TextEmbedFn.apply(bert.embeddings.LayerNorm.weight, self, ids, tts, T, ops.make_drop(p_emb, seed, 1000))
+        xs = []
+        p_joint = je.dropout_prob if (self.training and je.training) else 0.0
+        for k, info in enumerate(pair_info):
+            e = e1[k * B * T:(k + 1) * B * T]
+            if info is not None:
+                feats = tuple(f.to(dev).float().contiguous() for f in info[0])
+                e = _JointFn.apply(e, je.LayerNorm.weight, self, feats, info[1], B, T, ops.make_drop(p_joint, seed, 1001 + k))
+            xs.append(e)
+        x = torch.cat(xs) if len(xs) > 1 else xs[0]
+        split = self._split_layout(plan, kv_len, pending)
         # rows of the top layer's output that can have a gradient (MLM-labelled rows + the [CLS] rows the heads read): known
         # when the caller is forward() / forward_fused() -- only they guarantee that nothing else is differentiated
         top_rows = (rows, plan["first"]) if (rows is not None and getattr(self, "sparse_top_layer_backward", True)) else None
@@ -655,29 +662,41 @@ class _GpuModelBase(nn.Module):
             y = y.index_select(0, split.inv)
         return y, plan, lens
 
-    def _split_layout(self, plan, kv_len, labels):
+    def _request_lengths(self, plan, kv_len, labels):
+        """Starts the device -> host copy of (unmasked length per sequence, count of labels on masked-out rows); None when the
+        valid-first packing cannot apply (no labels given -- the caller may then put a gradient anywhere --, no grad, switched off)."""
+        self.last_backward_row_fraction = 1.0                            # (bookkeeping for bench.py: share of rows backward visits)
+        if labels is None or not torch.is_grad_enabled() or not getattr(self, "skip_padded_backward", True):
+            return None
+        bad = ((labels != -100) & (plan["row_pos"] >= kv_len.long().index_select(0, plan["row_seq"]))).sum().to(torch.int32).view(1)
+        host = torch.empty(kv_len.numel() + 1, dtype=torch.int32, pin_memory=True)
+        host.copy_(torch.cat((kv_len, bad)), non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        return host, ev
+
+    def _split_layout(self, plan, kv_len, pending):
         """Backward on the unmasked rows only.  A row behind its sequence's last unmasked key (a padded pair row; a [PAD] row of
         the text pass) that carries no MLM label has an exactly-zero gradient at the encoder output (the heads read [CLS] rows,
         the MLM loss ignores it), nothing flows into it through attention (as a key its probability is exactly 0, so dK = dV = 0;
         as a query dO = 0 gives dS = 0), and every other operator is row-wise -- by induction its gradient is zero in every layer
         and it adds nothing to any weight gradient.  Forward still computes those rows (the reference returns their prediction
         scores); they are packed BEHIND all other rows (ops.SplitLayout) so that backward is the same kernels on a shorter
-        matrix.  Needs the lengths on the host: one small blocking copy per step.  Returns None when it does not apply
-        (no labels given -- the caller may then put a gradient anywhere --, a label on such a row, or under 3 % to save)."""
-        self.last_backward_row_fraction = 1.0                            # (bookkeeping for bench.py: share of rows backward visits)
-        if labels is None or not torch.is_grad_enabled() or not getattr(self, "skip_padded_backward", True):
+        matrix.  Needs the lengths on the host: the one blocking wait of the step, on a copy requested before the embedding
+        kernels were queued (_request_lengths).  Returns None when it does not apply (see there; also: a label on such a row,
+        or under 3 % to save)."""
+        if pending is None:
             return None
         lay = plan["layout"]
-        bad = ((labels != -100) & (plan["row_pos"] >= kv_len.long().index_select(0, plan["row_seq"]))).sum().to(torch.int32).view(1)
-        host = torch.cat((kv_len, bad)).cpu()                            # the one host sync of the step
+        host, ev = pending
+        ev.synchronize()
         if int(host[-1]) != 0:
             return None
-        valid = host[:-1].numpy()
+        valid = host[:-1].numpy().copy()
         if int(valid.sum()) > 0.97 * lay.tokens:
             return None
         self.last_backward_row_fraction = float(valid.sum()) / lay.tokens
         return ops.SplitLayout(lay, valid, kv_len.device)
-
 
 class MMBertModel(_GpuModelBase):
     """REF:MMBertForPretraining.py:13-285.  Holds embeddings / encoder / pooler (+ jointEmbeddings)."""

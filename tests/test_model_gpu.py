@@ -288,7 +288,7 @@ def test_sparse_backward_of_the_top_layer_equals_dense(train):
         torch.cuda.synchronize()
         assert len(calls) == (1 if sparse else 0)                        # the short cut really ran (once: the top layer)
         res[sparse] = (float(out[0]), {n: q.grad.detach().float().clone() for n, q in m.named_parameters()})
-    assert res[True][0] == res[False][0]
+    assert abs(res[True][0] - res[False][0]) <= 1e-6 * abs(res[False][0])        # same forward (fp32 atomics in the loss sums)
     for n in res[True][1]:
         a, b = res[True][1][n], res[False][1][n]
         scale = float(b.abs().max())
