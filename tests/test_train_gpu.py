@@ -120,7 +120,7 @@ def _dp_worker(rank, world, port, q):
     opt, sched = T.build_optimizer(m, T.default_args(learning_rate=1e-3), 4)
     dp = parallel.DataParallel(m, opt, bucket_mb=0.25)
     m.eval()
-    batch = batch_to(synthetic_batch(2, 16, 16, 16, vocab=CFG["vocab"], seed=10 + rank), DEV)
+    batch = batch_to(synthetic_batch(2, 16, 40, 24, vocab=CFG["vocab"], seed=10 + rank), DEV)
     out, _ = m(**batch)
     out[0].mean().backward()
     n_calls = dp.bucketer.calls
@@ -153,7 +153,7 @@ def test_data_parallel_two_ranks_equals_mean_of_single_rank_grads():
     total = None
     for r in range(2):
         m._flat.grads.zero_()
-        out, _ = m(**batch_to(synthetic_batch(2, 16, 16, 16, vocab=CFG["vocab"], seed=10 + r), DEV))
+        out, _ = m(**batch_to(synthetic_batch(2, 16, 40, 24, vocab=CFG["vocab"], seed=10 + r), DEV))
         out[0].mean().backward()
         total = m._flat.grads.clone() if total is None else total + m._flat.grads
     got, ref = res["grads"], total.cpu()
