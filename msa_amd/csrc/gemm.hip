@@ -1195,8 +1195,10 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_kernel(const GemmTNG g) {
 
     const float alpha = g.alpha * (g.alpha_dev ? *g.alpha_dev : 1.0f);
     const int fr = lane & 15, fq = lane >> 4;
-    float* out = g.splits > 1 ? g.slab + (size_t)split * g.slab_stride + slab_off : Wp;
-    const bool accum = (g.splits == 1) && g.accumulate;
+    // split 0 writes (or accumulates into) the weight gradient itself, splits 1.. write fp32 slabs that tn_reduce_kernel adds to it
+    // afterwards: one slab write, one slab read and one launch-wide pass less than "all splits to slabs" (order stays fixed)
+    float* out = split > 0 ? g.slab + (size_t)(split - 1) * g.slab_stride + slab_off : Wp;
+    const bool accum = (split == 0) && g.accumulate;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int k = k0 + wk * 64 + i * 16 + fq * 4;
@@ -1230,7 +1232,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_kernel(const GemmTNG g) {
 #endif
 }
 
-// W[i] (+)= sum_s slab[s][i] over the concatenated outputs of all problems of a launch
+// W[i] += sum_{s >= 1} slab[s - 1][i] over the concatenated outputs of all problems of a launch (split 0 went to W directly)
 struct TNReduce { float* W[4]; long long off[5]; int nprob, splits, accumulate; long long slab_stride; };
 __global__ void tn_reduce_kernel(const TNReduce r, const float* __restrict__ slab) {
     const long long total4 = r.off[r.nprob] >> 2;
@@ -1243,8 +1245,8 @@ __global__ void tn_reduce_kernel(const TNReduce r, const float* __restrict__ sla
 #pragma unroll
         for (int q = 1; q < 4; ++q) if (pi == q) { W = r.W[q]; o = r.off[q]; }
         float4* dst = (float4*)(W + (e - o));
-        float4 v = r.accumulate ? *dst : make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int s = 0; s < r.splits; ++s) {
+        float4 v = *dst;                                   // split 0 of the GEMM has stored its part here
+        for (int s = 0; s + 1 < r.splits; ++s) {
             const float4 t = *(const float4*)(slab + (size_t)s * r.slab_stride + e);
             v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
         }
@@ -1428,7 +1430,7 @@ size_t mmbert_gemm_tn_grouped_workspace(int nprob, const int* N, const int* K, i
     if (splits == 1) return 0;
     size_t elems = 0;
     for (int i = 0; i < nprob; ++i) elems += (size_t)N[i] * K[i];
-    return (size_t)splits * elems * sizeof(float);
+    return (size_t)(splits - 1) * elems * sizeof(float);
 }
 
 size_t mmbert_gemm_tn_workspace(int M, int N, int K, int* splits_out) {
