@@ -651,7 +651,9 @@ class _GpuModelBase(nn.Module):
         key_bias = ops.pad_key_bias(key_bias, plan["layout"])        # per-sequence padded layout, -1e30 = "no such key"
         # padded pair rows are masked-out keys at the tail of every joint sequence: the attention kernels skip them (exact)
         kv_len = ops.attn_kv_len(key_bias, plan["layout"]) if getattr(self, "skip_masked_keys", True) else None
-        pending = self._request_lengths(plan, kv_len, labels) if kv_len is not None else None
+        # inference (no dropout, no autograd): the masked-out rows of a sequence are identical in every layer -> one stands for all
+        infer = (not self.training) and (not torch.is_grad_enabled()) and getattr(self, "dedupe_masked_rows", True)
+        pending = self._request_lengths(plan, kv_len, labels, infer, (pair_info, B, T)) if kv_len is not None else None
         # ---- embeddings
         ids = torch.cat([p["ids"].reshape(-1).long() for p in passes])
         tts = torch.cat([(p["tt"].reshape(-1).long() if p.get("tt") is not None else torch.zeros(B * T, dtype=torch.long, device=dev)) for p in passes])
@@ -666,31 +668,57 @@ class _GpuModelBase(nn.Module):
                 e = _JointFn.apply(e, je.LayerNorm.weight, self, feats, info[1], B, T, ops.make_drop(p_joint, seed, 1001 + k))
             xs.append(e)
         x = torch.cat(xs) if len(xs) > 1 else xs[0]
-        split = self._split_layout(plan, kv_len, pending)
+        split = self._split_layout(plan, kv_len, pending, infer)
         # rows of the top layer's output that can have a gradient (MLM-labelled rows + the [CLS] rows the heads read): known
         # when the caller is forward() / forward_fused() -- only they guarantee that nothing else is differentiated
         top_rows = (rows, plan["first"]) if (rows is not None and getattr(self, "sparse_top_layer_backward", True)) else None
         if split is None:
             y = _EncoderFn.apply(x, bert.embeddings.LayerNorm.weight, self, plan["layout"], key_bias, seed, kv_len, top_rows)
+        elif infer:
+            y = _EncoderFn.apply(x.index_select(0, split.perm), bert.embeddings.LayerNorm.weight, self, split, key_bias, seed, None, None)
+            y = y.index_select(0, split.inv)                          # every masked-out row reads its sequence's representative
         else:
             y = _EncoderFn.apply(_PermuteRowsFn.apply(x, split.perm, split.inv), bert.embeddings.LayerNorm.weight, self, split, key_bias, seed, None, top_rows)
             y = _PermuteRowsFn.apply(y, split.inv, split.perm)
         return y, plan, lens
 
-    def _request_lengths(self, plan, kv_len, labels):
+    def _request_lengths(self, plan, kv_len, labels, infer=False, pairs=None):
         """Starts the device -> host copy of (unmasked length per sequence, count of labels on masked-out rows); None when the
-        valid-first packing cannot apply (no labels given -- the caller may then put a gradient anywhere --, no grad, switched off)."""
+        valid-first packing cannot apply (no labels given -- the caller may then put a gradient anywhere --, no grad, switched off).
+        ``infer``: the lengths alone (inference needs no labels: nothing is differentiated)."""
         self.last_backward_row_fraction = 1.0                            # (bookkeeping for bench.py: share of rows backward visits)
-        if labels is None or not torch.is_grad_enabled() or not getattr(self, "skip_padded_backward", True):
+        if infer:
+            # rows may share one representative only if their INPUTS are equal: that holds for masked-out PAIR rows whose features
+            # are all zero (no position embedding on pair rows) -- not for [PAD] text rows (positions differ), so text-only
+            # sequences keep every row and joint sequences keep at least their T text rows; a masked-out pair row with a
+            # non-zero feature anywhere switches the short cut off
+            pair_info, B, T = pairs
+            keep, bad = [], torch.zeros((), dtype=torch.int64, device=kv_len.device)
+            for k, info in enumerate(pair_info):
+                kv = kv_len[k * B:(k + 1) * B]
+                if info is None:
+                    keep.append(torch.full_like(kv, T))
+                    continue
+                kv = kv.clamp(min=T)
+                keep.append(kv)
+                off = T
+                for f in info[0]:
+                    pos = off + torch.arange(f.shape[1], device=kv.device)[None, :]
+                    bad = bad + ((pos >= kv[:, None].long()) & (f.to(kv.device) != 0).any(-1)).sum()
+                    off += f.shape[1]
+            kv_len = torch.cat(keep)
+            bad = bad.to(torch.int32).view(1)
+        elif labels is None or not torch.is_grad_enabled() or not getattr(self, "skip_padded_backward", True):
             return None
-        bad = ((labels != -100) & (plan["row_pos"] >= kv_len.long().index_select(0, plan["row_seq"]))).sum().to(torch.int32).view(1)
+        else:
+            bad = ((labels != -100) & (plan["row_pos"] >= kv_len.long().index_select(0, plan["row_seq"]))).sum().to(torch.int32).view(1)
         host = torch.empty(kv_len.numel() + 1, dtype=torch.int32, pin_memory=True)
         host.copy_(torch.cat((kv_len, bad)), non_blocking=True)
         ev = torch.cuda.Event()
         ev.record()
         return host, ev
 
-    def _split_layout(self, plan, kv_len, pending):
+    def _split_layout(self, plan, kv_len, pending, infer=False):
         """Backward on the unmasked rows only.  A row behind its sequence's last unmasked key (a padded pair row; a [PAD] row of
         the text pass) that carries no MLM label has an exactly-zero gradient at the encoder output (the heads read [CLS] rows,
         the MLM loss ignores it), nothing flows into it through attention (as a key its probability is exactly 0, so dK = dV = 0;
@@ -710,6 +738,8 @@ class _GpuModelBase(nn.Module):
         valid = host[:-1].numpy().copy()
         if int(valid.sum()) > 0.97 * lay.tokens:
             return None
+        if infer:
+            return ops.SplitLayout(lay, valid, kv_len.device, dedupe=True)
         self.last_backward_row_fraction = float(valid.sum()) / lay.tokens
         return ops.SplitLayout(lay, valid, kv_len.device)
 

@@ -303,19 +303,31 @@ class SplitLayout:
     Dropout indices, key-bias slots and ``seq_len`` stay those of the ORIGINAL sequences, so masks do not depend on the packing.
     Built per batch on the host (numpy) and shipped in one copy."""
 
-    def __init__(self, base: SeqLayout, valid, device):
+    def __init__(self, base: SeqLayout, valid, device, dedupe=False):
+        """``dedupe`` (inference without dropout only): the masked-out rows of a sequence all have the same input and see the same
+        keys, hence the same hidden states in every layer -- region B keeps ONE of them per sequence and ``inv`` maps all of them
+        to it (``perm`` is then shorter than ``inv``: not a permutation, forward only)."""
         lens = np.asarray(base.lens, dtype=np.int64)
         v = np.minimum(np.asarray(valid, dtype=np.int64), lens)
         pad = lens - v
         start_a = np.concatenate(([0], np.cumsum(v)[:-1]))
         self.rows_a = int(v.sum())
         self.valid_host = [int(x) for x in v]
-        start_b = self.rows_a + np.concatenate(([0], np.cumsum(pad)[:-1]))
         rs, rp = base._row_seq, base._row_pos
         is_valid = rp < v[rs]
-        inv = np.where(is_valid, start_a[rs] + rp, start_b[rs] + rp - v[rs])
-        perm = np.empty_like(inv)
-        perm[inv] = np.arange(inv.size)
+        if dedupe:
+            pad = np.minimum(pad, 1)
+            start_b = self.rows_a + np.concatenate(([0], np.cumsum(pad)[:-1]))
+            inv = np.where(is_valid, start_a[rs] + rp, start_b[rs])
+            keep = is_valid | (rp == v[rs])
+            perm = np.empty(self.rows_a + int(pad.sum()), dtype=inv.dtype)
+            perm[inv[keep]] = np.nonzero(keep)[0]
+            lens = v + pad                                   # the sequences as the attention tiles see them
+        else:
+            start_b = self.rows_a + np.concatenate(([0], np.cumsum(pad)[:-1]))
+            inv = np.where(is_valid, start_a[rs] + rp, start_b[rs] + rp - v[rs])
+            perm = np.empty_like(inv)
+            perm[inv] = np.arange(inv.size)
         rows = base._rows_f
         f_seq, f_r0, f_sh, f_end, q_seq, q_r0, q_sh, q_end = [], [], [], [], [], [], [], []
         for i in range(len(lens)):
@@ -336,7 +348,8 @@ class SplitLayout:
         (self.ftile_seq, self.ftile_r0, self.ftile_qshift, self.ftile_qend, self.tile_seq, self.tile_r0, self.qtile_qshift,
          self.qtile_qend, self.seq_start, self.kv_len) = part
         self.nftiles, self.ntiles = nf, nq
-        self.perm, self.inv = dev_p[:inv.size], dev_p[inv.size:]
+        self.perm, self.inv = dev_p[:perm.size], dev_p[perm.size:]
+        self.rows_packed = int(perm.size)
         self.base, self.heads, self.tokens, self.lens = base, base.heads, base.tokens, base.lens
         self.seq_len, self.elem_base, self.bias_start, self.bias_len = base.seq_len, base.elem_base, base.bias_start, base.bias_len
         self.split = True

@@ -295,6 +295,33 @@ def test_sparse_backward_of_the_top_layer_equals_dense(train):
         assert float((a - b).abs().max()) <= 2e-3 * scale + 1e-7, (n, float((a - b).abs().max()), scale)
 
 
+def test_inference_dedupes_masked_rows_exactly():
+    """Without dropout and autograd the masked-out rows of a sequence are identical in every layer (same input, same keys), so
+    inference keeps one of them per sequence: every output -- losses, regression logits, all prediction scores incl. those of
+    the padded positions -- is bit-identical to the full computation."""
+    cfg = dict(hidden=256, layers=2, heads=4, intermediate=1024, vocab=4096, dataset="mosei", alpha=1.0, beta=1.0)
+    dbatch = batch_to(synthetic_batch(4, 24, 200, 130, dataset="mosei", vocab=cfg["vocab"], seed=35), DEV)
+    m = build(cfg)
+    outs = {}
+    for dd in (True, False):
+        m.dedupe_masked_rows = dd
+        seen = []
+        orig = m._split_layout
+        m._split_layout = lambda *a, _o=orig, _s=seen: (_s.append(_o(*a)), _s[-1])[1]
+        with torch.no_grad():
+            outs[dd] = m(**dbatch)
+        m._split_layout = orig
+        assert (seen[0] is not None) == dd
+        if dd:
+            assert seen[0].rows_packed < 0.9 * seen[0].tokens
+    (oa, la), (ob, lb) = outs[True], outs[False]
+    assert torch.equal(la, lb)
+    for i in (0, 4, 5, 6):
+        assert float(oa[i]) == float(ob[i])
+    for k in (7, 8, 9, 10, 11, 12):
+        assert torch.equal(oa[k], ob[k]), k
+
+
 def test_dropout_train_mode_is_seeded_and_unbiased():
     batch = batch_to(synthetic_batch(2, 50, 64, 64, seed=1), DEV)
     m = build(CFG1, train=True)
