@@ -17,6 +17,11 @@ Extra objects on the JSON line:
                   taken INSIDE the timed region with HIP events on the launch stream.
   cpu_baseline -- the CPU oracle (oracle/mmbert_oracle.py, kind "port") timed on this box's host
                   cores on a bounded sample: the same model/shapes at batch 4, one fwd+bwd step (~10 s on the box's 16-CPU quota).
+  fused1050    -- secondary: the same train step on ONE sequence text|visual|speech (S = 1050), a declared extension
+                  (model.forward_fused); never the headline value.
+config.tflop_per_sample is the dense algorithmic count; config.tflop_per_sample_executed subtracts the
+work whose result is exactly zero and therefore skipped (MLM-head backward of unlabelled rows, backward of rows behind a
+sequence's last unmasked key, attention over masked-out keys: DESIGN.md S2/S3); step_mfma_frac uses the executed count.
 """
 import argparse
 import json
