@@ -63,6 +63,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--no-fused", action="store_true", help="skip the secondary fused-sequence (S = T+V+A) measurement")
+    ap.add_argument("--no-dense-reference", action="store_true", help="skip the secondary measurement with the exact-zero short cuts off")
     ap.add_argument("--overlap-wgrad", action="store_true", help="weight-gradient GEMMs on a side stream (measured slower)")
     ap.add_argument("--eval-dropout-off", action="store_true", help="diagnostic only: not a valid headline number")
     ap.add_argument("--no-skip-masked-keys", action="store_true", help="A/B: attention also visits the key tiles that are entirely masked out")
@@ -159,11 +160,36 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     record[0] = False
+    main_row_frac = row_frac[-a.steps:]                   # (the secondary loops below append their own)
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(t)
     loss = float(last)
+
+    # For reference: the same step with every exact-zero short cut switched off (attention visits the masked-out keys, backward
+    # runs on all rows and densely through the top layer); identical gradients up to fp32 summation order, never the headline.
+    dense_ref = None
+    if not a.no_dense_reference and (model.skip_masked_keys or model.skip_padded_backward or model.sparse_top_layer_backward):
+        saved_flags = (model.skip_masked_keys, model.skip_padded_backward, model.sparse_top_layer_backward)
+        model.skip_masked_keys = model.skip_padded_backward = model.sparse_top_layer_backward = False
+        for i in range(min(a.warmup, 3) + 1):
+            step(i)
+        torch.cuda.synchronize()
+        barrier()
+        td0 = time.perf_counter()
+        for i in range(a.steps):
+            step(i)
+        torch.cuda.synchronize()
+        barrier()
+        delapsed = time.perf_counter() - td0
+        if world > 1:
+            t = torch.tensor([delapsed], device=dev, dtype=torch.float64)
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+            delapsed = float(t)
+        model.skip_masked_keys, model.skip_padded_backward, model.sparse_top_layer_backward = saved_flags
+        dense_ref = {"value": round(a.steps * a.batch * world / delapsed, 2), "unit": "samples/s", "ms_per_step": round(1e3 * delapsed / a.steps, 3),
+                     "note": "same step with the exact-zero short cuts off: all keys, all rows in backward (MLM-head backward still on labelled rows)"}
 
     # Secondary: the same train step on the fused single sequence text | visual | speech (S = T + V + A = 1050), the shape
     # BASELINE.json's metric name quotes.  The reference never builds that sequence (its step is the three passes above), so
@@ -209,7 +235,7 @@ def main():
     tokens = a.text + 2 * (a.text + a.pair)
     # ... and the rest of backward runs on the rows that can have a gradient (valid-first packing): f = their share,
     # measured per step; attention forward skips the masked-out key tiles (~ the same share of its keys)
-    f = sum(row_frac[-a.steps:]) / max(1, len(row_frac[-a.steps:]))
+    f = sum(main_row_frac) / max(1, len(main_row_frac))
     fp = flop_parts(L, H, I, V, a.text, a.pair, a.pair)
     head_bwd = 2.0 * fp["head"] * (0.15 * 3 * a.text / tokens)
     fps_exec = (fp["proj"] + fp["attn"] * f + fp["head"] + fp["joint"]) + 2.0 * (fp["proj"] * f + fp["attn"] * f * f + fp["joint"] * f) + head_bwd
@@ -227,6 +253,8 @@ def main():
         "final_loss": round(loss, 4),
         "step_mfma_frac": round(fps_exec * value / world / 2.5e15, 4),
     }
+    if dense_ref is not None:
+        res["dense_backward_reference"] = dense_ref
     if fused is not None:
         res["fused1050"] = fused
     if rank == 0:
