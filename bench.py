@@ -64,6 +64,7 @@ def main():
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--no-fused", action="store_true", help="skip the secondary fused-sequence (S = T+V+A) measurement")
     ap.add_argument("--no-dense-reference", action="store_true", help="skip the secondary measurement with the exact-zero short cuts off")
+    ap.add_argument("--no-train-only", action="store_true", help="skip the secondary measurement without the returned prediction scores")
     ap.add_argument("--overlap-wgrad", action="store_true", help="weight-gradient GEMMs on a side stream (measured slower)")
     ap.add_argument("--eval-dropout-off", action="store_true", help="diagnostic only: not a valid headline number")
     ap.add_argument("--no-skip-masked-keys", action="store_true", help="A/B: attention also visits the key tiles that are entirely masked out")
@@ -191,6 +192,31 @@ def main():
         dense_ref = {"value": round(a.steps * a.batch * world / delapsed, 2), "unit": "samples/s", "ms_per_step": round(1e3 * delapsed / a.steps, 3),
                      "note": "same step with the exact-zero short cuts off: all keys, all rows in backward (MLM-head backward still on labelled rows)"}
 
+    # Secondary: the train step as trainer.py consumes it -- model.return_scores = False: the six prediction-score tensors that
+    # the reference's forward returns and its trainer never reads are not produced, so the MLM head runs on the labelled rows
+    # only (forward too) and the encoder leaves out the rows that only those scores would read.  Same losses and gradients
+    # (tests/test_model_gpu.py); not the headline, which keeps every returned tensor.
+    train_only = None
+    if not a.no_train_only:
+        model.return_scores = False
+        for i in range(min(a.warmup, 3) + 1):
+            step(i)
+        torch.cuda.synchronize()
+        barrier()
+        tt0 = time.perf_counter()
+        for i in range(a.steps):
+            step(i)
+        torch.cuda.synchronize()
+        barrier()
+        telapsed = time.perf_counter() - tt0
+        if world > 1:
+            t = torch.tensor([telapsed], device=dev, dtype=torch.float64)
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+            telapsed = float(t)
+        model.return_scores = True
+        train_only = {"value": round(a.steps * a.batch * world / telapsed, 2), "unit": "samples/s", "ms_per_step": round(1e3 * telapsed / a.steps, 3),
+                      "note": "model.return_scores = False: losses and gradients as in the headline step, the returned prediction scores are None"}
+
     # Secondary: the same train step on the fused single sequence text | visual | speech (S = T + V + A = 1050), the shape
     # BASELINE.json's metric name quotes.  The reference never builds that sequence (its step is the three passes above), so
     # this is a declared extension (model.forward_fused, checked against oracle.fused_forward) and never the headline value.
@@ -255,6 +281,8 @@ def main():
     }
     if dense_ref is not None:
         res["dense_backward_reference"] = dense_ref
+    if train_only is not None:
+        res["train_only"] = train_only
     if fused is not None:
         res["fused1050"] = fused
     if rank == 0:

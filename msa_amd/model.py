@@ -379,18 +379,24 @@ class _EncoderFn(torch.autograd.Function):
 
 
 class _PermuteRowsFn(torch.autograd.Function):
-    """rows[new] = x[perm[new]] for a PERMUTATION perm with inverse inv: the gradient is the gather by inv (autograd's generic
-    index_select backward is an index_add scatter: 6x slower on the [tokens, H] matrix)."""
+    """out[i] = x[fwd_idx[i]], gradient g_in[j] = g[bwd_idx[j]] -- for a permutation (bwd_idx its inverse) or for the packing that
+    leaves rows out: an index equal to the source's row count reads an appended zero row (``pad_fwd`` / ``pad_bwd``).  (Autograd's
+    generic index_select backward is an index_add scatter: 6x slower on the [tokens, H] matrix.)"""
 
     @staticmethod
-    def forward(ctx, x, perm, inv):
-        ctx.save_for_backward(inv)
-        return x.index_select(0, perm)
+    def forward(ctx, x, fwd_idx, bwd_idx, pad_fwd=False, pad_bwd=False):
+        ctx.save_for_backward(bwd_idx)
+        ctx.pad_bwd = pad_bwd
+        if pad_fwd:
+            x = torch.cat((x, x.new_zeros((1, x.shape[1]))))
+        return x.index_select(0, fwd_idx)
 
     @staticmethod
     def backward(ctx, g):
-        (inv,) = ctx.saved_tensors
-        return g.index_select(0, inv), None, None
+        (bwd_idx,) = ctx.saved_tensors
+        if ctx.pad_bwd:
+            g = torch.cat((g, g.new_zeros((1, g.shape[1]))))
+        return g.index_select(0, bwd_idx), None, None, None, None
 
 
 def mlm_active_rows(labels, vocab):
@@ -418,6 +424,29 @@ class _MLMHeadFn(torch.autograd.Function):
         V, Vp = cfg.vocab_size, top._flat.vpad
         keep = ctx.needs_input_grad[0]
         y = y.contiguous()
+        ctx.compact = False
+        if (not want_scores) and keep and rows is not None and getattr(top, "sparse_mlm_backward", True):
+            # the caller does not want the prediction scores: the whole head runs on the labelled rows only (the loss is a mean
+            # over them; trainer.py never reads the scores) -- forward included
+            idx_all, host, ev = rows
+            ev.synchronize()                                  # requested at the start of forward: long complete
+            n = int(host[0])
+            if 0 < n and 2 * n <= M:
+                sel32 = idx_all[:n]
+                sel = sel32.long()
+                y_c = y.index_select(0, sel)
+                pre_c = torch.empty_like(y_c)
+                t0_c = ops.gemm_nt(y_c, w["Wt"], bias=w["bt"], gelu=True, aux=pre_c)
+                t_c, mean_c, rstd_c = ops.ln_fwd(t0_c, w["mlm_ln_g"], w["mlm_ln_b"], cfg.layer_norm_eps, stats=True)
+                logits_c = ops.gemm_nt(t_c, w["word_h"], bias=w["pred_bias"])          # [n, Vpad] bf16
+                labels_c = labels.index_select(0, sel)
+                nseg = len(seg_bounds_host) - 1
+                bounds_c = torch.searchsorted(sel32, seg_bounds.to(sel32.dtype)).to(torch.int32)   # labelled rows are in row order
+                loss, inv, lse = ops.ce_fwd(logits_c, V, labels_c, bounds_c, nseg)
+                ctx.top, ctx.nseg, ctx.compact, ctx.M = top, nseg, True, M
+                ctx.set_materialize_grads(False)
+                ctx.save_for_backward(y_c, pre_c, t0_c, mean_c, rstd_c, t_c, logits_c, labels_c, bounds_c, inv, lse, sel)
+                return loss.clone(), None
         pre = torch.empty_like(y) if keep else None
         t0 = ops.gemm_nt(y, w["Wt"], bias=w["bt"], gelu=True, aux=pre)
         t, mean, rstd = ops.ln_fwd(t0, w["mlm_ln_g"], w["mlm_ln_b"], cfg.layer_norm_eps, stats=keep)
@@ -441,12 +470,23 @@ class _MLMHeadFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dloss, _unused):
-        y, pre, t0, mean, rstd, t, logits, labels, seg_bounds, inv, lse = ctx.saved_tensors
         w = ctx.top._w
         V = ctx.top.config.vocab_size
         if dloss is None:
             return None, None, None, None, None, None, None, None
         gs = dloss.contiguous().float()
+        if ctx.compact:
+            y_c, pre_c, t0_c, mean_c, rstd_c, t_c, logits_c, labels_c, bounds_c, inv, lse, sel = ctx.saved_tensors
+            dl = ops.ce_bwd(logits_c, V, labels_c, bounds_c, ctx.nseg, inv, gs, lse, logits_c)       # in place: the scores go nowhere
+            ops.gemm_tn(dl, t_c, w["g_word_pad"], bias_out=w["g_pred_bias"])
+            dt = ops.gemm_nt_splitk(dl, w["wordT"])
+            dt0 = ops.ln_bwd(dt, t0_c, mean_c, rstd_c, w["mlm_ln_g"], w["g_mlm_ln_g"], w["g_mlm_ln_b"])
+            dpre = ops.gelu_bwd(dt0, pre_c)
+            ops.gemm_tn(dpre, y_c, w["g_Wt"], bias_out=w["g_bt"])
+            dy = torch.zeros((ctx.M, y_c.shape[1]), device=y_c.device, dtype=y_c.dtype)
+            dy.index_copy_(0, sel, ops.gemm_nt(dpre, w["WtT"]))
+            return dy, None, None, None, None, None, None, None
+        y, pre, t0, mean, rstd, t, logits, labels, seg_bounds, inv, lse = ctx.saved_tensors
         M = y.shape[0]
         if ctx.rows is not None:
             idx_all, host, ev = ctx.rows
@@ -668,7 +708,9 @@ class _GpuModelBase(nn.Module):
                 e = _JointFn.apply(e, je.LayerNorm.weight, self, feats, info[1], B, T, ops.make_drop(p_joint, seed, 1001 + k))
             xs.append(e)
         x = torch.cat(xs) if len(xs) > 1 else xs[0]
-        split = self._split_layout(plan, kv_len, pending, infer)
+        # the caller does not want the prediction scores (trainer.py never reads them): rows that nothing else reads are left out
+        drop = (not infer) and labels is not None and not getattr(self, "return_scores", True)
+        split = self._split_layout(plan, kv_len, pending, infer, drop)
         # rows of the top layer's output that can have a gradient (MLM-labelled rows + the [CLS] rows the heads read): known
         # when the caller is forward() / forward_fused() -- only they guarantee that nothing else is differentiated
         top_rows = (rows, plan["first"]) if (rows is not None and getattr(self, "sparse_top_layer_backward", True)) else None
@@ -677,6 +719,9 @@ class _GpuModelBase(nn.Module):
         elif infer:
             y = _EncoderFn.apply(x.index_select(0, split.perm), bert.embeddings.LayerNorm.weight, self, split, key_bias, seed, None, None)
             y = y.index_select(0, split.inv)                          # every masked-out row reads its sequence's representative
+        elif getattr(split, "dropped", False):
+            y = _EncoderFn.apply(_PermuteRowsFn.apply(x, split.perm, split.inv, False, True), bert.embeddings.LayerNorm.weight, self, split, key_bias, seed, None, top_rows)
+            y = _PermuteRowsFn.apply(y, split.inv, split.perm, True, False)      # left-out rows read as zeros (nothing reads them)
         else:
             y = _EncoderFn.apply(_PermuteRowsFn.apply(x, split.perm, split.inv), bert.embeddings.LayerNorm.weight, self, split, key_bias, seed, None, top_rows)
             y = _PermuteRowsFn.apply(y, split.inv, split.perm)
@@ -718,7 +763,7 @@ class _GpuModelBase(nn.Module):
         ev.record()
         return host, ev
 
-    def _split_layout(self, plan, kv_len, pending, infer=False):
+    def _split_layout(self, plan, kv_len, pending, infer=False, drop=False):
         """Backward on the unmasked rows only.  A row behind its sequence's last unmasked key (a padded pair row; a [PAD] row of
         the text pass) that carries no MLM label has an exactly-zero gradient at the encoder output (the heads read [CLS] rows,
         the MLM loss ignores it), nothing flows into it through attention (as a key its probability is exactly 0, so dK = dV = 0;
@@ -741,7 +786,9 @@ class _GpuModelBase(nn.Module):
         if infer:
             return ops.SplitLayout(lay, valid, kv_len.device, dedupe=True)
         self.last_backward_row_fraction = float(valid.sum()) / lay.tokens
-        return ops.SplitLayout(lay, valid, kv_len.device)
+        lay2 = ops.SplitLayout(lay, valid, kv_len.device, drop=drop)
+        lay2.dropped = drop
+        return lay2
 
 class MMBertModel(_GpuModelBase):
     """REF:MMBertForPretraining.py:13-285.  Holds embeddings / encoder / pooler (+ jointEmbeddings)."""

@@ -303,10 +303,13 @@ class SplitLayout:
     Dropout indices, key-bias slots and ``seq_len`` stay those of the ORIGINAL sequences, so masks do not depend on the packing.
     Built per batch on the host (numpy) and shipped in one copy."""
 
-    def __init__(self, base: SeqLayout, valid, device, dedupe=False):
+    def __init__(self, base: SeqLayout, valid, device, dedupe=False, drop=False):
         """``dedupe`` (inference without dropout only): the masked-out rows of a sequence all have the same input and see the same
         keys, hence the same hidden states in every layer -- region B keeps ONE of them per sequence and ``inv`` maps all of them
-        to it (``perm`` is then shorter than ``inv``: not a permutation, forward only)."""
+        to it (``perm`` is then shorter than ``inv``: not a permutation, forward only).
+        ``drop`` (training when the caller does not ask for the prediction scores): region B is left out altogether -- nothing
+        but the returned scores ever reads those rows -- and ``inv`` sends them to row ``rows_a``, one past the packed matrix
+        (callers append a zero row before gathering)."""
         lens = np.asarray(base.lens, dtype=np.int64)
         v = np.minimum(np.asarray(valid, dtype=np.int64), lens)
         pad = lens - v
@@ -315,7 +318,13 @@ class SplitLayout:
         self.valid_host = [int(x) for x in v]
         rs, rp = base._row_seq, base._row_pos
         is_valid = rp < v[rs]
-        if dedupe:
+        if drop:
+            pad = np.zeros_like(pad)
+            start_b = np.full_like(start_a, self.rows_a)
+            inv = np.where(is_valid, start_a[rs] + rp, self.rows_a)
+            perm = np.nonzero(is_valid)[0]                   # valid rows keep their relative order: perm[inv[valid]] = valid
+            lens = v
+        elif dedupe:
             pad = np.minimum(pad, 1)
             start_b = self.rows_a + np.concatenate(([0], np.cumsum(pad)[:-1]))
             inv = np.where(is_valid, start_a[rs] + rp, start_b[rs])

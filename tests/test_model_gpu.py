@@ -322,6 +322,39 @@ def test_inference_dedupes_masked_rows_exactly():
         assert torch.equal(oa[k], ob[k]), k
 
 
+@pytest.mark.parametrize("train", [False, True])
+def test_training_without_returned_scores_equals_the_faithful_step(train):
+    """model.return_scores = False (what trainer.py needs: it never reads outputs[7..12]'s score tensors): the MLM head runs on the
+    labelled rows only -- forward too -- and the encoder leaves out the rows that only the returned scores would read.  Losses
+    and every parameter gradient equal the faithful step's (also in TRAIN mode with the same seed: the rows that remain keep
+    their packed positions, hence their dropout masks); the score slots are None."""
+    cfg = dict(hidden=256, layers=2, heads=4, intermediate=1024, vocab=4096, dataset="mosei", alpha=1.0, beta=1.0)
+    dbatch = batch_to(synthetic_batch(4, 24, 200, 130, dataset="mosei", vocab=cfg["vocab"], seed=37), DEV)
+    res = {}
+    for scores in (True, False):
+        m = build(cfg, train=train)
+        m.return_scores = scores
+        m.manual_seed(23)
+        seen, orig = [], m._split_layout
+        m._split_layout = lambda *a, _o=orig, _s=seen: (_s.append(_o(*a)), _s[-1])[1]
+        out, logits = m(**dbatch)
+        out[0].mean().backward()
+        torch.cuda.synchronize()
+        assert (out[7] is None and out[9] is None and out[11] is None) == (not scores)
+        assert seen[0] is not None and seen[0].dropped == (not scores)
+        if not scores:
+            assert seen[0].rows_packed == seen[0].rows_a < 0.9 * seen[0].tokens
+        res[scores] = ([float(out[i]) for i in (0, 4, 5, 6)], logits.detach().float().clone(),
+                       {n: q.grad.detach().float().clone() for n, q in m.named_parameters()})
+    for a, b in zip(res[False][0], res[True][0]):
+        assert abs(a - b) <= 2e-6 * abs(b) + 1e-7, (res[False][0], res[True][0])
+    assert float((res[False][1] - res[True][1]).abs().max()) <= 1e-5
+    for n in res[True][2]:
+        a, b = res[False][2][n], res[True][2][n]
+        scale = float(b.abs().max())
+        assert float((a - b).abs().max()) <= 2e-3 * scale + 1e-7, (n, float((a - b).abs().max()), scale)
+
+
 def test_dropout_train_mode_is_seeded_and_unbiased():
     batch = batch_to(synthetic_batch(2, 50, 64, 64, seed=1), DEV)
     m = build(CFG1, train=True)
