@@ -218,6 +218,16 @@ def test_fused_sequence_extension_matches_its_oracle():
     assert checked > 30
     # both projection matrices received a gradient (each pair block found its rows)
     assert float(m.bert.jointEmbeddings.Wv.weight.grad.abs().sum()) > 0 and float(m.bert.jointEmbeddings.Ws.weight.grad.abs().sum()) > 0
+    # the same step without the returned scores (sparse MLM head forward, masked-out tail rows left out): same losses, same gradients
+    g_full = {n: q.grad.detach().float().clone() for n, q in m.named_parameters()}
+    m2 = build(cfg)
+    m2.return_scores = False
+    out2, logits2 = m2.forward_fused(**batch_to(batch, DEV))
+    out2[0].mean().backward()
+    assert out2[7] is None and abs(float(out2[0]) - float(out[0])) <= 2e-6 * abs(float(out[0]))
+    for n, q in m2.named_parameters():
+        scale = float(g_full[n].abs().max())
+        assert float((q.grad.float() - g_full[n]).abs().max()) <= 2e-3 * scale + 1e-7, n
 
 
 def test_backward_on_unmasked_rows_only_equals_full_backward():
