@@ -144,6 +144,12 @@ int mmbert_ce_fwd(mmbert_stream_t stream, const void* logits, int ldv, int V, co
 int mmbert_ce_bwd(mmbert_stream_t stream, const void* logits, int ldv, int V, const int64_t* labels, int M,
                   const int* seg_bounds, int nseg, const float* inv_count, const float* gscale, const float* row_lse, void* dlogits, int ldd,
                   const int* rows /* NULL: all M rows; else a row list: dlogits row j = gradient of row rows[j] */, int nrows);
+/* Row maps of the valid-first packing (msa_amd/ops.py SplitLayout): inv[original row] = packed row, perm = the
+ * inverse, from the per-sequence unmasked lengths.  mode 0: masked-out rows behind all others, in order; 1: ONE shared row per
+ * sequence (inference); 2: left out (inv = rows_a). */
+int mmbert_split_rows(mmbert_stream_t stream, const int64_t* row_seq, const int64_t* row_pos, const int* start_a, const int* start_b,
+                      const int* valid, int mode, int M, int rows_a, int64_t* perm, int64_t* inv);
+
 /* idx[0..count) = the rows with a label in [0, V), ascending; every other row of the CE gradient is exactly zero (ignore_index),
  * so the head's backward may run on this list alone.  idx has room for M entries; count is one int on the device. */
 int mmbert_active_rows(mmbert_stream_t stream, const int64_t* labels, int M, int V, int* idx, int* count);

@@ -8,6 +8,22 @@
 // maps (int32) where a kernel gathers or scatters rows of the packed token matrix.
 #include "common.h"
 
+// Row maps of the valid-first packing (ops.SplitLayout): packed row of every original row (inv) and back (perm), from the
+// per-sequence unmasked length `valid`, the region starts and the row -> (sequence, position) tables.  mode 0: masked-out rows
+// go to region B in order; 1: all masked-out rows of a sequence share its ONE region-B row (inference); 2: they are left out
+// (inv = rows_a, one past the packed matrix).
+__global__ void split_rows_kernel(const int64_t* __restrict__ row_seq, const int64_t* __restrict__ row_pos, const int* __restrict__ start_a,
+                                  const int* __restrict__ start_b, const int* __restrict__ valid, int mode, int M, int rows_a,
+                                  int64_t* __restrict__ perm, int64_t* __restrict__ inv) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= M) return;
+    const int s = (int)row_seq[i], p = (int)row_pos[i], v = valid[s];
+    if (p < v) { const int n = start_a[s] + p; inv[i] = n; perm[n] = i; }
+    else if (mode == 0) { const int n = start_b[s] + p - v; inv[i] = n; perm[n] = i; }
+    else if (mode == 1) { const int n = start_b[s]; inv[i] = n; if (p == v) perm[n] = i; }
+    else inv[i] = rows_a;
+}
+
 extern "C" {
 int mmbert_gemm_tn(hipStream_t stream, const void* A, int lda, const void* B, int ldb, float* W, int ldw,
                    int M, int N, int K, int accumulate, float alpha, const float* alpha_dev, void* slab, float* bias_out);
@@ -749,6 +765,15 @@ int mmbert_ce_bwd(hipStream_t stream, const void* logits, int ldv, int V, const 
     if (nseg < 1 || nseg > 4 || (ldv & 7) || (ldd & 7) || ldv > CE_MAXC * 256 * 8 || V > ldv) return -1;
     hipLaunchKernelGGL(ce_row_kernel<1>, dim3(rows ? nrows : M), dim3(256), 0, stream, (const bf16_t*)logits, ldv, V, labels, seg_bounds, nseg, inv_count,
                        (float*)nullptr, (float*)row_lse, gscale, (bf16_t*)dlogits, ldd, rows);
+    MMB_CHECK_LAUNCH();
+    return 0;
+}
+
+int mmbert_split_rows(hipStream_t stream, const int64_t* row_seq, const int64_t* row_pos, const int* start_a, const int* start_b, const int* valid,
+                      int mode, int M, int rows_a, int64_t* perm, int64_t* inv) {
+    if (M <= 0) return 0;
+    if (mode < 0 || mode > 2) return -1;
+    hipLaunchKernelGGL(split_rows_kernel, dim3((M + 255) / 256), dim3(256), 0, stream, row_seq, row_pos, start_a, start_b, valid, mode, M, rows_a, perm, inv);
     MMB_CHECK_LAUNCH();
     return 0;
 }

@@ -291,8 +291,19 @@ class SeqLayout:
         self.ftile_r0 = mk(ftiles_r0, torch.int32)
         self.nftiles = len(ftiles_seq)
         self._rows_f = rows_f
+        self._row_dev = None
         self._row_seq = np.repeat(np.arange(len(lens)), lens)                      # host: sequence of every packed row
         self._row_pos = np.concatenate([np.arange(n) for n in lens]) if len(lens) else np.zeros(0, np.int64)
+
+
+def _seq_row_tables(self, device):
+    """(sequence, position) of every packed row as device int64 tensors (cached)."""
+    if self._row_dev is None:
+        self._row_dev = (torch.from_numpy(self._row_seq).to(device), torch.from_numpy(self._row_pos).to(device))
+    return self._row_dev
+
+
+SeqLayout.row_tables = _seq_row_tables
 
 
 class SplitLayout:
@@ -316,49 +327,68 @@ class SplitLayout:
         start_a = np.concatenate(([0], np.cumsum(v)[:-1]))
         self.rows_a = int(v.sum())
         self.valid_host = [int(x) for x in v]
-        rs, rp = base._row_seq, base._row_pos
-        is_valid = rp < v[rs]
+        on_gpu = torch.device(device).type == "cuda"         # the [tokens]-sized row maps come from a kernel there (mmbert_split_rows)
+        mode = 2 if drop else 1 if dedupe else 0
         if drop:
             pad = np.zeros_like(pad)
             start_b = np.full_like(start_a, self.rows_a)
-            inv = np.where(is_valid, start_a[rs] + rp, self.rows_a)
-            perm = np.nonzero(is_valid)[0]                   # valid rows keep their relative order: perm[inv[valid]] = valid
             lens = v
         elif dedupe:
             pad = np.minimum(pad, 1)
             start_b = self.rows_a + np.concatenate(([0], np.cumsum(pad)[:-1]))
-            inv = np.where(is_valid, start_a[rs] + rp, start_b[rs])
-            keep = is_valid | (rp == v[rs])
-            perm = np.empty(self.rows_a + int(pad.sum()), dtype=inv.dtype)
-            perm[inv[keep]] = np.nonzero(keep)[0]
             lens = v + pad                                   # the sequences as the attention tiles see them
         else:
             start_b = self.rows_a + np.concatenate(([0], np.cumsum(pad)[:-1]))
-            inv = np.where(is_valid, start_a[rs] + rp, start_b[rs] + rp - v[rs])
-            perm = np.empty_like(inv)
-            perm[inv] = np.arange(inv.size)
+        n_packed = self.rows_a + int(pad.sum())
+        if not on_gpu:                                       # host form of the same maps (CPU tests of the packing)
+            rs, rp = base._row_seq, base._row_pos
+            is_valid = rp < v[rs]
+            if drop:
+                inv = np.where(is_valid, start_a[rs] + rp, self.rows_a)
+                perm = np.nonzero(is_valid)[0]               # valid rows keep their relative order: perm[inv[valid]] = valid
+            elif dedupe:
+                inv = np.where(is_valid, start_a[rs] + rp, start_b[rs])
+                keep = is_valid | (rp == v[rs])
+                perm = np.empty(n_packed, dtype=inv.dtype)
+                perm[inv[keep]] = np.nonzero(keep)[0]
+            else:
+                inv = np.where(is_valid, start_a[rs] + rp, start_b[rs] + rp - v[rs])
+                perm = np.empty_like(inv)
+                perm[inv] = np.arange(inv.size)
         rows = base._rows_f
-        f_seq, f_r0, f_sh, f_end, q_seq, q_r0, q_sh, q_end = [], [], [], [], [], [], [], []
-        for i in range(len(lens)):
-            vi, n, a0, b0 = int(v[i]), int(lens[i]), int(start_a[i]), int(start_b[i])
-            for r0 in range(0, vi, rows):
-                f_seq.append(i); f_r0.append(r0); f_sh.append(a0); f_end.append(vi)
-            na = len(f_seq)
-            q_seq.extend(f_seq[na - (vi + rows - 1) // rows:]); q_r0.extend(f_r0[na - (vi + rows - 1) // rows:])
-            q_sh.extend(f_sh[na - (vi + rows - 1) // rows:]); q_end.extend(f_end[na - (vi + rows - 1) // rows:])
-            for r0 in range(vi, n, rows):
-                f_seq.append(i); f_r0.append(r0); f_sh.append(b0 - vi); f_end.append(n)
+        # tile lists (numpy, no per-sequence Python loop: this runs on the critical path of every step): region A tiles of all
+        # sequences, then region B tiles; backward uses the region A part only
+        ns_ = len(lens)
+        seq_ids = np.arange(ns_)
+
+        def tiles(count_rows, first_row, shift, end):
+            nt = (count_rows + rows - 1) // rows
+            sq = np.repeat(seq_ids, nt)
+            k = np.arange(int(nt.sum())) - np.repeat(np.cumsum(nt) - nt, nt)
+            return sq, first_row[sq] + k * rows, shift[sq], end[sq]
+        qa = tiles(v, np.zeros_like(v), start_a, v)
+        qb = tiles(lens - v, v, start_b - v, lens)
+        q_seq, q_r0, q_sh, q_end = qa
+        f_seq, f_r0, f_sh, f_end = (np.concatenate((x, y)) for x, y in zip(qa, qb))
         nf, nq, ns = len(f_seq), len(q_seq), len(lens)
-        ints = np.concatenate([np.asarray(x, dtype=np.int32) for x in (f_seq, f_r0, f_sh, f_end, q_seq, q_r0, q_sh, q_end, start_a, v)])
+        ints = np.concatenate([np.asarray(x, dtype=np.int32) for x in (f_seq, f_r0, f_sh, f_end, q_seq, q_r0, q_sh, q_end, start_a, v, start_b)])
         dev_i = torch.from_numpy(ints).to(device, non_blocking=True)
-        dev_p = torch.from_numpy(np.concatenate((perm, inv))).to(device, non_blocking=True)
-        cut = np.cumsum([0, nf, nf, nf, nf, nq, nq, nq, nq, ns, ns])
-        part = [dev_i[cut[k]:cut[k + 1]] for k in range(10)]
+        cut = np.cumsum([0, nf, nf, nf, nf, nq, nq, nq, nq, ns, ns, ns])
+        part = [dev_i[cut[k]:cut[k + 1]] for k in range(11)]
         (self.ftile_seq, self.ftile_r0, self.ftile_qshift, self.ftile_qend, self.tile_seq, self.tile_r0, self.qtile_qshift,
-         self.qtile_qend, self.seq_start, self.kv_len) = part
+         self.qtile_qend, self.seq_start, self.kv_len, start_b_dev) = part
         self.nftiles, self.ntiles = nf, nq
-        self.perm, self.inv = dev_p[:perm.size], dev_p[perm.size:]
-        self.rows_packed = int(perm.size)
+        M = base.tokens
+        if on_gpu:
+            rs_d, rp_d = base.row_tables(device)
+            dev_p = torch.empty(n_packed + M, dtype=torch.int64, device=device)
+            _lib.check(_lib.load().mmbert_split_rows(_stream(), rs_d.data_ptr(), rp_d.data_ptr(), self.seq_start.data_ptr(), start_b_dev.data_ptr(),
+                                                     self.kv_len.data_ptr(), mode, M, self.rows_a, dev_p.data_ptr(), dev_p.data_ptr() + 8 * n_packed),
+                       "mmbert_split_rows")
+        else:
+            dev_p = torch.from_numpy(np.concatenate((perm, inv))).to(device)
+        self.perm, self.inv = dev_p[:n_packed], dev_p[n_packed:]
+        self.rows_packed = n_packed
         self.base, self.heads, self.tokens, self.lens = base, base.heads, base.tokens, base.lens
         self.seq_len, self.elem_base, self.bias_start, self.bias_len = base.seq_len, base.elem_base, base.bias_start, base.bias_len
         self.split = True
