@@ -327,7 +327,7 @@ def test_inference_dedupes_masked_rows_exactly():
     (oa, la), (ob, lb) = outs[True], outs[False]
     assert torch.equal(la, lb)
     for i in (0, 4, 5, 6):
-        assert float(oa[i]) == float(ob[i])
+        assert abs(float(oa[i]) - float(ob[i])) <= 1e-6 * abs(float(ob[i]))      # (the loss sums use fp32 atomics: not bit-stable run to run)
     for k in (7, 8, 9, 10, 11, 12):
         assert torch.equal(oa[k], ob[k]), k
 
