@@ -384,6 +384,35 @@ def test_attention_skips_trailing_masked_keys_exactly(ops, p):
     assert float(d1[320:550, H:].abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("mode", ["split", "dedupe", "drop"])
+def test_split_layout_row_maps_kernel_equals_host_form(ops, mode):
+    """ops.SplitLayout builds its [tokens]-sized row maps with mmbert_split_rows on the GPU and with numpy on the CPU: same maps,
+    same tile lists, and the maps are consistent (every kept row round-trips, every forward tile row is covered once)."""
+    import numpy as np
+    lens = [50] * 5 + [550, 300, 129, 128, 64]
+    valid = [27, 50, 31, 44, 50, 377, 300, 1, 128, 63]
+    base = ops.SeqLayout(lens, 4, DEV)
+    kw = dict(dedupe=(mode == "dedupe"), drop=(mode == "drop"))
+    g = ops.SplitLayout(base, valid, DEV, **kw)
+    c = ops.SplitLayout(base, valid, "cpu", **kw)
+    torch.cuda.synchronize()
+    for name in ("perm", "inv", "ftile_seq", "ftile_r0", "ftile_qshift", "ftile_qend", "tile_seq", "tile_r0", "qtile_qshift", "qtile_qend",
+                 "seq_start", "kv_len"):
+        assert torch.equal(getattr(g, name).cpu(), getattr(c, name)), name
+    assert g.rows_a == sum(valid) and g.rows_packed == c.rows_packed
+    perm, inv = g.perm.cpu().numpy(), g.inv.cpu().numpy()
+    kept = inv < g.rows_packed
+    assert (inv[perm] == np.arange(g.rows_packed)).all()                    # packed -> original -> packed
+    if mode == "split":
+        assert kept.all() and sorted(perm.tolist()) == list(range(sum(lens)))
+    if mode == "drop":
+        assert kept.sum() == g.rows_a and (inv[~kept] == g.rows_a).all()
+    cov = np.zeros(g.rows_packed, int)
+    for r0, sh, en in zip(g.ftile_r0.tolist(), g.ftile_qshift.tolist(), g.ftile_qend.tolist()):
+        cov[sh + r0: sh + min(r0 + 128, en)] += 1
+    assert (cov == 1).all()
+
+
 def test_attention_rescale_branch(ops):
     """Force the running max to jump at a later key tile (guide rule 26): spike one key."""
     n, heads, H = 200, 1, 64
