@@ -356,8 +356,23 @@ def cpu_baseline(a, L, H, I, V):
     out, _ = O.pretraining_forward(p, cfg, **batch, train=True)
     out[0].mean().backward()
     dt = time.perf_counter() - t0
+    # BASELINE.json configs[0], the reference's own CPU-runnable case (2-layer d=128, batch 2, T=50, A=V=64): medians of 3
+    cfg1 = dict(hidden=128, layers=2, heads=2, intermediate=512, vocab=V, dataset="mosei", alpha=1.0, beta=1.0)
+    p1 = {k: v.requires_grad_(True) for k, v in O.seeded_params(cfg1).items()}
+    b1 = synthetic_batch(2, 50, 64, 64, vocab=V, seed=1)
+    tf, tb = [], []
+    for _ in range(3):
+        t1 = time.perf_counter()
+        out1, _ = O.pretraining_forward(p1, cfg1, **b1, train=True)
+        t2 = time.perf_counter()
+        out1[0].mean().backward()
+        t3 = time.perf_counter()
+        tf.append(t2 - t1); tb.append(t3 - t1)
+    c1 = {"fwd_loss_samples_per_s": round(2 / sorted(tf)[1], 2), "fwd_bwd_samples_per_s": round(2 / sorted(tb)[1], 2),
+          "sample": "BASELINE configs[0]: 2-layer d=128, batch 2, T=50 A=V=64, median of 3"}
     return {"value": round(B / dt, 4), "unit": "samples/s", "cores": cores, "kind": "port",
-            "sample": f"oracle fwd+loss+bwd (fp32, dropout on), same model and S=50/550/550 shapes, batch {B}, 1 step = {dt:.1f} s"}
+            "sample": f"oracle fwd+loss+bwd (fp32, dropout on), same model and S=50/550/550 shapes, batch {B}, 1 step = {dt:.1f} s",
+            "configs0": c1}
 
 
 if __name__ == "__main__":
