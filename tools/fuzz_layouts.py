@@ -1,0 +1,49 @@
+#!/usr/bin/env python3
+"""Fuzz: random small shapes / padding patterns; the short cuts (masked-key skipping, valid-first packing, sparse top layer, no-scores
+mode, inference dedupe) against the plain dense path of the same model: losses and gradients must agree."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from oracle import mmbert_oracle as O
+from msa_amd.data import synthetic_batch, batch_to
+from msa_amd.model import MMBertConfig, MMBertForPretraining
+
+def build(cfg):
+    c = MMBertConfig(vocab_size=cfg["vocab"], hidden_size=cfg["hidden"], num_hidden_layers=cfg["layers"], num_attention_heads=cfg["heads"], intermediate_size=cfg["intermediate"])
+    m = MMBertForPretraining(c); m.bert.set_joint_embeddings(cfg["dataset"]); m.set_alpha_beta(1.0, 1.0)
+    m.load_state_dict(O.seeded_params(cfg, 0), strict=False)
+    return m.cuda().eval()
+
+rng = np.random.default_rng(int(os.environ.get("SEED", 0)))
+bad = 0
+for it in range(int(os.environ.get("N", 24))):
+    heads = int(rng.choice([1, 2, 4])); hidden = 64 * heads
+    cfg = dict(hidden=hidden, layers=int(rng.integers(1, 4)), heads=heads, intermediate=4 * hidden, vocab=int(rng.choice([1024, 4096])),
+               dataset=str(rng.choice(["mosei", "mosi", "ur_funny"])), alpha=1.0, beta=1.0)
+    B, T, Pv, Pa = int(rng.integers(1, 6)), int(rng.integers(4, 60)), int(rng.integers(1, 400)), int(rng.integers(1, 300))
+    full = bool(rng.random() < 0.2)
+    batch = batch_to(synthetic_batch(B, T, Pv, Pa, dataset=cfg["dataset"], vocab=cfg["vocab"], seed=100 + it, full_length=full), "cuda")
+    res = {}
+    for mode in ("dense", "fast", "noscores"):
+        m = build(cfg)
+        on = mode != "dense"
+        m.skip_masked_keys = m.skip_padded_backward = m.sparse_top_layer_backward = on
+        m.return_scores = mode != "noscores"
+        out, logits = m(**batch)
+        out[0].mean().backward()
+        res[mode] = ([float(out[i]) for i in (0, 4, 5, 6)], {n: q.grad.float().clone() for n, q in m.named_parameters()}, out)
+    with torch.no_grad():
+        m = build(cfg); m.dedupe_masked_rows = True; o1, l1 = m(**batch)
+        m.dedupe_masked_rows = False; o2, l2 = m(**batch)
+    ok = all(torch.equal(o1[k], o2[k]) for k in (7, 9, 11)) and torch.equal(l1, l2)
+    for mode in ("fast", "noscores"):
+        for a, b in zip(res[mode][0], res["dense"][0]):
+            ok &= abs(a - b) <= 3e-6 * abs(b) + 1e-7
+        for n in res["dense"][1]:
+            g0, g1 = res["dense"][1][n], res[mode][1][n]
+            ok &= float((g1 - g0).abs().max()) <= 3e-3 * float(g0.abs().max()) + 1e-7
+    ok &= all(torch.equal(res["fast"][2][k], res["dense"][2][k]) for k in (7, 9, 11))
+    bad += (not ok)
+    print(f"{it:2d} {'ok ' if ok else 'BAD'} L={cfg['layers']} H={hidden} heads={heads} {cfg['dataset']:8s} B={B} T={T} Pv={Pv} Pa={Pa} full={full} rowfrac={getattr(m, 'last_backward_row_fraction', 1):.2f}", flush=True)
+print("failures:", bad)
+sys.exit(1 if bad else 0)
