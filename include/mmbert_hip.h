@@ -6,8 +6,11 @@
  * binds instead of those ATen calls (INTEGRATION.md shows the ctypes stubs).  Every entry point:
  *   - is extern "C", takes plain device pointers / sizes / strides (elements) and a hipStream_t,
  *   - returns 0, a negative value for rejected arguments, or a positive hipError_t,
- *   - allocates nothing, synchronises nothing, keeps no state between calls (graph-capturable);
- *     workspaces are passed in by the caller.
+ *   - allocates no device memory, synchronises nothing and keeps no per-call state (graph-capturable): every workspace,
+ *     the tile queue of the persistent GEMM included, is passed in by the caller.  Process-global and documented as such:
+ *     the one-time per-device opt-in of kernels to > 64 KiB of LDS (hipFuncSetAttribute on first use -- warm each kernel up once
+ *     before capturing a graph), a cached CU count per device, and the two test / A-B knobs mmbert_gemm_nt_force and
+ *     mmbert_gemm_tn_force_splits (atomics, default 0 = choose by shape; every choice computes the same product).
  * bf16 tensors are row-major `uint16` storage; "ld*" are leading dimensions in elements.
  * REF: = /root/reference/<file>:<line>;  HF: = transformers models/bert/modeling_bert.py (5.15.0).
  */
@@ -32,10 +35,15 @@ typedef struct ihipStream_t* mmbert_stream_t;   /* == hipStream_t */
 /* C[M,N] = epi(alpha * alpha_dev[0] * A[M,K] . B[N,K]^T).  Replaces nn.Linear forward (HF:175-177,
  * 289, 334, 347, 476, 493) and, with the transposed bf16 weight copy as B, its input gradient.
  * K % 64 == 0, N % 4 == 0.  Accepted epi: 0, 1, 1|2, 1|4, 4, 8, 16, 1|16. */
+/* tile_queue (may be NULL): two ints in device memory, zero before the first launch that uses them; the persistent kernel then
+ * draws its tiles from this queue instead of the static b, b+G, ... schedule and leaves both ints zero again when it exits, so
+ * one 8-byte buffer serves all launches of ONE stream (launches that share a queue must not overlap).  For processes whose
+ * GEMMs share the CUs with concurrently running kernels of another stream (data-parallel training: RCCL's channel kernels hold
+ * CUs while the gradient all-reduce overlaps backward; a late workgroup would otherwise run its whole static share alone). */
 int mmbert_gemm_nt(mmbert_stream_t stream, const void* A, int lda, const void* B, int ldb, void* C, int ldc,
                    int M, int N, int K, int epi, const float* bias, const void* R, int ldr, void* aux, int ldaux,
                    const void* U, int ldu, float alpha, const float* alpha_dev,
-                   uint32_t drop_stream, uint32_t drop_thr16, float drop_scale);
+                   uint32_t drop_stream, uint32_t drop_thr16, float drop_scale, int* tile_queue);
 
 /* Split-K form of the plain product (C bf16 = A . B^T) for long K with few output tiles: fp32 partial slabs in the
  * caller's workspace (mmbert_gemm_nt_splitk_workspace() bytes), reduced deterministically. */
@@ -47,9 +55,6 @@ size_t mmbert_gemm_nt_splitk_workspace(int M, int N, int K);
  * with the tile height (256 or 224 rows) chosen by tile-round count, 3 = ring kernel 256x256, 4 = ring kernel
  * 224x256.  For tests and A/B benchmarking; results are identical up to fp32 summation order. */
 void mmbert_gemm_nt_force(int mode);
-/* Persistent NT kernel: draw tiles from a device-side queue instead of the static b, b+G, ... schedule.  For processes whose
- * GEMMs share the GPU's CUs with concurrently running kernels of another stream (data-parallel training: RCCL). */
-void mmbert_gemm_nt_dynamic(int on);
 /* Split count of the token axis in mmbert_gemm_tn / _grouped: 0 = by shape (default), > 0 forced.  A/B benchmarking. */
 void mmbert_gemm_tn_force_splits(int splits);
 

@@ -15,9 +15,8 @@ P, I, F, U32, SZ, U64 = C.c_void_p, C.c_int, C.c_float, C.c_uint32, C.c_size_t, 
 
 # name -> (restype, argtypes); must list every symbol of include/mmbert_hip.h
 SIGNATURES = {
-    "mmbert_gemm_nt": (I, [P, P, I, P, I, P, I, I, I, I, I, P, P, I, P, I, P, I, F, P, U32, U32, F]),
+    "mmbert_gemm_nt": (I, [P, P, I, P, I, P, I, I, I, I, I, P, P, I, P, I, P, I, F, P, U32, U32, F, P]),
     "mmbert_gemm_nt_force": (None, [I]),
-    "mmbert_gemm_nt_dynamic": (None, [I]),
     "mmbert_gemm_nt_splitk": (I, [P, P, I, P, I, P, I, I, I, I, P]),
     "mmbert_gemm_nt_splitk_workspace": (SZ, [I, I, I]),
     "mmbert_gemm_tn_force_splits": (None, [I]),
@@ -76,8 +75,6 @@ def load() -> C.CDLL:
         fn = getattr(lib, name)          # AttributeError if the symbol is missing -> loud
         fn.restype = res
         fn.argtypes = args
-    if os.environ.get("MMBERT_NT_DYNAMIC"):
-        lib.mmbert_gemm_nt_dynamic(int(os.environ["MMBERT_NT_DYNAMIC"]))
     mode = os.environ.get("MMBERT_NT_MODE")          # A/B benchmarking only: kernel selection of mmbert_gemm_nt
     if mode:
         lib.mmbert_gemm_nt_force(int(mode))

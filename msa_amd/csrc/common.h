@@ -13,6 +13,20 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 
 #define MMB_CHECK_LAUNCH() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return (int)e_; } while (0)
 
+#include <atomic>
+// One-time opt-in of a kernel to more than 64 KiB of dynamic LDS, per device.  `done` is the call site's bit mask of devices
+// already set (thread-safe; the attribute call itself is idempotent).  Returns 0 or a hipError_t.
+static inline int mmb_allow_lds(const void* fn, int bytes, std::atomic<unsigned long long>& done) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return (int)hipErrorInvalidDevice;
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (done.load(std::memory_order_acquire) & bit) return 0;
+    const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e != hipSuccess) return (int)e;
+    done.fetch_or(bit, std::memory_order_release);
+    return 0;
+}
+
 // address-space casts for the LDS-DMA builtin
 #define GPTR(p) ((const void __attribute__((address_space(1)))*)(p))
 #define LPTR(p) ((void __attribute__((address_space(3)))*)(p))

@@ -14,6 +14,7 @@
 // NT reads fragments with ds_read_b128 (rows are K-contiguous).  TN needs 8 consecutive m for one
 // column, i.e. a column of the row-major LDS tile: ds_read_b64_tr_b16 (hardware transpose read).
 #include "common.h"
+#include <atomic>
 #include <type_traits>
 
 #define EPI_BIAS 1
@@ -29,7 +30,7 @@ struct GemmNT {
     float alpha;
     uint32_t drop_stream, drop_thr16; float drop_scale;
     int kt_per_split; long long split_stride;     // gemm_nt_kernel only: split-K over blockIdx.z into fp32 slabs (0 = no split)
-    int* tile_counter; int* tile_counter_next;    // gemm_ntp_kernel only: dynamic tile queue (null = static b, b+G, ...)
+    int* tile_counter; int* tile_counter_next;    // gemm_ntp_kernel only: dynamic tile queue = {fetch counter, exit counter} (null = static b, b+G, ...)
 };
 
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
@@ -223,12 +224,8 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const GemmNT p) {
 template <int EPI>
 static int launch_nt(hipStream_t s, const GemmNT& p) {
     const int tiles = ((p.M + 127) / 128) * ((p.N + 127) / 128);
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)gemm_nt_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
-        if (e != hipSuccess) return (int)e;
-        attr_set = true;
-    }
+    static std::atomic<unsigned long long> attr_done{0};
+    if (int e = mmb_allow_lds((const void*)gemm_nt_kernel<EPI>, 65536, attr_done)) return e;
     hipLaunchKernelGGL(gemm_nt_kernel<EPI>, dim3(tiles), dim3(256), 65536, s, p);
     MMB_CHECK_LAUNCH();
     return 0;
@@ -409,19 +406,24 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(const GemmNT p) {
 #endif
 }
 
-static int g_nt_force = 0;   // 0 auto, 1 force 128^2, 2 force the 256-wide kernels (tests / A-B benchmarking)
-static int g_nt_bm = 0;      // 0 auto, 256 / 224 forced (A-B benchmarking)
-static int g_nt_dynamic = 0;  // dynamic tile queue in the persistent kernel: mmbert_gemm_nt_dynamic(1), used when other kernels share the CUs
-static int g_nt_persist = 1;  // persistent stream kernel where eligible (0: launch-per-tile ring kernel)
+// Test / A-B knobs (mmbert_gemm_nt_force, mmbert_gemm_tn_force_splits): process-global, relaxed atomics, default 0 = "by shape".
+// They select between kernels that compute the same product; nothing else in the library keeps state between calls.
+static std::atomic<int> g_nt_force{0};   // 0 auto, 1 force 128^2, 2 force the 256-wide kernels
+static std::atomic<int> g_nt_bm{0};      // 0 auto, 256 / 224 forced
+static std::atomic<int> g_nt_persist{1}; // persistent stream kernel where eligible (0: launch-per-tile ring kernel)
 static int device_cus() {
-    static int cus = 0;
-    if (!cus) {
-        int dev = 0;
+    // per-device cache of the CU count (a process may drive several devices)
+    static std::atomic<int> cus[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+    int c = cus[dev].load(std::memory_order_relaxed);
+    if (!c) {
         hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 256;
-        cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+        if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return 256;
+        c = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+        cus[dev].store(c, std::memory_order_relaxed);
     }
-    return cus;
+    return c;
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -588,10 +590,8 @@ __global__ __launch_bounds__(512, 2) void gemm_ntp_kernel(const GemmNT p) {
     const float alpha = p.alpha * (p.alpha_dev ? *p.alpha_dev : 1.0f);
 
     int first_fetch = 0;
-    if (p.tile_counter && tid == 0) {
-        if (blockIdx.x == 0) *p.tile_counter_next = 0;               // the NEXT launch's queue (launches are stream-ordered)
+    if (p.tile_counter && tid == 0)
         first_fetch = G + atomicAdd(p.tile_counter, 1);              // issued ahead of the prologue loads, parked behind them
-    }
     bf16x8 a0[MI], b0[4], a1[MI], b1[4];
     if constexpr (STAG) {
         issue(0, cur, 0); issue(1, cur, 64); issue(2, cur, 128);
@@ -884,6 +884,17 @@ __global__ __launch_bounds__(512, 2) void gemm_ntp_kernel(const GemmNT p) {
 #undef NTP_BOFF
     if constexpr (STAG) { if (wr == 0) __builtin_amdgcn_s_barrier(); }   // balances the stagger barrier of the other group
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // the dead tail stages
+    {   // the last workgroup to leave hands the queue back zeroed (its fetches are complete: vmcnt(0) above) for the stream's next launch
+        auto kpe = __builtin_amdgcn_kernarg_segment_ptr();
+        asm volatile("" : "+s"(kpe));
+        const __attribute__((address_space(4))) GemmNT& qe = *(const __attribute__((address_space(4))) GemmNT*)kpe;
+        if (qe.tile_counter && tid == 0) {
+            if (atomicAdd(qe.tile_counter_next, 1) == (int)gridDim.x - 1) {
+                atomicExch(qe.tile_counter, 0);
+                atomicExch(qe.tile_counter_next, 0);
+            }
+        }
+    }
 #ifdef MMB_STAMPS
     if (g_stamps && lane == 0) {
         asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rt3) :: "memory");
@@ -899,32 +910,14 @@ template <int EPI, int MI>
 static int launch_ntp_mi(hipStream_t s, const GemmNT& p) {
     constexpr int BM = 32 * MI;
     const int tiles = ((p.M + BM - 1) / BM) * ((p.N + 255) / 256);
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)gemm_ntp_kernel<EPI, MI, MI == 8>, hipFuncAttributeMaxDynamicSharedMemorySize, NTP_LDS_BYTES);
-        if (e != hipSuccess) return (int)e;
-        attr_set = true;
-    }
+    static std::atomic<unsigned long long> attr_done{0};
+    if (int e = mmb_allow_lds((const void*)gemm_ntp_kernel<EPI, MI, MI == 8>, NTP_LDS_BYTES, attr_done)) return e;
     const int cus = device_cus();
     GemmNT q = p;
-    q.tile_counter = q.tile_counter_next = nullptr;
-    if (tiles > cus) {
-        // two counters used alternately: launch k draws from ctr[k & 1] and zeroes ctr[(k + 1) & 1] for its successor.  Valid
-        // for launches that are ordered on ONE stream (the forward / backward pass); a launch on another stream gets the
-        // static schedule.  8 bytes of device memory owned by the library, allocated once.
-        static int* ctr = nullptr;
-        static hipStream_t ctr_stream = nullptr;
-        static unsigned launches = 0;
-        if (!ctr) {
-            if (hipMalloc((void**)&ctr, 2 * sizeof(int)) == hipSuccess && hipMemset(ctr, 0, 2 * sizeof(int)) == hipSuccess) ctr_stream = s;
-            else ctr = nullptr;
-        }
-        if (ctr && s == ctr_stream && g_nt_dynamic) {
-            q.tile_counter = ctr + (launches & 1);
-            q.tile_counter_next = ctr + ((launches + 1) & 1);
-            ++launches;
-        }
-    }
+    // Dynamic tile queue: the CALLER's two zero-initialised ints (mmbert_gemm_nt(..., tile_queue)); the kernel leaves them zero
+    // again (the last workgroup to exit resets them), so one 8-byte buffer serves every launch of a stream.  Launches with no
+    // more tiles than workgroups need no queue.
+    if (tiles <= cus) q.tile_counter = q.tile_counter_next = nullptr;
     hipLaunchKernelGGL((gemm_ntp_kernel<EPI, MI, MI == 8>), dim3(tiles < cus ? tiles : cus), dim3(512), NTP_LDS_BYTES, s, q);
     MMB_CHECK_LAUNCH();
     return 0;
@@ -938,12 +931,8 @@ template <int EPI, int MI>
 static int launch_nt256_mi(hipStream_t s, const GemmNT& p) {
     constexpr int BM = 32 * MI;
     const int tiles = ((p.M + BM - 1) / BM) * ((p.N + 255) / 256);
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)gemm_nt256_kernel<EPI, MI>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
-        if (e != hipSuccess) return (int)e;
-        attr_set = true;
-    }
+    static std::atomic<unsigned long long> attr_done{0};
+    if (int e = mmb_allow_lds((const void*)gemm_nt256_kernel<EPI, MI>, 131072, attr_done)) return e;
     hipLaunchKernelGGL((gemm_nt256_kernel<EPI, MI>), dim3(tiles), dim3(512), 131072, s, p);
     MMB_CHECK_LAUNCH();
     return 0;
@@ -1327,12 +1316,8 @@ int mmbert_gemm_nt_splitk(hipStream_t stream, const void* A, int lda, const void
     p.kt_per_split = (kt + splits - 1) / splits;
     p.split_stride = (long long)M * N;
     const int zs = (kt + p.kt_per_split - 1) / p.kt_per_split;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)gemm_nt_kernel<EPI_OUT_F32>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
-        if (e != hipSuccess) return (int)e;
-        attr_set = true;
-    }
+    static std::atomic<unsigned long long> attr_done{0};
+    if (int e = mmb_allow_lds((const void*)gemm_nt_kernel<EPI_OUT_F32>, 65536, attr_done)) return e;
     hipLaunchKernelGGL(gemm_nt_kernel<EPI_OUT_F32>, dim3(((M + 127) / 128) * ((N + 127) / 128), 1, zs), dim3(256), 65536, stream, p);
     MMB_CHECK_LAUNCH();
     const long long n4 = ((long long)M * N + 3) / 4;
@@ -1344,7 +1329,7 @@ int mmbert_gemm_nt_splitk(hipStream_t stream, const void* A, int lda, const void
 int mmbert_gemm_nt(hipStream_t stream, const void* A, int lda, const void* B, int ldb, void* C, int ldc,
                    int M, int N, int K, int epi, const float* bias, const void* R, int ldr, void* aux, int ldaux,
                    const void* U, int ldu, float alpha, const float* alpha_dev,
-                   uint32_t drop_stream, uint32_t drop_thr16, float drop_scale) {
+                   uint32_t drop_stream, uint32_t drop_thr16, float drop_scale, int* tile_queue) {
     if (M <= 0 || N <= 0) return 0;
     if (K <= 0 || (K & 63) || (N & 3) || (lda & 7) || (ldb & 7) || (ldc & 3)) return -1;
     GemmNT p;
@@ -1352,7 +1337,8 @@ int mmbert_gemm_nt(hipStream_t stream, const void* A, int lda, const void* B, in
     p.aux = (bf16_t*)aux; p.U = (const bf16_t*)U; p.alpha_dev = alpha_dev;
     p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.ldr = ldr; p.ldaux = ldaux; p.ldu = ldu;
     p.alpha = alpha; p.drop_stream = drop_stream; p.drop_thr16 = drop_thr16; p.drop_scale = drop_scale;
-    p.kt_per_split = 0; p.split_stride = 0; p.tile_counter = p.tile_counter_next = nullptr;
+    p.kt_per_split = 0; p.split_stride = 0;
+    p.tile_counter = tile_queue; p.tile_counter_next = tile_queue ? tile_queue + 1 : nullptr;
     switch (epi) {
         case 0: return dispatch_nt<0>(stream, p);
         case EPI_BIAS: return dispatch_nt<EPI_BIAS>(stream, p);
@@ -1375,19 +1361,16 @@ int mmbert_debug_set_nt_dbg(int v) {
     return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_nt_dbg), &v, sizeof(v));
 }
 #endif
-// Dynamic tile queue of the persistent NT kernel (off by default: on a GPU of its own the static schedule is ~0.4 % faster;
-// on when kernels of another stream -- RCCL during the overlapped gradient all-reduce -- hold CUs, see gemm_ntp_kernel).
-void mmbert_gemm_nt_dynamic(int on) { g_nt_dynamic = on ? 1 : 0; }
 void mmbert_gemm_nt_force(int mode) {
     // 0 auto | 1 128^2 | ring kernel, one launch slot per tile: 2 (tile height auto), 3 (256x256), 4 (224x256)
     // | persistent stream kernel: 5 (tile height auto), 6 (256x256), 7 (224x256)
-    g_nt_force = mode >= 2 ? 2 : mode;
-    g_nt_bm = (mode == 3 || mode == 6) ? 256 : (mode == 4 || mode == 7) ? 224 : 0;
-    g_nt_persist = (mode >= 2 && mode <= 4) ? 0 : (mode >= 6 ? 2 : 1);      // 2: forced persistent tile height
+    g_nt_force.store(mode >= 2 ? 2 : mode);
+    g_nt_bm.store((mode == 3 || mode == 6) ? 256 : (mode == 4 || mode == 7) ? 224 : 0);
+    g_nt_persist.store((mode >= 2 && mode <= 4) ? 0 : (mode >= 6 ? 2 : 1));      // 2: forced persistent tile height
 }
 
-static int g_tn_splits = 0;   // 0 = by shape; > 0 forces the split count of the token axis (A/B benchmarking)
-void mmbert_gemm_tn_force_splits(int splits) { g_tn_splits = splits; }
+static std::atomic<int> g_tn_splits{0};   // 0 = by shape; > 0 forces the split count of the token axis (A/B benchmarking)
+void mmbert_gemm_tn_force_splits(int splits) { g_tn_splits.store(splits); }
 
 static int tn_plan(int nprob, const int* N, const int* K, int M, int* splits_out, int* tiles_out) {
     int tiles = 0;
@@ -1415,7 +1398,7 @@ static int tn_plan(int nprob, const int* N, const int* K, int M, int* splits_out
     for (int sp = 1; sp <= top; ++sp)
         if (cost[sp] <= 1.03 * best_cost) { best = sp; break; }
     int splits = best;
-    if (g_tn_splits > 0) splits = g_tn_splits;
+    if (g_tn_splits.load() > 0) splits = g_tn_splits.load();
     if (splits > max_splits) splits = max_splits;
     if (splits < 1) splits = 1;
     *splits_out = splits; *tiles_out = tiles;
@@ -1464,12 +1447,8 @@ int mmbert_gemm_tn_grouped(hipStream_t stream, int nprob, const void* const* A, 
     if (splits > 1 && !slab) return -3;
     g.slab = (float*)slab; g.alpha_dev = alpha_dev; g.slab_stride = off; g.nprob = nprob; g.total_tiles = tiles; g.M = M;
     g.splits = splits; g.rows_per_split = (((M + splits - 1) / splits) + 31) / 32 * 32; g.accumulate = accumulate; g.alpha = alpha;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)gemm_tn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
-        if (e != hipSuccess) return (int)e;
-        attr_set = true;
-    }
+    static std::atomic<unsigned long long> attr_done{0};
+    if (int e = mmb_allow_lds((const void*)gemm_tn_kernel, 131072, attr_done)) return e;
     hipLaunchKernelGGL(gemm_tn_kernel, dim3(tiles, splits), dim3(512), 131072, stream, g);
     MMB_CHECK_LAUNCH();
     if (splits > 1) {

@@ -230,12 +230,9 @@ int mmbert_heads_loss_fwd(hipStream_t stream, const float* P, const float* XP, c
     if (H > 1024 || B > 16) return -1;
     const size_t lds = ((size_t)2 * 16 * (H + 1) + 256 + 32 + 128) * sizeof(float);
     if (lds > 160 * 1024 - 256) return -1;                   // the kernel also has a few static LDS words
-    static size_t attr_bytes = 0;
-    if (lds > attr_bytes) {
-        hipError_t e = hipFuncSetAttribute((const void*)heads_loss_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return (int)e;
-        attr_bytes = lds;
-    }
+    constexpr int LDS_MAX = (2 * 16 * (1024 + 1) + 256 + 32 + 128) * (int)sizeof(float);     // the H = 1024 request: allowed once per device
+    static std::atomic<unsigned long long> attr_done{0};
+    if (int e = mmb_allow_lds((const void*)heads_loss_fwd_kernel, LDS_MAX, attr_done)) return e;
     hipLaunchKernelGGL(heads_loss_fwd_kernel, dim3(3), dim3(256), lds, stream, P, XP, B, H, beta, dXP, dPc, nce_part);
     MMB_CHECK_LAUNCH();
     hipLaunchKernelGGL(heads_loss_finish_kernel, dim3(1), dim3(256), 0, stream, rel, ap, lo, sent, (const float*)nce_part, B, beta, tanh_lo, out4, drel, dlo);

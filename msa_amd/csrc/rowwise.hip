@@ -404,13 +404,17 @@ __global__ __launch_bounds__(1024) void active_rows_kernel(const int64_t* __rest
     if (tid == 0) *count = base;
 }
 
-__global__ void ce_count_kernel(const int64_t* __restrict__ labels, int M, const int* __restrict__ seg_bounds, int nseg,
+// One predicate for "row i carries a label" in every kernel of the MLM head (ce_count / ce_row / active_rows): 0 <= label < V.
+// -100 is the reference's ignore_index; any other value outside the vocabulary makes torch's CrossEntropyLoss raise in the
+// reference -- here the host side counts such labels (model.mlm_active_rows) and raises when it reads the count.
+__global__ void ce_count_kernel(const int64_t* __restrict__ labels, int M, int V, const int* __restrict__ seg_bounds, int nseg,
                                 float* __restrict__ inv_count, float* __restrict__ loss_sum) {
     __shared__ int cnt[4];
     if (threadIdx.x < 4) cnt[threadIdx.x] = 0;
     __syncthreads();
     for (int i = threadIdx.x; i < M; i += blockDim.x) {
-        if (labels[i] != -100) {
+        const int64_t lab = labels[i];
+        if (lab >= 0 && lab < V) {
             int s = 0;
             while (s + 1 < nseg && i >= seg_bounds[s + 1]) ++s;
             atomicAdd(&cnt[s], 1);
@@ -441,7 +445,7 @@ __global__ __launch_bounds__(256) void ce_row_kernel(const bf16_t* __restrict__ 
     const int64_t lab = labels[i];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int nchunk = ldv >> 3;
-    if (lab == -100 || lab < 0 || lab >= V) {
+    if (lab < 0 || lab >= V) {
         if (MODE == 0) { if (tid == 0) row_lse[i] = 0.f; }
         else {
             bf16_t* drow = dlogits + (size_t)(rows ? blockIdx.x : i) * ldd;
@@ -750,7 +754,7 @@ int mmbert_ce_fwd(hipStream_t stream, const void* logits, int ldv, int V, const 
                   const int* seg_bounds, int nseg, float* inv_count, float* loss_sum, float* row_lse) {
     if (M <= 0) return 0;
     if (nseg < 1 || nseg > 4 || (ldv & 7) || ldv > CE_MAXC * 256 * 8 || V > ldv) return -1;
-    hipLaunchKernelGGL(ce_count_kernel, dim3(1), dim3(1024), 0, stream, labels, M, seg_bounds, nseg, inv_count, loss_sum);
+    hipLaunchKernelGGL(ce_count_kernel, dim3(1), dim3(1024), 0, stream, labels, M, V, seg_bounds, nseg, inv_count, loss_sum);
     MMB_CHECK_LAUNCH();
     hipLaunchKernelGGL(ce_row_kernel<0>, dim3(M), dim3(256), 0, stream, (const bf16_t*)logits, ldv, V, labels, seg_bounds, nseg, inv_count, loss_sum,
                        row_lse, (const float*)nullptr, (bf16_t*)nullptr, 0, (const int*)nullptr);

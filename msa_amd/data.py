@@ -11,7 +11,8 @@ the same tuple structure, dtypes and quirks directly:
 * text mask float64 with 0 at PAD (REF:model_utils.py:118-120); pair masks ``feature != 0`` with the
   features' shape (float64 for visual, int64 for speech, REF:model_utils.py:124-133); the
   text-with-pair masks are all ones (the ``==`` bug, REF:model_utils.py:128,136).
-* labels: -100 where not selected, 80 % of the selected inputs -> 103 (REF:model_utils.py:27-32);
+* labels: -100 where not selected, 80 % of the selected inputs -> 103 (REF:model_utils.py:27-32); [CLS]/[SEP] are never
+  selected, [PAD] positions are (the reference's PAD exclusion is a discarded ``masked_fill``, see ``_mask_tokens``);
   pair-position labels are a copy of the text labels when P == T (REF:trainer.py:50,53) and -100
   otherwise (the reference cannot express P != T through ``collate``).
 
@@ -26,10 +27,15 @@ PAD, CLS, SEP, MASK = 0, 101, 102, 103
 MODALITY_DIMS = {"mosi": (47, 74), "mosei": (35, 74), "ur_funny": (371, 81)}    # REF:config.py:13-17
 
 
-def _mask_tokens(rng, ids, p_mlm):
-    """REF:model_utils.py:6-39 on numpy arrays (special tokens never selected; PAD counts as
-    special because ``get_special_tokens_mask`` flags it)."""
-    special = (ids == PAD) | (ids == CLS) | (ids == SEP)
+def _mask_tokens(rng, ids, p_mlm, pad_selectable=True):
+    """REF:model_utils.py:6-39 on numpy arrays.  Never selected: [CLS] and [SEP] -- what transformers-2.8
+    ``BertTokenizer.get_special_tokens_mask(already_has_special_tokens=True)`` flags (the pin of REF:requirement.txt).
+    [PAD] positions ARE selectable in the reference: its PAD branch (:24-26) is a non-in-place ``masked_fill`` whose
+    result is dropped, so 15 % of the padding gets label 0 and 80 % of those become [MASK].  ``pad_selectable=False``
+    is the opt-in deviation (PAD never selected: what the branch was meant to do)."""
+    special = (ids == CLS) | (ids == SEP)
+    if not pad_selectable:
+        special |= ids == PAD
     select = (rng.random(ids.shape) < p_mlm) & ~special
     replace = (rng.random(ids.shape) < 0.8) & select
     labels = np.where(select, ids, -100)
@@ -38,7 +44,7 @@ def _mask_tokens(rng, ids, p_mlm):
 
 
 def synthetic_batch(batch: int, text_len: int, visual_len: int, speech_len: int, *, dataset="mosei",
-                    vocab=30522, seed=1, mlm_probability=0.15, full_length=False):
+                    vocab=30522, seed=1, mlm_probability=0.15, full_length=False, pad_selectable=True):
     """Returns the six keyword arguments of ``MMBertForPretraining.forward`` as CPU tensors:
     ``dict(input_ids=..., token_type_ids=..., attention_mask=..., masked_labels=..., ap_label=...,
     sentiment=...)``."""
@@ -62,9 +68,9 @@ def synthetic_batch(batch: int, text_len: int, visual_len: int, speech_len: int,
         return x
     visual, speech = feats(visual_len, vd), feats(speech_len, sd)
 
-    t_in, t_lab = _mask_tokens(rng, text, mlm_probability)
-    v_in, v_lab = _mask_tokens(rng, text, mlm_probability)
-    s_in, s_lab = _mask_tokens(rng, text, mlm_probability)
+    t_in, t_lab = _mask_tokens(rng, text, mlm_probability, pad_selectable)
+    v_in, v_lab = _mask_tokens(rng, text, mlm_probability, pad_selectable)
+    s_in, s_lab = _mask_tokens(rng, text, mlm_probability, pad_selectable)
 
     def pair_labels(lab, P):
         if P == T:

@@ -182,13 +182,23 @@ class DeviceBatchBuilder:
 
     def epoch(self, args, *, batch_size=None, shuffle=True, generator=None, mask_generator=None, rank=0, world=1):
         """One pass over the data as ready keyword-argument dicts for the model (``trainer.train_epoch(batches=...)``): a random
-        permutation (the reference's ``RandomSampler``, REF:trainer.py:28; last batch kept short like its ``DataLoader``),
-        sharded ``perm[rank::world]`` for data-parallel runs (every rank draws the SAME permutation from ``generator``, so the
-        shards are disjoint: SURVEY S8(e)), batches built on the device and packed with the trainer's MLM masking."""
+        permutation (the reference's ``RandomSampler``, REF:trainer.py:28; last batch kept short like its ``DataLoader``), batches
+        built on the device and packed with the trainer's MLM masking.
+        Data parallel (``world`` > 1): every rank must draw the SAME permutation, so a ``generator`` seeded
+        identically on all ranks is required when shuffling; the permutation is padded by wrapping around to a multiple of
+        ``world`` (torch's ``DistributedSampler`` rule) and sharded ``perm[rank::world]`` -- every rank then yields the same
+        number of batches of the same sizes, which the gradient all-reduce of ``parallel.DataParallel`` needs (a rank with one
+        batch more would wait in a collective nobody else joins)."""
         from .trainer import pack_step_inputs
         n = len(self.ds)
         bs = int(batch_size or args.train_batch_size)
+        if world > 1 and shuffle and generator is None:
+            raise ValueError("DeviceBatchBuilder.epoch: with world > 1 pass a torch.Generator seeded identically on every rank "
+                             "(each process has its own global RNG: the shards would overlap)")
         order = torch.randperm(n, generator=generator).tolist() if shuffle else list(range(n))
-        order = order[rank::world]
+        if world > 1:
+            per_rank = -(-n // world)
+            order = (order * (1 + (per_rank * world - 1) // max(n, 1)))[:per_rank * world]
+            order = order[rank::world]
         for k in range(0, len(order), bs):
             yield pack_step_inputs(self.batch(order[k:k + bs]), args, self.device, mask_generator)

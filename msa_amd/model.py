@@ -113,22 +113,23 @@ def _hf_init(module: nn.Module, std: float):
 
 
 class CPC(nn.Module):
-    """REF:MMBertEmbedding.py:7-32 (InfoNCE with in-batch negatives); [B,H] inputs, torch fp32 glue."""
+    """Contrastive predictive coding head (REF:MMBertEmbedding.py:7-32): holds the one projection ``net`` (state-dict keys
+    ``cpc_z*.net.{weight,bias}``, y_size -> x_size) and evaluates InfoNCE with in-batch negatives.  In the model the three CPC terms
+    run batched inside the heads kernels (``_HeadsFn`` / ``_heads``); this ``forward`` serves callers that use the module alone:
+    with S the [B,B] matrix of cosine similarities between x and net(y), the loss is mean_i(logsumexp_j S_ij - S_ii)."""
 
     def __init__(self, x_size, y_size, n_layers=1, activation="Tanh"):
         super().__init__()
+        if n_layers != 1:
+            raise NotImplementedError("the reference builds a projection for n_layers == 1 only (REF:MMBertEmbedding.py:15-19)")
         self.x_size, self.y_size, self.layers = x_size, y_size, n_layers
-        self.activation = getattr(nn, activation)
-        if n_layers == 1:
-            self.net = nn.Linear(in_features=y_size, out_features=x_size)
+        self.activation = getattr(nn, activation)              # attribute kept for checkpoints / introspection; never applied
+        self.net = nn.Linear(y_size, x_size)
 
     def forward(self, x, y):
-        x_pred = self.net(y)
-        x_pred = x_pred / x_pred.norm(dim=1, keepdim=True)
-        x = x / x.norm(dim=1, keepdim=True)
-        pos = torch.sum(x * x_pred, dim=-1)
-        neg = torch.logsumexp(torch.matmul(x, x_pred.t()), dim=-1)
-        return -(pos - neg).mean()
+        unit = lambda t: t / torch.linalg.vector_norm(t, dim=1, keepdim=True)
+        sim = unit(x) @ unit(self.net(y)).t()
+        return (torch.logsumexp(sim, dim=1) - torch.diagonal(sim)).mean()
 
 
 class JointEmbeddings(nn.Module):
@@ -334,10 +335,9 @@ class _EncoderFn(torch.autograd.Function):
         """The rows of the LAST layer's output that have a gradient: the MLM-labelled rows and the [CLS] rows (everything else
         feeds nothing but the returned scores).  (device int64 list in the encoder's packed order) or None if not worth it."""
         (idx, host, ev), first = top_rows
-        ev.synchronize()                                          # (long complete: the MLM head's backward ran before this)
-        n = int(host[0])
+        n = _active_row_count(top_rows[0])                        # (long complete: the MLM head's backward ran before this)
         r = n + first.numel()
-        if 4 * r > ra:
+        if 4 * r > ra or int(host[1]) != 0:                       # a labelled [CLS] row would be gathered twice: dense backward
             return None
         R = torch.cat((idx[:n].long(), first))
         if getattr(layout, "split", False):
@@ -399,18 +399,33 @@ class _PermuteRowsFn(torch.autograd.Function):
         return g.index_select(0, bwd_idx), None, None, None, None
 
 
-def mlm_active_rows(labels, vocab):
-    """(row list on the device, its COUNT in a pinned host word, event): which packed rows carry an MLM label.  The count
-    travels by an async copy; issue this as EARLY in the forward pass as the labels exist -- the sparse MLM backward
-    synchronises on the event, and a copy issued at the end of forward would make the host wait at the start of every
-    backward until the GPU has finished the whole forward pass (measured: no throughput difference on one GPU, where the
-    host is far ahead anyway; kept early so that nothing depends on that)."""
+def mlm_active_rows(labels, vocab, first=None):
+    """(row list on the device, pinned host words, event): which packed rows carry an MLM label.  Host words (they travel by ONE
+    async copy): [0] the COUNT of labelled rows, [1] how many of the ``first`` ([CLS]) rows are among them (the sparse top-layer
+    backward gathers labelled rows and [CLS] rows as one list and must not see a row twice), [2] how many labels are neither
+    -100 nor a vocabulary index (torch's CrossEntropyLoss raises on those; here the error surfaces when the words are read).
+    Issue this as EARLY in the forward pass as the labels exist -- the sparse MLM backward synchronises on the event, and a copy
+    issued at the end of forward would make the host wait at the start of every backward until the GPU has finished the whole
+    forward pass (measured: no throughput difference on one GPU, where the host is far ahead anyway; kept early so that nothing
+    depends on that)."""
     idx, cnt = ops.active_rows(labels, vocab)
-    host = torch.empty(1, dtype=torch.int32, pin_memory=True)
-    host.copy_(cnt, non_blocking=True)
+    dup = (labels.index_select(0, first) != -100).sum().to(torch.int32).view(1) if first is not None else torch.zeros_like(cnt)
+    bad = ((labels != -100) & ((labels < 0) | (labels >= vocab))).sum().to(torch.int32).view(1)
+    host = torch.empty(3, dtype=torch.int32, pin_memory=True)
+    host.copy_(torch.cat((cnt, dup, bad)), non_blocking=True)
     ev = torch.cuda.Event()
     ev.record()
     return idx, host, ev
+
+
+def _active_row_count(rows) -> int:
+    """Waits for the words of mlm_active_rows() and returns the labelled-row count; labels outside the vocabulary raise like
+    torch.nn.CrossEntropyLoss does in the reference (REF:MMBertForPretraining.py:381-384)."""
+    _idx, host, ev = rows
+    ev.synchronize()
+    if int(host[2]) != 0:
+        raise IndexError(f"masked_labels: {int(host[2])} label(s) are neither -100 nor in [0, vocab_size) -- Target out of bounds")
+    return int(host[0])
 
 
 class _MLMHeadFn(torch.autograd.Function):
@@ -429,8 +444,7 @@ class _MLMHeadFn(torch.autograd.Function):
             # the caller does not want the prediction scores: the whole head runs on the labelled rows only (the loss is a mean
             # over them; trainer.py never reads the scores) -- forward included
             idx_all, host, ev = rows
-            ev.synchronize()                                  # requested at the start of forward: long complete
-            n = int(host[0])
+            n = _active_row_count(rows)                       # requested at the start of forward: long complete
             if 0 < n and 2 * n <= M:
                 sel32 = idx_all[:n]
                 sel = sel32.long()
@@ -490,8 +504,7 @@ class _MLMHeadFn(torch.autograd.Function):
         M = y.shape[0]
         if ctx.rows is not None:
             idx_all, host, ev = ctx.rows
-            ev.synchronize()
-            n = int(host[0])
+            n = _active_row_count(ctx.rows)
             if 2 * n <= M:
                 dy = torch.zeros_like(y)
                 if n == 0:
@@ -728,9 +741,11 @@ class _GpuModelBase(nn.Module):
         return y, plan, lens
 
     def _request_lengths(self, plan, kv_len, labels, infer=False, pairs=None):
-        """Starts the device -> host copy of (unmasked length per sequence, count of labels on masked-out rows); None when the
-        valid-first packing cannot apply (no labels given -- the caller may then put a gradient anywhere --, no grad, switched off).
-        ``infer``: the lengths alone (inference needs no labels: nothing is differentiated)."""
+        """Starts the device -> host copy of the per-sequence count of leading rows that backward must visit (= the unmasked length,
+        extended to the sequence's last labelled row) plus one flag word; None when the valid-first packing cannot apply (no labels
+        given -- the caller may then put a gradient anywhere --, no grad, switched off).
+        ``infer``: the lengths alone (inference needs no labels: nothing is differentiated); the flag counts masked-out pair rows
+        with a non-zero feature (they may not share a representative)."""
         self.last_backward_row_fraction = 1.0                            # (bookkeeping for bench.py: share of rows backward visits)
         if infer:
             # rows may share one representative only if their INPUTS are equal: that holds for masked-out PAIR rows whose features
@@ -756,7 +771,13 @@ class _GpuModelBase(nn.Module):
         elif labels is None or not torch.is_grad_enabled() or not getattr(self, "skip_padded_backward", True):
             return None
         else:
-            bad = ((labels != -100) & (plan["row_pos"] >= kv_len.long().index_select(0, plan["row_seq"]))).sum().to(torch.int32).view(1)
+            # a label on a row behind the last unmasked key (the reference's mask_tokens selects [PAD] positions too; trainer.py
+            # copies the text labels onto the pair positions): that row is a QUERY with a gradient, so its sequence keeps every
+            # row up to its last labelled one in region A -- the masked-out keys among them have probability exactly 0, as before
+            lab_end = torch.zeros(kv_len.numel(), dtype=torch.int64, device=kv_len.device)
+            lab_end.scatter_reduce_(0, plan["row_seq"], torch.where(labels != -100, plan["row_pos"] + 1, 0), "amax", include_self=True)
+            kv_len = torch.maximum(kv_len, lab_end.to(torch.int32))
+            bad = torch.zeros(1, dtype=torch.int32, device=kv_len.device)
         host = torch.empty(kv_len.numel() + 1, dtype=torch.int32, pin_memory=True)
         host.copy_(torch.cat((kv_len, bad)), non_blocking=True)
         ev = torch.cuda.Event()
@@ -771,8 +792,9 @@ class _GpuModelBase(nn.Module):
         and it adds nothing to any weight gradient.  Forward still computes those rows (the reference returns their prediction
         scores); they are packed BEHIND all other rows (ops.SplitLayout) so that backward is the same kernels on a shorter
         matrix.  Needs the lengths on the host: the one blocking wait of the step, on a copy requested before the embedding
-        kernels were queued (_request_lengths).  Returns None when it does not apply (see there; also: a label on such a row,
-        or under 3 % to save)."""
+        kernels were queued (_request_lengths).  A labelled row behind the last unmasked key keeps its sequence's rows up to it in
+        the leading region (per sequence, not all-or-nothing).  Returns None when it does not apply (see there; also: under 3 %
+        to save)."""
         if pending is None:
             return None
         lay = plan["layout"]
@@ -979,6 +1001,11 @@ class MMBertForPretraining(_GpuModelBase):
         self.cpc_zt, self.cpc_zv, self.cpc_za = (CPC(H, H, 1, "Tanh") for _ in range(3))
         self._init_runtime()
         self.return_scores = True
+        # dtype of the six returned prediction-score tensors (outputs[7], [9], [11]).  DEVIATION from the reference, which computes
+        # in fp32 and returns fp32: the vocabulary GEMM writes bf16 logits (the compute dtype of the whole path) and the default
+        # hands out zero-copy [B, S, vocab] views of them -- torch.float32 converts them (+2.2 GB of writes per headline step,
+        # ~3 %) for consumers that call ``.numpy()`` on them (REF:sampling.py-style readers); trainer.py never reads them.
+        self.scores_dtype = torch.bfloat16
         # heads through _HeadsFn (hand-written backward, csrc/heads.hip); False = the eager autograd form (_heads), in which
         # ap_loss / label_loss / nce and the relationship scores stay differentiable outputs
         self.fused_heads = os.environ.get("MMBERT_FUSED_HEADS", "1") != "0"
@@ -1084,6 +1111,12 @@ class MMBertForPretraining(_GpuModelBase):
         return self._heads(first, ap_v.to(dev), ap_s.to(dev), None if sentiment is None else sentiment.to(dev))
 
     def forward(self, input_ids, token_type_ids, attention_mask, masked_labels, ap_label, sentiment):
+        """REF:MMBertForPretraining.py:392-449, same arguments and the same 13-tuple + logits.  Deviations, all switchable:
+        * outputs[7], [9], [11] (prediction scores) are ``self.scores_dtype`` = bf16 views by default (reference: fp32; set
+          ``model.scores_dtype = torch.float32``), or None with ``model.return_scores = False``;
+        * outputs[4], [5], [6] (ap_loss, label_loss, nce) are returned as VALUES by the fused heads path -- the one differentiable
+          output is outputs[0], which is what trainer.py differentiates (REF:trainer.py:83); ``model.fused_heads = False``
+          (the eager heads) keeps them in the autograd graph like the reference."""
         self.outputs = ()
         text_ids, visual, speech, twv, tws = input_ids
         tt_t = token_type_ids[0]
@@ -1097,9 +1130,12 @@ class MMBertForPretraining(_GpuModelBase):
                   dict(ids=tws, tt=None, mask=am_s[0].to(dev), pair=speech, pair_mask=am_s[1].to(dev))]
         H, V = self.config.hidden_size, self.config.vocab_size
         labels = torch.cat((lab_t.reshape(-1), lab_v.reshape(-1), lab_s.reshape(-1))).to(device=dev, dtype=torch.long)
-        rows = mlm_active_rows(labels, V) if (torch.is_grad_enabled() and getattr(self, "sparse_mlm_backward", True) and labels.is_cuda) else None
         if labels.numel() != B * (T + (T + visual.shape[1]) + (T + speech.shape[1])):
             raise ValueError("masked_labels must cover text (+ pair) positions of every pass")
+        rows = None
+        if torch.is_grad_enabled() and getattr(self, "sparse_mlm_backward", True) and labels.is_cuda:
+            self._ensure_ready(dev)
+            rows = mlm_active_rows(labels, V, self._plan([T, T + visual.shape[1], T + speech.shape[1]], B, dev)["first"])
         y, plan, lens = self._encode(passes, labels, rows)
         mlm, logits = _MLMHeadFn.apply(y, self.cls.predictions.transform.LayerNorm.weight, self, labels, plan["bounds"], plan["bounds_dev"], self.return_scores, rows)
 
@@ -1111,6 +1147,8 @@ class MMBertForPretraining(_GpuModelBase):
         if logits is not None:
             b = plan["bounds"]
             scores = tuple(logits[b[k]:b[k + 1]].view(B, lens[k], -1)[:, :, :V] for k in range(3))
+            if self.scores_dtype != logits.dtype:
+                scores = tuple(sc.to(self.scores_dtype) for sc in scores)
         self.outputs = (joint_loss, None, None, None, ap_loss, label_loss, nce,
                         scores[0], t_rel, scores[1], v_rel, scores[2], s_rel)
         return self.outputs, logits_out
@@ -1135,14 +1173,19 @@ class MMBertForPretraining(_GpuModelBase):
         passes = [dict(ids=text_ids, tt=token_type_ids, mask=am_t, pair=(visual, speech), pair_mask=(am_v, am_s))]
         V = self.config.vocab_size
         labels = masked_labels.reshape(-1).to(device=dev, dtype=torch.long)
-        rows = mlm_active_rows(labels, V) if (torch.is_grad_enabled() and getattr(self, "sparse_mlm_backward", True) and labels.is_cuda) else None
         if labels.numel() != B * (T + visual.shape[1] + speech.shape[1]):
             raise ValueError("masked_labels must cover the text and both pair blocks")
+        rows = None
+        if torch.is_grad_enabled() and getattr(self, "sparse_mlm_backward", True) and labels.is_cuda:
+            self._ensure_ready(dev)
+            rows = mlm_active_rows(labels, V, self._plan([T + visual.shape[1] + speech.shape[1]], B, dev)["first"])
         y, plan, lens = self._encode(passes, labels, rows)
         mlm, logits = _MLMHeadFn.apply(y, self.cls.predictions.transform.LayerNorm.weight, self, labels, plan["bounds"], plan["bounds_dev"], self.return_scores, rows)
         first = y.index_select(0, plan["first"].repeat(3)).float()                   # the one [CLS] row in the t / v / s slots
         heads_loss, ap_loss, label_loss, nce, logits_out, _t_rel, v_rel, _s_rel = self._run_heads(first, ap_v, ap_s, sentiment, dev, B)
         joint_loss = self.alpha * mlm[0] + heads_loss
         scores = None if logits is None else logits.view(B, lens[0], -1)[:, :, :V]
+        if scores is not None and self.scores_dtype != scores.dtype:
+            scores = scores.to(self.scores_dtype)
         self.outputs = (joint_loss, None, None, None, ap_loss, label_loss, nce, scores, v_rel)
         return self.outputs, logits_out

@@ -41,6 +41,22 @@ def make_drop(p: float, seed: int, site: int) -> Tuple[int, int, float]:
     return (rng_stream(seed, site), thr, 1.0 / (1.0 - thr / 65536.0))
 
 
+_tile_queues = {}
+dynamic_tile_queue = bool(int(__import__("os").environ.get("MMBERT_NT_DYNAMIC", "0")))    # set by parallel.DataParallel (world > 1)
+
+
+def _tile_queue(device) -> Optional[int]:
+    """The 8-byte tile queue of the persistent NT GEMM for the current stream (mmbert_gemm_nt's ``tile_queue``), or None for the
+    static schedule.  One zeroed buffer per (device, stream): the kernel leaves it zeroed, launches of one stream are ordered."""
+    if not dynamic_tile_queue:
+        return None
+    key = (device, torch.cuda.current_stream().cuda_stream)
+    q = _tile_queues.get(key)
+    if q is None:
+        q = _tile_queues[key] = torch.zeros(2, device=device, dtype=torch.int32)
+    return q.data_ptr()
+
+
 def gemm_nt(A, B, *, out=None, bias=None, gelu=False, aux=None, resid=None, gelu_bwd_u=None, alpha=1.0,
             alpha_dev=None, drop: Drop = None, out_f32=False):
     """out[M,N] = epi(alpha * A[M,K] @ B[N,K]^T)  (see mmbert_gemm_nt)."""
@@ -66,7 +82,7 @@ def gemm_nt(A, B, *, out=None, bias=None, gelu=False, aux=None, resid=None, gelu
                                   M, N, K, epi, _ptr(bias), _ptr(resid), resid.stride(0) if resid is not None else 0,
                                   _ptr(aux), aux.stride(0) if aux is not None else 0,
                                   _ptr(gelu_bwd_u), gelu_bwd_u.stride(0) if gelu_bwd_u is not None else 0,
-                                  float(alpha), _ptr(alpha_dev), d[0], d[1], d[2]), "mmbert_gemm_nt")
+                                  float(alpha), _ptr(alpha_dev), d[0], d[1], d[2], _tile_queue(A.device)), "mmbert_gemm_nt")
     return out
 
 

@@ -86,8 +86,8 @@ class DataParallel:
         if dev.type == "cuda" and self.world > 1:
             # RCCL's channel kernels hold CUs while the all-reduce of finished layers overlaps the rest of backward: let the
             # persistent GEMM draw its tiles from a queue, so that workgroups that start late do not strand a static share
-            from . import _lib
-            _lib.load().mmbert_gemm_nt_dynamic(1)
+            from . import ops
+            ops.dynamic_tile_queue = True
         L = model.config.num_hidden_layers
         # slice k (k = 0..L-1) ends with encoder layer L-1-k; slice L is the embedding tail
         bounds = [0]

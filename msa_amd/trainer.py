@@ -19,11 +19,17 @@ from torch.nn.utils.rnn import pad_sequence
 PAD, CLS, SEP, MASK = 0, 101, 102, 103
 
 
-def mask_tokens(inputs: torch.Tensor, args, generator: Optional[torch.Generator] = None, special_ids=(PAD, CLS, SEP), mask_id=MASK):
+def mask_tokens(inputs: torch.Tensor, args, generator: Optional[torch.Generator] = None, special_ids=(CLS, SEP), mask_id=MASK):
     """REF:model_utils.py:6-39 on the tensor's own device: Bernoulli(mlm_probability) selection with
     special tokens excluded (:17-23), labels -100 elsewhere (:28), 80 % of the selected positions
     -> [MASK] (:30-32, in place like the reference); the 10 % random-token branch is commented out
-    in the reference (:34-37) and therefore absent."""
+    in the reference (:34-37) and therefore absent.
+    ``special_ids``: [CLS] and [SEP] -- what ``get_special_tokens_mask(already_has_special_tokens=True)`` of the pinned
+    transformers 2.8 flags.  [PAD] is NOT excluded: the reference's PAD branch (:24-26) calls the non-in-place
+    ``masked_fill`` and drops the result, so padding positions are selected at the same 15 % (label 0, 80 % -> [MASK]);
+    pass ``special_ids=(PAD, CLS, SEP)`` for the intended rule (a deviation from the reference).  With ``generator=None``
+    on CPU the draws are the reference's own (same two ``torch.bernoulli`` calls in the same order on the global RNG:
+    pinned by tests/golden/mask_tokens.npz)."""
     labels = inputs.clone()
     prob = torch.full(labels.shape, float(args.mlm_probability), device=inputs.device)
     special = torch.zeros_like(inputs, dtype=torch.bool)
@@ -283,13 +289,20 @@ def train(args, model, train_dataset, val_dataset, test_dataset, optimizer, sche
         log("[Val Epoch {}] Joint Loss : {} AP Loss : {} Label Loss : {}".format(epoch + 1, va[0], va[4], va[5]))
         te = eval_epoch(args, model, test_dataset, tokenizer, device=device, batches=epoch_batches("test", epoch) if epoch_batches else None)
         acc, mae, f_score = score(te[6], te[7])
+        if dp is not None and torch.distributed.get_world_size() > 1:
+            # ranks evaluate with their own sampler order and MLM draws, so their metrics can differ in the last digits: rank 0's
+            # numbers decide the save rule and the patience stop on EVERY rank (a rank that stopped alone would leave the
+            # others waiting in the next epoch's gradient all-reduce)
+            t = torch.tensor([acc, mae, f_score], dtype=torch.float64, device=device)
+            torch.distributed.broadcast(t, src=0)
+            acc, mae, f_score = (float(x) for x in t.tolist())
         log("[Epoch {}] Test_ACC : {}, Test_MAE : {}, Test_F_Score: {}".format(epoch + 1, acc, mae, f_score))
         history.append(dict(epoch=epoch + 1, train_loss=tr[0], valid_loss=va[0], test_acc=acc, test_mae=mae, test_f_score=f_score))
         if acc > best["acc"]:
             path = os.path.join(save_dir, "model_" + str(epoch + 1) + ".pt")
             if rank0:
                 torch.save(model.state_dict(), path)
-            best.update(epoch=epoch, acc=acc, loss=va[0], mae=mae, f_score=f_score, preds=te[6], labels=te[7], path=path)
+            best.update(epoch=epoch, acc=acc, loss=va[0], mae=mae, f_score=f_score, preds=te[6], labels=te[7], path=path if rank0 else None)
             patience = 0
         if patience == patience_limit:
             if rank0 and best["preds"] is not None:

@@ -479,10 +479,12 @@ def should_step(step_idx: int, gas: int, quirk: bool = True) -> bool:
 # a16: MLM masking rule (input contract)
 # ----------------------------------------------------------------------------------------------
 def mask_tokens_rule(inputs: torch.Tensor, select: torch.Tensor, replace: torch.Tensor,
-                     special_ids: Sequence[int] = (0, 101, 102), mask_id: int = 103):
+                     special_ids: Sequence[int] = (101, 102), mask_id: int = 103):
     """REF:model_utils.py:6-39 with the two Bernoulli draws passed in (``select`` ~ B(p=0.15),
     ``replace`` ~ B(0.8)): special tokens are never selected (:17-23), labels = -100 where not
-    selected (:28), 80% of selected -> [MASK] (:30-32); the 10% random branch is commented out."""
+    selected (:28), 80% of selected -> [MASK] (:30-32); the 10% random branch is commented out.
+    Special = [CLS], [SEP]: what the pinned transformers-2.8 ``get_special_tokens_mask`` flags; the PAD branch (:24-26) is a
+    non-in-place ``masked_fill`` whose result is dropped, so [PAD] stays selectable (pinned by tests/golden/mask_tokens.npz)."""
     special = torch.zeros_like(inputs, dtype=torch.bool)
     for s in special_ids:
         special |= inputs == s

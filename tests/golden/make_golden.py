@@ -311,9 +311,117 @@ def gen_train(cfg):
     print("train4 losses", losses, "ret", d["ret"])
 
 
+def _make_items(rng, N, T, vocab):
+    """N examples in the 16-tuple layout MMBertDataset.__getitem__ yields (REF:MMBertDataset.py:194-202), padded to T."""
+    items = []
+    for b in range(N):
+        n = 3 + (b % (T - 5))
+        te = [101] + list(map(int, rng.integers(1000, vocab, n))) + [102] + [0] * (T - n - 2)
+        ve = rng.standard_normal((T, 35)); ve[n + 2:] = 0
+        se = rng.standard_normal((T, 74)); se[n + 2:] = 0
+        tti = torch.zeros(T)
+        vti = torch.cat((torch.zeros(T), torch.ones(T)))
+        sent = float(rng.uniform(-3, 3))
+        items.append((torch.tensor(te), torch.tensor(0), tti, torch.tensor(sent),
+                      te, ve, torch.tensor(int(rng.integers(0, 2))), vti, torch.tensor(sent),
+                      te, se, torch.tensor(int(rng.integers(0, 2))), vti, torch.tensor(sent), "s", "r"))
+    return items
+
+
+def gen_eval(cfg):
+    """G9: REF trainer.eval_epoch (REF:trainer.py:103-194) on 6 examples with val_batch_size 4 (a full and a short batch), mlm off,
+    model.eval(): its 8-tuple -- dev loss, the three always-zero modality losses, ap_loss of the LAST batch / steps, label loss,
+    predictions [N,1], labels [N] -- plus the per-batch losses, the sampler's order, and what test_MSE_score_model
+    (REF:trainer.py:217-228, sklearn metrics) makes of the predictions."""
+    import model_utils
+    import trainer
+    trainer.DEVICE = model_utils.DEVICE = torch.device("cpu")
+    trainer.tqdm = lambda x, **k: x
+    model = build_reference(cfg, dropout=0.0)
+    rng = np.random.Generator(np.random.PCG64(19))
+    N, T = 6, 12
+    items = _make_items(rng, N, T, cfg["vocab"])
+    order = []
+
+    class DS(torch.utils.data.Dataset):
+        def __len__(self):
+            return N
+
+        def __getitem__(self, i):
+            order.append(int(i))
+            return items[i]
+    args = types.SimpleNamespace(val_batch_size=4, mlm=False, mlm_probability=0.15)
+    losses = []
+    orig_fwd = model.forward
+
+    def rec_fwd(*a, **k):
+        out = orig_fwd(*a, **k)
+        losses.append([float(out[0][0]), float(out[0][4]), float(out[0][5]), float(out[0][6])])
+        return out
+    model.forward = rec_fwd
+    torch.manual_seed(7)
+    ret = trainer.eval_epoch(args, model, DS(), None)
+    d = {"order": np.array(order), "losses": np.array(losses), "ret6": np.array([float(r) for r in ret[:6]]),
+         "preds": np.asarray(ret[6]), "labels": np.asarray(ret[7]), "val_batch_size": np.array(4)}
+    d["mse_scores"] = np.array([float(x) for x in trainer.test_MSE_score_model(ret[6], ret[7])])
+    for i, it in enumerate(items):
+        d[f"item{i}_text"] = np.array(it[4])
+        d[f"item{i}_visual"] = np.array(it[5])
+        d[f"item{i}_speech"] = np.array(it[10])
+        d[f"item{i}_ap"] = np.array([int(it[6]), int(it[11])])
+        d[f"item{i}_sent"] = np.array(float(it[3]))
+    np.savez_compressed(os.path.join(OUT, "eval6.npz"), **d)
+    print("eval6 losses", losses, "ret", d["ret6"], "scores", d["mse_scores"])
+
+
+def gen_mask_tokens():
+    """G10: REF model_utils.mask_tokens (REF:model_utils.py:6-39) under a seeded global torch RNG on CPU, with a stand-in for the
+    tokenizer of the pinned transformers 2.8: ``get_special_tokens_mask(already_has_special_tokens=True)`` flags [CLS] and [SEP]
+    only.  ``_pad_token`` is None here so that the reference's PAD branch (:24-26) is skipped: it computes a non-in-place
+    ``masked_fill`` whose result is dropped (and calls ``.cuda()``, which this CPU container lacks) -- skipping it changes nothing."""
+    import model_utils
+    model_utils.DEVICE = torch.device("cpu")
+
+    class Tok28:
+        mask_token = "[MASK]"
+        _pad_token = None
+        pad_token_id = 0
+
+        def get_special_tokens_mask(self, ids, already_has_special_tokens=False):
+            assert already_has_special_tokens
+            return [1 if x in (101, 102) else 0 for x in ids]
+
+        def convert_tokens_to_ids(self, tok):
+            assert tok == "[MASK]"
+            return 103
+    rng = np.random.Generator(np.random.PCG64(23))
+    B, T = 48, 20
+    ids = np.zeros((B, T), np.int64)
+    for b in range(B):
+        n = int(rng.integers(3, T - 2))
+        ids[b, 0] = 101
+        ids[b, 1:1 + n] = rng.integers(1000, 30000, n)
+        ids[b, 1 + n] = 102
+    args = types.SimpleNamespace(mlm_probability=0.15)
+    d = {"inputs": ids}
+    for seed in (1, 2):
+        torch.manual_seed(seed)
+        out, labels = model_utils.mask_tokens(torch.from_numpy(ids.copy()), Tok28(), args)
+        d[f"out_seed{seed}"], d[f"labels_seed{seed}"] = np_(out), np_(labels)
+    sel = d["labels_seed1"] != -100
+    assert sel[ids == 0].any(), "the reference selects [PAD] positions"
+    assert not sel[(ids == 101) | (ids == 102)].any()
+    np.savez_compressed(os.path.join(OUT, "mask_tokens.npz"), **d)
+    print("mask_tokens ok: selected", int(sel.sum()), "of", sel.size, "| on PAD", int(sel[ids == 0].sum()))
+
+
 if __name__ == "__main__":
     if sys.argv[1:] == ["dataset"]:                 # only the MMBertDataset fixture (the others are unchanged)
         gen_dataset()
+        sys.exit(0)
+    if sys.argv[1:] == ["eval"]:
+        gen_eval(dict(CFG1, vocab=4096))
+        gen_mask_tokens()
         sys.exit(0)
     gen_units(CFG1)
     gen_collate()
@@ -322,6 +430,8 @@ if __name__ == "__main__":
     gen_full("h64_L1_T16_P24x40", dict(CFG1, hidden=64, layers=1, heads=4, intermediate=128, vocab=2048,
                                        alpha=0.7, beta=0.3), 3, 16, 24, 40, seed=3)
     gen_train(dict(CFG1, vocab=4096))
+    gen_eval(dict(CFG1, vocab=4096))
+    gen_mask_tokens()
     gen_dataset()
     for f in sorted(os.listdir(OUT)):
         if f.endswith(".npz"):

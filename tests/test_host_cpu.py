@@ -53,15 +53,50 @@ def test_mask_tokens_rule_and_pack():
     ids = torch.tensor([[101, 7, 8, 9, 10, 11, 102, 0, 0]] * 64)
     out, labels = T.mask_tokens(ids.clone(), args, g)
     sel = labels != -100
-    assert not sel[:, 0].any() and not sel[:, 6:].any()                 # CLS / SEP / PAD never selected
+    assert not sel[:, 0].any() and not sel[:, 6].any()                  # [CLS] / [SEP] never selected
+    assert 0.3 < sel[:, 7:].float().mean() < 0.7                        # [PAD] IS selectable in the reference (dropped masked_fill)
+    assert (labels[:, 7:][sel[:, 7:]] == 0).all()                       # ... with label 0
     assert 0.4 < sel[:, 1:6].float().mean() < 0.6
     assert ((out == 103) <= sel).all() and (labels[sel] == ids[sel]).all()
     assert 0.7 < (out[sel] == 103).float().mean() < 0.9                 # 80 % -> [MASK]
     assert (out[~sel] == ids[~sel]).all()
+    # the opt-in deviation: PAD never selected
+    _, lab2 = T.mask_tokens(ids.clone(), args, torch.Generator().manual_seed(0), special_ids=(T.PAD, T.CLS, T.SEP))
+    assert not (lab2[:, 6:] != -100).any()
     batch = T.collate(_collate_examples())
     kw = T.pack_step_inputs(batch, T.default_args(mlm=False), "cpu")
     assert kw["masked_labels"][1].shape == (3, 16) and (kw["masked_labels"][1][:, :8] == kw["masked_labels"][1][:, 8:]).all()
     assert kw["input_ids"][1].dtype == torch.float64 and kw["attention_mask"][2][1].dtype == torch.int64
+
+
+def test_mask_tokens_reproduces_the_reference_draws(golden_dir):
+    """G10: REF model_utils.mask_tokens run for real (transformers-2.8-style tokenizer stand-in, seeded global RNG, CPU): with
+    ``generator=None`` ours makes the same two ``torch.bernoulli`` draws in the same order -- inputs and labels bit for bit,
+    [PAD] positions selected like the reference selects them."""
+    g = np.load(os.path.join(golden_dir, "mask_tokens.npz"))
+    ids = torch.from_numpy(g["inputs"])
+    for seed in (1, 2):
+        torch.manual_seed(seed)
+        out, labels = T.mask_tokens(ids.clone(), T.default_args(mlm_probability=0.15))
+        np.testing.assert_array_equal(out.numpy(), g[f"out_seed{seed}"])
+        np.testing.assert_array_equal(labels.numpy(), g[f"labels_seed{seed}"])
+    assert (g["labels_seed1"][g["inputs"] == 0] != -100).any()
+    # the synthetic generator follows the same rule: some PAD position of the text carries label 0
+    from msa_amd.data import synthetic_batch
+    b = synthetic_batch(16, 50, 8, 8, seed=1)
+    lab, msk = b["masked_labels"][0], b["attention_mask"][0]
+    assert ((lab == 0) & (msk == 0)).any() and not (lab[:, 0] != -100).any()
+    b2 = synthetic_batch(16, 50, 8, 8, seed=1, pad_selectable=False)
+    assert not ((b2["masked_labels"][0] != -100) & (msk == 0)).any()
+
+
+def test_eval_scores_reproduce_the_reference(golden_dir):
+    """G9 (host part): test_MSE_score_model on the reference's own eval predictions gives the reference's (acc, MAE, F1),
+    the [N,1] - [N] broadcast of its MAE included."""
+    g = np.load(os.path.join(golden_dir, "eval6.npz"))
+    acc, mae, f1 = T.test_MSE_score_model(g["preds"], g["labels"])
+    np.testing.assert_allclose([acc, mae, f1], g["mse_scores"], rtol=1e-6)
+    assert g["preds"].shape == (6, 1) and g["labels"].shape == (6,)
 
 
 def test_step_rule_and_schedule():
@@ -236,3 +271,52 @@ def test_device_batch_feeds_pack_step_inputs():
         assert sizes == [2, 1]
         seen += got
     assert sorted(seen) == list(range(6))
+    # n % world != 0: the permutation wraps around to a multiple of world (DistributedSampler's rule) -- every rank yields the SAME
+    # batch sizes (a rank with one batch more would wait in an all-reduce nobody joins), every item is still visited
+    ds7 = MMBertDataset(None, synthetic_features(n_items=7, L=10, seed=4), "mosei", "sentiment", 1)
+    bld = DeviceBatchBuilder(ds7, "cpu")
+    per_rank, seen = [], []
+    for rank in range(2):
+        orig, got = bld.batch, []
+        bld.batch = lambda idx, _o=orig, _g=got: (_g.extend(idx), _o(idx))[1]
+        per_rank.append([kw["input_ids"][0].shape[0] for kw in bld.epoch(args, batch_size=3, generator=torch.Generator().manual_seed(5), rank=rank, world=2)])
+        bld.batch = orig
+        seen += got
+    assert per_rank[0] == per_rank[1] == [3, 1] and sorted(set(seen)) == list(range(7)) and len(seen) == 8
+    with pytest.raises(ValueError, match="seeded identically"):
+        next(bld.epoch(args, batch_size=3, rank=0, world=2))
+
+
+def _epoch_worker(rank, world, port, q):
+    """Two ranks walk an epoch of 7 items and all-reduce once per batch, the way DataParallel does per stepping micro-batch."""
+    from tests.golden.dataset_features import synthetic_features
+    from msa_amd.dataset import MMBertDataset, DeviceBatchBuilder
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    ds = MMBertDataset(None, synthetic_features(n_items=7, L=10, seed=4), "mosei", "sentiment", 1)
+    bld = DeviceBatchBuilder(ds, "cpu")
+    args = T.default_args(mlm=True, mlm_probability=0.3)
+    n, total = 0, torch.zeros(1)
+    for kw in bld.epoch(args, batch_size=2, generator=torch.Generator().manual_seed(11), rank=rank, world=world):
+        t = torch.tensor([float(kw["input_ids"][0].shape[0])])
+        dist.all_reduce(t)                      # hangs (-> test timeout) if the ranks disagree on the number of batches
+        total += t
+        n += 1
+    if rank == 0:
+        q.put((n, float(total)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_epoch_shards_have_equal_batch_counts_world2_gloo():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29800 + os.getpid() % 200
+    procs = [ctx.Process(target=_epoch_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    n, total = q.get(timeout=120)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert n == 2 and total == 8.0              # 7 items -> 8 after wrapping, 4 per rank, batches of 2

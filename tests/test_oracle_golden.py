@@ -206,12 +206,24 @@ def test_schedule_and_step_rule():
     assert not O.decays("bert.encoder.layer.0.output.LayerNorm.weight") and not O.decays("cls.predictions.bias")
 
 
-def test_mask_tokens_rule_invariants():
+def test_mask_tokens_rule_invariants(golden_dir):
     b = synthetic_batch(4, 32, 8, 8, seed=11)
     ids, lab = b["input_ids"][0], b["masked_labels"][0]
     sel = lab != -100
-    assert not sel[ids == 0].any() and not sel[:, 0].any()
+    assert not sel[:, 0].any() and not sel[ids == 102].any()             # [CLS] / [SEP] never selected
     assert ((ids == 103) <= sel).all()
     inp = torch.tensor([[101, 5, 6, 102, 0]])
     out, labels = O.mask_tokens_rule(inp, torch.ones_like(inp), torch.tensor([[1, 1, 0, 1, 1]]))
-    assert out.tolist() == [[101, 103, 6, 102, 0]] and labels.tolist() == [[-100, 5, 6, -100, -100]]
+    assert out.tolist() == [[101, 103, 6, 102, 103]] and labels.tolist() == [[-100, 5, 6, -100, 0]]     # [PAD] is selectable
+    # G10: the rule against the REAL mask_tokens -- its outputs are reproduced by feeding the rule the draws it made
+    g = load(golden_dir, "mask_tokens")
+    ids = torch.from_numpy(g["inputs"])
+    for seed in (1, 2):
+        torch.manual_seed(seed)                                          # the reference's two draws, in its order (:27,30)
+        prob = torch.full(ids.shape, 0.15)
+        prob[(ids == 101) | (ids == 102)] = 0.0
+        select = torch.bernoulli(prob)
+        replace = torch.bernoulli(torch.full(ids.shape, 0.8))
+        out, labels = O.mask_tokens_rule(ids, select, replace)
+        np.testing.assert_array_equal(out.numpy(), g[f"out_seed{seed}"])
+        np.testing.assert_array_equal(labels.numpy(), g[f"labels_seed{seed}"])
