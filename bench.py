@@ -16,7 +16,8 @@ Extra objects on the JSON line:
                   step's FLOPs): algorithmic FLOPs of its launches / their summed durations, both
                   taken INSIDE the timed region with HIP events on the launch stream.
   cpu_baseline -- the CPU oracle (oracle/mmbert_oracle.py, kind "port") timed on this box's host
-                  cores on a bounded sample: the same model/shapes at batch 4, one fwd+bwd step (~10 s on the box's 16-CPU quota).
+                  cores on a bounded sample: the same model / shapes at batch 2, 1 warm-up + median of 3
+                  fwd+bwd steps, plus BASELINE configs[0] exactly.
   fused1050    -- secondary: the same train step on ONE sequence text|visual|speech (S = 1050), a declared extension
                   (model.forward_fused); never the headline value.
 config.tflop_per_sample is the dense algorithmic count; config.tflop_per_sample_executed subtracts the
@@ -70,6 +71,9 @@ def main():
     ap.add_argument("--no-skip-masked-keys", action="store_true", help="A/B: attention also visits the key tiles that are entirely masked out")
     ap.add_argument("--no-skip-padded-backward", action="store_true", help="A/B: backward also runs on the rows whose gradients are exactly zero")
     ap.add_argument("--no-sparse-top-layer", action="store_true", help="A/B: dense backward of the top encoder layer")
+    ap.add_argument("--force-dp", action="store_true", help="run the data-parallel path (RCCL process group, DataParallel wrapper, bucketed "
+                    "all-reduce hooks, dynamic tile queue) even with ONE process: the N = 1 execution of the code the driver launches at N = 2/4/8")
+    ap.add_argument("--scores-fp32", action="store_true", help="return the prediction scores as fp32 (model.scores_dtype = torch.float32)")
     a = ap.parse_args()
 
     from msa_amd import ops, parallel
@@ -77,7 +81,7 @@ def main():
     from msa_amd.model import MMBertConfig, MMBertForPretraining
     from msa_amd.trainer import build_optimizer, default_args
 
-    rank, local, world = parallel.init_from_env()
+    rank, local, world = parallel.init_from_env(force=a.force_dp)
     if world != a.gpus:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {a.gpus}")
     torch.cuda.set_device(local)
@@ -97,9 +101,11 @@ def main():
     model.skip_padded_backward = not a.no_skip_padded_backward
     model.sparse_top_layer_backward = not a.no_sparse_top_layer
     model.return_scores = True            # the reference returns the six score tensors; keep them materialised
+    if a.scores_fp32:
+        model.scores_dtype = torch.float32
     targs = default_args(train_batch_size=a.batch, learning_rate=5e-5)
     opt, sched = build_optimizer(model, targs, num_train_optimization_steps=10 * (a.steps + a.warmup))
-    dp = parallel.DataParallel(model, opt) if world > 1 else None
+    dp = parallel.DataParallel(model, opt, force_dynamic_queue=a.force_dp) if (world > 1 or a.force_dp) else None
     pool = [batch_to(synthetic_batch(a.batch, a.text, a.pair, a.pair, vocab=V, seed=1 + i + 1000 * rank), dev) for i in range(4)]
 
     timing = {"nt": [], "tn": [], "attn_fwd": [], "attn_bwd": []}
@@ -279,6 +285,9 @@ def main():
         "final_loss": round(loss, 4),
         "step_mfma_frac": round(fps_exec * value / world / 2.5e15, 4),
     }
+    if dp is not None:
+        res["config"]["dp"] = {"backend": torch.distributed.get_backend(), "forced_single_process": bool(a.force_dp and world == 1),
+                               "gemm_tile_queue": "dynamic", "bucket_mb": 32.0}
     if dense_ref is not None:
         res["dense_backward_reference"] = dense_ref
     if train_only is not None:
@@ -299,7 +308,11 @@ def main():
             res["roofline"] = {"bound": "mfma", "kernel": "gemm_ntp_kernel (bf16 MFMA 16x16x32, persistent 224x256-tile stream through a 4-slot LDS-DMA ring; all epilogues)",
                                "achieved": round(ach, 1), "peak": 2500.0, "unit": "TFLOP/s", "frac": round(ach / 2500.0, 4),
                                "traffic": traffic, "traffic_source": traffic_src, "launches": n, "avg_launch_us": round(1e3 * ms / n, 2),
-                               "share_of_step_time": round(ms * 1e-3 / elapsed, 3)}
+                               "share_of_step_time": round(ms * 1e-3 / elapsed, 3),
+                               # whole-step MFMA fractions of 2.5 PF, side by side: FLOPs actually executed by the headline step, and the
+                               # dense algorithmic count at the speed of the step with every exact-zero short cut switched off
+                               "frac_step_executed": round(fps_exec * value / world / 2.5e15, 4),
+                               "frac_step_dense_shortcuts_off": (round(fps * dense_ref["value"] / world / 2.5e15, 4) if dense_ref else None)}
             for k in ("tn", "attn_fwd", "attn_bwd"):
                 if k in kern:
                     fl2, ms2, n2 = kern[k]
@@ -312,21 +325,43 @@ def main():
         torch.distributed.destroy_process_group()
 
 
-def pmc_traffic_per_launch(kernel_substr):
+def csrc_digest():
+    """sha256 over the kernel sources: PMC summaries under profiles/ carry the digest of the sources they were measured on."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "msa_amd", "csrc")
+    for f in sorted(x for x in os.listdir(d) if x.endswith((".hip", ".h"))):
+        with open(os.path.join(d, f), "rb") as fh:
+            h.update(f.encode() + b"\0" + fh.read())
+    return h.hexdigest()[:16]
+
+
+def pmc_traffic_per_launch(kernel_substr, path=None):
     """HBM/fabric bytes per launch of the dominant kernel family from the committed PMC summary (two separate rocprofv3 --pmc
     passes over this same bench command, FETCH_SIZE doubled as the gfx950 correction asks: tools/pmc_traffic.py).  Counters
-    cannot be collected from inside the timed run, so this is the measured figure of record, or None if the file is absent."""
-    path = os.path.join(ROOT, "profiles", "r1_pmc_hbm_traffic.csv")
-    try:
-        import csv
-        rows = [r for r in csv.DictReader(l for l in open(path) if not l.startswith("#")) if kernel_substr in r["kernel"]]
-        n = sum(int(r["launches"]) for r in rows)
-        if not n:
-            return None, None
-        mb = sum(float(r["total_MB"]) * int(r["launches"]) for r in rows) / n
-        return round(mb * 1e6), "profiles/r1_pmc_hbm_traffic.csv (mean over %d launches, read x2-corrected + written)" % n
-    except Exception:
-        return None, None
+    cannot be collected from inside the timed run, so this is the measured figure of record -- REFUSED (None, with the reason)
+    when the summary was measured on other kernel sources than the ones in the tree (its ``# csrc_sha256:`` line)."""
+    import glob
+    cands = [path] if path else sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_hbm_traffic.csv")), reverse=True)
+    for path in cands:
+        try:
+            import csv
+            lines = open(path).read().splitlines()
+            stamp = [l.split(":", 1)[1].strip() for l in lines if l.startswith("# csrc_sha256:")]
+            rel = os.path.relpath(path, ROOT)
+            if not stamp:
+                return None, f"{rel}: no csrc_sha256 stamp (measured on unknown sources): refused"
+            if stamp[0] != csrc_digest():
+                return None, f"{rel}: stale (measured on kernel sources {stamp[0]}, tree has {csrc_digest()}): refused"
+            rows = [r for r in csv.DictReader(l for l in lines if not l.startswith("#")) if kernel_substr in r["kernel"]]
+            n = sum(int(r["launches"]) for r in rows)
+            if not n:
+                continue
+            mb = sum(float(r["total_MB"]) * int(r["launches"]) for r in rows) / n
+            return round(mb * 1e6), f"{rel} (mean over {n} launches, read x2-corrected + written; sources {stamp[0]})"
+        except Exception as e:
+            return None, f"{path}: {e}"
+    return None, None
 
 
 def usable_cores(cap=32):
@@ -343,36 +378,39 @@ def usable_cores(cap=32):
 
 
 def cpu_baseline(a, L, H, I, V):
-    """The CPU oracle on the host cores: same architecture and sequence shapes, batch 2 (bounded sample)."""
+    """the CPU oracle on the host cores -- C2 shapes at batch 2 (same 12-layer d=768 model, S = 50/550/550), fp32,
+    dropout on, forward+loss and forward+backward, 1 warm-up then the median of 3; and C1 exactly (BASELINE.json configs[0])."""
     from oracle import mmbert_oracle as O
     from msa_amd.data import synthetic_batch
     cores = usable_cores()
     torch.set_num_threads(cores)
-    cfg = dict(hidden=H, layers=L, heads=a.heads, intermediate=I, vocab=V, dataset="mosei", alpha=1.0, beta=1.0)
-    p = {k: v.requires_grad_(True) for k, v in O.seeded_params(cfg).items()}
-    B = 4
-    batch = synthetic_batch(B, a.text, a.pair, a.pair, vocab=V, seed=1)
+
+    def timed(cfg, B, T, P, iters):
+        p = {k: v.requires_grad_(True) for k, v in O.seeded_params(cfg).items()}
+        batch = synthetic_batch(B, T, P, P, vocab=V, seed=1)
+        tf, tb = [], []
+        for it in range(iters + 1):
+            for v in p.values():
+                v.grad = None
+            t1 = time.perf_counter()
+            out, _ = O.pretraining_forward(p, cfg, **batch, train=True)
+            t2 = time.perf_counter()
+            out[0].mean().backward()
+            t3 = time.perf_counter()
+            if it:                                              # iteration 0 is the warm-up
+                tf.append(t2 - t1); tb.append(t3 - t1)
+        return sorted(tf)[len(tf) // 2], sorted(tb)[len(tb) // 2]
     t0 = time.perf_counter()
-    out, _ = O.pretraining_forward(p, cfg, **batch, train=True)
-    out[0].mean().backward()
-    dt = time.perf_counter() - t0
-    # BASELINE.json configs[0], the reference's own CPU-runnable case (2-layer d=128, batch 2, T=50, A=V=64): medians of 3
-    cfg1 = dict(hidden=128, layers=2, heads=2, intermediate=512, vocab=V, dataset="mosei", alpha=1.0, beta=1.0)
-    p1 = {k: v.requires_grad_(True) for k, v in O.seeded_params(cfg1).items()}
-    b1 = synthetic_batch(2, 50, 64, 64, vocab=V, seed=1)
-    tf, tb = [], []
-    for _ in range(3):
-        t1 = time.perf_counter()
-        out1, _ = O.pretraining_forward(p1, cfg1, **b1, train=True)
-        t2 = time.perf_counter()
-        out1[0].mean().backward()
-        t3 = time.perf_counter()
-        tf.append(t2 - t1); tb.append(t3 - t1)
-    c1 = {"fwd_loss_samples_per_s": round(2 / sorted(tf)[1], 2), "fwd_bwd_samples_per_s": round(2 / sorted(tb)[1], 2),
-          "sample": "BASELINE configs[0]: 2-layer d=128, batch 2, T=50 A=V=64, median of 3"}
-    return {"value": round(B / dt, 4), "unit": "samples/s", "cores": cores, "kind": "port",
-            "sample": f"oracle fwd+loss+bwd (fp32, dropout on), same model and S=50/550/550 shapes, batch {B}, 1 step = {dt:.1f} s",
-            "configs0": c1}
+    B = 2
+    f2, b2 = timed(dict(hidden=H, layers=L, heads=a.heads, intermediate=I, vocab=V, dataset="mosei", alpha=1.0, beta=1.0), B, a.text, a.pair, 3)
+    f1, b1 = timed(dict(hidden=128, layers=2, heads=2, intermediate=512, vocab=V, dataset="mosei", alpha=1.0, beta=1.0), 2, 50, 64, 3)
+    c1 = {"fwd_loss_samples_per_s": round(2 / f1, 2), "fwd_bwd_samples_per_s": round(2 / b1, 2),
+          "sample": "BASELINE configs[0]: 2-layer d=128, batch 2, T=50 A=V=64, 1 warm-up + median of 3"}
+    return {"value": round(B / b2, 4), "unit": "samples/s", "cores": cores, "kind": "port",
+            "sample": f"oracle fwd+loss+bwd (fp32, dropout on), same model and S={a.text}/{a.text + a.pair}/{a.text + a.pair} shapes at batch {B} "
+                      f"(BASELINE.md S4: C2 shapes at B=2), 1 warm-up + median of 3: fwd+loss {f2:.2f} s, fwd+bwd {b2:.2f} s; "
+                      f"whole leg {time.perf_counter() - t0:.0f} s",
+            "fwd_loss_samples_per_s": round(B / f2, 4), "configs0": c1}
 
 
 if __name__ == "__main__":

@@ -80,6 +80,13 @@ uint32_t mmbert_rng_stream(uint64_t seed, uint32_t site);
 uint32_t mmbert_dropout_thr16(float p);          /* keep iff 16 random bits >= thr16; 0 = no dropout */
 int mmbert_dropout_mask(mmbert_stream_t stream, uint8_t* out, size_t n, uint32_t rng_stream, uint32_t thr16);
 
+/* MLM masking of a batch of token ids on the device (REF:model_utils.py:6-39): position i is selected with probability
+ * select_thr16 / 65536 unless its id is one of the three special ids (pass an id twice, or -1, for fewer); labels[i] = the id where
+ * selected and -100 elsewhere; a selected position becomes mask_id with probability replace_thr16 / 65536 (ids rewritten in
+ * place, like the reference).  Counter RNG: the same (rng_stream, n) gives the same masks.  n < 2^32. */
+int mmbert_mlm_mask(mmbert_stream_t stream, int64_t* ids, int64_t* labels, size_t n, uint32_t rng_stream, uint32_t select_thr16,
+                    uint32_t replace_thr16, int64_t special0, int64_t special1, int64_t special2, int64_t mask_id);
+
 /* ---- LayerNorm (+ the reference's dropout placements) ----
  * fwd: y[out_rows[i]] = dropout(LN(x[in_rows[i]]))              BertEmbeddings HF:104-107,
  *      JointEmbeddings REF:MMBertEmbedding.py:69-70, BertSelfOutput/BertOutput LN HF:292,350.

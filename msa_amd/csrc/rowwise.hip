@@ -632,6 +632,21 @@ __global__ void dropout_mask_kernel(uint8_t* __restrict__ out, size_t n, uint32_
         out[i] = mmb_keep(stream, i, thr) ? 1 : 0;
 }
 
+// MLM masking on the device (REF:model_utils.py:6-39): element i draws ONE 32-bit word from the counter RNG; its low half decides
+// "selected" (probability sel_thr16 / 65536, never for the special ids), its high half "replaced by [MASK]" (rep_thr16 / 65536 of
+// the selected).  labels[i] = the original id where selected, -100 elsewhere; ids are rewritten in place like the reference does.
+__global__ void mlm_mask_kernel(int64_t* __restrict__ ids, int64_t* __restrict__ labels, size_t n, uint32_t stream, uint32_t sel_thr16,
+                                uint32_t rep_thr16, int64_t special0, int64_t special1, int64_t special2, int64_t mask_id) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const int64_t id = ids[i];
+        const uint32_t h = mmb_pair_bits(stream, (uint32_t)i);
+        const bool special = (id == special0) | (id == special1) | (id == special2);
+        const bool sel = !special && (h & 0xFFFFu) < sel_thr16;
+        labels[i] = sel ? id : (int64_t)-100;
+        if (sel && (h >> 16) < rep_thr16) ids[i] = mask_id;
+    }
+}
+
 static inline int grid_for(size_t work_items, int per_block, int cap = 2048) {
     size_t b = (work_items + per_block - 1) / per_block;
     if (b < 1) b = 1;
@@ -828,6 +843,16 @@ int mmbert_cast_bf16_f32(hipStream_t stream, const void* x, float* y, size_t n) 
 int mmbert_transpose_cast(hipStream_t stream, const float* src, void* dst, const void* descs, int ndesc, int total_tiles) {
     if (ndesc <= 0 || total_tiles <= 0) return 0;
     hipLaunchKernelGGL(transpose_cast_kernel, dim3(total_tiles), dim3(256), 0, stream, src, (bf16_t*)dst, (const TransDesc*)descs, ndesc);
+    MMB_CHECK_LAUNCH();
+    return 0;
+}
+
+int mmbert_mlm_mask(hipStream_t stream, int64_t* ids, int64_t* labels, size_t n, uint32_t rng_stream, uint32_t select_thr16,
+                    uint32_t replace_thr16, int64_t special0, int64_t special1, int64_t special2, int64_t mask_id) {
+    if (n == 0) return 0;
+    if (n >= ((size_t)1 << 32) || select_thr16 > 65536u || replace_thr16 > 65536u) return -1;
+    hipLaunchKernelGGL(mlm_mask_kernel, dim3(grid_for(n, 256, 1024)), dim3(256), 0, stream, ids, labels, n, rng_stream, select_thr16,
+                       replace_thr16, special0, special1, special2, mask_id);
     MMB_CHECK_LAUNCH();
     return 0;
 }

@@ -261,6 +261,8 @@ class _EncoderFn(torch.autograd.Function):
             if keep:
                 saved.append((x, qkv, actx, lse, z1, m1, r1, y1, u, g, z2, m2, r2, d_att, d_h1, d_h2))
             x = y2
+            if top.debug_hidden is not None:
+                top.debug_hidden.setdefault("_layers_packed", []).append(y2.detach())
         ctx.top, ctx.layout, ctx.key_bias, ctx.saved, ctx.kv_len, ctx.top_rows = top, layout, key_bias, saved, kv_len, top_rows
         return x
 
@@ -545,6 +547,9 @@ class _GpuModelBase(nn.Module):
         self._calls = 0
         self._plans = {}
         self.grad_hook = None           # set by parallel.DataParallel: called as layers finish in backward
+        # tests only: a dict here collects, per _encode() call, "emb" (text embeddings of all passes), "x" (encoder input) and
+        # "layers" (every encoder layer's output), all [tokens, H] bf16 in the ORIGINAL packed row order (pass, sample, position)
+        self.debug_hidden = None
 
     def _wgrad_stream(self):
         """Side stream for the weight-gradient GEMMs (None = run them in line, the default); see _EncoderFn.backward.
@@ -724,6 +729,9 @@ class _GpuModelBase(nn.Module):
         # the caller does not want the prediction scores (trainer.py never reads them): rows that nothing else reads are left out
         drop = (not infer) and labels is not None and not getattr(self, "return_scores", True)
         split = self._split_layout(plan, kv_len, pending, infer, drop)
+        if self.debug_hidden is not None:
+            self.debug_hidden.update(emb=e1.detach(), x=x.detach())
+            self.debug_hidden.pop("_layers_packed", None)
         # rows of the top layer's output that can have a gradient (MLM-labelled rows + the [CLS] rows the heads read): known
         # when the caller is forward() / forward_fused() -- only they guarantee that nothing else is differentiated
         top_rows = (rows, plan["first"]) if (rows is not None and getattr(self, "sparse_top_layer_backward", True)) else None
@@ -738,6 +746,12 @@ class _GpuModelBase(nn.Module):
         else:
             y = _EncoderFn.apply(_PermuteRowsFn.apply(x, split.perm, split.inv), bert.embeddings.LayerNorm.weight, self, split, key_bias, seed, None, top_rows)
             y = _PermuteRowsFn.apply(y, split.inv, split.perm)
+        if self.debug_hidden is not None:
+            packed = self.debug_hidden.pop("_layers_packed", [])
+            if split is not None:                   # back to the original row order (left-out rows of the drop form read as zeros)
+                pad = getattr(split, "dropped", False)
+                packed = [(torch.cat((t, t.new_zeros((1, t.shape[1])))) if pad else t).index_select(0, split.inv) for t in packed]
+            self.debug_hidden["layers"] = packed
         return y, plan, lens
 
     def _request_lengths(self, plan, kv_len, labels, infer=False, pairs=None):

@@ -174,6 +174,16 @@ def dropout_mask(n: int, drop: Tuple[int, int, float], device) -> torch.Tensor:
     return out
 
 
+def mlm_mask(ids, p_select: float, seed: int, *, special_ids=(101, 102), mask_id=103, p_replace=0.8, site=4242):
+    """In-place MLM masking of an int64 id tensor on the GPU (mmbert_mlm_mask); returns the labels (-100 = not selected)."""
+    assert ids.dtype == torch.int64 and ids.is_contiguous() and len(special_ids) <= 3
+    sp = list(special_ids) + [special_ids[0] if special_ids else -1] * (3 - len(special_ids))
+    labels = torch.empty_like(ids)
+    _lib.check(_lib.load().mmbert_mlm_mask(_stream(), ids.data_ptr(), labels.data_ptr(), ids.numel(), rng_stream(seed, site),
+                                           int(round(p_select * 65536)), int(round(p_replace * 65536)), sp[0], sp[1], sp[2], mask_id), "mmbert_mlm_mask")
+    return labels
+
+
 def ln_fwd(x, gamma, beta, eps, *, M=None, out=None, in_rows=None, out_rows=None, drop: Drop = None, stats=True):
     lib = _lib.load()
     H = x.shape[1]

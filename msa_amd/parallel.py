@@ -11,8 +11,8 @@ contiguous slices of the model's flat fp32 gradient buffer instead of one call p
   reduced by ``finish()``;
 * consecutive finished layers are merged until a bucket holds >= ``bucket_mb`` MiB;
 * the 1/world_size average is folded into the AdamW kernel's gradient scale (no extra pass);
-* never-differentiated parameters hold zeros and are frozen in the optimizer, so
-  reducing them is a no-op; on accumulation micro-steps (the reference steps every 2nd
+* never-differentiated parameters hold zeros and are frozen in the optimizer:
+  their slices are cut out of the buckets (``GradBucketer(skip=...)``); on accumulation micro-steps (the reference steps every 2nd
   micro-batch, REF:trainer.py:96) ``no_sync()`` skips the exchange.
 
 Parity definition: DP(N ranks, local batch b) == mean over ranks of the single-rank gradients of
@@ -34,24 +34,42 @@ class GradBucketer:
     [b_k, b_{k+1}) becomes final when ``ready(k)`` is called (k must be called in order).  Pure
     torch.distributed: works on CPU tensors with gloo (tests) and on GPU tensors with RCCL."""
 
-    def __init__(self, flat_grads: torch.Tensor, boundaries: Sequence[int], group=None, bucket_mb: float = 32.0):
+    def __init__(self, flat_grads: torch.Tensor, boundaries: Sequence[int], group=None, bucket_mb: float = 32.0,
+                 skip: Sequence[Tuple[int, int]] = ()):
+        """``skip``: ascending, disjoint element ranges [a, b) that are never exchanged (parameters the reference never
+        differentiates: their gradient slots hold zeros on every rank) -- a bucket is cut around them."""
         assert boundaries[0] == 0 and boundaries[-1] == flat_grads.numel() and list(boundaries) == sorted(boundaries)
         self.flat, self.bounds, self.group = flat_grads, list(boundaries), group
         self.min_elems = int(bucket_mb * (1 << 20) / flat_grads.element_size())
+        self.skip = [(int(a), int(b)) for a, b in skip if b > a]
+        assert all(self.skip[i][1] <= self.skip[i + 1][0] for i in range(len(self.skip) - 1))
         self.handles: List = []
         self.done = 0            # elements already handed to the collective
         self.next_slice = 0
         self.enabled = True
         self.calls = 0           # number of collectives issued since reset (observable in tests)
+        self.elems = 0           # elements exchanged since reset
 
     def reset(self):
-        self.handles, self.done, self.next_slice, self.calls = [], 0, 0, 0
+        self.handles, self.done, self.next_slice, self.calls, self.elems = [], 0, 0, 0, 0
+
+    def _segments(self, lo: int, hi: int):
+        """[lo, hi) minus the skip ranges."""
+        for a, b in self.skip:
+            if b <= lo or a >= hi:
+                continue
+            if a > lo:
+                yield lo, a
+            lo = max(lo, b)
+        if lo < hi:
+            yield lo, hi
 
     def _issue(self, end: int):
         if end > self.done and self.enabled:
-            t = self.flat[self.done:end]
-            self.handles.append(dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
-            self.calls += 1
+            for lo, hi in self._segments(self.done, end):
+                self.handles.append(dist.all_reduce(self.flat[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+                self.calls += 1
+                self.elems += hi - lo
         self.done = end
 
     def ready(self, k: int):
@@ -73,7 +91,7 @@ class DataParallel:
     """Wraps an ``MMBertForPretraining``: broadcast of the initial weights, bucketed gradient
     all-reduce overlapped with backward, gradient averaging folded into the optimizer."""
 
-    def __init__(self, model, optimizer=None, group=None, bucket_mb: float = 32.0):
+    def __init__(self, model, optimizer=None, group=None, bucket_mb: float = 32.0, force_dynamic_queue: bool = False):
         if not dist.is_initialized():
             raise RuntimeError("torch.distributed is not initialised")
         self.model, self.group = model, group
@@ -83,7 +101,7 @@ class DataParallel:
         flat = model._flat
         dist.broadcast(flat.params, src=0, group=group)               # REF has one process; ranks must start equal
         flat.refresh()
-        if dev.type == "cuda" and self.world > 1:
+        if dev.type == "cuda" and (self.world > 1 or force_dynamic_queue):
             # RCCL's channel kernels hold CUs while the all-reduce of finished layers overlaps the rest of backward: let the
             # persistent GEMM draw its tiles from a queue, so that workgroups that start late do not strand a static share
             from . import ops
@@ -95,7 +113,12 @@ class DataParallel:
             last = f"bert.encoder.layer.{i}.attention.self.value.bias"
             bounds.append(flat.offset[last] + flat.numel[last])
         bounds.append(flat.total)
-        self.bucketer = GradBucketer(flat.grads, bounds, group, bucket_mb)
+        # frozen 256-element blocks (flat.FROZEN: W_cv / W_cs / seq_relationship -- no gradient in the reference, zeros here) are left out
+        fl = (flat.flags == 2).cpu().numpy().astype("int8")
+        edges = (fl[1:] != fl[:-1]).nonzero()[0] + 1
+        cuts = [0, *[int(e) for e in edges], len(fl)]
+        skip = [(256 * a, 256 * b) for a, b in zip(cuts[:-1], cuts[1:]) if fl[a] == 1]
+        self.bucketer = GradBucketer(flat.grads, bounds, group, bucket_mb, skip=skip)
         self._L = L
         model.grad_hook = self._on_layer_done
         if optimizer is not None:
@@ -123,12 +146,14 @@ class DataParallel:
         return self.model(*a, **k)
 
 
-def init_from_env(backend: Optional[str] = None) -> Tuple[int, int, int]:
-    """(rank, local_rank, world) from torchrun's environment; initialises the process group."""
+def init_from_env(backend: Optional[str] = None, force: bool = False) -> Tuple[int, int, int]:
+    """(rank, local_rank, world) from torchrun's environment; initialises the process group when world > 1 -- or, with
+    ``force``, also for a single process (``bench.py --force-dp``: the RCCL path exercised on one GPU).  Call it BEFORE the
+    first GPU call of the process."""
     import os
     rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
     local = int(os.environ.get("LOCAL_RANK", 0))
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or force) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")

@@ -17,6 +17,7 @@ import torch
 from torch.nn.utils.rnn import pad_sequence
 
 PAD, CLS, SEP, MASK = 0, 101, 102, 103
+_mask_calls = 0          # call counter folded into the seed of the device-side masking kernel
 
 
 def mask_tokens(inputs: torch.Tensor, args, generator: Optional[torch.Generator] = None, special_ids=(CLS, SEP), mask_id=MASK):
@@ -30,6 +31,18 @@ def mask_tokens(inputs: torch.Tensor, args, generator: Optional[torch.Generator]
     pass ``special_ids=(PAD, CLS, SEP)`` for the intended rule (a deviation from the reference).  With ``generator=None``
     on CPU the draws are the reference's own (same two ``torch.bernoulli`` calls in the same order on the global RNG:
     pinned by tests/golden/mask_tokens.npz)."""
+    if inputs.is_cuda and generator is None and inputs.dtype == torch.int64 and len(special_ids) <= 3:
+        # on the GPU: one launch of the library's counter-RNG masking kernel (mmbert_mlm_mask) instead of ~10 element-wise
+        # torch kernels; the per-call seed comes from torch's default CUDA generator, so torch.manual_seed() governs it
+        global _mask_calls
+        _mask_calls += 1
+        from . import ops
+        x = inputs if inputs.is_contiguous() else inputs.contiguous()
+        labels = ops.mlm_mask(x, float(args.mlm_probability), torch.cuda.initial_seed() * 1000003 + _mask_calls,
+                              special_ids=tuple(special_ids), mask_id=mask_id)
+        if x is not inputs:
+            inputs.copy_(x)
+        return inputs, labels
     labels = inputs.clone()
     prob = torch.full(labels.shape, float(args.mlm_probability), device=inputs.device)
     special = torch.zeros_like(inputs, dtype=torch.bool)

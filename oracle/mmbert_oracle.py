@@ -195,11 +195,17 @@ def mmbert_model(p: Params, cfg: dict, input_ids, attention_mask, token_type_ids
             tt = torch.zeros_like(text_ids, dtype=torch.long)
         ext = extended_attention_mask(tmask, False)
     x = bert_embeddings(p, text_ids, tt, hidden_dropout=hd, train=train, masks=masks, tag=tag)
+    inter = collect if isinstance(collect, dict) else None      # dict form: {tag + "emb" / "jemb" / "hidden": ...} of every pass
+    if inter is not None:
+        inter[tag + "emb"] = x
     if joint:
         x = joint_embeddings(p, x, pair, MODALITY_DIMS[cfg["dataset"]],
                              joint_dropout=cfg.get("joint_dropout", 0.5), train=train, masks=masks, tag=tag)
+        if inter is not None:
+            inter[tag + "jemb"] = x
+    hidden = inter.setdefault(tag + "hidden", []) if inter is not None else collect
     seq = encoder(p, x, ext, cfg["layers"], cfg["heads"], hidden_dropout=hd, attn_dropout=ad,
-                  train=train, masks=masks, tag=tag, collect=collect)
+                  train=train, masks=masks, tag=tag, collect=hidden)
     pooled = torch.tanh(_linear(seq[:, 0], p, "bert.pooler.dense"))          # HF:457-463
     return seq, pooled
 
@@ -257,9 +263,20 @@ def pretraining_forward(p: Params, cfg: dict, input_ids, token_type_ids, attenti
     ap_v, ap_s = ap_label
     kw = dict(train=train, masks=masks)
     t_mlm, _, pt, t_sc, t_rel = _one_pass(p, cfg, text_ids, am_t, tt_t, lab_t, None, False, tag="t.", collect=collect, **kw)
-    v_mlm, v_ap, pv, v_sc, v_rel = _one_pass(p, cfg, (twv, visual), am_v, tt_v, lab_v, ap_v, True, tag="v.", **kw)
-    s_mlm, s_ap, ps, s_sc, s_rel = _one_pass(p, cfg, (tws, speech), am_s, tt_s, lab_s, ap_s, True, tag="s.", **kw)
+    cj = collect if isinstance(collect, dict) else None       # (a list collects the text pass only; a dict every pass)
+    v_mlm, v_ap, pv, v_sc, v_rel = _one_pass(p, cfg, (twv, visual), am_v, tt_v, lab_v, ap_v, True, tag="v.", collect=cj, **kw)
+    s_mlm, s_ap, ps, s_sc, s_rel = _one_pass(p, cfg, (tws, speech), am_s, tt_s, lab_s, ap_s, True, tag="s.", collect=cj, **kw)
 
+    ap, label, nce, logits = fusion_objective(p, cfg, pt, pv, ps, v_ap, s_ap, sentiment)
+    mlm = (t_mlm + v_mlm + s_mlm) / 3.0                      # :427
+    joint_loss = cfg.get("alpha", 1.0) * mlm + ap + label - cfg.get("beta", 1.0) * nce   # :443
+    outputs = (joint_loss, None, None, None, ap, label, nce, t_sc, t_rel, v_sc, v_rel, s_sc, s_rel)
+    return outputs, logits
+
+
+def fusion_objective(p: Params, cfg: dict, pt, pv, ps, v_ap, s_ap, sentiment):
+    """REF:MMBertForPretraining.py:406-436 -- everything downstream of the three pooled vectors and the two alignment losses:
+    gates, gated concatenation, classifier, the three CPC terms, ap / label losses.  Returns (ap, label, nce, logits)."""
     def gate(x, vname):                                      # :407-409
         a = F.relu(_linear(torch.cat((x, x), dim=1), p, "attn"))
         return _linear(a, p, vname)
@@ -267,15 +284,27 @@ def pretraining_forward(p: Params, cfg: dict, input_ids, token_type_ids, attenti
     temp = _linear(pooled, p, "classifier1_1")               # :414
     logits = _linear(temp, p, "classifier1_2")               # :415
     nce = cpc(p, "cpc_zt", pt, temp) + cpc(p, "cpc_zv", pv, temp) + cpc(p, "cpc_za", ps, temp)
-    mlm = (t_mlm + v_mlm + s_mlm) / 3.0                      # :427
     ap = (v_ap + s_ap) / 2.0                                 # :428
     num_labels = cfg.get("num_labels", 7)
     if num_labels == 1:
         logits = torch.tanh(logits)                          # :434-435
     label = F.mse_loss(logits.view(-1), sentiment.view(-1).float())      # :433-436
-    joint_loss = cfg.get("alpha", 1.0) * mlm + ap + label - cfg.get("beta", 1.0) * nce   # :443
-    outputs = (joint_loss, None, None, None, ap, label, nce, t_sc, t_rel, v_sc, v_rel, s_sc, s_rel)
-    return outputs, logits
+    return ap, label, nce, logits
+
+
+def heads_from_cls(p: Params, cfg: dict, first, ap_v, ap_s, sentiment):
+    """The objective's part that hangs off the [CLS] rows, given those rows: ``first`` [3B, H] = the encoder outputs at position 0
+    of the text / visual / speech passes (in that order).  pooler (HF:457-463), ``align`` on the joint passes' rows
+    (REF:MMBertForPretraining.py:297-298), their 2-way CE (:385-388), then fusion_objective -- the same functions
+    pretraining_forward runs (pinned by the golden full-forward fixtures).  Returns (ap + label - beta * nce, ap, label, nce,
+    logits): what the HIP path's fused heads (csrc/heads.hip) are checked against in fp32, free of the encoder's bf16 noise."""
+    B = first.shape[0] // 3
+    pooled = torch.tanh(_linear(first, p, "bert.pooler.dense"))
+    v_rel, s_rel = _linear(first[B:2 * B], p, "cls.align"), _linear(first[2 * B:], p, "cls.align")
+    v_ap = F.cross_entropy(v_rel.view(-1, 2), ap_v.view(-1).long())
+    s_ap = F.cross_entropy(s_rel.view(-1, 2), ap_s.view(-1).long())
+    ap, label, nce, logits = fusion_objective(p, cfg, pooled[:B], pooled[B:2 * B], pooled[2 * B:], v_ap, s_ap, sentiment)
+    return ap + label - cfg.get("beta", 1.0) * nce, ap, label, nce, logits
 
 
 def fused_forward(p: Params, cfg: dict, input_ids, token_type_ids, attention_mask, masked_labels, ap_label, sentiment, *,

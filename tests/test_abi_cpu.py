@@ -58,7 +58,9 @@ def test_torch_operator_namespace_registers_without_a_gpu():
     import pytest
     import torch
     import msa_amd.torch_ops  # noqa: F401
-    for n in ("linear", "linear_pre", "linear_bwd", "layer_norm", "layer_norm_fwd", "layer_norm_bwd", "attention", "attention_fwd", "attention_bwd"):
+    for n in ("linear", "linear_pre", "linear_bwd", "layer_norm", "layer_norm_fwd", "layer_norm_bwd", "attention", "attention_fwd", "attention_bwd",
+              "embed_ln", "embed_ln_fwd", "embed_ln_bwd", "joint_embed", "joint_embed_fwd", "joint_embed_bwd", "mlm_head_ce", "mlm_head_ce_fwd",
+              "mlm_head_ce_bwd", "adamw_multi_tensor", "mlm_mask_rng"):
         assert hasattr(torch.ops.mmbert, n), n
     with pytest.raises((NotImplementedError, RuntimeError)):
         torch.ops.mmbert.layer_norm(torch.zeros(4, 64), torch.ones(64), torch.zeros(64), 1e-5)

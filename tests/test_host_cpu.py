@@ -139,6 +139,16 @@ def _bucket_worker(rank, world, port, q):
         bk2.ready(k)
     bk2.reset()
     res["nosync_ok"] = bool(torch.equal(flat2, base * (rank + 1))) and bk2.calls == 0
+    # frozen ranges are cut out of the buckets: never exchanged, whatever bucket they fall into (one straddles a bucket edge)
+    flat3 = base * (rank + 1)
+    bk3 = GradBucketer(flat3, bounds, bucket_mb=1000 * 4 / (1 << 20) * 0.3, skip=[(120, 200), (340, 360)])
+    for k in range(len(bounds) - 2):
+        bk3.ready(k)
+    bk3.finish()
+    keep = torch.zeros(n, dtype=torch.bool)
+    keep[120:200] = True
+    keep[340:360] = True
+    res["skip_ok"] = bool(torch.equal(flat3[~keep], (base * 3)[~keep])) and bool(torch.equal(flat3[keep], (base * (rank + 1))[keep]))
     # out-of-order readiness is a bug
     try:
         bk2.ready(2)
@@ -162,7 +172,7 @@ def test_grad_bucketer_world2_gloo():
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
-    assert res["sum_ok"] and res["nosync_ok"] and res["order_checked"]
+    assert res["sum_ok"] and res["nosync_ok"] and res["order_checked"] and res["skip_ok"]
     assert res["calls"] == 2, res          # slices merged into >=300-element buckets: [0,350) and [350,900); tail in finish()
 
 
@@ -194,14 +204,15 @@ def test_make_date_dir_counts_up(tmp_path):
 
 # ------------------------------------------------------------------------------- MMBertDataset / device batch builder
 def _np(v):
-    return np.asarray(v.detach().numpy() if torch.is_tensor(v) else v)
+    return np.asarray(v.detach().cpu().numpy() if torch.is_tensor(v) else v)
 
 
-def test_dataset_items_and_batches_match_the_reference(golden_dir):
+def check_dataset_fixture(golden_dir, device):
     """msa_amd.dataset.MMBertDataset against the REAL reference class (tests/golden/make_golden.py:gen_dataset) on the same
     synthetic items under the same seeded `random`: every field of every item (values, dtypes, the label-1-for-the-true-pair
     quirk, the self-paired last item), every sentiment rule, then collate() of four items -- and the device batch builder's
-    batch for the same indices from the same `random` state (fp32 features, otherwise identical)."""
+    batch on ``device`` for the same indices from the same `random` state (fp32 features, otherwise identical: integer and
+    mask tensors BIT-exact).  Runs on "cpu" here and on "cuda" from tests/test_train_gpu.py."""
     import random
     from tests.golden.dataset_features import synthetic_features
     from msa_amd.dataset import MMBertDataset, DeviceBatchBuilder
@@ -232,11 +243,13 @@ def test_dataset_items_and_batches_match_the_reference(golden_dir):
         idx = (0, 3, 4, 2)
         batch = T.collate([ds[i] for i in idx])
         random.seed(200 + ci)
-        dbatch = DeviceBatchBuilder(ds, "cpu").batch(idx)
+        dbatch = DeviceBatchBuilder(ds, device).batch(idx)
         for which, bt in (("collate", batch), ("device builder", dbatch)):
             for gname, grp in (("text", bt[0]), ("visual", bt[1]), ("speech", bt[2]), ("attention", bt[3])):
                 for i, t in enumerate(grp):
                     ref = g[f"{tag}/batch/{gname}{i}"]
+                    if which == "device builder":
+                        assert t.device.type == torch.device(device).type, (tag, gname, i, t.device)
                     a = _np(t)
                     a = a[..., :4] if a.ndim == 3 else a
                     is_feature = gname in ("visual", "speech") and i == 1
@@ -246,6 +259,10 @@ def test_dataset_items_and_batches_match_the_reference(golden_dir):
                         assert np.array_equal(a, ref), (which, tag, gname, i)
                         assert str(t.dtype) == str(g[f"{tag}/batch/{gname}{i}_dtype"]), (which, tag, gname, i, t.dtype)
             assert list(bt[4]) == [str(x) for x in g[f"{tag}/batch/seg"]]
+
+
+def test_dataset_items_and_batches_match_the_reference(golden_dir):
+    check_dataset_fixture(golden_dir, "cpu")
 
 
 def test_device_batch_feeds_pack_step_inputs():

@@ -59,8 +59,15 @@ def test_full_forward_backward(golden_dir, name):
     B, T, Pv, Pa, seed = (int(x) for x in g["meta"])
     batch = synthetic_batch(B, T, Pv, Pa, dataset=cfg["dataset"], vocab=cfg["vocab"], seed=seed)
     p = {k: v.clone().requires_grad_(True) for k, v in O.seeded_params(cfg).items()}
-    hidden = []
-    outputs, logits = O.pretraining_forward(p, cfg, **batch, collect=hidden)
+    inter = {}
+    outputs, logits = O.pretraining_forward(p, cfg, **batch, collect=inter)
+    hidden = inter["t.hidden"]
+    for tag in "tvs":                                           # every pass's embeddings and per-layer hidden states
+        close(inter[tag + ".emb"].detach(), g[f"{tag}_emb"], rtol=1e-4, atol=1e-5)
+        for l in range(cfg["layers"]):
+            close(inter[tag + ".hidden"][l].detach(), g[f"{tag}_hidden{l}"], rtol=1e-4, atol=2e-5)
+    close(inter["v.jemb"].detach(), g["v_jemb"], rtol=1e-4, atol=1e-5)
+    close(inter["s.jemb"].detach(), g["s_jemb"], rtol=1e-4, atol=1e-5)
     close(outputs[0].detach(), g["joint_loss"], rtol=1e-5)
     close(outputs[4].detach(), g["ap_loss"], rtol=1e-5)
     close(outputs[5].detach(), g["label_loss"], rtol=1e-5)

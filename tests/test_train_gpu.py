@@ -213,3 +213,176 @@ def test_device_batch_builder_drives_train_epoch():
         first = ret[0] if first is None else first
         last = ret[0]
     assert np.isfinite(last) and last < first, (first, last)
+
+
+# ================================================================================================ round 2
+def test_device_batch_builder_is_bit_exact_on_cuda(golden_dir):
+    """SURVEY S8(f) row 2 on the device: DeviceBatchBuilder("cuda").batch() against the REAL reference's collate() output for the
+    same items and the same `random` state (tests/golden/dataset.npz) -- ids, labels, token types, masks and sentiments BIT-exact
+    with the reference's dtypes; features equal to the reference's float64 values rounded to fp32 (the one declared difference)."""
+    from tests.test_host_cpu import check_dataset_fixture
+    check_dataset_fixture(golden_dir, DEV)
+
+
+def _eval_items(g, n):
+    Tn = len(g["item0_text"])
+    items = []
+    for i in range(n):
+        te = [int(x) for x in g[f"item{i}_text"]]
+        tti, vti = torch.zeros(Tn), torch.cat((torch.zeros(Tn), torch.ones(Tn)))
+        sent = float(g[f"item{i}_sent"])
+        items.append((torch.tensor(te), torch.tensor(0), tti, torch.tensor(sent), te, g[f"item{i}_visual"], torch.tensor(int(g[f"item{i}_ap"][0])), vti,
+                      torch.tensor(sent), te, g[f"item{i}_speech"], torch.tensor(int(g[f"item{i}_ap"][1])), vti, torch.tensor(sent), "s", "r"))
+    return items
+
+
+def test_eval_epoch_matches_reference_golden(golden_dir):
+    """G9: the REAL reference's trainer.eval_epoch (REF:trainer.py:103-194) on six items, val_batch_size 4 (one full and one short
+    batch), mlm off, eval mode -- replayed in the order its RandomSampler drew: the 8-tuple (dev loss, three zero modality losses,
+    LAST batch's ap_loss / steps, label loss, predictions [N,1], labels [N]), the per-batch losses, and what test_MSE_score_model
+    makes of the predictions.  Stated: losses 4e-3 relative (bf16 path), predictions 2e-2 abs, labels exact, accuracy / F1 exact
+    when no prediction lies within 2e-2 of the sign boundary (asserted on the fixture)."""
+    from msa_amd import trainer as T
+    g = np.load(os.path.join(golden_dir, "eval6.npz"))
+    order = [int(i) for i in g["order"]]
+    items = _eval_items(g, 6)
+    data = [items[i] for i in order]
+    m = build()
+    args = T.default_args(val_batch_size=int(g["val_batch_size"]), mlm=False)
+    losses = []
+    orig = m.forward
+
+    def rec(*a, **k):
+        out = orig(*a, **k)
+        losses.append([float(out[0][i]) for i in (0, 4, 5, 6)])
+        return out
+    m.forward = rec
+
+    class Seq(torch.utils.data.Dataset):                       # replay: eval_epoch's own RandomSampler must see the recorded order
+        def __len__(self):
+            return len(data)
+
+        def __getitem__(self, i):
+            return data[i]
+    from torch.utils.data import DataLoader, SequentialSampler
+    loader = DataLoader(Seq(), sampler=SequentialSampler(Seq()), batch_size=args.val_batch_size, collate_fn=T.collate)
+    ret = T.eval_epoch(args, m, None, device=DEV, batches=(T.pack_step_inputs(b, args, DEV) for b in loader))
+    m.forward = orig
+    assert not m.training and len(ret) == 8
+    ref = g["losses"]
+    assert len(losses) == len(ref) == 2
+    for s_ in range(2):
+        for j in range(4):
+            assert abs(losses[s_][j] - ref[s_][j]) < 4e-3 * max(1.0, abs(ref[s_][j])), (s_, j, losses[s_], ref[s_])
+    r6 = g["ret6"]
+    assert abs(ret[0] - r6[0]) < 4e-3 * r6[0] and ret[1] == ret[2] == ret[3] == 0.0 == r6[1] == r6[2] == r6[3]
+    assert abs(ret[4] - r6[4]) < 4e-3 * abs(r6[4]) + 1e-4              # LAST batch's ap_loss / number of steps (REF:trainer.py:194)
+    assert abs(ret[5] - r6[5]) < 4e-3 * r6[5]
+    assert ret[6].shape == g["preds"].shape == (6, 1) and ret[7].shape == g["labels"].shape == (6,)
+    assert np.abs(ret[6] - g["preds"]).max() < 2e-2
+    np.testing.assert_allclose(ret[7], g["labels"], rtol=0, atol=0)
+    assert np.abs(g["preds"]).min() > 2e-2                               # no prediction near the sign boundary: the metrics must agree exactly
+    acc, mae, f1 = T.test_MSE_score_model(ret[6], ret[7])
+    assert acc == g["mse_scores"][0] and abs(f1 - g["mse_scores"][2]) < 1e-12 and abs(mae - g["mse_scores"][1]) < 2e-2
+
+
+def test_mosei_shape_trainer_loop_50_steps():
+    """BASELINE configs[4]: the full pretraining loop through msa_amd.trainer.train_epoch (the reference's trainer.py counterpart)
+    at the MOSEI shape -- 12-layer d=768, T=50, speech 74-dim x 500, visual 35-dim x 500, batch 16, train mode (all dropouts),
+    AdamW (HF mode) + the reference's warm-up schedule, the `&` stepping quirk: 52 micro-batches = 26 optimizer steps.  Asserts
+    the size-independent properties: every loss finite, the joint loss falls, the step-count rule, parameters the reference never
+    differentiates stay bit-identical while every other parameter moves, and the bf16 working copy follows the fp32 masters."""
+    from msa_amd import trainer as T
+    cfg = dict(hidden=768, layers=12, heads=12, intermediate=3072, vocab=30522, dataset="mosei", alpha=1.0, beta=1.0)
+    m = build(cfg, dropout=0.1)
+    m.train()
+    m.manual_seed(7)
+    n_micro = 52
+    args = T.default_args(train_batch_size=16, learning_rate=1e-4, mlm=True)
+    opt, sched = T.build_optimizer(m, args, n_micro // 2, mode="hf")
+    pool = [batch_to(synthetic_batch(16, 50, 500, 500, dataset="mosei", vocab=cfg["vocab"], seed=300 + i), DEV) for i in range(4)]
+    assert pool[0]["input_ids"][1].shape == (16, 500, 35) and pool[0]["input_ids"][2].shape == (16, 500, 74)
+    before = {n: p.detach().clone() for n, p in m.named_parameters()}
+    losses = []
+    orig = m.forward
+
+    def rec(*a, **k):
+        out = orig(*a, **k)
+        losses.append(out[0][0].detach())
+        return out
+    m.forward = rec
+    ret = T.train_epoch(args, m, None, opt, sched, device=DEV, batches=(pool[i % 4] for i in range(n_micro)))
+    m.forward = orig
+    torch.cuda.synchronize()
+    ls = torch.stack(losses).float().cpu().numpy()
+    assert len(ls) == n_micro and np.isfinite(ls).all() and all(np.isfinite(r) for r in ret)
+    assert opt._steps == n_micro // 2 and sched.last_step == n_micro // 2           # (step + 1) & 1 == 0: every second micro-batch
+    assert ls[-8:].mean() < ls[:8].mean() - 0.5, (ls[:8].mean(), ls[-8:].mean())    # MLM loss leaves ln(30522) = 10.3 quickly
+    frozen = ("bert.jointEmbeddings.W_cv.", "bert.jointEmbeddings.W_cs.", "cls.seq_relationship.")
+    moved = 0
+    for n, p in m.named_parameters():
+        assert bool(torch.isfinite(p).all()), n
+        if n.startswith(frozen):
+            assert torch.equal(p.detach(), before[n]), n                              # never differentiated in the reference (App. B-9)
+        else:
+            moved += int(not torch.equal(p.detach(), before[n]))
+    assert moved >= len(before) - 6 - 12                                              # (key biases have a zero true gradient: may or may not move)
+    f = m._flat
+    assert torch.equal(f.half.float(), f.params.to(torch.bfloat16).float())           # AdamW refreshed the bf16 copy it computes with
+
+
+def _nccl_world1_worker(port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import torch
+    import torch.distributed as dist
+    from msa_amd import ops, parallel
+    from msa_amd import trainer as T
+    try:
+        rank, local, world = parallel.init_from_env(force=True)                       # RCCL with world_size 1, before any GPU call
+        assert dist.is_initialized() and dist.get_backend() == "nccl" and world == 1
+        cfg = dict(hidden=256, layers=3, heads=4, intermediate=1024, vocab=4096, dataset="mosei", alpha=1.0, beta=1.0)
+        batch = batch_to(synthetic_batch(4, 24, 200, 130, dataset="mosei", vocab=cfg["vocab"], seed=31), "cuda")
+        grads = {}
+        for use_dp in (False, True):
+            m = build(cfg, dropout=0.1)
+            m.train()
+            m.manual_seed(5)
+            args = T.default_args(train_batch_size=4, learning_rate=1e-3)
+            opt, sched = T.build_optimizer(m, args, 4)
+            dp = parallel.DataParallel(m, opt, bucket_mb=0.5, force_dynamic_queue=True) if use_dp else None
+            out, _ = m(**batch)
+            out[0].mean().backward()
+            if dp is not None:
+                calls = dp.bucketer.calls
+                dp.finish_backward()
+                assert calls >= 2, calls                                              # layer buckets were reduced DURING backward
+                assert ops.dynamic_tile_queue                                         # the persistent GEMM ran on its device-side queue
+            torch.cuda.synchronize()
+            grads[use_dp] = m._flat.grads.clone()
+            ops.dynamic_tile_queue = False
+        a, b = grads[True], grads[False]
+        err = float((a - b).abs().max() / b.abs().max())
+        q.put(("ok", err, float(b.abs().max())))
+        dist.destroy_process_group()
+    except Exception as e:                                                            # pragma: no cover
+        import traceback
+        q.put(("error", traceback.format_exc(), 0.0))
+
+
+def test_data_parallel_over_rccl_world1_equals_plain_step():
+    """The DP code path on hardware with ONE GPU: torch.distributed "nccl" (= RCCL) initialised with world_size 1, the model
+    wrapped in parallel.DataParallel (weight broadcast, bucketed all-reduce hooks fired from backward as layers finish, the
+    persistent GEMM on its dynamic tile queue), against the same seeded train-mode step without the wrapper: gradients equal up
+    to fp32 atomic-order noise.  Runs in a child process (the process group must exist before the first GPU call)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    with socket.socket() as s_:
+        s_.bind(("127.0.0.1", 0))
+        port = s_.getsockname()[1]
+    p = ctx.Process(target=_nccl_world1_worker, args=(port, q))
+    p.start()
+    status, err, scale = q.get(timeout=600)
+    p.join(120)
+    assert status == "ok", err
+    assert p.exitcode == 0
+    assert err < 2e-3, (err, scale)

@@ -5,7 +5,10 @@ wide coalesced stream -> doubled; WRITE_SIZE is exact for 16-B-per-lane stores. 
 
     python tools/pmc_traffic.py gpurun_out/pmc_FETCH_SIZE/pmc_counter_collection.csv gpurun_out/pmc_WRITE_SIZE/pmc_counter_collection.csv > profiles/...
 """
-import csv, sys, collections, re
+import csv, sys, collections, re, os, subprocess
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from bench import csrc_digest
 def load(path, name):
     acc = collections.defaultdict(lambda: [0, 0.0])
     for r in csv.DictReader(open(path)):
@@ -15,6 +18,11 @@ def load(path, name):
     return acc
 f, w = load(sys.argv[1], "FETCH_SIZE"), load(sys.argv[2], "WRITE_SIZE")
 print("# rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timing")
+print("# csrc_sha256: " + csrc_digest())      # bench.py refuses this summary once the kernel sources differ
+try:
+    print("# git_sha: " + subprocess.check_output(["git", "-C", ROOT, "rev-parse", "HEAD"], text=True, stderr=subprocess.DEVNULL).strip())
+except Exception:
+    pass
 print("# per launch (mean over the run's launches of that kernel); fetch_MB = 2*FETCH_SIZE[KiB]/1024 (gfx950: 64 B counted per 128-B request), write_MB = WRITE_SIZE[KiB]/1024")
 print("kernel,launches,FETCH_SIZE_KiB,WRITE_SIZE_KiB,fetch_MB,write_MB,total_MB")
 rows = []
