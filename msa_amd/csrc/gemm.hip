@@ -31,12 +31,28 @@ struct GemmNT {
     uint32_t drop_stream, drop_thr16; float drop_scale;
     int kt_per_split; long long split_stride;     // gemm_nt_kernel only: split-K over blockIdx.z into fp32 slabs (0 = no split)
     int* tile_counter; int* tile_counter_next;    // gemm_ntp_kernel only: dynamic tile queue = {fetch counter, exit counter} (null = static b, b+G, ...)
+    int group_m;                                  // gemm_ntp_kernel only: tile walk in groups of group_m row tiles (<= 1: row-major), see ntp_tile_mn
 };
 
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     // bijective "each XCD gets a contiguous chunk" remap (blocks b and b+8 share an XCD)
     const int q = nwg >> 3, r = nwg & 7, x = bid & 7, j = bid >> 3;
     return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + j;
+}
+
+// Tile walk of the persistent kernel.  Linear tile index t (the XCD-contiguous order of xcd_remap) -> (row tile, column tile).
+// group_m <= 1: row-major (all column tiles of a row tile, then the next row tile): right when the B operand (N x K weights) fits an
+// XCD's 4 MiB L2 -- the 32 workgroups of an XCD then share a few A row panels and the resident B.  For the vocabulary projection
+// (B = 47 MB) that order streams the WHOLE B from the Infinity Cache once per row tile (round 1, PMC: 3.6 GB fetched per launch for
+// 75 MB of operands); with group_m = 4 the walk sweeps the column tiles with 4 row tiles at a time (index within the group fastest),
+// so 32 consecutive tiles = 4 row tiles x 8 column tiles: the 4 A panels (1.6 MB) stay in L2 for the whole sweep and every B panel
+// is fetched once per GROUP -- a quarter of the B traffic.
+__device__ __forceinline__ void ntp_tile_mn(int t, int tiles_m, int tiles_n, int gm, int& tm, int& tn) {
+    if (gm <= 1) { tm = t / tiles_n; tn = t - tm * tiles_n; return; }
+    const int per = gm * tiles_n, g = t / per, r = t - g * per;
+    const int gs = min(gm, tiles_m - g * gm);                  // the last group may be short
+    tn = r / gs;
+    tm = g * gm + (r - tn * gs);
 }
 
 // shared epilogue: v[0..3] = alpha-scaled accumulators of C[m][n..n+3]
@@ -490,8 +506,9 @@ __global__ __launch_bounds__(512, 2) void gemm_ntp_kernel(const GemmNT p) {
         asm volatile("" : "+v"(l));                               // recomputed per call, nothing kept alive across the K loop
         const int srow = l >> 2;
         const uint32_t schunk = (l & 3) ^ ((GT >> (2 * ((srow >> 2) & 3))) & 3);
-        const int t = xcd_remap(v, ntiles);
-        const int tm0 = (t / tiles_n) * BM, tn0 = (t % tiles_n) << 8;
+        int tmi, tni;
+        ntp_tile_mn(xcd_remap(v, ntiles), tiles_m, tiles_n, p.group_m, tmi, tni);
+        const int tm0 = tmi * BM, tn0 = tni << 8;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int r = wave * 32 + i * 16 + srow;
@@ -673,8 +690,9 @@ __global__ __launch_bounds__(512, 2) void gemm_ntp_kernel(const GemmNT p) {
     };
     if (p.tile_counter && tid == 0) vq_write(first_fetch);
     for (int v = blockIdx.x, vn = 0; v < ntiles; v = vn) {
-        const int tile = xcd_remap(v, ntiles);
-        const int m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) << 8;
+        int tmi, tni;
+        ntp_tile_mn(xcd_remap(v, ntiles), tiles_m, tiles_n, p.group_m, tmi, tni);
+        const int m0 = tmi * BM, n0 = tni << 8;
 
         // K steps 0-3 issue stages 4-7 of this tile (ns >= 8).  `early` only selects the wait immediate (a scalar branch
         // around one s_waitcnt); two full copies of the steps made hipcc spill accumulator tuples at the join
@@ -918,6 +936,9 @@ static int launch_ntp_mi(hipStream_t s, const GemmNT& p) {
     // again (the last workgroup to exit resets them), so one 8-byte buffer serves every launch of a stream.  Launches with no
     // more tiles than workgroups need no queue.
     if (tiles <= cus) q.tile_counter = q.tile_counter_next = nullptr;
+    // B panels that do not fit an XCD's L2 next to the A stream (> 3 MiB of weights: the vocabulary projection): grouped tile walk
+    static const int gm_env = getenv("MMBERT_NT_GROUP_M") ? atoi(getenv("MMBERT_NT_GROUP_M")) : -1;        // A/B switch
+    q.group_m = gm_env >= 0 ? gm_env : (((long long)p.N * p.K * 2 > (3ll << 20) && tiles > 4 * cus) ? 4 : 1);
     hipLaunchKernelGGL((gemm_ntp_kernel<EPI, MI, MI == 8>), dim3(tiles < cus ? tiles : cus), dim3(512), NTP_LDS_BYTES, s, q);
     MMB_CHECK_LAUNCH();
     return 0;
@@ -958,6 +979,12 @@ static int launch_nt256(hipStream_t s, const GemmNT& p) {
         // tile times): backward runs on a data-dependent row count (model.py, SplitLayout), e.g. 14 400 rows x N = 3072 is 780
         // tiles = 4 rounds at 224 rows but 684 = 3 rounds at 256.  A 256-row tile is priced at 1.1 of a 224-row one.
         static const bool tall_ok = !(getenv("MMBERT_NT_TALL") && atoi(getenv("MMBERT_NT_TALL")) == 0);     // A/B switch
+        // Round 2 (profiles/r2_exp_nt_tile_heights.log): 192- and 160-row forms of this kernel were built and timed on the
+        // single-round N = 768 input-gradient shapes (13-14.4 k rows): a tile takes the SAME time at 160 / 192 / 224 / 256 rows
+        // (23.2-23.6, 52.7-53.6, 68.3-70.0 us) -- the K step issues its 32 stage loads whatever the tile height (all 256 A rows
+        // are staged) and that, not the MFMA count, is its length -- so only the round count matters and the two forms below
+        // stay.  A start stagger of the workgroups (to spread the epilogues' store bursts) was a loss on every shape, the
+        // 34-round vocabulary projection included (profiles/r2_exp_nt_start_stagger.log).
         if (can_persist) return (tall_ok && (float)r256 * 1.1f < (float)r224) ? launch_ntp_mi<EPI, 8>(s, p) : launch_ntp_mi<EPI, 7>(s, p);
         return r224 <= r256 ? launch_nt256_mi<EPI, 7>(s, p) : launch_nt256_mi<EPI, 8>(s, p);
     }
@@ -1337,7 +1364,7 @@ int mmbert_gemm_nt(hipStream_t stream, const void* A, int lda, const void* B, in
     p.aux = (bf16_t*)aux; p.U = (const bf16_t*)U; p.alpha_dev = alpha_dev;
     p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.ldr = ldr; p.ldaux = ldaux; p.ldu = ldu;
     p.alpha = alpha; p.drop_stream = drop_stream; p.drop_thr16 = drop_thr16; p.drop_scale = drop_scale;
-    p.kt_per_split = 0; p.split_stride = 0;
+    p.kt_per_split = 0; p.split_stride = 0; p.group_m = 1;
     p.tile_counter = tile_queue; p.tile_counter_next = tile_queue ? tile_queue + 1 : nullptr;
     switch (epi) {
         case 0: return dispatch_nt<0>(stream, p);

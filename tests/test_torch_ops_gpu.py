@@ -115,7 +115,8 @@ def test_embed_ln_operator_forward_and_gradients():
     ref.backward(dy.float())
     close(y, ref, 1e-2, 2e-2, "y")
     for got, want, what in zip(dv, rv, ("dword", "dtype", "dpos", "dgamma", "dbeta")):
-        close(got.grad, want.grad, 3e-2, 6e-2, what)
+        # table gradients are sums over up to B*T = 60 rows of a bf16-stored gradient (entries up to ~10: half an ulp 2e-2 each)
+        close(got.grad, want.grad, 3e-2, 3e-1 if what == "dtype" else 1e-1, what)
     assert float(dv[0].grad[0].abs().max()) == 0.0                       # padding_idx row
     # dropout: seeded and unbiased
     a = torch.ops.mmbert.embed_ln(ids.to(DEV), None, *[t.detach() for t in dv], 1e-12, 0.25, 7)

@@ -13,7 +13,10 @@ shapes = [("qkv", M, 2304, 768, "bias"), ("o", M, 768, 768, "resid"), ("w1", M, 
           ("vocab", M, 30592, 768, "bias"), ("dvocab", M, 768, 30592, "plain")]
 rounds = int(os.environ.get("ROUNDS", 5))
 MODES = [int(x) for x in os.environ.get("MODES", "3,4").split(",")]
-NAMES = {8: "static", 0: "default", 1: "128sq", 2: "ring auto", 3: "ring256", 4: "ring224", 5: "pers auto", 6: "pers256", 7: "pers224"}
+NAMES = {0: "default", 1: "128sq", 2: "ring auto", 3: "ring256", 4: "ring224", 5: "pers auto", 6: "pers256", 7: "pers224"}
+only = os.environ.get("SHAPES")
+if only:
+    shapes = [sh for sh in shapes if sh[0] in only.split(",")]
 for name, m, n, k, epi in shapes:
     A = torch.randn(m, k, device=dev).bfloat16(); B = (torch.randn(n, k, device=dev) * 0.05).bfloat16()
     bias = torch.randn(n, device=dev); R = torch.randn(m, n, device=dev).bfloat16(); U = torch.randn(m, n, device=dev).bfloat16()
