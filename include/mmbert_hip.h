@@ -100,8 +100,13 @@ int mmbert_ln_bwd(mmbert_stream_t stream, const void* dy, int lddy, const int* d
                   void* dx, int lddx, const int* dx_rows, void* dx2, int lddx2, float* dgamma, float* dbeta, float* dbias2,
                   uint32_t post_stream, uint32_t post_thr, float post_scale,
                   uint32_t pre_stream, uint32_t pre_thr, float pre_scale,
-                  float* partial_ws /* mmbert_ln_bwd_workspace() floats, or NULL: contended atomics */, const int* drop_rows);
+                  float* partial_ws /* mmbert_ln_bwd_workspace() floats, or NULL: contended atomics */, const int* drop_rows,
+                  int defer_reduce /* != 0: leave the per-block partial sums in partial_ws for mmbert_ln_bwd_reduce */);
 size_t mmbert_ln_bwd_workspace(int M, int H);
+/* One launch that folds the partial sums of `items` (<= 32) deferred mmbert_ln_bwd calls into their dgamma / dbeta (/ dbias2)
+ * gradients (+=).  The calls must share M and H.  Host arrays of `items` pointers; dbias2 (or single entries of it) may be NULL. */
+int mmbert_ln_bwd_reduce(mmbert_stream_t stream, int items, const float* const* partial_ws, float* const* dgamma, float* const* dbeta,
+                         float* const* dbias2, int M, int H);
 
 /* ---- embeddings ----
  * gather: out[i] = word[ids[i]] + type[tts[i]] + pos[i % T]     HF:96-102 via REF:MMBertForPretraining.py:264

@@ -208,24 +208,33 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
     }
 }
 
-// out_k[col] += sum_b partial[b][k][col]  for k = 0 (dgamma), 1 (dbeta), 2 (dbias2, optional).
-// grid (ceil(H/64), 3, 16): a workgroup = 64 columns x 4 interleaved row groups over 1/16 of the partials,
-// LDS-reduced, then ONE atomic per column per workgroup (16 adders per address: no contention to speak of).
-__global__ __launch_bounds__(256) void ln_bwd_reduce_kernel(const float* __restrict__ partial, int nblocks, int H, float* __restrict__ dgamma,
-                                                            float* __restrict__ dbeta, float* __restrict__ dbias2) {
+// Round 2: 16-byte-per-lane forms of the two LayerNorm kernels (half a wave per row, bf16x8 accesses, two rows in flight per wave)
+// were built and timed against the 8-byte one-wave-per-row kernels above in one process (tools/bench_ln.py at the time): forward
+// 13.6 vs 13.7 us, backward in the encoder's form (dx, dx2) 25.6 vs 22.8 us at 18 400 rows, 21.6 vs 20.2 us at 13 745 -- the wider
+// accesses buy nothing here (the kernels run 12-25 us: launch ramp and drain, not the access width, separate them from the copy
+// ceiling) and the 200+ VGPRs of the wide backward cost occupancy.  Not kept.  What did pay: the encoder's bias gradients ride on
+// the weight-gradient GEMM and the gamma / beta partial sums of all its LayerNorms are folded in by ONE launch (below).
+
+// out_k[col] += sum_b partial[b][k][col]  for k = 0 (dgamma), 1 (dbeta), 2 (dbias2, optional), batched: up to 32 LayerNorm backward
+// passes of one launch sequence (same H, same block count) are folded into their gradients by ONE launch.
+// grid (ceil(H/64), items * 3, 8): a workgroup = 64 columns x 4 interleaved row groups over 1/8 of the partials, LDS-reduced, then
+// ONE atomic per column per workgroup (8 adders per address: no contention to speak of).
+struct LnReduceBatch { float* out[32][3]; const float* partial[32]; int nblocks, H, nq, items; };
+__global__ __launch_bounds__(256) void ln_bwd_reduce_batch_kernel(const LnReduceBatch b) {
     __shared__ float red[4][64];
     const int col = blockIdx.x * 64 + (threadIdx.x & 63), sub = threadIdx.x >> 6;
-    const int k = blockIdx.y;
-    float* out = k == 0 ? dgamma : (k == 1 ? dbeta : dbias2);
+    const int item = blockIdx.y / b.nq, k = blockIdx.y - item * b.nq;
+    float* out = b.out[item][k];
     if (out == nullptr) return;
-    const int per = (nblocks + gridDim.z - 1) / gridDim.z;
-    const int b0 = blockIdx.z * per, b1 = min(nblocks, b0 + per);
+    const float* partial = b.partial[item];
+    const int per = (b.nblocks + gridDim.z - 1) / gridDim.z;
+    const int b0 = blockIdx.z * per, b1 = min(b.nblocks, b0 + per);
     float s = 0.f;
-    if (col < H)
-        for (int b = b0 + sub; b < b1; b += 4) s += partial[((size_t)b * 3 + k) * H + col];
+    if (col < b.H)
+        for (int q = b0 + sub; q < b1; q += 4) s += partial[((size_t)q * b.nq + k) * b.H + col];
     red[sub][threadIdx.x & 63] = s;
     __syncthreads();
-    if (sub == 0 && col < H) atomicAdd(out + col, red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
+    if (sub == 0 && col < b.H) atomicAdd(out + col, red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
 
 // --------------------------------------------------------------------------------------------
@@ -679,27 +688,49 @@ int mmbert_ln_fwd(hipStream_t stream, const void* x, int ldx, const int* in_rows
     return 0;
 }
 
+static inline int ln_bwd_blocks(int M) { return grid_for(M, 16, 1024); }
+
 int mmbert_ln_bwd(hipStream_t stream, const void* dy, int lddy, const int* dy_rows, const void* x, int ldx, const int* x_rows,
                   const float* mean, const float* rstd, const float* gamma, int M, int H,
                   void* dx, int lddx, const int* dx_rows, void* dx2, int lddx2, float* dgamma, float* dbeta, float* dbias2,
                   uint32_t post_stream, uint32_t post_thr, float post_scale,
-                  uint32_t pre_stream, uint32_t pre_thr, float pre_scale, float* partial_ws, const int* drop_rows) {
+                  uint32_t pre_stream, uint32_t pre_thr, float pre_scale, float* partial_ws, const int* drop_rows, int defer_reduce) {
     if (M <= 0) return 0;
     if (H > LN_MAXV * 256 || (H & 3) || (ldx & 3) || (lddy & 3) || (lddx & 3) || (lddx2 & 3)) return -1;
-    const int nblocks = grid_for(M, 16, 1024);
+    if (defer_reduce && !partial_ws) return -1;
+    const int nblocks = ln_bwd_blocks(M);
     hipLaunchKernelGGL(ln_bwd_kernel, dim3(nblocks), dim3(256), 0, stream, (const bf16_t*)dy, lddy, dy_rows, (const bf16_t*)x, ldx, x_rows,
                        mean, rstd, gamma, M, H, (bf16_t*)dx, lddx, dx_rows, (bf16_t*)dx2, lddx2, dgamma, dbeta, dbias2, partial_ws,
                        post_stream, post_thr, post_scale, pre_stream, pre_thr, pre_scale, drop_rows);
     MMB_CHECK_LAUNCH();
-    if (partial_ws) {
-        hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3((H + 63) / 64, 3, 16), dim3(256), 0, stream, (const float*)partial_ws, nblocks, H, dgamma, dbeta, dbias2);
+    if (partial_ws && !defer_reduce) {
+        LnReduceBatch b = {};
+        b.out[0][0] = dgamma; b.out[0][1] = dbeta; b.out[0][2] = dbias2; b.partial[0] = partial_ws;
+        b.nblocks = nblocks; b.H = H; b.nq = 3; b.items = 1;
+        hipLaunchKernelGGL(ln_bwd_reduce_batch_kernel, dim3((H + 63) / 64, 3, 8), dim3(256), 0, stream, b);
         MMB_CHECK_LAUNCH();
     }
     return 0;
 }
 
 // floats the caller must provide as partial_ws for mmbert_ln_bwd (0 = use the atomic path)
-size_t mmbert_ln_bwd_workspace(int M, int H) { return (size_t)grid_for(M, 16, 1024) * 3 * H; }
+size_t mmbert_ln_bwd_workspace(int M, int H) { return (size_t)ln_bwd_blocks(M) * 3 * H; }
+
+// Deferred reduction (mmbert_ln_bwd(..., defer_reduce = 1)): folds the partial sums of `items` (<= 32) earlier mmbert_ln_bwd calls
+// -- same M and H, each with its own partial_ws -- into their gradients in one launch.
+int mmbert_ln_bwd_reduce(hipStream_t stream, int items, const float* const* partial_ws, float* const* dgamma, float* const* dbeta,
+                         float* const* dbias2, int M, int H) {
+    if (items <= 0 || M <= 0) return 0;
+    if (items > 32) return -1;
+    LnReduceBatch b = {};
+    for (int i = 0; i < items; ++i) {
+        b.out[i][0] = dgamma[i]; b.out[i][1] = dbeta[i]; b.out[i][2] = dbias2 ? dbias2[i] : nullptr; b.partial[i] = partial_ws[i];
+    }
+    b.nblocks = ln_bwd_blocks(M); b.H = H; b.nq = 3; b.items = items;
+    hipLaunchKernelGGL(ln_bwd_reduce_batch_kernel, dim3((H + 63) / 64, items * 3, 8), dim3(256), 0, stream, b);
+    MMB_CHECK_LAUNCH();
+    return 0;
+}
 
 int mmbert_embed_gather(hipStream_t stream, const int64_t* ids, const int64_t* tts, const float* word, const float* type, const float* pos,
                         int n, int T, int H, int V, void* out, int ldo) {

@@ -278,6 +278,10 @@ class _EncoderFn(torch.autograd.Function):
         ra = layout.rows_a if getattr(layout, "split", False) else M_all
         if ra < M_all:
             dy = dy[:ra]
+        # LayerNorm' leaves its gamma / beta partial sums in a workspace; ONE reduce launch folds all layers' sums into the gradients at
+        # the end (with a data-parallel hook: per layer, before the layer's gradient slice is handed to the all-reduce); same-process
+        # A/B against round 1's form (bias sums inside LayerNorm', one reduce launch per call): 16.58 vs 16.76 ms per step
+        lnd = ops.LnDeferred()
         for i in reversed(range(top.config.num_hidden_layers)):
             lw = top._lw[i]
             saved_i = ctx.saved[i]
@@ -291,16 +295,17 @@ class _EncoderFn(torch.autograd.Function):
                     dy = _EncoderFn._last_layer_sparse(top, lw, layout, key_bias, ctx.kv_len, saved_i, dy, R, H, ra)
                     top._layer_grads_done(i)
                     continue
-            # --- output sublayer: y2 = LN(dropout(g.W2^T + b2) + y1)      (b2 / bo gradients come out of ln_bwd)
+            # --- output sublayer: y2 = LN(dropout(g.W2^T + b2) + y1)      (b2 / bo gradients = column sums of dz2d / dz1d: they ride
+            # on the weight-gradient launch below, like b1 and bqkv, on an all-ones MFMA operand)
             dz2d = torch.empty_like(dy) if d_h2[1] else None
-            dz2 = ops.ln_bwd(dy, z2, m2, r2, lw["ln2_g"], lw["g_ln2_g"], lw["g_ln2_b"], dx2=dz2d, pre_drop=d_h2, dbias2=lw["g_b2"])
+            dz2 = ops.ln_bwd(dy, z2, m2, r2, lw["ln2_g"], lw["g_ln2_g"], lw["g_ln2_b"], dx2=dz2d, pre_drop=d_h2, deferred=lnd)
             if dz2d is None:
                 dz2d = dz2
             du = ops.gemm_nt(dz2d, lw["W2T"], gelu_bwd_u=u)
             dy1 = ops.gemm_nt(du, lw["W1T"], resid=dz2)
             # --- attention sublayer: y1 = LN(dropout(ctx.Wo^T + bo) + x)
             dz1d = torch.empty_like(dy) if d_h1[1] else None
-            dz1 = ops.ln_bwd(dy1, z1, m1, r1, lw["ln1_g"], lw["g_ln1_g"], lw["g_ln1_b"], dx2=dz1d, pre_drop=d_h1, dbias2=lw["g_bo"])
+            dz1 = ops.ln_bwd(dy1, z1, m1, r1, lw["ln1_g"], lw["g_ln1_g"], lw["g_ln1_b"], dx2=dz1d, pre_drop=d_h1, deferred=lnd)
             if dz1d is None:
                 dz1d = dz1
             dctx = ops.gemm_nt(dz1d, lw["WoT"])
@@ -308,8 +313,8 @@ class _EncoderFn(torch.autograd.Function):
             dy = ops.gemm_nt(dqkv, lw["WqkvT"], resid=dz1)
             # --- all four weight gradients (+ b1, bqkv gradients on the ones-operand MFMA) of the layer in ONE launch.
             # They are off the critical path of backward; model.overlap_wgrad = True moves them to a side stream (measured: a loss).
-            probs = [(du, y1, lw["g_W1"], lw["g_b1"]), (dz2d, g, lw["g_W2"], None),
-                     (dqkv, x, lw["g_Wqkv"], lw["g_bqkv"]), (dz1d, actx, lw["g_Wo"], None)]
+            probs = [(du, y1, lw["g_W1"], lw["g_b1"]), (dz2d, g, lw["g_W2"], lw["g_b2"]),
+                     (dqkv, x, lw["g_Wqkv"], lw["g_bqkv"]), (dz1d, actx, lw["g_Wo"], lw["g_bo"])]
             side = top._wgrad_stream()
             if side is None:
                 ops.gemm_tn_grouped(probs)
@@ -322,7 +327,10 @@ class _EncoderFn(torch.autograd.Function):
                     t.record_stream(side)                  # the caching allocator must not hand these out while the side stream reads them
                 if top.grad_hook is not None:
                     main.wait_stream(side)                 # DP: the layer's gradient slice is final only after its wgrad
+            if top.grad_hook is not None:
+                lnd.flush()                                # ... and after its LayerNorm sums
             top._layer_grads_done(i)
+        lnd.flush()
         side = top._wgrad_stream()
         if side is not None:
             torch.cuda.current_stream().wait_stream(side)     # optimizer / all-reduce tail see complete gradients
@@ -359,14 +367,14 @@ class _EncoderFn(torch.autograd.Function):
         dy_c = sel(dy)
         dz2d_c = torch.empty_like(dy_c) if d_h2[1] else None
         dz2_c = ops.ln_bwd(dy_c, z2, sel(m2), sel(r2), lw["ln2_g"], lw["g_ln2_g"], lw["g_ln2_b"], x_rows=R32, dx2=dz2d_c, pre_drop=d_h2,
-                           dbias2=lw["g_b2"], drop_rows=R32)
+                           drop_rows=R32)
         if dz2d_c is None:
             dz2d_c = dz2_c
         du_c = ops.gemm_nt(dz2d_c, lw["W2T"], gelu_bwd_u=sel(u))
         dy1_c = ops.gemm_nt(du_c, lw["W1T"], resid=dz2_c)
         dz1d_c = torch.empty_like(dy_c) if d_h1[1] else None
         dz1_c = ops.ln_bwd(dy1_c, z1, sel(m1), sel(r1), lw["ln1_g"], lw["g_ln1_g"], lw["g_ln1_b"], x_rows=R32, dx2=dz1d_c, pre_drop=d_h1,
-                           dbias2=lw["g_bo"], drop_rows=R32)
+                           drop_rows=R32)
         if dz1d_c is None:
             dz1d_c = dz1_c
         dctx = torch.zeros((ra, H), device=dy.device, dtype=torch.bfloat16)
@@ -375,7 +383,8 @@ class _EncoderFn(torch.autograd.Function):
         dz1 = torch.zeros((ra, H), device=dy.device, dtype=torch.bfloat16)
         dz1.index_copy_(0, R, dz1_c)
         out = ops.gemm_nt(dqkv, lw["WqkvT"], resid=dz1)
-        ops.gemm_tn_grouped([(du_c, sel(y1), lw["g_W1"], lw["g_b1"]), (dz2d_c, sel(g), lw["g_W2"], None), (dz1d_c, sel(actx), lw["g_Wo"], None)])
+        # (bias gradients b1 / b2 / bo: column sums of the bf16 gradients on the ones-operand MFMA, as in the dense layers)
+        ops.gemm_tn_grouped([(du_c, sel(y1), lw["g_W1"], lw["g_b1"]), (dz2d_c, sel(g), lw["g_W2"], lw["g_b2"]), (dz1d_c, sel(actx), lw["g_Wo"], lw["g_bo"])])
         ops.gemm_tn_grouped([(dqkv, x, lw["g_Wqkv"], lw["g_bqkv"])])
         return out
 

@@ -200,7 +200,9 @@ def ln_fwd(x, gamma, beta, eps, *, M=None, out=None, in_rows=None, out_rows=None
 
 
 def ln_bwd(dy, x, mean, rstd, gamma, dgamma, dbeta, *, M=None, dx=None, dx2=None, dy_rows=None, x_rows=None, dx_rows=None,
-           post_drop: Drop = None, pre_drop: Drop = None, dbias2=None, drop_rows=None):
+           post_drop: Drop = None, pre_drop: Drop = None, dbias2=None, drop_rows=None, deferred: "LnDeferred" = None):
+    """``deferred``: an LnDeferred collector -- the gamma / beta (/ bias) partial sums of this call stay in a workspace slice of
+    the collector and are folded into the gradients by ITS one reduce launch (``deferred.flush()``) instead of one per call."""
     lib = _lib.load()
     H = x.shape[1]
     if M is None:
@@ -208,12 +210,45 @@ def ln_bwd(dy, x, mean, rstd, gamma, dgamma, dbeta, *, M=None, dx=None, dx2=None
     if dx is None:
         dx = torch.empty((M, H), device=x.device, dtype=torch.bfloat16)
     po, pr = post_drop or NO_DROP, pre_drop or NO_DROP
-    ws = _ws_f32(lib.mmbert_ln_bwd_workspace(M, H), x.device)
+    if deferred is not None:
+        ws_ptr = deferred.slot(M, H, x.device, dgamma, dbeta, dbias2)
+    else:
+        ws_ptr = _ws_f32(lib.mmbert_ln_bwd_workspace(M, H), x.device).data_ptr()
     _lib.check(lib.mmbert_ln_bwd(_stream(), dy.data_ptr(), dy.stride(0), _ptr(dy_rows), x.data_ptr(), x.stride(0), _ptr(x_rows),
                                  mean.data_ptr(), rstd.data_ptr(), gamma.data_ptr(), M, H,
                                  dx.data_ptr(), dx.stride(0), _ptr(dx_rows), _ptr(dx2), dx2.stride(0) if dx2 is not None else 0,
-                                 _ptr(dgamma), _ptr(dbeta), _ptr(dbias2), po[0], po[1], po[2], pr[0], pr[1], pr[2], ws.data_ptr(), _ptr(drop_rows)), "mmbert_ln_bwd")
+                                 _ptr(dgamma), _ptr(dbeta), _ptr(dbias2), po[0], po[1], po[2], pr[0], pr[1], pr[2], ws_ptr, _ptr(drop_rows),
+                                 1 if deferred is not None else 0), "mmbert_ln_bwd")
     return dx
+
+
+class LnDeferred:
+    """Collects the partial-sum workspaces of several ``ln_bwd(..., deferred=self)`` calls that share M and H (an encoder's 2 per
+    layer) and folds them into their gradients with ONE ``mmbert_ln_bwd_reduce`` launch per 32 calls: ``flush()``."""
+
+    def __init__(self):
+        self.items, self.key, self.ws, self.used = [], None, None, 0
+
+    def slot(self, M, H, device, dgamma, dbeta, dbias2) -> int:
+        key = (M, H)
+        if self.key is not None and (key != self.key or len(self.items) == 32):
+            self.flush()
+        self.key = key
+        per = _lib.load().mmbert_ln_bwd_workspace(M, H)
+        if self.ws is None or self.ws.numel() < 32 * per or self.ws.device != device:
+            self.ws = torch.empty(32 * per, device=device, dtype=torch.float32)
+        ptr = self.ws.data_ptr() + 4 * per * len(self.items)
+        self.items.append((ptr, dgamma.data_ptr(), dbeta.data_ptr(), dbias2.data_ptr() if dbias2 is not None else None))
+        return ptr
+
+    def flush(self):
+        n = len(self.items)
+        if n:
+            M, H = self.key
+            PA = ctypes.c_void_p * n
+            cols = list(zip(*self.items))
+            _lib.check(_lib.load().mmbert_ln_bwd_reduce(_stream(), n, PA(*cols[0]), PA(*cols[1]), PA(*cols[2]), PA(*cols[3]), M, H), "mmbert_ln_bwd_reduce")
+        self.items, self.key = [], None
 
 
 def embed_gather(ids, tts, word, type_, pos, T, out=None):

@@ -94,7 +94,10 @@ def check_against_oracle(cfg, B, T, Pv, Pa, seed, loss_tol=3e-3):
         dev_emul = float((pe[n].grad - og).norm() / og.norm())
         # 4.5 % relative error == cosine 0.999; ill-conditioned head gradients (CPC, pooler, gates at
         # init) are allowed 3x what bf16 storage alone does to the ORACLE's gradient
-        assert dev < max(0.045, 3.0 * dev_emul), (n, dev, dev_emul)
+        # ... and a gradient whose norm is three orders below the other head gradients (the CPC biases at initialisation: ~5e-5
+        # against 0.4-1.3, see DESIGN numerics) is noise at bf16 precision on BOTH sides (the emulated oracle itself moves it by
+        # 30-55 %): bounded absolutely, 2e-4
+        assert dev < max(0.045, 3.0 * dev_emul) or float((g - og).norm()) < 2e-4, (n, dev, dev_emul, float(og.norm()))
         if dev > 0.045:
             loose.append((n, round(dev, 3), round(dev_emul, 3)))
         cos = float(torch.nn.functional.cosine_similarity(g.reshape(1, -1), og.reshape(1, -1)))
@@ -518,8 +521,12 @@ def test_bert_base_12_layers_match_oracle():
     the oracle itself run with bf16 storage (oracle.bf16_storage_emulation: fp32 arithmetic, activations / GEMM weights rounded
     where the HIP path stores bf16) -- stated, L = 12:
       losses 4e-3 relative; regression logits 3e-2 abs; prediction scores 8e-2 abs (max over 1.1e8 values) and 8e-3 mean abs;
-      per-parameter gradient: relative L2 error <= max(6 %, 3 x the emulated oracle's own deviation), cosine >= 0.995.
-    The measured numbers (ours and the emulated oracle's) are written to gpurun_out/parity_L12.json."""
+      per-parameter gradient: relative L2 error <= max(6 %, 2 x the emulated oracle's own deviation) (or 2e-4 absolute for
+      gradients of norm < 1e-3: the CPC biases), encoder-side cosine >= 0.995.
+    Measured (round 2, gpurun_out/parity_L12.json -> profiles/r2_parity_L12.json): losses 5e-5 / 5e-5 / 5e-6 / 1e-7 (emulated oracle:
+    4e-5 / 2e-3 / 5e-4 / 1e-5); scores 0.034-0.044 max, 0.0052-0.0057 mean (emulated: 0.036-0.044 / 0.0054-0.0059); encoder-side
+    gradients median 4.5 % / max 8.7 % (emulated: 3.9 % / 7.5 %), cosine >= 0.9962; [B,H] head gradients at batch 2: 17-26 %
+    (emulated: 18-55 %) -- the HIP path deviates from the fp32 oracle by what bf16 storage alone does to the oracle."""
     cfg = BASE12
     batch = synthetic_batch(2, 50, 500, 500, dataset=cfg["dataset"], vocab=cfg["vocab"], seed=5)
     p, oout, ologits = oracle_run(cfg, batch)
@@ -558,7 +565,7 @@ def test_bert_base_12_layers_match_oracle():
         dev_emul = float((pe[n].grad - og).norm() / og.norm())
         cos = float(torch.nn.functional.cosine_similarity(g.reshape(1, -1), og.reshape(1, -1)))
         rep["grads"][n] = dict(rel_err=dev, emulated_oracle_rel_err=dev_emul, cosine=cos)
-        assert dev < max(0.06, 3.0 * dev_emul), (n, dev, dev_emul)
+        assert dev < max(0.06, 2.0 * dev_emul) or float((g - og).norm()) < 2e-4, (n, dev, dev_emul, float(og.norm()))
         encoder_like = n.startswith(("bert.embeddings", "bert.encoder", "bert.jointEmbeddings", "cls.predictions"))
         if encoder_like:
             assert cos > 0.995, (n, cos)

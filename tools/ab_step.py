@@ -1,0 +1,65 @@
+#!/usr/bin/env python3
+"""Same-process, interleaved A/B of the headline train step under environment toggles (box-to-box clocks differ by 5-10 %, so only
+ratios measured in one process count).
+
+    python tools/ab_step.py base: legacy:MMBERT_LN_DEFER=0            # each variant = name:ENV=VAL[,ENV=VAL...]
+
+Only toggles that are read per call take effect (python-side os.environ reads, or C getenv per call)."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from msa_amd.data import synthetic_batch, batch_to
+from msa_amd.model import MMBertConfig, MMBertForPretraining
+from msa_amd.trainer import build_optimizer, default_args
+
+variants = []
+for a in sys.argv[1:]:
+    name, _, envs = a.partition(":")
+    variants.append((name, dict(e.split("=", 1) for e in envs.split(",") if e)))
+steps, rounds = int(os.environ.get("STEPS", 8)), int(os.environ.get("ROUNDS", 5))
+dev = torch.device("cuda", 0)
+torch.manual_seed(0)
+model = MMBertForPretraining(MMBertConfig())
+model.bert.set_joint_embeddings("mosei")
+model.to(dev).train()
+model.manual_seed(1234)
+opt, sched = build_optimizer(model, default_args(train_batch_size=16, learning_rate=5e-5), 1000)
+pool = [batch_to(synthetic_batch(16, 50, 500, 500, seed=1 + i), dev) for i in range(4)]
+all_keys = {k for _, env in variants for k in env}
+
+
+def step(i):
+    out, _ = model(**pool[i % 4])
+    out[0].mean().backward()
+    opt.step(); sched.step(); opt.zero_grad()
+
+
+def setenv(env):
+    for k in all_keys:
+        os.environ.pop(k, None)
+    os.environ.update(env)
+    for k, v in env.items():
+        if k.startswith("attr."):                      # model attribute toggles: attr.NAME=python-literal
+            setattr(model, k[5:], eval(v))
+
+
+ts = {n: [] for n, _ in variants}
+for n, env in variants:
+    setenv(env)
+    for i in range(3):
+        step(i)
+torch.cuda.synchronize()
+for r in range(rounds):
+    for n, env in variants:
+        setenv(env)
+        step(0)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            step(i)
+        torch.cuda.synchronize()
+        ts[n].append((time.perf_counter() - t0) / steps * 1e3)
+base = sorted(ts[variants[0][0]])[rounds // 2]
+for n, _ in variants:
+    t = sorted(ts[n])
+    print(f"{n:24s} median {t[rounds // 2]:7.3f} ms/step  (min {t[0]:.3f} max {t[-1]:.3f})  {16 / t[rounds // 2] * 1e3:7.1f} samples/s   x{t[rounds // 2] / base:.4f}", flush=True)
