@@ -167,6 +167,23 @@ int mmbert_ce_bwd(mmbert_stream_t stream, const void* logits, int ldv, int V, co
 int mmbert_split_rows(mmbert_stream_t stream, const int64_t* row_seq, const int64_t* row_pos, const int* start_a, const int* start_b,
                       const int* valid, int mode, int M, int rows_a, int64_t* perm, int64_t* inv);
 
+/* Step prologue (two launches): from the caller's attention masks and MLM labels to what the encoder's launches need.
+ * Sequences: npass passes x B samples, pass p has pass_len[p] positions per sequence; packed rows pass-major, then sample, then
+ * position (the order of the token matrix).  Mask segment q (host arrays of nseg <= 12 entries) covers positions
+ * [seg_offset, seg_offset + seg_len) of every sequence of pass seg_pass; its element (b, pos) is at
+ * seg_ptr + b * seg_stride_b + pos * seg_stride_p BYTES, dtype code 0 f32 / 1 f64 / 2 i64 / 3 i32 / 4 bf16 / 5 u8 / 6 f16
+ * (REF:model_utils.py:118-136 hands over float64 and int64 masks; joint passes use feature 0 of the [B,P,D] pair mask,
+ * REF:MMBertForPretraining.py:76: pass the tensor's own strides).  labels: int64 per packed row, -100 = none (may be NULL).
+ * Outputs (device): key_bias in the padded layout mmbert_attn_fwd reads ((1 - mask) * -10000 per key; ceil128(len) slots per
+ * sequence, the padding <= -1e30); kv_len[s] (mmbert_attn_kv_len's rule); valid[s] = max(kv_len[s], last labelled position + 1);
+ * idx = the rows with a label in [0, vocab), ascending (mmbert_active_rows' list; room for every row); seq_cnt: 3 * nseq ints of
+ * scratch; words = [valid[0..nseq), #labelled rows, #labelled position-0 rows, #labels that are neither -100 nor in [0, vocab)]
+ * -- nseq + 3 ints, contiguous for one device->host copy. */
+int mmbert_prologue(mmbert_stream_t stream, int nseg, const void* const* seg_ptr, const long long* seg_stride_b, const long long* seg_stride_p,
+                    const int* seg_dtype, const int* seg_pass, const int* seg_offset, const int* seg_len,
+                    int npass, const int* pass_len, int B, const int64_t* labels, int vocab,
+                    float* key_bias, int* kv_len, int* valid, int* seq_cnt, int* idx, int* words);
+
 /* idx[0..count) = the rows with a label in [0, V), ascending; every other row of the CE gradient is exactly zero (ignore_index),
  * so the head's backward may run on this list alone.  idx has room for M entries; count is one int on the device. */
 int mmbert_active_rows(mmbert_stream_t stream, const int64_t* labels, int M, int V, int* idx, int* count);

@@ -656,6 +656,125 @@ __global__ void mlm_mask_kernel(int64_t* __restrict__ ids, int64_t* __restrict__
     }
 }
 
+
+// --------------------------------------------------------------------------------------------
+// Step prologue: from the caller's attention masks and MLM labels to everything the encoder's launches need, in TWO launches
+// (round 1 spent ~45 element-wise torch launches and two device->host copies on this: 0.8 ms of a 17.5 ms step).
+//   A (one workgroup per sequence): the padded additive key bias (REF:MMBertForPretraining.py:57-154: (1 - mask) * -10000 per key,
+//     -1e30 in the padding slots), kv_len (keys behind it are all masked out: attn_kv_len_kernel's rule), valid = max(kv_len, last
+//     labelled position + 1) (the rows backward must visit: model._split_layout), and per-sequence label counts;
+//   B (one workgroup per sequence): the ascending list of labelled rows (mmbert_active_rows' output) and the host words
+//     [valid[0..nseq), #labelled rows, #labelled first rows, #labels outside {-100} u [0, V)] -- ONE device->host copy.
+// A mask segment = positions [offset, offset + len) of every sequence of one pass, element (b, p) at ptr + b*sb + p*sp bytes, any of
+// the dtypes the reference's collate produces (float64 / int64) or torch hands over.
+// --------------------------------------------------------------------------------------------
+struct MaskSeg { const char* ptr; long long sb, sp; int dtype, pass, offset, len; };
+#define PRO_MAXSEG 12
+#define PRO_MAXPASS 4
+struct PrologueArgs {
+    MaskSeg seg[PRO_MAXSEG];
+    int nseg, npass, B, vocab;
+    int pass_len[PRO_MAXPASS], pass_row0[PRO_MAXPASS], pass_bias0[PRO_MAXPASS];
+    const int64_t* labels;
+    float* key_bias; int* kv_len; int* valid; int* seq_cnt;      // seq_cnt: [3][nseq] labelled rows / labelled first row / bad labels
+    int* idx; int* words;
+};
+
+__device__ __forceinline__ float mask_value(const MaskSeg& g, int b, int p) {
+    const char* a = g.ptr + (long long)b * g.sb + (long long)p * g.sp;
+    switch (g.dtype) {
+        case 0: return *(const float*)a;
+        case 1: return (float)*(const double*)a;
+        case 2: return (float)*(const int64_t*)a;
+        case 3: return (float)*(const int*)a;
+        case 4: return bf2f(*(const bf16_t*)a);
+        case 5: return (float)*(const uint8_t*)a;
+        default: return (float)*(const _Float16*)a;
+    }
+}
+
+__global__ __launch_bounds__(256) void prologue_seq_kernel(const PrologueArgs a) {
+    __shared__ int red[4][5];
+    const int s = blockIdx.x, p = s / a.B, b = s - p * a.B;
+    const int S = a.pass_len[p], row0 = a.pass_row0[p] + b * S;
+    const int slots = (S + 127) & ~127;
+    float* kb = a.key_bias + a.pass_bias0[p] + b * slots;
+    int last_key = -1, last_lab = -1, cnt = 0, first = 0, bad = 0;
+    for (int pos = threadIdx.x; pos < slots; pos += 256) {
+        float bias = -1.0e30f;
+        if (pos < S) {
+            float m = 1.0f;
+            for (int q = 0; q < a.nseg; ++q) {
+                const MaskSeg& g = a.seg[q];
+                if (g.pass == p && pos >= g.offset && pos < g.offset + g.len) { m = mask_value(g, b, pos - g.offset); break; }
+            }
+            bias = (1.0f - m) * -10000.0f;
+            if (bias > -10000.0f) last_key = pos;
+            if (a.labels) {
+                const int64_t lab = a.labels[row0 + pos];
+                if (lab != -100) {
+                    last_lab = pos;
+                    if (lab >= 0 && lab < a.vocab) { ++cnt; if (pos == 0) first = 1; } else ++bad;
+                }
+            }
+        }
+        kb[pos] = bias;
+    }
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        last_key = max(last_key, __shfl_xor(last_key, o, 64)); last_lab = max(last_lab, __shfl_xor(last_lab, o, 64));
+        cnt += __shfl_xor(cnt, o, 64); first += __shfl_xor(first, o, 64); bad += __shfl_xor(bad, o, 64);
+    }
+    if (lane == 0) { red[w][0] = last_key; red[w][1] = last_lab; red[w][2] = cnt; red[w][3] = first; red[w][4] = bad; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int nseq = a.npass * a.B;
+        int lk = -1, ll = -1, c = 0, f = 0, bd = 0;
+        for (int q = 0; q < 4; ++q) { lk = max(lk, red[q][0]); ll = max(ll, red[q][1]); c += red[q][2]; f += red[q][3]; bd += red[q][4]; }
+        const int kv = lk < 0 ? S : lk + 1;                     // no unmasked key at all: the sequence keeps its full length
+        a.kv_len[s] = kv;
+        a.valid[s] = max(kv, ll + 1);
+        a.seq_cnt[s] = c; a.seq_cnt[nseq + s] = f; a.seq_cnt[2 * nseq + s] = bd;
+    }
+}
+
+__global__ __launch_bounds__(256) void prologue_rows_kernel(const PrologueArgs a) {
+    __shared__ int wsum[4];
+    __shared__ int base_s;
+    const int s = blockIdx.x, p = s / a.B, b = s - p * a.B, nseq = a.npass * a.B;
+    const int S = a.pass_len[p], row0 = a.pass_row0[p] + b * S;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    if (tid == 0) {
+        int off = 0;
+        for (int q = 0; q < s; ++q) off += a.seq_cnt[q];
+        base_s = off;
+        a.words[s] = a.valid[s];
+        if (s == 0) {
+            int t0 = 0, t1 = 0, t2 = 0;
+            for (int q = 0; q < nseq; ++q) { t0 += a.seq_cnt[q]; t1 += a.seq_cnt[nseq + q]; t2 += a.seq_cnt[2 * nseq + q]; }
+            a.words[nseq] = t0; a.words[nseq + 1] = t1; a.words[nseq + 2] = t2;
+        }
+    }
+    __syncthreads();
+    if (!a.labels || a.seq_cnt[s] == 0) return;
+    int base = base_s;
+    for (int p0 = 0; p0 < S; p0 += 256) {
+        const int pos = p0 + tid;
+        bool act = false;
+        if (pos < S) { const int64_t lab = a.labels[row0 + pos]; act = lab >= 0 && lab < a.vocab; }
+        const unsigned long long bal = __ballot(act);
+        const int before = __popcll(bal & ((1ull << lane) - 1ull));
+        __syncthreads();
+        if (lane == 0) wsum[w] = __popcll(bal);
+        __syncthreads();
+        int off = base;
+        for (int q = 0; q < w; ++q) off += wsum[q];
+        if (act) a.idx[off + before] = row0 + pos;
+        base += wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    }
+}
+
 static inline int grid_for(size_t work_items, int per_block, int cap = 2048) {
     size_t b = (work_items + per_block - 1) / per_block;
     if (b < 1) b = 1;
@@ -824,6 +943,32 @@ int mmbert_split_rows(hipStream_t stream, const int64_t* row_seq, const int64_t*
     if (M <= 0) return 0;
     if (mode < 0 || mode > 2) return -1;
     hipLaunchKernelGGL(split_rows_kernel, dim3((M + 255) / 256), dim3(256), 0, stream, row_seq, row_pos, start_a, start_b, valid, mode, M, rows_a, perm, inv);
+    MMB_CHECK_LAUNCH();
+    return 0;
+}
+
+int mmbert_prologue(hipStream_t stream, int nseg, const void* const* seg_ptr, const long long* seg_stride_b, const long long* seg_stride_p,
+                    const int* seg_dtype, const int* seg_pass, const int* seg_offset, const int* seg_len,
+                    int npass, const int* pass_len, int B, const int64_t* labels, int vocab,
+                    float* key_bias, int* kv_len, int* valid, int* seq_cnt, int* idx, int* words) {
+    if (npass <= 0 || B <= 0) return 0;
+    if (nseg < 0 || nseg > PRO_MAXSEG || npass > PRO_MAXPASS) return -1;
+    PrologueArgs a = {};
+    for (int q = 0; q < nseg; ++q) {
+        if (seg_dtype[q] < 0 || seg_dtype[q] > 6 || seg_pass[q] < 0 || seg_pass[q] >= npass) return -1;
+        a.seg[q].ptr = (const char*)seg_ptr[q]; a.seg[q].sb = seg_stride_b[q]; a.seg[q].sp = seg_stride_p[q];
+        a.seg[q].dtype = seg_dtype[q]; a.seg[q].pass = seg_pass[q]; a.seg[q].offset = seg_offset[q]; a.seg[q].len = seg_len[q];
+    }
+    int row = 0, slot = 0;
+    for (int p = 0; p < npass; ++p) {
+        a.pass_len[p] = pass_len[p]; a.pass_row0[p] = row; a.pass_bias0[p] = slot;
+        row += B * pass_len[p]; slot += B * ((pass_len[p] + 127) & ~127);
+    }
+    a.nseg = nseg; a.npass = npass; a.B = B; a.vocab = vocab; a.labels = labels;
+    a.key_bias = key_bias; a.kv_len = kv_len; a.valid = valid; a.seq_cnt = seq_cnt; a.idx = idx; a.words = words;
+    hipLaunchKernelGGL(prologue_seq_kernel, dim3(npass * B), dim3(256), 0, stream, a);
+    MMB_CHECK_LAUNCH();
+    hipLaunchKernelGGL(prologue_rows_kernel, dim3(npass * B), dim3(256), 0, stream, a);
     MMB_CHECK_LAUNCH();
     return 0;
 }

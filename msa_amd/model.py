@@ -676,19 +676,19 @@ class _GpuModelBase(nn.Module):
         return pl
 
     @staticmethod
-    def _key_bias(mask, joint_pair: bool, device):
-        """REF:MMBertForPretraining.py:57-154: 2-D masks as is; 3-D joint masks -> feature 0."""
+    def _mask2d(mask, joint_pair: bool, dev):
+        """The [B, positions] mask whose (1 - m) * -10000 is the key bias (REF:MMBertForPretraining.py:57-154): 2-D masks as they
+        are; 3-D joint masks -> feature 0 (a strided VIEW, :76); 3-D non-joint masks -> the mean over features (:111)."""
+        mask = mask.to(dev)
         if mask.dim() == 3:
-            m = torch.narrow(mask, 2, 0, 1).squeeze(-1) if joint_pair else mask.float().mean(2)
-        elif mask.dim() == 2:
-            m = mask
-        else:
+            return mask[:, :, 0] if joint_pair else mask.float().mean(2)
+        if mask.dim() != 2:
             raise ValueError("You have so large dimension (), Check dimension or shape ")
-        return (1.0 - m.to(device=device, dtype=torch.float32)) * MASK_NEG
+        return mask
 
-    def _encode(self, passes, labels=None, rows=None):
+    def _encode(self, passes, labels=None, want_rows=False):
         """passes: list of dict(ids[B,T], tt[B,T]|None, mask, pair[B,P,D]|None, pair_mask|None).
-        Returns (Y [tokens,H] bf16, plan, lens_per_pass)."""
+        Returns (Y [tokens,H] bf16, plan, lens_per_pass, rows) -- ``rows`` = (labelled-row list, host words, event) when asked for."""
         bert = self._bert()
         dev = passes[0]["ids"].device
         self._ensure_ready(dev)
@@ -698,29 +698,44 @@ class _GpuModelBase(nn.Module):
             raise ValueError("text length exceeds max_position_embeddings")
         seed = self._next_seed()
         je = bert.jointEmbeddings
-        # ---- masks first: key bias, per-sequence unmasked lengths, and the request for those lengths on the host (an async
-        # copy; the embedding kernels below keep the GPU busy while it travels and the host packs the layout)
-        kbs, lens, pair_info = [], [], []
-        for p in passes:
-            kb = self._key_bias(p["mask"], False, dev)
+        # ---- masks and labels first: ONE prologue call (two launches) gives the padded key bias, the per-sequence unmasked
+        # lengths, the rows backward must visit and the labelled-row list, and starts the one device -> host copy of the step
+        # (the embedding kernels below keep the GPU busy while it travels and the host packs the layout)
+        segs, lens, pair_info = [], [], []
+        for k, p in enumerate(passes):
+            segs.append((self._mask2d(p["mask"], False, dev), k, 0))
             if p.get("pair") is not None:
                 pairs = p["pair"] if isinstance(p["pair"], (tuple, list)) else (p["pair"],)
                 pmasks = p["pair_mask"] if isinstance(p["pair_mask"], (tuple, list)) else (p["pair_mask"],)
-                kb = torch.cat((kb, *(self._key_bias(pm.to(dev), True, dev) for pm in pmasks)), dim=-1)
-                lens.append(T + sum(f.shape[1] for f in pairs))
+                off = T
+                for f, pm in zip(pairs, pmasks):
+                    segs.append((self._mask2d(pm, True, dev), k, off))
+                    off += f.shape[1]
+                lens.append(off)
                 pair_info.append((pairs, tuple(je.which(f) for f in pairs)))
             else:
                 lens.append(T)
                 pair_info.append(None)
-            kbs.append(kb.reshape(-1))
-        key_bias = torch.cat(kbs) if len(kbs) > 1 else kbs[0]
         plan = self._plan(lens, B, dev)
-        key_bias = ops.pad_key_bias(key_bias, plan["layout"])        # per-sequence padded layout, -1e30 = "no such key"
+        pro = ops.prologue(segs, lens, B, labels, cfg.vocab_size, dev)
+        key_bias = pro.key_bias                                       # per-sequence padded layout, -1e30 = "no such key"
+        nseq = pro.nseq
+        host = torch.empty(nseq + 3, dtype=torch.int32, pin_memory=True)
+        host.copy_(pro.words, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        rows = (pro.idx, host[nseq:], ev) if want_rows else None
         # padded pair rows are masked-out keys at the tail of every joint sequence: the attention kernels skip them (exact)
-        kv_len = ops.attn_kv_len(key_bias, plan["layout"]) if getattr(self, "skip_masked_keys", True) else None
+        kv_len = pro.kv_len if getattr(self, "skip_masked_keys", True) else None
         # inference (no dropout, no autograd): the masked-out rows of a sequence are identical in every layer -> one stands for all
         infer = (not self.training) and (not torch.is_grad_enabled()) and getattr(self, "dedupe_masked_rows", True)
-        pending = self._request_lengths(plan, kv_len, labels, infer, (pair_info, B, T)) if kv_len is not None else None
+        self.last_backward_row_fraction = 1.0                            # (bookkeeping for bench.py: share of rows backward visits)
+        pending = None
+        if kv_len is not None:
+            if infer:
+                pending = self._request_lengths(plan, kv_len, labels, True, (pair_info, B, T))
+            elif labels is not None and torch.is_grad_enabled() and getattr(self, "skip_padded_backward", True):
+                pending = (host[:nseq], None, ev)                     # the prologue's valid[]: unmasked length, extended to the last label
         # ---- embeddings
         ids = torch.cat([p["ids"].reshape(-1).long() for p in passes])
         tts = torch.cat([(p["tt"].reshape(-1).long() if p.get("tt") is not None else torch.zeros(B * T, dtype=torch.long, device=dev)) for p in passes])
@@ -761,51 +776,35 @@ class _GpuModelBase(nn.Module):
                 pad = getattr(split, "dropped", False)
                 packed = [(torch.cat((t, t.new_zeros((1, t.shape[1])))) if pad else t).index_select(0, split.inv) for t in packed]
             self.debug_hidden["layers"] = packed
-        return y, plan, lens
+        return y, plan, lens, rows
 
     def _request_lengths(self, plan, kv_len, labels, infer=False, pairs=None):
-        """Starts the device -> host copy of the per-sequence count of leading rows that backward must visit (= the unmasked length,
-        extended to the sequence's last labelled row) plus one flag word; None when the valid-first packing cannot apply (no labels
-        given -- the caller may then put a gradient anywhere --, no grad, switched off).
-        ``infer``: the lengths alone (inference needs no labels: nothing is differentiated); the flag counts masked-out pair rows
-        with a non-zero feature (they may not share a representative)."""
-        self.last_backward_row_fraction = 1.0                            # (bookkeeping for bench.py: share of rows backward visits)
-        if infer:
-            # rows may share one representative only if their INPUTS are equal: that holds for masked-out PAIR rows whose features
-            # are all zero (no position embedding on pair rows) -- not for [PAD] text rows (positions differ), so text-only
-            # sequences keep every row and joint sequences keep at least their T text rows; a masked-out pair row with a
-            # non-zero feature anywhere switches the short cut off
-            pair_info, B, T = pairs
-            keep, bad = [], torch.zeros((), dtype=torch.int64, device=kv_len.device)
-            for k, info in enumerate(pair_info):
-                kv = kv_len[k * B:(k + 1) * B]
-                if info is None:
-                    keep.append(torch.full_like(kv, T))
-                    continue
-                kv = kv.clamp(min=T)
-                keep.append(kv)
-                off = T
-                for f in info[0]:
-                    pos = off + torch.arange(f.shape[1], device=kv.device)[None, :]
-                    bad = bad + ((pos >= kv[:, None].long()) & (f.to(kv.device) != 0).any(-1)).sum()
-                    off += f.shape[1]
-            kv_len = torch.cat(keep)
-            bad = bad.to(torch.int32).view(1)
-        elif labels is None or not torch.is_grad_enabled() or not getattr(self, "skip_padded_backward", True):
-            return None
-        else:
-            # a label on a row behind the last unmasked key (the reference's mask_tokens selects [PAD] positions too; trainer.py
-            # copies the text labels onto the pair positions): that row is a QUERY with a gradient, so its sequence keeps every
-            # row up to its last labelled one in region A -- the masked-out keys among them have probability exactly 0, as before
-            lab_end = torch.zeros(kv_len.numel(), dtype=torch.int64, device=kv_len.device)
-            lab_end.scatter_reduce_(0, plan["row_seq"], torch.where(labels != -100, plan["row_pos"] + 1, 0), "amax", include_self=True)
-            kv_len = torch.maximum(kv_len, lab_end.to(torch.int32))
-            bad = torch.zeros(1, dtype=torch.int32, device=kv_len.device)
+        """Inference only (training takes the prologue's ``valid`` words): starts the device -> host copy of the per-sequence count
+        of leading rows that keep a row of their own, plus one flag word.  Rows may share one representative only if their INPUTS
+        are equal: that holds for masked-out PAIR rows whose features are all zero (no position embedding on pair rows) -- not for
+        [PAD] text rows (positions differ), so text-only sequences keep every row and joint sequences keep at least their T text
+        rows; the flag counts masked-out pair rows with a non-zero feature (they switch the short cut off)."""
+        assert infer
+        pair_info, B, T = pairs
+        keep, bad = [], torch.zeros((), dtype=torch.int64, device=kv_len.device)
+        for k, info in enumerate(pair_info):
+            kv = kv_len[k * B:(k + 1) * B]
+            if info is None:
+                keep.append(torch.full_like(kv, T))
+                continue
+            kv = kv.clamp(min=T)
+            keep.append(kv)
+            off = T
+            for f in info[0]:
+                pos = off + torch.arange(f.shape[1], device=kv.device)[None, :]
+                bad = bad + ((pos >= kv[:, None].long()) & (f.to(kv.device) != 0).any(-1)).sum()
+                off += f.shape[1]
+        kv_len = torch.cat(keep)
         host = torch.empty(kv_len.numel() + 1, dtype=torch.int32, pin_memory=True)
-        host.copy_(torch.cat((kv_len, bad)), non_blocking=True)
+        host.copy_(torch.cat((kv_len, bad.to(torch.int32).view(1))), non_blocking=True)
         ev = torch.cuda.Event()
         ev.record()
-        return host, ev
+        return host[:-1], host[-1:], ev
 
     def _split_layout(self, plan, kv_len, pending, infer=False, drop=False):
         """Backward on the unmasked rows only.  A row behind its sequence's last unmasked key (a padded pair row; a [PAD] row of
@@ -821,11 +820,11 @@ class _GpuModelBase(nn.Module):
         if pending is None:
             return None
         lay = plan["layout"]
-        host, ev = pending
+        valid_host, flag, ev = pending
         ev.synchronize()
-        if int(host[-1]) != 0:
+        if flag is not None and int(flag[0]) != 0:
             return None
-        valid = host[:-1].numpy().copy()
+        valid = valid_host.numpy().copy()
         if int(valid.sum()) > 0.97 * lay.tokens:
             return None
         if infer:
@@ -882,7 +881,7 @@ class MMBertModel(_GpuModelBase):
             text = input_ids
             tmask = attention_mask if attention_mask is not None else torch.ones(text.shape, device=text.device)
             p = dict(ids=text, tt=token_type_ids, mask=tmask)
-        y, plan, lens = top._encode([p])
+        y, plan, lens, _ = top._encode([p])
         B = text.shape[0]
         seq = y.view(B, lens[0], -1).float()
         pooled = torch.tanh(F.linear(seq[:, 0], self.pooler.dense.weight, self.pooler.dense.bias))     # HF:457-463
@@ -1155,11 +1154,8 @@ class MMBertForPretraining(_GpuModelBase):
         labels = torch.cat((lab_t.reshape(-1), lab_v.reshape(-1), lab_s.reshape(-1))).to(device=dev, dtype=torch.long)
         if labels.numel() != B * (T + (T + visual.shape[1]) + (T + speech.shape[1])):
             raise ValueError("masked_labels must cover text (+ pair) positions of every pass")
-        rows = None
-        if torch.is_grad_enabled() and getattr(self, "sparse_mlm_backward", True) and labels.is_cuda:
-            self._ensure_ready(dev)
-            rows = mlm_active_rows(labels, V, self._plan([T, T + visual.shape[1], T + speech.shape[1]], B, dev)["first"])
-        y, plan, lens = self._encode(passes, labels, rows)
+        want_rows = torch.is_grad_enabled() and getattr(self, "sparse_mlm_backward", True) and labels.is_cuda
+        y, plan, lens, rows = self._encode(passes, labels, want_rows)
         mlm, logits = _MLMHeadFn.apply(y, self.cls.predictions.transform.LayerNorm.weight, self, labels, plan["bounds"], plan["bounds_dev"], self.return_scores, rows)
 
         first = y.index_select(0, plan["first"]).float()                             # [3B, H]: [CLS] rows of every sequence
@@ -1198,11 +1194,8 @@ class MMBertForPretraining(_GpuModelBase):
         labels = masked_labels.reshape(-1).to(device=dev, dtype=torch.long)
         if labels.numel() != B * (T + visual.shape[1] + speech.shape[1]):
             raise ValueError("masked_labels must cover the text and both pair blocks")
-        rows = None
-        if torch.is_grad_enabled() and getattr(self, "sparse_mlm_backward", True) and labels.is_cuda:
-            self._ensure_ready(dev)
-            rows = mlm_active_rows(labels, V, self._plan([T + visual.shape[1] + speech.shape[1]], B, dev)["first"])
-        y, plan, lens = self._encode(passes, labels, rows)
+        want_rows = torch.is_grad_enabled() and getattr(self, "sparse_mlm_backward", True) and labels.is_cuda
+        y, plan, lens, rows = self._encode(passes, labels, want_rows)
         mlm, logits = _MLMHeadFn.apply(y, self.cls.predictions.transform.LayerNorm.weight, self, labels, plan["bounds"], plan["bounds_dev"], self.return_scores, rows)
         first = y.index_select(0, plan["first"].repeat(3)).float()                   # the one [CLS] row in the t / v / s slots
         heads_loss, ap_loss, label_loss, nce, logits_out, _t_rel, v_rel, _s_rel = self._run_heads(first, ap_v, ap_s, sentiment, dev, B)

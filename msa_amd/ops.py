@@ -462,6 +462,45 @@ def pad_key_bias(key_bias, layout: "SeqLayout"):
     return out
 
 
+_MASK_DTYPES = {torch.float32: 0, torch.float64: 1, torch.int64: 2, torch.int32: 3, torch.bfloat16: 4, torch.uint8: 5, torch.bool: 5, torch.float16: 6}
+
+
+class Prologue:
+    """Result of ``prologue()``: padded key bias, kv_len / valid per sequence, the labelled-row list and the host words' device copy."""
+    __slots__ = ("key_bias", "kv_len", "valid", "idx", "words", "nseq")
+
+
+def prologue(segs, pass_lens, B, labels, vocab, device) -> Prologue:
+    """The step prologue in two launches (mmbert_prologue): ``segs`` = [(mask2d [B, len] -- any stride, any mask dtype --, pass index,
+    first position)], ``pass_lens`` = positions per sequence of every pass, ``labels`` = int64 [tokens] in packed order or None."""
+    lib = _lib.load()
+    n, npass = len(segs), len(pass_lens)
+    nseq = npass * B
+    tokens = sum(B * S for S in pass_lens)
+    bias_len = sum(B * ((S + 127) // 128 * 128) for S in pass_lens)
+    out = Prologue()
+    out.nseq = nseq
+    out.key_bias = torch.empty(bias_len, device=device, dtype=torch.float32)
+    ints = torch.empty(2 * nseq + 3 * nseq + max(tokens, 1) + nseq + 3, device=device, dtype=torch.int32)
+    out.kv_len, out.valid = ints[:nseq], ints[nseq:2 * nseq]
+    seq_cnt = ints[2 * nseq:5 * nseq]
+    out.idx = ints[5 * nseq:5 * nseq + max(tokens, 1)]
+    out.words = ints[5 * nseq + max(tokens, 1):]
+    PA, LA, IA = ctypes.c_void_p * max(n, 1), ctypes.c_longlong * max(n, 1), ctypes.c_int * max(n, 1)
+    for m, _, _ in segs:
+        assert m.dim() == 2 and m.shape[0] == B and m.device.type == "cuda" and m.dtype in _MASK_DTYPES, (m.shape, m.dtype, m.device)
+    es = [m.element_size() for m, _, _ in segs]
+    if labels is not None:
+        assert labels.dtype == torch.int64 and labels.is_contiguous() and labels.numel() == tokens
+    _lib.check(lib.mmbert_prologue(_stream(), n, PA(*[m.data_ptr() for m, _, _ in segs]), LA(*[m.stride(0) * e for (m, _, _), e in zip(segs, es)]),
+                                   LA(*[m.stride(1) * e for (m, _, _), e in zip(segs, es)]), IA(*[_MASK_DTYPES[m.dtype] for m, _, _ in segs]),
+                                   IA(*[p for _, p, _ in segs]), IA(*[o for _, _, o in segs]), IA(*[m.shape[1] for m, _, _ in segs]),
+                                   npass, (ctypes.c_int * npass)(*pass_lens), B, _ptr(labels), int(vocab),
+                                   out.key_bias.data_ptr(), out.kv_len.data_ptr(), out.valid.data_ptr(), seq_cnt.data_ptr(), out.idx.data_ptr(),
+                                   out.words.data_ptr()), "mmbert_prologue")
+    return out
+
+
 def attn_kv_len(key_bias_padded, layout: SeqLayout):
     """int32 [sequences]: per sequence the count of leading keys behind which every key is masked out (see
     mmbert_attn_kv_len); pass it to attn_fwd / attn_bwd as ``kv_len`` and they skip those keys (exact)."""
