@@ -205,8 +205,24 @@ int mmbert_heads_loss_fwd(mmbert_stream_t stream, const float* P, const float* X
 int mmbert_heads_scale(mmbert_stream_t stream, float* x, size_t n, const float* s);
 int mmbert_heads_gate_bwd(mmbert_stream_t stream, const float* dC, const float* P, const float* Apre, const float* g, const float* const* vw3, const float* dPc,
                           int B, int H, float* dP, float* dApre, float* E, float* dg);
+int mmbert_heads_tanh(mmbert_stream_t stream, float* x, size_t n);            /* x = tanh(x) in place (the pooler's activation, HF:457-463) */
 int mmbert_heads_tanh_bwd(mmbert_stream_t stream, const float* dP, const float* P, float* dpre, size_t n);
 int mmbert_heads_colsum(mmbert_stream_t stream, int nseg, const float* const* src, float* const* dst, const int* rows, const int* cols, const int* ld);
+
+/* ---- the heads' dense layers: lists of fp32 products with at most 64 rows, one launch per dependency level ----
+ * mmbert_skinny_mm: for every op, Y[M, N] += bias + sum_j X_j . op(W_j) -- the sum is split over workgroups and added with fp32
+ * atomics, so Y must hold zeros (or the value to add to) before the call; `act` must be 0 and `accumulate` is informational
+ * (an activation goes in its own pass: mmbert_heads_tanh).  Source j
+ * contributes to the output rows [row0, row0 + rows) from X_j [rows, inner] (ldx); W_j is a Linear weight [N, inner] (ldw) applied
+ * as y = x W^T (w_inner_major = 0: forward layers, HF:457-463, REF:MMBertForPretraining.py:293-301,406-415, REF:MMBertEmbedding.py:22),
+ * or [inner, N] applied as y = x W (w_inner_major = 1: the input gradients dX = dY W of the same layers).
+ * mmbert_skinny_wgrad: for every op, dW[N, K] (ldw) += dY[M, N]^T . X[M, K] and db[N] += column sums of dY (db may be NULL).
+ * nops <= 12, M <= 64, at most 4 sources per op; ops of one call must not write the same memory. */
+typedef struct { const float* X; const float* W; int ldx, ldw, inner, row0, rows, w_inner_major; } mmbert_skinny_src;
+typedef struct { float* Y; const float* bias; int ldy, M, N, nsrc, act, accumulate; mmbert_skinny_src src[4]; } mmbert_skinny_op;
+typedef struct { const float* dY; const float* X; float* dW; float* db; int ldy, ldx, ldw, M, N, K; } mmbert_skinny_wgrad_op;
+int mmbert_skinny_mm(mmbert_stream_t stream, int nops, const mmbert_skinny_op* ops);
+int mmbert_skinny_wgrad(mmbert_stream_t stream, int nops, const mmbert_skinny_wgrad_op* ops);
 
 /* ---- optimizer: flat AdamW (REF:train.py:76-97; mode 0 = transformers-2.8 AdamW, 1 = torch.optim.AdamW) ----
  * flags[i/256]: 0 no decay, 1 decay, 2 frozen.  n % 256 == 0.  Also refreshes the bf16 copy, and zeroes g. */

@@ -52,8 +52,11 @@ SIGNATURES = {
     "mmbert_heads_loss_fwd": (I, [P, P, P, P, P, P, P, I, I, F, I, P, P, P, P, P, P]),
     "mmbert_heads_scale": (I, [P, P, SZ, P]),
     "mmbert_heads_gate_bwd": (I, [P, P, P, P, P, P, P, I, I, P, P, P, P]),
+    "mmbert_heads_tanh": (I, [P, P, SZ]),
     "mmbert_heads_tanh_bwd": (I, [P, P, P, P, SZ]),
     "mmbert_heads_colsum": (I, [P, I, P, P, P, P, P]),
+    "mmbert_skinny_mm": (I, [P, I, P]),
+    "mmbert_skinny_wgrad": (I, [P, I, P]),
     "mmbert_adamw": (I, [P, P, P, P, P, P, P, SZ, F, F, F, F, F, I, F, I, I]),
     "mmbert_gelu_bwd": (I, [P, P, P, P, SZ]),
     "mmbert_cast_f32_bf16": (I, [P, P, P, SZ]),

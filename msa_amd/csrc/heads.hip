@@ -1,8 +1,8 @@
 // Pretraining heads of MMBertForPretraining (REF:MMBertForPretraining.py:293-301, 399-443; CPC REF:MMBertEmbedding.py:21-32):
 // the fp32, [B,H]-sized arithmetic BETWEEN the dense products -- gates, gated concatenation, CPC normalisation / in-batch
-// InfoNCE, the 2-way and regression losses, and their hand-derived backward.  The dense products themselves stay with the
-// host (hipBLASLt through torch.addmm): what this file replaces is ~200 element-wise / reduction launches of 2-4 us each
-// (1.1 ms of device time per step) by 6 kernels.  Everything here is HBM/latency trivial: a few [48, 768] fp32 arrays.
+// InfoNCE, the 2-way and regression losses, and their hand-derived backward -- and, since round 2, the dense products themselves
+// (skinny_mm / skinny_wgrad below: lists of <= 64-row fp32 products per launch; round 1 left them to torch.addmm -> hipBLASLt).
+// Together: 16 launches per step where the eager autograd form needs ~250.  Everything here is HBM/latency trivial.
 //
 // Notation (B samples, H hidden, m = modality 0 text / 1 visual / 2 speech, rows of every [3B, H] array ordered m-major):
 //   P   = tanh(first Wp^T + bp)                      pooled rows                 (host: addmm + tanh)
@@ -201,6 +201,135 @@ __global__ void heads_tanh_bwd_kernel(const float* __restrict__ dP, const float*
     }
 }
 
+
+// --------------------------------------------------------------------------------------------------------------------------------
+// The heads' dense layers themselves: fp32 products with at most 64 rows ([3B, H] pooled vectors against [H..3H, H] weights, B <= 16).
+// Round 1 sent each through torch.addmm -> hipBLASLt: ~45 launches of 6-27 us per step for 0.9 GFLOP, plus the host cost of as many
+// library calls.  Here a launch is a LIST of independent products (one dependency level of the heads' graph), memory-bound on the
+// weights it streams once:
+//   skinny_mm    Y[M, N] += bias + sum_j X_j . op(W_j)   (Y zeroed by the caller, or holding what to add to)   forward layers and input gradients
+//                (op = W^T for a Linear weight [N, inner] -- "y = x W^T" --, or W itself [inner, N] -- "dx = dy W"; a source may
+//                 cover a row range only: the alignment head reads / feeds the visual and speech rows)
+//   skinny_wgrad dW[N, K] += dY[M, N]^T . X[M, K],  db[N] += column sums of dY                    weight and bias gradients
+// Workgroup = 256 threads = one 16-column output tile x all rows (mm) or one 16 x 64 tile of dW (wgrad); operands staged through LDS
+// in 64-deep chunks, float4 LDS reads (row pitch 68 floats: 16-byte aligned and bank-spread).
+// --------------------------------------------------------------------------------------------------------------------------------
+#define SK_MAXOPS 12
+#define SK_MAXSRC 4
+struct SkSrc { const float* X; const float* W; int ldx, ldw, inner, row0, rows, w_inner_major; };
+struct SkOp { float* Y; const float* bias; int ldy, M, N, nsrc, act, accumulate, tile0, pad_; SkSrc src[SK_MAXSRC]; };
+struct SkArgs { SkOp op[SK_MAXOPS]; int nops; };
+
+__global__ __launch_bounds__(256) void skinny_mm_kernel(const SkArgs a) {
+    // One workgroup = one 16-column output tile x ONE 64-deep chunk of one source: a few hundred to a few thousand independent
+    // workgroups per launch, each a single round trip to memory (a first version walked all chunks of a tile in one workgroup:
+    // 12-36 dependent round trips on 48-144 workgroups, 130 us per launch).  The partial products are added to Y with fp32 atomics,
+    // so Y must hold zeros (or the value to accumulate onto) before the launch; the chunk 0 workgroup of a tile also adds the bias.
+    __shared__ __attribute__((aligned(16))) float Xs[64][68];
+    __shared__ __attribute__((aligned(16))) float Ws[16][68];
+    int oi = 0;
+    for (int q = 1; q < a.nops; ++q) if ((int)blockIdx.x >= a.op[q].tile0) oi = q;
+    const SkOp& op = a.op[oi];
+    int t = (int)blockIdx.x - op.tile0;
+    const int chunks = op.pad_;                                    // 64-deep chunks over all sources of this op
+    const int n0 = (t / chunks) * 16;
+    int ch = t - (t / chunks) * chunks, j = 0;
+    while (j + 1 < op.nsrc && ch >= (op.src[j].inner + 63) / 64) { ch -= (op.src[j].inner + 63) / 64; ++j; }
+    const SkSrc& sc = op.src[j];
+    const int c0 = ch * 64;
+    const int tid = threadIdx.x, tn = tid & 15, tg = tid >> 4;
+    // all 20 global loads of the workgroup's two operand chunks are issued before the first LDS store: one round trip
+    float xv[16], wv[4];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {                                 // X chunk: 64 rows x 64 inner (rows outside the source's range: 0)
+        const int idx = tid + 256 * i, row = idx >> 6, kk = idx & 63;
+        const int r = row - sc.row0;
+        xv[i] = (r >= 0 && r < sc.rows && c0 + kk < sc.inner) ? sc.X[(size_t)r * sc.ldx + c0 + kk] : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {                                  // W chunk: 16 output columns x 64 inner
+        const int idx = tid + 256 * i;
+        int c, kk;
+        if (sc.w_inner_major) { kk = idx >> 4; c = idx & 15; } else { c = idx >> 6; kk = idx & 63; }
+        wv[i] = 0.f;
+        if (n0 + c < op.N && c0 + kk < sc.inner)
+            wv[i] = sc.w_inner_major ? sc.W[(size_t)(c0 + kk) * sc.ldw + n0 + c] : sc.W[(size_t)(n0 + c) * sc.ldw + c0 + kk];
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { const int idx = tid + 256 * i; Xs[idx >> 6][idx & 63] = xv[i]; }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int idx = tid + 256 * i;
+        if (sc.w_inner_major) Ws[idx & 15][idx >> 4] = wv[i]; else Ws[idx >> 6][idx & 63] = wv[i];
+    }
+    __syncthreads();
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+    for (int kk = 0; kk < 64; kk += 4) {
+        const float4 w4 = *(const float4*)&Ws[tn][kk];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float4 x4 = *(const float4*)&Xs[tg + 16 * r][kk];
+            acc[r] += x4.x * w4.x + x4.y * w4.y + x4.z * w4.z + x4.w * w4.w;
+        }
+    }
+    const int n = n0 + tn;
+    if (n < op.N) {
+        const float b = (op.bias && j == 0 && ch == 0) ? op.bias[n] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = tg + 16 * r;
+            if (row < op.M) atomicAdd(op.Y + (size_t)row * op.ldy + n, acc[r] + b);
+        }
+    }
+}
+
+struct SkWOp { const float* dY; const float* X; float* dW; float* db; int ldy, ldx, ldw, M, N, K, tile0, tiles_k; };
+struct SkWArgs { SkWOp op[SK_MAXOPS]; int nops; };
+
+__global__ __launch_bounds__(256) void skinny_wgrad_kernel(const SkWArgs a) {
+    __shared__ float dYs[64][17];
+    __shared__ __attribute__((aligned(16))) float Xs[64][68];
+    int oi = 0;
+    for (int q = 1; q < a.nops; ++q) if ((int)blockIdx.x >= a.op[q].tile0) oi = q;
+    const SkWOp& op = a.op[oi];
+    const int t = (int)blockIdx.x - op.tile0;
+    const int n0 = (t / op.tiles_k) * 16, k0 = (t % op.tiles_k) * 64;
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int idx = tid + 256 * i, m = idx >> 4, c = idx & 15;
+        dYs[m][c] = (m < op.M && n0 + c < op.N) ? op.dY[(size_t)m * op.ldy + n0 + c] : 0.f;
+    }
+#pragma unroll 4
+    for (int i = 0; i < 16; ++i) {
+        const int idx = tid + 256 * i, m = idx >> 6, kk = idx & 63;
+        Xs[m][kk] = (m < op.M && k0 + kk < op.K) ? op.X[(size_t)m * op.ldx + k0 + kk] : 0.f;
+    }
+    __syncthreads();
+    const int tk4 = tid & 15, tn = tid >> 4;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    float bsum = 0.f;
+    for (int m = 0; m < op.M; ++m) {
+        const float dy = dYs[m][tn];
+        const float4 x4 = *(const float4*)&Xs[m][4 * tk4];
+        acc.x += dy * x4.x; acc.y += dy * x4.y; acc.z += dy * x4.z; acc.w += dy * x4.w;
+        bsum += dy;
+    }
+    const int n = n0 + tn;
+    if (n < op.N) {
+        float* w = op.dW + (size_t)n * op.ldw + k0 + 4 * tk4;
+        const float v[4] = {acc.x, acc.y, acc.z, acc.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) if (k0 + 4 * tk4 + e < op.K) w[e] += v[e];
+        if (op.db && k0 == 0 && tk4 == 0) op.db[n] += bsum;
+    }
+}
+
+__global__ void heads_tanh_kernel(float* __restrict__ x, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) x[i] = tanhf(x[i]);
+}
+
 // bias (and gate-vector) gradients: dst[c] += sum_r src[r][c] for up to 16 (src, rows, cols, dst) segments in one launch; grid.y = segment
 struct ColsumSeg { const float* src; float* dst; int rows, cols, ld; };
 struct ColsumArgs { ColsumSeg s[16]; };
@@ -257,9 +386,68 @@ int mmbert_heads_gate_bwd(hipStream_t stream, const float* dC, const float* P, c
     return 0;
 }
 
+int mmbert_heads_tanh(hipStream_t stream, float* x, size_t n) {
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(heads_tanh_kernel, dim3((unsigned)((n + 255) / 256 < 256 ? (n + 255) / 256 : 256)), dim3(256), 0, stream, x, n);
+    MMB_CHECK_LAUNCH();
+    return 0;
+}
+
 int mmbert_heads_tanh_bwd(hipStream_t stream, const float* dP, const float* P, float* dpre, size_t n) {
     if (n == 0) return 0;
     hipLaunchKernelGGL(heads_tanh_bwd_kernel, dim3((unsigned)((n + 255) / 256 < 256 ? (n + 255) / 256 : 256)), dim3(256), 0, stream, dP, P, dpre, n);
+    MMB_CHECK_LAUNCH();
+    return 0;
+}
+
+// see include/mmbert_hip.h for the two op structs (mirrored here field by field)
+struct mmbert_skinny_src { const float* X; const float* W; int ldx, ldw, inner, row0, rows, w_inner_major; };
+struct mmbert_skinny_op { float* Y; const float* bias; int ldy, M, N, nsrc, act, accumulate; mmbert_skinny_src src[4]; };
+struct mmbert_skinny_wgrad_op { const float* dY; const float* X; float* dW; float* db; int ldy, ldx, ldw, M, N, K; };
+
+int mmbert_skinny_mm(hipStream_t stream, int nops, const mmbert_skinny_op* ops) {
+    if (nops <= 0) return 0;
+    if (nops > SK_MAXOPS) return -1;
+    SkArgs a = {};
+    int tiles = 0;
+    for (int i = 0; i < nops; ++i) {
+        const mmbert_skinny_op& o = ops[i];
+        if (o.M < 0 || o.M > 64 || o.N <= 0 || o.nsrc < 1 || o.nsrc > SK_MAXSRC || !o.Y) return -1;
+        SkOp& d = a.op[i];
+        if (o.act != 0) return -1;                                 // (an activation cannot follow a sum that is still being added to)
+        d.Y = o.Y; d.bias = o.bias; d.ldy = o.ldy; d.M = o.M; d.N = o.N; d.nsrc = o.nsrc; d.act = 0; d.accumulate = o.accumulate; d.tile0 = tiles;
+        int chunks = 0;
+        for (int j = 0; j < o.nsrc; ++j) {
+            const mmbert_skinny_src& sc = o.src[j];
+            if (sc.rows < 0 || sc.row0 < 0 || sc.row0 + sc.rows > 64 || sc.inner <= 0 || !sc.X || !sc.W) return -1;
+            d.src[j].X = sc.X; d.src[j].W = sc.W; d.src[j].ldx = sc.ldx; d.src[j].ldw = sc.ldw; d.src[j].inner = sc.inner;
+            d.src[j].row0 = sc.row0; d.src[j].rows = sc.rows; d.src[j].w_inner_major = sc.w_inner_major;
+            chunks += (sc.inner + 63) / 64;
+        }
+        d.pad_ = chunks;
+        tiles += ((o.N + 15) / 16) * chunks;
+    }
+    a.nops = nops;
+    hipLaunchKernelGGL(skinny_mm_kernel, dim3(tiles), dim3(256), 0, stream, a);
+    MMB_CHECK_LAUNCH();
+    return 0;
+}
+
+int mmbert_skinny_wgrad(hipStream_t stream, int nops, const mmbert_skinny_wgrad_op* ops) {
+    if (nops <= 0) return 0;
+    if (nops > SK_MAXOPS) return -1;
+    SkWArgs a = {};
+    int tiles = 0;
+    for (int i = 0; i < nops; ++i) {
+        const mmbert_skinny_wgrad_op& o = ops[i];
+        if (o.M < 0 || o.M > 64 || o.N <= 0 || o.K <= 0 || !o.dY || !o.X || !o.dW) return -1;
+        SkWOp& d = a.op[i];
+        d.dY = o.dY; d.X = o.X; d.dW = o.dW; d.db = o.db; d.ldy = o.ldy; d.ldx = o.ldx; d.ldw = o.ldw; d.M = o.M; d.N = o.N; d.K = o.K;
+        d.tile0 = tiles; d.tiles_k = (o.K + 63) / 64;
+        tiles += ((o.N + 15) / 16) * d.tiles_k;
+    }
+    a.nops = nops;
+    hipLaunchKernelGGL(skinny_wgrad_kernel, dim3(tiles), dim3(256), 0, stream, a);
     MMB_CHECK_LAUNCH();
     return 0;
 }

@@ -922,10 +922,12 @@ class MMBertPreTrainingHeads(nn.Module):
 
 class _HeadsFn(torch.autograd.Function):
     """heads_loss = ap_loss + label_loss - beta * nce and the auxiliary outputs from the [CLS] rows, with a hand-written
-    backward: dense products through torch (hipBLASLt), everything between them in csrc/heads.hip.  Same arithmetic as
+    backward, entirely in csrc/heads.hip: the dense layers as lists of <= 64-row fp32 products (mmbert_skinny_mm / _wgrad, one
+    launch per dependency level), the gates / CPC / losses and their gradients in between.  Same arithmetic as
     MMBertForPretraining._heads (the eager form, kept as the reference for tests and for configurations this path does not
-    cover); ~35 launches instead of ~250.  Parameter gradients are accumulated straight into ``p.grad`` (views of the flat
-    gradient buffer); the auxiliary outputs are values (non-differentiable)."""
+    cover); 19 launches where the eager form needs ~250 (round 1: ~60, the dense layers through torch.addmm -> hipBLASLt).
+    Parameter gradients are accumulated straight into ``p.grad`` (views of the flat gradient buffer); the auxiliary outputs are
+    values (non-differentiable)."""
 
     @staticmethod
     def forward(ctx, first, top, ap, sent):
@@ -935,17 +937,23 @@ class _HeadsFn(torch.autograd.Function):
         c1, c2 = top.classifier1_1, top.classifier1_2
         qs = (top.cpc_zt.net, top.cpc_zv.net, top.cpc_za.net)
         first = first.contiguous()
-        P = torch.addmm(pool.bias, first, pool.weight.t()).tanh_()
-        t_rel = torch.addmm(sr.bias, P[:B], sr.weight.t())
-        rel = torch.addmm(al.bias, first[B:], al.weight.t())                         # [2B, 2]: visual rows, speech rows
-        Apre = torch.addmm(at.bias, P, at.weight[:, :H].t())                         # attn(cat(x, x)) = x (W1 + W2)^T + b
-        Apre.addmm_(P, at.weight[:, H:].t())
+        dev = first.device
+        # the products are summed into zeroed outputs (fp32 atomics over the split inner dimension): ONE zero fill for all of them
+        nl = c2.weight.shape[0]
+        sizes = (3 * B * H, 2 * B, 4 * B, 3 * B * H, B * H, B * nl, 3 * B * H)
+        buf = torch.zeros(sum(sizes), device=dev, dtype=torch.float32)
+        parts = torch.split(buf, sizes)
+        P, t_rel, rel, Apre, T, lo, XP = (parts[0].view(3 * B, H), parts[1].view(B, 2), parts[2].view(2 * B, 2), parts[3].view(3 * B, H),
+                                          parts[4].view(B, H), parts[5].view(B, nl), parts[6].view(3, B, H))
+        ops.skinny_mm([(P, pool.bias, 0, False, [(first, pool.weight, 0, 0)])])
+        ops.heads_tanh_(P)                                                                            # pooled = tanh(pooler(first))  HF:457-463
+        ops.skinny_mm([(t_rel, sr.bias, 0, False, [(P[:B], sr.weight, 0, 0)]),                         # computed, never in a loss (:301)
+                       (rel, al.bias, 0, False, [(first[B:], al.weight, 0, 0)]),                       # [2B, 2]: visual rows, speech rows (:297)
+                       (Apre, at.bias, 0, False, [(P, at.weight[:, :H], 0, 0), (P, at.weight[:, H:], 0, 0)])])   # attn(cat(x, x)) = x (W1 + W2)^T + b
         g, Cc = ops.heads_gate_fwd(P, Apre, [v.weight for v in vs3], [v.bias for v in vs3], B)
-        T = torch.addmm(c1.bias, Cc, c1.weight.t())
-        lo = torch.addmm(c2.bias, T, c2.weight.t())                                  # [B, 1]
-        XP = torch.empty((3, B, H), device=first.device, dtype=torch.float32)
-        for m in range(3):
-            torch.addmm(qs[m].bias, T, qs[m].weight.t(), out=XP[m])
+        ops.skinny_mm([(T, c1.bias, 0, False, [(Cc, c1.weight, 0, 0)])])                              # :414
+        ops.skinny_mm([(lo, c2.bias, 0, False, [(T, c2.weight, 0, 0)])]                               # :415
+                      + [(XP[m], qs[m].bias, 0, False, [(T, qs[m].weight, 0, 0)]) for m in range(3)])  # REF:MMBertEmbedding.py:22
         tanh_lo = top.num_labels == 1
         out4, seeds = ops.heads_loss_fwd(P, XP, rel, ap, lo, sent, B, top.beta, tanh_lo)
         ctx.top, ctx.B = top, B
@@ -969,33 +977,27 @@ class _HeadsFn(torch.autograd.Function):
         c1, c2 = top.classifier1_1, top.classifier1_2
         qs = (top.cpc_zt.net, top.cpc_zv.net, top.cpc_za.net)
         n = 3 * B * H
+        dev = first.device
         seeds = seeds.clone()                                                        # backward may run twice (retain_graph)
         ops.heads_scale(seeds, d.reshape(1).float().contiguous())
         dXP, dPc = seeds[:n].view(3, B, H), seeds[n:2 * n].view(3 * B, H)
         dlo, drel = seeds[2 * n:2 * n + B].view(B, 1), seeds[2 * n + B:].view(2 * B, 2)
-        for m in range(3):
-            qs[m].weight.grad.addmm_(dXP[m].t(), T)
-        dT = torch.mm(dXP[0], qs[0].weight)
-        dT.addmm_(dXP[1], qs[1].weight)
-        dT.addmm_(dXP[2], qs[2].weight)
-        dT.addmm_(dlo, c2.weight)
-        c2.weight.grad.addmm_(dlo.t(), T)
-        dC = torch.mm(dT, c1.weight)
-        c1.weight.grad.addmm_(dT.t(), Cc)
+        zb = torch.zeros(B * H + 3 * B * H + 3 * B * H, device=dev, dtype=torch.float32)             # dT | dC | dfirst: summed into
+        dT, dC, dfirst = zb[:B * H].view(B, H), zb[B * H:4 * B * H].view(B, 3 * H), zb[4 * B * H:].view(3 * B, H)
+        ops.skinny_mm([(dT, None, 0, False, [(dXP[0], qs[0].weight, 1, 0), (dXP[1], qs[1].weight, 1, 0), (dXP[2], qs[2].weight, 1, 0),
+                                            (dlo, c2.weight, 1, 0)])])
+        ops.skinny_mm([(dC, None, 0, False, [(dT, c1.weight, 1, 0)])])
         dP, dA, E, dg = ops.heads_gate_bwd(dC, P, Apre, g, [v.weight for v in vs3], dPc, B)
-        dP.addmm_(dA, at.weight[:, :H])
-        dP.addmm_(dA, at.weight[:, H:])
-        at.weight.grad[:, :H].addmm_(dA.t(), P)
-        at.weight.grad[:, H:].addmm_(dA.t(), P)
+        ops.skinny_mm([(dP, None, 0, True, [(dA, at.weight[:, :H], 1, 0), (dA, at.weight[:, H:], 1, 0)])])
         dpre = ops.heads_tanh_bwd(dP, P)
-        dfirst = torch.mm(dpre, pool.weight)
-        dfirst[B:].addmm_(drel, al.weight)
-        pool.weight.grad.addmm_(dpre.t(), first)
-        al.weight.grad.addmm_(drel.t(), first[B:])
+        ops.skinny_mm([(dfirst, None, 0, False, [(dpre, pool.weight, 1, 0), (drel, al.weight, 1, B)])])
+        # every weight / bias gradient of the heads' dense layers in ONE launch
+        ops.skinny_wgrad([(dXP[m], T, qs[m].weight.grad, qs[m].bias.grad) for m in range(3)]
+                         + [(dlo, T, c2.weight.grad, c2.bias.grad), (dT, Cc, c1.weight.grad, c1.bias.grad),
+                            (dA, P, at.weight.grad[:, :H], at.bias.grad), (dA, P, at.weight.grad[:, H:], None),
+                            (dpre, first, pool.weight.grad, pool.bias.grad), (drel, first[B:], al.weight.grad, al.bias.grad)])
         E3, dg3 = E.view(3, B, H), dg.view(3, B, 1)
-        ops.heads_colsum([(dXP[0], qs[0].bias.grad), (dXP[1], qs[1].bias.grad), (dXP[2], qs[2].bias.grad), (dT, c1.bias.grad),
-                          (dlo, c2.bias.grad), (dA, at.bias.grad), (dpre, pool.bias.grad), (drel, al.bias.grad)]
-                         + [(E3[m], vs3[m].weight.grad) for m in range(3)] + [(dg3[m], vs3[m].bias.grad) for m in range(3)])
+        ops.heads_colsum([(E3[m], vs3[m].weight.grad) for m in range(3)] + [(dg3[m], vs3[m].bias.grad) for m in range(3)])
         return dfirst, None, None, None
 
 
@@ -1124,7 +1126,7 @@ class MMBertForPretraining(_GpuModelBase):
         """The heads on the [3B, H] [CLS] rows: the fused kernels (csrc/heads.hip) where they apply, else the eager form.
         (A captured hipGraph of the eager [B,H]-sized glue -- forward and backward, ~200 dependent launches -- was built and
         measured in round 1: no gain; the device time of the tiny kernels, not their dispatch, is the cost.)"""
-        fused = (self.fused_heads and sentiment is not None and first.is_cuda and self.num_labels in (1, 7)
+        fused = (self.fused_heads and sentiment is not None and first.is_cuda and self.num_labels in (1, 7) and B <= 16
                  and all(q.grad is not None for q in (self.attn.weight, self.vt.weight, self.classifier1_1.weight)))
         if fused:
             ap = torch.cat((ap_v.to(dev).view(-1), ap_s.to(dev).view(-1))).long()

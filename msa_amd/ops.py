@@ -669,6 +669,11 @@ def heads_gate_bwd(dC, P, Apre, g, vws, dPc, B):
     return dP, dA, E, dg
 
 
+def heads_tanh_(x):
+    _lib.check(_lib.load().mmbert_heads_tanh(_stream(), x.data_ptr(), x.numel()), "mmbert_heads_tanh")
+    return x
+
+
 def heads_tanh_bwd(dP, P):
     dpre = torch.empty_like(P)
     _lib.check(_lib.load().mmbert_heads_tanh_bwd(_stream(), dP.data_ptr(), P.data_ptr(), dpre.data_ptr(), P.numel()), "mmbert_heads_tanh_bwd")
@@ -682,3 +687,57 @@ def heads_colsum(pairs):
     _lib.check(_lib.load().mmbert_heads_colsum(_stream(), n, PA(*[s.data_ptr() for s, _ in pairs]), PA(*[d.data_ptr() for _, d in pairs]),
                                                IA(*[s.shape[0] for s, _ in pairs]), IA(*[s.shape[1] for s, _ in pairs]),
                                                IA(*[s.stride(0) for s, _ in pairs])), "mmbert_heads_colsum")
+
+
+# ------------------------------------------------------------------------------------ the heads' dense layers (skinny fp32 products)
+class _SkSrc(ctypes.Structure):
+    _fields_ = [("X", ctypes.c_void_p), ("W", ctypes.c_void_p), ("ldx", ctypes.c_int), ("ldw", ctypes.c_int), ("inner", ctypes.c_int),
+                ("row0", ctypes.c_int), ("rows", ctypes.c_int), ("w_inner_major", ctypes.c_int)]
+
+
+class _SkOp(ctypes.Structure):
+    _fields_ = [("Y", ctypes.c_void_p), ("bias", ctypes.c_void_p), ("ldy", ctypes.c_int), ("M", ctypes.c_int), ("N", ctypes.c_int),
+                ("nsrc", ctypes.c_int), ("act", ctypes.c_int), ("accumulate", ctypes.c_int), ("src", _SkSrc * 4)]
+
+
+class _SkWOp(ctypes.Structure):
+    _fields_ = [("dY", ctypes.c_void_p), ("X", ctypes.c_void_p), ("dW", ctypes.c_void_p), ("db", ctypes.c_void_p), ("ldy", ctypes.c_int),
+                ("ldx", ctypes.c_int), ("ldw", ctypes.c_int), ("M", ctypes.c_int), ("N", ctypes.c_int), ("K", ctypes.c_int)]
+
+
+def _f32_2d(t):
+    assert t.dtype == torch.float32 and t.dim() == 2 and (t.shape[1] == 1 or t.stride(1) == 1) and t.is_cuda, (t.dtype, t.shape, t.stride())
+    return t
+
+
+def skinny_mm(oplist):
+    """One launch of mmbert_skinny_mm: Y += bias + sum of the sources' products (fp32 atomics: Y must be zeroed, or hold what to add
+    to).  Each op: (Y [M,N], bias [N] | None, 0, accumulate (informational), sources) with sources =
+    [(X [rows, inner], W, w_inner_major, row0)]: W is [N, inner] (y = x W^T) for w_inner_major = 0, [inner, N] (y = x W) for 1;
+    the source feeds the output rows row0 .. row0 + rows.  fp32, unit column stride, any row stride."""
+    n = len(oplist)
+    arr = (_SkOp * n)()
+    keep = []
+    for o, (Y, bias, act, accumulate, sources) in zip(arr, oplist):
+        _f32_2d(Y)
+        o.Y, o.bias, o.ldy, o.M, o.N = Y.data_ptr(), _ptr(bias), Y.stride(0), Y.shape[0], Y.shape[1]
+        o.nsrc, o.act, o.accumulate = len(sources), int(act), 1 if accumulate else 0
+        for sc, (X, W, wim, row0) in zip(o.src, sources):
+            _f32_2d(X); _f32_2d(W)
+            inner = X.shape[1]
+            assert (W.shape == (inner, Y.shape[1])) if wim else (W.shape == (Y.shape[1], inner)), (W.shape, inner, Y.shape, wim)
+            sc.X, sc.W, sc.ldx, sc.ldw, sc.inner, sc.row0, sc.rows, sc.w_inner_major = X.data_ptr(), W.data_ptr(), X.stride(0), W.stride(0), inner, row0, X.shape[0], 1 if wim else 0
+            keep.append((X, W))
+    _lib.check(_lib.load().mmbert_skinny_mm(_stream(), n, ctypes.cast(arr, ctypes.c_void_p)), "mmbert_skinny_mm")
+
+
+def skinny_wgrad(oplist):
+    """One launch of mmbert_skinny_wgrad.  Each op: (dY [M,N], X [M,K], dW [N,K] (+=), db [N] | None (+= column sums of dY))."""
+    n = len(oplist)
+    arr = (_SkWOp * n)()
+    for o, (dY, X, dW, db) in zip(arr, oplist):
+        _f32_2d(dY); _f32_2d(X); _f32_2d(dW)
+        assert dY.shape[0] == X.shape[0] and dW.shape == (dY.shape[1], X.shape[1]), (dY.shape, X.shape, dW.shape)
+        o.dY, o.X, o.dW, o.db = dY.data_ptr(), X.data_ptr(), dW.data_ptr(), _ptr(db)
+        o.ldy, o.ldx, o.ldw, o.M, o.N, o.K = dY.stride(0), X.stride(0), dW.stride(0), dY.shape[0], dY.shape[1], X.shape[1]
+    _lib.check(_lib.load().mmbert_skinny_wgrad(_stream(), n, ctypes.cast(arr, ctypes.c_void_p)), "mmbert_skinny_wgrad")

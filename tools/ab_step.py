@@ -34,10 +34,15 @@ def step(i):
     opt.step(); sched.step(); opt.zero_grad()
 
 
+attr_defaults = {k[5:]: getattr(model, k[5:]) for k in all_keys if k.startswith("attr.")}
+
+
 def setenv(env):
     for k in all_keys:
         os.environ.pop(k, None)
-    os.environ.update(env)
+    for k, v in attr_defaults.items():
+        setattr(model, k, v)
+    os.environ.update({k: v for k, v in env.items() if not k.startswith("attr.")})
     for k, v in env.items():
         if k.startswith("attr."):                      # model attribute toggles: attr.NAME=python-literal
             setattr(model, k[5:], eval(v))
