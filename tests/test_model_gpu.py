@@ -348,11 +348,13 @@ def test_inference_dedupes_masked_rows_exactly():
         if dd:
             assert seen[0].rows_packed < 0.9 * seen[0].tokens
     (oa, la), (ob, lb) = outs[True], outs[False]
-    assert torch.equal(la, lb)
+    assert torch.allclose(la, lb, rtol=1e-5, atol=1e-7)           # (the heads' dense layers sum their split products with fp32 atomics)
     for i in (0, 4, 5, 6):
         assert abs(float(oa[i]) - float(ob[i])) <= 1e-6 * abs(float(ob[i]))      # (the loss sums use fp32 atomics: not bit-stable run to run)
-    for k in (7, 8, 9, 10, 11, 12):
-        assert torch.equal(oa[k], ob[k]), k
+    for k in (7, 9, 11):
+        assert torch.equal(oa[k], ob[k]), k                                      # every prediction score, bit for bit
+    for k in (8, 10, 12):
+        assert torch.allclose(oa[k], ob[k], rtol=1e-5, atol=1e-7), k            # relationship scores: summed with fp32 atomics
 
 
 @pytest.mark.parametrize("train", [False, True])
@@ -429,7 +431,7 @@ def test_sparse_mlm_backward_equals_dense_backward():
         scale = float(b.abs().max()) + 1e-12
         # 4e-3 of the largest entry: downstream of the head one bf16 rounding flip of an activation gradient is 2^-9 = 2e-3 relative
         # on that element (observed 2.3e-3 on one pair-projection weight)
-        assert float((a - b).abs().max()) <= 4e-3 * scale + 1e-9, (n, float((a - b).abs().max()), scale)
+        assert float((a - b).abs().max()) <= 4e-3 * scale + 1e-8, (n, float((a - b).abs().max()), scale)   # (1e-8: the CPC gradients at init are ~4e-8)
     lab = batch["masked_labels"]
     n_act = sum(int((x != -100).sum()) for x in lab)
     assert 0 < n_act < sum(x.numel() for x in lab) // 2          # the sparse path was really taken
@@ -766,7 +768,7 @@ def test_from_pretrained_local_directory(tmp_path):
         with torch.no_grad():
             a, la = m(**batch)
             b, lb = ref(**batch)
-        assert torch.equal(la, lb) and torch.equal(a[7], b[7]) and abs(float(a[0]) - float(b[0])) <= 1e-6 * abs(float(b[0]))
+        assert torch.allclose(la, lb, rtol=1e-5, atol=1e-7) and torch.equal(a[7], b[7]) and abs(float(a[0]) - float(b[0])) <= 1e-6 * abs(float(b[0]))
         outs.append(float(a[0]))
     assert abs(outs[0] - outs[1]) <= 1e-6 * abs(outs[0])           # .bin and .safetensors load the same model
     with pytest.raises(OSError, match="local checkpoint directory"):
