@@ -985,7 +985,13 @@ static int launch_nt256(hipStream_t s, const GemmNT& p) {
         // are staged) and that, not the MFMA count, is its length -- so only the round count matters and the two forms below
         // stay.  A start stagger of the workgroups (to spread the epilogues' store bursts) was a loss on every shape, the
         // 34-round vocabulary projection included (profiles/r2_exp_nt_start_stagger.log).
-        if (can_persist) return (tall_ok && (float)r256 * 1.1f < (float)r224) ? launch_ntp_mi<EPI, 8>(s, p) : launch_ntp_mi<EPI, 7>(s, p);
+        if (can_persist) {
+            // experiment switch (read per call): MMBERT_NT_PREFER_TALL=1 takes the 256-row form whenever it needs no more rounds,
+            // for the epilogues without GELU / GELU' (where the staggered form lost 8-9 % in isolation)
+            const char* pt = getenv("MMBERT_NT_PREFER_TALL");
+            if (pt && pt[0] == '1' && !(EPI & (EPI_GELU | EPI_GELU_BWD)) && r256 <= r224) return launch_ntp_mi<EPI, 8>(s, p);
+            return (tall_ok && (float)r256 * 1.1f < (float)r224) ? launch_ntp_mi<EPI, 8>(s, p) : launch_ntp_mi<EPI, 7>(s, p);
+        }
         return r224 <= r256 ? launch_nt256_mi<EPI, 7>(s, p) : launch_nt256_mi<EPI, 8>(s, p);
     }
     if (can_persist && g_nt_force == 2 && g_nt_persist == 2) return g_nt_bm == 224 ? launch_ntp_mi<EPI, 7>(s, p) : launch_ntp_mi<EPI, 8>(s, p);
