@@ -986,10 +986,8 @@ static int launch_nt256(hipStream_t s, const GemmNT& p) {
         // stay.  A start stagger of the workgroups (to spread the epilogues' store bursts) was a loss on every shape, the
         // 34-round vocabulary projection included (profiles/r2_exp_nt_start_stagger.log).
         if (can_persist) {
-            // experiment switch (read per call): MMBERT_NT_PREFER_TALL=1 takes the 256-row form whenever it needs no more rounds,
-            // for the epilogues without GELU / GELU' (where the staggered form lost 8-9 % in isolation)
-            const char* pt = getenv("MMBERT_NT_PREFER_TALL");
-            if (pt && pt[0] == '1' && !(EPI & (EPI_GELU | EPI_GELU_BWD)) && r256 <= r224) return launch_ntp_mi<EPI, 8>(s, p);
+            // (round 2, same-process A/B of the train step: taking the 256-row form whenever it needs no more rounds, for the
+            // epilogues without GELU / GELU', is 0.5-0.7 % SLOWER in situ although it wins 3-5 % per shape in isolation)
             return (tall_ok && (float)r256 * 1.1f < (float)r224) ? launch_ntp_mi<EPI, 8>(s, p) : launch_ntp_mi<EPI, 7>(s, p);
         }
         return r224 <= r256 ? launch_nt256_mi<EPI, 7>(s, p) : launch_nt256_mi<EPI, 8>(s, p);
