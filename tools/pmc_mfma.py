@@ -8,6 +8,9 @@ M=18400, N=K=768 product counts 4.284e7 = 83 tiles x 224 x 768 x 768 x 2 / 512).
 """
 import csv, collections, re, sys
 pre = sys.argv[1]
+import os, sys as _s
+_s.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from bench import csrc_digest
 def load(c):
     acc = collections.defaultdict(lambda: [0, 0.0, 0.0])
     for r in csv.DictReader(open(f"{pre}{c}/pmc_counter_collection.csv")):
@@ -16,6 +19,7 @@ def load(c):
         acc[k][0] += 1; acc[k][1] += float(r["Counter_Value"]); acc[k][2] += float(r["End_Timestamp"]) - float(r["Start_Timestamp"])
     return acc
 m, g, o = load("SQ_VALU_MFMA_BUSY_CYCLES"), load("GRBM_GUI_ACTIVE"), load("SQ_INSTS_VALU_MFMA_MOPS_BF16")
+print("# csrc_sha256: " + csrc_digest())
 print("# rocprofv3 --pmc <counter> --kernel-trace, one counter per pass -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timing --no-fused")
 print("# mfma_util = SQ_VALU_MFMA_BUSY_CYCLES / (128 SIMDs per XCD x GRBM_GUI_ACTIVE); executed_TFLOP_s = MOPS x 512 / duration (duration of the MOPS pass)")
 print("# (GRBM_GUI_ACTIVE / 8 / duration reads ~2.2-2.3 GHz on these 30-180 us dispatches: the guide notes the quotient reads high below 0.3 ms)")

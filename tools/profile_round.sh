@@ -1,13 +1,21 @@
 #!/bin/bash
-# Round-end evidence on the GPU box: kernel trace + stats of the bench command, two HBM-traffic PMC passes, four MFMA PMC passes.
-cd /tmp && export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT
-BENCH="python3 $R/bench.py --no-cpu-baseline --no-kernel-timing --no-fused --no-dense-reference --no-train-only"
-rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_final -o final --output-format csv -- $BENCH --steps 20 --warmup 5 > $R/gpurun_out/prof_final.log 2>&1
-for c in FETCH_SIZE WRITE_SIZE SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_BF16; do
-  rocprofv3 --pmc $c --kernel-trace -d $R/gpurun_out/pmcf_$c -o pmc --output-format csv -- $BENCH --steps 2 --warmup 1 > $R/gpurun_out/pmcf_$c.log 2>&1
-  echo "$c rc=$?"
+# Round profile set (run on the GPU box): kernel stats + trace, HBM traffic PMC passes, MFMA-utilisation PMC passes, NT-family SQ counters.
+#   bash tools/profile_round.sh r2     -> gpurun_out/prof_r2/*, summaries written by the python tools into gpurun_out/ (copy to profiles/)
+cd "$(dirname "$0")/.."
+R=${1:-rX}
+export TMPDIR=/tmp
+BENCH="python3 bench.py --no-cpu-baseline --no-kernel-timing --no-fused --no-dense-reference --no-train-only"
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_$R -o $R -- $BENCH --steps 20 --warmup 5 > gpurun_out/prof_$R.log 2>&1
+for c in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --pmc $c --kernel-trace --output-format csv -d gpurun_out/pmc_${R}_$c -o pmc -- $BENCH --steps 2 --warmup 1 > gpurun_out/pmc_${R}_$c.log 2>&1
 done
-python3 $R/bench.py --steps 30 --warmup 8 > $R/gpurun_out/bench_final.json 2> $R/gpurun_out/bench_final.err
-tail -c 600 $R/gpurun_out/bench_final.json
-ls $R/gpurun_out/prof_final
+for c in SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_BF16; do
+  rocprofv3 --pmc $c --kernel-trace --output-format csv -d gpurun_out/pmcm_${R}_$c -o pmc -- $BENCH --steps 2 --warmup 1 > gpurun_out/pmcm_${R}_$c.log 2>&1
+done
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VMEM SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --kernel-trace --output-format csv \
+  -d gpurun_out/pmcs_$R -o pmc -- $BENCH --steps 2 --warmup 1 > gpurun_out/pmcs_$R.log 2>&1
+python3 tools/pmc_traffic.py gpurun_out/pmc_${R}_FETCH_SIZE/pmc_counter_collection.csv gpurun_out/pmc_${R}_WRITE_SIZE/pmc_counter_collection.csv > gpurun_out/${R}_pmc_hbm_traffic.csv
+python3 tools/pmc_mfma.py gpurun_out/pmcm_${R}_ > gpurun_out/${R}_pmc_mfma_util.csv
+python3 tools/pmc_sq.py gpurun_out/pmcs_$R/pmc_counter_collection.csv > gpurun_out/${R}_pmc_sq_gemm.csv
+python3 tools/trace_gaps.py gpurun_out/prof_$R/${R}_kernel_trace.csv > gpurun_out/${R}_step_timeline.txt
+ls gpurun_out/prof_$R gpurun_out/pmc_${R}_FETCH_SIZE | head
