@@ -948,6 +948,14 @@ static bool ntp_eligible(const GemmNT& p) {
     return !(p.K & 127) && p.K >= 256 && (long long)p.M * p.lda < (1ll << 31) && (long long)p.N * p.ldb < (1ll << 31);
 }
 
+// Round 2, tried and dropped: a "big tile" form of this kernel -- 320 / 384 x 256 output tile, ONE 4-wave workgroup per CU (one wave
+// per SIMD, a wave owns 160 / 192 x 128 = 320 / 384 accumulator registers of the SIMD's 512), 4-slot ring, the step's one barrier
+// in the middle of its MFMA stream -- to lift the FLOPs per staged byte from 115 to 142 / 157 (S3.1: the K step is bound by its
+// (A rows + B rows) / 16 one-KiB LDS-DMA instructions, so only a bigger tile helps).  It does not survive hipcc: the accumulator
+// file (AGPRs) holds 256 registers, the remaining 64 / 128 accumulators live in VGPRs and the allocator shuttles tuples between
+// the two files inside the K loop (MI2 = 10: 773 v_accvgpr moves and 72 scratch accesses per 320 MFMAs; MI2 = 12: 1044 and 252 per
+// 384), with or without scheduling barriers and with single- or double-buffered B fragments.  At 256 x 256 (all accumulators in
+// AGPRs, no spills in the loop) the tile is the one the staggered 8-wave form already has.
 template <int EPI, int MI>
 static int launch_nt256_mi(hipStream_t s, const GemmNT& p) {
     constexpr int BM = 32 * MI;
