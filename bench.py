@@ -81,6 +81,13 @@ def main():
     from msa_amd.model import MMBertConfig, MMBertForPretraining
     from msa_amd.trainer import build_optimizer, default_args
 
+    # RCCL prints a version banner through C stdio on stdout when its first communicator comes up; the contract is ONE JSON line on
+    # stdout, so stdout is parked on stderr while the process group exists and restored (C buffers flushed) right before the line
+    saved_stdout = None
+    if int(os.environ.get("WORLD_SIZE", 1)) > 1 or a.force_dp:
+        sys.stdout.flush()
+        saved_stdout = os.dup(1)
+        os.dup2(2, 1)
     rank, local, world = parallel.init_from_env(force=a.force_dp)
     if world != a.gpus:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {a.gpus}")
@@ -294,6 +301,15 @@ def main():
         res["train_only"] = train_only
     if fused is not None:
         res["fused1050"] = fused
+    if saved_stdout is not None:
+        import ctypes
+        if torch.distributed.is_initialized():
+            torch.distributed.barrier()
+            torch.distributed.destroy_process_group()
+        sys.stdout.flush()
+        ctypes.CDLL(None).fflush(None)
+        os.dup2(saved_stdout, 1)
+        os.close(saved_stdout)
     if rank == 0:
         if not a.no_kernel_timing and timing["nt"]:
             kern = {}
@@ -321,8 +337,6 @@ def main():
         if world == 1 and not a.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(a, L, H, I, V)
         print(json.dumps(res), flush=True)
-    if world > 1:
-        torch.distributed.destroy_process_group()
 
 
 def csrc_digest():
