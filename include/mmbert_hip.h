@@ -157,10 +157,12 @@ int mmbert_attn_dropout_mask(mmbert_stream_t stream, uint8_t* out, int S, unsign
  * seg_bounds[s]..seg_bounds[s+1].  fwd: loss_sum[s] = mean loss of segment s, row_lse[i] = logsumexp(row i),
  * inv_count[s] = 1/#valid rows.  bwd: dlogits = d(sum_s gscale[s]*loss_sum[s])/d(logits) (may alias logits). */
 int mmbert_ce_fwd(mmbert_stream_t stream, const void* logits, int ldv, int V, const int64_t* labels, int M,
-                  const int* seg_bounds, int nseg, float* inv_count, float* loss_sum, float* row_lse);
+                  const int* seg_bounds, int nseg, float* inv_count, float* loss_sum, float* row_lse,
+                  int logits_f32 /* logits are fp32 (rounded to bf16 as loaded: same losses as the bf16 form) */);
 int mmbert_ce_bwd(mmbert_stream_t stream, const void* logits, int ldv, int V, const int64_t* labels, int M,
                   const int* seg_bounds, int nseg, const float* inv_count, const float* gscale, const float* row_lse, void* dlogits, int ldd,
-                  const int* rows /* NULL: all M rows; else a row list: dlogits row j = gradient of row rows[j] */, int nrows);
+                  const int* rows /* NULL: all M rows; else a row list: dlogits row j = gradient of row rows[j] */, int nrows,
+                  int logits_f32 /* logits are fp32; dlogits stays bf16 */);
 /* Row maps of the valid-first packing (msa_amd/ops.py SplitLayout): inv[original row] = packed row, perm = the
  * inverse, from the per-sequence unmasked lengths.  mode 0: masked-out rows behind all others, in order; 1: ONE shared row per
  * sequence (inference); 2: left out (inv = rows_a). */

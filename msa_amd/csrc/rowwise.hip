@@ -467,8 +467,10 @@ __global__ void ce_count_kernel(const int64_t* __restrict__ labels, int M, int V
 //   MODE 1 (backward): dlogits = (exp(logit - row_lse) - onehot) * inv_count[seg] * gscale[seg]
 //                      (0 for ignored rows and for the pad columns V..ldv); gscale = upstream d(loss)/d(loss_seg)
 // Ignored rows (label -100) are never read.
-template <int MODE>
-__global__ __launch_bounds__(256) void ce_row_kernel(const bf16_t* __restrict__ logits, int ldv, int V, const int64_t* __restrict__ labels,
+// F32: the logits are fp32 (the vocabulary GEMM's EPI_OUT_F32 output, handed to the caller as the reference's fp32 prediction scores);
+// they are rounded to bf16 as they are loaded, so losses and gradients are bit-identical to the bf16-logits path.
+template <int MODE, bool F32>
+__global__ __launch_bounds__(256) void ce_row_kernel(const void* __restrict__ logits_, int ldv, int V, const int64_t* __restrict__ labels,
                                                      const int* __restrict__ seg_bounds, int nseg, const float* __restrict__ inv_count,
                                                      float* __restrict__ loss_sum, float* __restrict__ row_lse, const float* __restrict__ gscale,
                                                      bf16_t* __restrict__ dlogits, int ldd, const int* __restrict__ rows) {
@@ -489,12 +491,24 @@ __global__ __launch_bounds__(256) void ce_row_kernel(const bf16_t* __restrict__ 
     }
     int s = 0;
     while (s + 1 < nseg && i >= seg_bounds[s + 1]) ++s;
-    const bf16_t* row = logits + (size_t)i * ldv;
     bf16x8 v[CE_MAXC];
+    if constexpr (F32) {
+        const float* row = (const float*)logits_ + (size_t)i * ldv;
 #pragma unroll
-    for (int c = 0; c < CE_MAXC; ++c) {
-        const int ch = c * 256 + tid;
-        if (ch < nchunk) v[c] = *(const bf16x8*)(row + ch * 8);
+        for (int c = 0; c < CE_MAXC; ++c) {
+            const int ch = c * 256 + tid;
+            if (ch < nchunk) {
+                const float4 lo = *(const float4*)(row + ch * 8), hi = *(const float4*)(row + ch * 8 + 4);
+                v[c] = (bf16x8){f2bf(lo.x), f2bf(lo.y), f2bf(lo.z), f2bf(lo.w), f2bf(hi.x), f2bf(hi.y), f2bf(hi.z), f2bf(hi.w)};
+            }
+        }
+    } else {
+        const bf16_t* row = (const bf16_t*)logits_ + (size_t)i * ldv;
+#pragma unroll
+        for (int c = 0; c < CE_MAXC; ++c) {
+            const int ch = c * 256 + tid;
+            if (ch < nchunk) v[c] = *(const bf16x8*)(row + ch * 8);
+        }
     }
     if (MODE == 0) {
         float mx = -INFINITY;
@@ -941,24 +955,32 @@ int mmbert_pair_proj_bwd(hipStream_t stream, const float* feat, int B, int P, in
 }
 
 int mmbert_ce_fwd(hipStream_t stream, const void* logits, int ldv, int V, const int64_t* labels, int M,
-                  const int* seg_bounds, int nseg, float* inv_count, float* loss_sum, float* row_lse) {
+                  const int* seg_bounds, int nseg, float* inv_count, float* loss_sum, float* row_lse, int logits_f32) {
     if (M <= 0) return 0;
     if (nseg < 1 || nseg > 4 || (ldv & 7) || ldv > CE_MAXC * 256 * 8 || V > ldv) return -1;
     hipLaunchKernelGGL(ce_count_kernel, dim3(1), dim3(1024), 0, stream, labels, M, V, seg_bounds, nseg, inv_count, loss_sum);
     MMB_CHECK_LAUNCH();
-    hipLaunchKernelGGL(ce_row_kernel<0>, dim3(M), dim3(256), 0, stream, (const bf16_t*)logits, ldv, V, labels, seg_bounds, nseg, inv_count, loss_sum,
-                       row_lse, (const float*)nullptr, (bf16_t*)nullptr, 0, (const int*)nullptr);
+    if (logits_f32)
+        hipLaunchKernelGGL((ce_row_kernel<0, true>), dim3(M), dim3(256), 0, stream, logits, ldv, V, labels, seg_bounds, nseg, inv_count, loss_sum,
+                           row_lse, (const float*)nullptr, (bf16_t*)nullptr, 0, (const int*)nullptr);
+    else
+        hipLaunchKernelGGL((ce_row_kernel<0, false>), dim3(M), dim3(256), 0, stream, logits, ldv, V, labels, seg_bounds, nseg, inv_count, loss_sum,
+                           row_lse, (const float*)nullptr, (bf16_t*)nullptr, 0, (const int*)nullptr);
     MMB_CHECK_LAUNCH();
     return 0;
 }
 
 int mmbert_ce_bwd(hipStream_t stream, const void* logits, int ldv, int V, const int64_t* labels, int M,
                   const int* seg_bounds, int nseg, const float* inv_count, const float* gscale, const float* row_lse, void* dlogits, int ldd,
-                  const int* rows, int nrows) {
+                  const int* rows, int nrows, int logits_f32) {
     if (M <= 0 || (rows && nrows <= 0)) return 0;
     if (nseg < 1 || nseg > 4 || (ldv & 7) || (ldd & 7) || ldv > CE_MAXC * 256 * 8 || V > ldv) return -1;
-    hipLaunchKernelGGL(ce_row_kernel<1>, dim3(rows ? nrows : M), dim3(256), 0, stream, (const bf16_t*)logits, ldv, V, labels, seg_bounds, nseg, inv_count,
-                       (float*)nullptr, (float*)row_lse, gscale, (bf16_t*)dlogits, ldd, rows);
+    if (logits_f32)
+        hipLaunchKernelGGL((ce_row_kernel<1, true>), dim3(rows ? nrows : M), dim3(256), 0, stream, logits, ldv, V, labels, seg_bounds, nseg, inv_count,
+                           (float*)nullptr, (float*)row_lse, gscale, (bf16_t*)dlogits, ldd, rows);
+    else
+        hipLaunchKernelGGL((ce_row_kernel<1, false>), dim3(rows ? nrows : M), dim3(256), 0, stream, logits, ldv, V, labels, seg_bounds, nseg, inv_count,
+                           (float*)nullptr, (float*)row_lse, gscale, (bf16_t*)dlogits, ldd, rows);
     MMB_CHECK_LAUNCH();
     return 0;
 }

@@ -475,7 +475,9 @@ class _MLMHeadFn(torch.autograd.Function):
         pre = torch.empty_like(y) if keep else None
         t0 = ops.gemm_nt(y, w["Wt"], bias=w["bt"], gelu=True, aux=pre)
         t, mean, rstd = ops.ln_fwd(t0, w["mlm_ln_g"], w["mlm_ln_b"], cfg.layer_norm_eps, stats=keep)
-        logits = ops.gemm_nt(t, w["word_h"], bias=w["pred_bias"])                 # [M, Vpad] bf16
+        # [M, Vpad]: bf16, or fp32 straight from the accumulators when the caller wants the reference's fp32 prediction scores
+        f32_scores = want_scores and getattr(top, "scores_dtype", torch.bfloat16) == torch.float32
+        logits = ops.gemm_nt(t, w["word_h"], bias=w["pred_bias"], out_f32=f32_scores)
         nseg = len(seg_bounds_host) - 1
         loss, inv, lse = ops.ce_fwd(logits, V, labels, seg_bounds, nseg)
         ctx.top, ctx.nseg, ctx.keep_logits = top, nseg, want_scores
@@ -533,7 +535,7 @@ class _MLMHeadFn(torch.autograd.Function):
                 dy.index_copy_(0, sel, ops.gemm_nt(dpre, w["WtT"]))
                 return dy, None, None, None, None, None, None, None
         # dense path: dlogits with the per-pass upstream gradients folded in; in place unless the scores were handed to the caller
-        dl = torch.empty_like(logits) if ctx.keep_logits else logits
+        dl = torch.empty(logits.shape, device=logits.device, dtype=torch.bfloat16) if (ctx.keep_logits or logits.dtype != torch.bfloat16) else logits
         ops.ce_bwd(logits, V, labels, seg_bounds, ctx.nseg, inv, gs, lse, dl)
         ops.gemm_tn(dl, t, w["g_word_pad"], bias_out=w["g_pred_bias"])          # tied decoder weight + prediction bias gradient
         dt = ops.gemm_nt(dl, w["wordT"])
@@ -1025,11 +1027,12 @@ class MMBertForPretraining(_GpuModelBase):
         self.cpc_zt, self.cpc_zv, self.cpc_za = (CPC(H, H, 1, "Tanh") for _ in range(3))
         self._init_runtime()
         self.return_scores = True
-        # dtype of the six returned prediction-score tensors (outputs[7], [9], [11]).  DEVIATION from the reference, which computes
-        # in fp32 and returns fp32: the vocabulary GEMM writes bf16 logits (the compute dtype of the whole path) and the default
-        # hands out zero-copy [B, S, vocab] views of them -- torch.float32 converts them (+2.2 GB of writes per headline step,
-        # ~3 %) for consumers that call ``.numpy()`` on them (REF:sampling.py-style readers); trainer.py never reads them.
-        self.scores_dtype = torch.bfloat16
+        # dtype of the returned prediction-score tensors (outputs[7], [9], [11]): zero-copy [B, S, vocab] views of the logits the
+        # vocabulary GEMM writes.  torch.float32 (the reference's dtype; consumers may call ``.numpy()`` on them) makes that GEMM
+        # store its fp32 accumulators (EPI_OUT_F32: +1.1 GB of writes per headline step); torch.bfloat16 stores bf16 (the compute
+        # dtype of the path).  Losses and gradients are bit-identical either way (the CE kernels round fp32 logits to bf16 as they
+        # load them).  trainer.py never reads the scores (``return_scores = False`` drops them altogether).
+        self.scores_dtype = torch.float32
         # heads through _HeadsFn (hand-written backward, csrc/heads.hip); False = the eager autograd form (_heads), in which
         # ap_loss / label_loss / nce and the relationship scores stay differentiable outputs
         self.fused_heads = os.environ.get("MMBERT_FUSED_HEADS", "1") != "0"
@@ -1136,8 +1139,8 @@ class MMBertForPretraining(_GpuModelBase):
 
     def forward(self, input_ids, token_type_ids, attention_mask, masked_labels, ap_label, sentiment):
         """REF:MMBertForPretraining.py:392-449, same arguments and the same 13-tuple + logits.  Deviations, all switchable:
-        * outputs[7], [9], [11] (prediction scores) are ``self.scores_dtype`` = bf16 views by default (reference: fp32; set
-          ``model.scores_dtype = torch.float32``), or None with ``model.return_scores = False``;
+        * outputs[7], [9], [11] (prediction scores) are ``self.scores_dtype`` views of the logits: fp32 by default like the reference's
+          (``torch.bfloat16`` stores them in the compute dtype: -1.1 GB of writes per headline step), None with ``return_scores = False``;
         * outputs[4], [5], [6] (ap_loss, label_loss, nce) are returned as VALUES by the fused heads path -- the one differentiable
           output is outputs[0], which is what trainer.py differentiates (REF:trainer.py:83); ``model.fused_heads = False``
           (the eager heads) keeps them in the autograd graph like the reference."""

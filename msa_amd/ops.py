@@ -42,7 +42,11 @@ def make_drop(p: float, seed: int, site: int) -> Tuple[int, int, float]:
 
 
 _tile_queues = {}
-dynamic_tile_queue = bool(int(__import__("os").environ.get("MMBERT_NT_DYNAMIC", "0")))    # set by parallel.DataParallel (world > 1)
+# the persistent NT GEMM draws its tiles from a device-side queue (mmbert_gemm_nt's tile_queue) instead of the static b, b+G, ...
+# schedule: round 2, same-process A/B of the train step on one GPU: 16.30 vs 16.55 ms per step (-1.5 %; round 1's queue, with its
+# host-side launch counter, had measured +0.4 %), and it is what data-parallel runs need while RCCL's channel kernels hold CUs.
+# MMBERT_NT_DYNAMIC=0 restores the static schedule.
+dynamic_tile_queue = bool(int(__import__("os").environ.get("MMBERT_NT_DYNAMIC", "1")))
 
 
 def _tile_queue(device) -> Optional[int]:
@@ -571,8 +575,9 @@ def ce_fwd(logits, V, labels, seg_bounds, nseg):
     inv = torch.empty(4, device=logits.device, dtype=torch.float32)
     loss = torch.empty(4, device=logits.device, dtype=torch.float32)
     lse = torch.empty(M, device=logits.device, dtype=torch.float32)
+    assert logits.dtype in (torch.bfloat16, torch.float32)
     _lib.check(lib.mmbert_ce_fwd(_stream(), logits.data_ptr(), logits.stride(0), V, labels.data_ptr(), M, seg_bounds.data_ptr(), nseg,
-                                 inv.data_ptr(), loss.data_ptr(), lse.data_ptr()), "mmbert_ce_fwd")
+                                 inv.data_ptr(), loss.data_ptr(), lse.data_ptr(), 1 if logits.dtype == torch.float32 else 0), "mmbert_ce_fwd")
     return loss[:nseg], inv, lse
 
 
@@ -583,7 +588,7 @@ def ce_bwd(logits, V, labels, seg_bounds, nseg, inv, gscale, lse, dlogits, rows=
     M = logits.shape[0]
     _lib.check(lib.mmbert_ce_bwd(_stream(), logits.data_ptr(), logits.stride(0), V, labels.data_ptr(), M, seg_bounds.data_ptr(), nseg,
                                  inv.data_ptr(), gscale.data_ptr(), lse.data_ptr(), dlogits.data_ptr(), dlogits.stride(0),
-                                 _ptr(rows), 0 if rows is None else rows.numel()), "mmbert_ce_bwd")
+                                 _ptr(rows), 0 if rows is None else rows.numel(), 1 if logits.dtype == torch.float32 else 0), "mmbert_ce_bwd")
     return dlogits
 
 

@@ -230,6 +230,8 @@ def test_fused_sequence_extension_matches_its_oracle():
     out2[0].mean().backward()
     assert out2[7] is None and abs(float(out2[0]) - float(out[0])) <= 2e-6 * abs(float(out[0]))
     for n, q in m2.named_parameters():
+        if "attention.self.key.bias" in n:
+            continue
         scale = float(g_full[n].abs().max())
         assert float((q.grad.float() - g_full[n]).abs().max()) <= 2e-3 * scale + 1e-7, n
 
@@ -262,6 +264,8 @@ def test_backward_on_unmasked_rows_only_equals_full_backward():
     for k in (7, 9, 11):
         assert torch.equal(oa[k], ob[k])                                    # forward is the same arithmetic row by row
     for n in ga:
+        if "attention.self.key.bias" in n:                  # true gradient 0: rounding noise on both sides
+            continue
         scale = float(gb[n].abs().max())
         assert float((ga[n] - gb[n]).abs().max()) <= 2e-3 * scale + 1e-7, n
     # labels on rows behind the last unmasked key (what the reference's pipeline produces: mask_tokens selects [PAD] positions,
@@ -292,6 +296,8 @@ def test_backward_on_unmasked_rows_only_equals_full_backward():
     for i in (0, 4, 5, 6):
         assert abs(float(res2[True][0][i]) - float(res2[False][0][i])) <= 1e-6 * abs(float(res2[False][0][i]))
     for n in res2[True][1]:
+        if "attention.self.key.bias" in n:
+            continue
         a, b = res2[True][1][n], res2[False][1][n]
         scale = float(b.abs().max())
         assert float((a - b).abs().max()) <= 2e-3 * scale + 1e-7, n
@@ -323,6 +329,8 @@ def test_sparse_backward_of_the_top_layer_equals_dense(train):
         res[sparse] = (float(out[0]), {n: q.grad.detach().float().clone() for n, q in m.named_parameters()})
     assert abs(res[True][0] - res[False][0]) <= 1e-6 * abs(res[False][0])        # same forward (fp32 atomics in the loss sums)
     for n in res[True][1]:
+        if "attention.self.key.bias" in n:                  # true gradient 0: rounding noise on both sides
+            continue
         a, b = res[True][1][n], res[False][1][n]
         scale = float(b.abs().max())
         assert float((a - b).abs().max()) <= 2e-3 * scale + 1e-7, (n, float((a - b).abs().max()), scale)
@@ -385,6 +393,8 @@ def test_training_without_returned_scores_equals_the_faithful_step(train):
         assert abs(a - b) <= 2e-6 * abs(b) + 1e-7, (res[False][0], res[True][0])
     assert float((res[False][1] - res[True][1]).abs().max()) <= 1e-5
     for n in res[True][2]:
+        if "attention.self.key.bias" in n:
+            continue
         a, b = res[False][2][n], res[True][2][n]
         scale = float(b.abs().max())
         assert float((a - b).abs().max()) <= 2e-3 * scale + 1e-7, (n, float((a - b).abs().max()), scale)
@@ -663,22 +673,40 @@ def test_fused_heads_match_oracle_in_fp32(B, H, num_labels):
 
 
 def test_scores_dtype_float32_for_numpy_consumers():
-    """outputs[7/9/11] are bf16 views by default (documented deviation); ``model.scores_dtype = torch.float32`` hands out what the
-    reference does: fp32 tensors that ``.cpu().numpy()`` accepts (REF:sampling.py-style consumers)."""
+    """outputs[7/9/11] are fp32 by default like the reference's (the vocabulary GEMM stores its fp32 accumulators): ``.cpu().numpy()``
+    works (REF:sampling.py-style consumers); ``model.scores_dtype = torch.bfloat16`` stores them in the compute dtype.  Losses are
+    identical (the CE kernels round fp32 logits to bf16 as they load them) and the bf16 scores are the rounded fp32 ones."""
     batch = batch_to(synthetic_batch(2, 50, 64, 64, seed=1), DEV)
     m = build(CFG1)
+    assert m.scores_dtype == torch.float32
     with torch.no_grad():
-        o16, _ = m(**batch)
-        m.scores_dtype = torch.float32
         o32, _ = m(**batch)
+        m.scores_dtype = torch.bfloat16
+        o16, _ = m(**batch)
     for k, S in ((7, 50), (9, 114), (11, 114)):
         assert o16[k].dtype == torch.bfloat16 and o32[k].dtype == torch.float32
         a = o32[k].cpu().numpy()
         assert a.shape == (2, S, CFG1["vocab"]) and np.isfinite(a).all()
-        assert np.array_equal(a, o16[k].float().cpu().numpy())
+        assert torch.equal(o32[k].to(torch.bfloat16), o16[k])
         with pytest.raises(TypeError):
             o16[k].cpu().numpy()
     assert o32[8].dtype == torch.float32 and o32[8].cpu().numpy().shape == (2, 2)
+    for i in (0, 4, 5, 6):
+        assert abs(float(o32[i]) - float(o16[i])) <= 1e-6 * abs(float(o16[i]))
+    # ... and in training: same loss, same gradients, whatever the score dtype
+    grads = {}
+    for dt in (torch.float32, torch.bfloat16):
+        m2 = build(CFG1)
+        m2.scores_dtype = dt
+        out, _ = m2(**batch)
+        out[0].mean().backward()
+        grads[dt] = (float(out[0]), {n: q.grad.detach().float().clone() for n, q in m2.named_parameters()})
+    assert abs(grads[torch.float32][0] - grads[torch.bfloat16][0]) <= 1e-6 * abs(grads[torch.bfloat16][0])
+    for n in grads[torch.float32][1]:
+        if "attention.self.key.bias" in n:
+            continue
+        a, b = grads[torch.float32][1][n], grads[torch.bfloat16][1][n]
+        assert float((a - b).abs().max()) <= 1e-3 * float(b.abs().max()) + 1e-8, n
 
 
 def test_label_on_a_cls_row_and_bad_labels():
@@ -706,6 +734,8 @@ def test_label_on_a_cls_row_and_bad_labels():
         assert calls == []                                       # never taken: not asked for, or a [CLS] row is labelled
         res[sparse] = {n: q.grad.detach().float().clone() for n, q in m.named_parameters()}
     for n in res[True]:
+        if "attention.self.key.bias" in n:
+            continue
         scale = float(res[False][n].abs().max())
         assert float((res[True][n] - res[False][n]).abs().max()) <= 2e-3 * scale + 1e-7, n
     lab_bad = batch["masked_labels"][0].clone()

@@ -34,7 +34,9 @@ def step(i):
     opt.step(); sched.step(); opt.zero_grad()
 
 
-attr_defaults = {k[5:]: getattr(model, k[5:]) for k in all_keys if k.startswith("attr.")}
+from msa_amd import ops as _ops
+attr_defaults = {k[5:]: getattr(model, k[5:], None) for k in all_keys if k.startswith("attr.")}
+ops_defaults = {k[4:]: getattr(_ops, k[4:]) for k in all_keys if k.startswith("ops.")}
 
 
 def setenv(env):
@@ -42,10 +44,14 @@ def setenv(env):
         os.environ.pop(k, None)
     for k, v in attr_defaults.items():
         setattr(model, k, v)
-    os.environ.update({k: v for k, v in env.items() if not k.startswith("attr.")})
+    for k, v in ops_defaults.items():
+        setattr(_ops, k, v)
+    os.environ.update({k: v for k, v in env.items() if not k.startswith(("attr.", "ops."))})
     for k, v in env.items():
         if k.startswith("attr."):                      # model attribute toggles: attr.NAME=python-literal
             setattr(model, k[5:], eval(v))
+        elif k.startswith("ops."):                     # msa_amd.ops module toggles: ops.NAME=python-literal
+            setattr(_ops, k[4:], eval(v))
 
 
 ts = {n: [] for n, _ in variants}
