@@ -548,3 +548,105 @@ def test_transpose_cast_and_casts(ops):
     y = torch.empty(5000, device=DEV, dtype=torch.bfloat16)
     ops.cast_f32_bf16(src[:5000].to(DEV), y)
     assert torch.equal(y.cpu(), src.to(torch.bfloat16))
+
+
+def test_step_prologue_matches_the_torch_formulation(ops):
+    """mmbert_prologue (two launches) against the element-wise formulation it replaced: (1 - mask) * -10000 per key from the
+    reference's mask dtypes (float64 text mask, float64 [B,P,D] visual mask and int64 speech mask read at feature 0 through
+    their own strides, REF:MMBertForPretraining.py:76), padded per sequence; kv_len by mmbert_attn_kv_len's rule; valid =
+    max(kv_len, last labelled position + 1); the ascending labelled-row list of mmbert_active_rows; the host words."""
+    B, T, Pv, Pa, V = 5, 12, 40, 33, 1000
+    g = torch.Generator().manual_seed(4)
+    lens_t = torch.randint(3, T + 1, (B,), generator=g)
+    tmask = (torch.arange(T)[None, :] < lens_t[:, None]).double()
+    ones_f, ones_i = torch.ones(B, T, dtype=torch.float64), torch.ones(B, T, dtype=torch.int64)
+    vis = torch.randn(B, Pv, 35, generator=g, dtype=torch.float64)
+    sp = torch.randn(B, Pa, 74, generator=g, dtype=torch.float64)
+    for b in range(B):
+        vis[b, int(torch.randint(Pv // 2, Pv + 1, (1,), generator=g)):] = 0
+        sp[b, int(torch.randint(1, Pa + 1, (1,), generator=g)):] = 0
+    vis[1, 2, 0] = 0.0                                      # a live frame whose feature 0 is exactly 0 (quirk B-2): masked as a key
+    vmask, smask = (vis != 0).double(), (sp != 0).long()
+    lens = [T, T + Pv, T + Pa]
+    tokens = B * sum(lens)
+    labels = torch.full((tokens,), -100, dtype=torch.int64)
+    sel = torch.rand(tokens, generator=g) < 0.05
+    labels[sel] = torch.randint(0, V, (int(sel.sum()),), generator=g)
+    labels[B * T + 2 * (T + Pv) + T + Pv - 1] = 7           # a label on the last (padded) pair row of sample 2, visual pass
+    labels[0] = 3                                           # ... and on a [CLS] row
+    labels[5] = V + 9                                       # ... and one outside the vocabulary
+    dev_masks = [t.to(DEV) for t in (tmask, ones_f, vmask, ones_i, smask)]
+    segs = [(dev_masks[0], 0, 0), (dev_masks[1], 1, 0), (dev_masks[2][:, :, 0], 1, T), (dev_masks[3], 2, 0), (dev_masks[4][:, :, 0], 2, T)]
+    pro = ops.prologue(segs, lens, B, labels.to(DEV), V, DEV)
+    torch.cuda.synchronize()
+    # reference formulation
+    layout = ops.SeqLayout([n for n in lens for _ in range(B)], 2, DEV)
+    kb_rows = torch.cat([((1.0 - tmask.float()) * -10000.0).reshape(-1),
+                         torch.cat(((1.0 - ones_f.float()) * -10000.0, (1.0 - vmask[:, :, 0].float()) * -10000.0), dim=1).reshape(-1),
+                         torch.cat(((1.0 - ones_i.float()) * -10000.0, (1.0 - smask[:, :, 0].float()) * -10000.0), dim=1).reshape(-1)])
+    kb_ref = ops.pad_key_bias(kb_rows.to(DEV), layout)
+    assert torch.equal(pro.key_bias, kb_ref)
+    kv_ref = ops.attn_kv_len(kb_ref, layout)
+    assert torch.equal(pro.kv_len, kv_ref)
+    row_seq = torch.from_numpy(layout._row_seq)
+    row_pos = torch.from_numpy(layout._row_pos)
+    lab_end = torch.zeros(3 * B, dtype=torch.int64).scatter_reduce_(0, row_seq, torch.where(labels != -100, row_pos + 1, 0), "amax")
+    valid_ref = torch.maximum(kv_ref.cpu().long(), lab_end)
+    assert torch.equal(pro.valid.cpu().long(), valid_ref)
+    assert int(valid_ref[B + 2]) == T + Pv                  # the labelled padded row keeps its whole sequence
+    ok = (labels >= 0) & (labels < V)
+    idx_ref = ok.nonzero().reshape(-1)
+    words = pro.words.cpu()
+    n = int(words[3 * B])
+    assert n == idx_ref.numel() and torch.equal(pro.idx[:n].cpu().long(), idx_ref)
+    assert torch.equal(words[:3 * B].long(), valid_ref)
+    first_rows = torch.tensor([int(s_) for s_ in layout.seq_start.cpu()])
+    assert int(words[3 * B + 1]) == int(ok[first_rows].sum()) >= 1                           # labelled [CLS] (position-0) rows
+    assert int(words[3 * B + 2]) == int(((labels != -100) & ~ok).sum()) == 1                 # the one out-of-vocabulary label
+    # no labels: valid = kv_len, nothing labelled
+    pro2 = ops.prologue(segs, lens, B, None, V, DEV)
+    assert torch.equal(pro2.valid, kv_ref) and int(pro2.words[3 * B]) == 0 and torch.equal(pro2.key_bias, kb_ref)
+
+
+def test_skinny_products_of_the_heads(ops):
+    """mmbert_skinny_mm / mmbert_skinny_wgrad (the heads' dense layers) against fp32 torch: y = x W^T + b with two sources and a row
+    range, dx = dy W as the inner-major form accumulated onto an existing tensor, odd sizes (N = 2, inner = 1 / 2), and the weight
+    / bias gradients of several layers in one launch."""
+    g = torch.Generator().manual_seed(7)
+    rnd_ = lambda *s: torch.randn(*s, generator=g)
+    B, H = 16, 768
+    X, W1, W2, b = rnd_(3 * B, H), rnd_(H, 2 * H) * 0.05, rnd_(2, H) * 0.05, rnd_(H)
+    Xd, W1d, W2d, bd = (t.to(DEV) for t in (X, W1, W2, b))
+    Y = torch.zeros(3 * B, H, device=DEV)
+    rel = torch.zeros(2 * B, 2, device=DEV)
+    b2 = rnd_(2).to(DEV)
+    ops.skinny_mm([(Y, bd, 0, False, [(Xd, W1d[:, :H], 0, 0), (Xd, W1d[:, H:], 0, 0)]),
+                   (rel, b2, 0, False, [(Xd[B:], W2d, 0, 0)])])
+    ref = X @ (W1[:, :H] + W1[:, H:]).t() + b
+    assert float((Y.cpu() - ref).abs().max()) < 2e-4 * float(ref.abs().max())
+    assert float((rel.cpu() - (X[B:] @ W2.t() + b2.cpu())).abs().max()) < 1e-4
+    # input gradients: dX = dY W (+ a second source on the rows B..3B only), accumulated onto an existing tensor
+    dY, drel = rnd_(3 * B, H), rnd_(2 * B, 2)
+    base = rnd_(3 * B, H)
+    dX = base.clone().to(DEV)
+    Wp = rnd_(H, H) * 0.05
+    ops.skinny_mm([(dX, None, 0, True, [(dY.to(DEV), Wp.to(DEV), 1, 0), (drel.to(DEV), W2d, 1, B)])])
+    ref = base + dY @ Wp
+    ref[B:] += drel @ W2
+    assert float((dX.cpu() - ref).abs().max()) < 2e-4 * float(ref.abs().max())
+    dlo, Wc2 = rnd_(B, 1), rnd_(1, H)
+    dT = torch.zeros(B, H, device=DEV)
+    ops.skinny_mm([(dT, None, 0, False, [(dlo.to(DEV), Wc2.to(DEV), 1, 0)])])
+    assert float((dT.cpu() - dlo @ Wc2).abs().max()) < 1e-5
+    # weight / bias gradients, several layers in one launch (one of them into a column slice of a wider weight)
+    T_ = rnd_(B, H)
+    gW, gb = torch.zeros(H, H, device=DEV), torch.zeros(H, device=DEV)
+    gW2, gb2 = torch.ones(2, H, device=DEV), torch.zeros(2, device=DEV)
+    gWide = torch.zeros(H, 2 * H, device=DEV)
+    dYb = dY[:B]
+    ops.skinny_wgrad([(dYb.to(DEV), T_.to(DEV), gW, gb), (drel.to(DEV), Xd[B:], gW2, gb2), (dYb.to(DEV), T_.to(DEV), gWide[:, H:], None)])
+    assert float((gW.cpu() - dYb.t() @ T_).abs().max()) < 2e-4 * float((dYb.t() @ T_).abs().max())
+    assert float((gb.cpu() - dYb.sum(0)).abs().max()) < 1e-4
+    assert float((gW2.cpu() - (1.0 + drel.t() @ X[B:])).abs().max()) < 2e-4 * float((drel.t() @ X[B:]).abs().max())
+    assert float((gb2.cpu() - drel.sum(0)).abs().max()) < 1e-4
+    assert float(gWide[:, :H].abs().max()) == 0.0 and torch.allclose(gWide[:, H:], gW, rtol=1e-5, atol=1e-6)
