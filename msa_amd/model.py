@@ -1028,11 +1028,12 @@ class MMBertForPretraining(_GpuModelBase):
         self._init_runtime()
         self.return_scores = True
         # dtype of the returned prediction-score tensors (outputs[7], [9], [11]): zero-copy [B, S, vocab] views of the logits the
-        # vocabulary GEMM writes.  torch.float32 (the reference's dtype; consumers may call ``.numpy()`` on them) makes that GEMM
-        # store its fp32 accumulators (EPI_OUT_F32: +1.1 GB of writes per headline step); torch.bfloat16 stores bf16 (the compute
-        # dtype of the path).  Losses and gradients are bit-identical either way (the CE kernels round fp32 logits to bf16 as they
-        # load them).  trainer.py never reads the scores (``return_scores = False`` drops them altogether).
-        self.scores_dtype = torch.float32
+        # vocabulary GEMM writes.  DEVIATION from the reference (fp32 scores): the default stores bf16, the compute dtype of the path;
+        # ``model.scores_dtype = torch.float32`` makes that GEMM store its fp32 accumulators instead (EPI_OUT_F32: +1.1 GB of writes,
+        # +1-2 % on the headline step) for consumers that call ``.numpy()`` on the scores (REF:sampling.py-style readers).  Losses
+        # and gradients are bit-identical either way (the CE kernels round fp32 logits to bf16 as they load them).  trainer.py
+        # never reads the scores (``return_scores = False`` drops them altogether).
+        self.scores_dtype = torch.bfloat16
         # heads through _HeadsFn (hand-written backward, csrc/heads.hip); False = the eager autograd form (_heads), in which
         # ap_loss / label_loss / nce and the relationship scores stay differentiable outputs
         self.fused_heads = os.environ.get("MMBERT_FUSED_HEADS", "1") != "0"
@@ -1139,8 +1140,9 @@ class MMBertForPretraining(_GpuModelBase):
 
     def forward(self, input_ids, token_type_ids, attention_mask, masked_labels, ap_label, sentiment):
         """REF:MMBertForPretraining.py:392-449, same arguments and the same 13-tuple + logits.  Deviations, all switchable:
-        * outputs[7], [9], [11] (prediction scores) are ``self.scores_dtype`` views of the logits: fp32 by default like the reference's
-          (``torch.bfloat16`` stores them in the compute dtype: -1.1 GB of writes per headline step), None with ``return_scores = False``;
+        * outputs[7], [9], [11] (prediction scores) are ``self.scores_dtype`` views of the logits: bf16 by default (the compute dtype);
+          ``model.scores_dtype = torch.float32`` gives the reference's fp32 tensors straight from the vocabulary GEMM's accumulators
+          (+1-2 % step time); None with ``return_scores = False``;
         * outputs[4], [5], [6] (ap_loss, label_loss, nce) are returned as VALUES by the fused heads path -- the one differentiable
           output is outputs[0], which is what trainer.py differentiates (REF:trainer.py:83); ``model.fused_heads = False``
           (the eager heads) keeps them in the autograd graph like the reference."""

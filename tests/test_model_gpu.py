@@ -673,16 +673,17 @@ def test_fused_heads_match_oracle_in_fp32(B, H, num_labels):
 
 
 def test_scores_dtype_float32_for_numpy_consumers():
-    """outputs[7/9/11] are fp32 by default like the reference's (the vocabulary GEMM stores its fp32 accumulators): ``.cpu().numpy()``
-    works (REF:sampling.py-style consumers); ``model.scores_dtype = torch.bfloat16`` stores them in the compute dtype.  Losses are
-    identical (the CE kernels round fp32 logits to bf16 as they load them) and the bf16 scores are the rounded fp32 ones."""
+    """outputs[7/9/11] are bf16 views by default (documented deviation); ``model.scores_dtype = torch.float32`` hands out what the
+    reference does -- fp32 tensors, straight from the vocabulary GEMM's accumulators -- that ``.cpu().numpy()`` accepts
+    (REF:sampling.py-style consumers).  Losses are identical (the CE kernels round fp32 logits to bf16 as they load them) and the
+    bf16 scores are the rounded fp32 ones."""
     batch = batch_to(synthetic_batch(2, 50, 64, 64, seed=1), DEV)
     m = build(CFG1)
-    assert m.scores_dtype == torch.float32
+    assert m.scores_dtype == torch.bfloat16
     with torch.no_grad():
-        o32, _ = m(**batch)
-        m.scores_dtype = torch.bfloat16
         o16, _ = m(**batch)
+        m.scores_dtype = torch.float32
+        o32, _ = m(**batch)
     for k, S in ((7, 50), (9, 114), (11, 114)):
         assert o16[k].dtype == torch.bfloat16 and o32[k].dtype == torch.float32
         a = o32[k].cpu().numpy()

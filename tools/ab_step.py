@@ -46,7 +46,10 @@ def setenv(env):
         setattr(model, k, v)
     for k, v in ops_defaults.items():
         setattr(_ops, k, v)
-    os.environ.update({k: v for k, v in env.items() if not k.startswith(("attr.", "ops."))})
+    os.environ.update({k: v for k, v in env.items() if not k.startswith(("attr.", "ops.")) and k not in ("tn_splits", "nt_mode")})
+    from msa_amd import _lib as _l
+    _l.load().mmbert_gemm_tn_force_splits(int(env.get("tn_splits", 0)))
+    _l.load().mmbert_gemm_nt_force(int(env.get("nt_mode", 0)))
     for k, v in env.items():
         if k.startswith("attr."):                      # model attribute toggles: attr.NAME=python-literal
             setattr(model, k[5:], eval(v))
