@@ -294,7 +294,7 @@ def main():
     }
     if dp is not None:
         res["config"]["dp"] = {"backend": torch.distributed.get_backend(), "forced_single_process": bool(a.force_dp and world == 1),
-                               "gemm_tile_queue": "dynamic", "bucket_mb": 32.0}
+                               "gemm_tile_queue": "dynamic, one counter per XCD", "bucket_mb": 32.0}
     if dense_ref is not None:
         res["dense_backward_reference"] = dense_ref
     if train_only is not None:

@@ -35,9 +35,11 @@ typedef struct ihipStream_t* mmbert_stream_t;   /* == hipStream_t */
 /* C[M,N] = epi(alpha * alpha_dev[0] * A[M,K] . B[N,K]^T).  Replaces nn.Linear forward (HF:175-177,
  * 289, 334, 347, 476, 493) and, with the transposed bf16 weight copy as B, its input gradient.
  * K % 64 == 0, N % 4 == 0.  Accepted epi: 0, 1, 1|2, 1|4, 4, 8, 16, 1|16. */
-/* tile_queue (may be NULL): two ints in device memory, zero before the first launch that uses them; the persistent kernel then
- * draws its tiles from this queue instead of the static b, b+G, ... schedule and leaves both ints zero again when it exits, so
- * one 8-byte buffer serves all launches of ONE stream (launches that share a queue must not overlap).  For processes whose
+/* tile_queue (may be NULL): 16 ints (64 bytes) in device memory, zero before the first launch that uses them -- eight fetch
+ * counters, one per XCD (a workgroup draws tiles of its own XCD's share, in order, so the L2 locality of the static walk holds),
+ * an exit counter, padding.  The persistent kernel then draws its tiles from this queue instead of the static b, b+G, ...
+ * schedule and leaves all of it zero again when it exits, so one 64-byte buffer serves all launches of ONE stream (launches
+ * that share a queue must not overlap).  For processes whose
  * GEMMs share the CUs with concurrently running kernels of another stream (data-parallel training: RCCL's channel kernels hold
  * CUs while the gradient all-reduce overlaps backward; a late workgroup would otherwise run its whole static share alone). */
 int mmbert_gemm_nt(mmbert_stream_t stream, const void* A, int lda, const void* B, int ldb, void* C, int ldc,

@@ -30,7 +30,8 @@ struct GemmNT {
     float alpha;
     uint32_t drop_stream, drop_thr16; float drop_scale;
     int kt_per_split; long long split_stride;     // gemm_nt_kernel only: split-K over blockIdx.z into fp32 slabs (0 = no split)
-    int* tile_counter; int* tile_counter_next;    // gemm_ntp_kernel only: dynamic tile queue = {fetch counter, exit counter} (null = static b, b+G, ...)
+    int* tile_counter; int* tile_counter_next;    // gemm_ntp_kernel only: dynamic tile queue = {8 fetch counters (one per XCD), exit counter} (null = static b, b+G, ...)
+    int queue_xcd;                                // 1: a workgroup draws from its XCD's counter (tile order stays v = x mod 8: the XCD's L2 keeps its panels); 0: one counter
     int group_m;                                  // gemm_ntp_kernel only: tile walk in groups of group_m row tiles (<= 1: row-major), see ntp_tile_mn
 };
 
@@ -607,8 +608,12 @@ __global__ __launch_bounds__(512, 2) void gemm_ntp_kernel(const GemmNT p) {
     const float alpha = p.alpha * (p.alpha_dev ? *p.alpha_dev : 1.0f);
 
     int first_fetch = 0;
+    // Queue: per XCD (workgroups are dealt round-robin: XCD = blockIdx & 7; G is a multiple of 8 whenever the queue is on), the k-th
+    // draw of XCD x is tile number G + 8 k + x -- the same residue class the static walk gives that XCD, so xcd_remap()'s contiguous
+    // chunk per XCD (and the grouped walk inside it) holds and only the order WITHIN an XCD's 32 CUs is dynamic.
+    const int qx = p.queue_xcd ? (int)(blockIdx.x & 7) : 0, qs = p.queue_xcd ? 8 : 1;
     if (p.tile_counter && tid == 0)
-        first_fetch = G + atomicAdd(p.tile_counter, 1);              // issued ahead of the prologue loads, parked behind them
+        first_fetch = G + qs * atomicAdd(p.tile_counter + qx, 1) + qx;   // issued ahead of the prologue loads, parked behind them
     bf16x8 a0[MI], b0[4], a1[MI], b1[4];
     if constexpr (STAG) {
         issue(0, cur, 0); issue(1, cur, 64); issue(2, cur, 128);
@@ -771,7 +776,10 @@ __global__ __launch_bounds__(512, 2) void gemm_ntp_kernel(const GemmNT p) {
         const __attribute__((address_space(4))) GemmNT& q = *(const __attribute__((address_space(4))) GemmNT*)kp;
         int fetched = 0;
         const bool fetcher = q.tile_counter && tid == 0 && vn < ntiles;     // the tile after the next one (if there is a next one)
-        if (fetcher) fetched = G + atomicAdd(q.tile_counter, 1);
+        if (fetcher) {
+            const int fx = q.queue_xcd ? (int)(blockIdx.x & 7) : 0;
+            fetched = G + (q.queue_xcd ? 8 : 1) * atomicAdd(q.tile_counter + fx, 1) + fx;
+        }
         int elane = lane;
         asm volatile("" : "+v"(elane));
         const int efr = elane & 15, efq = elane >> 4;
@@ -908,7 +916,7 @@ __global__ __launch_bounds__(512, 2) void gemm_ntp_kernel(const GemmNT p) {
         const __attribute__((address_space(4))) GemmNT& qe = *(const __attribute__((address_space(4))) GemmNT*)kpe;
         if (qe.tile_counter && tid == 0) {
             if (atomicAdd(qe.tile_counter_next, 1) == (int)gridDim.x - 1) {
-                atomicExch(qe.tile_counter, 0);
+                for (int x = 0; x < 8; ++x) atomicExch(qe.tile_counter + x, 0);
                 atomicExch(qe.tile_counter_next, 0);
             }
         }
@@ -932,9 +940,11 @@ static int launch_ntp_mi(hipStream_t s, const GemmNT& p) {
     if (int e = mmb_allow_lds((const void*)gemm_ntp_kernel<EPI, MI, MI == 8>, NTP_LDS_BYTES, attr_done)) return e;
     const int cus = device_cus();
     GemmNT q = p;
-    // Dynamic tile queue: the CALLER's two zero-initialised ints (mmbert_gemm_nt(..., tile_queue)); the kernel leaves them zero
-    // again (the last workgroup to exit resets them), so one 8-byte buffer serves every launch of a stream.  Launches with no
-    // more tiles than workgroups need no queue.
+    // Dynamic tile queue: the CALLER's 16 zero-initialised ints (mmbert_gemm_nt(..., tile_queue): 8 per-XCD fetch counters, exit
+    // counter, padding); the kernel leaves them zero again (the last workgroup to exit resets them), so one 64-byte buffer serves
+    // every launch of a stream.  Launches with no more tiles than workgroups need no queue.
+    static const int qg_env = getenv("MMBERT_NT_QUEUE_GLOBAL") ? atoi(getenv("MMBERT_NT_QUEUE_GLOBAL")) : 0;   // A/B switch: one counter
+    q.queue_xcd = (qg_env || (cus & 7)) ? 0 : 1;
     if (tiles <= cus) q.tile_counter = q.tile_counter_next = nullptr;
     // B panels that do not fit an XCD's L2 next to the A stream (> 3 MiB of weights: the vocabulary projection): grouped tile walk
     static const int gm_env = getenv("MMBERT_NT_GROUP_M") ? atoi(getenv("MMBERT_NT_GROUP_M")) : -1;        // A/B switch
@@ -1377,7 +1387,7 @@ int mmbert_gemm_nt(hipStream_t stream, const void* A, int lda, const void* B, in
     p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.ldr = ldr; p.ldaux = ldaux; p.ldu = ldu;
     p.alpha = alpha; p.drop_stream = drop_stream; p.drop_thr16 = drop_thr16; p.drop_scale = drop_scale;
     p.kt_per_split = 0; p.split_stride = 0; p.group_m = 1;
-    p.tile_counter = tile_queue; p.tile_counter_next = tile_queue ? tile_queue + 1 : nullptr;
+    p.tile_counter = tile_queue; p.tile_counter_next = tile_queue ? tile_queue + 8 : nullptr;
     switch (epi) {
         case 0: return dispatch_nt<0>(stream, p);
         case EPI_BIAS: return dispatch_nt<EPI_BIAS>(stream, p);

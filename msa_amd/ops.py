@@ -43,21 +43,23 @@ def make_drop(p: float, seed: int, site: int) -> Tuple[int, int, float]:
 
 _tile_queues = {}
 # the persistent NT GEMM draws its tiles from a device-side queue (mmbert_gemm_nt's tile_queue) instead of the static b, b+G, ...
-# schedule: round 2, same-process A/B of the train step on one GPU: 16.30 vs 16.55 ms per step (-1.5 %; round 1's queue, with its
-# host-side launch counter, had measured +0.4 %), and it is what data-parallel runs need while RCCL's channel kernels hold CUs.
-# MMBERT_NT_DYNAMIC=0 restores the static schedule.
-dynamic_tile_queue = bool(int(__import__("os").environ.get("MMBERT_NT_DYNAMIC", "1")))
+# schedule: what data-parallel runs need while RCCL's channel kernels hold CUs (parallel.DataParallel turns it on).  On an
+# otherwise idle GPU the static schedule is the faster one -- round 2, same-process A/B of the train step, after the grouped walk
+# of the vocabulary projection went in: static 15.99 ms, per-XCD queue 16.06 (+0.4 %), ONE global counter 16.22 (+1.5 %: any CU
+# takes the next tile, the XCD's L2 loses its panels -- that kernel's fetch 1.27 -> 4.2 GB, 750 -> 940 us) -- so it is off by
+# default there.  MMBERT_NT_DYNAMIC=1 turns it on everywhere.
+dynamic_tile_queue = bool(int(__import__("os").environ.get("MMBERT_NT_DYNAMIC", "0")))
 
 
 def _tile_queue(device) -> Optional[int]:
-    """The 8-byte tile queue of the persistent NT GEMM for the current stream (mmbert_gemm_nt's ``tile_queue``), or None for the
+    """The 64-byte tile queue (8 per-XCD fetch counters + exit counter) of the persistent NT GEMM for the current stream (mmbert_gemm_nt's ``tile_queue``), or None for the
     static schedule.  One zeroed buffer per (device, stream): the kernel leaves it zeroed, launches of one stream are ordered."""
     if not dynamic_tile_queue:
         return None
     key = (device, torch.cuda.current_stream().cuda_stream)
     q = _tile_queues.get(key)
     if q is None:
-        q = _tile_queues[key] = torch.zeros(2, device=device, dtype=torch.int32)
+        q = _tile_queues[key] = torch.zeros(16, device=device, dtype=torch.int32)
     return q.data_ptr()
 
 
