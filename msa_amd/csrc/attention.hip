@@ -144,6 +144,15 @@ __device__ __forceinline__ void lds_read16(f32x4& dst, unsigned lds_addr) {
 
 #define FWD_BUF 16640          // K 8192 | V 8192 | bias 256
 
+// Diagnostic build only (-DMMB_STAMPS, tools/stamp_attn.py): s_memtime stamps at the phase boundaries of a key tile, summed per
+// wave in SGPRs and stored once at the end.  No stamp exists in the product build.
+#ifdef MMB_STAMPS
+__device__ unsigned long long* g_attn_stamps = nullptr;
+#define ATT_STAMP(var) { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var) :: "memory"); __builtin_amdgcn_sched_barrier(0); }
+#else
+#define ATT_STAMP(var)
+#endif
+
 template <bool DROP>
 __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnArgs a) {
     __shared__ __attribute__((aligned(16))) char smem[2 * FWD_BUF];
@@ -214,14 +223,20 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnArgs a) {
 
     const unsigned baddr = lds0 + 16 * g;                    // bias tile: 4 consecutive keys per lane group
     const int ntile = (Skv + 63) >> 6;                       // trailing masked-out keys contribute exact zeros: their tiles are skipped
+#ifdef MMB_STAMPS
+    unsigned long long st0 = 0, st1 = 0, st2 = 0, st3 = 0, st4 = 0, t_wait = 0, t_qk = 0, t_soft = 0, t_pv = 0, t_begin = 0, t_end = 0;
+    ATT_STAMP(t_begin)
+#endif
     stage(0, 0);
     // the buffer index must be a compile-time constant: with a runtime index hipcc cannot prove that the
     // fragment reads do not alias the LDS-DMA it has just issued and drains vmcnt(0) in front of them
     auto tile_body = [&](auto buf_c, int t) {
         constexpr int buf = decltype(buf_c)::value;
         const int kv0 = t << 6;
+        ATT_STAMP(st0)
         __builtin_amdgcn_s_waitcnt(0x0F70);                  // vmcnt(0): tile t landed (tile t+1 is issued below, after the barrier)
         __builtin_amdgcn_s_barrier();                        // ... for every wave; buffer buf^1 (tile t-1) is free
+        ATT_STAMP(st1)
         if (t + 1 < ntile) stage(buf ^ 1, kv0 + 64);
         if (!wave_active) return;                            // a wave whose 32 rows lie past the sequence end only helps staging
         const char* Ks = smem + buf * FWD_BUF;
@@ -251,6 +266,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnArgs a) {
             tr_read<buf * FWD_BUF + 32 * 128>(vlo[1][d], vaddr[d]); tr_read<buf * FWD_BUF + 48 * 128>(vhi[1][d], vaddr[d]);
         }
         bf16x8 pf[2][2];
+        ATT_STAMP(st2)
 #pragma unroll
         for (int qb = 0; qb < 2; ++qb) {
             float tmax = rowmax16(s[qb][0], s[qb][1], s[qb][2], s[qb][3], mraw[qb]);   // running maximum folded in
@@ -294,6 +310,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnArgs a) {
                 }
             }
         }
+        ATT_STAMP(st3)
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the asm V reads
         __builtin_amdgcn_sched_barrier(0);
         typedef __attribute__((ext_vector_type(8))) short s16x8;
@@ -306,6 +323,10 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnArgs a) {
                 for (int qb = 0; qb < 2; ++qb)
                     o[qb][d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[qb][ks], o[qb][d], 0, 0, 0);
             }
+#ifdef MMB_STAMPS
+        ATT_STAMP(st4)
+        t_wait += st1 - st0; t_qk += st2 - st1; t_soft += st3 - st2; t_pv += st4 - st3;
+#endif
     };
     for (int t = 0; t < ntile; t += 2) {
         tile_body(std::integral_constant<int, 0>{}, t);
@@ -325,6 +346,13 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnArgs a) {
             if (g == 0) a.lse[(size_t)(qshift + qi[qb]) * a.heads + head] = (mraw[qb] * c2 + log2f(l)) * LN2;
         }
     }
+#ifdef MMB_STAMPS
+    ATT_STAMP(t_end)
+    if (g_attn_stamps && lane == 0) {
+        unsigned long long* o = g_attn_stamps + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 4 + wave) * 8;
+        o[0] = t_wait; o[1] = t_qk; o[2] = t_soft; o[3] = t_pv; o[4] = t_end - t_begin; o[5] = wave_active ? ntile : 0; o[6] = t_begin; o[7] = t_end;
+    }
+#endif
 }
 
 // =============================================================================================
@@ -786,6 +814,12 @@ int mmbert_attn_bwd(hipStream_t stream, const void* qkv, const void* ctx, const 
     MMB_CHECK_LAUNCH();
     return 0;
 }
+
+#ifdef MMB_STAMPS
+int mmbert_debug_set_attn_stamps(void* buf) {
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_attn_stamps), &buf, sizeof(buf));
+}
+#endif
 
 int mmbert_attn_kv_len(hipStream_t stream, const float* key_bias, const int* bias_start, const int* seq_len, int nseq, int* kv_len) {
     if (nseq <= 0) return 0;

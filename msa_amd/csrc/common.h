@@ -66,6 +66,9 @@ __host__ __device__ __forceinline__ uint32_t mmb_hash32(uint32_t x) {
 // seed = pair_idx * MMB_WEYL + stream is linear in the index: callers that walk an index grid keep a per-lane seed and add
 // (wave-uniform) multiples of MMB_WEYL instead of multiplying per pair
 __host__ __device__ __forceinline__ uint32_t mmb_pair_mix(uint32_t x) {
+#ifdef MMB_AB_FREE_HASH          // timing experiment only (tools/ab_attn.py): what the attention kernels would gain from a free hash
+    return x;
+#endif
     x ^= x >> 15; x *= 0x2C1B3C6Du; x ^= x >> 16;
     return x;
 }
