@@ -197,15 +197,18 @@ int mmbert_active_rows(mmbert_stream_t stream, const int64_t* labels, int M, int
  * [3B, H] array: modality-major (text, visual, speech).  See csrc/heads.hip for the notation.
  *   gate_fwd : g[m,b] = relu(Apre[m,b,:]).vw3[m] + vb3[m][0];  C[b, mH+k] = P[m,b,k] * g[m,b]   (vw3/vb3: host arrays of 3 device
  *              pointers -- the vt / vv / vs layers)
- *   loss_fwd : out4 = {ap_loss, label_loss, nce, ap_loss + label_loss - beta*nce}; seeds of the backward for upstream 1:
- *              dXP, dPc [3B,H] (CPC), drel [2B,2] (alignment CE), dlo [B] (label loss; pre-tanh when tanh_lo); nce_part: 3 floats
+ *   loss_fwd : out5 = {ap_loss, label_loss, nce, heads = ap_loss + label_loss - beta*nce, joint = alpha*mean(mlm[0..nmlm)) + heads}
+ *              (mlm: device array of the per-pass MLM losses, nmlm = 0: joint = heads; REF :427, :443); seeds of the backward for
+ *              upstream 1: dXP, dPc [3B,H] (CPC), drel [2B,2] (alignment CE), dlo [B] (label loss; pre-tanh when tanh_lo);
+ *              nce_part: 3 floats
  *   scale    : x *= *s (device scalar: the upstream gradient)
  *   gate_bwd : dg = <dC[b,mH:], P[m,b]> [3B]; dP = dC_m*g + dPc; dApre = dg*vw3[m]*(Apre>0); E = dg*relu(Apre) [3B,H] (the column
  *              sums of E and dg over b are the gradients of the vt / vv / vs layers: mmbert_heads_colsum)
  *   tanh_bwd : dpre = dP*(1-P^2);   colsum: dst_i[c] += sum_r src_i[r][c] for up to 16 segments (bias and gate-vector gradients) */
 int mmbert_heads_gate_fwd(mmbert_stream_t stream, const float* P, const float* Apre, const float* const* vw3, const float* const* vb3, int B, int H, float* g, float* C);
 int mmbert_heads_loss_fwd(mmbert_stream_t stream, const float* P, const float* XP, const float* rel, const int64_t* ap, const float* lo, const float* sent,
-                          int B, int H, float beta, int tanh_lo, float* out4, float* dXP, float* dPc, float* drel, float* dlo, float* nce_part);
+                          int B, int H, float beta, int tanh_lo, float* out5, float* dXP, float* dPc, float* drel, float* dlo, float* nce_part,
+                          const float* mlm, int nmlm, float alpha);
 int mmbert_heads_scale(mmbert_stream_t stream, float* x, size_t n, const float* s);
 int mmbert_heads_gate_bwd(mmbert_stream_t stream, const float* dC, const float* P, const float* Apre, const float* g, const float* const* vw3, const float* dPc,
                           int B, int H, float* dP, float* dApre, float* E, float* dg);

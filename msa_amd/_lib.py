@@ -49,7 +49,7 @@ SIGNATURES = {
     "mmbert_prologue": (I, [P, I, P, P, P, P, P, P, P, I, P, I, P, I, P, P, P, P, P, P]),
     "mmbert_split_rows": (I, [P, P, P, P, P, P, I, I, I, P, P]),
     "mmbert_heads_gate_fwd": (I, [P, P, P, P, P, I, I, P, P]),
-    "mmbert_heads_loss_fwd": (I, [P, P, P, P, P, P, P, I, I, F, I, P, P, P, P, P, P]),
+    "mmbert_heads_loss_fwd": (I, [P, P, P, P, P, P, P, I, I, F, I, P, P, P, P, P, P, P, I, F]),
     "mmbert_heads_scale": (I, [P, P, SZ, P]),
     "mmbert_heads_gate_bwd": (I, [P, P, P, P, P, P, P, I, I, P, P, P, P]),
     "mmbert_heads_tanh": (I, [P, P, SZ]),

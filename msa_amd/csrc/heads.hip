@@ -37,37 +37,48 @@ __global__ __launch_bounds__(256) void heads_gate_fwd_kernel(const float* __rest
     for (int k = threadIdx.x; k < H; k += 256) C[(size_t)b * 3 * H + (size_t)m * H + k] = P[(size_t)row * H + k] * gv;
 }
 
-// CPC terms and their backward seeds (for an upstream gradient of 1; backward scales them).  grid = 3: one workgroup per
-// modality, everything for its [B,H] pair of arrays in LDS (rows padded by one float: column reads of different rows hit
-// different banks), B <= 16, H <= 1024, 256 threads.
+// CPC terms and their backward seeds (for an upstream gradient of 1; backward scales them).  grid = (3, ceil(H / 64)): a
+// workgroup per modality and 64-column block.  Every workgroup builds the modality's 16 x 16 similarity matrix from ALL columns
+// (both [B,H] arrays normalised into LDS, 98 KB from L2: the round-1 kernel did this in 3 workgroups and then walked the H
+// gradient columns in them, 46 us of a 16.4-ms step), then writes the gradients of its own 64 columns.  B <= 16, H <= 1024, H % 4 == 0.
 //   nce_part[m] = mean_b (logsumexp_b' S[b][b'] - S[b][b]),  S = Xn XPn^T,  Xn = P_m/|.|, XPn = XP_m/|.|
 //   dS[b][b'] = (-beta/B) (softmax_b'(S[b])[b'] - delta);  dXn = dS XPn, dXPn = dS^T Xn;  through y = x/|x|: dx = (dy - y<y,dy>)/|x|
+//   with <Xn[b], dXn[b]> = sum_j dS[b][j] S[b][j] and <XPn[b], dXPn[b]> = sum_j dS[j][b] S[j][b] (no pass over the columns)
 //   dPc [3,B,H] = d loss / d P (CPC part), dXP [3,B,H] = d loss / d XP
 __global__ __launch_bounds__(256) void heads_loss_fwd_kernel(const float* __restrict__ P, const float* __restrict__ XP, int B, int H, float beta,
                                                              float* __restrict__ dXP, float* __restrict__ dPc, float* __restrict__ nce_part) {
-    extern __shared__ float sm[];                       // Xn [16][HP] | XPn [16][HP] | dS [16][16] | n1 [16] | n2 [16] | red [32][4]
-    const int HP = H + 1;
+    extern __shared__ __attribute__((aligned(16))) float sm[];   // Xn [16][HP] | XPn [16][HP] | dS [16][16] | SdS [16][16] | n1 [16] | n2 [16] | dots [32] | red [4]
+    const int HP = H + 4;                               // rows stay 16-byte aligned; 4 floats of skew between rows
     const int m = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    float* Xn = sm; float* XPn = sm + 16 * HP; float* dS = XPn + 16 * HP; float* n1 = dS + 256; float* n2 = n1 + 16; float* red = n2 + 16;
+    float* Xn = sm; float* XPn = sm + 16 * HP; float* dS = XPn + 16 * HP; float* SdS = dS + 256;
+    float* n1 = SdS + 256; float* n2 = n1 + 16; float* dots = n2 + 16; float* red = dots + 32;
     const float* Pm = P + (size_t)m * B * H; const float* XPm = XP + (size_t)m * B * H;
     const int r = tid >> 4, q = tid & 15;               // 16 threads per row
-    // rows into LDS + norms (16-lane shuffles: a row's 16 threads sit in one wave)
+    // rows into LDS (float4, 256 contiguous bytes per row and step), norms by 16-lane shuffles (a row's 16 threads sit in one wave)
     float sa = 0.f, sc = 0.f;
-    for (int k = q; k < H; k += 16) {
-        const float x = r < B ? Pm[(size_t)r * H + k] : 0.f, y = r < B ? XPm[(size_t)r * H + k] : 0.f;
-        Xn[r * HP + k] = x; XPn[r * HP + k] = y;
-        sa += x * x; sc += y * y;
+    for (int k = 4 * q; k < H; k += 64) {
+        const float4 z = {0.f, 0.f, 0.f, 0.f};
+        const float4 x = r < B ? *(const float4*)(Pm + (size_t)r * H + k) : z, y = r < B ? *(const float4*)(XPm + (size_t)r * H + k) : z;
+        *(float4*)(Xn + r * HP + k) = x; *(float4*)(XPn + r * HP + k) = y;
+        sa += x.x * x.x + x.y * x.y + x.z * x.z + x.w * x.w; sc += y.x * y.x + y.y * y.y + y.z * y.z + y.w * y.w;
     }
 #pragma unroll
     for (int o = 8; o >= 1; o >>= 1) { sa += __shfl_xor(sa, o, 64); sc += __shfl_xor(sc, o, 64); }
     const float nx = sqrtf(sa), ny = sqrtf(sc);
     if (q == 0) { n2[r] = nx; n1[r] = ny; }
     const float ix = r < B ? 1.f / nx : 0.f, iy = r < B ? 1.f / ny : 0.f;
-    for (int k = q; k < H; k += 16) { Xn[r * HP + k] *= ix; XPn[r * HP + k] *= iy; }
+    for (int k = 4 * q; k < H; k += 64) {               // each thread rescales what it wrote
+        float4 x = *(float4*)(Xn + r * HP + k), y = *(float4*)(XPn + r * HP + k);
+        x.x *= ix; x.y *= ix; x.z *= ix; x.w *= ix; y.x *= iy; y.y *= iy; y.z *= iy; y.w *= iy;
+        *(float4*)(Xn + r * HP + k) = x; *(float4*)(XPn + r * HP + k) = y;
+    }
     __syncthreads();
     // S[b = r][c = q]
     float sv = 0.f;
-    for (int k = 0; k < H; ++k) sv += Xn[r * HP + k] * XPn[q * HP + k];
+    for (int k = 0; k < H; k += 4) {
+        const float4 x = *(const float4*)(Xn + r * HP + k), y = *(const float4*)(XPn + q * HP + k);
+        sv += x.x * y.x + x.y * y.y + x.z * y.z + x.w * y.w;
+    }
     const bool valid = r < B && q < B;
     float mx = valid ? sv : -INFINITY;
 #pragma unroll
@@ -77,54 +88,36 @@ __global__ __launch_bounds__(256) void heads_loss_fwd_kernel(const float* __rest
     for (int o = 8; o >= 1; o >>= 1) se += __shfl_xor(se, o, 64);
     const float neg = mx + logf(se);
     const float w = -beta / (float)B;
-    dS[r * 16 + q] = valid ? w * (e / se - (q == r ? 1.f : 0.f)) : 0.f;
+    const float ds = valid ? w * (e / se - (q == r ? 1.f : 0.f)) : 0.f;
+    dS[r * 16 + q] = ds;
+    SdS[r * 16 + q] = valid ? ds * sv : 0.f;
     float part = (valid && q == r) ? (neg - sv) / (float)B : 0.f;
     part = wave_sum(part);
     if (lane == 0) red[wv] = part;
     __syncthreads();
-    if (tid == 0) nce_part[m] = red[0] + red[1] + red[2] + red[3];
-    __syncthreads();
-    // gradients: thread owns columns k = tid + 256 i
-    float av[4][16], cv[4][16], dx[16], dy[16];
-#pragma unroll
-    for (int b = 0; b < 16; ++b) { dx[b] = 0.f; dy[b] = 0.f; }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int k = tid + 256 * i;
-        if (k < H) {
-            float x[16], y[16];
-#pragma unroll
-            for (int j = 0; j < 16; ++j) { x[j] = Xn[j * HP + k]; y[j] = XPn[j * HP + k]; }
-#pragma unroll
-            for (int b = 0; b < 16; ++b) {
-                float a = 0.f, c = 0.f;
-#pragma unroll
-                for (int j = 0; j < 16; ++j) { a += dS[b * 16 + j] * y[j]; c += dS[j * 16 + b] * x[j]; }
-                av[i][b] = a; cv[i][b] = c;
-                dx[b] += a * x[b]; dy[b] += c * y[b];
-            }
-        }
-    }
-    // <y, dy> per row: 32 block-wide sums (wave shuffles, then 4 partials each through LDS)
-    __syncthreads();
-#pragma unroll
-    for (int b = 0; b < 16; ++b) {
-        const float u = wave_sum(dx[b]), v = wave_sum(dy[b]);
-        if (lane == 0) { red[b * 4 + wv] = u; red[(16 + b) * 4 + wv] = v; }
+    if (tid == 0 && blockIdx.y == 0) nce_part[m] = red[0] + red[1] + red[2] + red[3];
+    if (tid < 32) {                                     // <Xn[b], dXn[b]> (row sums of S o dS) and <XPn[b], dXPn[b]> (column sums)
+        const int b = tid & 15;
+        float t = 0.f;
+        for (int j2 = 0; j2 < 16; ++j2) t += tid < 16 ? SdS[b * 16 + j2] : SdS[j2 * 16 + b];
+        dots[tid] = t;
     }
     __syncthreads();
+    // gradients of this workgroup's 64 columns: thread = (column c, 4 rows b = 4 rg ..)
+    const int c = lane, rg = wv, k = blockIdx.y * 64 + c;
+    if (k < H) {
+        float x[16], y[16];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int k = tid + 256 * i;
-        if (k < H) {
+        for (int j2 = 0; j2 < 16; ++j2) { x[j2] = Xn[j2 * HP + k]; y[j2] = XPn[j2 * HP + k]; }
 #pragma unroll
-            for (int b = 0; b < 16; ++b) {
-                if (b < B) {
-                    const float dotx = red[b * 4] + red[b * 4 + 1] + red[b * 4 + 2] + red[b * 4 + 3];
-                    const float doty = red[(16 + b) * 4] + red[(16 + b) * 4 + 1] + red[(16 + b) * 4 + 2] + red[(16 + b) * 4 + 3];
-                    dPc[((size_t)m * B + b) * H + k] = (av[i][b] - Xn[b * HP + k] * dotx) / n2[b];
-                    dXP[((size_t)m * B + b) * H + k] = (cv[i][b] - XPn[b * HP + k] * doty) / n1[b];
-                }
+        for (int bb = 0; bb < 4; ++bb) {
+            const int b = 4 * rg + bb;
+            if (b < B) {
+                float a = 0.f, cc = 0.f;
+#pragma unroll
+                for (int j2 = 0; j2 < 16; ++j2) { a += dS[b * 16 + j2] * y[j2]; cc += dS[j2 * 16 + b] * x[j2]; }
+                dPc[((size_t)m * B + b) * H + k] = (a - x[b] * dots[b]) / n2[b];
+                dXP[((size_t)m * B + b) * H + k] = (cc - y[b] * dots[16 + b]) / n1[b];
             }
         }
     }
@@ -135,7 +128,8 @@ __global__ __launch_bounds__(256) void heads_loss_fwd_kernel(const float* __rest
 //   out: [ap_loss, label_loss, nce, heads_loss];  seeds: drel [2B,2], dlo [B] (gradient w.r.t. the PRE-tanh output when tanh_lo)
 __global__ __launch_bounds__(256) void heads_loss_finish_kernel(const float* __restrict__ rel, const int64_t* __restrict__ ap, const float* __restrict__ lo,
                                                                 const float* __restrict__ sent, const float* __restrict__ nce_part, int B, float beta,
-                                                                int tanh_lo, float* __restrict__ out, float* __restrict__ drel, float* __restrict__ dlo) {
+                                                                int tanh_lo, float* __restrict__ out, float* __restrict__ drel, float* __restrict__ dlo,
+                                                                const float* __restrict__ mlm, int nmlm, float alpha) {
     __shared__ float red[4];
     const int tid = threadIdx.x;
     float ce = 0.f, se = 0.f;
@@ -158,7 +152,11 @@ __global__ __launch_bounds__(256) void heads_loss_finish_kernel(const float* __r
     se = block_sum_256(se, red);
     if (tid == 0) {
         const float nce = nce_part[0] + nce_part[1] + nce_part[2];
-        out[0] = ce; out[1] = se; out[2] = nce; out[3] = ce + se - beta * nce;
+        const float heads = ce + se - beta * nce;
+        out[0] = ce; out[1] = se; out[2] = nce; out[3] = heads;
+        float ms = 0.f;                                  // joint = alpha * mean(mlm) + heads   (REF :427, :443)
+        for (int i = 0; i < nmlm; ++i) ms += mlm[i];
+        out[4] = nmlm > 0 ? alpha * (ms / (float)nmlm) + heads : heads;
     }
 }
 
@@ -354,17 +352,18 @@ int mmbert_heads_gate_fwd(hipStream_t stream, const float* P, const float* Apre,
 }
 
 int mmbert_heads_loss_fwd(hipStream_t stream, const float* P, const float* XP, const float* rel, const int64_t* ap, const float* lo, const float* sent,
-                          int B, int H, float beta, int tanh_lo, float* out4, float* dXP, float* dPc, float* drel, float* dlo, float* nce_part) {
+                          int B, int H, float beta, int tanh_lo, float* out5, float* dXP, float* dPc, float* drel, float* dlo, float* nce_part,
+                          const float* mlm, int nmlm, float alpha) {
     if (B <= 0) return 0;
-    if (H > 1024 || B > 16) return -1;
-    const size_t lds = ((size_t)2 * 16 * (H + 1) + 256 + 32 + 128) * sizeof(float);
-    if (lds > 160 * 1024 - 256) return -1;                   // the kernel also has a few static LDS words
-    constexpr int LDS_MAX = (2 * 16 * (1024 + 1) + 256 + 32 + 128) * (int)sizeof(float);     // the H = 1024 request: allowed once per device
+    if (H > 1024 || (H & 3) || B > 16 || nmlm < 0 || (nmlm > 0 && !mlm)) return -1;
+    const size_t lds = ((size_t)2 * 16 * (H + 4) + 512 + 32 + 32 + 4) * sizeof(float);
+    constexpr int LDS_MAX = (2 * 16 * (1024 + 4) + 512 + 32 + 32 + 4) * (int)sizeof(float);     // the H = 1024 request: allowed once per device
     static std::atomic<unsigned long long> attr_done{0};
     if (int e = mmb_allow_lds((const void*)heads_loss_fwd_kernel, LDS_MAX, attr_done)) return e;
-    hipLaunchKernelGGL(heads_loss_fwd_kernel, dim3(3), dim3(256), lds, stream, P, XP, B, H, beta, dXP, dPc, nce_part);
+    hipLaunchKernelGGL(heads_loss_fwd_kernel, dim3(3, (H + 63) / 64), dim3(256), lds, stream, P, XP, B, H, beta, dXP, dPc, nce_part);
     MMB_CHECK_LAUNCH();
-    hipLaunchKernelGGL(heads_loss_finish_kernel, dim3(1), dim3(256), 0, stream, rel, ap, lo, sent, (const float*)nce_part, B, beta, tanh_lo, out4, drel, dlo);
+    hipLaunchKernelGGL(heads_loss_finish_kernel, dim3(1), dim3(256), 0, stream, rel, ap, lo, sent, (const float*)nce_part, B, beta, tanh_lo, out5, drel, dlo,
+                       mlm, nmlm, alpha);
     MMB_CHECK_LAUNCH();
     return 0;
 }

@@ -441,16 +441,21 @@ def _active_row_count(rows) -> int:
 
 class _MLMHeadFn(torch.autograd.Function):
     """decoder(LN(gelu(dense(seq)))) + per-pass CrossEntropy(ignore -100)
-    (HF:466-496 via REF:MMBertForPretraining.py:293,381-384).  Returns (loss[nseg], logits or None)."""
+    (HF:466-496 via REF:MMBertForPretraining.py:293,381-384).  Returns (loss[nseg], logits or None, first): ``first`` = the rows
+    ``first_rows`` of y in fp32 (the [CLS] rows the other heads read) -- handed out here so that y has ONE consumer in the autograd
+    graph and its gradient is assembled once (labelled rows copied in, [CLS] rows added) instead of two [tokens, H] tensors and
+    their sum."""
 
     @staticmethod
-    def forward(ctx, y, anchor, top, labels, seg_bounds_host, seg_bounds, want_scores, rows=None):
+    def forward(ctx, y, anchor, top, labels, seg_bounds_host, seg_bounds, want_scores, rows=None, first_rows=None):
         cfg, w = top.config, top._w
         M, H = y.shape
         V, Vp = cfg.vocab_size, top._flat.vpad
         keep = ctx.needs_input_grad[0]
         y = y.contiguous()
         ctx.compact = False
+        ctx.first_rows = first_rows
+        first = y.index_select(0, first_rows).float() if first_rows is not None else None
         if (not want_scores) and keep and rows is not None and getattr(top, "sparse_mlm_backward", True):
             # the caller does not want the prediction scores: the whole head runs on the labelled rows only (the loss is a mean
             # over them; trainer.py never reads the scores) -- forward included
@@ -471,7 +476,7 @@ class _MLMHeadFn(torch.autograd.Function):
                 ctx.top, ctx.nseg, ctx.compact, ctx.M = top, nseg, True, M
                 ctx.set_materialize_grads(False)
                 ctx.save_for_backward(y_c, pre_c, t0_c, mean_c, rstd_c, t_c, logits_c, labels_c, bounds_c, inv, lse, sel)
-                return loss.clone(), None
+                return loss.clone(), None, first
         pre = torch.empty_like(y) if keep else None
         t0 = ops.gemm_nt(y, w["Wt"], bias=w["bt"], gelu=True, aux=pre)
         t, mean, rstd = ops.ln_fwd(t0, w["mlm_ln_g"], w["mlm_ln_b"], cfg.layer_norm_eps, stats=keep)
@@ -480,7 +485,7 @@ class _MLMHeadFn(torch.autograd.Function):
         logits = ops.gemm_nt(t, w["word_h"], bias=w["pred_bias"], out_f32=f32_scores)
         nseg = len(seg_bounds_host) - 1
         loss, inv, lse = ops.ce_fwd(logits, V, labels, seg_bounds, nseg)
-        ctx.top, ctx.nseg, ctx.keep_logits = top, nseg, want_scores
+        ctx.top, ctx.nseg, ctx.keep_logits, ctx.M = top, nseg, want_scores, M
         ctx.set_materialize_grads(False)      # or autograd zero-fills a [tokens, vocab] gradient for the returned scores
         # Rows without a label have an exactly-zero CE gradient (ignore_index): backward needs the labelled rows only (~2 % of
         # the packed tokens).  ``rows`` = (device row list, pinned host count, event), normally made by mlm_active_rows() at
@@ -493,14 +498,23 @@ class _MLMHeadFn(torch.autograd.Function):
         out_logits = logits if want_scores else None
         if out_logits is not None:
             ctx.mark_non_differentiable(out_logits)
-        return loss.clone(), out_logits
+        return loss.clone(), out_logits, first
 
     @staticmethod
-    def backward(ctx, dloss, _unused):
+    def backward(ctx, dloss, _unused, dfirst=None):
+        dy = _MLMHeadFn._backward(ctx, dloss)
+        if dfirst is not None:                                # a [CLS] row may also carry a label: add, after the copy
+            if dy is None:
+                dy = torch.zeros((ctx.M, dfirst.shape[1]), device=dfirst.device, dtype=torch.bfloat16)
+            dy.index_add_(0, ctx.first_rows, dfirst.to(dy.dtype))
+        return dy, None, None, None, None, None, None, None, None
+
+    @staticmethod
+    def _backward(ctx, dloss):
         w = ctx.top._w
         V = ctx.top.config.vocab_size
         if dloss is None:
-            return None, None, None, None, None, None, None, None
+            return None
         gs = dloss.contiguous().float()
         if ctx.compact:
             y_c, pre_c, t0_c, mean_c, rstd_c, t_c, logits_c, labels_c, bounds_c, inv, lse, sel = ctx.saved_tensors
@@ -512,7 +526,7 @@ class _MLMHeadFn(torch.autograd.Function):
             ops.gemm_tn(dpre, y_c, w["g_Wt"], bias_out=w["g_bt"])
             dy = torch.zeros((ctx.M, y_c.shape[1]), device=y_c.device, dtype=y_c.dtype)
             dy.index_copy_(0, sel, ops.gemm_nt(dpre, w["WtT"]))
-            return dy, None, None, None, None, None, None, None
+            return dy
         y, pre, t0, mean, rstd, t, logits, labels, seg_bounds, inv, lse = ctx.saved_tensors
         M = y.shape[0]
         if ctx.rows is not None:
@@ -521,7 +535,7 @@ class _MLMHeadFn(torch.autograd.Function):
             if 2 * n <= M:
                 dy = torch.zeros_like(y)
                 if n == 0:
-                    return dy, None, None, None, None, None, None, None
+                    return dy
                 idx = idx_all[:n]
                 sel = idx.long()
                 dl = torch.empty((n, logits.shape[1]), device=y.device, dtype=torch.bfloat16)
@@ -533,7 +547,7 @@ class _MLMHeadFn(torch.autograd.Function):
                 dpre = ops.gelu_bwd(dt0, pre_c)
                 ops.gemm_tn(dpre, y_c, w["g_Wt"], bias_out=w["g_bt"])
                 dy.index_copy_(0, sel, ops.gemm_nt(dpre, w["WtT"]))
-                return dy, None, None, None, None, None, None, None
+                return dy
         # dense path: dlogits with the per-pass upstream gradients folded in; in place unless the scores were handed to the caller
         dl = torch.empty(logits.shape, device=logits.device, dtype=torch.bfloat16) if (ctx.keep_logits or logits.dtype != torch.bfloat16) else logits
         ops.ce_bwd(logits, V, labels, seg_bounds, ctx.nseg, inv, gs, lse, dl)
@@ -542,8 +556,7 @@ class _MLMHeadFn(torch.autograd.Function):
         dt0 = ops.ln_bwd(dt, t0, mean, rstd, w["mlm_ln_g"], w["g_mlm_ln_g"], w["g_mlm_ln_b"])
         dpre = ops.gelu_bwd(dt0, pre)
         ops.gemm_tn(dpre, y, w["g_Wt"], bias_out=w["g_bt"])
-        dy = ops.gemm_nt(dpre, w["WtT"])
-        return dy, None, None, None, None, None, None, None
+        return ops.gemm_nt(dpre, w["WtT"])
 
 
 # ================================================================================================
@@ -915,7 +928,7 @@ class MMBertPreTrainingHeads(nn.Module):
         top._ensure_ready(y.device)
         labels = torch.full((B * S,), -100, dtype=torch.long, device=y.device)
         bounds = [0, B * S]
-        _, logits = _MLMHeadFn.apply(y, self.predictions.transform.LayerNorm.weight, top, labels, bounds, torch.tensor(bounds, dtype=torch.int32, device=y.device), True)
+        _, logits, _ = _MLMHeadFn.apply(y, self.predictions.transform.LayerNorm.weight, top, labels, bounds, torch.tensor(bounds, dtype=torch.int32, device=y.device), True)
         scores = logits.view(B, S, -1)[:, :, :top.config.vocab_size]
         if joint:
             return scores, self.align(sequence_output[:, 0])
@@ -932,7 +945,9 @@ class _HeadsFn(torch.autograd.Function):
     values (non-differentiable)."""
 
     @staticmethod
-    def forward(ctx, first, top, ap, sent):
+    def forward(ctx, first, top, ap, sent, mlm=None):
+        """``mlm`` (fp32 vector of the per-pass MLM losses, optional): the returned loss is then the joint loss
+        alpha * mean(mlm) + heads_loss (REF :427, :443) -- assembled by the loss kernel, one autograd node instead of seven."""
         B, H = first.shape[0] // 3, first.shape[1]
         pool, al, sr, at = top.bert.pooler.dense, top.cls.align, top.cls.seq_relationship, top.attn
         vs3 = (top.vt, top.vv, top.vs)
@@ -957,20 +972,23 @@ class _HeadsFn(torch.autograd.Function):
         ops.skinny_mm([(lo, c2.bias, 0, False, [(T, c2.weight, 0, 0)])]                               # :415
                       + [(XP[m], qs[m].bias, 0, False, [(T, qs[m].weight, 0, 0)]) for m in range(3)])  # REF:MMBertEmbedding.py:22
         tanh_lo = top.num_labels == 1
-        out4, seeds = ops.heads_loss_fwd(P, XP, rel, ap, lo, sent, B, top.beta, tanh_lo)
+        if mlm is not None:
+            mlm = mlm.detach().float().contiguous()
+        out4, seeds = ops.heads_loss_fwd(P, XP, rel, ap, lo, sent, B, top.beta, tanh_lo, mlm=mlm, alpha=top.alpha)
         ctx.top, ctx.B = top, B
+        ctx.nmlm, ctx.alpha = (0 if mlm is None else mlm.numel()), float(top.alpha)
         ctx.save_for_backward(first, P, Apre, g, Cc, T, seeds)
         logits_out = torch.tanh(lo) if tanh_lo else lo
         ctx.mark_non_differentiable(t_rel, rel, logits_out)
         ctx.set_materialize_grads(False)
         aux = out4[:3].clone()
         ctx.mark_non_differentiable(aux)
-        return out4[3].clone(), aux, logits_out, t_rel, rel
+        return out4[4 if mlm is not None else 3].clone(), aux, logits_out, t_rel, rel
 
     @staticmethod
     def backward(ctx, d, *_unused):
         if d is None:
-            return None, None, None, None
+            return None, None, None, None, None
         first, P, Apre, g, Cc, T, seeds = ctx.saved_tensors
         top, B = ctx.top, ctx.B
         H = P.shape[1]
@@ -1000,7 +1018,8 @@ class _HeadsFn(torch.autograd.Function):
                             (dpre, first, pool.weight.grad, pool.bias.grad), (drel, first[B:], al.weight.grad, al.bias.grad)])
         E3, dg3 = E.view(3, B, H), dg.view(3, B, 1)
         ops.heads_colsum([(E3[m], vs3[m].weight.grad) for m in range(3)] + [(dg3[m], vs3[m].bias.grad) for m in range(3)])
-        return dfirst, None, None, None
+        dmlm = (d.reshape(1).float() * (ctx.alpha / ctx.nmlm)).expand(ctx.nmlm) if ctx.nmlm else None
+        return dfirst, None, None, None, dmlm
 
 
 class MMBertForPretraining(_GpuModelBase):
@@ -1126,7 +1145,7 @@ class MMBertForPretraining(_GpuModelBase):
         heads_loss = ap_loss + label_loss - self.beta * nce
         return heads_loss, ap_loss, label_loss, nce, logits_out, t_rel, v_rel, s_rel
 
-    def _run_heads(self, first, ap_v, ap_s, sentiment, dev, B):
+    def _run_heads(self, first, ap_v, ap_s, sentiment, dev, B, mlm=None):
         """The heads on the [3B, H] [CLS] rows: the fused kernels (csrc/heads.hip) where they apply, else the eager form.
         (A captured hipGraph of the eager [B,H]-sized glue -- forward and backward, ~200 dependent launches -- was built and
         measured in round 1: no gain; the device time of the tiny kernels, not their dispatch, is the cost.)"""
@@ -1134,9 +1153,12 @@ class MMBertForPretraining(_GpuModelBase):
                  and all(q.grad is not None for q in (self.attn.weight, self.vt.weight, self.classifier1_1.weight)))
         if fused:
             ap = torch.cat((ap_v.to(dev).view(-1), ap_s.to(dev).view(-1))).long()
-            heads_loss, aux, logits_out, t_rel, rel = _HeadsFn.apply(first, self, ap, sentiment.to(dev).view(-1).float())
-            return heads_loss, aux[0], aux[1], aux[2], logits_out, t_rel, rel[:B], rel[B:]
-        return self._heads(first, ap_v.to(dev), ap_s.to(dev), None if sentiment is None else sentiment.to(dev))
+            loss, aux, logits_out, t_rel, rel = _HeadsFn.apply(first, self, ap, sentiment.to(dev).view(-1).float(), mlm)
+            return loss, aux[0], aux[1], aux[2], logits_out, t_rel, rel[:B], rel[B:]
+        out = self._heads(first, ap_v.to(dev), ap_s.to(dev), None if sentiment is None else sentiment.to(dev))
+        if mlm is not None:                                   # joint loss, eager form   (:427, :443)
+            out = (self.alpha * mlm.mean() + out[0],) + tuple(out[1:])
+        return out
 
     def forward(self, input_ids, token_type_ids, attention_mask, masked_labels, ap_label, sentiment):
         """REF:MMBertForPretraining.py:392-449, same arguments and the same 13-tuple + logits.  Deviations, all switchable:
@@ -1163,12 +1185,10 @@ class MMBertForPretraining(_GpuModelBase):
             raise ValueError("masked_labels must cover text (+ pair) positions of every pass")
         want_rows = torch.is_grad_enabled() and getattr(self, "sparse_mlm_backward", True) and labels.is_cuda
         y, plan, lens, rows = self._encode(passes, labels, want_rows)
-        mlm, logits = _MLMHeadFn.apply(y, self.cls.predictions.transform.LayerNorm.weight, self, labels, plan["bounds"], plan["bounds_dev"], self.return_scores, rows)
-
-        first = y.index_select(0, plan["first"]).float()                             # [3B, H]: [CLS] rows of every sequence
-        mlm_loss = (mlm[0] + mlm[1] + mlm[2]) / 3.0                                  # :427
-        heads_loss, ap_loss, label_loss, nce, logits_out, t_rel, v_rel, s_rel = self._run_heads(first, ap_v, ap_s, sentiment, dev, B)
-        joint_loss = self.alpha * mlm_loss + heads_loss                              # :443
+        # first = [3B, H]: the [CLS] rows of every sequence; joint_loss = alpha * (mlm_t + mlm_v + mlm_s) / 3 + heads_loss  (:427, :443)
+        mlm, logits, first = _MLMHeadFn.apply(y, self.cls.predictions.transform.LayerNorm.weight, self, labels, plan["bounds"], plan["bounds_dev"],
+                                              self.return_scores, rows, plan["first"])
+        joint_loss, ap_loss, label_loss, nce, logits_out, t_rel, v_rel, s_rel = self._run_heads(first, ap_v, ap_s, sentiment, dev, B, mlm=mlm)
         scores = (None, None, None)
         if logits is not None:
             b = plan["bounds"]
@@ -1203,10 +1223,9 @@ class MMBertForPretraining(_GpuModelBase):
             raise ValueError("masked_labels must cover the text and both pair blocks")
         want_rows = torch.is_grad_enabled() and getattr(self, "sparse_mlm_backward", True) and labels.is_cuda
         y, plan, lens, rows = self._encode(passes, labels, want_rows)
-        mlm, logits = _MLMHeadFn.apply(y, self.cls.predictions.transform.LayerNorm.weight, self, labels, plan["bounds"], plan["bounds_dev"], self.return_scores, rows)
-        first = y.index_select(0, plan["first"].repeat(3)).float()                   # the one [CLS] row in the t / v / s slots
-        heads_loss, ap_loss, label_loss, nce, logits_out, _t_rel, v_rel, _s_rel = self._run_heads(first, ap_v, ap_s, sentiment, dev, B)
-        joint_loss = self.alpha * mlm[0] + heads_loss
+        mlm, logits, first = _MLMHeadFn.apply(y, self.cls.predictions.transform.LayerNorm.weight, self, labels, plan["bounds"], plan["bounds_dev"],
+                                              self.return_scores, rows, plan["first"].repeat(3))   # the one [CLS] row in the t / v / s slots
+        joint_loss, ap_loss, label_loss, nce, logits_out, _t_rel, v_rel, _s_rel = self._run_heads(first, ap_v, ap_s, sentiment, dev, B, mlm=mlm)
         scores = None if logits is None else logits.view(B, lens[0], -1)[:, :, :V]
         if scores is not None and self.scores_dtype != scores.dtype:
             scores = scores.to(self.scores_dtype)

@@ -648,17 +648,20 @@ def heads_gate_fwd(P, Apre, vws, vbs, B):
     return g, Cc
 
 
-def heads_loss_fwd(P, XP, rel, ap, lo, sent, B, beta, tanh_lo):
-    """returns (out4, seeds) with seeds = [dXP (3BH) | dPc (3BH) | dlo (B) | drel (4B)] for an upstream gradient of 1."""
+def heads_loss_fwd(P, XP, rel, ap, lo, sent, B, beta, tanh_lo, mlm=None, alpha=1.0):
+    """returns (out5, seeds) with out5 = [ap_loss, label_loss, nce, heads_loss, alpha * mean(mlm) + heads_loss] and
+    seeds = [dXP (3BH) | dPc (3BH) | dlo (B) | drel (4B)] for an upstream gradient of 1."""
     H = P.shape[1]
     n = 3 * B * H
     seeds = torch.empty(2 * n + 5 * B, device=P.device, dtype=torch.float32)
-    out4 = torch.empty(4, device=P.device, dtype=torch.float32)
+    out4 = torch.empty(5, device=P.device, dtype=torch.float32)
+    if mlm is not None:
+        assert mlm.dtype == torch.float32 and mlm.is_contiguous()
     part = torch.empty(3, device=P.device, dtype=torch.float32)
     base = seeds.data_ptr()
     _lib.check(_lib.load().mmbert_heads_loss_fwd(_stream(), P.data_ptr(), XP.data_ptr(), rel.data_ptr(), ap.data_ptr(), lo.data_ptr(), sent.data_ptr(),
                                                  B, H, float(beta), int(tanh_lo), out4.data_ptr(), base, base + 4 * n, base + 4 * (2 * n + B), base + 4 * 2 * n,
-                                                 part.data_ptr()), "mmbert_heads_loss_fwd")
+                                                 part.data_ptr(), _ptr(mlm), 0 if mlm is None else mlm.numel(), float(alpha)), "mmbert_heads_loss_fwd")
     return out4, seeds
 
 

@@ -441,7 +441,8 @@ def test_sparse_mlm_backward_equals_dense_backward():
         scale = float(b.abs().max()) + 1e-12
         # 4e-3 of the largest entry: downstream of the head one bf16 rounding flip of an activation gradient is 2^-9 = 2e-3 relative
         # on that element (observed 2.3e-3 on one pair-projection weight)
-        assert float((a - b).abs().max()) <= 4e-3 * scale + 1e-8, (n, float((a - b).abs().max()), scale)   # (1e-8: the CPC gradients at init are ~4e-8)
+        # (5e-8: the CPC gradients at init are ~4e-8, what is left of cancelling terms, and the heads sum with fp32 atomics: run-to-run noise)
+        assert float((a - b).abs().max()) <= 4e-3 * scale + 5e-8, (n, float((a - b).abs().max()), scale)
     lab = batch["masked_labels"]
     n_act = sum(int((x != -100).sum()) for x in lab)
     assert 0 < n_act < sum(x.numel() for x in lab) // 2          # the sparse path was really taken
