@@ -47,10 +47,10 @@ int mmbert_gemm_nt(mmbert_stream_t stream, const void* A, int lda, const void* B
                    const void* U, int ldu, float alpha, const float* alpha_dev,
                    uint32_t drop_stream, uint32_t drop_thr16, float drop_scale, int* tile_queue);
 
-/* Split-K form of the plain product (C bf16 = A . B^T) for long K with few output tiles: fp32 partial slabs in the
- * caller's workspace (mmbert_gemm_nt_splitk_workspace() bytes), reduced deterministically. */
+/* Split-K form of the plain product (C bf16 = A . B^T, + R[M,N] bf16 when R is not null) for long K with few output tiles: fp32
+ * partial slabs in the caller's workspace (mmbert_gemm_nt_splitk_workspace() bytes), reduced deterministically. */
 int mmbert_gemm_nt_splitk(mmbert_stream_t stream, const void* A, int lda, const void* B, int ldb, void* C, int ldc,
-                          int M, int N, int K, void* workspace);
+                          int M, int N, int K, void* workspace, const void* R, int ldr);
 size_t mmbert_gemm_nt_splitk_workspace(int M, int N, int K);
 
 /* Kernel selection for mmbert_gemm_nt: 0 = by shape (default), 1 = 128x128 tile kernel, 2 = 4-stage-ring kernel

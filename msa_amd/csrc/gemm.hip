@@ -1332,19 +1332,22 @@ __global__ __launch_bounds__(256) void colsum_kernel(const bf16_t* __restrict__ 
 
 extern "C" {
 
-// C (bf16) = sum over the split-K slabs
-__global__ void nt_splitk_reduce_kernel(const float* __restrict__ slabs, int splits, long long stride, int M, int N, bf16_t* __restrict__ C, int ldc) {
+// C (bf16) = sum over the split-K slabs (+ R)
+__global__ void nt_splitk_reduce_kernel(const float* __restrict__ slabs, int splits, long long stride, int M, int N, bf16_t* __restrict__ C, int ldc,
+                                        const bf16_t* __restrict__ R, int ldr) {
     const long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
     if (i >= (long long)M * N) return;
     float4 a = *(const float4*)(slabs + i);
     for (int z = 1; z < splits; ++z) { const float4 b = *(const float4*)(slabs + z * stride + i); a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; }
     const int m = (int)(i / N), n = (int)(i - (long long)m * N);
+    if (R) { const bf16x4 r = *(const bf16x4*)(R + (size_t)m * ldr + n); a.x += bf2f(r[0]); a.y += bf2f(r[1]); a.z += bf2f(r[2]); a.w += bf2f(r[3]); }
     bf16x4 o = {f2bf(a.x), f2bf(a.y), f2bf(a.z), f2bf(a.w)};
     *(bf16x4*)(C + (size_t)m * ldc + n) = o;
 }
 
 // Split-K form for long-K products with few output tiles (the MLM head's compact dlogits . E^T: M ~ 360, K = 30592):
-// C[M,N] (bf16) = A[M,K] . B[N,K]^T through fp32 slabs (deterministic).  workspace >= mmbert_gemm_nt_splitk_workspace() bytes.
+// C[M,N] (bf16) = A[M,K] . B[N,K]^T (+ R[M,N] bf16, optional: the residual form of the top layer's few-row input gradients)
+// through fp32 slabs (deterministic).  workspace >= mmbert_gemm_nt_splitk_workspace() bytes.
 static int nt_splitk_plan(int M, int N, int K) {
     const int tiles = ((M + 127) / 128) * ((N + 127) / 128), kt = K >> 6;
     int splits = (2 * device_cus() + tiles - 1) / tiles;          // ~2 workgroups per CU
@@ -1355,9 +1358,9 @@ static int nt_splitk_plan(int M, int N, int K) {
 size_t mmbert_gemm_nt_splitk_workspace(int M, int N, int K) { return (size_t)nt_splitk_plan(M, N, K) * M * N * sizeof(float); }
 
 int mmbert_gemm_nt_splitk(hipStream_t stream, const void* A, int lda, const void* B, int ldb, void* C, int ldc,
-                          int M, int N, int K, void* workspace) {
+                          int M, int N, int K, void* workspace, const void* R, int ldr) {
     if (M <= 0 || N <= 0) return 0;
-    if (K <= 0 || (K & 63) || (N & 3) || (lda & 7) || (ldb & 7) || (ldc & 3) || !workspace) return -1;
+    if (K <= 0 || (K & 63) || (N & 3) || (lda & 7) || (ldb & 7) || (ldc & 3) || !workspace || (R && (ldr & 3))) return -1;
     GemmNT p = {};
     p.A = (const bf16_t*)A; p.B = (const bf16_t*)B; p.C = workspace; p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = N;
     p.alpha = 1.0f;
@@ -1370,7 +1373,8 @@ int mmbert_gemm_nt_splitk(hipStream_t stream, const void* A, int lda, const void
     hipLaunchKernelGGL(gemm_nt_kernel<EPI_OUT_F32>, dim3(((M + 127) / 128) * ((N + 127) / 128), 1, zs), dim3(256), 65536, stream, p);
     MMB_CHECK_LAUNCH();
     const long long n4 = ((long long)M * N + 3) / 4;
-    hipLaunchKernelGGL(nt_splitk_reduce_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, stream, (const float*)workspace, zs, p.split_stride, M, N, (bf16_t*)C, ldc);
+    hipLaunchKernelGGL(nt_splitk_reduce_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, stream, (const float*)workspace, zs, p.split_stride, M, N, (bf16_t*)C, ldc,
+                       (const bf16_t*)R, ldr);
     MMB_CHECK_LAUNCH();
     return 0;
 }

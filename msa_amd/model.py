@@ -371,7 +371,8 @@ class _EncoderFn(torch.autograd.Function):
         if dz2d_c is None:
             dz2d_c = dz2_c
         du_c = ops.gemm_nt(dz2d_c, lw["W2T"], gelu_bwd_u=sel(u))
-        dy1_c = ops.gemm_nt(du_c, lw["W1T"], resid=dz2_c)
+        # K = 4H with a few hundred rows: 18 output tiles -> split-K (50 -> 15 us at the headline shape)
+        dy1_c = ops.gemm_nt_splitk(du_c, lw["W1T"], resid=dz2_c) if du_c.shape[0] <= 1024 else ops.gemm_nt(du_c, lw["W1T"], resid=dz2_c)
         dz1d_c = torch.empty_like(dy_c) if d_h1[1] else None
         dz1_c = ops.ln_bwd(dy1_c, z1, sel(m1), sel(r1), lw["ln1_g"], lw["g_ln1_g"], lw["g_ln1_b"], x_rows=R32, dx2=dz1d_c, pre_drop=d_h1,
                            drop_rows=R32)

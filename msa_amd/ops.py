@@ -118,16 +118,18 @@ def _ws_f32(nfloats: int, device) -> torch.Tensor:
     return t
 
 
-def gemm_nt_splitk(A, B, out=None):
-    """out[M,N] (bf16) = A[M,K] @ B[N,K]^T for long K and few output tiles (see mmbert_gemm_nt_splitk)."""
+def gemm_nt_splitk(A, B, out=None, resid=None):
+    """out[M,N] (bf16) = A[M,K] @ B[N,K]^T (+ resid[M,N] bf16) for long K and few output tiles (see mmbert_gemm_nt_splitk)."""
     lib = _lib.load()
     M, K = A.shape
     N = B.shape[0]
     if out is None:
         out = torch.empty((M, N), device=A.device, dtype=torch.bfloat16)
+    if resid is not None:
+        assert resid.shape == (M, N) and resid.dtype == torch.bfloat16 and resid.stride(1) == 1
     ws = _ws_f32((lib.mmbert_gemm_nt_splitk_workspace(M, N, K) + 3) // 4, A.device)
     _lib.check(lib.mmbert_gemm_nt_splitk(_stream(), A.data_ptr(), A.stride(0), B.data_ptr(), B.stride(0), out.data_ptr(), out.stride(0),
-                                         M, N, K, ws.data_ptr()), "mmbert_gemm_nt_splitk")
+                                         M, N, K, ws.data_ptr(), _ptr(resid), 0 if resid is None else resid.stride(0)), "mmbert_gemm_nt_splitk")
     return out
 
 

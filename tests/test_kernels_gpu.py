@@ -100,6 +100,9 @@ def test_gemm_nt_splitk(ops, M, N, K):
     assert_close(out, A.float() @ B.float().t(), 1e-2, 2e-2, "split-K")
     again = ops.gemm_nt_splitk(A.to(DEV), B.to(DEV))
     assert torch.equal(out, again)                                   # slabs + ordered reduction: reproducible
+    R = bf(rnd(M, N + 8, seed=17))[:, :N]                            # the residual form (row pitch != N)
+    with_r = ops.gemm_nt_splitk(A.to(DEV), B.to(DEV), resid=R.to(DEV)[:, :N])
+    assert_close(with_r, A.float() @ B.float().t() + R.float(), 1e-2, 2e-2, "split-K + residual")
 
 
 def test_gemm_nt_strided_views_and_alpha_dev(ops):
