@@ -243,6 +243,8 @@ int mmbert_cast_f32_bf16(mmbert_stream_t stream, const float* x, void* y, size_t
 int mmbert_cast_bf16_f32(mmbert_stream_t stream, const void* x, float* y, size_t n);
 /* descs: device array of {int64 src_off, int64 dst_off, int rows, cols, dst_ld, tile0} (64x64 tiles) */
 int mmbert_transpose_cast(mmbert_stream_t stream, const float* src, void* dst, const void* descs, int ndesc, int total_tiles);
+/* the same from a bf16 source with the fp32 source's element offsets (the working copy mmbert_adamw has just written) */
+int mmbert_transpose_bf16(mmbert_stream_t stream, const void* src, void* dst, const void* descs, int ndesc, int total_tiles);
 
 #ifdef __cplusplus
 }

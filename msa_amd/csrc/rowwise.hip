@@ -35,6 +35,9 @@ size_t mmbert_gemm_tn_workspace(int M, int N, int K, int* splits_out);
 // --------------------------------------------------------------------------------------------
 // LayerNorm forward: y[out_row(i)] = dropout(LN(x[in_row(i)]))   (dropout index = i*H + col)
 // --------------------------------------------------------------------------------------------
+// R rows per wave and trip: their loads are issued together (a wave with one 1.5-KB row in flight at a time leaves the memory
+// system idle between its dependent reductions; see mmbert_ln_fwd for the measured choice of R).
+template <int NV, int R>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const bf16_t* __restrict__ x, int ldx, const int* __restrict__ in_rows,
                                                      bf16_t* __restrict__ y, int ldy, const int* __restrict__ out_rows,
                                                      int M, int H, const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -42,52 +45,72 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const bf16_t* __restrict__ 
                                                      uint32_t dstream, uint32_t dthr, float dscale) {
     const int lane = threadIdx.x & 63;
     const int wpb = blockDim.x >> 6;
-    for (int i = blockIdx.x * wpb + (threadIdx.x >> 6); i < M; i += gridDim.x * wpb) {
-        const bf16_t* xr = x + (size_t)(in_rows ? in_rows[i] : i) * ldx;
-        float v[LN_MAXV][4];
-        float s = 0.f;
+    for (int i0 = (blockIdx.x * wpb + (threadIdx.x >> 6)) * R; i0 < M; i0 += gridDim.x * wpb * R) {
+        float v[R][NV][4];
+        float s[R];
 #pragma unroll
-        for (int c = 0; c < LN_MAXV; ++c) {
-            const int col = c * 256 + lane * 4;
-            if (col < H) {
-                const bf16x4 t = *(const bf16x4*)(xr + col);
+        for (int rr = 0; rr < R; ++rr) {
+            const int i = min(i0 + rr, M - 1);                 // (a row past the end is computed again and not stored)
+            const bf16_t* xr = x + (size_t)(in_rows ? in_rows[i] : i) * ldx;
+            s[rr] = 0.f;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) { v[c][r] = bf2f(t[r]); s += v[c][r]; }
-            } else {
+            for (int c = 0; c < NV; ++c) {
+                const int col = c * 256 + lane * 4;
+                if (col < H) {
+                    const bf16x4 t = *(const bf16x4*)(xr + col);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) v[c][r] = 0.f;
+                    for (int r = 0; r < 4; ++r) { v[rr][c][r] = bf2f(t[r]); s[rr] += v[rr][c][r]; }
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[rr][c][r] = 0.f;
+                }
             }
         }
-        const float mean = wave_sum(s) / H;
-        float q = 0.f;
+        float mean[R], q[R], rstd[R];
 #pragma unroll
-        for (int c = 0; c < LN_MAXV; ++c) {
-            const int col = c * 256 + lane * 4;
-            if (col < H) {
+        for (int rr = 0; rr < R; ++rr) mean[rr] = wave_sum(s[rr]) / H;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) { const float d = v[c][r] - mean; q += d * d; }
+        for (int rr = 0; rr < R; ++rr) {
+            q[rr] = 0.f;
+#pragma unroll
+            for (int c = 0; c < NV; ++c) {
+                const int col = c * 256 + lane * 4;
+                if (col < H) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { const float d = v[rr][c][r] - mean[rr]; q[rr] += d * d; }
+                }
             }
         }
-        const float rstd = rsqrtf(wave_sum(q) / H + eps);
-        if (lane == 0) { if (mean_out) mean_out[i] = mean; if (rstd_out) rstd_out[i] = rstd; }
-        bf16_t* yr = y + (size_t)(out_rows ? out_rows[i] : i) * ldy;
 #pragma unroll
-        for (int c = 0; c < LN_MAXV; ++c) {
+        for (int rr = 0; rr < R; ++rr) rstd[rr] = rsqrtf(wave_sum(q[rr]) / H + eps);
+#pragma unroll
+        for (int c = 0; c < NV; ++c) {
             const int col = c * 256 + lane * 4;
             if (col < H) {
                 const float4 g = *(const float4*)(gamma + col);
                 const float4 b = *(const float4*)(beta + col);
-                float o[4] = {(v[c][0] - mean) * rstd * g.x + b.x, (v[c][1] - mean) * rstd * g.y + b.y,
-                              (v[c][2] - mean) * rstd * g.z + b.z, (v[c][3] - mean) * rstd * g.w + b.w};
-                if (dthr) {
-                    bool k[4];
-                    mmb_keep4(dstream, (uint64_t)i * H + col, dthr, k);
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) o[r] = k[r] ? o[r] * dscale : 0.f;
+                for (int rr = 0; rr < R; ++rr) {
+                    const int i = i0 + rr;
+                    if (i < M) {
+                        float o[4] = {(v[rr][c][0] - mean[rr]) * rstd[rr] * g.x + b.x, (v[rr][c][1] - mean[rr]) * rstd[rr] * g.y + b.y,
+                                      (v[rr][c][2] - mean[rr]) * rstd[rr] * g.z + b.z, (v[rr][c][3] - mean[rr]) * rstd[rr] * g.w + b.w};
+                        if (dthr) {
+                            bool k[4];
+                            mmb_keep4(dstream, (uint64_t)i * H + col, dthr, k);
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) o[r] = k[r] ? o[r] * dscale : 0.f;
+                        }
+                        bf16x4 ob = {f2bf(o[0]), f2bf(o[1]), f2bf(o[2]), f2bf(o[3])};
+                        *(bf16x4*)(y + (size_t)(out_rows ? out_rows[i] : i) * ldy + col) = ob;
+                    }
                 }
-                bf16x4 ob = {f2bf(o[0]), f2bf(o[1]), f2bf(o[2]), f2bf(o[3])};
-                *(bf16x4*)(yr + col) = ob;
             }
+        }
+#pragma unroll
+        for (int rr = 0; rr < R; ++rr) {
+            const int i = i0 + rr;
+            if (lane == 0 && i < M) { if (mean_out) mean_out[i] = mean[rr]; if (rstd_out) rstd_out[i] = rstd[rr]; }
         }
     }
 }
@@ -100,6 +123,9 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const bf16_t* __restrict__ 
 //   dx2 -> dx * pre-LN branch dropout mask (index i*H+col) when dx2 != null          -- d(GEMM out)
 //   dgamma += sum_i g*xhat, dbeta += sum_i g   (fp32 atomics, one per column per workgroup)
 // --------------------------------------------------------------------------------------------
+// NV = 256-column chunks per row (ceil(H / 256)): accumulators and row registers are sized to it; R = rows per wave and trip
+// (their loads are issued together, as in ln_fwd_kernel).
+template <int NV, int R>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ dy, int lddy, const int* __restrict__ dy_rows,
                                                      const bf16_t* __restrict__ x, int ldx, const int* __restrict__ x_rows,
                                                      const float* __restrict__ mean_in, const float* __restrict__ rstd_in,
@@ -111,74 +137,93 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
                                                      uint32_t post_stream, uint32_t post_thr, float post_scale,
                                                      uint32_t pre_stream, uint32_t pre_thr, float pre_scale,
                                                      const int* __restrict__ drop_rows) {
-    __shared__ float red[2][4][1024];
+    __shared__ float red[2][4][NV * 256];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    float ag[LN_MAXV][4], ab[LN_MAXV][4], ad[LN_MAXV][4];
+    float ag[NV][4], ab[NV][4], ad[NV][4];
 #pragma unroll
-    for (int c = 0; c < LN_MAXV; ++c)
+    for (int c = 0; c < NV; ++c)
 #pragma unroll
         for (int r = 0; r < 4; ++r) { ag[c][r] = 0.f; ab[c][r] = 0.f; ad[c][r] = 0.f; }
-    for (int i = blockIdx.x * 4 + w; i < M; i += gridDim.x * 4) {
-        const bf16_t* dyr = dy + (size_t)(dy_rows ? dy_rows[i] : i) * lddy;
-        const bf16_t* xr = x + (size_t)(x_rows ? x_rows[i] : i) * ldx;
-        const float mean = mean_in[i], rstd = rstd_in[i];
-        const uint64_t di = drop_rows ? (uint64_t)drop_rows[i] : (uint64_t)i;      // the row the dropout masks were drawn for
-        float g[LN_MAXV][4], xh[LN_MAXV][4];
-        float s1 = 0.f, s2 = 0.f;
+    const int stride = gridDim.x * 4;
+    for (int i0 = blockIdx.x * 4 + w; i0 < M; i0 += stride * R) {
+        bf16x4 dl[R][NV], tl[R][NV];
+        float mean[R], rstd[R];
+        uint64_t di[R];
+        bool live[R];
 #pragma unroll
-        for (int c = 0; c < LN_MAXV; ++c) {
-            const int col = c * 256 + lane * 4;
-            if (col < H) {
-                const bf16x4 d = *(const bf16x4*)(dyr + col);
-                const bf16x4 t = *(const bf16x4*)(xr + col);
-                const float4 gm = *(const float4*)(gamma + col);
-                const float gmv[4] = {gm.x, gm.y, gm.z, gm.w};
-                bool k[4] = {true, true, true, true};
-                if (post_thr) mmb_keep4(post_stream, di * H + col, post_thr, k);
+        for (int rr = 0; rr < R; ++rr) {                       // all loads of the trip first
+            const int i = i0 + rr * stride;
+            live[rr] = i < M;
+            const int ic = live[rr] ? i : i0;
+            const bf16_t* dyr = dy + (size_t)(dy_rows ? dy_rows[ic] : ic) * lddy;
+            const bf16_t* xr = x + (size_t)(x_rows ? x_rows[ic] : ic) * ldx;
+            mean[rr] = mean_in[ic]; rstd[rr] = rstd_in[ic];
+            di[rr] = drop_rows ? (uint64_t)drop_rows[ic] : (uint64_t)ic;           // the row the dropout masks were drawn for
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    float dv = bf2f(d[r]);
-                    if (post_thr) dv = k[r] ? dv * post_scale : 0.f;
-                    xh[c][r] = (bf2f(t[r]) - mean) * rstd;
-                    ag[c][r] += dv * xh[c][r];
-                    ab[c][r] += dv;
-                    g[c][r] = dv * gmv[r];
-                    s1 += g[c][r]; s2 += g[c][r] * xh[c][r];
-                }
-            } else {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) { g[c][r] = 0.f; xh[c][r] = 0.f; }
+            for (int c = 0; c < NV; ++c) {
+                const int col = c * 256 + lane * 4;
+                if (col < H) { dl[rr][c] = *(const bf16x4*)(dyr + col); tl[rr][c] = *(const bf16x4*)(xr + col); }
             }
         }
-        s1 = wave_sum(s1) / H; s2 = wave_sum(s2) / H;
-        bf16_t* dxr = dx + (size_t)(dx_rows ? dx_rows[i] : i) * lddx;
 #pragma unroll
-        for (int c = 0; c < LN_MAXV; ++c) {
-            const int col = c * 256 + lane * 4;
-            if (col < H) {
-                float o[4];
+        for (int rr = 0; rr < R; ++rr) {
+            if (!live[rr]) continue;                           // wave-uniform
+            const int i = i0 + rr * stride;
+            float g[NV][4], xh[NV][4];
+            float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) o[r] = rstd * (g[c][r] - s1 - xh[c][r] * s2);
-                bf16x4 ob = {f2bf(o[0]), f2bf(o[1]), f2bf(o[2]), f2bf(o[3])};
-                *(bf16x4*)(dxr + col) = ob;
-                if (dx2) {
-                    if (pre_thr) {
-                        bool k[4];
-                        mmb_keep4(pre_stream, di * H + col, pre_thr, k);
+            for (int c = 0; c < NV; ++c) {
+                const int col = c * 256 + lane * 4;
+                if (col < H) {
+                    const float4 gm = *(const float4*)(gamma + col);
+                    const float gmv[4] = {gm.x, gm.y, gm.z, gm.w};
+                    bool k[4] = {true, true, true, true};
+                    if (post_thr) mmb_keep4(post_stream, di[rr] * H + col, post_thr, k);
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) o[r] = k[r] ? o[r] * pre_scale : 0.f;
+                    for (int r = 0; r < 4; ++r) {
+                        float dv = bf2f(dl[rr][c][r]);
+                        if (post_thr) dv = k[r] ? dv * post_scale : 0.f;
+                        xh[c][r] = (bf2f(tl[rr][c][r]) - mean[rr]) * rstd[rr];
+                        ag[c][r] += dv * xh[c][r];
+                        ab[c][r] += dv;
+                        g[c][r] = dv * gmv[r];
+                        s1 += g[c][r]; s2 += g[c][r] * xh[c][r];
                     }
-                    bf16x4 o2 = {f2bf(o[0]), f2bf(o[1]), f2bf(o[2]), f2bf(o[3])};
-                    *(bf16x4*)(dx2 + (size_t)i * lddx2 + col) = o2;
-                }
+                } else {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) ad[c][r] += o[r];       // column sums of the dense layer's output gradient = its bias gradient
+                    for (int r = 0; r < 4; ++r) { g[c][r] = 0.f; xh[c][r] = 0.f; }
+                }
+            }
+            s1 = wave_sum(s1) / H; s2 = wave_sum(s2) / H;
+            bf16_t* dxr = dx + (size_t)(dx_rows ? dx_rows[i] : i) * lddx;
+#pragma unroll
+            for (int c = 0; c < NV; ++c) {
+                const int col = c * 256 + lane * 4;
+                if (col < H) {
+                    float o[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) o[r] = rstd[rr] * (g[c][r] - s1 - xh[c][r] * s2);
+                    bf16x4 ob = {f2bf(o[0]), f2bf(o[1]), f2bf(o[2]), f2bf(o[3])};
+                    *(bf16x4*)(dxr + col) = ob;
+                    if (dx2) {
+                        if (pre_thr) {
+                            bool k[4];
+                            mmb_keep4(pre_stream, di[rr] * H + col, pre_thr, k);
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) o[r] = k[r] ? o[r] * pre_scale : 0.f;
+                        }
+                        bf16x4 o2 = {f2bf(o[0]), f2bf(o[1]), f2bf(o[2]), f2bf(o[3])};
+                        *(bf16x4*)(dx2 + (size_t)i * lddx2 + col) = o2;
+                    }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) ad[c][r] += o[r];       // column sums of the dense layer's output gradient = its bias gradient
+                }
             }
         }
     }
     // workgroup reduction of the gamma/beta partials, then one atomic per column
 #pragma unroll
-    for (int c = 0; c < LN_MAXV; ++c)
+    for (int c = 0; c < NV; ++c)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             red[0][w][c * 256 + lane * 4 + r] = ag[c][r];
@@ -196,7 +241,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
     if (dbias2) {
         __syncthreads();
 #pragma unroll
-        for (int c = 0; c < LN_MAXV; ++c)
+        for (int c = 0; c < NV; ++c)
 #pragma unroll
             for (int r = 0; r < 4; ++r) red[0][w][c * 256 + lane * 4 + r] = ad[c][r];
         __syncthreads();
@@ -618,9 +663,11 @@ __global__ void gelu_bwd_kernel(const bf16_t* __restrict__ dy, const bf16_t* __r
     }
 }
 
-// batched transpose-cast: for each descriptor d: dst[c][r] (bf16, ld = dst_ld) = src[r][c] (fp32 [rows, cols])
+// batched transpose-cast: for each descriptor d: dst[c][r] (bf16, ld = dst_ld) = src[r][c] (fp32 or bf16 [rows, cols])
+// (the bf16 source is the working copy AdamW has just written: half the bytes to read, the same values)
 struct TransDesc { long long src_off, dst_off; int rows, cols, dst_ld, tile0; };
-__global__ __launch_bounds__(256) void transpose_cast_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst,
+template <typename SRC>
+__global__ __launch_bounds__(256) void transpose_cast_kernel(const SRC* __restrict__ src, bf16_t* __restrict__ dst,
                                                              const TransDesc* __restrict__ descs, int ndesc) {
     __shared__ float t[64][65];
     int d = 0;
@@ -629,14 +676,19 @@ __global__ __launch_bounds__(256) void transpose_cast_kernel(const float* __rest
     const int tl = blockIdx.x - ds.tile0;
     const int tc = (ds.cols + 63) >> 6;
     const int r0 = (tl / tc) << 6, c0 = (tl % tc) << 6;
-    const float* s = src + ds.src_off;
+    const SRC* s = src + ds.src_off;
     bf16_t* o = dst + ds.dst_off;
     const bool full = r0 + 64 <= ds.rows && c0 + 64 <= ds.cols && r0 + 64 <= ds.dst_ld && !(ds.cols & 3) && !(ds.dst_ld & 7) && !(ds.src_off & 3) && !(ds.dst_off & 7);
     if (full) {                                  // interior tile: 16-byte reads along a source row, 16-byte writes along a destination row
         for (int e = threadIdx.x; e < 1024; e += 256) {
             const int r = e >> 4, c = (e & 15) << 2;
-            const float4 v = *(const float4*)(s + (size_t)(r0 + r) * ds.cols + c0 + c);
-            t[r][c] = v.x; t[r][c + 1] = v.y; t[r][c + 2] = v.z; t[r][c + 3] = v.w;
+            if constexpr (sizeof(SRC) == 4) {
+                const float4 v = *(const float4*)(s + (size_t)(r0 + r) * ds.cols + c0 + c);
+                t[r][c] = v.x; t[r][c + 1] = v.y; t[r][c + 2] = v.z; t[r][c + 3] = v.w;
+            } else {
+                const bf16x4 v = *(const bf16x4*)(s + (size_t)(r0 + r) * ds.cols + c0 + c);
+                t[r][c] = bf2f(v[0]); t[r][c + 1] = bf2f(v[1]); t[r][c + 2] = bf2f(v[2]); t[r][c + 3] = bf2f(v[3]);
+            }
         }
         __syncthreads();
         for (int e = threadIdx.x; e < 512; e += 256) {
@@ -650,7 +702,7 @@ __global__ __launch_bounds__(256) void transpose_cast_kernel(const float* __rest
     }
     for (int e = threadIdx.x; e < 4096; e += 256) {
         const int r = e >> 6, c = e & 63;
-        t[r][c] = (r0 + r < ds.rows && c0 + c < ds.cols) ? s[(size_t)(r0 + r) * ds.cols + c0 + c] : 0.f;
+        t[r][c] = (r0 + r < ds.rows && c0 + c < ds.cols) ? (float)s[(size_t)(r0 + r) * ds.cols + c0 + c] : 0.f;
     }
     __syncthreads();
     for (int e = threadIdx.x; e < 4096; e += 256) {
@@ -825,14 +877,24 @@ int mmbert_ln_fwd(hipStream_t stream, const void* x, int ldx, const int* in_rows
                   uint32_t dstream, uint32_t dthr, float dscale) {
     if (M <= 0) return 0;
     if (H > LN_MAXV * 256 || (H & 3) || (ldx & 3) || (ldy & 3)) return -1;
-    hipLaunchKernelGGL(ln_fwd_kernel, dim3(grid_for(M, 4)), dim3(256), 0, stream, (const bf16_t*)x, ldx, in_rows, (bf16_t*)y, ldy, out_rows,
-                       M, H, gamma, beta, eps, mean, rstd, dstream, dthr, dscale);
+    static const int rows_env = getenv("MMBERT_LN_ROWS") ? atoi(getenv("MMBERT_LN_ROWS")) : 0;      // A/B switch: rows per wave
+    // rows per wave, measured at 18 400 x 768 (stand-alone, same box): 1 / 2 / 4 -> 18.3 / 14.9 / 20.9 us
+    const int R = rows_env ? rows_env : (M >= 8192 ? 2 : 1);
+    const int NV = (H + 255) / 256;
+#define LN_FWD_LAUNCH(NVV, RR) hipLaunchKernelGGL((ln_fwd_kernel<NVV, RR>), dim3(grid_for(M, 4 * RR)), dim3(256), 0, stream, (const bf16_t*)x, ldx, in_rows, \
+                                                  (bf16_t*)y, ldy, out_rows, M, H, gamma, beta, eps, mean, rstd, dstream, dthr, dscale)
+    if (R >= 2) { if (NV == 1) LN_FWD_LAUNCH(1, 2); else if (NV == 2) LN_FWD_LAUNCH(2, 2); else if (NV == 3) LN_FWD_LAUNCH(3, 2); else LN_FWD_LAUNCH(4, 2); }
+    else { if (NV == 1) LN_FWD_LAUNCH(1, 1); else if (NV == 2) LN_FWD_LAUNCH(2, 1); else if (NV == 3) LN_FWD_LAUNCH(3, 1); else LN_FWD_LAUNCH(4, 1); }
+#undef LN_FWD_LAUNCH
     MMB_CHECK_LAUNCH();
     return 0;
 }
 
 // (block cap swept in round 2 at 13 745 rows, encoder form: 256 / 512 / 1024 / 2048 / 4096 blocks -> 37.6 / 24.3 / 18.5 / 20.3 / 23.3 us)
-static inline int ln_bwd_blocks(int M) { return grid_for(M, 4, 1024); }
+static inline int ln_bwd_blocks(int M) {
+    static const int cap_env = getenv("MMBERT_LN_BWD_BLOCKS") ? atoi(getenv("MMBERT_LN_BWD_BLOCKS")) : 0;     // A/B switch
+    return grid_for(M, 4, cap_env > 0 ? cap_env : 1024);
+}
 
 int mmbert_ln_bwd(hipStream_t stream, const void* dy, int lddy, const int* dy_rows, const void* x, int ldx, const int* x_rows,
                   const float* mean, const float* rstd, const float* gamma, int M, int H,
@@ -843,9 +905,18 @@ int mmbert_ln_bwd(hipStream_t stream, const void* dy, int lddy, const int* dy_ro
     if (H > LN_MAXV * 256 || (H & 3) || (ldx & 3) || (lddy & 3) || (lddx & 3) || (lddx2 & 3)) return -1;
     if (defer_reduce && !partial_ws) return -1;
     const int nblocks = ln_bwd_blocks(M);
-    hipLaunchKernelGGL(ln_bwd_kernel, dim3(nblocks), dim3(256), 0, stream, (const bf16_t*)dy, lddy, dy_rows, (const bf16_t*)x, ldx, x_rows,
-                       mean, rstd, gamma, M, H, (bf16_t*)dx, lddx, dx_rows, (bf16_t*)dx2, lddx2, dgamma, dbeta, dbias2, partial_ws,
-                       post_stream, post_thr, post_scale, pre_stream, pre_thr, pre_scale, drop_rows);
+    static const int rows_env = getenv("MMBERT_LN_BWD_ROWS") ? atoi(getenv("MMBERT_LN_BWD_ROWS")) : 0;      // A/B switch: rows per wave and trip
+    // measured at 18 400 x 768 (stand-alone, same box): registers sized for 1024 columns (round 1: 142 VGPRs, 3 waves per SIMD) 35.0 us;
+    // sized to the row (NV = 3: 116 VGPRs, 4 waves per SIMD = all 4096 waves of the launch resident) 28.5; two rows per trip 34.0
+    const int R = rows_env ? rows_env : 1;
+    static const int nv4_env = getenv("MMBERT_LN_NV4") ? atoi(getenv("MMBERT_LN_NV4")) : 0;               // A/B switch: round-1 register sizing
+    const int NV = nv4_env ? 4 : (H + 255) / 256;
+#define LN_BWD_LAUNCH(NVV, RR) hipLaunchKernelGGL((ln_bwd_kernel<NVV, RR>), dim3(nblocks), dim3(256), 0, stream, (const bf16_t*)dy, lddy, dy_rows, \
+        (const bf16_t*)x, ldx, x_rows, mean, rstd, gamma, M, H, (bf16_t*)dx, lddx, dx_rows, (bf16_t*)dx2, lddx2, dgamma, dbeta, dbias2, partial_ws, \
+        post_stream, post_thr, post_scale, pre_stream, pre_thr, pre_scale, drop_rows)
+    if (R >= 2) { if (NV == 1) LN_BWD_LAUNCH(1, 2); else if (NV == 2) LN_BWD_LAUNCH(2, 2); else if (NV == 3) LN_BWD_LAUNCH(3, 2); else LN_BWD_LAUNCH(4, 2); }
+    else { if (NV == 1) LN_BWD_LAUNCH(1, 1); else if (NV == 2) LN_BWD_LAUNCH(2, 1); else if (NV == 3) LN_BWD_LAUNCH(3, 1); else LN_BWD_LAUNCH(4, 1); }
+#undef LN_BWD_LAUNCH
     MMB_CHECK_LAUNCH();
     if (partial_ws && !defer_reduce) {
         LnReduceBatch b = {};
@@ -1050,7 +1121,15 @@ int mmbert_cast_bf16_f32(hipStream_t stream, const void* x, float* y, size_t n) 
 // descs: device array of {src_off, dst_off, rows, cols, dst_ld, tile0}; total_tiles = sum of 64x64 tiles
 int mmbert_transpose_cast(hipStream_t stream, const float* src, void* dst, const void* descs, int ndesc, int total_tiles) {
     if (ndesc <= 0 || total_tiles <= 0) return 0;
-    hipLaunchKernelGGL(transpose_cast_kernel, dim3(total_tiles), dim3(256), 0, stream, src, (bf16_t*)dst, (const TransDesc*)descs, ndesc);
+    hipLaunchKernelGGL(transpose_cast_kernel<float>, dim3(total_tiles), dim3(256), 0, stream, src, (bf16_t*)dst, (const TransDesc*)descs, ndesc);
+    MMB_CHECK_LAUNCH();
+    return 0;
+}
+
+// the same from a bf16 source laid out like the fp32 one (same element offsets)
+int mmbert_transpose_bf16(hipStream_t stream, const void* src, void* dst, const void* descs, int ndesc, int total_tiles) {
+    if (ndesc <= 0 || total_tiles <= 0) return 0;
+    hipLaunchKernelGGL(transpose_cast_kernel<bf16_t>, dim3(total_tiles), dim3(256), 0, stream, (const bf16_t*)src, (bf16_t*)dst, (const TransDesc*)descs, ndesc);
     MMB_CHECK_LAUNCH();
     return 0;
 }

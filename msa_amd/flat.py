@@ -172,7 +172,7 @@ class FlatParams:
         self._version = self._param_versions()
 
     def refresh_transposes(self):
-        ops.transpose_cast(self.params, self.halfT, self._descs, self._ndesc, self._ntiles)
+        ops.transpose_cast(self.half, self.halfT, self._descs, self._ndesc, self._ntiles)      # from the bf16 copy: half the bytes, same values
 
     def mark_synced(self):
         """The bf16 copies were just refreshed by the optimizer kernel itself."""

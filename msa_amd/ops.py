@@ -632,8 +632,10 @@ def cast_bf16_f32(x, y):
 
 
 def transpose_cast(src_flat, dst_flat, descs_dev, ndesc, total_tiles):
-    _lib.check(_lib.load().mmbert_transpose_cast(_stream(), src_flat.data_ptr(), dst_flat.data_ptr(), descs_dev.data_ptr(), ndesc, total_tiles),
-               "mmbert_transpose_cast")
+    """Batched transposes into bf16; ``src_flat`` fp32, or bf16 with the same element offsets."""
+    fn = "mmbert_transpose_cast" if src_flat.dtype == torch.float32 else "mmbert_transpose_bf16"
+    assert src_flat.dtype in (torch.float32, torch.bfloat16)
+    _lib.check(getattr(_lib.load(), fn)(_stream(), src_flat.data_ptr(), dst_flat.data_ptr(), descs_dev.data_ptr(), ndesc, total_tiles), fn)
 
 
 # ------------------------------------------------------------------------------------ pretraining heads (csrc/heads.hip)

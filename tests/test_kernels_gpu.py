@@ -551,6 +551,9 @@ def test_transpose_cast_and_casts(ops):
     y = torch.empty(5000, device=DEV, dtype=torch.bfloat16)
     ops.cast_f32_bf16(src[:5000].to(DEV), y)
     assert torch.equal(y.cpu(), src.to(torch.bfloat16))
+    dst2 = torch.zeros_like(dst)                                        # the bf16-source form: same bits
+    ops.transpose_cast(y, dst2, torch.from_numpy(raw).to(DEV), len(mats), tile0)
+    assert torch.equal(dst, dst2)
 
 
 def test_step_prologue_matches_the_torch_formulation(ops):
