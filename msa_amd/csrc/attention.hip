@@ -42,6 +42,9 @@ struct AttnArgs {
     int H, heads;
     float scale;
     uint32_t dstream, dthr; float dscale;
+    // launch order: 1 = grid (heads, tiles), the heads of a tile are dispatched together and the tile list's order (longest work
+    // first, ops.SplitLayout) holds for the WHOLE launch; 0 = grid (tiles, heads), every head walks the list on its own
+    int head_fast;
 };
 
 // stage a [64 rows x 64 cols] bf16 tile (rows row0.., clamped to nrows-1) into LDS (8 KiB).
@@ -158,10 +161,11 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnArgs a) {
     __shared__ __attribute__((aligned(16))) char smem[2 * FWD_BUF];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int seq = a.tile_seq[blockIdx.x], r0 = a.tile_r0[blockIdx.x], head = blockIdx.y;
+    const int tix = a.head_fast ? blockIdx.y : blockIdx.x, head = a.head_fast ? blockIdx.x : blockIdx.y;       // see AttnArgs::head_fast
+    const int seq = a.tile_seq[tix], r0 = a.tile_r0[tix];
     const int start = a.seq_start[seq], S = a.seq_len[seq];
-    const int qshift = a.tile_qshift ? a.tile_qshift[blockIdx.x] : start;     // packed row of query index 0
-    const int Sq = a.tile_qend ? a.tile_qend[blockIdx.x] : S;                 // query indices of this tile end here
+    const int qshift = a.tile_qshift ? a.tile_qshift[tix] : start;     // packed row of query index 0
+    const int Sq = a.tile_qend ? a.tile_qend[tix] : S;                 // query indices of this tile end here
     const int Skv = a.kv_len ? min(S, a.kv_len[seq]) : S;                     // keys at and past Skv are all masked out
     const bool wave_active = r0 + wave * 32 < Sq;            // (128-row tiles: S = 550 leaves waves 2, 3 of the fifth tile without rows)
     const int Spad = (S + 3) & ~3;
@@ -349,7 +353,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnArgs a) {
 #ifdef MMB_STAMPS
     ATT_STAMP(t_end)
     if (g_attn_stamps && lane == 0) {
-        unsigned long long* o = g_attn_stamps + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 4 + wave) * 8;
+        unsigned long long* o = g_attn_stamps + ((size_t)(head * (a.head_fast ? gridDim.y : gridDim.x) + tix) * 4 + wave) * 8;
         o[0] = t_wait; o[1] = t_qk; o[2] = t_soft; o[3] = t_pv; o[4] = t_end - t_begin; o[5] = wave_active ? ntile : 0; o[6] = t_begin; o[7] = t_end;
     }
 #endif
@@ -369,10 +373,11 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnArgs a) {
     __shared__ __attribute__((aligned(16))) char smem[2 * DQ_BUF];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int seq = a.tile_seq[blockIdx.x], r0 = a.tile_r0[blockIdx.x], head = blockIdx.y;
+    const int tix = a.head_fast ? blockIdx.y : blockIdx.x, head = a.head_fast ? blockIdx.x : blockIdx.y;       // see AttnArgs::head_fast
+    const int seq = a.tile_seq[tix], r0 = a.tile_r0[tix];
     const int start = a.seq_start[seq], S = a.seq_len[seq];
-    const int qshift = a.tile_qshift ? a.tile_qshift[blockIdx.x] : start;
-    const int Sq = a.tile_qend ? a.tile_qend[blockIdx.x] : S;
+    const int qshift = a.tile_qshift ? a.tile_qshift[tix] : start;
+    const int Sq = a.tile_qend ? a.tile_qend[tix] : S;
     const int Skv = a.kv_len ? min(S, a.kv_len[seq]) : S;
     const bool wave_active = r0 + wave * 32 < Sq;            // (128-row tiles: S = 550 leaves waves 2, 3 of the fifth tile without rows)
     const int Spad = (S + 3) & ~3;
@@ -542,7 +547,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnArgs a) 
     __shared__ __attribute__((aligned(16))) char smem[2 * DKV_BUF];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int seq = a.tile_seq[blockIdx.x], r0 = a.tile_r0[blockIdx.x], head = blockIdx.y;
+    const int tix = a.head_fast ? blockIdx.y : blockIdx.x, head = a.head_fast ? blockIdx.x : blockIdx.y;       // see AttnArgs::head_fast
+    const int seq = a.tile_seq[tix], r0 = a.tile_r0[tix];
     const int start = a.seq_start[seq], S = a.seq_len[seq];
     // keys at and past Skv are all masked out: p = exp(s - 10000 - lse) underflows to exactly 0, so dK = dV = 0 for them.  A wave
     // whose 32 keys lie there computes nothing (its zero accumulators are stored at the end); a tile that lies there entirely
@@ -774,6 +780,8 @@ static int fill_args(AttnArgs& a, const void* qkv, int H, int heads, const float
     a.lse = lse; a.scale = 0.125f; a.dstream = dstream; a.dthr = dthr; a.dscale = dscale;
     a.ctx = nullptr; a.dctx = nullptr; a.dqkv = nullptr; a.delta = nullptr; a.kv_len = kv_len;
     a.tile_qshift = nullptr; a.tile_qend = nullptr; a.split = 0;
+    const char* hf = getenv("MMBERT_ATTN_HEAD_FAST");                 // A/B switch, read per call
+    a.head_fast = hf ? atoi(hf) : 1;
     return 0;
 }
 
@@ -786,8 +794,8 @@ int mmbert_attn_fwd(hipStream_t stream, const void* qkv, void* ctx, float* lse, 
     if (fill_args(a, qkv, H, heads, key_bias, bias_start, seq_start, seq_len, elem_base, tile_seq, tile_r0, lse, dstream, dthr, dscale, kv_len)) return -1;
     a.ctx = (bf16_t*)ctx; a.tile_qshift = tile_qshift; a.tile_qend = tile_qend;
     static const int extra_lds = getenv("MMBERT_ATTN_EXTRA_LDS") ? atoi(getenv("MMBERT_ATTN_EXTRA_LDS")) : 0;   // occupancy experiments
-    if (dthr) hipLaunchKernelGGL(attn_fwd_kernel<true>, dim3(ntiles, heads), dim3(256), extra_lds, stream, a);
-    else hipLaunchKernelGGL(attn_fwd_kernel<false>, dim3(ntiles, heads), dim3(256), extra_lds, stream, a);
+    if (dthr) hipLaunchKernelGGL(attn_fwd_kernel<true>, a.head_fast ? dim3(heads, ntiles) : dim3(ntiles, heads), dim3(256), extra_lds, stream, a);
+    else hipLaunchKernelGGL(attn_fwd_kernel<false>, a.head_fast ? dim3(heads, ntiles) : dim3(ntiles, heads), dim3(256), extra_lds, stream, a);
     MMB_CHECK_LAUNCH();
     return 0;
 }
@@ -804,13 +812,13 @@ int mmbert_attn_bwd(hipStream_t stream, const void* qkv, const void* ctx, const 
     {
         AttnArgs q = a;
         q.tile_seq = qtile_seq; q.tile_r0 = qtile_r0; q.tile_qshift = qtile_qshift; q.tile_qend = qtile_qend;
-        if (dthr) hipLaunchKernelGGL(attn_bwd_dq_kernel<true>, dim3(nqtiles, heads), dim3(256), 0, stream, q);
-        else hipLaunchKernelGGL(attn_bwd_dq_kernel<false>, dim3(nqtiles, heads), dim3(256), 0, stream, q);
+        if (dthr) hipLaunchKernelGGL(attn_bwd_dq_kernel<true>, q.head_fast ? dim3(heads, nqtiles) : dim3(nqtiles, heads), dim3(256), 0, stream, q);
+        else hipLaunchKernelGGL(attn_bwd_dq_kernel<false>, q.head_fast ? dim3(heads, nqtiles) : dim3(nqtiles, heads), dim3(256), 0, stream, q);
         MMB_CHECK_LAUNCH();
     }
     a.split = split;
-    if (dthr) hipLaunchKernelGGL(attn_bwd_dkv_kernel<true>, dim3(ntiles, heads), dim3(256), 0, stream, a);
-    else hipLaunchKernelGGL(attn_bwd_dkv_kernel<false>, dim3(ntiles, heads), dim3(256), 0, stream, a);
+    if (dthr) hipLaunchKernelGGL(attn_bwd_dkv_kernel<true>, a.head_fast ? dim3(heads, ntiles) : dim3(ntiles, heads), dim3(256), 0, stream, a);
+    else hipLaunchKernelGGL(attn_bwd_dkv_kernel<false>, a.head_fast ? dim3(heads, ntiles) : dim3(ntiles, heads), dim3(256), 0, stream, a);
     MMB_CHECK_LAUNCH();
     return 0;
 }

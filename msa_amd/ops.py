@@ -7,6 +7,7 @@ taken from ``stride(0)`` so row-slices of larger buffers can be passed without c
 from __future__ import annotations
 
 import ctypes
+import os
 from typing import Optional, Tuple
 
 import numpy as np
@@ -430,11 +431,19 @@ class SplitLayout:
         ns_ = len(lens)
         seq_ids = np.arange(ns_)
 
+        lpt = os.environ.get("MMBERT_ATTN_LPT", "1") != "0"          # (read per call: A/B switch)
+
         def tiles(count_rows, first_row, shift, end):
             nt = (count_rows + rows - 1) // rows
             sq = np.repeat(seq_ids, nt)
             k = np.arange(int(nt.sum())) - np.repeat(np.cumsum(nt) - nt, nt)
-            return sq, first_row[sq] + k * rows, shift[sq], end[sq]
+            r0 = first_row[sq] + k * rows
+            if lpt and len(sq):
+                # longest work first: a workgroup's time is its key (or query) loop, i.e. the sequence's unmasked length; the
+                # launch is 2-3 rounds of workgroups, and short tiles at the END fill the last round instead of trailing it
+                order = np.argsort(-(v[sq] * 1024 + np.minimum(rows, end[sq] - r0)), kind="stable")
+                sq, r0 = sq[order], r0[order]
+            return sq, r0, shift[sq], end[sq]
         qa = tiles(v, np.zeros_like(v), start_a, v)
         qb = tiles(lens - v, v, start_b - v, lens)
         q_seq, q_r0, q_sh, q_end = qa
