@@ -431,7 +431,8 @@ class SplitLayout:
         ns_ = len(lens)
         seq_ids = np.arange(ns_)
 
-        lpt = os.environ.get("MMBERT_ATTN_LPT", "1") != "0"          # (read per call: A/B switch)
+        lpt = os.environ.get("MMBERT_ATTN_LPT", "1") != "0"          # (read per call: A/B switches)
+        xcd_group = os.environ.get("MMBERT_ATTN_XCD_GROUP", "1") != "0"
 
         def tiles(count_rows, first_row, shift, end):
             nt = (count_rows + rows - 1) // rows
@@ -440,8 +441,15 @@ class SplitLayout:
             r0 = first_row[sq] + k * rows
             if lpt and len(sq):
                 # longest work first: a workgroup's time is its key (or query) loop, i.e. the sequence's unmasked length; the
-                # launch is 2-3 rounds of workgroups, and short tiles at the END fill the last round instead of trailing it
-                order = np.argsort(-(v[sq] * 1024 + np.minimum(rows, end[sq] - r0)), kind="stable")
+                # launch is 2-3 rounds of workgroups, and short tiles at the END fill the last round instead of trailing it.
+                # The kernels launch grid (heads, tiles) and workgroups go to the 8 XCDs round-robin, so tile t of head h lands
+                # on XCD (heads * t + h) % 8: sequences are interleaved in groups of `xs` = 8 / gcd(heads, 8), which puts the
+                # tiles of ONE (sequence, head) -- they all read the same K / V (dK/dV: the same Q / dO) -- `xs` list entries
+                # apart, i.e. on ONE XCD and its L2.
+                xs = 8 // int(np.gcd(base.heads, 8)) if xcd_group else 1
+                rank = np.empty(ns_, dtype=np.int64)
+                rank[np.argsort(-v, kind="stable")] = np.arange(ns_)
+                order = np.lexsort((rank[sq] % xs, k, rank[sq] // xs))
                 sq, r0 = sq[order], r0[order]
             return sq, r0, shift[sq], end[sq]
         qa = tiles(v, np.zeros_like(v), start_a, v)
