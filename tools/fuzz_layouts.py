@@ -37,15 +37,29 @@ for it in range(int(os.environ.get("N", 24))):
     with torch.no_grad():
         m = build(cfg); m.dedupe_masked_rows = True; o1, l1 = m(**batch)
         m.dedupe_masked_rows = False; o2, l2 = m(**batch)
-    ok = all(torch.equal(o1[k], o2[k]) for k in (7, 9, 11)) and torch.equal(l1, l2)
+    why = []
+    if not all(torch.equal(o1[k], o2[k]) for k in (7, 9, 11)):
+        why.append("dedupe scores")
+    if not torch.allclose(l1, l2, rtol=1e-5, atol=1e-6):       # (the heads sum with fp32 atomics: not bit-reproducible run to run)
+        why.append("dedupe logits")
     for mode in ("fast", "noscores"):
         for a, b in zip(res[mode][0], res["dense"][0]):
-            ok &= abs(a - b) <= 3e-6 * abs(b) + 1e-7
+            if not abs(a - b) <= 3e-6 * abs(b) + 1e-7:
+                why.append(f"{mode} loss {a} vs {b}")
         for n in res["dense"][1]:
+            if "attention.self.key.bias" in n:                 # true gradient 0 (softmax is shift invariant): rounding noise on both sides
+                continue
             g0, g1 = res["dense"][1][n], res[mode][1][n]
-            ok &= float((g1 - g0).abs().max()) <= 3e-3 * float(g0.abs().max()) + 1e-7
-    ok &= all(torch.equal(res["fast"][2][k], res["dense"][2][k]) for k in (7, 9, 11))
+            # one bf16 rounding flip of an activation gradient is 2^-9 relative on that element; 5e-7: gradients that are what is left
+            # of cancelling terms (CPC at init) carry the fp32-atomics noise of the heads
+            if not float((g1 - g0).abs().max()) <= 5e-3 * float(g0.abs().max()) + 5e-7:
+                why.append(f"{mode} grad {n} {float((g1 - g0).abs().max()):.3g} of {float(g0.abs().max()):.3g}")
+    if not all(torch.equal(res["fast"][2][k], res["dense"][2][k]) for k in (7, 9, 11)):
+        why.append("fast scores")
+    ok = not why
     bad += (not ok)
+    if why:
+        print("   ", "; ".join(why[:6]), flush=True)
     print(f"{it:2d} {'ok ' if ok else 'BAD'} L={cfg['layers']} H={hidden} heads={heads} {cfg['dataset']:8s} B={B} T={T} Pv={Pv} Pa={Pa} full={full} rowfrac={getattr(m, 'last_backward_row_fraction', 1):.2f}", flush=True)
 print("failures:", bad)
 sys.exit(1 if bad else 0)
