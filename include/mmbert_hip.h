@@ -10,7 +10,11 @@
  *     the tile queue of the persistent GEMM included, is passed in by the caller.  Process-global and documented as such:
  *     the one-time per-device opt-in of kernels to > 64 KiB of LDS (hipFuncSetAttribute on first use -- warm each kernel up once
  *     before capturing a graph), a cached CU count per device, and the two test / A-B knobs mmbert_gemm_nt_force and
- *     mmbert_gemm_tn_force_splits (atomics, default 0 = choose by shape; every choice computes the same product).
+ *     mmbert_gemm_tn_force_splits (atomics, default 0 = choose by shape; every choice computes the same product), and the
+ *     measurement switches read from the environment once per process -- schedule choices only, the results do not depend
+ *     on them: MMBERT_NT_GROUP_M, MMBERT_NT_QUEUE_GLOBAL, MMBERT_NT_TALL (tile walk / queue / tile height of the persistent GEMM),
+ *     MMBERT_LN_ROWS, MMBERT_LN_BWD_ROWS, MMBERT_LN_BWD_BLOCKS, MMBERT_LN_NV4 (LayerNorm rows per wave / grid / register sizing),
+ *     MMBERT_ATTN_HEAD_FAST (grid order of the attention kernels; read per call), MMBERT_ATTN_EXTRA_LDS (occupancy experiments).
  * bf16 tensors are row-major `uint16` storage; "ld*" are leading dimensions in elements.
  * REF: = /root/reference/<file>:<line>;  HF: = transformers models/bert/modeling_bert.py (5.15.0).
  */
