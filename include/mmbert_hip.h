@@ -247,6 +247,11 @@ int mmbert_cast_f32_bf16(mmbert_stream_t stream, const float* x, void* y, size_t
 int mmbert_cast_bf16_f32(mmbert_stream_t stream, const void* x, float* y, size_t n);
 /* descs: device array of {int64 src_off, int64 dst_off, int rows, cols, dst_ld, tile0} (64x64 tiles) */
 int mmbert_transpose_cast(mmbert_stream_t stream, const float* src, void* dst, const void* descs, int ndesc, int total_tiles);
+/* Batched row gather: dst_k[i] = src_k[idx[i]] for i < nrows and up to 12 matrices k that share the row list idx (int32, device); rows
+ * are row_bytes[k] bytes (a multiple of 4) at byte pitches src_pitch[k] / dst_pitch[k].  The sparse backward paths use it to pull
+ * the labelled rows out of every saved activation in one launch. */
+int mmbert_gather_rows(mmbert_stream_t stream, int nseg, const void* const* src, void* const* dst, const long long* src_pitch, const long long* dst_pitch,
+                       const int* row_bytes, const int* idx, int nrows);
 /* the same from a bf16 source with the fp32 source's element offsets (the working copy mmbert_adamw has just written) */
 int mmbert_transpose_bf16(mmbert_stream_t stream, const void* src, void* dst, const void* descs, int ndesc, int total_tiles);
 

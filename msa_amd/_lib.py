@@ -63,6 +63,7 @@ SIGNATURES = {
     "mmbert_cast_bf16_f32": (I, [P, P, P, SZ]),
     "mmbert_transpose_cast": (I, [P, P, P, P, I, I]),
     "mmbert_transpose_bf16": (I, [P, P, P, P, I, I]),
+    "mmbert_gather_rows": (I, [P, I, P, P, P, P, P, P, I]),
 }
 
 _lib = None

@@ -363,18 +363,18 @@ class _EncoderFn(torch.autograd.Function):
         cfg = top.config
         x, qkv, actx, lse, z1, m1, r1, y1, u, g, z2, m2, r2, d_att, d_h1, d_h2 = saved_i
         R32 = R.int()
-        sel = lambda t: t.index_select(0, R)
-        dy_c = sel(dy)
+        # the rows R of every saved activation this path reads, in ONE launch (9 index_select launches before)
+        dy_c, m2_c, r2_c, u_c, m1_c, r1_c, y1_c, g_c, actx_c = ops.gather_rows([dy, m2, r2, u, m1, r1, y1, g, actx], R32)
         dz2d_c = torch.empty_like(dy_c) if d_h2[1] else None
-        dz2_c = ops.ln_bwd(dy_c, z2, sel(m2), sel(r2), lw["ln2_g"], lw["g_ln2_g"], lw["g_ln2_b"], x_rows=R32, dx2=dz2d_c, pre_drop=d_h2,
+        dz2_c = ops.ln_bwd(dy_c, z2, m2_c, r2_c, lw["ln2_g"], lw["g_ln2_g"], lw["g_ln2_b"], x_rows=R32, dx2=dz2d_c, pre_drop=d_h2,
                            drop_rows=R32)
         if dz2d_c is None:
             dz2d_c = dz2_c
-        du_c = ops.gemm_nt(dz2d_c, lw["W2T"], gelu_bwd_u=sel(u))
+        du_c = ops.gemm_nt(dz2d_c, lw["W2T"], gelu_bwd_u=u_c)
         # K = 4H with a few hundred rows: 18 output tiles -> split-K (50 -> 15 us at the headline shape)
         dy1_c = ops.gemm_nt_splitk(du_c, lw["W1T"], resid=dz2_c) if du_c.shape[0] <= 1024 else ops.gemm_nt(du_c, lw["W1T"], resid=dz2_c)
         dz1d_c = torch.empty_like(dy_c) if d_h1[1] else None
-        dz1_c = ops.ln_bwd(dy1_c, z1, sel(m1), sel(r1), lw["ln1_g"], lw["g_ln1_g"], lw["g_ln1_b"], x_rows=R32, dx2=dz1d_c, pre_drop=d_h1,
+        dz1_c = ops.ln_bwd(dy1_c, z1, m1_c, r1_c, lw["ln1_g"], lw["g_ln1_g"], lw["g_ln1_b"], x_rows=R32, dx2=dz1d_c, pre_drop=d_h1,
                            drop_rows=R32)
         if dz1d_c is None:
             dz1d_c = dz1_c
@@ -385,7 +385,7 @@ class _EncoderFn(torch.autograd.Function):
         dz1.index_copy_(0, R, dz1_c)
         out = ops.gemm_nt(dqkv, lw["WqkvT"], resid=dz1)
         # (bias gradients b1 / b2 / bo: column sums of the bf16 gradients on the ones-operand MFMA, as in the dense layers)
-        ops.gemm_tn_grouped([(du_c, sel(y1), lw["g_W1"], lw["g_b1"]), (dz2d_c, sel(g), lw["g_W2"], lw["g_b2"]), (dz1d_c, sel(actx), lw["g_Wo"], lw["g_bo"])])
+        ops.gemm_tn_grouped([(du_c, y1_c, lw["g_W1"], lw["g_b1"]), (dz2d_c, g_c, lw["g_W2"], lw["g_b2"]), (dz1d_c, actx_c, lw["g_Wo"], lw["g_bo"])])
         ops.gemm_tn_grouped([(dqkv, x, lw["g_Wqkv"], lw["g_bqkv"])])
         return out
 
@@ -541,10 +541,10 @@ class _MLMHeadFn(torch.autograd.Function):
                 sel = idx.long()
                 dl = torch.empty((n, logits.shape[1]), device=y.device, dtype=torch.bfloat16)
                 ops.ce_bwd(logits, V, labels, seg_bounds, ctx.nseg, inv, gs, lse, dl, rows=idx)
-                t_c, t0_c, pre_c, y_c = (x.index_select(0, sel) for x in (t, t0, pre, y))
+                t_c, t0_c, pre_c, y_c, mean_c, rstd_c = ops.gather_rows([t, t0, pre, y, mean, rstd], idx)      # one launch
                 ops.gemm_tn(dl, t_c, w["g_word_pad"], bias_out=w["g_pred_bias"])
                 dt = ops.gemm_nt_splitk(dl, w["wordT"])                     # K = vocabulary, a few hundred rows: split-K
-                dt0 = ops.ln_bwd(dt, t0_c, mean.index_select(0, sel), rstd.index_select(0, sel), w["mlm_ln_g"], w["g_mlm_ln_g"], w["g_mlm_ln_b"])
+                dt0 = ops.ln_bwd(dt, t0_c, mean_c, rstd_c, w["mlm_ln_g"], w["g_mlm_ln_g"], w["g_mlm_ln_b"])
                 dpre = ops.gelu_bwd(dt0, pre_c)
                 ops.gemm_tn(dpre, y_c, w["g_Wt"], bias_out=w["g_bt"])
                 dy.index_copy_(0, sel, ops.gemm_nt(dpre, w["WtT"]))

@@ -711,6 +711,25 @@ def heads_tanh_bwd(dP, P):
     return dpre
 
 
+def gather_rows(srcs, idx32):
+    """[t.index_select(0, idx) for t in srcs] in ONE launch (mmbert_gather_rows): ``srcs`` = up to 12 tensors (1-D or 2-D, unit inner
+    stride, element size a multiple of 4 bytes per row) sharing the int32 row list ``idx32``."""
+    n = len(srcs)
+    assert 0 < n <= 12 and idx32.dtype == torch.int32 and idx32.is_contiguous()
+    rows = idx32.numel()
+    outs = [torch.empty((rows,) + tuple(t.shape[1:]), device=t.device, dtype=t.dtype) for t in srcs]
+    if rows == 0:
+        return outs
+    for t in srcs:
+        assert t.dim() in (1, 2) and (t.dim() == 1 or t.stride(1) == 1)
+    LA = ctypes.c_longlong * n
+    rb = [(t.shape[1] if t.dim() == 2 else 1) * t.element_size() for t in srcs]
+    _lib.check(_lib.load().mmbert_gather_rows(_stream(), n, _PtrArr[n](*[t.data_ptr() for t in srcs]), _PtrArr[n](*[o.data_ptr() for o in outs]),
+                                              LA(*[t.stride(0) * t.element_size() for t in srcs]), LA(*[b for b in rb]),
+                                              _IntArr[n](*rb), idx32.data_ptr(), rows), "mmbert_gather_rows")
+    return outs
+
+
 def heads_colsum(pairs):
     """pairs: list of (src [rows, cols] fp32 with unit column stride, dst [cols] fp32): dst += column sums, one launch."""
     n = len(pairs)

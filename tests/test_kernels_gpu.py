@@ -556,6 +556,19 @@ def test_transpose_cast_and_casts(ops):
     assert torch.equal(dst, dst2)
 
 
+def test_gather_rows_batched(ops):
+    """mmbert_gather_rows: one row list, several matrices (bf16 / fp32 rows of different widths, 1-D vectors, a strided view)."""
+    g = torch.Generator().manual_seed(70)
+    M = 500
+    idx = torch.randint(0, M, (77,), generator=g).int().to(DEV)
+    big = bf(rnd(M, 96, seed=71)).to(DEV)
+    srcs = [bf(rnd(M, 768, seed=72)).to(DEV), rnd(M, seed=73).to(DEV), rnd(M, 36, seed=74).to(DEV), big[:, 32:64], bf(rnd(M, 3072, seed=75)).to(DEV)]
+    outs = ops.gather_rows(srcs, idx)
+    for t, o in zip(srcs, outs):
+        assert torch.equal(o, t.index_select(0, idx.long()))
+    assert ops.gather_rows(srcs[:2], idx[:0])[0].shape == (0, 768)
+
+
 def test_step_prologue_matches_the_torch_formulation(ops):
     """mmbert_prologue (two launches) against the element-wise formulation it replaced: (1 - mask) * -10000 per key from the
     reference's mask dtypes (float64 text mask, float64 [B,P,D] visual mask and int64 speech mask read at feature 0 through
