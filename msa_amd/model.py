@@ -588,6 +588,23 @@ class _GpuModelBase(nn.Module):
             s = self._side_stream = torch.cuda.Stream()
         return s
 
+    @property
+    def input_stream(self):
+        """The stream the step prologue runs on with ``async_prologue`` (created on first use).  A data pipeline that builds its
+        batches on the GPU does so on this stream (see ``async_prologue``)."""
+        s = self.__dict__.get("_input_stream")
+        if s is None:
+            s = self.__dict__["_input_stream"] = torch.cuda.Stream()
+        return s
+
+    def _prologue_stream(self):
+        """None, or the input stream when ``model.async_prologue`` is set.  That switch is the CALLER's statement that (a) the tensors
+        it passes to forward() are not still being written by work queued on the current stream -- they are static or prefetched
+        (and synchronised), or were built on ``model.input_stream`` -- and (b) it runs the trainer's order, every forward followed
+        by its backward before the next forward but one (the prologue's outputs live in two alternating buffer sets).  The masks
+        and labels are then read on the input stream without waiting for the current one."""
+        return self.input_stream if getattr(self, "async_prologue", False) else None
+
     def manual_seed(self, seed: int):
         self._seed, self._calls = int(seed), 0
 
@@ -733,13 +750,42 @@ class _GpuModelBase(nn.Module):
                 lens.append(T)
                 pair_info.append(None)
         plan = self._plan(lens, B, dev)
-        pro = ops.prologue(segs, lens, B, labels, cfg.vocab_size, dev)
+        side = self._prologue_stream()
+        if side is None:
+            pro = ops.prologue(segs, lens, B, labels, cfg.vocab_size, dev)
+            nseq = pro.nseq
+            host = torch.empty(nseq + 3, dtype=torch.int32, pin_memory=True)
+            host.copy_(pro.words, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+        else:
+            # async_prologue: the prologue and its device -> host copy run on the input stream, AHEAD of whatever the current stream
+            # still has queued (the previous step's backward and optimizer) -- the host gets the lengths without waiting for the GPU
+            # to drain and keeps enqueueing a step ahead.  Outputs alternate between two persistent buffer sets: set k % 2 was last
+            # read by step k - 2, which is complete once the current stream reaches the mark recorded at the start of step k - 1.
+            main = torch.cuda.current_stream()
+            k = self._pro_calls = getattr(self, "_pro_calls", 0) + 1
+            marks = self.__dict__.setdefault("_pro_marks", {})
+            if (k - 1) % 2 in marks:
+                side.wait_event(marks[(k - 1) % 2])
+            nf, ni = ops.prologue_sizes(lens, B)
+            sets = self.__dict__.setdefault("_pro_bufs", {})
+            bufs = sets.get(k % 2)
+            if bufs is None or bufs[0].numel() < nf or bufs[1].numel() < ni or bufs[0].device != dev:
+                bufs = sets[k % 2] = (torch.empty(nf, device=dev, dtype=torch.float32), torch.empty(ni, device=dev, dtype=torch.int32))
+                side.wait_stream(main)                                   # (new buffers: ordered behind everything, once per shape)
+            with torch.cuda.stream(side):
+                pro = ops.prologue(segs, lens, B, labels, cfg.vocab_size, dev, bufs=bufs)
+                nseq = pro.nseq
+                host = torch.empty(nseq + 3, dtype=torch.int32, pin_memory=True)
+                host.copy_(pro.words, non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record()
+            mark = torch.cuda.Event()
+            mark.record(main)
+            marks[k % 2] = mark
+            main.wait_event(ev)
         key_bias = pro.key_bias                                       # per-sequence padded layout, -1e30 = "no such key"
-        nseq = pro.nseq
-        host = torch.empty(nseq + 3, dtype=torch.int32, pin_memory=True)
-        host.copy_(pro.words, non_blocking=True)
-        ev = torch.cuda.Event()
-        ev.record()
         rows = (pro.idx, host[nseq:], ev) if want_rows else None
         # padded pair rows are masked-out keys at the tail of every joint sequence: the attention kernels skip them (exact)
         kv_len = pro.kv_len if getattr(self, "skip_masked_keys", True) else None
@@ -1181,7 +1227,13 @@ class MMBertForPretraining(_GpuModelBase):
                   dict(ids=twv, tt=None, mask=am_v[0].to(dev), pair=visual, pair_mask=am_v[1].to(dev)),
                   dict(ids=tws, tt=None, mask=am_s[0].to(dev), pair=speech, pair_mask=am_s[1].to(dev))]
         H, V = self.config.hidden_size, self.config.vocab_size
-        labels = torch.cat((lab_t.reshape(-1), lab_v.reshape(-1), lab_s.reshape(-1))).to(device=dev, dtype=torch.long)
+        side = self._prologue_stream() if lab_t.is_cuda else None
+        if side is None:
+            labels = torch.cat((lab_t.reshape(-1), lab_v.reshape(-1), lab_s.reshape(-1))).to(device=dev, dtype=torch.long)
+        else:                                   # async_prologue: the prologue's inputs must not queue behind the current stream
+            with torch.cuda.stream(side):
+                labels = torch.cat((lab_t.reshape(-1), lab_v.reshape(-1), lab_s.reshape(-1))).to(device=dev, dtype=torch.long)
+            labels.record_stream(torch.cuda.current_stream())
         if labels.numel() != B * (T + (T + visual.shape[1]) + (T + speech.shape[1])):
             raise ValueError("masked_labels must cover text (+ pair) positions of every pass")
         want_rows = torch.is_grad_enabled() and getattr(self, "sparse_mlm_backward", True) and labels.is_cuda

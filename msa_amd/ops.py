@@ -21,7 +21,16 @@ Drop = Optional[Tuple[int, int, float]]      # (rng stream, thr16, scale)
 NO_DROP = (0, 0, 1.0)
 
 
+# The current HIP stream of the calling thread as a raw handle.  torch.cuda.current_stream() builds a Python Stream object per call
+# (~9 us, ~110 calls per train step = 1 ms of host time on the critical enqueue path); the two C accessors below return the same
+# handle in well under a microsecond.  They are private torch API: the public path is the fallback.
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+_raw_device = getattr(torch._C, "_cuda_getDevice", None)
+
+
 def _stream() -> int:
+    if _raw_stream is not None and _raw_device is not None:
+        return _raw_stream(_raw_device())
     return torch.cuda.current_stream().cuda_stream
 
 
@@ -57,7 +66,7 @@ def _tile_queue(device) -> Optional[int]:
     static schedule.  One zeroed buffer per (device, stream): the kernel leaves it zeroed, launches of one stream are ordered."""
     if not dynamic_tile_queue:
         return None
-    key = (device, torch.cuda.current_stream().cuda_stream)
+    key = (device, _stream())
     q = _tile_queues.get(key)
     if q is None:
         q = _tile_queues[key] = torch.zeros(16, device=device, dtype=torch.int32)
@@ -99,7 +108,7 @@ _slab_cache = {}
 def _slab(nbytes: int, device) -> Optional[torch.Tensor]:
     if nbytes == 0:
         return None
-    key = (device, torch.cuda.current_stream().cuda_stream)
+    key = (device, _stream())
     t = _slab_cache.get(key)
     if t is None or t.numel() < nbytes:
         t = torch.empty(nbytes, device=device, dtype=torch.uint8)
@@ -111,7 +120,7 @@ _ws_cache = {}
 
 
 def _ws_f32(nfloats: int, device) -> torch.Tensor:
-    key = (device, torch.cuda.current_stream().cuda_stream)
+    key = (device, _stream())
     t = _ws_cache.get(key)
     if t is None or t.numel() < nfloats:
         t = torch.empty(max(nfloats, 1), device=device, dtype=torch.float32)
@@ -458,7 +467,14 @@ class SplitLayout:
         f_seq, f_r0, f_sh, f_end = (np.concatenate((x, y)) for x, y in zip(qa, qb))
         nf, nq, ns = len(f_seq), len(q_seq), len(lens)
         ints = np.concatenate([np.asarray(x, dtype=np.int32) for x in (f_seq, f_r0, f_sh, f_end, q_seq, q_r0, q_sh, q_end, start_a, v, start_b)])
-        dev_i = torch.from_numpy(ints).to(device, non_blocking=True)
+        if on_gpu:
+            # through pinned memory: a copy from pageable memory makes the host wait until the stream has drained (hipMemcpyAsync
+            # stages it synchronously), i.e. for the whole previous step when the host runs ahead (model.async_prologue)
+            pin = torch.empty(ints.size, dtype=torch.int32, pin_memory=True)
+            pin.numpy()[:] = ints
+            dev_i = pin.to(device, non_blocking=True)
+        else:
+            dev_i = torch.from_numpy(ints).to(device, non_blocking=True)
         cut = np.cumsum([0, nf, nf, nf, nf, nq, nq, nq, nq, ns, ns, ns])
         part = [dev_i[cut[k]:cut[k + 1]] for k in range(11)]
         (self.ftile_seq, self.ftile_r0, self.ftile_qshift, self.ftile_qend, self.tile_seq, self.tile_r0, self.qtile_qshift,
@@ -495,18 +511,30 @@ class Prologue:
     __slots__ = ("key_bias", "kv_len", "valid", "idx", "words", "nseq")
 
 
-def prologue(segs, pass_lens, B, labels, vocab, device) -> Prologue:
+def prologue_sizes(pass_lens, B):
+    """(floats of the padded key bias, ints of everything else) that ``prologue`` writes for these shapes."""
+    nseq = len(pass_lens) * B
+    tokens = sum(B * S for S in pass_lens)
+    return sum(B * ((S + 127) // 128 * 128) for S in pass_lens), 2 * nseq + 3 * nseq + max(tokens, 1) + nseq + 3
+
+
+def prologue(segs, pass_lens, B, labels, vocab, device, bufs=None) -> Prologue:
     """The step prologue in two launches (mmbert_prologue): ``segs`` = [(mask2d [B, len] -- any stride, any mask dtype --, pass index,
-    first position)], ``pass_lens`` = positions per sequence of every pass, ``labels`` = int64 [tokens] in packed order or None."""
+    first position)], ``pass_lens`` = positions per sequence of every pass, ``labels`` = int64 [tokens] in packed order or None.
+    ``bufs`` = (fp32, int32) output buffers of ``prologue_sizes`` elements (the caller's persistent ones) instead of fresh tensors."""
     lib = _lib.load()
     n, npass = len(segs), len(pass_lens)
     nseq = npass * B
     tokens = sum(B * S for S in pass_lens)
-    bias_len = sum(B * ((S + 127) // 128 * 128) for S in pass_lens)
+    bias_len, nints = prologue_sizes(pass_lens, B)
     out = Prologue()
     out.nseq = nseq
-    out.key_bias = torch.empty(bias_len, device=device, dtype=torch.float32)
-    ints = torch.empty(2 * nseq + 3 * nseq + max(tokens, 1) + nseq + 3, device=device, dtype=torch.int32)
+    if bufs is not None:
+        out.key_bias, ints = bufs[0][:bias_len], bufs[1][:nints]
+        assert out.key_bias.numel() == bias_len and ints.numel() == nints and ints.dtype == torch.int32 and out.key_bias.dtype == torch.float32
+    else:
+        out.key_bias = torch.empty(bias_len, device=device, dtype=torch.float32)
+        ints = torch.empty(nints, device=device, dtype=torch.int32)
     out.kv_len, out.valid = ints[:nseq], ints[nseq:2 * nseq]
     seq_cnt = ints[2 * nseq:5 * nseq]
     out.idx = ints[5 * nseq:5 * nseq + max(tokens, 1)]

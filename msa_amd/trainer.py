@@ -158,6 +158,38 @@ def train_epoch(args, model, traindata, optimizer, scheduler, tokenizer=None, *,
     return (float(train_loss) / n, 0.0, 0.0, 0.0, float(ap_loss) / n, float(label_loss) / n)
 
 
+def on_input_stream(model, batches):
+    """Wraps an iterable of model-kwargs dicts whose tensors are BUILT ON THE GPU (dataset.DeviceBatchBuilder, the MLM masking
+    kernel): every batch is produced on ``model.input_stream`` instead of the compute stream, and ``model.async_prologue`` is set --
+    batch building and the step prologue then run ahead of the previous step's backward / optimizer tail, and the host enqueues a
+    step ahead of the GPU (a slow host no longer shows up as GPU idle time).  The source tensors the builder reads must be
+    complete (a resident dataset).  ``train_epoch(..., batches=on_input_stream(model, builder_batches))``."""
+    side = model.input_stream
+    model.async_prologue = True
+
+    def mark(x, main):
+        if torch.is_tensor(x):
+            if x.is_cuda:
+                x.record_stream(main)              # allocated on the input stream's pool, read by the compute stream
+        elif isinstance(x, (tuple, list)):
+            for y in x:
+                mark(y, main)
+        elif isinstance(x, dict):
+            for y in x.values():
+                mark(y, main)
+
+    it = iter(batches)
+    while True:
+        main = torch.cuda.current_stream()
+        with torch.cuda.stream(side):
+            try:
+                b = next(it)
+            except StopIteration:
+                return
+        mark(b, main)
+        yield b
+
+
 class _null:
     def __enter__(self):
         return self

@@ -215,6 +215,38 @@ def test_device_batch_builder_drives_train_epoch():
     assert np.isfinite(last) and last < first, (first, last)
 
 
+def test_batches_built_on_the_input_stream_train_the_same():
+    """trainer.on_input_stream: DeviceBatchBuilder's gathers and the MLM masking kernel run on model.input_stream, the step
+    prologue follows them there (model.async_prologue), the compute stream picks the batch up through an event -- the same epochs
+    as with everything on the compute stream (same seeds: the first epoch's losses agree to rounding noise, the loss falls)."""
+    from tests.golden.dataset_features import synthetic_features
+    from msa_amd.dataset import MMBertDataset, DeviceBatchBuilder
+    from msa_amd import trainer as T
+    ds = MMBertDataset(None, synthetic_features(n_items=24, L=16, seed=4), "mosei", "sentiment", 1)
+    got = {}
+    for side in (False, True):
+        bld = DeviceBatchBuilder(ds, DEV)
+        m = build()
+        m.train()
+        m.manual_seed(3)
+        T._mask_calls = 0                                                 # the masking kernel's seed = torch's CUDA seed, call count
+        torch.manual_seed(100)
+        import random
+        random.seed(9)                                                    # the pair draws follow the reference: Python's ``random``
+        args = T.default_args(train_batch_size=8, learning_rate=2e-3, mlm=True)
+        opt, sched = T.build_optimizer(m, args, 40)
+        rets = []
+        for ep in range(4):
+            batches = bld.epoch(args, generator=torch.Generator().manual_seed(ep))
+            rets.append(T.train_epoch(args, m, None, opt, sched, device=DEV, quirk_step=False,
+                                      batches=T.on_input_stream(m, batches) if side else batches))
+        torch.cuda.synchronize()
+        got[side] = rets
+        assert m.async_prologue == side if side else not getattr(m, "async_prologue", False)
+    assert all(np.isfinite(r[0]) for r in got[True]) and got[True][-1][0] < got[True][0][0]
+    assert abs(got[True][0][0] - got[False][0][0]) <= 2e-3 * abs(got[False][0][0]), (got[True][0], got[False][0])
+
+
 # ================================================================================================ round 2
 def test_device_batch_builder_is_bit_exact_on_cuda(golden_dir):
     """SURVEY S8(f) row 2 on the device: DeviceBatchBuilder("cuda").batch() against the REAL reference's collate() output for the
@@ -367,6 +399,41 @@ def _nccl_world1_worker(port, q):
     except Exception as e:                                                            # pragma: no cover
         import traceback
         q.put(("error", traceback.format_exc(), 0.0))
+
+
+def test_async_prologue_gives_the_same_training_run():
+    """model.async_prologue: the step prologue (key bias, unmasked lengths, labelled rows) and its device -> host copy run on the
+    model's input stream, ahead of the previous step's tail, with two alternating output buffer sets -- the host enqueues a step
+    ahead of the GPU.  Ten seeded train steps (dropout on, AdamW, four different ragged batches, no host synchronisation in
+    between, so the host really runs ahead) against the same run with the prologue on the compute stream.  Training amplifies the
+    fp32-atomics noise of the heads and the embedding scatter, so the yardstick is a SECOND run on the compute stream: the first
+    step (before any update) agrees to rounding, the later ones no worse than two identical runs do."""
+    from msa_amd import trainer as T
+    cfg = dict(hidden=256, layers=3, heads=4, intermediate=1024, vocab=4096, dataset="mosei", alpha=1.0, beta=1.0)
+    pool = [batch_to(synthetic_batch(6, 30, 200, 170, dataset="mosei", vocab=cfg["vocab"], seed=500 + i), DEV) for i in range(4)]
+    runs = {}
+    for tag, async_ in (("a", False), ("b", False), ("async", True)):
+        m = build(cfg, dropout=0.1)
+        m.train()
+        m.manual_seed(11)
+        m.async_prologue = async_
+        opt, sched = T.build_optimizer(m, T.default_args(train_batch_size=6, learning_rate=3e-4), 10, mode="hf")
+        losses = []
+        for i in range(10):
+            out, _ = m(**pool[i % 4])
+            out[0].mean().backward()
+            opt.step(); sched.step(); opt.zero_grad()
+            losses.append(out[0].detach())
+        torch.cuda.synchronize()
+        runs[tag] = (torch.stack(losses).double().cpu(), {n: q.detach().double().clone() for n, q in m.named_parameters()})
+    la, lb, lc = runs["a"][0], runs["b"][0], runs["async"][0]
+    assert bool(torch.isfinite(lc).all())
+    assert abs(float(lc[0] - la[0])) <= 2e-6 * abs(float(la[0]))                     # the same forward
+    noise = float((la - lb).abs().max())
+    assert float((lc - la).abs().max()) <= 3.0 * noise + 1e-3, (lc, la, noise)       # (a wrong key bias or row list moves the loss by > 0.1)
+    pn = max(float((runs["a"][1][n] - runs["b"][1][n]).abs().max()) for n in runs["a"][1])
+    pa = max(float((runs["async"][1][n] - runs["a"][1][n]).abs().max()) for n in runs["a"][1])
+    assert pa <= 3.0 * pn + 1e-4, (pa, pn)
 
 
 def test_data_parallel_over_rccl_world1_equals_plain_step():

@@ -23,6 +23,7 @@ model = MMBertForPretraining(MMBertConfig())
 model.bert.set_joint_embeddings("mosei")
 model.to(dev).train()
 model.manual_seed(1234)
+model.async_prologue = os.environ.get("ASYNC_PROLOGUE", "1") != "0"     # (the pool below is resident; attr.async_prologue=False for the A/B)
 opt, sched = build_optimizer(model, default_args(train_batch_size=16, learning_rate=5e-5), 1000)
 pool = [batch_to(synthetic_batch(16, 50, 500, 500, seed=1 + i), dev) for i in range(4)]
 all_keys = {k for _, env in variants for k in env}

@@ -16,17 +16,16 @@ def step(i):
     out, _ = model(**pool[i % 2]); out[0].mean().backward(); opt.step(); sched.step(); opt.zero_grad()
 for i in range(4): step(i)
 torch.cuda.synchronize()
-with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True) as prof:
+with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True) as prof:
     step(0); torch.cuda.synchronize()
 rows = []
-for ev in prof.key_averages(group_by_stack_n=12):
+for ev in prof.key_averages(group_by_input_shape=True):
     t = getattr(ev, "self_device_time_total", 0) or 0
     if t <= 0 or not ev.key.startswith("aten::"):
         continue
-    src = next((f for f in ev.stack if "msa_amd/" in f), (ev.stack[0] if ev.stack else "?"))
-    rows.append((t, ev.count, ev.key, src.split("msa_amd/")[-1][:80]))
+    rows.append((t, ev.count, ev.key, str(ev.input_shapes)[:110]))
 tot = 0.0
-for t, n, name, src in sorted(rows, reverse=True)[:50]:
-    print(f"{t:8.1f} us {n:3d}x  {name:28s} {src}")
+for t, n, name, shp in sorted(rows, reverse=True)[:60]:
+    print(f"{t:8.1f} us {n:3d}x  {name:20s} {shp}")
     tot += t
 print(f"aten self device time listed: {tot:.0f} us")
