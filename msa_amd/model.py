@@ -23,6 +23,8 @@ import json
 import os
 from typing import Optional
 
+import contextlib
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -735,22 +737,23 @@ class _GpuModelBase(nn.Module):
         # lengths, the rows backward must visit and the labelled-row list, and starts the one device -> host copy of the step
         # (the embedding kernels below keep the GPU busy while it travels and the host packs the layout)
         segs, lens, pair_info = [], [], []
-        for k, p in enumerate(passes):
-            segs.append((self._mask2d(p["mask"], False, dev), k, 0))
-            if p.get("pair") is not None:
-                pairs = p["pair"] if isinstance(p["pair"], (tuple, list)) else (p["pair"],)
-                pmasks = p["pair_mask"] if isinstance(p["pair_mask"], (tuple, list)) else (p["pair_mask"],)
-                off = T
-                for f, pm in zip(pairs, pmasks):
-                    segs.append((self._mask2d(pm, True, dev), k, off))
-                    off += f.shape[1]
-                lens.append(off)
-                pair_info.append((pairs, tuple(je.which(f) for f in pairs)))
-            else:
-                lens.append(T)
-                pair_info.append(None)
-        plan = self._plan(lens, B, dev)
         side = self._prologue_stream()
+        with (torch.cuda.stream(side) if side is not None else contextlib.nullcontext()):     # (a 3-D text mask is reduced by a kernel)
+            for k, p in enumerate(passes):
+                segs.append((self._mask2d(p["mask"], False, dev), k, 0))
+                if p.get("pair") is not None:
+                    pairs = p["pair"] if isinstance(p["pair"], (tuple, list)) else (p["pair"],)
+                    pmasks = p["pair_mask"] if isinstance(p["pair_mask"], (tuple, list)) else (p["pair_mask"],)
+                    off = T
+                    for f, pm in zip(pairs, pmasks):
+                        segs.append((self._mask2d(pm, True, dev), k, off))
+                        off += f.shape[1]
+                    lens.append(off)
+                    pair_info.append((pairs, tuple(je.which(f) for f in pairs)))
+                else:
+                    lens.append(T)
+                    pair_info.append(None)
+        plan = self._plan(lens, B, dev)
         if side is None:
             pro = ops.prologue(segs, lens, B, labels, cfg.vocab_size, dev)
             nseq = pro.nseq
@@ -1271,7 +1274,13 @@ class MMBertForPretraining(_GpuModelBase):
         B, T = text_ids.shape
         passes = [dict(ids=text_ids, tt=token_type_ids, mask=am_t, pair=(visual, speech), pair_mask=(am_v, am_s))]
         V = self.config.vocab_size
-        labels = masked_labels.reshape(-1).to(device=dev, dtype=torch.long)
+        side = self._prologue_stream() if masked_labels.is_cuda else None
+        if side is None:
+            labels = masked_labels.reshape(-1).to(device=dev, dtype=torch.long)
+        else:                                   # async_prologue: see forward()
+            with torch.cuda.stream(side):
+                labels = masked_labels.reshape(-1).to(device=dev, dtype=torch.long)
+            labels.record_stream(torch.cuda.current_stream())
         if labels.numel() != B * (T + visual.shape[1] + speech.shape[1]):
             raise ValueError("masked_labels must cover the text and both pair blocks")
         want_rows = torch.is_grad_enabled() and getattr(self, "sparse_mlm_backward", True) and labels.is_cuda
