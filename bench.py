@@ -73,6 +73,7 @@ def main():
     ap.add_argument("--no-sparse-top-layer", action="store_true", help="A/B: dense backward of the top encoder layer")
     ap.add_argument("--force-dp", action="store_true", help="run the data-parallel path (RCCL process group, DataParallel wrapper, bucketed "
                     "all-reduce hooks, dynamic tile queue) even with ONE process: the N = 1 execution of the code the driver launches at N = 2/4/8")
+    ap.add_argument("--bucket-mb", type=float, default=32.0, help="data parallel: smallest gradient slice handed to an all-reduce")
     ap.add_argument("--sync-prologue", action="store_true", help="A/B: the step prologue on the compute stream (model.async_prologue = False)")
     ap.add_argument("--scores-fp32", action="store_true", help="return the prediction scores as fp32 (model.scores_dtype = torch.float32)")
     a = ap.parse_args()
@@ -116,7 +117,7 @@ def main():
         model.scores_dtype = torch.float32
     targs = default_args(train_batch_size=a.batch, learning_rate=5e-5)
     opt, sched = build_optimizer(model, targs, num_train_optimization_steps=10 * (a.steps + a.warmup))
-    dp = parallel.DataParallel(model, opt, force_dynamic_queue=a.force_dp) if (world > 1 or a.force_dp) else None
+    dp = parallel.DataParallel(model, opt, bucket_mb=a.bucket_mb, force_dynamic_queue=a.force_dp) if (world > 1 or a.force_dp) else None
     pool = [batch_to(synthetic_batch(a.batch, a.text, a.pair, a.pair, vocab=V, seed=1 + i + 1000 * rank), dev) for i in range(4)]
 
     timing = {"nt": [], "tn": [], "attn_fwd": [], "attn_bwd": []}
@@ -298,7 +299,8 @@ def main():
     }
     if dp is not None:
         res["config"]["dp"] = {"backend": torch.distributed.get_backend(), "forced_single_process": bool(a.force_dp and world == 1),
-                               "gemm_tile_queue": "dynamic, one counter per XCD", "bucket_mb": 32.0}
+                               "gemm_tile_queue": "dynamic, one counter per XCD", "bucket_mb": a.bucket_mb,
+                               "all_reduce_calls_per_step": dp.bucketer.calls_per_step if hasattr(dp.bucketer, "calls_per_step") else None}
     if dense_ref is not None:
         res["dense_backward_reference"] = dense_ref
     if train_only is not None:

@@ -84,6 +84,7 @@ class GradBucketer:
         self._issue(self.bounds[-1])
         for h in self.handles:
             h.wait()
+        self.calls_per_step = self.calls
         self.reset()
 
 
