@@ -670,9 +670,14 @@ template <typename SRC>
 __global__ __launch_bounds__(256) void transpose_cast_kernel(const SRC* __restrict__ src, bf16_t* __restrict__ dst,
                                                              const TransDesc* __restrict__ descs, int ndesc) {
     __shared__ float t[64][65];
-    int d = 0;
-    while (d + 1 < ndesc && (int)blockIdx.x >= descs[d + 1].tile0) ++d;
-    const TransDesc ds = descs[d];
+    // the matrix this tile belongs to: binary search over the descriptors' first-tile numbers (a linear scan of the ~50 matrices of a
+    // 12-layer model was ~25 dependent loads in front of every 16-KB tile: 150 -> 118 us per step for the search alone)
+    int lo = 0, hi = ndesc - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if ((int)blockIdx.x >= descs[mid].tile0) lo = mid; else hi = mid - 1;
+    }
+    const TransDesc ds = descs[lo];
     const int tl = blockIdx.x - ds.tile0;
     const int tc = (ds.cols + 63) >> 6;
     const int r0 = (tl / tc) << 6, c0 = (tl % tc) << 6;
