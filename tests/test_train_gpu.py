@@ -215,6 +215,29 @@ def test_device_batch_builder_drives_train_epoch():
     assert np.isfinite(last) and last < first, (first, last)
 
 
+def test_async_prologue_with_changing_batch_shapes():
+    """The prologue's two persistent output sets are sized on demand: batches of different pair lengths and batch sizes in turn
+    (each first use of a larger shape re-allocates a set behind the compute stream) give the losses of the synchronous prologue."""
+    from msa_amd import trainer as T
+    cfg = dict(hidden=128, layers=2, heads=2, intermediate=512, vocab=2048, dataset="mosei", alpha=1.0, beta=1.0)
+    shapes = [(3, 20, 60, 40), (5, 24, 200, 170), (2, 12, 30, 30), (5, 24, 200, 170), (6, 30, 260, 90), (3, 20, 60, 40)]
+    pool = [batch_to(synthetic_batch(b, t, pv, pa, dataset="mosei", vocab=cfg["vocab"], seed=700 + i), DEV) for i, (b, t, pv, pa) in enumerate(shapes)]
+    got = {}
+    for async_ in (False, True):
+        m = build(cfg)
+        m.eval()                                                           # no dropout, no update: every step is a pure function of its batch
+        m.async_prologue = async_
+        losses = []
+        for b in pool:
+            out, _ = m(**b)
+            out[0].mean().backward()
+            losses.append(out[0].detach())
+        torch.cuda.synchronize()
+        got[async_] = torch.stack(losses).double().cpu()
+    assert bool(torch.isfinite(got[True]).all())
+    assert torch.allclose(got[True], got[False], rtol=3e-6, atol=1e-7), (got[True], got[False])
+
+
 def test_batches_built_on_the_input_stream_train_the_same():
     """trainer.on_input_stream: DeviceBatchBuilder's gathers and the MLM masking kernel run on model.input_stream, the step
     prologue follows them there (model.async_prologue), the compute stream picks the batch up through an event -- the same epochs
