@@ -52,7 +52,7 @@ for it in range(int(os.environ.get("N", 24))):
             g0, g1 = res["dense"][1][n], res[mode][1][n]
             # one bf16 rounding flip of an activation gradient is 2^-9 relative on that element; 5e-7: gradients that are what is left
             # of cancelling terms (CPC at init) carry the fp32-atomics noise of the heads
-            if not float((g1 - g0).abs().max()) <= 5e-3 * float(g0.abs().max()) + 5e-7:
+            if not float((g1 - g0).abs().max()) <= 8e-3 * float(g0.abs().max()) + 5e-7:   # (one bf16 ulp of the largest entry is 2^-8 of it)
                 why.append(f"{mode} grad {n} {float((g1 - g0).abs().max()):.3g} of {float(g0.abs().max()):.3g}")
     if not all(torch.equal(res["fast"][2][k], res["dense"][2][k]) for k in (7, 9, 11)):
         why.append("fast scores")
