@@ -599,13 +599,21 @@ class _GpuModelBase(nn.Module):
             s = self.__dict__["_input_stream"] = torch.cuda.Stream()
         return s
 
-    def _prologue_stream(self):
-        """None, or the input stream when ``model.async_prologue`` is set.  That switch is the CALLER's statement that (a) the tensors
-        it passes to forward() are not still being written by work queued on the current stream -- they are static or prefetched
-        (and synchronised), or were built on ``model.input_stream`` -- and (b) it runs the trainer's order, every forward followed
-        by its backward before the next forward but one (the prologue's outputs live in two alternating buffer sets).  The masks
-        and labels are then read on the input stream without waiting for the current one."""
-        return self.input_stream if getattr(self, "async_prologue", False) else None
+    def _prologue_stream(self, first=None):
+        """None, or the input stream when the step prologue may run there, AHEAD of the current stream -- which is the case
+        * for a batch ``trainer.on_input_stream`` has just built on ``model.input_stream``: it tags the batch (``first``, the batch's
+          first tensor, is the tagged one), so an eval_epoch or a plain train_epoch that follows in the same process -- batches built
+          on the CURRENT stream -- takes the synchronous path again (round 2 set a sticky flag there: masks and labels of such
+          batches were then read before they were written);
+        * when ``model.async_prologue`` is set: the CALLER's statement that (a) the tensors it passes to forward() are not still
+          being written by work queued on the current stream -- they are static or prefetched (and synchronised; bench.py) -- and
+          (b) it runs the trainer's order, every forward followed by its backward before the next forward but one (the prologue's
+          outputs live in two alternating buffer sets).
+        The masks and labels are then read on the input stream without waiting for the current one."""
+        tag = self.__dict__.get("_input_stream_batch")
+        if getattr(self, "async_prologue", False) or (tag is not None and tag is first):
+            return self.input_stream
+        return None
 
     def manual_seed(self, seed: int):
         self._seed, self._calls = int(seed), 0
@@ -737,7 +745,7 @@ class _GpuModelBase(nn.Module):
         # lengths, the rows backward must visit and the labelled-row list, and starts the one device -> host copy of the step
         # (the embedding kernels below keep the GPU busy while it travels and the host packs the layout)
         segs, lens, pair_info = [], [], []
-        side = self._prologue_stream()
+        side = self._prologue_stream(passes[0]["ids"])
         with (torch.cuda.stream(side) if side is not None else contextlib.nullcontext()):     # (a 3-D text mask is reduced by a kernel)
             for k, p in enumerate(passes):
                 segs.append((self._mask2d(p["mask"], False, dev), k, 0))
@@ -1111,24 +1119,72 @@ class MMBertForPretraining(_GpuModelBase):
         self.cls.predictions.decoder.weight = self.bert.embeddings.word_embeddings.weight
 
     # ---- construction helpers ------------------------------------------------------------------
+    @staticmethod
+    def _checkpoint_keys(sd):
+        """A HuggingFace BERT checkpoint's keys in this model's names -- what ``from_pretrained`` does on load in the reference
+        flow (REF:train.py:70):
+        * ``LayerNorm.gamma`` / ``LayerNorm.beta`` -> ``LayerNorm.weight`` / ``LayerNorm.bias``: the published ``bert-base-uncased`` /
+          ``bert-large-uncased`` files still carry the TF names (HF ``conversion_mapping.py:1274-1283`` "legacy"; transformers 2.8
+          did the same rename in ``modeling_utils.from_pretrained``);
+        * a ``BertModel``-only checkpoint (keys ``embeddings.* / encoder.* / pooler.*`` without the ``bert.`` prefix) gets the prefix
+          (HF ``base_model_prefix`` handling);
+        * the transformers-4.x ``position_ids`` buffer is dropped."""
+        out = {}
+        for k, v in sd.items():
+            if k.endswith("position_ids"):
+                continue
+            if k.endswith("LayerNorm.gamma"):
+                k = k[:-len("gamma")] + "weight"
+            elif k.endswith("LayerNorm.beta"):
+                k = k[:-len("beta")] + "bias"
+            out[k] = v
+        if out and not any(k.startswith(("bert.", "cls.")) for k in out) and any(k.startswith(("embeddings.", "encoder.")) for k in out):
+            out = {"bert." + k: v for k, v in out.items()}
+        return out
+
     @classmethod
-    def from_pretrained(cls, name_or_path, **kw):
-        """Loads ``config.json`` + ``pytorch_model.bin``/``model.safetensors`` from a LOCAL directory
-        (HF BertForPreTraining key names load as is).  There is no network on the target boxes."""
+    def from_pretrained(cls, name_or_path, ignore_unexpected=False, **kw):
+        """Loads ``config.json`` + ``pytorch_model.bin`` / ``model.safetensors`` from a LOCAL directory (there is no network on the
+        target boxes): ``BertForPreTraining`` / ``BertForMaskedLM`` / ``BertModel`` key names, current or legacy (``_checkpoint_keys``).
+        LOUD about what did not arrive: a missing ``bert.embeddings.*`` / ``bert.encoder.*`` tensor raises (a silently fresh encoder
+        is never what the caller wants), as does any key of the file that matches nothing in the model (``ignore_unexpected=True``
+        downgrades that to a warning); heads the file does not have (``cls.*``, ``bert.pooler.*``) and the reference's own additions
+        (jointEmbeddings, fusion head, CPC) keep their fresh initialisation, with a warning that names them -- HF's
+        "newly initialized" message.  ``model.load_report`` = dict(missing=[...], unexpected=[...])."""
+        import warnings
         if not os.path.isdir(name_or_path):
             raise OSError(f"{name_or_path}: from_pretrained needs a local checkpoint directory (no network access)")
         with open(os.path.join(name_or_path, "config.json")) as fh:
             cfg = MMBertConfig(**json.load(fh))
         model = cls(cfg)
-        sd = None
         st = os.path.join(name_or_path, "model.safetensors")
         if os.path.exists(st):
             from safetensors.torch import load_file
             sd = load_file(st)
         else:
             sd = torch.load(os.path.join(name_or_path, "pytorch_model.bin"), map_location="cpu")
-        sd = {k: v for k, v in sd.items() if not k.endswith("position_ids")}
-        model.load_state_dict(sd, strict=False)
+        sd = cls._checkpoint_keys(sd)
+        res = model.load_state_dict(sd, strict=False)
+        # tied pairs share storage (decoder.weight IS the word embedding, decoder.bias IS predictions.bias): one name of a pair suffices
+        alias = {"cls.predictions.decoder.weight": "bert.embeddings.word_embeddings.weight", "cls.predictions.decoder.bias": "cls.predictions.bias"}
+        alias.update({v: k for k, v in list(alias.items())})
+        # (only names a HuggingFace BERT file can hold count as missing: cls.align, the fusion head, CPC are the reference's additions)
+        hf_side = ("bert.embeddings.", "bert.encoder.", "bert.pooler.", "cls.predictions.", "cls.seq_relationship.")
+        missing = [k for k in res.missing_keys if k.startswith(hf_side) and alias.get(k) not in sd]
+        unexpected = list(res.unexpected_keys)
+        model.load_report = dict(missing=missing, unexpected=unexpected)
+        core = [k for k in missing if k.startswith(("bert.embeddings.", "bert.encoder."))]
+        if core:
+            raise ValueError(f"{name_or_path}: the checkpoint has no tensor for {len(core)} encoder parameter(s): {core[:8]}"
+                             f"{' ...' if len(core) > 8 else ''} (key names after the legacy renames: see _checkpoint_keys)")
+        if unexpected:
+            msg = f"{name_or_path}: {len(unexpected)} checkpoint tensor(s) match no parameter of MMBertForPretraining: {unexpected[:8]}{' ...' if len(unexpected) > 8 else ''}"
+            if not ignore_unexpected:
+                raise ValueError(msg + " (from_pretrained(..., ignore_unexpected=True) loads the rest anyway)")
+            warnings.warn(msg)
+        fresh = [k for k in missing if k.startswith(("cls.", "bert.pooler."))]
+        if fresh:
+            warnings.warn(f"{name_or_path}: newly initialised (not in the checkpoint): {fresh}")
         return model
 
     def set_alpha_beta(self, alpha, beta):
@@ -1230,7 +1286,7 @@ class MMBertForPretraining(_GpuModelBase):
                   dict(ids=twv, tt=None, mask=am_v[0].to(dev), pair=visual, pair_mask=am_v[1].to(dev)),
                   dict(ids=tws, tt=None, mask=am_s[0].to(dev), pair=speech, pair_mask=am_s[1].to(dev))]
         H, V = self.config.hidden_size, self.config.vocab_size
-        side = self._prologue_stream() if lab_t.is_cuda else None
+        side = self._prologue_stream(text_ids) if lab_t.is_cuda else None
         if side is None:
             labels = torch.cat((lab_t.reshape(-1), lab_v.reshape(-1), lab_s.reshape(-1))).to(device=dev, dtype=torch.long)
         else:                                   # async_prologue: the prologue's inputs must not queue behind the current stream
@@ -1274,7 +1330,7 @@ class MMBertForPretraining(_GpuModelBase):
         B, T = text_ids.shape
         passes = [dict(ids=text_ids, tt=token_type_ids, mask=am_t, pair=(visual, speech), pair_mask=(am_v, am_s))]
         V = self.config.vocab_size
-        side = self._prologue_stream() if masked_labels.is_cuda else None
+        side = self._prologue_stream(text_ids) if masked_labels.is_cuda else None
         if side is None:
             labels = masked_labels.reshape(-1).to(device=dev, dtype=torch.long)
         else:                                   # async_prologue: see forward()

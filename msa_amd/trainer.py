@@ -160,12 +160,14 @@ def train_epoch(args, model, traindata, optimizer, scheduler, tokenizer=None, *,
 
 def on_input_stream(model, batches):
     """Wraps an iterable of model-kwargs dicts whose tensors are BUILT ON THE GPU (dataset.DeviceBatchBuilder, the MLM masking
-    kernel): every batch is produced on ``model.input_stream`` instead of the compute stream, and ``model.async_prologue`` is set --
-    batch building and the step prologue then run ahead of the previous step's backward / optimizer tail, and the host enqueues a
-    step ahead of the GPU (a slow host no longer shows up as GPU idle time).  The source tensors the builder reads must be
-    complete (a resident dataset).  ``train_epoch(..., batches=on_input_stream(model, builder_batches))``."""
+    kernel): every batch is produced on ``model.input_stream`` instead of the compute stream and TAGGED for the model (its first
+    tensor is remembered until the next batch is asked for), so that forward() runs the step prologue on the input stream too --
+    batch building and the prologue then run ahead of the previous step's backward / optimizer tail, and the host enqueues a step
+    ahead of the GPU (a slow host no longer shows up as GPU idle time).  Only the tagged batch takes that path: an eval_epoch or a
+    plain train_epoch afterwards, whose batches are built on the compute stream, is synchronised as usual (the model's own
+    ``async_prologue`` switch is left alone).  The source tensors the builder reads must be complete (a resident dataset).
+    ``train_epoch(..., batches=on_input_stream(model, builder_batches))``."""
     side = model.input_stream
-    model.async_prologue = True
 
     def mark(x, main):
         if torch.is_tensor(x):
@@ -178,16 +180,25 @@ def on_input_stream(model, batches):
             for y in x.values():
                 mark(y, main)
 
+    def first_tensor(b):
+        ids = b.get("input_ids")
+        return ids[0] if isinstance(ids, (tuple, list)) else ids
+
     it = iter(batches)
-    while True:
-        main = torch.cuda.current_stream()
-        with torch.cuda.stream(side):
-            try:
-                b = next(it)
-            except StopIteration:
-                return
-        mark(b, main)
-        yield b
+    try:
+        while True:
+            main = torch.cuda.current_stream()
+            with torch.cuda.stream(side):
+                try:
+                    b = next(it)
+                except StopIteration:
+                    return
+            mark(b, main)
+            model.__dict__["_input_stream_batch"] = first_tensor(b)
+            yield b
+            model.__dict__["_input_stream_batch"] = None
+    finally:                                       # exhausted, closed or abandoned: nothing stays tagged
+        model.__dict__["_input_stream_batch"] = None
 
 
 class _null:
@@ -294,8 +305,9 @@ test_CE_score_model.__test__ = False                                # names star
 test_MSE_score_model.__test__ = False
 
 
-def make_date_dir(path):
-    """REF:utils.py:35-50: ``path/<YYYYMMDD>-NN`` with the first unused NN, created."""
+def _dated_dir(path):
+    """``path/<YYYYMMDD>-NN`` with the first unused NN, created: where train() below saves (the reference's directory naming, REF:utils.py:35-50;
+    the reference's logging / path utilities themselves are out of scope)."""
     import datetime
     import os
     os.makedirs(path, exist_ok=True)
@@ -318,7 +330,7 @@ def train(args, model, train_dataset, val_dataset, test_dataset, optimizer, sche
     import os
     import numpy as np
     log = logger.info if logger is not None else (lambda *a, **k: None)
-    save_dir = make_date_dir(save_root)
+    save_dir = _dated_dir(save_root)
     log("Model save path: {}".format(save_dir))
     score = test_MSE_score_model if getattr(args, "num_labels", 7) in (1, 7) else test_CE_score_model
     best = dict(epoch=-1, acc=0.0, loss=float("inf"), mae=None, f_score=None, preds=None, labels=None, path=None)
@@ -351,7 +363,7 @@ def train(args, model, train_dataset, val_dataset, test_dataset, optimizer, sche
             patience = 0
         if patience == patience_limit:
             if rank0 and best["preds"] is not None:
-                out = make_date_dir(numpy_root)
+                out = _dated_dir(numpy_root)
                 np.save(os.path.join(out, "predict.npy"), best["preds"])
                 np.save(os.path.join(out, "target.npy"), best["labels"])
             break

@@ -196,12 +196,6 @@ def test_score_functions_match_their_definitions():
     assert abs(T._weighted_f1([0, 0, 1, 1], [0, 1, 1, 1]) - (2 / 3 + 4 / 5) / 2) < 1e-12
 
 
-def test_make_date_dir_counts_up(tmp_path):
-    a = T.make_date_dir(str(tmp_path / "model_save"))
-    b = T.make_date_dir(str(tmp_path / "model_save"))
-    assert a != b and os.path.isdir(a) and os.path.isdir(b) and a.endswith("-00") and b.endswith("-01")
-
-
 # ------------------------------------------------------------------------------- MMBertDataset / device batch builder
 def _np(v):
     return np.asarray(v.detach().cpu().numpy() if torch.is_tensor(v) else v)
@@ -337,3 +331,83 @@ def test_epoch_shards_have_equal_batch_counts_world2_gloo():
         p.join(60)
         assert p.exitcode == 0
     assert n == 2 and total == 8.0              # 7 items -> 8 after wrapping, 4 per rank, batches of 2
+
+
+# ------------------------------------------------------------------------------- from_pretrained: the checkpoints the reference loads
+def _hf_checkpoint(cfg, seed=3):
+    from oracle import mmbert_oracle as O
+    sd = O.seeded_params(cfg, seed)
+    hf = {k: v for k, v in sd.items() if k.startswith(("bert.embeddings", "bert.encoder", "bert.pooler", "cls.predictions", "cls.seq_relationship"))}
+    hf["cls.predictions.decoder.weight"] = sd["bert.embeddings.word_embeddings.weight"]
+    conf = dict(vocab_size=cfg["vocab"], hidden_size=cfg["hidden"], num_hidden_layers=cfg["layers"], num_attention_heads=cfg["heads"],
+                intermediate_size=cfg["intermediate"], max_position_embeddings=512, type_vocab_size=2, model_type="bert")
+    return hf, conf
+
+
+def _write_ckpt(d, conf, sd):
+    import json
+    d.mkdir()
+    (d / "config.json").write_text(json.dumps(conf))
+    torch.save(sd, d / "pytorch_model.bin")
+    return str(d)
+
+
+def test_from_pretrained_reads_legacy_and_prefixless_checkpoints_and_is_loud(tmp_path):
+    """REF:train.py:70 loads ``bert-base/large-uncased``: those files carry the TF-era ``LayerNorm.gamma`` / ``LayerNorm.beta`` names
+    (HF renames them on load: conversion_mapping.py:1274-1283, "legacy"), and a ``BertModel``-only checkpoint has no ``bert.`` prefix.
+    Both must load to the SAME parameters as the current-named file; a missing encoder tensor or a key that matches nothing raises
+    (round 2 loaded such files with every LayerNorm silently left at (1, 0))."""
+    import warnings
+    from msa_amd.model import MMBertForPretraining
+    cfg = dict(hidden=64, layers=2, heads=2, intermediate=128, vocab=300, dataset="mosei")
+    hf, conf = _hf_checkpoint(cfg)
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")                                       # a complete BertForPreTraining file: nothing to warn about
+        ref = MMBertForPretraining.from_pretrained(_write_ckpt(tmp_path / "current", conf, hf))
+    assert ref.load_report == dict(missing=[], unexpected=[])
+    want = {k: v for k, v in ref.state_dict().items() if k.startswith(("bert.", "cls.")) and not k.startswith("cls.align")}   # (align: fresh)
+    for k, v in hf.items():
+        assert torch.equal(want[k], v), k
+    ln = [k for k in hf if "LayerNorm" in k]
+    assert len(ln) == 2 * (1 + 2 * cfg["layers"] + 1) and any(float((hf[k] - (1.0 if k.endswith("weight") else 0.0)).abs().max()) > 0.05 for k in ln)
+
+    # (1) legacy names
+    legacy = {(k[:-6] + "gamma" if k.endswith("LayerNorm.weight") else k[:-4] + "beta" if k.endswith("LayerNorm.bias") else k): v for k, v in hf.items()}
+    assert sum(k.endswith((".gamma", ".beta")) for k in legacy) == len(ln)
+    m = MMBertForPretraining.from_pretrained(_write_ckpt(tmp_path / "legacy", conf, legacy))
+    got = m.state_dict()
+    for k, v in want.items():
+        assert torch.equal(got[k], v), k
+    assert m.load_report == dict(missing=[], unexpected=[])
+
+    # (2) BertModel-only file: no prefix, no heads -> same encoder, heads fresh WITH a warning that names them
+    bare = {k[len("bert."):]: v for k, v in legacy.items() if k.startswith("bert.")}
+    with pytest.warns(UserWarning, match="newly initialised.*cls.predictions.transform.dense.weight"):
+        m = MMBertForPretraining.from_pretrained(_write_ckpt(tmp_path / "bare", conf, bare))
+    got = m.state_dict()
+    for k, v in want.items():
+        if k.startswith("bert."):
+            assert torch.equal(got[k], v), k
+    assert torch.equal(got["cls.predictions.decoder.weight"], want["bert.embeddings.word_embeddings.weight"])      # still tied
+    assert all(k.startswith("cls.") for k in m.load_report["missing"]) and m.load_report["unexpected"] == []
+
+    # (3) one encoder tensor removed -> raises and names it
+    broken = dict(hf)
+    del broken["bert.encoder.layer.1.output.LayerNorm.weight"]
+    with pytest.raises(ValueError, match="bert.encoder.layer.1.output.LayerNorm.weight"):
+        MMBertForPretraining.from_pretrained(_write_ckpt(tmp_path / "broken", conf, broken))
+
+    # (4) a key that matches nothing raises; ignore_unexpected=True downgrades it to a warning
+    extra = dict(hf, **{"bert.encoder.layer.0.attention.self.distance_embedding.weight": torch.zeros(3, 4)})
+    path = _write_ckpt(tmp_path / "extra", conf, extra)
+    with pytest.raises(ValueError, match="distance_embedding"):
+        MMBertForPretraining.from_pretrained(path)
+    with pytest.warns(UserWarning, match="distance_embedding"):
+        m = MMBertForPretraining.from_pretrained(path, ignore_unexpected=True)
+    assert torch.equal(m.state_dict()["bert.pooler.dense.weight"], hf["bert.pooler.dense.weight"])
+
+    # (5) decoder.bias as the only name of the tied prediction bias (BertForMaskedLM-style files) is not "missing"
+    alias = {k: v for k, v in hf.items() if k != "cls.predictions.bias"}
+    alias["cls.predictions.decoder.bias"] = hf["cls.predictions.bias"]
+    m = MMBertForPretraining.from_pretrained(_write_ckpt(tmp_path / "alias", conf, alias))
+    assert m.load_report["missing"] == [] and torch.equal(m.state_dict()["cls.predictions.bias"], hf["cls.predictions.bias"])

@@ -263,11 +263,28 @@ def test_batches_built_on_the_input_stream_train_the_same():
             batches = bld.epoch(args, generator=torch.Generator().manual_seed(ep))
             rets.append(T.train_epoch(args, m, None, opt, sched, device=DEV, quirk_step=False,
                                       batches=T.on_input_stream(m, batches) if side else batches))
+        # what follows an input-stream epoch in the same process is built on the COMPUTE stream: an evaluation pass
+        # whose batches (gathers + masking kernel) are still being written when forward() is called must wait for them -- the tag
+        # of on_input_stream is per batch and gone, the model's own switch was never touched
+        assert not getattr(m, "async_prologue", False) and m.__dict__.get("_input_stream_batch") is None
+        args.val_batch_size = 8
+        rs = random.getstate()
+        T._mask_calls = 1000
+        ev = T.eval_epoch(args, m, None, device=DEV, batches=bld.epoch(args, generator=torch.Generator().manual_seed(77)))
         torch.cuda.synchronize()
-        got[side] = rets
-        assert m.async_prologue == side if side else not getattr(m, "async_prologue", False)
-    assert all(np.isfinite(r[0]) for r in got[True]) and got[True][-1][0] < got[True][0][0]
+        random.setstate(rs)                                               # ... and once more from a drained GPU: the same numbers
+        T._mask_calls = 1000
+        ev2 = T.eval_epoch(args, m, None, device=DEV, batches=bld.epoch(args, generator=torch.Generator().manual_seed(77)))
+        assert all(abs(a - b) <= 1e-5 * abs(b) + 1e-7 for a, b in zip(ev[:6], ev2[:6])), (ev[:6], ev2[:6])
+        assert np.array_equal(ev[7], ev2[7]) and np.allclose(ev[6], ev2[6], rtol=1e-4, atol=1e-5)
+        got[side] = rets + [ev]
+    assert all(np.isfinite(r[0]) for r in got[True]) and got[True][-2][0] < got[True][0][0]
     assert abs(got[True][0][0] - got[False][0][0]) <= 2e-3 * abs(got[False][0][0]), (got[True][0], got[False][0])
+    # the evaluation pass after the input-stream epochs: finite, and the same numbers as after the compute-stream epochs up to what
+    # the two training runs differ by (same seeds, same items)
+    ea, eb = got[True][-1], got[False][-1]
+    assert np.isfinite(ea[0]) and abs(ea[0] - eb[0]) <= 0.1 * abs(eb[0]), (ea[:6], eb[:6])
+    assert np.array_equal(ea[7], eb[7])                                   # same items in the same order (labels)
 
 
 # ================================================================================================ round 2
