@@ -793,6 +793,7 @@ int mmbert_attn_fwd(hipStream_t stream, const void* qkv, void* ctx, float* lse, 
     AttnArgs a;
     if (fill_args(a, qkv, H, heads, key_bias, bias_start, seq_start, seq_len, elem_base, tile_seq, tile_r0, lse, dstream, dthr, dscale, kv_len)) return -1;
     a.ctx = (bf16_t*)ctx; a.tile_qshift = tile_qshift; a.tile_qend = tile_qend;
+    if (ntiles > 65535) a.head_fast = 0;               // gridDim.y is a 16-bit field: very long tile lists go back to grid (tiles, heads)
     static const int extra_lds = getenv("MMBERT_ATTN_EXTRA_LDS") ? atoi(getenv("MMBERT_ATTN_EXTRA_LDS")) : 0;   // occupancy experiments
     if (dthr) hipLaunchKernelGGL(attn_fwd_kernel<true>, a.head_fast ? dim3(heads, ntiles) : dim3(ntiles, heads), dim3(256), extra_lds, stream, a);
     else hipLaunchKernelGGL(attn_fwd_kernel<false>, a.head_fast ? dim3(heads, ntiles) : dim3(ntiles, heads), dim3(256), extra_lds, stream, a);
@@ -812,11 +813,13 @@ int mmbert_attn_bwd(hipStream_t stream, const void* qkv, const void* ctx, const 
     {
         AttnArgs q = a;
         q.tile_seq = qtile_seq; q.tile_r0 = qtile_r0; q.tile_qshift = qtile_qshift; q.tile_qend = qtile_qend;
+        if (nqtiles > 65535) q.head_fast = 0;          // (gridDim.y limit, see mmbert_attn_fwd)
         if (dthr) hipLaunchKernelGGL(attn_bwd_dq_kernel<true>, q.head_fast ? dim3(heads, nqtiles) : dim3(nqtiles, heads), dim3(256), 0, stream, q);
         else hipLaunchKernelGGL(attn_bwd_dq_kernel<false>, q.head_fast ? dim3(heads, nqtiles) : dim3(nqtiles, heads), dim3(256), 0, stream, q);
         MMB_CHECK_LAUNCH();
     }
     a.split = split;
+    if (ntiles > 65535) a.head_fast = 0;
     if (dthr) hipLaunchKernelGGL(attn_bwd_dkv_kernel<true>, a.head_fast ? dim3(heads, ntiles) : dim3(ntiles, heads), dim3(256), 0, stream, a);
     else hipLaunchKernelGGL(attn_bwd_dkv_kernel<false>, a.head_fast ? dim3(heads, ntiles) : dim3(ntiles, heads), dim3(256), 0, stream, a);
     MMB_CHECK_LAUNCH();

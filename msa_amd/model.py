@@ -283,7 +283,7 @@ class _EncoderFn(torch.autograd.Function):
         # LayerNorm' leaves its gamma / beta partial sums in a workspace; ONE reduce launch folds all layers' sums into the gradients at
         # the end (with a data-parallel hook: per layer, before the layer's gradient slice is handed to the all-reduce); same-process
         # A/B against round 1's form (bias sums inside LayerNorm', one reduce launch per call): 16.58 vs 16.76 ms per step
-        lnd = ops.LnDeferred()
+        lnd = ops.LnDeferred(2 * top.config.num_hidden_layers)
         for i in reversed(range(top.config.num_hidden_layers)):
             lw = top._lw[i]
             saved_i = ctx.saved[i]

@@ -240,21 +240,32 @@ def ln_bwd(dy, x, mean, rstd, gamma, dgamma, dbeta, *, M=None, dx=None, dx2=None
     return dx
 
 
+_lnd_cache = {}
+
+
 class LnDeferred:
     """Collects the partial-sum workspaces of several ``ln_bwd(..., deferred=self)`` calls that share M and H (an encoder's 2 per
-    layer) and folds them into their gradients with ONE ``mmbert_ln_bwd_reduce`` launch per 32 calls: ``flush()``."""
+    layer) and folds them into their gradients with ONE ``mmbert_ln_bwd_reduce`` launch per ``slots`` calls: ``flush()``.
+    ``slots``: how many calls the caller expects before its flush (2 x layers for an encoder backward; at most 32 per launch).  The
+    workspace is ONE persistent buffer per (device, stream) that grows on demand -- not a fresh 32-slot allocation per backward
+    (300 MB at the headline shape where 24 slots are used, and churn in the caching allocator when M changes with the data)."""
 
-    def __init__(self):
-        self.items, self.key, self.ws, self.used = [], None, None, 0
+    def __init__(self, slots: int = 32):
+        self.items, self.key, self.ws = [], None, None
+        self.slots = max(1, min(32, int(slots)))
 
     def slot(self, M, H, device, dgamma, dbeta, dbias2) -> int:
         key = (M, H)
-        if self.key is not None and (key != self.key or len(self.items) == 32):
+        if self.key is not None and (key != self.key or len(self.items) == self.slots):
             self.flush()
         self.key = key
         per = _lib.load().mmbert_ln_bwd_workspace(M, H)
-        if self.ws is None or self.ws.numel() < 32 * per or self.ws.device != device:
-            self.ws = torch.empty(32 * per, device=device, dtype=torch.float32)
+        if not self.items:                                   # (a buffer in use by queued launches is never replaced mid-collection)
+            ck = (device, _stream())
+            ws = _lnd_cache.get(ck)
+            if ws is None or ws.numel() < self.slots * per:
+                ws = _lnd_cache[ck] = torch.empty(self.slots * per, device=device, dtype=torch.float32)
+            self.ws = ws
         ptr = self.ws.data_ptr() + 4 * per * len(self.items)
         self.items.append((ptr, dgamma.data_ptr(), dbeta.data_ptr(), dbias2.data_ptr() if dbias2 is not None else None))
         return ptr

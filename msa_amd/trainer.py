@@ -17,7 +17,28 @@ import torch
 from torch.nn.utils.rnn import pad_sequence
 
 PAD, CLS, SEP, MASK = 0, 101, 102, 103
-_mask_calls = 0          # call counter folded into the seed of the device-side masking kernel
+_mask_calls = 0          # fallback call counter (only when the CUDA generator's offset cannot be read)
+
+
+def _device_mask_seed(device) -> int:
+    """The per-call seed of the device-side masking kernel, taken from torch's default CUDA generator of ``device``: its seed and
+    its philox OFFSET, which this call advances by 4 (what one ``torch.bernoulli`` launch would consume).  So ``torch.manual_seed(s)``
+    (seed := s, offset := 0) reproduces the masks from that point on, ``get_rng_state`` / ``set_rng_state`` capture them, and other
+    CUDA draws in between shift them -- like a torch draw.  The data-parallel rank is folded in: ranks seeded alike still draw
+    different selection patterns.  NOT the bits torch.bernoulli would produce (counter RNG of csrc/common.h; selection / replacement
+    probabilities are quantised to 1/65536)."""
+    global _mask_calls
+    dev = torch.device(device)
+    idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    gen = torch.cuda.default_generators[idx]
+    try:
+        off = gen.get_offset()
+        gen.set_offset(off + 4)
+    except (AttributeError, RuntimeError):                    # (older torch: no offset accessors -> process-wide call counter)
+        _mask_calls += 1
+        off = 4 * _mask_calls
+    rank = torch.distributed.get_rank() if (torch.distributed.is_available() and torch.distributed.is_initialized()) else 0
+    return (gen.initial_seed() * 1000003 + (off // 4) * 8191 + rank * 0x9E3779B97F4A7C15) & 0xFFFFFFFFFFFFFFFF
 
 
 def mask_tokens(inputs: torch.Tensor, args, generator: Optional[torch.Generator] = None, special_ids=(CLS, SEP), mask_id=MASK):
@@ -33,12 +54,11 @@ def mask_tokens(inputs: torch.Tensor, args, generator: Optional[torch.Generator]
     pinned by tests/golden/mask_tokens.npz)."""
     if inputs.is_cuda and generator is None and inputs.dtype == torch.int64 and len(special_ids) <= 3:
         # on the GPU: one launch of the library's counter-RNG masking kernel (mmbert_mlm_mask) instead of ~10 element-wise
-        # torch kernels; the per-call seed comes from torch's default CUDA generator, so torch.manual_seed() governs it
-        global _mask_calls
-        _mask_calls += 1
+        # torch kernels; the per-call seed is drawn from torch's default CUDA generator (seed + offset, see _device_mask_seed), so
+        # torch.manual_seed() / the CUDA RNG state govern it; pass a ``generator`` for torch's own bernoulli draws
         from . import ops
         x = inputs if inputs.is_contiguous() else inputs.contiguous()
-        labels = ops.mlm_mask(x, float(args.mlm_probability), torch.cuda.initial_seed() * 1000003 + _mask_calls,
+        labels = ops.mlm_mask(x, float(args.mlm_probability), _device_mask_seed(inputs.device),
                               special_ids=tuple(special_ids), mask_id=mask_id)
         if x is not inputs:
             inputs.copy_(x)

@@ -669,3 +669,26 @@ def test_skinny_products_of_the_heads(ops):
     assert float((gW2.cpu() - (1.0 + drel.t() @ X[B:])).abs().max()) < 2e-4 * float((drel.t() @ X[B:]).abs().max())
     assert float((gb2.cpu() - drel.sum(0)).abs().max()) < 1e-4
     assert float(gWide[:, :H].abs().max()) == 0.0 and torch.allclose(gWide[:, H:], gW, rtol=1e-5, atol=1e-6)
+
+
+def test_attention_with_more_than_65535_tiles(ops):
+    """Tile lists longer than gridDim.y's 16-bit range (a large no-grad evaluation batch: 3 passes x B x ~5 tiles) -- the launchers
+    fall back to grid (tiles, heads) there; spot-checked sequences against fp32, forward and backward."""
+    n, S, heads = 66000, 8, 1
+    H = 64 * heads
+    g = torch.Generator().manual_seed(3)
+    qkv = bf(torch.randn(n * S, 3 * H, generator=g))
+    dctx = bf(torch.randn(n * S, H, generator=g))
+    layout = ops.SeqLayout([S] * n, heads, DEV)
+    assert layout.nftiles > 65535
+    bias = torch.zeros(n * S)
+    ctx, lse = ops.attn_fwd(qkv.to(DEV), bias.to(DEV), layout, H)
+    dqkv = ops.attn_bwd(qkv.to(DEV), ctx, dctx.to(DEV), lse, bias.to(DEV), layout, H)
+    torch.cuda.synchronize()
+    for i in (0, 1, 32767, 65535, 65536, n - 1):
+        x = qkv[i * S:(i + 1) * S].float().requires_grad_(True)
+        q, k, v = (x[:, j * H:(j + 1) * H].view(S, heads, 64).transpose(0, 1)[None] for j in range(3))
+        ref = ref_attention(q, k, v, bias[:S])[0].transpose(0, 1).reshape(S, H)
+        ref.backward(dctx[i * S:(i + 1) * S].float())
+        assert_close(ctx[i * S:(i + 1) * S], ref, 2e-2, 2e-2, f"ctx seq{i}")
+        assert_close(dqkv[i * S:(i + 1) * S], x.grad, 3e-2, 3e-2, f"dqkv seq{i}")

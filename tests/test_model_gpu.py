@@ -693,6 +693,55 @@ def test_bert_base_12_layers_match_oracle():
     print("L=12 worst encoder-side gradient cosine", worst_cos)
 
 
+def test_bert_base_12_layers_batch8_gradients_without_calibrator():
+    """The headline depth again at batch 8 (half the bench's batch; the fp32 CPU oracle needs about a minute and ~20 GB for it):
+    the [B,H]-sized head gradients -- pooler, gates, classifier, CPC: sums over the batch of per-sample terms that partly cancel,
+    17-26 % off at batch 2 where only the bf16-emulation calibrator bounds them -- are better conditioned here and are held to
+    10 % relative L2 error WITHOUT the calibrator (2e-4 absolute for gradients of norm < 1e-3), like every encoder-side gradient
+    (cosine >= 0.995); losses 4e-3.  Deviations go to gpurun_out/parity_L12_B8.json."""
+    avail = 0
+    try:
+        with open("/proc/meminfo") as fh:
+            avail = {l.split(":")[0]: int(l.split()[1]) for l in fh}.get("MemAvailable", 0) // (1 << 20)
+    except OSError:
+        pass
+    if avail and avail < 40:
+        pytest.skip(f"needs ~20 GB of host memory for the fp32 oracle at batch 8 (MemAvailable {avail} GiB)")
+    cfg = BASE12
+    B = 8
+    batch = synthetic_batch(B, 50, 500, 500, dataset=cfg["dataset"], vocab=cfg["vocab"], seed=5)
+    m = build(cfg)
+    out, logits = m(**batch_to(batch, DEV))
+    out[0].mean().backward()
+    torch.cuda.synchronize()
+    ours = {n: q.grad.float().cpu() for n, q in m.named_parameters()}
+    vals = [float(out[i]) for i in (0, 4, 5, 6)]
+    lg = logits.float().cpu()
+    del m, out, logits
+    torch.cuda.empty_cache()
+    p, oout, ologits = oracle_run(cfg, batch)
+    rep = {"losses": {}, "grads": {}}
+    for v, i, name in zip(vals, (0, 4, 5, 6), ("joint", "ap", "label", "nce")):
+        rep["losses"][name] = dict(ours=rel(v, oout[i].detach()), value=float(oout[i]))
+        assert rel(v, oout[i].detach()) < 4e-3, (name, v, float(oout[i]))
+    assert float((lg - ologits.detach()).abs().max()) < 3e-2
+    for n, g in ours.items():
+        og = p[n].grad
+        if og is None or float(og.abs().sum()) == 0.0:
+            assert float(g.abs().sum()) == 0.0, n
+            continue
+        if "attention.self.key.bias" in n:
+            continue
+        dev = float((g - og).norm() / og.norm())
+        cos = float(torch.nn.functional.cosine_similarity(g.reshape(1, -1), og.reshape(1, -1)))
+        rep["grads"][n] = dict(rel_err=dev, cosine=cos, norm=float(og.norm()))
+    _report("parity_L12_B8", rep)
+    for n, r in rep["grads"].items():
+        assert r["rel_err"] < 0.10 or r["rel_err"] * r["norm"] < 2e-4, (n, r)
+        if n.startswith(("bert.embeddings", "bert.encoder", "bert.jointEmbeddings", "cls.predictions")):
+            assert r["cosine"] > 0.995, (n, r)
+
+
 def test_hidden_states_match_reference_golden(golden_dir):
     """Per-layer hidden states, the text embeddings and the JointEmbeddings outputs of all three passes against what forward hooks
     recorded on the REAL reference (tests/golden/make_golden.py:88-102): stated 8e-2 max abs over ~3e4 values per tensor / 6e-3 mean

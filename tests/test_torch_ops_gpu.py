@@ -214,3 +214,15 @@ def test_mlm_mask_rng_operator():
     out, labels = T.mask_tokens(ids0.clone().to(DEV), T.default_args(mlm_probability=0.15))
     s2 = labels != -100
     assert 0.10 < float(s2.float().mean()) < 0.20 and not bool(s2[:, 0].any()) and bool(((out == 103) <= s2).all())
+    # ... seeded by torch's CUDA generator: re-seeding in the middle of a process reproduces the draws, consecutive calls differ,
+    # and the CUDA RNG state captures / restores them (the round-2 seed was a process-wide call counter)
+    out2, labels2 = T.mask_tokens(ids0.clone().to(DEV), T.default_args(mlm_probability=0.15))
+    assert not torch.equal(labels2, labels)
+    state = torch.cuda.get_rng_state()
+    out3, labels3 = T.mask_tokens(ids0.clone().to(DEV), T.default_args(mlm_probability=0.15))
+    torch.cuda.set_rng_state(state)
+    out4, labels4 = T.mask_tokens(ids0.clone().to(DEV), T.default_args(mlm_probability=0.15))
+    assert torch.equal(labels3, labels4) and torch.equal(out3, out4)
+    torch.manual_seed(5)
+    out5, labels5 = T.mask_tokens(ids0.clone().to(DEV), T.default_args(mlm_probability=0.15))
+    assert torch.equal(labels5, labels) and torch.equal(out5, out)

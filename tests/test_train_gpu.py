@@ -252,8 +252,7 @@ def test_batches_built_on_the_input_stream_train_the_same():
         m = build()
         m.train()
         m.manual_seed(3)
-        T._mask_calls = 0                                                 # the masking kernel's seed = torch's CUDA seed, call count
-        torch.manual_seed(100)
+        torch.manual_seed(100)                                            # governs the masking kernel too (CUDA generator seed + offset)
         import random
         random.seed(9)                                                    # the pair draws follow the reference: Python's ``random``
         args = T.default_args(train_batch_size=8, learning_rate=2e-3, mlm=True)
@@ -268,12 +267,11 @@ def test_batches_built_on_the_input_stream_train_the_same():
         # of on_input_stream is per batch and gone, the model's own switch was never touched
         assert not getattr(m, "async_prologue", False) and m.__dict__.get("_input_stream_batch") is None
         args.val_batch_size = 8
-        rs = random.getstate()
-        T._mask_calls = 1000
+        rs, cs = random.getstate(), torch.cuda.get_rng_state()
         ev = T.eval_epoch(args, m, None, device=DEV, batches=bld.epoch(args, generator=torch.Generator().manual_seed(77)))
         torch.cuda.synchronize()
         random.setstate(rs)                                               # ... and once more from a drained GPU: the same numbers
-        T._mask_calls = 1000
+        torch.cuda.set_rng_state(cs)                                      # (the masking kernel's seed is the CUDA generator's state)
         ev2 = T.eval_epoch(args, m, None, device=DEV, batches=bld.epoch(args, generator=torch.Generator().manual_seed(77)))
         assert all(abs(a - b) <= 1e-5 * abs(b) + 1e-7 for a, b in zip(ev[:6], ev2[:6])), (ev[:6], ev2[:6])
         assert np.array_equal(ev[7], ev2[7]) and np.allclose(ev[6], ev2[6], rtol=1e-4, atol=1e-5)

@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """One train step out of a rocprofv3 --kernel-trace CSV: busy time, idle gaps, and the kernels in timeline order.
-    python tools/trace_gaps.py gpurun_out/prof_x/x_kernel_trace.csv [--list]"""
+    python tools/trace_gaps.py gpurun_out/prof_x/x_kernel_trace.csv [--list] [--gaps US]
+--gaps US (default 20): every idle gap longer than US microseconds with the kernel that ends before it and the one that starts after
+it, for the cut-out step and -- as a count / sum per (before, after) pair -- over the last 10 steps of the trace."""
 import csv, sys, collections, re
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
@@ -23,6 +25,28 @@ gaps = []
 for p, q in zip(step[:-1], step[1:]):
     gaps.append((int(q["Start_Timestamp"]) - int(p["End_Timestamp"]), short(p["Kernel_Name"]), short(q["Kernel_Name"])))
 print("idle by gap size: ", {f">{lo}us": round(sum(g for g, _, _ in gaps if g > lo * 1000) / 1e3) for lo in (0, 2, 5, 10, 20, 50)}, "us")
+thr = 20.0
+if "--gaps" in sys.argv:
+    thr = float(sys.argv[sys.argv.index("--gaps") + 1])
+print(f"gaps > {thr:g} us in this step (offset in step, gap, kernel before -> kernel after):")
+for (g, kb, ka), q in zip(gaps, step[1:]):
+    if g > thr * 1000:
+        print(f"  {(int(q['Start_Timestamp']) - t0) / 1e3:9.1f}  {g / 1e3:7.1f} us   {kb[:48]}  ->  {ka[:48]}")
+# the same over the last 10 steps (which gaps are systematic)
+if len(idx) >= 12:
+    lo, hi = idx[-12], idx[-2]
+    pairs = collections.defaultdict(lambda: [0, 0.0])
+    seq = rows[lo + 1:hi + 1]
+    for p, q in zip(seq[:-1], seq[1:]):
+        g = int(q["Start_Timestamp"]) - int(p["End_Timestamp"])
+        if g > thr * 1000:
+            k = (short(p["Kernel_Name"])[:44], short(q["Kernel_Name"])[:44])
+            pairs[k][0] += 1; pairs[k][1] += g / 1e3
+    wall = (int(seq[-1]["End_Timestamp"]) - int(seq[0]["Start_Timestamp"])) / 1e3
+    busy10 = sum(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in seq) / 1e3
+    print(f"last 10 steps: wall {wall / 10:.1f} us/step, kernels {busy10 / 10:.1f} us/step, idle {(wall - busy10) / 10:.1f} us/step, {len(seq) / 10:.1f} launches/step; gaps > {thr:g} us by (before -> after), per step:")
+    for (kb, ka), (n, t) in sorted(pairs.items(), key=lambda kv: -kv[1][1])[:25]:
+        print(f"  {t / 10:8.1f} us  {n / 10:5.1f}x  {kb}  ->  {ka}")
 if "--list" in sys.argv:
     for r, (g, _, _) in zip(step, [(0, "", "")] + gaps):
         print(f"{(int(r['Start_Timestamp']) - t0) / 1e3:9.1f} +{(int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3:7.1f} gap {g / 1e3:6.1f}  {short(r['Kernel_Name'])}")
