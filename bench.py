@@ -13,8 +13,10 @@ Weak scaling: per-GPU batch is fixed, global batch = 16*N.
 
 Extra objects on the JSON line:
   roofline     -- the dominant kernel (gemm_nt: forward projections + input gradients, 2/3 of the
-                  step's FLOPs): algorithmic FLOPs of its launches / their summed durations, both
-                  taken INSIDE the timed region with HIP events on the launch stream.
+                  step's FLOPs): algorithmic FLOPs of its launches / their summed durations, taken live
+                  with HIP events on the launch stream over a timed region of the SAME K steps that follows
+                  the headline region (the ~340 event records per step cost ~0.5 ms per step of queue time,
+                  so they are kept out of `value`; `ms_per_step_instrumented` is that second region).
   cpu_baseline -- the CPU oracle (oracle/mmbert_oracle.py, kind "port") timed on this box's host
                   cores on a bounded sample: the same model / shapes at batch 2, 1 warm-up + median of 3
                   fwd+bwd steps, plus BASELINE configs[0] exactly.
@@ -170,7 +172,6 @@ def main():
         step(i)
     torch.cuda.synchronize()
     barrier()
-    record[0] = not a.no_kernel_timing
     t0 = time.perf_counter()
     last = None
     for i in range(a.steps):
@@ -178,13 +179,26 @@ def main():
     torch.cuda.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0
-    record[0] = False
     main_row_frac = row_frac[-a.steps:]                   # (the secondary loops below append their own)
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(t)
     loss = float(last)
+    # The roofline leg: the SAME K steps once more, bracketed the same way, with a HIP event pair around every GEMM / attention launch
+    # on the launch stream.  Kept out of the headline region because the instrumentation is not free: ~340 event records per step
+    # are ~340 extra packets in the queue between kernels (round 2 timed both in one pass: 16.4 ms per step against 15.9 without the
+    # events, same box, same process); `ms_per_step_instrumented` reports what this leg took.
+    elapsed_instr = None
+    if not a.no_kernel_timing:
+        record[0] = True
+        ti0 = time.perf_counter()
+        for i in range(a.steps):
+            step(a.warmup + i)
+        torch.cuda.synchronize()
+        barrier()
+        elapsed_instr = time.perf_counter() - ti0
+        record[0] = False
 
     # For reference: the same step with every exact-zero short cut switched off (attention visits the masked-out keys, backward
     # runs on all rows and densely through the top layer); identical gradients up to fp32 summation order, never the headline.
@@ -285,7 +299,8 @@ def main():
     fps_exec = (fp["proj"] + fp["attn"] * f + fp["head"] + fp["joint"]) + 2.0 * (fp["proj"] * f + fp["attn"] * f * f + fp["joint"] * f) + head_bwd
     res = {
         "metric": "train-step samples/sec", "value": round(value, 2), "unit": "samples/s", "n_gpus": world, "steps": a.steps,
-        "warmup": a.warmup, "ms_per_step": round(1e3 * elapsed / a.steps, 3), "higher_is_better": True, "scaling": "weak",
+        "warmup": a.warmup, "ms_per_step": round(1e3 * elapsed / a.steps, 3),
+        "ms_per_step_instrumented": (round(1e3 * elapsed_instr / a.steps, 3) if elapsed_instr else None), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
         "config": {"workload": f"MMBertForPretraining train step, 3 passes S={a.text}/{a.text + a.pair}/{a.text + a.pair}, "
                                f"{L}-layer d={H} heads={a.heads} vocab={V}, T={a.text} A={a.pair} V={a.pair}, dropout on, AdamW",
@@ -330,7 +345,8 @@ def main():
             res["roofline"] = {"bound": "mfma", "kernel": "gemm_ntp_kernel (bf16 MFMA 16x16x32, persistent 224x256-tile stream through a 4-slot LDS-DMA ring; all epilogues)",
                                "achieved": round(ach, 1), "peak": 2500.0, "unit": "TFLOP/s", "frac": round(ach / 2500.0, 4),
                                "traffic": traffic, "traffic_source": traffic_src, "launches": n, "avg_launch_us": round(1e3 * ms / n, 2),
-                               "share_of_step_time": round(ms * 1e-3 / elapsed, 3),
+                               "share_of_step_time": round(ms * 1e-3 / elapsed_instr, 3),
+                               "timed_in": f"a second pass of the same {a.steps} steps with an event pair around every GEMM / attention launch (ms_per_step_instrumented)",
                                # whole-step MFMA fractions of 2.5 PF, side by side: FLOPs actually executed by the headline step, and the
                                # dense algorithmic count at the speed of the step with every exact-zero short cut switched off
                                "frac_step_executed": round(fps_exec * value / world / 2.5e15, 4),
@@ -339,7 +355,7 @@ def main():
                 if k in kern:
                     fl2, ms2, n2 = kern[k]
                     res["roofline"]["gemm_tn" if k == "tn" else k] = {"achieved": round(fl2 / (ms2 * 1e-3) / 1e12, 1), "launches": n2,
-                                                                      "share_of_step_time": round(ms2 * 1e-3 / elapsed, 3)}
+                                                                      "share_of_step_time": round(ms2 * 1e-3 / elapsed_instr, 3)}
         if world == 1 and not a.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(a, L, H, I, V)
         print(json.dumps(res), flush=True)
