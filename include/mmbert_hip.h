@@ -171,9 +171,11 @@ int mmbert_ce_bwd(mmbert_stream_t stream, const void* logits, int ldv, int V, co
                   int logits_f32 /* logits are fp32; dlogits stays bf16 */);
 /* Row maps of the valid-first packing (msa_amd/ops.py SplitLayout): inv[original row] = packed row, perm = the
  * inverse, from the per-sequence unmasked lengths.  mode 0: masked-out rows behind all others, in order; 1: ONE shared row per
- * sequence (inference); 2: left out (inv = rows_a). */
+ * sequence (inference); 2: left out (inv = rows_a).  rank (optional, from mmbert_prologue's row-set mode): the position of every
+ * row in its sequence's own valid-first order, used instead of row_pos -- the leading valid[s] rows of a sequence are then its
+ * ACTIVE rows wherever they sit (a sequence whose padding lies in the middle: the fused text | visual | speech extension). */
 int mmbert_split_rows(mmbert_stream_t stream, const int64_t* row_seq, const int64_t* row_pos, const int* start_a, const int* start_b,
-                      const int* valid, int mode, int M, int rows_a, int64_t* perm, int64_t* inv);
+                      const int* valid, int mode, int M, int rows_a, int64_t* perm, int64_t* inv, const int* rank);
 
 /* Step prologue (two launches): from the caller's attention masks and MLM labels to what the encoder's launches need.
  * Sequences: npass passes x B samples, pass p has pass_len[p] positions per sequence; packed rows pass-major, then sample, then
@@ -186,11 +188,16 @@ int mmbert_split_rows(mmbert_stream_t stream, const int64_t* row_seq, const int6
  * sequence, the padding <= -1e30); kv_len[s] (mmbert_attn_kv_len's rule); valid[s] = max(kv_len[s], last labelled position + 1);
  * idx = the rows with a label in [0, vocab), ascending (mmbert_active_rows' list; room for every row); seq_cnt: 3 * nseq ints of
  * scratch; words = [valid[0..nseq), #labelled rows, #labelled position-0 rows, #labels that are neither -100 nor in [0, vocab)]
- * -- nseq + 3 ints, contiguous for one device->host copy. */
+ * -- nseq + 3 ints, contiguous for one device->host copy.
+ * Row-set mode (rank and key_bias_perm both non-NULL; both NULL otherwise): a row is ACTIVE iff its key is unmasked, it carries a
+ * label or it is position 0 of its sequence (the row the heads read); valid[s] = the COUNT of active rows of sequence s, rank[row] = the row's position in the order "active rows first, both
+ * groups in their original order" (one int per packed row), key_bias_perm = the padded key bias in that order (same size as
+ * key_bias, which still receives the original order).  With mmbert_split_rows(..., rank) the packed sequences then look like
+ * prefix-valid ones to every other entry point (attention reads key_bias_perm; its dropout indices follow the new order). */
 int mmbert_prologue(mmbert_stream_t stream, int nseg, const void* const* seg_ptr, const long long* seg_stride_b, const long long* seg_stride_p,
                     const int* seg_dtype, const int* seg_pass, const int* seg_offset, const int* seg_len,
                     int npass, const int* pass_len, int B, const int64_t* labels, int vocab,
-                    float* key_bias, int* kv_len, int* valid, int* seq_cnt, int* idx, int* words);
+                    float* key_bias, int* kv_len, int* valid, int* seq_cnt, int* idx, int* words, int* rank, float* key_bias_perm);
 
 /* idx[0..count) = the rows with a label in [0, V), ascending; every other row of the CE gradient is exactly zero (ignore_index),
  * so the head's backward may run on this list alone.  idx has room for M entries; count is one int on the device. */

@@ -46,8 +46,8 @@ SIGNATURES = {
     "mmbert_ce_fwd": (I, [P, P, I, I, P, I, P, I, P, P, P, I]),
     "mmbert_ce_bwd": (I, [P, P, I, I, P, I, P, I, P, P, P, P, I, P, I, I]),
     "mmbert_active_rows": (I, [P, P, I, I, P, P]),
-    "mmbert_prologue": (I, [P, I, P, P, P, P, P, P, P, I, P, I, P, I, P, P, P, P, P, P]),
-    "mmbert_split_rows": (I, [P, P, P, P, P, P, I, I, I, P, P]),
+    "mmbert_prologue": (I, [P, I, P, P, P, P, P, P, P, I, P, I, P, I, P, P, P, P, P, P, P, P]),
+    "mmbert_split_rows": (I, [P, P, P, P, P, P, I, I, I, P, P, P]),
     "mmbert_heads_gate_fwd": (I, [P, P, P, P, P, I, I, P, P]),
     "mmbert_heads_loss_fwd": (I, [P, P, P, P, P, P, P, I, I, F, I, P, P, P, P, P, P, P, I, F]),
     "mmbert_heads_scale": (I, [P, P, SZ, P]),

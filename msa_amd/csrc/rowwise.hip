@@ -12,12 +12,15 @@
 // per-sequence unmasked length `valid`, the region starts and the row -> (sequence, position) tables.  mode 0: masked-out rows
 // go to region B in order; 1: all masked-out rows of a sequence share its ONE region-B row (inference); 2: they are left out
 // (inv = rows_a, one past the packed matrix).
+// ``rank`` (optional, mmbert_prologue's row-set mode): the position of every row in its sequence's OWN valid-first order (active
+// rows first, order kept) -- it replaces row_pos, so that the leading ``valid[s]`` rows of sequence s are its active rows wherever
+// they sit in the original sequence (the fused text | visual | speech sequence has its visual padding in the middle).
 __global__ void split_rows_kernel(const int64_t* __restrict__ row_seq, const int64_t* __restrict__ row_pos, const int* __restrict__ start_a,
                                   const int* __restrict__ start_b, const int* __restrict__ valid, int mode, int M, int rows_a,
-                                  int64_t* __restrict__ perm, int64_t* __restrict__ inv) {
+                                  int64_t* __restrict__ perm, int64_t* __restrict__ inv, const int* __restrict__ rank) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= M) return;
-    const int s = (int)row_seq[i], p = (int)row_pos[i], v = valid[s];
+    const int s = (int)row_seq[i], p = rank ? rank[i] : (int)row_pos[i], v = valid[s];
     if (p < v) { const int n = start_a[s] + p; inv[i] = n; perm[n] = i; }
     else if (mode == 0) { const int n = start_b[s] + p - v; inv[i] = n; perm[n] = i; }
     else if (mode == 1) { const int n = start_b[s]; inv[i] = n; if (p == v) perm[n] = i; }
@@ -776,6 +779,9 @@ struct PrologueArgs {
     const int64_t* labels;
     float* key_bias; int* kv_len; int* valid; int* seq_cnt;      // seq_cnt: [3][nseq] labelled rows / labelled first row / bad labels
     int* idx; int* words;
+    // row-set mode (both or neither): rank[row] = position of the row in its sequence's valid-first order, key_bias_perm = the padded
+    // key bias in that order; valid[s] then COUNTS the active rows (unmasked key, or labelled) instead of bounding a prefix
+    int* rank; float* key_bias_perm;
 };
 
 __device__ __forceinline__ float mask_value(const MaskSeg& g, int b, int p) {
@@ -826,14 +832,58 @@ __global__ __launch_bounds__(256) void prologue_seq_kernel(const PrologueArgs a)
     }
     if (lane == 0) { red[w][0] = last_key; red[w][1] = last_lab; red[w][2] = cnt; red[w][3] = first; red[w][4] = bad; }
     __syncthreads();
+    __shared__ int all_active;
     if (threadIdx.x == 0) {
         const int nseq = a.npass * a.B;
         int lk = -1, ll = -1, c = 0, f = 0, bd = 0;
         for (int q = 0; q < 4; ++q) { lk = max(lk, red[q][0]); ll = max(ll, red[q][1]); c += red[q][2]; f += red[q][3]; bd += red[q][4]; }
         const int kv = lk < 0 ? S : lk + 1;                     // no unmasked key at all: the sequence keeps its full length
         a.kv_len[s] = kv;
-        a.valid[s] = max(kv, ll + 1);
+        if (!a.rank) a.valid[s] = max(kv, ll + 1);
         a.seq_cnt[s] = c; a.seq_cnt[nseq + s] = f; a.seq_cnt[2 * nseq + s] = bd;
+        all_active = lk < 0;
+    }
+    if (!a.rank) return;
+    // ---- row-set mode: a row is ACTIVE iff it is an unmasked key or carries a label (a query with a gradient); the active rows of the
+    // sequence come first, both groups keep their order.  Two sweeps over the positions: count, then place (ballot prefix sums).
+    __shared__ int wcount[4];
+    __shared__ int nact_s;
+    __syncthreads();                                               // kb[] of this sequence (pass 1) and all_active are visible
+    const bool every = all_active != 0;
+    auto active = [&](int pos) {                                   // position 0 always: the heads read the [CLS] row of every sequence
+        if (every || pos == 0 || kb[pos] > -10000.0f) return true;
+        return a.labels && a.labels[row0 + pos] != -100;
+    };
+    int mine = 0;
+    for (int pos = threadIdx.x; pos < S; pos += 256) mine += active(pos) ? 1 : 0;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mine += __shfl_xor(mine, o, 64);
+    if (lane == 0) wcount[w] = mine;
+    __syncthreads();
+    if (threadIdx.x == 0) { nact_s = wcount[0] + wcount[1] + wcount[2] + wcount[3]; a.valid[s] = nact_s; }
+    __syncthreads();
+    const int nact = nact_s;
+    float* kp = a.key_bias_perm + a.pass_bias0[p] + b * slots;
+    int base = 0;                                                  // active rows before this chunk
+    for (int p0 = 0; p0 < slots; p0 += 256) {
+        const int pos = p0 + threadIdx.x;
+        const bool in = pos < S, act = in && active(pos);
+        const unsigned long long bal = __ballot(act);
+        const int before = __popcll(bal & ((1ull << lane) - 1ull));
+        __syncthreads();
+        if (lane == 0) wcount[w] = __popcll(bal);
+        __syncthreads();
+        int off = base;
+        for (int q = 0; q < w; ++q) off += wcount[q];
+        if (in) {
+            const int ab = off + before;                           // active rows in front of this position
+            const int np = act ? ab : nact + (pos - ab);
+            a.rank[row0 + pos] = np;
+            kp[np] = kb[pos];
+        } else {
+            kp[pos] = -1.0e30f;
+        }
+        base += wcount[0] + wcount[1] + wcount[2] + wcount[3];
     }
 }
 
@@ -1064,10 +1114,10 @@ int mmbert_ce_bwd(hipStream_t stream, const void* logits, int ldv, int V, const 
 }
 
 int mmbert_split_rows(hipStream_t stream, const int64_t* row_seq, const int64_t* row_pos, const int* start_a, const int* start_b, const int* valid,
-                      int mode, int M, int rows_a, int64_t* perm, int64_t* inv) {
+                      int mode, int M, int rows_a, int64_t* perm, int64_t* inv, const int* rank) {
     if (M <= 0) return 0;
     if (mode < 0 || mode > 2) return -1;
-    hipLaunchKernelGGL(split_rows_kernel, dim3((M + 255) / 256), dim3(256), 0, stream, row_seq, row_pos, start_a, start_b, valid, mode, M, rows_a, perm, inv);
+    hipLaunchKernelGGL(split_rows_kernel, dim3((M + 255) / 256), dim3(256), 0, stream, row_seq, row_pos, start_a, start_b, valid, mode, M, rows_a, perm, inv, rank);
     MMB_CHECK_LAUNCH();
     return 0;
 }
@@ -1075,9 +1125,9 @@ int mmbert_split_rows(hipStream_t stream, const int64_t* row_seq, const int64_t*
 int mmbert_prologue(hipStream_t stream, int nseg, const void* const* seg_ptr, const long long* seg_stride_b, const long long* seg_stride_p,
                     const int* seg_dtype, const int* seg_pass, const int* seg_offset, const int* seg_len,
                     int npass, const int* pass_len, int B, const int64_t* labels, int vocab,
-                    float* key_bias, int* kv_len, int* valid, int* seq_cnt, int* idx, int* words) {
+                    float* key_bias, int* kv_len, int* valid, int* seq_cnt, int* idx, int* words, int* rank, float* key_bias_perm) {
     if (npass <= 0 || B <= 0) return 0;
-    if (nseg < 0 || nseg > PRO_MAXSEG || npass > PRO_MAXPASS) return -1;
+    if (nseg < 0 || nseg > PRO_MAXSEG || npass > PRO_MAXPASS || ((rank == nullptr) != (key_bias_perm == nullptr))) return -1;
     PrologueArgs a = {};
     for (int q = 0; q < nseg; ++q) {
         if (seg_dtype[q] < 0 || seg_dtype[q] > 6 || seg_pass[q] < 0 || seg_pass[q] >= npass) return -1;
@@ -1091,6 +1141,7 @@ int mmbert_prologue(hipStream_t stream, int nseg, const void* const* seg_ptr, co
     }
     a.nseg = nseg; a.npass = npass; a.B = B; a.vocab = vocab; a.labels = labels;
     a.key_bias = key_bias; a.kv_len = kv_len; a.valid = valid; a.seq_cnt = seq_cnt; a.idx = idx; a.words = words;
+    a.rank = rank; a.key_bias_perm = key_bias_perm;
     hipLaunchKernelGGL(prologue_seq_kernel, dim3(npass * B), dim3(256), 0, stream, a);
     MMB_CHECK_LAUNCH();
     hipLaunchKernelGGL(prologue_rows_kernel, dim3(npass * B), dim3(256), 0, stream, a);

@@ -729,9 +729,14 @@ class _GpuModelBase(nn.Module):
             raise ValueError("You have so large dimension (), Check dimension or shape ")
         return mask
 
-    def _encode(self, passes, labels=None, want_rows=False):
+    def _encode(self, passes, labels=None, want_rows=False, rowset=False):
         """passes: list of dict(ids[B,T], tt[B,T]|None, mask, pair[B,P,D]|None, pair_mask|None).
-        Returns (Y [tokens,H] bf16, plan, lens_per_pass, rows) -- ``rows`` = (labelled-row list, host words, event) when asked for."""
+        Returns (Y [tokens,H] bf16, plan, lens_per_pass, rows) -- ``rows`` = (labelled-row list, host words, event) when asked for.
+        ``rowset``: the valid-first packing over a row SET instead of a prefix per sequence (the prologue's row-set mode): for
+        sequences whose masked-out rows do not sit at the end -- the fused text | visual | speech sequence has its visual padding in
+        the middle.  Every sequence is then run in its own valid-first order (active rows = unmasked keys and labelled rows, first):
+        attention is invariant under a permutation of the keys that carries the key bias along, every other operator is row-wise,
+        and the un-packing gather restores the caller's order.  Only with a backward pass to save (labels, autograd on)."""
         bert = self._bert()
         dev = passes[0]["ids"].device
         self._ensure_ready(dev)
@@ -741,6 +746,8 @@ class _GpuModelBase(nn.Module):
             raise ValueError("text length exceeds max_position_embeddings")
         seed = self._next_seed()
         je = bert.jointEmbeddings
+        rowset = bool(rowset and labels is not None and torch.is_grad_enabled() and getattr(self, "skip_padded_backward", True)
+                      and getattr(self, "skip_masked_keys", True))
         # ---- masks and labels first: ONE prologue call (two launches) gives the padded key bias, the per-sequence unmasked
         # lengths, the rows backward must visit and the labelled-row list, and starts the one device -> host copy of the step
         # (the embedding kernels below keep the GPU busy while it travels and the host packs the layout)
@@ -763,7 +770,7 @@ class _GpuModelBase(nn.Module):
                     pair_info.append(None)
         plan = self._plan(lens, B, dev)
         if side is None:
-            pro = ops.prologue(segs, lens, B, labels, cfg.vocab_size, dev)
+            pro = ops.prologue(segs, lens, B, labels, cfg.vocab_size, dev, rowset=rowset)
             nseq = pro.nseq
             host = torch.empty(nseq + 3, dtype=torch.int32, pin_memory=True)
             host.copy_(pro.words, non_blocking=True)
@@ -779,14 +786,14 @@ class _GpuModelBase(nn.Module):
             marks = self.__dict__.setdefault("_pro_marks", {})
             if (k - 1) % 2 in marks:
                 side.wait_event(marks[(k - 1) % 2])
-            nf, ni = ops.prologue_sizes(lens, B)
+            nf, ni = ops.prologue_sizes(lens, B, rowset)
             sets = self.__dict__.setdefault("_pro_bufs", {})
             bufs = sets.get(k % 2)
             if bufs is None or bufs[0].numel() < nf or bufs[1].numel() < ni or bufs[0].device != dev:
                 bufs = sets[k % 2] = (torch.empty(nf, device=dev, dtype=torch.float32), torch.empty(ni, device=dev, dtype=torch.int32))
                 side.wait_stream(main)                                   # (new buffers: ordered behind everything, once per shape)
             with torch.cuda.stream(side):
-                pro = ops.prologue(segs, lens, B, labels, cfg.vocab_size, dev, bufs=bufs)
+                pro = ops.prologue(segs, lens, B, labels, cfg.vocab_size, dev, bufs=bufs, rowset=rowset)
                 nseq = pro.nseq
                 host = torch.empty(nseq + 3, dtype=torch.int32, pin_memory=True)
                 host.copy_(pro.words, non_blocking=True)
@@ -825,7 +832,7 @@ class _GpuModelBase(nn.Module):
         x = torch.cat(xs) if len(xs) > 1 else xs[0]
         # the caller does not want the prediction scores (trainer.py never reads them): rows that nothing else reads are left out
         drop = (not infer) and labels is not None and not getattr(self, "return_scores", True)
-        split = self._split_layout(plan, kv_len, pending, infer, drop)
+        split = self._split_layout(plan, kv_len, pending, infer, drop, pro.rank)
         if self.debug_hidden is not None:
             self.debug_hidden.update(emb=e1.detach(), x=x.detach())
             self.debug_hidden.pop("_layers_packed", None)
@@ -879,7 +886,7 @@ class _GpuModelBase(nn.Module):
         ev.record()
         return host[:-1], host[-1:], ev
 
-    def _split_layout(self, plan, kv_len, pending, infer=False, drop=False):
+    def _split_layout(self, plan, kv_len, pending, infer=False, drop=False, rank=None):
         """Backward on the unmasked rows only.  A row behind its sequence's last unmasked key (a padded pair row; a [PAD] row of
         the text pass) that carries no MLM label has an exactly-zero gradient at the encoder output (the heads read [CLS] rows,
         the MLM loss ignores it), nothing flows into it through attention (as a key its probability is exactly 0, so dK = dV = 0;
@@ -898,12 +905,12 @@ class _GpuModelBase(nn.Module):
         if flag is not None and int(flag[0]) != 0:
             return None
         valid = valid_host.numpy().copy()
-        if int(valid.sum()) > 0.97 * lay.tokens:
+        if rank is None and int(valid.sum()) > 0.97 * lay.tokens:          # (row-set mode: the key bias is in the packed order already)
             return None
         if infer:
             return ops.SplitLayout(lay, valid, kv_len.device, dedupe=True)
         self.last_backward_row_fraction = float(valid.sum()) / lay.tokens
-        lay2 = ops.SplitLayout(lay, valid, kv_len.device, drop=drop)
+        lay2 = ops.SplitLayout(lay, valid, kv_len.device, drop=drop, rank=rank)
         lay2.dropped = drop
         return lay2
 
@@ -1340,7 +1347,8 @@ class MMBertForPretraining(_GpuModelBase):
         if labels.numel() != B * (T + visual.shape[1] + speech.shape[1]):
             raise ValueError("masked_labels must cover the text and both pair blocks")
         want_rows = torch.is_grad_enabled() and getattr(self, "sparse_mlm_backward", True) and labels.is_cuda
-        y, plan, lens, rows = self._encode(passes, labels, want_rows)
+        # the visual padding sits in the MIDDLE of the fused sequence: valid-first packing over the row set, not over a prefix
+        y, plan, lens, rows = self._encode(passes, labels, want_rows, rowset=getattr(self, "fused_rowset_packing", True))
         mlm, logits, first = _MLMHeadFn.apply(y, self.cls.predictions.transform.LayerNorm.weight, self, labels, plan["bounds"], plan["bounds_dev"],
                                               self.return_scores, rows, plan["first"].repeat(3))   # the one [CLS] row in the t / v / s slots
         joint_loss, ap_loss, label_loss, nce, logits_out, _t_rel, v_rel, _s_rel = self._run_heads(first, ap_v, ap_s, sentiment, dev, B, mlm=mlm)

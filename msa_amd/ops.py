@@ -404,13 +404,16 @@ class SplitLayout:
     Dropout indices, key-bias slots and ``seq_len`` stay those of the ORIGINAL sequences, so masks do not depend on the packing.
     Built per batch on the host (numpy) and shipped in one copy."""
 
-    def __init__(self, base: SeqLayout, valid, device, dedupe=False, drop=False):
+    def __init__(self, base: SeqLayout, valid, device, dedupe=False, drop=False, rank=None):
         """``dedupe`` (inference without dropout only): the masked-out rows of a sequence all have the same input and see the same
         keys, hence the same hidden states in every layer -- region B keeps ONE of them per sequence and ``inv`` maps all of them
         to it (``perm`` is then shorter than ``inv``: not a permutation, forward only).
         ``drop`` (training when the caller does not ask for the prediction scores): region B is left out altogether -- nothing
         but the returned scores ever reads those rows -- and ``inv`` sends them to row ``rows_a``, one past the packed matrix
-        (callers append a zero row before gathering)."""
+        (callers append a zero row before gathering).
+        ``rank`` (device int32 per row, from prologue(rowset=True)): every sequence's own valid-first order -- ``valid[s]`` then
+        counts its active rows, which need not be a prefix of the original sequence (GPU only)."""
+        assert rank is None or (torch.device(device).type == "cuda" and not dedupe)
         lens = np.asarray(base.lens, dtype=np.int64)
         v = np.minimum(np.asarray(valid, dtype=np.int64), lens)
         pad = lens - v
@@ -496,7 +499,8 @@ class SplitLayout:
             rs_d, rp_d = base.row_tables(device)
             dev_p = torch.empty(n_packed + M, dtype=torch.int64, device=device)
             _lib.check(_lib.load().mmbert_split_rows(_stream(), rs_d.data_ptr(), rp_d.data_ptr(), self.seq_start.data_ptr(), start_b_dev.data_ptr(),
-                                                     self.kv_len.data_ptr(), mode, M, self.rows_a, dev_p.data_ptr(), dev_p.data_ptr() + 8 * n_packed),
+                                                     self.kv_len.data_ptr(), mode, M, self.rows_a, dev_p.data_ptr(), dev_p.data_ptr() + 8 * n_packed,
+                                                     _ptr(rank)),
                        "mmbert_split_rows")
         else:
             dev_p = torch.from_numpy(np.concatenate((perm, inv))).to(device)
@@ -519,33 +523,44 @@ _MASK_DTYPES = {torch.float32: 0, torch.float64: 1, torch.int64: 2, torch.int32:
 
 class Prologue:
     """Result of ``prologue()``: padded key bias, kv_len / valid per sequence, the labelled-row list and the host words' device copy."""
-    __slots__ = ("key_bias", "kv_len", "valid", "idx", "words", "nseq")
+    __slots__ = ("key_bias", "kv_len", "valid", "idx", "words", "nseq", "rank")
 
 
-def prologue_sizes(pass_lens, B):
-    """(floats of the padded key bias, ints of everything else) that ``prologue`` writes for these shapes."""
+def prologue_sizes(pass_lens, B, rowset=False):
+    """(floats of the padded key bias, ints of everything else) that ``prologue`` writes for these shapes (row-set mode: the key
+    bias twice -- original and valid-first order -- and one rank per row)."""
     nseq = len(pass_lens) * B
     tokens = sum(B * S for S in pass_lens)
-    return sum(B * ((S + 127) // 128 * 128) for S in pass_lens), 2 * nseq + 3 * nseq + max(tokens, 1) + nseq + 3
+    nf = sum(B * ((S + 127) // 128 * 128) for S in pass_lens)
+    ni = 2 * nseq + 3 * nseq + max(tokens, 1) + nseq + 3
+    return (2 * nf, ni + max(tokens, 1)) if rowset else (nf, ni)
 
 
-def prologue(segs, pass_lens, B, labels, vocab, device, bufs=None) -> Prologue:
+def prologue(segs, pass_lens, B, labels, vocab, device, bufs=None, rowset=False) -> Prologue:
     """The step prologue in two launches (mmbert_prologue): ``segs`` = [(mask2d [B, len] -- any stride, any mask dtype --, pass index,
     first position)], ``pass_lens`` = positions per sequence of every pass, ``labels`` = int64 [tokens] in packed order or None.
-    ``bufs`` = (fp32, int32) output buffers of ``prologue_sizes`` elements (the caller's persistent ones) instead of fresh tensors."""
+    ``bufs`` = (fp32, int32) output buffers of ``prologue_sizes`` elements (the caller's persistent ones) instead of fresh tensors.
+    ``rowset``: row-set mode (see mmbert_prologue) -- ``valid`` counts the active rows, ``rank`` orders every sequence valid-first
+    and ``key_bias`` comes back in THAT order (for SplitLayout(..., rank=...))."""
     lib = _lib.load()
     n, npass = len(segs), len(pass_lens)
     nseq = npass * B
     tokens = sum(B * S for S in pass_lens)
     bias_len, nints = prologue_sizes(pass_lens, B)
+    nf_all, ni_all = prologue_sizes(pass_lens, B, rowset)
     out = Prologue()
     out.nseq = nseq
+    out.rank = None
     if bufs is not None:
-        out.key_bias, ints = bufs[0][:bias_len], bufs[1][:nints]
-        assert out.key_bias.numel() == bias_len and ints.numel() == nints and ints.dtype == torch.int32 and out.key_bias.dtype == torch.float32
+        fl, ints_all = bufs[0][:nf_all], bufs[1][:ni_all]
+        assert fl.numel() == nf_all and ints_all.numel() == ni_all and ints_all.dtype == torch.int32 and fl.dtype == torch.float32
     else:
-        out.key_bias = torch.empty(bias_len, device=device, dtype=torch.float32)
-        ints = torch.empty(nints, device=device, dtype=torch.int32)
+        fl = torch.empty(nf_all, device=device, dtype=torch.float32)
+        ints_all = torch.empty(ni_all, device=device, dtype=torch.int32)
+    out.key_bias, ints = fl[:bias_len], ints_all[:nints]
+    bias_perm = None
+    if rowset:
+        out.rank, bias_perm = ints_all[nints:], fl[bias_len:]
     out.kv_len, out.valid = ints[:nseq], ints[nseq:2 * nseq]
     seq_cnt = ints[2 * nseq:5 * nseq]
     out.idx = ints[5 * nseq:5 * nseq + max(tokens, 1)]
@@ -561,7 +576,9 @@ def prologue(segs, pass_lens, B, labels, vocab, device, bufs=None) -> Prologue:
                                    IA(*[p for _, p, _ in segs]), IA(*[o for _, _, o in segs]), IA(*[m.shape[1] for m, _, _ in segs]),
                                    npass, (ctypes.c_int * npass)(*pass_lens), B, _ptr(labels), int(vocab),
                                    out.key_bias.data_ptr(), out.kv_len.data_ptr(), out.valid.data_ptr(), seq_cnt.data_ptr(), out.idx.data_ptr(),
-                                   out.words.data_ptr()), "mmbert_prologue")
+                                   out.words.data_ptr(), _ptr(out.rank), _ptr(bias_perm)), "mmbert_prologue")
+    if rowset:
+        out.key_bias = bias_perm
     return out
 
 

@@ -627,6 +627,60 @@ def test_step_prologue_matches_the_torch_formulation(ops):
     assert torch.equal(pro2.valid, kv_ref) and int(pro2.words[3 * B]) == 0 and torch.equal(pro2.key_bias, kb_ref)
 
 
+def test_step_prologue_row_set_mode_and_its_packing(ops):
+    """mmbert_prologue's row-set mode + mmbert_split_rows(rank): masked-out rows in the MIDDLE of a sequence (the fused text | visual
+    | speech sequence: the visual block's padding precedes the speech block).  Active = unmasked key, or labelled, or position 0;
+    valid[s] counts them; rank orders every sequence active-first with both groups in their original order; key_bias comes back in
+    that order; and the SplitLayout built from it is a permutation whose leading rows_a rows are exactly the active rows."""
+    B, T, Pv, Pa, V = 4, 10, 37, 29, 500
+    g = torch.Generator().manual_seed(11)
+    S = T + Pv + Pa
+    tmask = torch.ones(B, T, dtype=torch.float64)
+    tmask[1, 7:] = 0                                         # [PAD] text rows in the middle of the fused sequence too
+    tmask[2, 0] = 0                                          # a masked [CLS] key: position 0 stays active (the heads read it)
+    vis = torch.randn(B, Pv, 35, generator=g, dtype=torch.float64)
+    sp = torch.randn(B, Pa, 74, generator=g, dtype=torch.float64)
+    for b in range(B):
+        vis[b, int(torch.randint(Pv // 3, Pv, (1,), generator=g)):] = 0
+        sp[b, int(torch.randint(1, Pa + 1, (1,), generator=g)):] = 0
+    vmask, smask = (vis != 0).double(), (sp != 0).long()
+    labels = torch.full((B * S,), -100, dtype=torch.int64)
+    sel = torch.rand(B * S, generator=g) < 0.06                # labels everywhere, masked rows included
+    labels[sel] = torch.randint(0, V, (int(sel.sum()),), generator=g)
+    dm = [t.to(DEV) for t in (tmask, vmask, smask)]
+    segs = [(dm[0], 0, 0), (dm[1][:, :, 0], 0, T), (dm[2][:, :, 0], 0, T + Pv)]
+    pro = ops.prologue(segs, [S], B, labels.to(DEV), V, DEV, rowset=True)
+    plain = ops.prologue(segs, [S], B, labels.to(DEV), V, DEV)
+    torch.cuda.synchronize()
+    key_mask = torch.cat((tmask.float(), vmask[:, :, 0].float(), smask[:, :, 0].float()), dim=1)         # [B, S]
+    bias = (1.0 - key_mask) * -10000.0
+    active = (bias > -10000.0) | (labels.view(B, S) != -100)
+    active[:, 0] = True
+    assert torch.equal(pro.valid.cpu().long(), active.sum(1))
+    assert torch.equal(pro.kv_len, plain.kv_len) and torch.equal(pro.idx[:int(pro.words[B])], plain.idx[:int(plain.words[B])])
+    rank_ref = torch.empty(B, S, dtype=torch.int64)
+    slots = (S + 127) // 128 * 128
+    kb_ref = torch.full((B, slots), -1.0e30)
+    for b in range(B):
+        order = torch.cat((active[b].nonzero().reshape(-1), (~active[b]).nonzero().reshape(-1)))       # new position -> old position
+        rank_ref[b, order] = torch.arange(S)
+        kb_ref[b, :S] = bias[b, order]
+    assert torch.equal(pro.rank.cpu().long(), rank_ref.reshape(-1))
+    assert torch.equal(pro.key_bias.cpu(), kb_ref.reshape(-1))
+    assert bool((~active).any()) and bool((active[:, T:T + Pv].sum(1) < Pv).all())                  # padding in the middle block indeed
+    base = ops.SeqLayout([S] * B, 2, DEV)
+    lay = ops.SplitLayout(base, pro.valid.cpu().numpy(), DEV, rank=pro.rank)
+    perm, inv = lay.perm.cpu(), lay.inv.cpu()
+    assert lay.rows_a == int(active.sum()) and perm.numel() == B * S
+    assert torch.equal(perm[inv], torch.arange(B * S)) and torch.equal(torch.sort(perm).values, torch.arange(B * S))
+    assert bool(active.reshape(-1)[perm[:lay.rows_a]].all()) and not bool(active.reshape(-1)[perm[lay.rows_a:]].any())
+    # a sequence's active rows are contiguous in region A, in their original order
+    sa = lay.seq_start.cpu()
+    for b in range(B):
+        rows = perm[int(sa[b]):int(sa[b]) + int(active[b].sum())]
+        assert torch.equal(rows, b * S + active[b].nonzero().reshape(-1))
+
+
 def test_skinny_products_of_the_heads(ops):
     """mmbert_skinny_mm / mmbert_skinny_wgrad (the heads' dense layers) against fp32 torch: y = x W^T + b with two sources and a row
     range, dx = dy W as the inner-major form accumulated onto an existing tensor, odd sizes (N = 2, inner = 1 / 2), and the weight

@@ -261,6 +261,41 @@ def test_full_size_long_fusion_step_is_finite_and_seeded():
     assert abs(b - a) <= 1e-6 * abs(a)                        # same seed -> same masks; the loss sums themselves use fp32 atomics
 
 
+def test_full_size_fused_long_sequence_step_is_finite_and_seeded():
+    """BASELINE configs[3] in its fused form at full size (12-layer d=768, ONE sequence text | visual | speech of S = 50 + 1375 + 1375 =
+    2800 per sample, batch 4, train mode): far too large for the CPU oracle, so the size-independent properties -- finite losses and
+    gradients on every parameter the reference differentiates, the same seed -> the same loss, and the row-set packing really
+    skipping the padding of BOTH pair blocks (pair lengths are drawn from half to full: ~25 % of the rows)."""
+    cfg = dict(hidden=768, layers=12, heads=12, intermediate=3072, vocab=30522, dataset="mosei", alpha=1.0, beta=1.0)
+    fb = batch_to(to_fused(synthetic_batch(4, 50, 1375, 1375, seed=23)), DEV)
+    m = build(cfg, train=True)
+    m.manual_seed(6)
+    seen, orig = [], m._split_layout
+    m._split_layout = lambda *a, _o=orig, _s=seen: (_s.append(_o(*a)), _s[-1])[1]
+    out, logits = m.forward_fused(**fb)
+    a = float(out[0])
+    out[0].mean().backward()
+    torch.cuda.synchronize()
+    m._split_layout = orig
+    assert all(np.isfinite(float(out[i])) for i in (0, 4, 5, 6)) and bool(torch.isfinite(logits).all())
+    assert tuple(out[7].shape) == (4, 2800, cfg["vocab"])
+    lay = seen[0]
+    assert lay is not None and lay.rows_a < 0.9 * lay.tokens and lay.tokens == 4 * 2800
+    # both blocks contribute: more rows are skipped than the trailing (speech) padding alone accounts for
+    sp_mask = fb["attention_mask"][2][:, :, 0]
+    tail_pad = int((sp_mask == 0).sum())
+    assert lay.tokens - lay.rows_a > tail_pad
+    nz = 0
+    for n, q in m.named_parameters():
+        assert bool(torch.isfinite(q.grad).all()), n
+        nz += int(float(q.grad.abs().sum()) > 0.0)
+    assert nz >= len(list(m.named_parameters())) - 6
+    m.zero_grad()
+    m.manual_seed(6)
+    b = float(m.forward_fused(**fb)[0][0])
+    assert abs(b - a) <= 1e-6 * abs(a)
+
+
 def test_fused_sequence_extension_matches_its_oracle():
     """forward_fused (text | visual | speech in ONE sequence: a declared extension, BASELINE's "fused seq_len~1050" shape class)
     against oracle.fused_forward, the same extension of the CPU restatement: losses, regression logits, MLM scores, and the
@@ -307,6 +342,48 @@ def test_fused_sequence_extension_matches_its_oracle():
             continue
         scale = float(g_full[n].abs().max())
         assert float((q.grad.float() - g_full[n]).abs().max()) <= 2e-3 * scale + 1e-7, n
+
+
+def test_fused_sequence_packs_over_a_row_set():
+    """forward_fused with padding in BOTH pair blocks (the visual block's padded rows sit in the middle of the sequence) and labels on
+    padded rows: the valid-first packing over the row SET (default) against the prefix packing (``fused_rowset_packing = False``,
+    which can only skip the trailing speech padding) and against no packing at all.  A sequence run in its own valid-first order
+    computes the same function (attention sums its keys in another order: fp32 summation order, then bf16 rounding), so: losses to
+    1e-5, prediction scores to bf16 rounding of the largest logit, every parameter gradient to 4e-3 of its largest entry -- and
+    backward visits fewer rows than the prefix form."""
+    cfg = dict(hidden=256, layers=2, heads=4, intermediate=1024, vocab=4096, dataset="mosei", alpha=1.0, beta=1.0)
+    b3 = synthetic_batch(4, 24, 200, 130, dataset="mosei", vocab=cfg["vocab"], seed=43)
+    fb = to_fused(b3)
+    lab = fb["masked_labels"].clone()
+    lab[0, 24 + 199] = 77                                   # a label on the last (padded) visual row of sample 0: mid-sequence
+    lab[1, -1] = 5                                          # ... and on the last (padded) speech row of sample 1
+    fb = batch_to(dict(fb, masked_labels=lab), DEV)
+    res = {}
+    for mode in ("rowset", "prefix", "dense"):
+        m = build(cfg)
+        m.fused_rowset_packing = mode == "rowset"
+        m.skip_padded_backward = mode != "dense"
+        seen, orig = [], m._split_layout
+        m._split_layout = lambda *a, _o=orig, _s=seen, **k: (_s.append(_o(*a, **k)), _s[-1])[1]
+        out, logits = m.forward_fused(**fb)
+        out[0].mean().backward()
+        torch.cuda.synchronize()
+        res[mode] = (out, logits, {n: q.grad.detach().float().clone() for n, q in m.named_parameters()}, seen[0])
+    lr, lp = res["rowset"][3], res["prefix"][3]
+    assert lr is not None and lp is not None and res["dense"][3] is None
+    assert lr.rows_a < 0.85 * lp.rows_a and lr.rows_a < 0.8 * lr.tokens, (lr.rows_a, lp.rows_a, lr.tokens)      # the mid-sequence padding is skipped too
+    ob, gb = res["dense"][0], res["dense"][2]
+    for mode in ("rowset", "prefix"):
+        oa, ga = res[mode][0], res[mode][2]
+        for i in (0, 4, 5, 6):
+            assert abs(float(oa[i]) - float(ob[i])) <= 1e-5 * abs(float(ob[i])), (mode, i)
+        d = float((oa[7].float() - ob[7].float()).abs().max())
+        assert d <= 2.0 ** -7 * float(ob[7].float().abs().max()), (mode, d)                # a bf16 ulp or two of the largest logit
+        for n in ga:
+            if "attention.self.key.bias" in n:
+                continue
+            scale = float(gb[n].abs().max())
+            assert float((ga[n] - gb[n]).abs().max()) <= 4e-3 * scale + 1e-7, (mode, n, float((ga[n] - gb[n]).abs().max()), scale)
 
 
 def test_backward_on_unmasked_rows_only_equals_full_backward():
