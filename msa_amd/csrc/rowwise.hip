@@ -880,7 +880,7 @@ __global__ __launch_bounds__(256) void prologue_seq_kernel(const PrologueArgs a)
             const int np = act ? ab : nact + (pos - ab);
             a.rank[row0 + pos] = np;
             kp[np] = kb[pos];
-        } else {
+        } else if (pos < slots) {
             kp[pos] = -1.0e30f;
         }
         base += wcount[0] + wcount[1] + wcount[2] + wcount[3];
