@@ -95,19 +95,22 @@ int mmbert_mlm_mask(mmbert_stream_t stream, int64_t* ids, int64_t* labels, size_
 
 /* ---- LayerNorm (+ the reference's dropout placements) ----
  * fwd: y[out_rows[i]] = dropout(LN(x[in_rows[i]]))              BertEmbeddings HF:104-107,
- *      JointEmbeddings REF:MMBertEmbedding.py:69-70, BertSelfOutput/BertOutput LN HF:292,350.
+ *      JointEmbeddings REF:MMBertEmbedding.py:69-70, BertSelfOutput/BertOutput LN HF:292,350.  The dropout mask of row i is the
+ *      one of row i + drop_row0 of the dropout site (a launch over a slice of the rows the site covers).
  * bwd: see rowwise.hip; dx2 = dx * (pre-LN branch dropout mask) feeds the dense layer's gradients.  The dropout masks are
  *      functions of (row, column): drop_rows[i] (may be null: i) names the row of the forward pass that compact row i stands for. */
 int mmbert_ln_fwd(mmbert_stream_t stream, const void* x, int ldx, const int* in_rows, void* y, int ldy, const int* out_rows,
                   int M, int H, const float* gamma, const float* beta, float eps, float* mean, float* rstd,
-                  uint32_t dstream, uint32_t dthr, float dscale);
+                  uint32_t dstream, uint32_t dthr, float dscale, int drop_row0);
 int mmbert_ln_bwd(mmbert_stream_t stream, const void* dy, int lddy, const int* dy_rows, const void* x, int ldx, const int* x_rows,
                   const float* mean, const float* rstd, const float* gamma, int M, int H,
                   void* dx, int lddx, const int* dx_rows, void* dx2, int lddx2, float* dgamma, float* dbeta, float* dbias2,
                   uint32_t post_stream, uint32_t post_thr, float post_scale,
                   uint32_t pre_stream, uint32_t pre_thr, float pre_scale,
                   float* partial_ws /* mmbert_ln_bwd_workspace() floats, or NULL: contended atomics */, const int* drop_rows,
-                  int defer_reduce /* != 0: leave the per-block partial sums in partial_ws for mmbert_ln_bwd_reduce */);
+                  int defer_reduce /* != 0: leave the per-block partial sums in partial_ws for mmbert_ln_bwd_reduce */,
+                  int dy_row_limit /* > 0 (needs dy_rows): a mapped dy row >= the limit does not exist, its gradient is zero -- the rows
+                                      the valid-first packing leaves out of backward (mmbert_split_rows' inv32 as dy_rows, limit rows_a) */);
 size_t mmbert_ln_bwd_workspace(int M, int H);
 /* One launch that folds the partial sums of `items` (<= 32) deferred mmbert_ln_bwd calls into their dgamma / dbeta (/ dbias2)
  * gradients (+=).  The calls must share M and H.  Host arrays of `items` pointers; dbias2 (or single entries of it) may be NULL. */
@@ -175,7 +178,8 @@ int mmbert_ce_bwd(mmbert_stream_t stream, const void* logits, int ldv, int V, co
  * row in its sequence's own valid-first order, used instead of row_pos -- the leading valid[s] rows of a sequence are then its
  * ACTIVE rows wherever they sit (a sequence whose padding lies in the middle: the fused text | visual | speech extension). */
 int mmbert_split_rows(mmbert_stream_t stream, const int64_t* row_seq, const int64_t* row_pos, const int* start_a, const int* start_b,
-                      const int* valid, int mode, int M, int rows_a, int64_t* perm, int64_t* inv, const int* rank);
+                      const int* valid, int mode, int M, int rows_a, int64_t* perm, int64_t* inv, const int* rank,
+                      int* perm32 /* optional int32 copies of the two maps (row lists for mmbert_ln_fwd / _bwd) */, int* inv32);
 
 /* Step prologue (two launches): from the caller's attention masks and MLM labels to what the encoder's launches need.
  * Sequences: npass passes x B samples, pass p has pass_len[p] positions per sequence; packed rows pass-major, then sample, then

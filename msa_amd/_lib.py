@@ -29,8 +29,8 @@ SIGNATURES = {
     "mmbert_dropout_thr16": (U32, [F]),
     "mmbert_dropout_mask": (I, [P, P, SZ, U32, U32]),
     "mmbert_mlm_mask": (I, [P, P, P, SZ, U32, U32, U32, C.c_int64, C.c_int64, C.c_int64, C.c_int64]),
-    "mmbert_ln_fwd": (I, [P, P, I, P, P, I, P, I, I, P, P, F, P, P, U32, U32, F]),
-    "mmbert_ln_bwd": (I, [P, P, I, P, P, I, P, P, P, P, I, I, P, I, P, P, I, P, P, P, U32, U32, F, U32, U32, F, P, P, I]),
+    "mmbert_ln_fwd": (I, [P, P, I, P, P, I, P, I, I, P, P, F, P, P, U32, U32, F, I]),
+    "mmbert_ln_bwd": (I, [P, P, I, P, P, I, P, P, P, P, I, I, P, I, P, P, I, P, P, P, U32, U32, F, U32, U32, F, P, P, I, I]),
     "mmbert_ln_bwd_reduce": (I, [P, I, P, P, P, P, I, I]),
     "mmbert_ln_bwd_workspace": (SZ, [I, I]),
     "mmbert_embed_gather": (I, [P, P, P, P, P, P, I, I, I, I, P, I]),
@@ -47,7 +47,7 @@ SIGNATURES = {
     "mmbert_ce_bwd": (I, [P, P, I, I, P, I, P, I, P, P, P, P, I, P, I, I]),
     "mmbert_active_rows": (I, [P, P, I, I, P, P]),
     "mmbert_prologue": (I, [P, I, P, P, P, P, P, P, P, I, P, I, P, I, P, P, P, P, P, P, P, P]),
-    "mmbert_split_rows": (I, [P, P, P, P, P, P, I, I, I, P, P, P]),
+    "mmbert_split_rows": (I, [P, P, P, P, P, P, I, I, I, P, P, P, P, P]),
     "mmbert_heads_gate_fwd": (I, [P, P, P, P, P, I, I, P, P]),
     "mmbert_heads_loss_fwd": (I, [P, P, P, P, P, P, P, I, I, F, I, P, P, P, P, P, P, P, I, F]),
     "mmbert_heads_scale": (I, [P, P, SZ, P]),

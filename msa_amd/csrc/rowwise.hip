@@ -17,14 +17,19 @@
 // they sit in the original sequence (the fused text | visual | speech sequence has its visual padding in the middle).
 __global__ void split_rows_kernel(const int64_t* __restrict__ row_seq, const int64_t* __restrict__ row_pos, const int* __restrict__ start_a,
                                   const int* __restrict__ start_b, const int* __restrict__ valid, int mode, int M, int rows_a,
-                                  int64_t* __restrict__ perm, int64_t* __restrict__ inv, const int* __restrict__ rank) {
+                                  int64_t* __restrict__ perm, int64_t* __restrict__ inv, const int* __restrict__ rank,
+                                  int* __restrict__ perm32, int* __restrict__ inv32) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= M) return;
     const int s = (int)row_seq[i], p = rank ? rank[i] : (int)row_pos[i], v = valid[s];
-    if (p < v) { const int n = start_a[s] + p; inv[i] = n; perm[n] = i; }
-    else if (mode == 0) { const int n = start_b[s] + p - v; inv[i] = n; perm[n] = i; }
-    else if (mode == 1) { const int n = start_b[s]; inv[i] = n; if (p == v) perm[n] = i; }
-    else inv[i] = rows_a;
+    int n = rows_a;
+    bool own = false;                                          // does packed row n stand for original row i?
+    if (p < v) { n = start_a[s] + p; own = true; }
+    else if (mode == 0) { n = start_b[s] + p - v; own = true; }
+    else if (mode == 1) { n = start_b[s]; own = p == v; }
+    inv[i] = n;
+    if (inv32) inv32[i] = n;
+    if (own) { perm[n] = i; if (perm32) perm32[n] = i; }
 }
 
 extern "C" {
@@ -45,7 +50,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const bf16_t* __restrict__ 
                                                      bf16_t* __restrict__ y, int ldy, const int* __restrict__ out_rows,
                                                      int M, int H, const float* __restrict__ gamma, const float* __restrict__ beta,
                                                      float eps, float* __restrict__ mean_out, float* __restrict__ rstd_out,
-                                                     uint32_t dstream, uint32_t dthr, float dscale) {
+                                                     uint32_t dstream, uint32_t dthr, float dscale, int drop_row0) {
     const int lane = threadIdx.x & 63;
     const int wpb = blockDim.x >> 6;
     for (int i0 = (blockIdx.x * wpb + (threadIdx.x >> 6)) * R; i0 < M; i0 += gridDim.x * wpb * R) {
@@ -100,7 +105,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const bf16_t* __restrict__ 
                                       (v[rr][c][2] - mean[rr]) * rstd[rr] * g.z + b.z, (v[rr][c][3] - mean[rr]) * rstd[rr] * g.w + b.w};
                         if (dthr) {
                             bool k[4];
-                            mmb_keep4(dstream, (uint64_t)i * H + col, dthr, k);
+                            mmb_keep4(dstream, (uint64_t)(i + drop_row0) * H + col, dthr, k);
 #pragma unroll
                             for (int r = 0; r < 4; ++r) o[r] = k[r] ? o[r] * dscale : 0.f;
                         }
@@ -139,7 +144,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
                                                      float* __restrict__ partial,
                                                      uint32_t post_stream, uint32_t post_thr, float post_scale,
                                                      uint32_t pre_stream, uint32_t pre_thr, float pre_scale,
-                                                     const int* __restrict__ drop_rows) {
+                                                     const int* __restrict__ drop_rows, int dy_row_limit) {
     __shared__ float red[2][4][NV * 256];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     float ag[NV][4], ab[NV][4], ad[NV][4];
@@ -158,14 +163,21 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
             const int i = i0 + rr * stride;
             live[rr] = i < M;
             const int ic = live[rr] ? i : i0;
-            const bf16_t* dyr = dy + (size_t)(dy_rows ? dy_rows[ic] : ic) * lddy;
+            // dy_row_limit > 0: a mapped dy row at or past the limit does not exist -- its gradient is zero (the rows the valid-first
+            // packing leaves out of backward; wave-uniform)
+            const int dr = dy_rows ? dy_rows[ic] : ic;
+            const bool has_dy = !(dy_row_limit > 0 && dr >= dy_row_limit);
+            const bf16_t* dyr = dy + (size_t)(has_dy ? dr : 0) * lddy;
             const bf16_t* xr = x + (size_t)(x_rows ? x_rows[ic] : ic) * ldx;
             mean[rr] = mean_in[ic]; rstd[rr] = rstd_in[ic];
             di[rr] = drop_rows ? (uint64_t)drop_rows[ic] : (uint64_t)ic;           // the row the dropout masks were drawn for
 #pragma unroll
             for (int c = 0; c < NV; ++c) {
                 const int col = c * 256 + lane * 4;
-                if (col < H) { dl[rr][c] = *(const bf16x4*)(dyr + col); tl[rr][c] = *(const bf16x4*)(xr + col); }
+                if (col < H) {
+                    dl[rr][c] = has_dy ? *(const bf16x4*)(dyr + col) : (bf16x4){(bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f};
+                    tl[rr][c] = *(const bf16x4*)(xr + col);
+                }
             }
         }
 #pragma unroll
@@ -946,7 +958,7 @@ uint32_t mmbert_dropout_thr16(float p) {
 
 int mmbert_ln_fwd(hipStream_t stream, const void* x, int ldx, const int* in_rows, void* y, int ldy, const int* out_rows,
                   int M, int H, const float* gamma, const float* beta, float eps, float* mean, float* rstd,
-                  uint32_t dstream, uint32_t dthr, float dscale) {
+                  uint32_t dstream, uint32_t dthr, float dscale, int drop_row0) {
     if (M <= 0) return 0;
     if (H > LN_MAXV * 256 || (H & 3) || (ldx & 3) || (ldy & 3)) return -1;
     static const int rows_env = getenv("MMBERT_LN_ROWS") ? atoi(getenv("MMBERT_LN_ROWS")) : 0;      // A/B switch: rows per wave
@@ -954,7 +966,7 @@ int mmbert_ln_fwd(hipStream_t stream, const void* x, int ldx, const int* in_rows
     const int R = rows_env ? rows_env : (M >= 8192 ? 2 : 1);
     const int NV = (H + 255) / 256;
 #define LN_FWD_LAUNCH(NVV, RR) hipLaunchKernelGGL((ln_fwd_kernel<NVV, RR>), dim3(grid_for(M, 4 * RR)), dim3(256), 0, stream, (const bf16_t*)x, ldx, in_rows, \
-                                                  (bf16_t*)y, ldy, out_rows, M, H, gamma, beta, eps, mean, rstd, dstream, dthr, dscale)
+                                                  (bf16_t*)y, ldy, out_rows, M, H, gamma, beta, eps, mean, rstd, dstream, dthr, dscale, drop_row0)
     if (R >= 2) { if (NV == 1) LN_FWD_LAUNCH(1, 2); else if (NV == 2) LN_FWD_LAUNCH(2, 2); else if (NV == 3) LN_FWD_LAUNCH(3, 2); else LN_FWD_LAUNCH(4, 2); }
     else { if (NV == 1) LN_FWD_LAUNCH(1, 1); else if (NV == 2) LN_FWD_LAUNCH(2, 1); else if (NV == 3) LN_FWD_LAUNCH(3, 1); else LN_FWD_LAUNCH(4, 1); }
 #undef LN_FWD_LAUNCH
@@ -972,9 +984,11 @@ int mmbert_ln_bwd(hipStream_t stream, const void* dy, int lddy, const int* dy_ro
                   const float* mean, const float* rstd, const float* gamma, int M, int H,
                   void* dx, int lddx, const int* dx_rows, void* dx2, int lddx2, float* dgamma, float* dbeta, float* dbias2,
                   uint32_t post_stream, uint32_t post_thr, float post_scale,
-                  uint32_t pre_stream, uint32_t pre_thr, float pre_scale, float* partial_ws, const int* drop_rows, int defer_reduce) {
+                  uint32_t pre_stream, uint32_t pre_thr, float pre_scale, float* partial_ws, const int* drop_rows, int defer_reduce,
+                  int dy_row_limit) {
     if (M <= 0) return 0;
     if (H > LN_MAXV * 256 || (H & 3) || (ldx & 3) || (lddy & 3) || (lddx & 3) || (lddx2 & 3)) return -1;
+    if (dy_row_limit > 0 && !dy_rows) return -1;
     if (defer_reduce && !partial_ws) return -1;
     const int nblocks = ln_bwd_blocks(M);
     static const int rows_env = getenv("MMBERT_LN_BWD_ROWS") ? atoi(getenv("MMBERT_LN_BWD_ROWS")) : 0;      // A/B switch: rows per wave and trip
@@ -985,7 +999,7 @@ int mmbert_ln_bwd(hipStream_t stream, const void* dy, int lddy, const int* dy_ro
     const int NV = nv4_env ? 4 : (H + 255) / 256;
 #define LN_BWD_LAUNCH(NVV, RR) hipLaunchKernelGGL((ln_bwd_kernel<NVV, RR>), dim3(nblocks), dim3(256), 0, stream, (const bf16_t*)dy, lddy, dy_rows, \
         (const bf16_t*)x, ldx, x_rows, mean, rstd, gamma, M, H, (bf16_t*)dx, lddx, dx_rows, (bf16_t*)dx2, lddx2, dgamma, dbeta, dbias2, partial_ws, \
-        post_stream, post_thr, post_scale, pre_stream, pre_thr, pre_scale, drop_rows)
+        post_stream, post_thr, post_scale, pre_stream, pre_thr, pre_scale, drop_rows, dy_row_limit)
     if (R >= 2) { if (NV == 1) LN_BWD_LAUNCH(1, 2); else if (NV == 2) LN_BWD_LAUNCH(2, 2); else if (NV == 3) LN_BWD_LAUNCH(3, 2); else LN_BWD_LAUNCH(4, 2); }
     else { if (NV == 1) LN_BWD_LAUNCH(1, 1); else if (NV == 2) LN_BWD_LAUNCH(2, 1); else if (NV == 3) LN_BWD_LAUNCH(3, 1); else LN_BWD_LAUNCH(4, 1); }
 #undef LN_BWD_LAUNCH
@@ -1114,10 +1128,11 @@ int mmbert_ce_bwd(hipStream_t stream, const void* logits, int ldv, int V, const 
 }
 
 int mmbert_split_rows(hipStream_t stream, const int64_t* row_seq, const int64_t* row_pos, const int* start_a, const int* start_b, const int* valid,
-                      int mode, int M, int rows_a, int64_t* perm, int64_t* inv, const int* rank) {
+                      int mode, int M, int rows_a, int64_t* perm, int64_t* inv, const int* rank, int* perm32, int* inv32) {
     if (M <= 0) return 0;
     if (mode < 0 || mode > 2) return -1;
-    hipLaunchKernelGGL(split_rows_kernel, dim3((M + 255) / 256), dim3(256), 0, stream, row_seq, row_pos, start_a, start_b, valid, mode, M, rows_a, perm, inv, rank);
+    hipLaunchKernelGGL(split_rows_kernel, dim3((M + 255) / 256), dim3(256), 0, stream, row_seq, row_pos, start_a, start_b, valid, mode, M, rows_a, perm, inv, rank,
+                       perm32, inv32);
     MMB_CHECK_LAUNCH();
     return 0;
 }

@@ -179,27 +179,6 @@ class JointEmbeddings(nn.Module):
 # autograd functions over the C-ABI kernels.  Parameter gradients are accumulated straight into the
 # flat fp32 gradient buffer (p.grad views); the ``anchor`` parameter only makes autograd call backward.
 # ================================================================================================
-class _TextEmbedFn(torch.autograd.Function):
-    """word+type+pos -> LayerNorm(1e-12) -> dropout    (HF:53-108 via REF:MMBertForPretraining.py:264)"""
-
-    @staticmethod
-    def forward(ctx, anchor, top, ids, tts, T, drop):
-        w = top._w
-        e0 = ops.embed_gather(ids, tts, w["word"], w["type"], w["pos"], T)
-        e1, mean, rstd = ops.ln_fwd(e0, w["emb_ln_g"], w["emb_ln_b"], top.config.layer_norm_eps, drop=drop)
-        ctx.top, ctx.T, ctx.drop = top, T, drop
-        ctx.save_for_backward(ids, tts, e0, mean, rstd)
-        return e1
-
-    @staticmethod
-    def backward(ctx, de1):
-        ids, tts, e0, mean, rstd = ctx.saved_tensors
-        w = ctx.top._w
-        de0 = ops.ln_bwd(de1.contiguous(), e0, mean, rstd, w["emb_ln_g"], w["g_emb_ln_g"], w["g_emb_ln_b"], post_drop=ctx.drop)
-        ops.embed_scatter(ids, tts, de0, ctx.T, w["g_word"], w["g_type"], w["g_pos"])
-        return None, None, None, None, None, None
-
-
 class _JointFn(torch.autograd.Function):
     """cat(text_emb, relu(W.pair+b)) -> LayerNorm(1e-5) -> dropout(0.5)      (REF:MMBertEmbedding.py:57-72)
     ``feats`` / ``whichs`` are tuples: one modality in the reference's joint passes; both (text | visual | speech in ONE
@@ -236,19 +215,21 @@ class _JointFn(torch.autograd.Function):
         return de1, None, None, None, None, None, None, None
 
 
-class _EncoderFn(torch.autograd.Function):
-    """L x BertLayer (HF:374-416) over the packed token matrix."""
+class _EncoderFn:
+    """L x BertLayer (HF:374-416) over the packed token matrix: the forward / backward bodies that _TrunkFn runs between the
+    embedding stage and the heads (plain functions: the whole trunk is ONE autograd node, so no [tokens, H] tensor crosses
+    autograd between its stages)."""
 
     @staticmethod
-    def forward(ctx, x, anchor, top, layout, key_bias, seed, kv_len=None, top_rows=None):
+    def run_forward(top, x, layout, key_bias, seed, kv_len, keep, y_out=None, y_rows=None):
+        """Returns (y, saved).  ``y_out`` / ``y_rows``: the LAST layer's LayerNorm writes row i of its output to y_out[y_rows[i]] --
+        the un-packing of the valid-first layout (ops.SplitLayout.perm32) rides on that store instead of a [tokens, H] gather."""
         cfg = top.config
         H, L = cfg.hidden_size, cfg.num_hidden_layers
         train = top.training
         ph = cfg.hidden_dropout_prob if train else 0.0
         pa = cfg.attention_probs_dropout_prob if train else 0.0
-        keep = ctx.needs_input_grad[0]
         saved = []
-        x = x.contiguous()
         for i in range(L):
             lw = top._lw[i]
             d_att, d_h1, d_h2 = (ops.make_drop(pa, seed, 8 * i), ops.make_drop(ph, seed, 8 * i + 1), ops.make_drop(ph, seed, 8 * i + 2))
@@ -259,59 +240,77 @@ class _EncoderFn(torch.autograd.Function):
             u = torch.empty((x.shape[0], cfg.intermediate_size), device=x.device, dtype=torch.bfloat16) if keep else None
             g = ops.gemm_nt(y1, lw["W1"], bias=lw["b1"], gelu=True, aux=u)
             z2 = ops.gemm_nt(g, lw["W2"], bias=lw["b2"], resid=y1, drop=d_h2)
-            y2, m2, r2 = ops.ln_fwd(z2, lw["ln2_g"], lw["ln2_b"], cfg.layer_norm_eps, stats=keep)
+            last = i == L - 1 and y_out is not None
+            y2, m2, r2 = ops.ln_fwd(z2, lw["ln2_g"], lw["ln2_b"], cfg.layer_norm_eps, stats=keep,
+                                    out=y_out if last else None, out_rows=y_rows if last else None)
             if keep:
                 saved.append((x, qkv, actx, lse, z1, m1, r1, y1, u, g, z2, m2, r2, d_att, d_h1, d_h2))
             x = y2
             if top.debug_hidden is not None:
-                top.debug_hidden.setdefault("_layers_packed", []).append(y2.detach())
-        ctx.top, ctx.layout, ctx.key_bias, ctx.saved, ctx.kv_len, ctx.top_rows = top, layout, key_bias, saved, kv_len, top_rows
-        return x
+                top.debug_hidden.setdefault("_layers_packed", []).append(None if last else y2.detach())
+        return x, saved
 
     @staticmethod
-    def backward(ctx, dy):
-        top, layout, key_bias = ctx.top, ctx.layout, ctx.key_bias
+    def run_backward(top, layout, key_bias, kv_len, saved, dy, dy_rows, top_rows, compact=None):
+        """``dy``: gradient of the encoder output -- in the encoder's own row order, or (``dy_rows`` = the int32 row list
+        ops.SplitLayout.perm32[:rows_a]) in the caller's order, read through the map by the top layer's LayerNorm'.  ``compact`` =
+        (rows in the caller's order int64, their gradients [n, H] bf16): the only rows of the output that carry a gradient, handed
+        over by the MLM head (no dense [tokens, H] gradient exists then; ``dy`` is ignored).  Returns dx for the leading rows_a rows."""
         H = top.config.hidden_size
-        dy = dy.contiguous()
+        L = top.config.num_hidden_layers
         top._flat.grads_dirty = True
         # split (valid-first) layout: the rows behind rows_a have exactly-zero gradients in every layer (see _encode), so the
         # whole backward -- dgrads, weight gradients, LayerNorm', attention -- runs on the leading rows_a rows only
-        M_all = dy.shape[0]
+        M_all = saved[0][0].shape[0]
         ra = layout.rows_a if getattr(layout, "split", False) else M_all
-        if ra < M_all:
+        if dy is not None and dy_rows is None and ra < dy.shape[0]:
             dy = dy[:ra]
         # LayerNorm' leaves its gamma / beta partial sums in a workspace; ONE reduce launch folds all layers' sums into the gradients at
         # the end (with a data-parallel hook: per layer, before the layer's gradient slice is handed to the all-reduce); same-process
         # A/B against round 1's form (bias sums inside LayerNorm', one reduce launch per call): 16.58 vs 16.76 ms per step
-        lnd = ops.LnDeferred(2 * top.config.num_hidden_layers)
-        for i in reversed(range(top.config.num_hidden_layers)):
+        lnd = ops.LnDeferred(2 * L)
+        for i in reversed(range(L)):
             lw = top._lw[i]
-            saved_i = ctx.saved[i]
-            ctx.saved[i] = None
+            saved_i = saved[i]
+            saved[i] = None
             if ra < M_all:
                 saved_i = tuple(t[:ra] if torch.is_tensor(t) else t for t in saved_i)
             x, qkv, actx, lse, z1, m1, r1, y1, u, g, z2, m2, r2, d_att, d_h1, d_h2 = saved_i
-            if i == top.config.num_hidden_layers - 1 and ctx.top_rows is not None:
-                R = _EncoderFn._sparse_rows(ctx.top_rows, layout, ra)
+            if i == L - 1 and (top_rows is not None or compact is not None):
+                R = None
+                if compact is not None:
+                    R, dy_c = compact
+                    if getattr(layout, "split", False):
+                        R = layout.inv.index_select(0, R)
+                elif top_rows is not None:
+                    Ro = _EncoderFn._sparse_rows(top_rows, None, ra)          # rows in the caller's order
+                    if Ro is not None:
+                        R = layout.inv.index_select(0, Ro) if getattr(layout, "split", False) else Ro
+                        src_rows = Ro if dy_rows is not None else R            # dy is in the caller's order iff it comes with a map
+                        (dy_c,) = ops.gather_rows([dy], src_rows.int())
                 if R is not None:
-                    dy = _EncoderFn._last_layer_sparse(top, lw, layout, key_bias, ctx.kv_len, saved_i, dy, R, H, ra)
+                    dy = _EncoderFn._last_layer_sparse(top, lw, layout, key_bias, kv_len, saved_i, dy_c, R, H, ra)
+                    dy_rows = None
                     top._layer_grads_done(i)
                     continue
+                if compact is not None:
+                    raise RuntimeError("compact output gradient without the sparse top-layer path")
             # --- output sublayer: y2 = LN(dropout(g.W2^T + b2) + y1)      (b2 / bo gradients = column sums of dz2d / dz1d: they ride
             # on the weight-gradient launch below, like b1 and bqkv, on an all-ones MFMA operand)
-            dz2d = torch.empty_like(dy) if d_h2[1] else None
-            dz2 = ops.ln_bwd(dy, z2, m2, r2, lw["ln2_g"], lw["g_ln2_g"], lw["g_ln2_b"], dx2=dz2d, pre_drop=d_h2, deferred=lnd)
+            dz2d = torch.empty((ra, H), device=z2.device, dtype=torch.bfloat16) if d_h2[1] else None
+            dz2 = ops.ln_bwd(dy, z2, m2, r2, lw["ln2_g"], lw["g_ln2_g"], lw["g_ln2_b"], dx2=dz2d, pre_drop=d_h2, deferred=lnd, dy_rows=dy_rows)
+            dy_rows = None
             if dz2d is None:
                 dz2d = dz2
             du = ops.gemm_nt(dz2d, lw["W2T"], gelu_bwd_u=u)
             dy1 = ops.gemm_nt(du, lw["W1T"], resid=dz2)
             # --- attention sublayer: y1 = LN(dropout(ctx.Wo^T + bo) + x)
-            dz1d = torch.empty_like(dy) if d_h1[1] else None
+            dz1d = torch.empty((ra, H), device=z2.device, dtype=torch.bfloat16) if d_h1[1] else None
             dz1 = ops.ln_bwd(dy1, z1, m1, r1, lw["ln1_g"], lw["g_ln1_g"], lw["g_ln1_b"], dx2=dz1d, pre_drop=d_h1, deferred=lnd)
             if dz1d is None:
                 dz1d = dz1
             dctx = ops.gemm_nt(dz1d, lw["WoT"])
-            dqkv = ops.attn_bwd(qkv, actx, dctx, lse, key_bias, layout, H, drop=d_att, kv_len=ctx.kv_len)
+            dqkv = ops.attn_bwd(qkv, actx, dctx, lse, key_bias, layout, H, drop=d_att, kv_len=kv_len)
             dy = ops.gemm_nt(dqkv, lw["WqkvT"], resid=dz1)
             # --- all four weight gradients (+ b1, bqkv gradients on the ones-operand MFMA) of the layer in ONE launch.
             # They are off the critical path of backward; model.overlap_wgrad = True moves them to a side stream (measured: a loss).
@@ -336,11 +335,7 @@ class _EncoderFn(torch.autograd.Function):
         side = top._wgrad_stream()
         if side is not None:
             torch.cuda.current_stream().wait_stream(side)     # optimizer / all-reduce tail see complete gradients
-        if ra < M_all:
-            full = dy.new_zeros((M_all, dy.shape[1]))
-            full[:ra] = dy
-            dy = full
-        return dy, None, None, None, None, None, None, None
+        return dy
 
     @staticmethod
     def _sparse_rows(top_rows, layout, ra):
@@ -352,12 +347,12 @@ class _EncoderFn(torch.autograd.Function):
         if 4 * r > ra or int(host[1]) != 0:                       # a labelled [CLS] row would be gathered twice: dense backward
             return None
         R = torch.cat((idx[:n].long(), first))
-        if getattr(layout, "split", False):
+        if layout is not None and getattr(layout, "split", False):
             R = layout.inv.index_select(0, R)
         return R
 
     @staticmethod
-    def _last_layer_sparse(top, lw, layout, key_bias, kv_len, saved_i, dy, R, H, ra):
+    def _last_layer_sparse(top, lw, layout, key_bias, kv_len, saved_i, dy_c, R, H, ra):
         """Backward of the top encoder layer when only the rows R of its output carry a gradient: the output sublayer (LayerNorm',
         FFN-down and FFN-up input gradients, their weight gradients), LayerNorm' and the output projection of the attention
         sublayer run on those rows only (gathered operands, the dropout masks of the ORIGINAL rows); attention's backward is
@@ -366,7 +361,8 @@ class _EncoderFn(torch.autograd.Function):
         x, qkv, actx, lse, z1, m1, r1, y1, u, g, z2, m2, r2, d_att, d_h1, d_h2 = saved_i
         R32 = R.int()
         # the rows R of every saved activation this path reads, in ONE launch (9 index_select launches before)
-        dy_c, m2_c, r2_c, u_c, m1_c, r1_c, y1_c, g_c, actx_c = ops.gather_rows([dy, m2, r2, u, m1, r1, y1, g, actx], R32)
+        m2_c, r2_c, u_c, m1_c, r1_c, y1_c, g_c, actx_c = ops.gather_rows([m2, r2, u, m1, r1, y1, g, actx], R32)
+        dy = dy_c
         dz2d_c = torch.empty_like(dy_c) if d_h2[1] else None
         dz2_c = ops.ln_bwd(dy_c, z2, m2_c, r2_c, lw["ln2_g"], lw["g_ln2_g"], lw["g_ln2_b"], x_rows=R32, dx2=dz2d_c, pre_drop=d_h2,
                            drop_rows=R32)
@@ -392,25 +388,172 @@ class _EncoderFn(torch.autograd.Function):
         return out
 
 
-class _PermuteRowsFn(torch.autograd.Function):
-    """out[i] = x[fwd_idx[i]], gradient g_in[j] = g[bwd_idx[j]] -- for a permutation (bwd_idx its inverse) or for the packing that
-    leaves rows out: an index equal to the source's row count reads an appended zero row (``pad_fwd`` / ``pad_bwd``).  (Autograd's
-    generic index_select backward is an index_add scatter: 6x slower on the [tokens, H] matrix.)"""
+def _trunk_static(plan, B, T, lens, joff, dev):
+    """Shape-static row lists of the trunk (cached in the plan): ``jrows[k]`` = where the B*T text rows of joint pass k sit in the
+    joint passes' pre-LayerNorm matrix J (row joff[k] + b * S_k + t), ``arange`` = 0 .. passes * B * T - 1 (the embedding dropout's row
+    index of every text row), both int32 on the device."""
+    key = ("trunk_static", T, tuple(sorted(joff.items())))
+    st = plan.get(key)
+    if st is None:
+        jrows = {}
+        for k, lo in joff.items():
+            b = torch.arange(B, dtype=torch.int32)[:, None] * lens[k] + torch.arange(T, dtype=torch.int32)[None, :] + lo
+            jrows[k] = b.reshape(-1).to(dev)
+        st = plan[key] = dict(jrows=jrows, arange=torch.arange(len(lens) * B * T, dtype=torch.int32, device=dev))
+    return st
+
+
+class _Trunk:
+    """What one _TrunkFn call works on (plain attributes; built by _encode)."""
+    __slots__ = ("ids", "tts", "B", "T", "lens", "pair_info", "feats", "plan", "layout", "split", "key_bias", "kv_len", "seed", "top_rows",
+                 "d_emb", "d_joint", "infer", "late_split", "compact")
+
+
+class _TrunkFn(torch.autograd.Function):
+    """Embeddings -> (JointEmbeddings) -> L encoder layers as ONE autograd node (the anchor parameter only makes autograd call
+    backward; parameter gradients go straight into the flat gradient buffer).
+      word+type+pos -> LayerNorm(1e-12) -> dropout                          (HF:53-108 via REF:MMBertForPretraining.py:264)
+      cat(text_emb, relu(W.pair+b)) -> LayerNorm(1e-5) -> dropout(0.5)       (REF:MMBertEmbedding.py:57-72; joint passes)
+      L x BertLayer                                                         (HF:374-416)
+    Row maps instead of copies: the embedding LayerNorm stores the text-pass rows straight into the encoder's input X and the
+    text rows of a joint pass into that pass's pre-LayerNorm matrix J (round 2: a copy per pass); the joint LayerNorm stores into X
+    (round 2: torch.cat of the passes); with the valid-first packing both store through SplitLayout.inv32 (round 2: a [tokens, H]
+    gather), the last encoder layer's LayerNorm un-packs through perm32 (another gather), and backward reads its output gradient
+    through perm32 and hands the embedding stage its rows through inv32 with "past rows_a = zero" (two more gathers, a zero fill and
+    the slice / accumulate kernels of autograd's cat / index backward).  Output: [tokens, H] bf16 in the caller's row order."""
 
     @staticmethod
-    def forward(ctx, x, fwd_idx, bwd_idx, pad_fwd=False, pad_bwd=False):
-        ctx.save_for_backward(bwd_idx)
-        ctx.pad_bwd = pad_bwd
-        if pad_fwd:
-            x = torch.cat((x, x.new_zeros((1, x.shape[1]))))
-        return x.index_select(0, fwd_idx)
+    def forward(ctx, anchor, top, t):
+        cfg, w = top.config, top._w
+        H = cfg.hidden_size
+        B, T, lens, plan, split = t.B, t.T, t.lens, t.plan, t.split
+        bounds, tokens = plan["bounds"], plan["layout"].tokens
+        dev = t.ids.device
+        keep = ctx.needs_input_grad[0]
+        late = t.layout                                           # callable: the packing is decided after the embedding launches
+        npass = len(lens)
+        joint = [k for k in range(npass) if t.pair_info[k] is not None]
+        joff, jtot = {}, 0
+        for k in joint:
+            joff[k] = jtot
+            jtot += B * lens[k]
+        early = split is not None and not t.late_split and not t.infer          # the packing is known: store X in packed order right away
+        dropped = split is not None and getattr(split, "dropped", False)
+        Mx = split.rows_packed if early else tokens
+        pad = 1 if (early and dropped) else 0                   # left-out rows (inv = rows_a) land in one scratch row behind X
+        buf = torch.empty((Mx + pad + jtot, H), device=dev, dtype=torch.bfloat16)
+        X, J = buf[:Mx], buf[Mx + pad:]
+        st = _trunk_static(plan, B, T, lens, joff, dev)
+        # ---- embeddings: e0 = word + type + pos for the text rows of all passes, LayerNorm + dropout stored where the rows are needed
+        e0 = ops.embed_gather(t.ids, t.tts, w["word"], w["type"], w["pos"], T)
+        mean0 = torch.empty(npass * B * T, device=dev, dtype=torch.float32)
+        rstd0 = torch.empty_like(mean0)
+        for k in range(npass):                                   # (one launch per pass: 3 small ones at the headline shape)
+            rows = slice(k * B * T, (k + 1) * B * T)
+            if k in joff:
+                out, orows = J, st["jrows"][k]
+            elif early:
+                out, orows = X, split.inv32[bounds[k]:bounds[k + 1]]
+            else:
+                out, orows = X[bounds[k]:bounds[k + 1]], None
+            ops.ln_fwd(e0[rows], w["emb_ln_g"], w["emb_ln_b"], cfg.layer_norm_eps, out=out, out_rows=orows, drop=t.d_emb, drop_row0=k * B * T,
+                       stats=(mean0[rows], rstd0[rows]))
+        jstats = {}
+        for k in joint:
+            S = lens[k]
+            Jk = J[joff[k]:joff[k] + B * S]
+            off = T
+            for feat, which in zip(t.feats[k], t.pair_info[k][1]):
+                ops.pair_proj_fwd(feat, w[which + "_w"], w[which + "_b"], Jk, T, seq_len=S, offset=off)
+                off += feat.shape[1]
+            if early:
+                out, orows = X, split.inv32[bounds[k]:bounds[k + 1]]
+            else:
+                out, orows = X[bounds[k]:bounds[k + 1]], None
+            _, m_, r_ = ops.ln_fwd(Jk, w["joint_ln_g"], w["joint_ln_b"], LN_EPS_JOINT, out=out, out_rows=orows, drop=t.d_joint[k])
+            jstats[k] = (m_, r_)
+        if top.debug_hidden is not None:
+            e1 = torch.cat([(J[joff[k]:joff[k] + B * lens[k]].view(B, lens[k], H)[:, :T].reshape(B * T, H) if k in joff else
+                             (torch.cat((X, X.new_zeros((1, H)))).index_select(0, split.inv[bounds[k]:bounds[k + 1]]) if early else X[bounds[k]:bounds[k + 1]]))
+                            for k in range(npass)])
+            xo = torch.cat((X, X.new_zeros((1, H)))).index_select(0, split.inv) if early else X
+            top.debug_hidden.update(emb=e1.detach().clone(), x=xo.detach().clone())
+            top.debug_hidden.pop("_layers_packed", None)
+        # ---- the packing, when it was not known before the embedding kernels were queued (synchronous prologue) or for inference
+        if late is not None:
+            split = t.split = late()
+            t.layout = None
+            dropped = split is not None and getattr(split, "dropped", False)
+        x = X
+        if split is not None and not early:
+            x = X.index_select(0, split.perm)
+        # ---- encoder; the last layer's LayerNorm un-packs (not for the inference packing: several rows share one there)
+        layout = split if split is not None else plan["layout"]
+        y_out = y_rows = None
+        if split is not None and not t.infer:
+            y_out = (torch.zeros if dropped else torch.empty)((tokens, H), device=dev, dtype=torch.bfloat16)
+            y_rows = split.perm32
+        y, saved = _EncoderFn.run_forward(top, x, layout, t.key_bias, t.seed, None if split is not None else t.kv_len, keep, y_out, y_rows)
+        if split is not None and t.infer:
+            y = y.index_select(0, split.inv)                      # every masked-out row reads its sequence's representative
+        ctx.top, ctx.t, ctx.saved, ctx.joff, ctx.early = top, t, saved, joff, early
+        if keep:
+            ctx.save_for_backward(e0, mean0, rstd0, J, *[x_ for k in joint for x_ in jstats[k]])
+        return y
 
     @staticmethod
-    def backward(ctx, g):
-        (bwd_idx,) = ctx.saved_tensors
-        if ctx.pad_bwd:
-            g = torch.cat((g, g.new_zeros((1, g.shape[1]))))
-        return g.index_select(0, bwd_idx), None, None, None, None
+    def backward(ctx, dy):
+        top, t = ctx.top, ctx.t
+        cfg, w = top.config, top._w
+        H = cfg.hidden_size
+        e0, mean0, rstd0, J, *js = ctx.saved_tensors
+        B, T, lens, plan, split = t.B, t.T, t.lens, t.plan, t.split
+        bounds = plan["bounds"]
+        st = _trunk_static(plan, B, T, lens, ctx.joff, e0.device)
+        npass = len(lens)
+        layout = split if split is not None else plan["layout"]
+        compact, t.compact = t.compact, None                      # (rows in the caller's order, their gradients): set by the MLM head
+        dy_rows = None
+        if compact is None:
+            dy = dy.contiguous()
+            if split is not None:
+                dy_rows = split.perm32[:split.rows_a]             # dy is in the caller's order: the top LayerNorm' reads it through the map
+        dx = _EncoderFn.run_backward(top, layout, t.key_bias, None if split is not None else t.kv_len, ctx.saved, dy, dy_rows, t.top_rows,
+                                     compact)
+        ctx.saved = None
+        # ---- embedding stage: dx holds the leading rows_a rows of the packed order (all rows without the packing)
+        ra = dx.shape[0]
+        inv32 = split.inv32 if split is not None else None
+        limit = ra if split is not None else 0
+        dJ = torch.empty_like(J)
+        de0 = torch.empty_like(e0)
+        joint = sorted(ctx.joff)
+        for n, k in enumerate(joint):
+            S = lens[k]
+            lo = ctx.joff[k]
+            m_, r_ = js[2 * n], js[2 * n + 1]
+            if split is not None:
+                ops.ln_bwd(dx, J[lo:lo + B * S], m_, r_, w["joint_ln_g"], w["g_joint_ln_g"], w["g_joint_ln_b"], dx=dJ[lo:lo + B * S],
+                           dy_rows=inv32[bounds[k]:bounds[k + 1]], dy_row_limit=limit, post_drop=t.d_joint[k])
+            else:
+                ops.ln_bwd(dx[bounds[k]:bounds[k + 1]], J[lo:lo + B * S], m_, r_, w["joint_ln_g"], w["g_joint_ln_g"], w["g_joint_ln_b"],
+                           dx=dJ[lo:lo + B * S], post_drop=t.d_joint[k])
+            off = T
+            for feat, which in zip(t.feats[k], t.pair_info[k][1]):
+                ops.pair_proj_bwd(feat, J[lo:lo + B * S], dJ[lo:lo + B * S], T, w["g_" + which + "_w"], w["g_" + which + "_b"], seq_len=S, offset=off)
+                off += feat.shape[1]
+        for k in range(npass):
+            rows = slice(k * B * T, (k + 1) * B * T)
+            kw = dict(dx=de0[rows], post_drop=t.d_emb, drop_rows=st["arange"][rows] if t.d_emb[1] else None)
+            if k in ctx.joff:
+                ops.ln_bwd(dJ, e0[rows], mean0[rows], rstd0[rows], w["emb_ln_g"], w["g_emb_ln_g"], w["g_emb_ln_b"], dy_rows=st["jrows"][k], **kw)
+            elif split is not None:
+                ops.ln_bwd(dx, e0[rows], mean0[rows], rstd0[rows], w["emb_ln_g"], w["g_emb_ln_g"], w["g_emb_ln_b"],
+                           dy_rows=inv32[bounds[k]:bounds[k + 1]], dy_row_limit=limit, **kw)
+            else:
+                ops.ln_bwd(dx[bounds[k]:bounds[k + 1]], e0[rows], mean0[rows], rstd0[rows], w["emb_ln_g"], w["g_emb_ln_g"], w["g_emb_ln_b"], **kw)
+        ops.embed_scatter(t.ids, t.tts, de0, T, w["g_word"], w["g_type"], w["g_pos"])
+        return None, None, None
 
 
 def mlm_active_rows(labels, vocab, first=None):
@@ -442,6 +585,19 @@ def _active_row_count(rows) -> int:
     return int(host[0])
 
 
+_dummies = {}
+
+
+def _zero_dummy(M, H, dtype, device):
+    """A [M, H] all-zero tensor of stride 0 (one element of storage): what autograd is handed for a tensor whose real gradient
+    travels in compact form beside the graph."""
+    key = (dtype, str(device))
+    z = _dummies.get(key)
+    if z is None:
+        z = _dummies[key] = torch.zeros((1, 1), dtype=dtype, device=device)
+    return z.expand(M, H)
+
+
 class _MLMHeadFn(torch.autograd.Function):
     """decoder(LN(gelu(dense(seq)))) + per-pass CrossEntropy(ignore -100)
     (HF:466-496 via REF:MMBertForPretraining.py:293,381-384).  Returns (loss[nseg], logits or None, first): ``first`` = the rows
@@ -450,8 +606,13 @@ class _MLMHeadFn(torch.autograd.Function):
     their sum."""
 
     @staticmethod
-    def forward(ctx, y, anchor, top, labels, seg_bounds_host, seg_bounds, want_scores, rows=None, first_rows=None):
+    def forward(ctx, y, anchor, top, labels, seg_bounds_host, seg_bounds, want_scores, rows=None, first_rows=None, trunk=None):
+        """``trunk``: the _Trunk record of the _TrunkFn call that produced y (forward() / forward_fused() pass it): when the top encoder
+        layer's sparse backward applies, backward hands it the gradient of y in COMPACT form -- the labelled rows and the [CLS] rows,
+        the only ones with a gradient -- through ``trunk.compact`` and returns a stride-0 dummy for y (round 2: a zero-filled [tokens, H]
+        tensor, an index_copy, an index_add, and a row gather to pick the rows out again)."""
         cfg, w = top.config, top._w
+        ctx.trunk = trunk
         M, H = y.shape
         V, Vp = cfg.vocab_size, top._flat.vpad
         keep = ctx.needs_input_grad[0]
@@ -505,12 +666,36 @@ class _MLMHeadFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dloss, _unused, dfirst=None):
-        dy = _MLMHeadFn._backward(ctx, dloss)
+        res = _MLMHeadFn._backward(ctx, dloss)
+        nones = (None,) * 9
+        if isinstance(res, tuple):                            # (labelled rows int64, their gradients [n, H] bf16): the sparse paths
+            sel, dyl = res
+            t = ctx.trunk
+            if t is not None and t.top_rows is not None and dfirst is not None and _MLMHeadFn._compact_ok(ctx, t, sel.numel(), dfirst):
+                first = t.top_rows[1]
+                df = dfirst if dfirst.shape[0] == first.numel() else dfirst.view(-1, first.numel(), dfirst.shape[1]).sum(0)   # ([CLS] rows repeated: fused)
+                t.compact = (torch.cat((sel, first)), torch.cat((dyl, df.to(dyl.dtype))))
+                return (_zero_dummy(ctx.M, dyl.shape[1], dyl.dtype, dyl.device),) + nones
+            dy = torch.zeros((ctx.M, dyl.shape[1]), device=dyl.device, dtype=dyl.dtype)
+            if sel.numel():
+                dy.index_copy_(0, sel, dyl)
+        else:
+            dy = res
         if dfirst is not None:                                # a [CLS] row may also carry a label: add, after the copy
             if dy is None:
                 dy = torch.zeros((ctx.M, dfirst.shape[1]), device=dfirst.device, dtype=torch.bfloat16)
             dy.index_add_(0, ctx.first_rows, dfirst.to(dy.dtype))
-        return dy, None, None, None, None, None, None, None, None
+        return (dy,) + nones
+
+    @staticmethod
+    def _compact_ok(ctx, t, n, dfirst):
+        """The condition under which _EncoderFn.run_backward takes the sparse top-layer path (_sparse_rows): few rows, no labelled
+        [CLS] row -- evaluated here with the same numbers, so that a compact hand-over is never refused there."""
+        (idx, host, ev), first = t.top_rows
+        ra = t.split.rows_a if t.split is not None else t.plan["layout"].tokens
+        if ctx.first_rows is None or (ctx.first_rows.numel() % first.numel()) != 0:
+            return False
+        return 4 * (n + first.numel()) <= ra and int(host[1]) == 0 and n == _active_row_count(t.top_rows[0])
 
     @staticmethod
     def _backward(ctx, dloss):
@@ -527,18 +712,15 @@ class _MLMHeadFn(torch.autograd.Function):
             dt0 = ops.ln_bwd(dt, t0_c, mean_c, rstd_c, w["mlm_ln_g"], w["g_mlm_ln_g"], w["g_mlm_ln_b"])
             dpre = ops.gelu_bwd(dt0, pre_c)
             ops.gemm_tn(dpre, y_c, w["g_Wt"], bias_out=w["g_bt"])
-            dy = torch.zeros((ctx.M, y_c.shape[1]), device=y_c.device, dtype=y_c.dtype)
-            dy.index_copy_(0, sel, ops.gemm_nt(dpre, w["WtT"]))
-            return dy
+            return sel, ops.gemm_nt(dpre, w["WtT"])
         y, pre, t0, mean, rstd, t, logits, labels, seg_bounds, inv, lse = ctx.saved_tensors
         M = y.shape[0]
         if ctx.rows is not None:
             idx_all, host, ev = ctx.rows
             n = _active_row_count(ctx.rows)
             if 2 * n <= M:
-                dy = torch.zeros_like(y)
                 if n == 0:
-                    return dy
+                    return idx_all[:0].long(), y.new_zeros((0, y.shape[1]))
                 idx = idx_all[:n]
                 sel = idx.long()
                 dl = torch.empty((n, logits.shape[1]), device=y.device, dtype=torch.bfloat16)
@@ -549,8 +731,7 @@ class _MLMHeadFn(torch.autograd.Function):
                 dt0 = ops.ln_bwd(dt, t0_c, mean_c, rstd_c, w["mlm_ln_g"], w["g_mlm_ln_g"], w["g_mlm_ln_b"])
                 dpre = ops.gelu_bwd(dt0, pre_c)
                 ops.gemm_tn(dpre, y_c, w["g_Wt"], bias_out=w["g_bt"])
-                dy.index_copy_(0, sel, ops.gemm_nt(dpre, w["WtT"]))
-                return dy
+                return sel, ops.gemm_nt(dpre, w["WtT"])
         # dense path: dlogits with the per-pass upstream gradients folded in; in place unless the scores were handed to the caller
         dl = torch.empty(logits.shape, device=logits.device, dtype=torch.bfloat16) if (ctx.keep_logits or logits.dtype != torch.bfloat16) else logits
         ops.ce_bwd(logits, V, labels, seg_bounds, ctx.nseg, inv, gs, lse, dl)
@@ -816,46 +997,44 @@ class _GpuModelBase(nn.Module):
                 pending = self._request_lengths(plan, kv_len, labels, True, (pair_info, B, T))
             elif labels is not None and torch.is_grad_enabled() and getattr(self, "skip_padded_backward", True):
                 pending = (host[:nseq], None, ev)                     # the prologue's valid[]: unmasked length, extended to the last label
-        # ---- embeddings
+        # ---- embeddings + encoder: one autograd node (_TrunkFn)
         ids = torch.cat([p["ids"].reshape(-1).long() for p in passes])
         tts = torch.cat([(p["tt"].reshape(-1).long() if p.get("tt") is not None else torch.zeros(B * T, dtype=torch.long, device=dev)) for p in passes])
         p_emb = cfg.hidden_dropout_prob if self.training else 0.0
-        e1 = _TextEmbedFn.apply(bert.embeddings.LayerNorm.weight, self, ids, tts, T, ops.make_drop(p_emb, seed, 1000))
-        xs = []
         p_joint = je.dropout_prob if (self.training and je.training) else 0.0
-        for k, info in enumerate(pair_info):
-            e = e1[k * B * T:(k + 1) * B * T]
-            if info is not None:
-                feats = tuple(f.to(dev).float().contiguous() for f in info[0])
-                e = _JointFn.apply(e, je.LayerNorm.weight, self, feats, info[1], B, T, ops.make_drop(p_joint, seed, 1001 + k))
-            xs.append(e)
-        x = torch.cat(xs) if len(xs) > 1 else xs[0]
-        # the caller does not want the prediction scores (trainer.py never reads them): rows that nothing else reads are left out
-        drop = (not infer) and labels is not None and not getattr(self, "return_scores", True)
-        split = self._split_layout(plan, kv_len, pending, infer, drop, pro.rank)
-        if self.debug_hidden is not None:
-            self.debug_hidden.update(emb=e1.detach(), x=x.detach())
-            self.debug_hidden.pop("_layers_packed", None)
+        t = _Trunk()
+        t.compact = None
+        t.ids, t.tts, t.B, t.T, t.lens, t.pair_info, t.plan = ids, tts, B, T, lens, pair_info, plan
+        t.feats = [None if info is None else tuple(f.to(dev).float().contiguous() for f in info[0]) for info in pair_info]
+        t.key_bias, t.kv_len, t.seed, t.infer = key_bias, kv_len, seed, infer
+        t.d_emb = ops.make_drop(p_emb, seed, 1000)
+        t.d_joint = [ops.make_drop(p_joint, seed, 1001 + k) for k in range(len(lens))]
         # rows of the top layer's output that can have a gradient (MLM-labelled rows + the [CLS] rows the heads read): known
         # when the caller is forward() / forward_fused() -- only they guarantee that nothing else is differentiated
-        top_rows = (rows, plan["first"]) if (rows is not None and getattr(self, "sparse_top_layer_backward", True)) else None
-        if split is None:
-            y = _EncoderFn.apply(x, bert.embeddings.LayerNorm.weight, self, plan["layout"], key_bias, seed, kv_len, top_rows)
-        elif infer:
-            y = _EncoderFn.apply(x.index_select(0, split.perm), bert.embeddings.LayerNorm.weight, self, split, key_bias, seed, None, None)
-            y = y.index_select(0, split.inv)                          # every masked-out row reads its sequence's representative
-        elif getattr(split, "dropped", False):
-            y = _EncoderFn.apply(_PermuteRowsFn.apply(x, split.perm, split.inv, False, True), bert.embeddings.LayerNorm.weight, self, split, key_bias, seed, None, top_rows)
-            y = _PermuteRowsFn.apply(y, split.inv, split.perm, True, False)      # left-out rows read as zeros (nothing reads them)
-        else:
-            y = _EncoderFn.apply(_PermuteRowsFn.apply(x, split.perm, split.inv), bert.embeddings.LayerNorm.weight, self, split, key_bias, seed, None, top_rows)
-            y = _PermuteRowsFn.apply(y, split.inv, split.perm)
+        t.top_rows = (rows, plan["first"]) if (rows is not None and getattr(self, "sparse_top_layer_backward", True)) else None
+        # the caller does not want the prediction scores (trainer.py never reads them): rows that nothing else reads are left out
+        drop = (not infer) and labels is not None and not getattr(self, "return_scores", True)
+        # The valid-first packing needs the per-sequence lengths on the host.  With the prologue on the input stream (async_prologue)
+        # they are there already: the packing is built FIRST and the embedding kernels store their rows in packed order.  With the
+        # prologue on the compute stream the host would wait for the GPU to drain: the embedding kernels are queued first (they keep
+        # the GPU busy while the lengths travel and the host packs the layout), write the caller's order, and one gather packs.
+        rank = pro.rank
+        t.late_split = side is None
+        t.split = None
+        get_split = lambda: self._split_layout(plan, kv_len, pending, infer, drop, rank)
+        if not t.late_split:
+            t.split = get_split()
+            get_split = None
+        t.layout = get_split                                      # (late: _TrunkFn calls it once the embedding kernels are queued)
+        y = _TrunkFn.apply(bert.embeddings.LayerNorm.weight, self, t)
+        split = t.split
+        self._last_trunk = t                                       # (forward() hands it to the MLM head: compact output gradient)
         if self.debug_hidden is not None:
             packed = self.debug_hidden.pop("_layers_packed", [])
             if split is not None:                   # back to the original row order (left-out rows of the drop form read as zeros)
                 pad = getattr(split, "dropped", False)
-                packed = [(torch.cat((t, t.new_zeros((1, t.shape[1])))) if pad else t).index_select(0, split.inv) for t in packed]
-            self.debug_hidden["layers"] = packed
+                packed = [None if q is None else (torch.cat((q, q.new_zeros((1, q.shape[1])))) if pad else q).index_select(0, split.inv) for q in packed]
+            self.debug_hidden["layers"] = [y.detach() if q is None else q for q in packed]
         return y, plan, lens, rows
 
     def _request_lengths(self, plan, kv_len, labels, infer=False, pairs=None):
@@ -1304,9 +1483,10 @@ class MMBertForPretraining(_GpuModelBase):
             raise ValueError("masked_labels must cover text (+ pair) positions of every pass")
         want_rows = torch.is_grad_enabled() and getattr(self, "sparse_mlm_backward", True) and labels.is_cuda
         y, plan, lens, rows = self._encode(passes, labels, want_rows)
+        trunk, self._last_trunk = self._last_trunk, None
         # first = [3B, H]: the [CLS] rows of every sequence; joint_loss = alpha * (mlm_t + mlm_v + mlm_s) / 3 + heads_loss  (:427, :443)
         mlm, logits, first = _MLMHeadFn.apply(y, self.cls.predictions.transform.LayerNorm.weight, self, labels, plan["bounds"], plan["bounds_dev"],
-                                              self.return_scores, rows, plan["first"])
+                                              self.return_scores, rows, plan["first"], trunk)
         joint_loss, ap_loss, label_loss, nce, logits_out, t_rel, v_rel, s_rel = self._run_heads(first, ap_v, ap_s, sentiment, dev, B, mlm=mlm)
         scores = (None, None, None)
         if logits is not None:
@@ -1349,8 +1529,9 @@ class MMBertForPretraining(_GpuModelBase):
         want_rows = torch.is_grad_enabled() and getattr(self, "sparse_mlm_backward", True) and labels.is_cuda
         # the visual padding sits in the MIDDLE of the fused sequence: valid-first packing over the row set, not over a prefix
         y, plan, lens, rows = self._encode(passes, labels, want_rows, rowset=getattr(self, "fused_rowset_packing", True))
+        trunk, self._last_trunk = self._last_trunk, None
         mlm, logits, first = _MLMHeadFn.apply(y, self.cls.predictions.transform.LayerNorm.weight, self, labels, plan["bounds"], plan["bounds_dev"],
-                                              self.return_scores, rows, plan["first"].repeat(3))   # the one [CLS] row in the t / v / s slots
+                                              self.return_scores, rows, plan["first"].repeat(3), trunk)   # the one [CLS] row in the t / v / s slots
         joint_loss, ap_loss, label_loss, nce, logits_out, _t_rel, v_rel, _s_rel = self._run_heads(first, ap_v, ap_s, sentiment, dev, B, mlm=mlm)
         scores = None if logits is None else logits.view(B, lens[0], -1)[:, :, :V]
         if scores is not None and self.scores_dtype != scores.dtype:

@@ -202,25 +202,31 @@ def mlm_mask(ids, p_select: float, seed: int, *, special_ids=(101, 102), mask_id
     return labels
 
 
-def ln_fwd(x, gamma, beta, eps, *, M=None, out=None, in_rows=None, out_rows=None, drop: Drop = None, stats=True):
+def ln_fwd(x, gamma, beta, eps, *, M=None, out=None, in_rows=None, out_rows=None, drop: Drop = None, stats=True, drop_row0=0):
+    """``drop_row0``: row i of this launch draws the dropout mask of row i + drop_row0 of the site (a slice of the site's rows)."""
     lib = _lib.load()
     H = x.shape[1]
     if M is None:
         M = in_rows.numel() if in_rows is not None else x.shape[0]
     if out is None:
         out = torch.empty((M, H), device=x.device, dtype=torch.bfloat16)
-    mean = torch.empty(M, device=x.device, dtype=torch.float32) if stats else None
-    rstd = torch.empty(M, device=x.device, dtype=torch.float32) if stats else None
+    if isinstance(stats, tuple):                             # the caller's (mean, rstd) buffers (slices of larger ones)
+        mean, rstd = stats
+        assert mean.numel() == M and rstd.numel() == M and mean.dtype == torch.float32 and mean.is_contiguous() and rstd.is_contiguous()
+    else:
+        mean = torch.empty(M, device=x.device, dtype=torch.float32) if stats else None
+        rstd = torch.empty(M, device=x.device, dtype=torch.float32) if stats else None
     d = drop or NO_DROP
     _lib.check(lib.mmbert_ln_fwd(_stream(), x.data_ptr(), x.stride(0), _ptr(in_rows), out.data_ptr(), out.stride(0), _ptr(out_rows),
-                                 M, H, gamma.data_ptr(), beta.data_ptr(), float(eps), _ptr(mean), _ptr(rstd), d[0], d[1], d[2]), "mmbert_ln_fwd")
+                                 M, H, gamma.data_ptr(), beta.data_ptr(), float(eps), _ptr(mean), _ptr(rstd), d[0], d[1], d[2], int(drop_row0)), "mmbert_ln_fwd")
     return out, mean, rstd
 
 
 def ln_bwd(dy, x, mean, rstd, gamma, dgamma, dbeta, *, M=None, dx=None, dx2=None, dy_rows=None, x_rows=None, dx_rows=None,
-           post_drop: Drop = None, pre_drop: Drop = None, dbias2=None, drop_rows=None, deferred: "LnDeferred" = None):
+           post_drop: Drop = None, pre_drop: Drop = None, dbias2=None, drop_rows=None, deferred: "LnDeferred" = None, dy_row_limit=0):
     """``deferred``: an LnDeferred collector -- the gamma / beta (/ bias) partial sums of this call stay in a workspace slice of
-    the collector and are folded into the gradients by ITS one reduce launch (``deferred.flush()``) instead of one per call."""
+    the collector and are folded into the gradients by ITS one reduce launch (``deferred.flush()``) instead of one per call.
+    ``dy_row_limit`` (> 0, with ``dy_rows``): mapped dy rows at or past the limit do not exist -- their gradient is zero."""
     lib = _lib.load()
     H = x.shape[1]
     if M is None:
@@ -236,7 +242,7 @@ def ln_bwd(dy, x, mean, rstd, gamma, dgamma, dbeta, *, M=None, dx=None, dx2=None
                                  mean.data_ptr(), rstd.data_ptr(), gamma.data_ptr(), M, H,
                                  dx.data_ptr(), dx.stride(0), _ptr(dx_rows), _ptr(dx2), dx2.stride(0) if dx2 is not None else 0,
                                  _ptr(dgamma), _ptr(dbeta), _ptr(dbias2), po[0], po[1], po[2], pr[0], pr[1], pr[2], ws_ptr, _ptr(drop_rows),
-                                 1 if deferred is not None else 0), "mmbert_ln_bwd")
+                                 1 if deferred is not None else 0, int(dy_row_limit)), "mmbert_ln_bwd")
     return dx
 
 
@@ -498,13 +504,16 @@ class SplitLayout:
         if on_gpu:
             rs_d, rp_d = base.row_tables(device)
             dev_p = torch.empty(n_packed + M, dtype=torch.int64, device=device)
+            dev_p32 = torch.empty(n_packed + M, dtype=torch.int32, device=device)
             _lib.check(_lib.load().mmbert_split_rows(_stream(), rs_d.data_ptr(), rp_d.data_ptr(), self.seq_start.data_ptr(), start_b_dev.data_ptr(),
                                                      self.kv_len.data_ptr(), mode, M, self.rows_a, dev_p.data_ptr(), dev_p.data_ptr() + 8 * n_packed,
-                                                     _ptr(rank)),
+                                                     _ptr(rank), dev_p32.data_ptr(), dev_p32.data_ptr() + 4 * n_packed),
                        "mmbert_split_rows")
         else:
             dev_p = torch.from_numpy(np.concatenate((perm, inv))).to(device)
+            dev_p32 = dev_p.to(torch.int32)
         self.perm, self.inv = dev_p[:n_packed], dev_p[n_packed:]
+        self.perm32, self.inv32 = dev_p32[:n_packed], dev_p32[n_packed:]       # the same maps as int32 row lists (ln_fwd / ln_bwd / gather_rows)
         self.rows_packed = n_packed
         self.base, self.heads, self.tokens, self.lens = base, base.heads, base.tokens, base.lens
         self.seq_len, self.elem_base, self.bias_start, self.bias_len = base.seq_len, base.elem_base, base.bias_start, base.bias_len
