@@ -76,6 +76,9 @@ def main():
     ap.add_argument("--force-dp", action="store_true", help="run the data-parallel path (RCCL process group, DataParallel wrapper, bucketed "
                     "all-reduce hooks, dynamic tile queue) even with ONE process: the N = 1 execution of the code the driver launches at N = 2/4/8")
     ap.add_argument("--bucket-mb", type=float, default=32.0, help="data parallel: smallest gradient slice handed to an all-reduce")
+    ap.add_argument("--dp-wire", choices=["fp32", "bf16"], default="fp32", help="data parallel: dtype on the links (bf16: all-to-all + fp32 "
+                    "accumulation + all-gather instead of the fp32 all-reduce; opt-in, halves the bytes)")
+    ap.add_argument("--no-early-word", action="store_true", help="A/B: the word-embedding table's gradient reduced with the tail (round-2 form)")
     ap.add_argument("--sync-prologue", action="store_true", help="A/B: the step prologue on the compute stream (model.async_prologue = False)")
     ap.add_argument("--scores-fp32", action="store_true", help="return the prediction scores as fp32 (model.scores_dtype = torch.float32)")
     a = ap.parse_args()
@@ -119,7 +122,8 @@ def main():
         model.scores_dtype = torch.float32
     targs = default_args(train_batch_size=a.batch, learning_rate=5e-5)
     opt, sched = build_optimizer(model, targs, num_train_optimization_steps=10 * (a.steps + a.warmup))
-    dp = parallel.DataParallel(model, opt, bucket_mb=a.bucket_mb, force_dynamic_queue=a.force_dp) if (world > 1 or a.force_dp) else None
+    dp = (parallel.DataParallel(model, opt, bucket_mb=a.bucket_mb, force_dynamic_queue=a.force_dp, wire_dtype=torch.bfloat16 if a.dp_wire == "bf16" else None,
+                                early_word_embedding=not a.no_early_word) if (world > 1 or a.force_dp) else None)
     pool = [batch_to(synthetic_batch(a.batch, a.text, a.pair, a.pair, vocab=V, seed=1 + i + 1000 * rank), dev) for i in range(4)]
 
     timing = {"nt": [], "tn": [], "attn_fwd": [], "attn_bwd": []}
@@ -314,7 +318,9 @@ def main():
     }
     if dp is not None:
         res["config"]["dp"] = {"backend": torch.distributed.get_backend(), "forced_single_process": bool(a.force_dp and world == 1),
-                               "gemm_tile_queue": "dynamic, one counter per XCD", "bucket_mb": a.bucket_mb,
+                               "gemm_tile_queue": "dynamic, one counter per XCD", "bucket_mb": a.bucket_mb, "wire_dtype": a.dp_wire,
+                               "word_embedding_table": ("reduced right after the MLM head's backward; lookup rows exchanged in compact form"
+                                                        if dp.early_word else "with the tail"),
                                "all_reduce_calls_per_step": dp.bucketer.calls_per_step if hasattr(dp.bucketer, "calls_per_step") else None}
     if dense_ref is not None:
         res["dense_backward_reference"] = dense_ref

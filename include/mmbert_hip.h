@@ -119,7 +119,8 @@ int mmbert_ln_bwd_reduce(mmbert_stream_t stream, int items, const float* const* 
 
 /* ---- embeddings ----
  * gather: out[i] = word[ids[i]] + type[tts[i]] + pos[i % T]     HF:96-102 via REF:MMBertForPretraining.py:264
- * scatter: the matching scatter-add of the gradient (row 0 of word excluded: padding_idx, HF:58). */
+ * scatter: the matching scatter-add of the gradient (row 0 of word excluded: padding_idx, HF:58); gword may be NULL (position and
+ *          token-type gradients only). */
 int mmbert_embed_gather(mmbert_stream_t stream, const int64_t* ids, const int64_t* tts, const float* word, const float* type,
                         const float* pos, int n, int T, int H, int V, void* out, int ldo);
 int mmbert_embed_scatter(mmbert_stream_t stream, const int64_t* ids, const int64_t* tts, const void* d, int ldd, int n, int T, int H, int V,

@@ -335,7 +335,7 @@ __global__ __launch_bounds__(256) void embed_scatter_kernel(const int64_t* __res
             const long id = ids[i];
             const bool tt = tts ? (tts[i] != 0) : false;
             const bf16x4 v = *(const bf16x4*)(d + (size_t)i * ldd + col);
-            const bool word = id > 0 && id < V;
+            const bool word = gword != nullptr && id > 0 && id < V;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const float f = bf2f(v[r]);

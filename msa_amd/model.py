@@ -513,6 +513,8 @@ class _TrunkFn(torch.autograd.Function):
         npass = len(lens)
         layout = split if split is not None else plan["layout"]
         compact, t.compact = t.compact, None                      # (rows in the caller's order, their gradients): set by the MLM head
+        if top.head_grad_hook is not None:
+            top.head_grad_hook()                                  # every gradient of the heads is final, the tied decoder's included
         dy_rows = None
         if compact is None:
             dy = dy.contiguous()
@@ -552,7 +554,11 @@ class _TrunkFn(torch.autograd.Function):
                            dy_rows=inv32[bounds[k]:bounds[k + 1]], dy_row_limit=limit, **kw)
             else:
                 ops.ln_bwd(dx[bounds[k]:bounds[k + 1]], e0[rows], mean0[rows], rstd0[rows], w["emb_ln_g"], w["g_emb_ln_g"], w["g_emb_ln_b"], **kw)
-        ops.embed_scatter(t.ids, t.tts, de0, T, w["g_word"], w["g_type"], w["g_pos"])
+        if top.defer_embed_rows:
+            ops.embed_scatter(t.ids, t.tts, de0, T, None, w["g_type"], w["g_pos"], vocab=cfg.vocab_size)
+            top._deferred_embed_rows = (t.ids, de0)
+        else:
+            ops.embed_scatter(t.ids, t.tts, de0, T, w["g_word"], w["g_type"], w["g_pos"])
         return None, None, None
 
 
@@ -755,6 +761,10 @@ class _GpuModelBase(nn.Module):
         self._calls = 0
         self._plans = {}
         self.grad_hook = None           # set by parallel.DataParallel: called as layers finish in backward
+        self.head_grad_hook = None      # ... and once when the heads' backward is complete (the trunk's backward starts)
+        # parallel.DataParallel: the embedding lookup's row gradients stay OUT of the word-embedding table's gradient; backward leaves
+        # (ids, rows) in ``_deferred_embed_rows`` for the wrapper's compact exchange (the table itself is reduced early)
+        self.defer_embed_rows = False
         # tests only: a dict here collects, per _encode() call, "emb" (text embeddings of all passes), "x" (encoder input) and
         # "layers" (every encoder layer's output), all [tokens, H] bf16 in the ORIGINAL packed row order (pass, sample, position)
         self.debug_hidden = None

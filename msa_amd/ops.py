@@ -297,12 +297,13 @@ def embed_gather(ids, tts, word, type_, pos, T, out=None):
     return out
 
 
-def embed_scatter(ids, tts, d, T, gword, gtype, gpos):
+def embed_scatter(ids, tts, d, T, gword, gtype, gpos, vocab=None):
+    """``gword`` None: position and token-type gradients only (the word rows are exchanged in compact form: parallel.DataParallel)."""
     lib = _lib.load()
     n = ids.numel()
-    V, H = gword.shape
+    V, H = gword.shape if gword is not None else (int(vocab), d.shape[1])
     _lib.check(lib.mmbert_embed_scatter(_stream(), ids.data_ptr(), _ptr(tts), d.data_ptr(), d.stride(0), n, T, H, V,
-                                        gword.data_ptr(), gtype.data_ptr(), gpos.data_ptr()), "mmbert_embed_scatter")
+                                        _ptr(gword), gtype.data_ptr(), gpos.data_ptr()), "mmbert_embed_scatter")
 
 
 def _pair_rows(T, Pn, ld, seq_len, offset):

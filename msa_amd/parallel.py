@@ -32,10 +32,17 @@ class GradBucketer:
 
     ``boundaries``: ascending element offsets b_0=0 < b_1 < ... < b_n=len(flat); slice k =
     [b_k, b_{k+1}) becomes final when ``ready(k)`` is called (k must be called in order).  Pure
-    torch.distributed: works on CPU tensors with gloo (tests) and on GPU tensors with RCCL."""
+    torch.distributed: works on CPU tensors with gloo (tests) and on GPU tensors with RCCL.
+
+    ``wire_dtype`` (opt-in, e.g. torch.bfloat16): the exchange moves that dtype instead of fp32 -- half the bytes on the links.  Not
+    an all-reduce in the low precision (which would also ACCUMULATE in it): every rank's slice is cast into a staging buffer, an
+    all-to-all hands rank r the r-th chunk of every rank (on xGMI: all seven links at once, no ring), rank r adds the chunks in fp32
+    in rank order, rounds the sum once, and an all-gather returns the sums -- every rank ends up with bit-identical values, each
+    rank's contribution is rounded once on the way in and the sum once on the way out.  Stage two of a bucket is issued as soon as a
+    later ``ready()`` / ``finish()`` finds its stage one complete, so both overlap the rest of backward."""
 
     def __init__(self, flat_grads: torch.Tensor, boundaries: Sequence[int], group=None, bucket_mb: float = 32.0,
-                 skip: Sequence[Tuple[int, int]] = ()):
+                 skip: Sequence[Tuple[int, int]] = (), wire_dtype: Optional[torch.dtype] = None):
         """``skip``: ascending, disjoint element ranges [a, b) that are never exchanged (parameters the reference never
         differentiates: their gradient slots hold zeros on every rank) -- a bucket is cut around them."""
         assert boundaries[0] == 0 and boundaries[-1] == flat_grads.numel() and list(boundaries) == sorted(boundaries)
@@ -43,7 +50,11 @@ class GradBucketer:
         self.min_elems = int(bucket_mb * (1 << 20) / flat_grads.element_size())
         self.skip = [(int(a), int(b)) for a, b in skip if b > a]
         assert all(self.skip[i][1] <= self.skip[i + 1][0] for i in range(len(self.skip) - 1))
+        self.wire_dtype = wire_dtype
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.handles: List = []
+        self.stage1: List = []   # wire mode: (handle, lo, hi, recv buffer, padded chunk) of buckets whose all-to-all is in flight
+        self.stage2: List = []   # wire mode: (handle, lo, hi, gathered sums)
         self.done = 0            # elements already handed to the collective
         self.next_slice = 0
         self.enabled = True
@@ -52,6 +63,7 @@ class GradBucketer:
 
     def reset(self):
         self.handles, self.done, self.next_slice, self.calls, self.elems = [], 0, 0, 0, 0
+        self.stage1, self.stage2 = [], []
 
     def _segments(self, lo: int, hi: int):
         """[lo, hi) minus the skip ranges."""
@@ -64,12 +76,47 @@ class GradBucketer:
         if lo < hi:
             yield lo, hi
 
+    def reduce_range(self, lo: int, hi: int):
+        """Starts the exchange of [lo, hi) (minus the skip ranges) now, whatever the slice bookkeeping says -- for a range that is
+        final out of layout order (DataParallel: the tied decoder's dense gradient, final right after the MLM head's backward)."""
+        if not self.enabled:
+            return
+        for a, b in self._segments(lo, hi):
+            self._start(a, b)
+
+    def _start(self, lo: int, hi: int):
+        self.calls += 1
+        self.elems += hi - lo
+        if self.wire_dtype is None or self.world == 1:
+            self.handles.append(dist.all_reduce(self.flat[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+            return
+        W, n = self.world, hi - lo
+        chunk = (n + W - 1) // W
+        send = torch.zeros(W * chunk, device=self.flat.device, dtype=self.wire_dtype)
+        send[:n].copy_(self.flat[lo:hi])                          # one cast pass over the slice
+        recv = torch.empty_like(send)
+        h = dist.all_to_all_single(recv, send, group=self.group, async_op=True)
+        self.stage1.append((h, lo, hi, recv, chunk, send))
+
+    def _advance(self, block: bool):
+        """Stage two (fp32 sum of the received chunks, all-gather of the rounded sums) of every bucket whose stage one is complete, in
+        issue order; ``block``: wait for stage one instead of polling it."""
+        while self.stage1:
+            h, lo, hi, recv, chunk, send = self.stage1[0]
+            if not block and not h.is_completed():
+                break
+            h.wait()
+            self.stage1.pop(0)
+            W = self.world
+            total = recv.view(W, chunk).to(torch.float32).sum(0).to(self.wire_dtype)      # rank order, fp32: the same bits on every run
+            out = torch.empty(W * chunk, device=recv.device, dtype=self.wire_dtype)
+            h2 = dist.all_gather_into_tensor(out, total, group=self.group, async_op=True)
+            self.stage2.append((h2, lo, hi, out))
+
     def _issue(self, end: int):
         if end > self.done and self.enabled:
             for lo, hi in self._segments(self.done, end):
-                self.handles.append(dist.all_reduce(self.flat[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
-                self.calls += 1
-                self.elems += hi - lo
+                self._start(lo, hi)
         self.done = end
 
     def ready(self, k: int):
@@ -78,21 +125,38 @@ class GradBucketer:
         end = self.bounds[k + 1]
         if end - self.done >= self.min_elems:
             self._issue(end)
+        if self.stage1:
+            self._advance(block=False)
 
-    def finish(self):
-        """Reduce whatever is left and wait for every outstanding collective."""
-        self._issue(self.bounds[-1])
+    def finish(self, upto: Optional[int] = None):
+        """Reduce whatever is left (up to element ``upto``: default everything) and wait for every outstanding collective."""
+        self._issue(self.bounds[-1] if upto is None else upto)
+        self._advance(block=True)
         for h in self.handles:
             h.wait()
+        for h2, lo, hi, out in self.stage2:
+            h2.wait()
+            self.flat[lo:hi].copy_(out[:hi - lo])                 # back to fp32 in place
         self.calls_per_step = self.calls
         self.reset()
 
 
 class DataParallel:
     """Wraps an ``MMBertForPretraining``: broadcast of the initial weights, bucketed gradient
-    all-reduce overlapped with backward, gradient averaging folded into the optimizer."""
+    all-reduce overlapped with backward, gradient averaging folded into the optimizer.
 
-    def __init__(self, model, optimizer=None, group=None, bucket_mb: float = 32.0, force_dynamic_queue: bool = False):
+    The tail (``early_word_embedding``, default on).  The flat layout ends with the word-embedding table (94 MB of the 440 MB at the
+    headline size), whose gradient has two parts: the tied MLM decoder's DENSE gradient, final right after the MLM head's backward --
+    the first thing backward does -- and the embedding lookup's <= passes x B x T scattered rows, final only when backward ends.
+    Reduced as one slice it could not start before backward was over (the exposed tail of an 8-GPU step).  So: the table's slice
+    is all-reduced as soon as the MLM head's backward is done (``model.head_grad_hook``), the lookup keeps its rows OUT of the table
+    (``model.defer_embed_rows``: the trunk hands over ids and row gradients), and ``finish_backward`` exchanges them in compact
+    form -- all-gather of the ids, the same sorted union on every rank, the local rows summed into a [union, H] block, ONE
+    all-reduce of that block (a few MB), and a scatter of the reduced rows into the table (unique rows: deterministic, every
+    rank bit-identical)."""
+
+    def __init__(self, model, optimizer=None, group=None, bucket_mb: float = 32.0, force_dynamic_queue: bool = False,
+                 wire_dtype: Optional[torch.dtype] = None, early_word_embedding: bool = True):
         if not dist.is_initialized():
             raise RuntimeError("torch.distributed is not initialised")
         self.model, self.group = model, group
@@ -119,15 +183,30 @@ class DataParallel:
         edges = (fl[1:] != fl[:-1]).nonzero()[0] + 1
         cuts = [0, *[int(e) for e in edges], len(fl)]
         skip = [(256 * a, 256 * b) for a, b in zip(cuts[:-1], cuts[1:]) if fl[a] == 1]
-        self.bucketer = GradBucketer(flat.grads, bounds, group, bucket_mb, skip=skip)
+        self.bucketer = GradBucketer(flat.grads, bounds, group, bucket_mb, skip=skip, wire_dtype=wire_dtype)
         self._L = L
         model.grad_hook = self._on_layer_done
+        # the word-embedding table: the last tensor of the layout (flat.py)
+        wname = "bert.embeddings.word_embeddings.weight"
+        self._word = (flat.offset[wname], flat.offset[wname] + flat.vpad * model.config.hidden_size)
+        self.early_word = bool(early_word_embedding) and self._word[1] <= flat.total and flat.order[-1] == wname
+        self._word_started = False
+        if self.early_word:
+            model.head_grad_hook = self._on_heads_done
+            model.defer_embed_rows = True
         if optimizer is not None:
             optimizer.grad_scale = 1.0 / self.world
         self.optimizer = optimizer
 
     def _on_layer_done(self, i: int):
         self.bucketer.ready(self._L - 1 - i)
+
+    def _on_heads_done(self):
+        """The MLM head's backward is complete: the tied decoder's dense gradient of the word-embedding table is final (the lookup's
+        rows stay out of the table: model.defer_embed_rows)."""
+        if self.bucketer.enabled and not self._word_started:
+            self.bucketer.reduce_range(*self._word)
+            self._word_started = True
 
     @contextlib.contextmanager
     def no_sync(self):
@@ -138,13 +217,66 @@ class DataParallel:
         finally:
             self.bucketer.enabled = True
             self.bucketer.reset()
+            self._fold_rows_locally()
+
+    def _fold_rows_locally(self):
+        """A micro-step without exchange: the lookup's rows go into the local table like any other gradient."""
+        pend = self.model.__dict__.pop("_deferred_embed_rows", None)
+        if pend is not None:
+            ids, rows = pend
+            _scatter_rows(self.model._w["g_word"], ids, rows)
 
     def finish_backward(self):
         """Call after ``loss.backward()`` and before ``optimizer.step()``."""
-        self.bucketer.finish()
+        bk = self.bucketer
+        pend = self.model.__dict__.pop("_deferred_embed_rows", None)
+        started, self._word_started = self._word_started, False
+        if not (self.early_word and started):
+            if pend is not None:                                   # (no early exchange happened: rows into the table, then the usual tail)
+                _scatter_rows(self.model._w["g_word"], *pend)
+            bk.finish()
+            return
+        # compact exchange of the lookup's rows, while the table's own all-reduce (started long ago) and the tail are in flight
+        block = None
+        if pend is not None:
+            ids, rows = pend
+            block = exchange_rows(ids, rows, self.model.config.vocab_size, self.group)
+        bk.finish(upto=self._word[0])                               # the tail in front of the table + every outstanding collective
+        bk.done = 0
+        if block is not None:
+            union, summed = block
+            self.model._w["g_word"].index_add_(0, union, summed)    # unique rows: one add per element, the same bits on every rank
 
     def __call__(self, *a, **k):
         return self.model(*a, **k)
+
+
+def _scatter_rows(table: torch.Tensor, ids: torch.Tensor, rows: torch.Tensor):
+    """table[ids[i]] += rows[i] for ids in (0, V) -- row 0 is the padding row of the lookup (HF:58, no gradient)."""
+    keep = (ids > 0) & (ids < table.shape[0])
+    table.index_add_(0, ids.clamp(0, table.shape[0] - 1), rows.to(table.dtype) * keep[:, None].to(table.dtype))
+
+
+def exchange_rows(ids: torch.Tensor, rows: torch.Tensor, vocab: int, group=None):
+    """Sum over ranks of sparse row gradients: every rank holds n rows ``rows[i]`` for table row ``ids[i]`` (duplicates allowed, ids
+    outside (0, vocab) carry no gradient).  all-gather of the ids -> the same sorted union on every rank -> local rows summed into a
+    [union, H] fp32 block -> ONE all-reduce of the block.  Returns (union ids int64, summed rows fp32): what a dense all-reduce of
+    the scattered table would hold in those rows (tests/test_host_cpu.py: equal to it)."""
+    W = dist.get_world_size(group)
+    ids = ids.reshape(-1).long()
+    n = ids.numel()
+    allids = torch.empty(W * n, dtype=torch.long, device=ids.device)
+    dist.all_gather_into_tensor(allids, ids.contiguous(), group=group)
+    valid = (allids > 0) & (allids < vocab)
+    union = torch.unique(allids[valid])                            # sorted: every rank computes the same list
+    block = torch.zeros((union.numel(), rows.shape[1]), device=rows.device, dtype=torch.float32)
+    if union.numel():
+        mine = (ids > 0) & (ids < vocab)
+        pos = torch.searchsorted(union, ids.clamp(0, vocab - 1))
+        pos = pos.clamp(max=union.numel() - 1)
+        block.index_add_(0, pos, rows.to(torch.float32) * mine[:, None].to(torch.float32))
+        dist.all_reduce(block, op=dist.ReduceOp.SUM, group=group)
+    return union, block
 
 
 def init_from_env(backend: Optional[str] = None, force: bool = False) -> Tuple[int, int, int]:

@@ -176,6 +176,69 @@ def test_grad_bucketer_world2_gloo():
     assert res["calls"] == 2, res          # slices merged into >=300-element buckets: [0,350) and [350,900); tail in finish()
 
 
+def _exchange_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from msa_amd.parallel import exchange_rows, _scatter_rows
+    res = {}
+    # ---- compact exchange of embedding-lookup rows == dense all-reduce of the scattered table
+    V, H, n = 97, 16, 40
+    g = torch.Generator().manual_seed(100 + rank)
+    ids = torch.randint(0, V + 6, (n,), generator=g)                       # duplicates, the padding row 0 and ids past the vocabulary
+    ids[:3] = torch.tensor([0, 5, 5])
+    rows = torch.randn(n, H, generator=g)
+    dense = torch.zeros(V, H)
+    _scatter_rows(dense, ids, rows)
+    dist.all_reduce(dense)
+    union, block = exchange_rows(ids, rows, V)
+    table = torch.zeros(V, H)
+    table.index_add_(0, union, block)
+    res["rows_ok"] = bool(torch.allclose(table, dense, rtol=1e-6, atol=1e-6)) and bool((union[1:] > union[:-1]).all()) and int(union.min()) > 0 and int(union.max()) < V
+    res["rows_touch"] = int(union.numel())
+    # ---- the wire-dtype exchange: same sums as an fp32 all-reduce up to ONE rounding of each contribution and one of the sum;
+    # bit-identical on every rank; ranges out of layout order (reduce_range) and skip ranges honoured
+    nel = 1003
+    base = torch.linspace(-3.0, 3.0, nel)
+    flat = (base * (rank + 1) + 0.01 * rank).clone()
+    want = sum(base * (r + 1) + 0.01 * r for r in range(world))
+    bounds = [0, 100, 350, 600, 900, nel]
+    bk = GradBucketer(flat, bounds, bucket_mb=300 * 4 / (1 << 20), skip=[(120, 200)], wire_dtype=torch.bfloat16)
+    bk.reduce_range(900, nel)                                              # the "table" first, as DataParallel does
+    for k in range(4):
+        bk.ready(k)
+    bk.finish(upto=900)
+    keep = torch.ones(nel, dtype=torch.bool)
+    keep[120:200] = False
+    err = ((flat - want).abs() / (want.abs() + 1e-3))[keep].max()
+    res["wire_err"] = float(err)
+    res["wire_skip_ok"] = bool(torch.equal(flat[~keep], (base * (rank + 1) + 0.01 * rank)[~keep]))
+    other = [torch.empty_like(flat) for _ in range(world)]
+    dist.all_gather(other, flat)
+    res["wire_identical"] = all(bool(torch.equal(o[keep], other[0][keep])) for o in other)      # (the skipped range is never exchanged)
+    if rank == 0:
+        q.put(res)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_compact_row_exchange_and_wire_dtype_world2_gloo():
+    """parallel.exchange_rows (the embedding lookup's rows in compact form: all-gather of ids, sorted union, ONE all-reduce of the
+    [union, H] block) equals the dense all-reduce of the scattered table; GradBucketer(wire_dtype=bfloat16) gives every rank the
+    same bits, within bf16 rounding of the fp32 sums, honours skip ranges and out-of-order ranges (DESIGN S6)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29800 + os.getpid() % 150
+    procs = [ctx.Process(target=_exchange_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = q.get(timeout=120)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert res["rows_ok"] and res["rows_touch"] > 20, res
+    assert res["wire_err"] < 2.0 ** -7 and res["wire_skip_ok"] and res["wire_identical"], res
+
+
 def test_score_functions_match_their_definitions():
     """REF:trainer.py:201-228 restated: accuracy / MAE / support-weighted F1 (checked against scikit-learn when present)."""
     rng = np.random.default_rng(0)
