@@ -765,6 +765,7 @@ class _GpuModelBase(nn.Module):
         # parallel.DataParallel: the embedding lookup's row gradients stay OUT of the word-embedding table's gradient; backward leaves
         # (ids, rows) in ``_deferred_embed_rows`` for the wrapper's compact exchange (the table itself is reduced early)
         self.defer_embed_rows = False
+        self.embed_ids_hook = None      # ... called with the step's token ids at the start of a differentiated forward pass
         # tests only: a dict here collects, per _encode() call, "emb" (text embeddings of all passes), "x" (encoder input) and
         # "layers" (every encoder layer's output), all [tokens, H] bf16 in the ORIGINAL packed row order (pass, sample, position)
         self.debug_hidden = None
@@ -1008,6 +1009,12 @@ class _GpuModelBase(nn.Module):
             elif labels is not None and torch.is_grad_enabled() and getattr(self, "skip_padded_backward", True):
                 pending = (host[:nseq], None, ev)                     # the prologue's valid[]: unmasked length, extended to the last label
         # ---- embeddings + encoder: one autograd node (_TrunkFn)
+        if self.embed_ids_hook is not None and torch.is_grad_enabled():
+            # data parallel: the ranks agree on the union of touched embedding rows now, on the input stream when the inputs are
+            # complete (async_prologue) -- else on the current stream, where the prologue's host wait happens anyway
+            with (torch.cuda.stream(side) if side is not None else contextlib.nullcontext()):
+                early_ids = torch.cat([p["ids"].reshape(-1).long() for p in passes])
+            self.embed_ids_hook(early_ids, side)
         ids = torch.cat([p["ids"].reshape(-1).long() for p in passes])
         tts = torch.cat([(p["tt"].reshape(-1).long() if p.get("tt") is not None else torch.zeros(B * T, dtype=torch.long, device=dev)) for p in passes])
         p_emb = cfg.hidden_dropout_prob if self.training else 0.0

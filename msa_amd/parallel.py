@@ -191,15 +191,33 @@ class DataParallel:
         self._word = (flat.offset[wname], flat.offset[wname] + flat.vpad * model.config.hidden_size)
         self.early_word = bool(early_word_embedding) and self._word[1] <= flat.total and flat.order[-1] == wname
         self._word_started = False
+        self._union = None
         if self.early_word:
             model.head_grad_hook = self._on_heads_done
             model.defer_embed_rows = True
+            model.embed_ids_hook = self._on_ids
         if optimizer is not None:
             optimizer.grad_scale = 1.0 / self.world
         self.optimizer = optimizer
 
     def _on_layer_done(self, i: int):
         self.bucketer.ready(self._L - 1 - i)
+
+    def _on_ids(self, ids: torch.Tensor, stream=None):
+        """Start of a forward pass that will be differentiated: the token ids of the step (inputs) -> the union of touched table rows
+        over all ranks, long before backward needs it (gather_union reads a size back: here the host is ahead of the GPU)."""
+        if not self.bucketer.enabled:
+            self._union = None
+            return
+        if stream is not None:
+            with torch.cuda.stream(stream):
+                self._union = gather_union(ids, self.model.config.vocab_size, self.group)
+            self._union.record_stream(torch.cuda.current_stream())
+            self._union_event = torch.cuda.Event()
+            self._union_event.record(stream)
+        else:
+            self._union = gather_union(ids, self.model.config.vocab_size, self.group)
+            self._union_event = None
 
     def _on_heads_done(self):
         """The MLM head's backward is complete: the tied decoder's dense gradient of the word-embedding table is final (the lookup's
@@ -240,7 +258,10 @@ class DataParallel:
         block = None
         if pend is not None:
             ids, rows = pend
-            block = exchange_rows(ids, rows, self.model.config.vocab_size, self.group)
+            union, self._union = self._union, None
+            if union is not None and getattr(self, "_union_event", None) is not None:
+                torch.cuda.current_stream().wait_event(self._union_event)
+            block = exchange_rows(ids, rows, self.model.config.vocab_size, self.group, union=union)
         bk.finish(upto=self._word[0])                               # the tail in front of the table + every outstanding collective
         bk.done = 0
         if block is not None:
@@ -257,23 +278,31 @@ def _scatter_rows(table: torch.Tensor, ids: torch.Tensor, rows: torch.Tensor):
     table.index_add_(0, ids.clamp(0, table.shape[0] - 1), rows.to(table.dtype) * keep[:, None].to(table.dtype))
 
 
-def exchange_rows(ids: torch.Tensor, rows: torch.Tensor, vocab: int, group=None):
-    """Sum over ranks of sparse row gradients: every rank holds n rows ``rows[i]`` for table row ``ids[i]`` (duplicates allowed, ids
-    outside (0, vocab) carry no gradient).  all-gather of the ids -> the same sorted union on every rank -> local rows summed into a
-    [union, H] fp32 block -> ONE all-reduce of the block.  Returns (union ids int64, summed rows fp32): what a dense all-reduce of
-    the scattered table would hold in those rows (tests/test_host_cpu.py: equal to it)."""
+def gather_union(ids: torch.Tensor, vocab: int, group=None) -> torch.Tensor:
+    """The sorted union over all ranks of the table rows ``ids`` touches (ids outside (0, vocab) dropped): all-gather + unique, the
+    same list on every rank.  ``torch.unique`` reads its output size back to the host, so call this where the host is AHEAD of the
+    GPU anyway -- the ids are inputs of the step: DataParallel does it on the input stream at the start of forward, not at the
+    end of backward where it would drain the queue."""
     W = dist.get_world_size(group)
+    ids = ids.reshape(-1).long().contiguous()
+    allids = torch.empty(W * ids.numel(), dtype=torch.long, device=ids.device)
+    dist.all_gather_into_tensor(allids, ids, group=group)
+    return torch.unique(allids[(allids > 0) & (allids < vocab)])
+
+
+def exchange_rows(ids: torch.Tensor, rows: torch.Tensor, vocab: int, group=None, union: Optional[torch.Tensor] = None):
+    """Sum over ranks of sparse row gradients: every rank holds n rows ``rows[i]`` for table row ``ids[i]`` (duplicates allowed, ids
+    outside (0, vocab) carry no gradient).  The same sorted union of touched rows on every rank (``union``, or gather_union() here)
+    -> local rows summed into a [union, H] fp32 block -> ONE all-reduce of the block.  Returns (union ids int64, summed rows fp32):
+    what a dense all-reduce of the scattered table would hold in those rows (tests/test_host_cpu.py: equal to it).  With ``union``
+    given nothing here reads anything back to the host."""
     ids = ids.reshape(-1).long()
-    n = ids.numel()
-    allids = torch.empty(W * n, dtype=torch.long, device=ids.device)
-    dist.all_gather_into_tensor(allids, ids.contiguous(), group=group)
-    valid = (allids > 0) & (allids < vocab)
-    union = torch.unique(allids[valid])                            # sorted: every rank computes the same list
+    if union is None:
+        union = gather_union(ids, vocab, group)
     block = torch.zeros((union.numel(), rows.shape[1]), device=rows.device, dtype=torch.float32)
     if union.numel():
         mine = (ids > 0) & (ids < vocab)
-        pos = torch.searchsorted(union, ids.clamp(0, vocab - 1))
-        pos = pos.clamp(max=union.numel() - 1)
+        pos = torch.searchsorted(union, ids.clamp(0, vocab - 1)).clamp(max=union.numel() - 1)
         block.index_add_(0, pos, rows.to(torch.float32) * mine[:, None].to(torch.float32))
         dist.all_reduce(block, op=dist.ReduceOp.SUM, group=group)
     return union, block
