@@ -192,6 +192,9 @@ class DataParallel:
         self.early_word = bool(early_word_embedding) and self._word[1] <= flat.total and flat.order[-1] == wname
         self._word_started = False
         self._union = None
+        # the id exchange of step k + 1 must not queue behind the gradient collectives of step k (one communicator runs its
+        # collectives in order): it gets a communicator of its own
+        self._ids_group = dist.new_group(ranks=dist.get_process_group_ranks(group) if group is not None else None) if self.early_word else None
         if self.early_word:
             model.head_grad_hook = self._on_heads_done
             model.defer_embed_rows = True
@@ -211,12 +214,12 @@ class DataParallel:
             return
         if stream is not None:
             with torch.cuda.stream(stream):
-                self._union = gather_union(ids, self.model.config.vocab_size, self.group)
+                self._union = gather_union(ids, self.model.config.vocab_size, self._ids_group)
             self._union.record_stream(torch.cuda.current_stream())
             self._union_event = torch.cuda.Event()
             self._union_event.record(stream)
         else:
-            self._union = gather_union(ids, self.model.config.vocab_size, self.group)
+            self._union = gather_union(ids, self.model.config.vocab_size, self._ids_group)
             self._union_event = None
 
     def _on_heads_done(self):
