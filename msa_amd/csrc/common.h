@@ -69,7 +69,10 @@ __host__ __device__ __forceinline__ uint32_t mmb_pair_mix(uint32_t x) {
 #ifdef MMB_AB_FREE_HASH          // timing experiment only (tools/ab_attn.py): what the attention kernels would gain from a free hash
     return x;
 #endif
-    x ^= x >> 15; x *= 0x2C1B3C6Du; x ^= x >> 16;
+    // both folds shift by 16: hipcc emits each as ONE v_xor_b32_sdwa (src1_sel:WORD_1) -- round 2's first fold (>> 15) was a shift
+    // plus an xor, one VALU instruction more per element pair in every dropout site (round 3: attention forward 330 -> 314 VALU
+    // instructions per 64-key tile and wave)
+    x ^= x >> 16; x *= 0x2C1B3C6Du; x ^= x >> 16;
     return x;
 }
 __host__ __device__ __forceinline__ uint32_t mmb_pair_bits(uint32_t stream, uint32_t pair_idx) {

@@ -342,6 +342,13 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(const GemmNT p) {
         for (int i = 0; i < MI; ++i) af[i] = *(const bf16x8*)(a_rd + slot * 32768 + i * 1024);
     };
     auto mma = [&](const bf16x8 (&af)[MI], const bf16x8 (&bfr)[4]) {
+#ifdef MMB_EXP_NOMFMA
+#pragma unroll
+        for (int i = 0; i < MI; ++i) asm volatile("" :: "v"(af[i]));   // (ablation: no MFMAs; the fragments stay live)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) asm volatile("" :: "v"(bfr[j]));
+        return;
+#endif
 #pragma unroll
         for (int i = 0; i < MI; ++i)
 #pragma unroll
@@ -486,6 +493,17 @@ __device__ __forceinline__ void lds_read16f(f32x4& dst, uint32_t lds_addr) {
 //              of stage s+1 (phase a of step s+1, either group) has passed a barrier that pairs with or follows it.
 //         WAR: stage s+3 goes into the slot of stage s-1, whose last reads (phase b of step s-1) completed before their
 //              MFMAs, i.e. before that phase's second barrier in BOTH groups; phase b of step s lies behind it for both.
+// timing-only ablations of the K step (stamped builds only, tools/stamp_gemm.py STAMP_VARIANT=...): outputs wrong by construction
+#ifdef MMB_EXP_ALOADS
+#define NTP_ALOADS MMB_EXP_ALOADS
+#else
+#define NTP_ALOADS 2
+#endif
+#ifdef MMB_EXP_NOBLOADS
+#define NTP_BLOADS 0
+#else
+#define NTP_BLOADS 1
+#endif
 template <int EPI, int MI, bool STAG>
 __global__ __launch_bounds__(512, 2) void gemm_ntp_kernel(const GemmNT p) {
 #if __HIP_DEVICE_COMPILE__   // the host pass only needs the launch stub (the body uses device-only builtins)
@@ -544,10 +562,17 @@ __global__ __launch_bounds__(512, 2) void gemm_ntp_kernel(const GemmNT p) {
         char* base = smem + slot * 32768 + wave * 2048;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, LPTR(base + i * 1024), 16, o.a[i], kb, 0, 0);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, LPTR(base + 16384 + i * 1024), 16, o.b[i], kb, 0, 0);
+            // timing-only builds (round 3, -DMMB_EXP_ALOADS=1 / 0): every wave issues ONE of its two A-row loads per stage (24 LDS-DMA
+            // instructions per K step and CU instead of 32), or none (16): does the K step follow the instruction count?  Compile-time:
+            // a run-time switch around the loads made hipcc drain vmcnt at the joins (the K loop doubled)
+            if (i < NTP_ALOADS)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, LPTR(base + i * 1024), 16, o.a[i], kb, 0, 0);
+            if (NTP_BLOADS)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, LPTR(base + 16384 + i * 1024), 16, o.b[i], kb, 0, 0);
         }
     };
+    // s_waitcnt vmcnt(k stages x loads per stage and wave + e): 4 loads per stage in the product build
+#define NTP_WAIT(K_, E_, LG_) __builtin_amdgcn_s_waitcnt(mmb_waitcnt((2 * NTP_BLOADS + NTP_ALOADS) * (K_) + (E_), LG_));
 
     const int fr = lane & 15, fq = lane >> 4;
     const int lane_off = fr * 64 + ((fq ^ ((GT >> (2 * ((fr >> 2) & 3))) & 3)) << 4);
@@ -566,6 +591,10 @@ __global__ __launch_bounds__(512, 2) void gemm_ntp_kernel(const GemmNT p) {
     lds_cptr a_rd_hi = a_rd + 65536, b_rd_hi = b_rd + 65536;
     asm volatile("" : "+v"(a_rd_hi), "+v"(b_rd_hi));
     auto load_frags = [&](int slot, bf16x8 (&af)[MI], bf16x8 (&bfr)[4]) {
+#ifdef MMB_EXP_NOFRAGS
+        asm volatile("" : "+v"(af[0]), "+v"(bfr[0]));          // (ablation: no LDS fragment reads)
+        return;
+#endif
         const lds_cptr ab = slot < 2 ? a_rd : a_rd_hi;
         const lds_cptr bb = slot < 2 ? b_rd : b_rd_hi;
         const int so = (slot & 1) * 32768;
@@ -576,6 +605,13 @@ __global__ __launch_bounds__(512, 2) void gemm_ntp_kernel(const GemmNT p) {
     };
     f32x4 acc[MI][4];
     auto mma = [&](const bf16x8 (&af)[MI], const bf16x8 (&bfr)[4]) {
+#ifdef MMB_EXP_NOMFMA
+#pragma unroll
+        for (int i = 0; i < MI; ++i) asm volatile("" :: "v"(af[i]));   // (ablation: no MFMAs; the fragments stay live)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) asm volatile("" :: "v"(bfr[j]));
+        return;
+#endif
 #pragma unroll
         for (int i = 0; i < MI; ++i)
 #pragma unroll
@@ -631,8 +667,8 @@ __global__ __launch_bounds__(512, 2) void gemm_ntp_kernel(const GemmNT p) {
 
 #define NTP_STEP(SLOT, CUR_A, CUR_B, NXT_A, NXT_B, MMA, WEARLY, LOADNEXT, SRC, KB)        \
     {                                                                                     \
-        if (WEARLY) __builtin_amdgcn_s_waitcnt(mmb_waitcnt(8 + EST, 0));                  \
-        else __builtin_amdgcn_s_waitcnt(mmb_waitcnt(8, 0));                               \
+        if (WEARLY) NTP_WAIT(2, EST, 0)                                                   \
+        else NTP_WAIT(2, 0, 0)                                                            \
         __builtin_amdgcn_s_barrier();                                                     \
         issue(SLOT, SRC, KB);                                                             \
         if (LOADNEXT) load_frags((SLOT + 1) & 3, NXT_A, NXT_B);                           \
@@ -737,8 +773,8 @@ __global__ __launch_bounds__(512, 2) void gemm_ntp_kernel(const GemmNT p) {
             NT3_STEP(3, false, false, nxt, 128)
         } else {
             MMB_STAMP(sa)
-            if (early) __builtin_amdgcn_s_waitcnt(mmb_waitcnt(12 + EST, 0));
-            else __builtin_amdgcn_s_waitcnt(mmb_waitcnt(12, 0));
+            if (early) NTP_WAIT(3, EST, 0)
+            else NTP_WAIT(3, 0, 0)
             __builtin_amdgcn_s_barrier();
             MMB_STAMP(sb)
             load_frags(0, a0, b0);
@@ -907,6 +943,7 @@ __global__ __launch_bounds__(512, 2) void gemm_ntp_kernel(const GemmNT p) {
     }
 #undef NTP_STEP
 #undef NT3_STEP
+#undef NTP_WAIT
 #undef NTP_BOFF
     if constexpr (STAG) { if (wr == 0) __builtin_amdgcn_s_barrier(); }   // balances the stagger barrier of the other group
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // the dead tail stages

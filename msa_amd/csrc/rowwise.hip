@@ -961,11 +961,13 @@ int mmbert_ln_fwd(hipStream_t stream, const void* x, int ldx, const int* in_rows
                   uint32_t dstream, uint32_t dthr, float dscale, int drop_row0) {
     if (M <= 0) return 0;
     if (H > LN_MAXV * 256 || (H & 3) || (ldx & 3) || (ldy & 3)) return -1;
-    static const int rows_env = getenv("MMBERT_LN_ROWS") ? atoi(getenv("MMBERT_LN_ROWS")) : 0;      // A/B switch: rows per wave
+    const int rows_env = getenv("MMBERT_LN_ROWS") ? atoi(getenv("MMBERT_LN_ROWS")) : 0;      // A/B switch: rows per wave (read per call)
     // rows per wave, measured at 18 400 x 768 (stand-alone, same box): 1 / 2 / 4 -> 18.3 / 14.9 / 20.9 us
     const int R = rows_env ? rows_env : (M >= 8192 ? 2 : 1);
     const int NV = (H + 255) / 256;
-#define LN_FWD_LAUNCH(NVV, RR) hipLaunchKernelGGL((ln_fwd_kernel<NVV, RR>), dim3(grid_for(M, 4 * RR)), dim3(256), 0, stream, (const bf16_t*)x, ldx, in_rows, \
+    const char* cap_s = getenv("MMBERT_LN_FWD_BLOCKS");                                              // A/B switch, read per call
+    const int cap = cap_s ? atoi(cap_s) : 2048;
+#define LN_FWD_LAUNCH(NVV, RR) hipLaunchKernelGGL((ln_fwd_kernel<NVV, RR>), dim3(grid_for(M, 4 * RR, cap)), dim3(256), 0, stream, (const bf16_t*)x, ldx, in_rows, \
                                                   (bf16_t*)y, ldy, out_rows, M, H, gamma, beta, eps, mean, rstd, dstream, dthr, dscale, drop_row0)
     if (R >= 2) { if (NV == 1) LN_FWD_LAUNCH(1, 2); else if (NV == 2) LN_FWD_LAUNCH(2, 2); else if (NV == 3) LN_FWD_LAUNCH(3, 2); else LN_FWD_LAUNCH(4, 2); }
     else { if (NV == 1) LN_FWD_LAUNCH(1, 1); else if (NV == 2) LN_FWD_LAUNCH(2, 1); else if (NV == 3) LN_FWD_LAUNCH(3, 1); else LN_FWD_LAUNCH(4, 1); }

@@ -13,15 +13,20 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 OUT = os.path.join(ROOT, "tools", "_stamp")
-LIB = os.path.join(OUT, "libmmbert_hip_stamps.so")
+VARIANT = os.environ.get("STAMP_VARIANT", "")            # e.g. "aloads1": -DMMB_EXP_ALOADS=1 (timing-only builds of round 3)
+LIB = os.path.join(OUT, f"libmmbert_hip_stamps{('_' + VARIANT) if VARIANT else ''}.so")
+EXTRA = {"": [], "aloads1": ["-DMMB_EXP_ALOADS=1"], "aloads0": ["-DMMB_EXP_ALOADS=0"], "noloads": ["-DMMB_EXP_ALOADS=0", "-DMMB_EXP_NOBLOADS"],
+         "nomfma": ["-DMMB_EXP_NOMFMA"], "nofrags": ["-DMMB_EXP_NOFRAGS"], "nofrags_noloads": ["-DMMB_EXP_NOFRAGS", "-DMMB_EXP_ALOADS=0", "-DMMB_EXP_NOBLOADS"],
+         "nomfma_noloads": ["-DMMB_EXP_NOMFMA", "-DMMB_EXP_ALOADS=0", "-DMMB_EXP_NOBLOADS"],
+         "onlymfma": ["-DMMB_EXP_NOFRAGS", "-DMMB_EXP_ALOADS=0", "-DMMB_EXP_NOBLOADS"]}[VARIANT]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffast-math", "-fno-finite-math-only"]
 
 if "--build" in sys.argv:
     os.makedirs(OUT, exist_ok=True)
     objs = []
     for f in ("gemm", "attention", "rowwise", "heads"):
-        o = os.path.join(OUT, f + ".o")
-        subprocess.check_call(["/opt/rocm/bin/hipcc", *FLAGS, "-DMMB_STAMPS", "-c", os.path.join(ROOT, "msa_amd", "csrc", f + ".hip"), "-o", o])
+        o = os.path.join(OUT, f + VARIANT + ".o")
+        subprocess.check_call(["/opt/rocm/bin/hipcc", *FLAGS, "-DMMB_STAMPS", *EXTRA, "-c", os.path.join(ROOT, "msa_amd", "csrc", f + ".hip"), "-o", o])
         objs.append(o)
     subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs])
     print("built", LIB)
