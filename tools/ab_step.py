@@ -29,7 +29,21 @@ pool = [batch_to(synthetic_batch(16, 50, 500, 500, seed=1 + i), dev) for i in ra
 all_keys = {k for _, env in variants for k in env}
 
 
+_hi = None
+
+
 def step(i):
+    global _hi
+    if os.environ.get("AB_HIGH_PRIO_MAIN") == "1":          # the whole step on a high-priority stream (side streams stay at the default = lower)
+        if _hi is None:
+            _hi = torch.cuda.Stream(priority=-1)
+        _hi.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(_hi):
+            out, _ = model(**pool[i % 4])
+            out[0].mean().backward()
+            opt.step(); sched.step(); opt.zero_grad()
+        torch.cuda.current_stream().wait_stream(_hi)
+        return
     out, _ = model(**pool[i % 4])
     out[0].mean().backward()
     opt.step(); sched.step(); opt.zero_grad()
