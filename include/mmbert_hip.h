@@ -204,6 +204,12 @@ int mmbert_prologue(mmbert_stream_t stream, int nseg, const void* const* seg_ptr
                     int npass, const int* pass_len, int B, const int64_t* labels, int vocab,
                     float* key_bias, int* kv_len, int* valid, int* seq_cnt, int* idx, int* words, int* rank, float* key_bias_perm);
 
+/* out[dst_offset[k] + i] = src[k][i] (or fill[k] where src[k] is NULL), i < count[k], for up to 12 int64 segments in ONE launch: the
+ * token ids / token types / MLM labels of a step's passes packed into the order of the token matrix (REF:trainer.py:49-64 hands
+ * them over as separate tensors per pass). */
+int mmbert_pack_i64(mmbert_stream_t stream, int nseg, const int64_t* const* src, const long long* dst_offset, const long long* count,
+                    const long long* fill, int64_t* out);
+
 /* idx[0..count) = the rows with a label in [0, V), ascending; every other row of the CE gradient is exactly zero (ignore_index),
  * so the head's backward may run on this list alone.  idx has room for M entries; count is one int on the device. */
 int mmbert_active_rows(mmbert_stream_t stream, const int64_t* labels, int M, int V, int* idx, int* count);

@@ -64,6 +64,7 @@ SIGNATURES = {
     "mmbert_transpose_cast": (I, [P, P, P, P, I, I]),
     "mmbert_transpose_bf16": (I, [P, P, P, P, I, I]),
     "mmbert_gather_rows": (I, [P, I, P, P, P, P, P, P, I]),
+    "mmbert_pack_i64": (I, [P, I, P, P, P, P, P]),
 }
 
 _lib = None

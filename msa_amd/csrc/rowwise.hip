@@ -748,6 +748,16 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const GatherArgs a, co
     }
 }
 
+// Concatenation of up to 12 int64 segments into one buffer (token ids, token types and labels of the step's passes: three
+// torch.cat launches, two zero fills and their dtype conversions before); a segment without a source is filled with a constant.
+struct PackSeg { const int64_t* src; long long dst0, n, fill; };
+struct PackArgs { PackSeg s[12]; };
+__global__ __launch_bounds__(256) void pack_i64_kernel(const PackArgs a, int64_t* __restrict__ out) {
+    const PackSeg s = a.s[blockIdx.y];
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < s.n; i += (long long)gridDim.x * 256)
+        out[s.dst0 + i] = s.src ? s.src[i] : (int64_t)s.fill;
+}
+
 // test/debug: keep mask of a dropout site as bytes (so the CPU oracle can replay the same mask)
 __global__ void dropout_mask_kernel(uint8_t* __restrict__ out, size_t n, uint32_t stream, uint32_t thr) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
@@ -1237,6 +1247,23 @@ int mmbert_gather_rows(hipStream_t stream, int nseg, const void* const* src, voi
         a.s[k].vec16 = !((row_bytes[k] | src_pitch[k] | dst_pitch[k]) & 15) && !(((uintptr_t)src[k] | (uintptr_t)dst[k]) & 15);
     }
     hipLaunchKernelGGL(gather_rows_kernel, dim3(nrows, nseg), dim3(256), 0, stream, a, idx);
+    MMB_CHECK_LAUNCH();
+    return 0;
+}
+
+int mmbert_pack_i64(hipStream_t stream, int nseg, const int64_t* const* src, const long long* dst_offset, const long long* count,
+                    const long long* fill, int64_t* out) {
+    if (nseg <= 0) return 0;
+    if (nseg > 12 || !out) return -1;
+    PackArgs a = {};
+    long long most = 0;
+    for (int k = 0; k < nseg; ++k) {
+        if (count[k] < 0 || dst_offset[k] < 0) return -1;
+        a.s[k].src = src[k]; a.s[k].dst0 = dst_offset[k]; a.s[k].n = count[k]; a.s[k].fill = fill[k];
+        most = count[k] > most ? count[k] : most;
+    }
+    if (most == 0) return 0;
+    hipLaunchKernelGGL(pack_i64_kernel, dim3(grid_for((size_t)most, 256, 256), nseg), dim3(256), 0, stream, a, out);
     MMB_CHECK_LAUNCH();
     return 0;
 }

@@ -399,7 +399,14 @@ def _trunk_static(plan, B, T, lens, joff, dev):
         for k, lo in joff.items():
             b = torch.arange(B, dtype=torch.int32)[:, None] * lens[k] + torch.arange(T, dtype=torch.int32)[None, :] + lo
             jrows[k] = b.reshape(-1).to(dev)
-        st = plan[key] = dict(jrows=jrows, arange=torch.arange(len(lens) * B * T, dtype=torch.int32, device=dev))
+        groups, k = [], 0
+        while k < len(lens):                                   # maximal runs of consecutive passes of one kind: one LayerNorm launch each
+            k1 = k
+            while k1 + 1 < len(lens) and ((k1 + 1) in joff) == (k in joff):
+                k1 += 1
+            groups.append((k in joff, k, k1 + 1, torch.cat([jrows[q] for q in range(k, k1 + 1)]) if k in joff else None))
+            k = k1 + 1
+        st = plan[key] = dict(jrows=jrows, groups=groups, arange=torch.arange(len(lens) * B * T, dtype=torch.int32, device=dev))
     return st
 
 
@@ -448,15 +455,15 @@ class _TrunkFn(torch.autograd.Function):
         e0 = ops.embed_gather(t.ids, t.tts, w["word"], w["type"], w["pos"], T)
         mean0 = torch.empty(npass * B * T, device=dev, dtype=torch.float32)
         rstd0 = torch.empty_like(mean0)
-        for k in range(npass):                                   # (one launch per pass: 3 small ones at the headline shape)
-            rows = slice(k * B * T, (k + 1) * B * T)
-            if k in joff:
-                out, orows = J, st["jrows"][k]
+        for is_joint, k0, k1, jr in st["groups"]:               # one launch per run of passes of one kind (2 at the headline shape)
+            rows = slice(k0 * B * T, k1 * B * T)
+            if is_joint:
+                out, orows = J, jr
             elif early:
-                out, orows = X, split.inv32[bounds[k]:bounds[k + 1]]
+                out, orows = X, split.inv32[bounds[k0]:bounds[k1]]
             else:
-                out, orows = X[bounds[k]:bounds[k + 1]], None
-            ops.ln_fwd(e0[rows], w["emb_ln_g"], w["emb_ln_b"], cfg.layer_norm_eps, out=out, out_rows=orows, drop=t.d_emb, drop_row0=k * B * T,
+                out, orows = X[bounds[k0]:bounds[k1]], None
+            ops.ln_fwd(e0[rows], w["emb_ln_g"], w["emb_ln_b"], cfg.layer_norm_eps, out=out, out_rows=orows, drop=t.d_emb, drop_row0=k0 * B * T,
                        stats=(mean0[rows], rstd0[rows]))
         jstats = {}
         for k in joint:
@@ -530,30 +537,36 @@ class _TrunkFn(torch.autograd.Function):
         dJ = torch.empty_like(J)
         de0 = torch.empty_like(e0)
         joint = sorted(ctx.joff)
+        lnd = ops.LnDeferred(8)                                  # the partial sums of same-sized launches are folded by one reduce each
         for n, k in enumerate(joint):
             S = lens[k]
             lo = ctx.joff[k]
             m_, r_ = js[2 * n], js[2 * n + 1]
             if split is not None:
                 ops.ln_bwd(dx, J[lo:lo + B * S], m_, r_, w["joint_ln_g"], w["g_joint_ln_g"], w["g_joint_ln_b"], dx=dJ[lo:lo + B * S],
-                           dy_rows=inv32[bounds[k]:bounds[k + 1]], dy_row_limit=limit, post_drop=t.d_joint[k])
+                           dy_rows=inv32[bounds[k]:bounds[k + 1]], dy_row_limit=limit, post_drop=t.d_joint[k], deferred=lnd)
             else:
                 ops.ln_bwd(dx[bounds[k]:bounds[k + 1]], J[lo:lo + B * S], m_, r_, w["joint_ln_g"], w["g_joint_ln_g"], w["g_joint_ln_b"],
-                           dx=dJ[lo:lo + B * S], post_drop=t.d_joint[k])
+                           dx=dJ[lo:lo + B * S], post_drop=t.d_joint[k], deferred=lnd)
+        lnd.flush()                                              # (dJ complete before the projection's backward reads it: same stream)
+        for n, k in enumerate(joint):
+            S = lens[k]
+            lo = ctx.joff[k]
             off = T
             for feat, which in zip(t.feats[k], t.pair_info[k][1]):
                 ops.pair_proj_bwd(feat, J[lo:lo + B * S], dJ[lo:lo + B * S], T, w["g_" + which + "_w"], w["g_" + which + "_b"], seq_len=S, offset=off)
                 off += feat.shape[1]
-        for k in range(npass):
-            rows = slice(k * B * T, (k + 1) * B * T)
-            kw = dict(dx=de0[rows], post_drop=t.d_emb, drop_rows=st["arange"][rows] if t.d_emb[1] else None)
-            if k in ctx.joff:
-                ops.ln_bwd(dJ, e0[rows], mean0[rows], rstd0[rows], w["emb_ln_g"], w["g_emb_ln_g"], w["g_emb_ln_b"], dy_rows=st["jrows"][k], **kw)
+        for is_joint, k0, k1, jr in st["groups"]:
+            rows = slice(k0 * B * T, k1 * B * T)
+            kw = dict(dx=de0[rows], post_drop=t.d_emb, drop_rows=st["arange"][rows] if t.d_emb[1] else None, deferred=lnd)
+            if is_joint:
+                ops.ln_bwd(dJ, e0[rows], mean0[rows], rstd0[rows], w["emb_ln_g"], w["g_emb_ln_g"], w["g_emb_ln_b"], dy_rows=jr, **kw)
             elif split is not None:
                 ops.ln_bwd(dx, e0[rows], mean0[rows], rstd0[rows], w["emb_ln_g"], w["g_emb_ln_g"], w["g_emb_ln_b"],
-                           dy_rows=inv32[bounds[k]:bounds[k + 1]], dy_row_limit=limit, **kw)
+                           dy_rows=inv32[bounds[k0]:bounds[k1]], dy_row_limit=limit, **kw)
             else:
-                ops.ln_bwd(dx[bounds[k]:bounds[k + 1]], e0[rows], mean0[rows], rstd0[rows], w["emb_ln_g"], w["g_emb_ln_g"], w["g_emb_ln_b"], **kw)
+                ops.ln_bwd(dx[bounds[k0]:bounds[k1]], e0[rows], mean0[rows], rstd0[rows], w["emb_ln_g"], w["g_emb_ln_g"], w["g_emb_ln_b"], **kw)
+        lnd.flush()
         if top.defer_embed_rows:
             ops.embed_scatter(t.ids, t.tts, de0, T, None, w["g_type"], w["g_pos"], vocab=cfg.vocab_size)
             top._deferred_embed_rows = (t.ids, de0)
@@ -921,7 +934,24 @@ class _GpuModelBase(nn.Module):
             raise ValueError("You have so large dimension (), Check dimension or shape ")
         return mask
 
-    def _encode(self, passes, labels=None, want_rows=False, rowset=False):
+    def _pack_inputs(self, passes, label_parts=None):
+        """(ids, token types, labels) of all passes in the order of the token matrix from ONE launch (mmbert_pack_i64; round 2:
+        three torch.cat launches, two zero fills and the dtype conversions) -- on the input stream when the prologue runs there.
+        None when an input is not an int64 GPU tensor (the callers then take the torch path)."""
+        B, T = passes[0]["ids"].shape
+        tens = [p["ids"] for p in passes] + [p["tt"] for p in passes if p.get("tt") is not None] + list(label_parts or ())
+        if not all(torch.is_tensor(t_) and t_.is_cuda and t_.dtype == torch.int64 for t_ in tens):
+            return None
+        segs = [p["ids"] for p in passes] + [(p["tt"] if p.get("tt") is not None else (B * T, 0)) for p in passes] + list(label_parts or ())
+        side = self._prologue_stream(passes[0]["ids"])
+        with (torch.cuda.stream(side) if side is not None else contextlib.nullcontext()):
+            packed, _offs = ops.pack_i64(segs)
+        if side is not None:
+            packed.record_stream(torch.cuda.current_stream())
+        n = len(passes) * B * T
+        return packed[:n], packed[n:2 * n], (packed[2 * n:] if label_parts else None)
+
+    def _encode(self, passes, labels=None, want_rows=False, rowset=False, packed=None):
         """passes: list of dict(ids[B,T], tt[B,T]|None, mask, pair[B,P,D]|None, pair_mask|None).
         Returns (Y [tokens,H] bf16, plan, lens_per_pass, rows) -- ``rows`` = (labelled-row list, host words, event) when asked for.
         ``rowset``: the valid-first packing over a row SET instead of a prefix per sequence (the prologue's row-set mode): for
@@ -1009,14 +1039,20 @@ class _GpuModelBase(nn.Module):
             elif labels is not None and torch.is_grad_enabled() and getattr(self, "skip_padded_backward", True):
                 pending = (host[:nseq], None, ev)                     # the prologue's valid[]: unmasked length, extended to the last label
         # ---- embeddings + encoder: one autograd node (_TrunkFn)
+        if packed is not None:
+            ids, tts = packed
+        else:
+            ids = torch.cat([p["ids"].reshape(-1).long() for p in passes])
+            tts = torch.cat([(p["tt"].reshape(-1).long() if p.get("tt") is not None else torch.zeros(B * T, dtype=torch.long, device=dev)) for p in passes])
         if self.embed_ids_hook is not None and torch.is_grad_enabled():
             # data parallel: the ranks agree on the union of touched embedding rows now, on the input stream when the inputs are
             # complete (async_prologue) -- else on the current stream, where the prologue's host wait happens anyway
-            with (torch.cuda.stream(side) if side is not None else contextlib.nullcontext()):
-                early_ids = torch.cat([p["ids"].reshape(-1).long() for p in passes])
+            if packed is not None or side is None:
+                early_ids = ids                                    # (packed on the input stream when the prologue runs there)
+            else:
+                with torch.cuda.stream(side):
+                    early_ids = torch.cat([p["ids"].reshape(-1).long() for p in passes])
             self.embed_ids_hook(early_ids, side)
-        ids = torch.cat([p["ids"].reshape(-1).long() for p in passes])
-        tts = torch.cat([(p["tt"].reshape(-1).long() if p.get("tt") is not None else torch.zeros(B * T, dtype=torch.long, device=dev)) for p in passes])
         p_emb = cfg.hidden_dropout_prob if self.training else 0.0
         p_joint = je.dropout_prob if (self.training and je.training) else 0.0
         t = _Trunk()
@@ -1489,17 +1525,21 @@ class MMBertForPretraining(_GpuModelBase):
                   dict(ids=twv, tt=None, mask=am_v[0].to(dev), pair=visual, pair_mask=am_v[1].to(dev)),
                   dict(ids=tws, tt=None, mask=am_s[0].to(dev), pair=speech, pair_mask=am_s[1].to(dev))]
         H, V = self.config.hidden_size, self.config.vocab_size
-        side = self._prologue_stream(text_ids) if lab_t.is_cuda else None
-        if side is None:
-            labels = torch.cat((lab_t.reshape(-1), lab_v.reshape(-1), lab_s.reshape(-1))).to(device=dev, dtype=torch.long)
-        else:                                   # async_prologue: the prologue's inputs must not queue behind the current stream
-            with torch.cuda.stream(side):
+        pk = self._pack_inputs(passes, (lab_t, lab_v, lab_s))
+        if pk is not None:
+            labels, pk = pk[2], pk[:2]
+        else:
+            side = self._prologue_stream(text_ids) if lab_t.is_cuda else None
+            if side is None:
                 labels = torch.cat((lab_t.reshape(-1), lab_v.reshape(-1), lab_s.reshape(-1))).to(device=dev, dtype=torch.long)
-            labels.record_stream(torch.cuda.current_stream())
+            else:                                   # async_prologue: the prologue's inputs must not queue behind the current stream
+                with torch.cuda.stream(side):
+                    labels = torch.cat((lab_t.reshape(-1), lab_v.reshape(-1), lab_s.reshape(-1))).to(device=dev, dtype=torch.long)
+                labels.record_stream(torch.cuda.current_stream())
         if labels.numel() != B * (T + (T + visual.shape[1]) + (T + speech.shape[1])):
             raise ValueError("masked_labels must cover text (+ pair) positions of every pass")
         want_rows = torch.is_grad_enabled() and getattr(self, "sparse_mlm_backward", True) and labels.is_cuda
-        y, plan, lens, rows = self._encode(passes, labels, want_rows)
+        y, plan, lens, rows = self._encode(passes, labels, want_rows, packed=pk)
         trunk, self._last_trunk = self._last_trunk, None
         # first = [3B, H]: the [CLS] rows of every sequence; joint_loss = alpha * (mlm_t + mlm_v + mlm_s) / 3 + heads_loss  (:427, :443)
         mlm, logits, first = _MLMHeadFn.apply(y, self.cls.predictions.transform.LayerNorm.weight, self, labels, plan["bounds"], plan["bounds_dev"],
@@ -1534,18 +1574,22 @@ class MMBertForPretraining(_GpuModelBase):
         B, T = text_ids.shape
         passes = [dict(ids=text_ids, tt=token_type_ids, mask=am_t, pair=(visual, speech), pair_mask=(am_v, am_s))]
         V = self.config.vocab_size
-        side = self._prologue_stream(text_ids) if masked_labels.is_cuda else None
-        if side is None:
-            labels = masked_labels.reshape(-1).to(device=dev, dtype=torch.long)
-        else:                                   # async_prologue: see forward()
-            with torch.cuda.stream(side):
+        pk = self._pack_inputs(passes, (masked_labels,))
+        if pk is not None:
+            labels, pk = pk[2], pk[:2]
+        else:
+            side = self._prologue_stream(text_ids) if masked_labels.is_cuda else None
+            if side is None:
                 labels = masked_labels.reshape(-1).to(device=dev, dtype=torch.long)
-            labels.record_stream(torch.cuda.current_stream())
+            else:                                   # async_prologue: see forward()
+                with torch.cuda.stream(side):
+                    labels = masked_labels.reshape(-1).to(device=dev, dtype=torch.long)
+                labels.record_stream(torch.cuda.current_stream())
         if labels.numel() != B * (T + visual.shape[1] + speech.shape[1]):
             raise ValueError("masked_labels must cover the text and both pair blocks")
         want_rows = torch.is_grad_enabled() and getattr(self, "sparse_mlm_backward", True) and labels.is_cuda
         # the visual padding sits in the MIDDLE of the fused sequence: valid-first packing over the row set, not over a prefix
-        y, plan, lens, rows = self._encode(passes, labels, want_rows, rowset=getattr(self, "fused_rowset_packing", True))
+        y, plan, lens, rows = self._encode(passes, labels, want_rows, rowset=getattr(self, "fused_rowset_packing", True), packed=pk)
         trunk, self._last_trunk = self._last_trunk, None
         mlm, logits, first = _MLMHeadFn.apply(y, self.cls.predictions.transform.LayerNorm.weight, self, labels, plan["bounds"], plan["bounds_dev"],
                                               self.return_scores, rows, plan["first"].repeat(3), trunk)   # the one [CLS] row in the t / v / s slots

@@ -796,6 +796,32 @@ def gather_rows(srcs, idx32):
     return outs
 
 
+def pack_i64(segments, total=None):
+    """One int64 tensor holding ``segments`` back to back in ONE launch (mmbert_pack_i64): a segment is an int64 tensor (flattened;
+    contiguous) or ``(count, fill)`` for a constant run.  Returns (packed, [start offsets])."""
+    LA = ctypes.c_longlong * len(segments)
+    srcs, offs, cnts, fills, keep = [], [], [], [], []
+    off = 0
+    dev = None
+    for sg in segments:
+        if torch.is_tensor(sg):
+            assert sg.dtype == torch.int64 and sg.is_cuda
+            t = sg.reshape(-1)
+            if not t.is_contiguous():
+                t = t.contiguous()
+            keep.append(t)
+            srcs.append(t.data_ptr()); cnts.append(t.numel()); fills.append(0)
+            dev = t.device
+        else:
+            srcs.append(None); cnts.append(int(sg[0])); fills.append(int(sg[1]))
+        offs.append(off)
+        off += cnts[-1]
+    out = torch.empty(off if total is None else total, device=dev, dtype=torch.int64)
+    n = len(segments)
+    _lib.check(_lib.load().mmbert_pack_i64(_stream(), n, _PtrArr[n](*srcs), LA(*offs), LA(*cnts), LA(*fills), out.data_ptr()), "mmbert_pack_i64")
+    return out, offs
+
+
 def heads_colsum(pairs):
     """pairs: list of (src [rows, cols] fp32 with unit column stride, dst [cols] fp32): dst += column sums, one launch."""
     n = len(pairs)
