@@ -565,6 +565,9 @@ __global__ __launch_bounds__(512, 2) void gemm_ntp_kernel(const GemmNT p) {
             // timing-only builds (round 3, -DMMB_EXP_ALOADS=1 / 0): every wave issues ONE of its two A-row loads per stage (24 LDS-DMA
             // instructions per K step and CU instead of 32), or none (16): does the K step follow the instruction count?  Compile-time:
             // a run-time switch around the loads made hipcc drain vmcnt at the joins (the K loop doubled)
+#ifdef MMB_EXP_WAVEA
+            if (wave < MMB_EXP_WAVEA)                          // (ablation: a wave-uniform RUN-TIME branch around the A loads: waves >= N issue none)
+#endif
             if (i < NTP_ALOADS)
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, LPTR(base + i * 1024), 16, o.a[i], kb, 0, 0);
             if (NTP_BLOADS)
