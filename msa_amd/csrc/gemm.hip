@@ -560,6 +560,12 @@ __global__ __launch_bounds__(512, 2) void gemm_ntp_kernel(const GemmNT p) {
     const auto rsB = __builtin_amdgcn_make_buffer_rsrc((void*)p.B, 0, (int)recB, 0x00020000);
     auto issue = [&](int slot, const Src& o, uint32_t kb) {      // kb: byte offset along K (wave-uniform)
         char* base = smem + slot * 32768 + wave * 2048;
+#ifdef MMB_EXP_EXEC0
+        // (ablation: what does an LDS-DMA instruction cost with EXEC = 0?  bit 0: all loads, bit 1: only the A loads of waves 6, 7)
+        __builtin_amdgcn_sched_barrier(0);
+        if ((MMB_EXP_EXEC0) & 1) asm volatile("s_mov_b64 exec, 0" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+#endif
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             // timing-only builds (round 3, -DMMB_EXP_ALOADS=1 / 0): every wave issues ONE of its two A-row loads per stage (24 LDS-DMA
@@ -573,6 +579,11 @@ __global__ __launch_bounds__(512, 2) void gemm_ntp_kernel(const GemmNT p) {
             if (NTP_BLOADS)
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, LPTR(base + 16384 + i * 1024), 16, o.b[i], kb, 0, 0);
         }
+#ifdef MMB_EXP_EXEC0
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_mov_b64 exec, -1" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+#endif
     };
     // s_waitcnt vmcnt(k stages x loads per stage and wave + e): 4 loads per stage in the product build
 #define NTP_WAIT(K_, E_, LG_) __builtin_amdgcn_s_waitcnt(mmb_waitcnt((2 * NTP_BLOADS + NTP_ALOADS) * (K_) + (E_), LG_));

@@ -18,7 +18,7 @@ LIB = os.path.join(OUT, f"libmmbert_hip_stamps{('_' + VARIANT) if VARIANT else '
 EXTRA = {"": [], "aloads1": ["-DMMB_EXP_ALOADS=1"], "aloads0": ["-DMMB_EXP_ALOADS=0"], "noloads": ["-DMMB_EXP_ALOADS=0", "-DMMB_EXP_NOBLOADS"],
          "nomfma": ["-DMMB_EXP_NOMFMA"], "nofrags": ["-DMMB_EXP_NOFRAGS"], "nofrags_noloads": ["-DMMB_EXP_NOFRAGS", "-DMMB_EXP_ALOADS=0", "-DMMB_EXP_NOBLOADS"],
          "nomfma_noloads": ["-DMMB_EXP_NOMFMA", "-DMMB_EXP_ALOADS=0", "-DMMB_EXP_NOBLOADS"],
-         "wavea6": ["-DMMB_EXP_WAVEA=6"], "wavea4": ["-DMMB_EXP_WAVEA=4"],
+         "wavea6": ["-DMMB_EXP_WAVEA=6"], "wavea4": ["-DMMB_EXP_WAVEA=4"], "exec0": ["-DMMB_EXP_EXEC0=1"],
          "onlymfma": ["-DMMB_EXP_NOFRAGS", "-DMMB_EXP_ALOADS=0", "-DMMB_EXP_NOBLOADS"]}[VARIANT]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffast-math", "-fno-finite-math-only"]
 
