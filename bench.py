@@ -159,8 +159,8 @@ def main():
 
     def step(i):
         out, _ = model(**pool[i % len(pool)])
-        row_frac.append(getattr(model, "last_backward_row_fraction", 1.0))
         out[0].mean().backward()
+        row_frac.append(getattr(model, "last_backward_row_fraction", 1.0))      # (known on the host once backward has sized its launches)
         if dp is not None:
             dp.finish_backward()
         opt.step()

@@ -182,6 +182,15 @@ int mmbert_split_rows(mmbert_stream_t stream, const int64_t* row_seq, const int6
                       const int* valid, int mode, int M, int rows_a, int64_t* perm, int64_t* inv, const int* rank,
                       int* perm32 /* optional int32 copies of the two maps (row lists for mmbert_ln_fwd / _bwd) */, int* inv32);
 
+/* The same packing's per-sequence starts and attention tile lists built on the device from `valid` (mmbert_prologue's output) -- no
+ * host round trip in the forward pass.  tile_rows = mmbert_attn_tile_rows(); xs = 8 / gcd(heads, 8) (sequences interleaved in groups of
+ * xs so that one (sequence, head) stays on one XCD); lists are sized for the worst case: nq_max = sum ceil(len / tile_rows),
+ * nf_max = nq_max + nseq; unused entries carry sequence -1 (mmbert_attn_fwd / _bwd skip them).  out (int32):
+ * ftile_seq | ftile_r0 | ftile_qshift | ftile_qend (nf_max each) | tile_seq | tile_r0 | qtile_qshift | qtile_qend (nq_max each) |
+ * start_a | valid (clamped) | start_b (nseq each) | nf, nq, rows_a, 0.  nseq <= 1024. */
+int mmbert_split_layout(mmbert_stream_t stream, const int* seq_len, const int* valid, int nseq, int tile_rows, int xs, int nf_max, int nq_max,
+                        int* out);
+
 /* Step prologue (two launches): from the caller's attention masks and MLM labels to what the encoder's launches need.
  * Sequences: npass passes x B samples, pass p has pass_len[p] positions per sequence; packed rows pass-major, then sample, then
  * position (the order of the token matrix).  Mask segment q (host arrays of nseg <= 12 entries) covers positions

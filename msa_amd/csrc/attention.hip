@@ -163,6 +163,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnArgs a) {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int tix = a.head_fast ? blockIdx.y : blockIdx.x, head = a.head_fast ? blockIdx.x : blockIdx.y;       // see AttnArgs::head_fast
     const int seq = a.tile_seq[tix], r0 = a.tile_r0[tix];
+    if (seq < 0) return;                                     // a padding entry of a device-built tile list (mmbert_split_layout)
     const int start = a.seq_start[seq], S = a.seq_len[seq];
     const int qshift = a.tile_qshift ? a.tile_qshift[tix] : start;     // packed row of query index 0
     const int Sq = a.tile_qend ? a.tile_qend[tix] : S;                 // query indices of this tile end here
@@ -375,6 +376,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnArgs a) {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int tix = a.head_fast ? blockIdx.y : blockIdx.x, head = a.head_fast ? blockIdx.x : blockIdx.y;       // see AttnArgs::head_fast
     const int seq = a.tile_seq[tix], r0 = a.tile_r0[tix];
+    if (seq < 0) return;                                     // a padding entry of a device-built tile list (mmbert_split_layout)
     const int start = a.seq_start[seq], S = a.seq_len[seq];
     const int qshift = a.tile_qshift ? a.tile_qshift[tix] : start;
     const int Sq = a.tile_qend ? a.tile_qend[tix] : S;
@@ -549,6 +551,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnArgs a) 
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int tix = a.head_fast ? blockIdx.y : blockIdx.x, head = a.head_fast ? blockIdx.x : blockIdx.y;       // see AttnArgs::head_fast
     const int seq = a.tile_seq[tix], r0 = a.tile_r0[tix];
+    if (seq < 0) return;                                     // a padding entry of a device-built tile list (mmbert_split_layout)
     const int start = a.seq_start[seq], S = a.seq_len[seq];
     // keys at and past Skv are all masked out: p = exp(s - 10000 - lse) underflows to exactly 0, so dK = dV = 0 for them.  A wave
     // whose 32 keys lie there computes nothing (its zero accumulators are stored at the end); a tile that lies there entirely

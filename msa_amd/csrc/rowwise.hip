@@ -32,6 +32,76 @@ __global__ void split_rows_kernel(const int64_t* __restrict__ row_seq, const int
     if (own) { perm[n] = i; if (perm32) perm32[n] = i; }
 }
 
+// The valid-first packing's per-sequence starts and attention tile lists, built on the DEVICE from the prologue's ``valid`` counts
+// (round 3; ops.SplitLayout's numpy form needs them on the host: one blocking round trip per forward pass).  One workgroup:
+//   v[s] = min(valid[s], len[s]);  start_a = exclusive prefix sum of v;  start_b = rows_a + exclusive prefix sum of (len - v);
+//   region-A tiles (s, k), k < ceil(v / rows), then region-B tiles (s, k), k < ceil((len - v) / rows) -- each list ordered
+//   longest-work-first with the sequences interleaved in groups of xs (ops.SplitLayout's rule: rank = stable order of -v; key =
+//   (rank / xs, k, rank % xs));
+//   unused list entries (the lists are sized for the worst case) get sequence -1: the attention kernels leave at once.
+// out (int32): ftile_seq | ftile_r0 | ftile_qshift | ftile_qend  (nf_max each)  |  tile_seq | tile_r0 | qtile_qshift | qtile_qend
+// (nq_max each)  |  start_a | v | start_b (nseq each)  |  counts: nf, nq, rows_a, 0.
+#define SL_MAXSEQ 1024
+__global__ __launch_bounds__(1024) void split_layout_kernel(const int* __restrict__ lens, const int* __restrict__ valid, int nseq, int rows, int xs,
+                                                            int nf_max, int nq_max, int* __restrict__ out) {
+    __shared__ int v[SL_MAXSEQ], ln[SL_MAXSEQ], rk[SL_MAXSEQ], sa[SL_MAXSEQ], sb[SL_MAXSEQ], seq_of_rank[SL_MAXSEQ];
+    __shared__ int tot[3];
+    const int tid = threadIdx.x;
+    for (int s = tid; s < nseq; s += 1024) { ln[s] = lens[s]; v[s] = min(valid[s], lens[s]); }
+    __syncthreads();
+    for (int s = tid; s < nseq; s += 1024) {                   // stable rank of -v
+        int r = 0;
+        const int vs = v[s];
+        for (int t = 0; t < nseq; ++t) r += (v[t] > vs || (v[t] == vs && t < s)) ? 1 : 0;
+        rk[s] = r;
+        seq_of_rank[r] = s;
+    }
+    if (tid == 0) {                                            // prefix sums (nseq <= 1024: a serial pass is a few microseconds)
+        int a = 0;
+        for (int s = 0; s < nseq; ++s) { sa[s] = a; a += v[s]; }
+        int b = a;
+        for (int s = 0; s < nseq; ++s) { sb[s] = b; b += ln[s] - v[s]; }
+        tot[2] = a;
+    }
+    __syncthreads();
+    int* f_seq = out; int* f_r0 = out + nf_max; int* f_sh = out + 2 * nf_max; int* f_end = out + 3 * nf_max;
+    int* q_seq = out + 4 * nf_max; int* q_r0 = q_seq + nq_max; int* q_sh = q_seq + 2 * nq_max; int* q_end = q_seq + 3 * nq_max;
+    int* o_sa = q_seq + 4 * nq_max; int* o_v = o_sa + nseq; int* o_sb = o_v + nseq; int* o_cnt = o_sb + nseq;
+    for (int s = tid; s < nseq; s += 1024) { o_sa[s] = sa[s]; o_v[s] = v[s]; o_sb[s] = sb[s]; }
+    // position of tile (s, k) of a list with nt[.] tiles per sequence: tiles of earlier groups, then inside the group by (k, rank % xs)
+    auto place = [&](bool regionB, int base, int* cnt_out) {
+        auto nt = [&](int s) { const int c = regionB ? ln[s] - v[s] : v[s]; return (c + rows - 1) / rows; };
+        int total = 0;
+        for (int s = tid; s < nseq; s += 1024) {
+            const int n = nt(s);
+            if (n == 0) continue;
+            const int r = rk[s], g = r / xs, m = r - g * xs;
+            int before_groups = 0;
+            for (int r2 = 0; r2 < g * xs; ++r2) before_groups += nt(seq_of_rank[r2]);
+            for (int k = 0; k < n; ++k) {
+                int pos = before_groups;
+                for (int m2 = 0; m2 < xs && g * xs + m2 < nseq; ++m2) {
+                    const int n2 = nt(seq_of_rank[g * xs + m2]);
+                    pos += min(n2, k) + ((n2 > k && m2 < m) ? 1 : 0);
+                }
+                const int first = regionB ? v[s] : 0, shift = regionB ? sb[s] - v[s] : sa[s], end = regionB ? ln[s] : v[s];
+                f_seq[base + pos] = s; f_r0[base + pos] = first + k * rows; f_sh[base + pos] = shift; f_end[base + pos] = end;
+                if (!regionB) { q_seq[pos] = s; q_r0[pos] = k * rows; q_sh[pos] = shift; q_end[pos] = end; }
+            }
+        }
+        if (tid == 0) { for (int s = 0; s < nseq; ++s) total += nt(s); *cnt_out = total; }
+    };
+    place(false, 0, &tot[0]);
+    __syncthreads();
+    const int nA = tot[0];
+    place(true, nA, &tot[1]);
+    __syncthreads();
+    const int nf = nA + tot[1];
+    for (int i = nf + tid; i < nf_max; i += 1024) { f_seq[i] = -1; f_r0[i] = 0; f_sh[i] = 0; f_end[i] = 0; }
+    for (int i = nA + tid; i < nq_max; i += 1024) { q_seq[i] = -1; q_r0[i] = 0; q_sh[i] = 0; q_end[i] = 0; }
+    if (tid == 0) { o_cnt[0] = nf; o_cnt[1] = nA; o_cnt[2] = tot[2]; o_cnt[3] = 0; }
+}
+
 extern "C" {
 int mmbert_gemm_tn(hipStream_t stream, const void* A, int lda, const void* B, int ldb, float* W, int ldw,
                    int M, int N, int K, int accumulate, float alpha, const float* alpha_dev, void* slab, float* bias_out);
@@ -1145,6 +1215,14 @@ int mmbert_split_rows(hipStream_t stream, const int64_t* row_seq, const int64_t*
     if (mode < 0 || mode > 2) return -1;
     hipLaunchKernelGGL(split_rows_kernel, dim3((M + 255) / 256), dim3(256), 0, stream, row_seq, row_pos, start_a, start_b, valid, mode, M, rows_a, perm, inv, rank,
                        perm32, inv32);
+    MMB_CHECK_LAUNCH();
+    return 0;
+}
+
+int mmbert_split_layout(hipStream_t stream, const int* seq_len, const int* valid, int nseq, int tile_rows, int xs, int nf_max, int nq_max, int* out) {
+    if (nseq <= 0) return 0;
+    if (nseq > SL_MAXSEQ || tile_rows <= 0 || xs <= 0 || !out) return -1;
+    hipLaunchKernelGGL(split_layout_kernel, dim3(1), dim3(1024), 0, stream, seq_len, valid, nseq, tile_rows, xs, nf_max, nq_max, out);
     MMB_CHECK_LAUNCH();
     return 0;
 }

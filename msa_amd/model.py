@@ -530,6 +530,8 @@ class _TrunkFn(torch.autograd.Function):
         dx = _EncoderFn.run_backward(top, layout, t.key_bias, None if split is not None else t.kv_len, ctx.saved, dy, dy_rows, t.top_rows,
                                      compact)
         ctx.saved = None
+        if split is not None:
+            top.last_backward_row_fraction = float(split.rows_a) / split.tokens
         # ---- embedding stage: dx holds the leading rows_a rows of the packed order (all rows without the packing)
         ra = dx.shape[0]
         inv32 = split.inv32 if split is not None else None
@@ -1026,6 +1028,7 @@ class _GpuModelBase(nn.Module):
             marks[k % 2] = mark
             main.wait_event(ev)
         key_bias = pro.key_bias                                       # per-sequence padded layout, -1e30 = "no such key"
+        self._last_valid_dev = pro.valid
         rows = (pro.idx, host[nseq:], ev) if want_rows else None
         # padded pair rows are masked-out keys at the tail of every joint sequence: the attention kernels skip them (exact)
         kv_len = pro.kv_len if getattr(self, "skip_masked_keys", True) else None
@@ -1072,7 +1075,10 @@ class _GpuModelBase(nn.Module):
         # prologue on the compute stream the host would wait for the GPU to drain: the embedding kernels are queued first (they keep
         # the GPU busy while the lengths travel and the host packs the layout), write the caller's order, and one gather packs.
         rank = pro.rank
-        t.late_split = side is None
+        # (the device-built packing of the default training step needs no host wait at all: it always comes first)
+        on_device = (pending is not None and not infer and not drop and getattr(self, "device_split_layout", True) and len(lens) * B <= 1024
+                     and os.environ.get("MMBERT_ATTN_LPT", "1") != "0" and os.environ.get("MMBERT_ATTN_XCD_GROUP", "1") != "0")
+        t.late_split = side is None and not on_device
         t.split = None
         get_split = lambda: self._split_layout(plan, kv_len, pending, infer, drop, rank)
         if not t.late_split:
@@ -1133,6 +1139,13 @@ class _GpuModelBase(nn.Module):
             return None
         lay = plan["layout"]
         valid_host, flag, ev = pending
+        if (not infer and not drop and getattr(self, "device_split_layout", True) and len(lay.lens) <= 1024
+                and os.environ.get("MMBERT_ATTN_LPT", "1") != "0" and os.environ.get("MMBERT_ATTN_XCD_GROUP", "1") != "0"):
+            # the training step that returns its scores: every row is kept, so nothing about the packing has to be known on the HOST
+            # before backward -- the maps and tile lists are built by two kernels from the prologue's device-side counts, the forward
+            # pass has no host round trip (round 2 / early round 3: numpy on the prologue's words; async_prologue hid the wait)
+            lay2 = ops.DeviceSplitLayout(lay, self._last_valid_dev, kv_len.device, rank=rank, words=(valid_host, ev))
+            return lay2
         ev.synchronize()
         if flag is not None and int(flag[0]) != 0:
             return None

@@ -521,6 +521,62 @@ class SplitLayout:
         self.split = True
 
 
+class DeviceSplitLayout:
+    """The same valid-first packing as SplitLayout (mode 0: every row kept), but built on the DEVICE from the prologue's ``valid``
+    counts (mmbert_split_layout + mmbert_split_rows): the forward pass needs no host round trip.  The tile lists are sized for the
+    worst case (unused entries carry sequence -1: the attention kernels leave at once), ``nftiles`` is that static size.  What only
+    BACKWARD needs on the host -- ``rows_a`` (its launch sizes), ``ntiles``, ``valid_host`` -- is read lazily from the prologue's
+    pinned words (``words`` = (host int32 view, event)): by then they arrived a whole forward pass ago."""
+
+    split = True
+    dropped = False
+
+    def __init__(self, base: SeqLayout, valid_dev, device, rank=None, words=None):
+        lib = _lib.load()
+        ns = len(base.lens)
+        rows = base._rows_f
+        nq_max = sum((n + rows - 1) // rows for n in base.lens)
+        nf_max = nq_max + ns
+        xs = 8 // int(np.gcd(base.heads, 8))
+        buf = torch.empty(4 * nf_max + 4 * nq_max + 3 * ns + 4, device=device, dtype=torch.int32)
+        _lib.check(lib.mmbert_split_layout(_stream(), base.seq_len.data_ptr(), valid_dev.data_ptr(), ns, rows, xs, nf_max, nq_max, buf.data_ptr()),
+                   "mmbert_split_layout")
+        cut = np.cumsum([0, nf_max, nf_max, nf_max, nf_max, nq_max, nq_max, nq_max, nq_max, ns, ns, ns, 4])
+        part = [buf[cut[k]:cut[k + 1]] for k in range(12)]
+        (self.ftile_seq, self.ftile_r0, self.ftile_qshift, self.ftile_qend, self.tile_seq, self.tile_r0, self.qtile_qshift,
+         self.qtile_qend, self.seq_start, self.kv_len, start_b_dev, self.counts) = part
+        self.nftiles = nf_max
+        M = base.tokens
+        rs_d, rp_d = base.row_tables(device)
+        dev_p = torch.empty(2 * M, dtype=torch.int64, device=device)
+        dev_p32 = torch.empty(2 * M, dtype=torch.int32, device=device)
+        _lib.check(lib.mmbert_split_rows(_stream(), rs_d.data_ptr(), rp_d.data_ptr(), self.seq_start.data_ptr(), start_b_dev.data_ptr(),
+                                         self.kv_len.data_ptr(), 0, M, 0, dev_p.data_ptr(), dev_p.data_ptr() + 8 * M, _ptr(rank),
+                                         dev_p32.data_ptr(), dev_p32.data_ptr() + 4 * M), "mmbert_split_rows")
+        self.perm, self.inv = dev_p[:M], dev_p[M:]
+        self.perm32, self.inv32 = dev_p32[:M], dev_p32[M:]
+        self.rows_packed = M
+        self.base, self.heads, self.tokens, self.lens = base, base.heads, base.tokens, base.lens
+        self.seq_len, self.elem_base, self.bias_start, self.bias_len = base.seq_len, base.elem_base, base.bias_start, base.bias_len
+        self._words, self._host = words, None
+
+    def _resolve(self):
+        if self._host is None:
+            if self._words is not None:
+                host, ev = self._words
+                ev.synchronize()
+                v = np.minimum(host.numpy().astype(np.int64), np.asarray(self.lens, dtype=np.int64))
+            else:                                            # (no pinned words handed over: one blocking read)
+                v = self.kv_len.cpu().numpy().astype(np.int64)
+            rows = self.base._rows_f
+            self._host = (int(v.sum()), int(((v + rows - 1) // rows).sum()), [int(x) for x in v])
+        return self._host
+
+    rows_a = property(lambda self: self._resolve()[0])
+    ntiles = property(lambda self: self._resolve()[1])
+    valid_host = property(lambda self: self._resolve()[2])
+
+
 def pad_key_bias(key_bias, layout: "SeqLayout"):
     """[tokens] additive key bias -> the padded per-sequence layout the attention kernels read."""
     out = torch.full((layout.bias_len,), NO_KEY, device=key_bias.device, dtype=torch.float32)

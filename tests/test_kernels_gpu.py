@@ -416,6 +416,45 @@ def test_split_layout_row_maps_kernel_equals_host_form(ops, mode):
     assert (cov == 1).all()
 
 
+@pytest.mark.parametrize("heads", [12, 4, 3])
+def test_device_split_layout_equals_host_form(ops, heads):
+    """ops.DeviceSplitLayout (mmbert_split_layout + mmbert_split_rows: the packing built from DEVICE-side counts, no host round trip)
+    against ops.SplitLayout's numpy form on the same counts: identical starts, row maps and -- entry for entry, in the same
+    longest-work-first / XCD-grouped order -- tile lists; the worst-case-sized lists are padded with sequence -1; the lazily read
+    host numbers (rows_a, ntiles, valid_host) agree.  Incl. a sequence with nothing valid past row 1, full ones, and ties."""
+    import numpy as np
+    g = torch.Generator().manual_seed(heads)
+    lens = [50] * 6 + [550] * 9 + [300, 129, 128, 64, 1]
+    valid = [int(torch.randint(1, n + 1, (1,), generator=g)) for n in lens]
+    valid[0], valid[6], valid[7], valid[8], valid[-1] = 50, 550, 1, 377, 1
+    valid[9] = valid[10] = 377                                              # ties in the longest-first order
+    base = ops.SeqLayout(lens, heads, DEV)
+    vd = torch.tensor(valid, dtype=torch.int32, device=DEV)
+    host = torch.tensor(valid, dtype=torch.int32)
+    ev = torch.cuda.Event(); ev.record()
+    d = ops.DeviceSplitLayout(base, vd, DEV, words=(host, ev))
+    h = ops.SplitLayout(base, valid, DEV)
+    torch.cuda.synchronize()
+    nf, nq, ra = (int(x) for x in d.counts[:3].cpu())
+    assert (nf, nq, ra) == (h.nftiles, h.ntiles, h.rows_a) and d.rows_a == h.rows_a and d.ntiles == h.ntiles and d.valid_host == h.valid_host
+    assert d.nftiles >= nf and d.rows_packed == h.rows_packed == sum(lens)
+    for name in ("ftile_seq", "ftile_r0", "ftile_qshift", "ftile_qend"):
+        assert torch.equal(getattr(d, name)[:nf].cpu(), getattr(h, name).cpu()), name
+    for name in ("tile_seq", "tile_r0", "qtile_qshift", "qtile_qend"):
+        assert torch.equal(getattr(d, name)[:nq].cpu(), getattr(h, name).cpu()), name
+    assert bool((d.ftile_seq[nf:] == -1).all()) and bool((d.tile_seq[nq:] == -1).all())
+    for name in ("seq_start", "kv_len", "perm", "inv", "perm32", "inv32"):
+        assert torch.equal(getattr(d, name).cpu(), getattr(h, name).cpu()), name
+    # attention over the padded list: same context as over the exact list
+    H = heads * 64
+    M = sum(lens)
+    qkv = bf(torch.randn(M, 3 * H, generator=g)).to(DEV)
+    bias = torch.zeros(M, device=DEV)
+    c1, l1 = ops.attn_fwd(qkv, bias, d, H)
+    c2, l2 = ops.attn_fwd(qkv, bias, h, H)
+    assert torch.equal(c1, c2) and torch.equal(l1, l2)
+
+
 def test_attention_rescale_branch(ops):
     """Force the running max to jump at a later key tile (guide rule 26): spike one key."""
     n, heads, H = 200, 1, 64
