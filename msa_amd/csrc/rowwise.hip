@@ -123,27 +123,49 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const bf16_t* __restrict__ 
                                                      uint32_t dstream, uint32_t dthr, float dscale, int drop_row0) {
     const int lane = threadIdx.x & 63;
     const int wpb = blockDim.x >> 6;
-    for (int i0 = (blockIdx.x * wpb + (threadIdx.x >> 6)) * R; i0 < M; i0 += gridDim.x * wpb * R) {
-        float v[R][NV][4];
-        float s[R];
+    // Software pipeline: the rows of trip t + 1 are requested BEFORE trip t is reduced, normalised and stored, so a wave always has
+    // reads in flight under its arithmetic and its stores (one trip per wave -- the round-1/2 launch shape -- made the whole launch
+    // "every read, then every store": 2.8 TB/s on cold operands where a plain copy of the same bytes reaches 5.2,
+    // tools/ubench/stream_rate.py).
+    const int step = gridDim.x * wpb * R;
+    // gamma / beta live in registers: loaded inside the loop they would sit BEHIND the next trip's row requests in the in-order
+    // vmcnt queue, and waiting for them would wait for those rows too (no pipeline left)
+    float4 gam[NV], bet[NV];
+#pragma unroll
+    for (int c = 0; c < NV; ++c) {
+        const int col = c * 256 + lane * 4;
+        gam[c] = col < H ? *(const float4*)(gamma + col) : make_float4(0.f, 0.f, 0.f, 0.f);
+        bet[c] = col < H ? *(const float4*)(beta + col) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    bf16x4 nx[R][NV];
+    auto request = [&](int i0) {
 #pragma unroll
         for (int rr = 0; rr < R; ++rr) {
             const int i = min(i0 + rr, M - 1);                 // (a row past the end is computed again and not stored)
             const bf16_t* xr = x + (size_t)(in_rows ? in_rows[i] : i) * ldx;
+#pragma unroll
+            for (int c = 0; c < NV; ++c) {
+                const int col = c * 256 + lane * 4;
+                if (col < H) nx[rr][c] = *(const bf16x4*)(xr + col);
+            }
+        }
+    };
+    int i0 = (blockIdx.x * wpb + (threadIdx.x >> 6)) * R;
+    if (i0 < M) request(i0);
+    for (; i0 < M; i0 += step) {
+        float v[R][NV][4];
+        float s[R];
+#pragma unroll
+        for (int rr = 0; rr < R; ++rr) {
             s[rr] = 0.f;
 #pragma unroll
             for (int c = 0; c < NV; ++c) {
                 const int col = c * 256 + lane * 4;
-                if (col < H) {
-                    const bf16x4 t = *(const bf16x4*)(xr + col);
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) { v[rr][c][r] = bf2f(t[r]); s[rr] += v[rr][c][r]; }
-                } else {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) v[rr][c][r] = 0.f;
-                }
+                for (int r = 0; r < 4; ++r) { v[rr][c][r] = col < H ? bf2f(nx[rr][c][r]) : 0.f; s[rr] += v[rr][c][r]; }
             }
         }
+        if (i0 + step < M) request(i0 + step);
         float mean[R], q[R], rstd[R];
 #pragma unroll
         for (int rr = 0; rr < R; ++rr) mean[rr] = wave_sum(s[rr]) / H;
@@ -165,8 +187,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const bf16_t* __restrict__ 
         for (int c = 0; c < NV; ++c) {
             const int col = c * 256 + lane * 4;
             if (col < H) {
-                const float4 g = *(const float4*)(gamma + col);
-                const float4 b = *(const float4*)(beta + col);
+                const float4 g = gam[c], b = bet[c];
 #pragma unroll
                 for (int rr = 0; rr < R; ++rr) {
                     const int i = i0 + rr;
@@ -223,33 +244,55 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
 #pragma unroll
         for (int r = 0; r < 4; ++r) { ag[c][r] = 0.f; ab[c][r] = 0.f; ad[c][r] = 0.f; }
     const int stride = gridDim.x * 4;
-    for (int i0 = blockIdx.x * 4 + w; i0 < M; i0 += stride * R) {
-        bf16x4 dl[R][NV], tl[R][NV];
-        float mean[R], rstd[R];
-        uint64_t di[R];
-        bool live[R];
+    float4 gam[NV];                                            // in registers, see ln_fwd_kernel
 #pragma unroll
-        for (int rr = 0; rr < R; ++rr) {                       // all loads of the trip first
+    for (int c = 0; c < NV; ++c) {
+        const int col = c * 256 + lane * 4;
+        gam[c] = col < H ? *(const float4*)(gamma + col) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    // software pipeline as in ln_fwd_kernel: the operands of trip t + 1 are requested before trip t is evaluated and stored
+    bf16x4 ndl[R][NV], ntl[R][NV];
+    float nmean[R], nrstd[R];
+    uint64_t ndi[R];
+    bool nlive[R];
+    auto request = [&](int i0) {
+#pragma unroll
+        for (int rr = 0; rr < R; ++rr) {
             const int i = i0 + rr * stride;
-            live[rr] = i < M;
-            const int ic = live[rr] ? i : i0;
+            nlive[rr] = i < M;
+            const int ic = nlive[rr] ? i : i0;
             // dy_row_limit > 0: a mapped dy row at or past the limit does not exist -- its gradient is zero (the rows the valid-first
             // packing leaves out of backward; wave-uniform)
             const int dr = dy_rows ? dy_rows[ic] : ic;
             const bool has_dy = !(dy_row_limit > 0 && dr >= dy_row_limit);
             const bf16_t* dyr = dy + (size_t)(has_dy ? dr : 0) * lddy;
             const bf16_t* xr = x + (size_t)(x_rows ? x_rows[ic] : ic) * ldx;
-            mean[rr] = mean_in[ic]; rstd[rr] = rstd_in[ic];
-            di[rr] = drop_rows ? (uint64_t)drop_rows[ic] : (uint64_t)ic;           // the row the dropout masks were drawn for
+            nmean[rr] = mean_in[ic]; nrstd[rr] = rstd_in[ic];
+            ndi[rr] = drop_rows ? (uint64_t)drop_rows[ic] : (uint64_t)ic;           // the row the dropout masks were drawn for
 #pragma unroll
             for (int c = 0; c < NV; ++c) {
                 const int col = c * 256 + lane * 4;
                 if (col < H) {
-                    dl[rr][c] = has_dy ? *(const bf16x4*)(dyr + col) : (bf16x4){(bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f};
-                    tl[rr][c] = *(const bf16x4*)(xr + col);
+                    ndl[rr][c] = has_dy ? *(const bf16x4*)(dyr + col) : (bf16x4){(bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f};
+                    ntl[rr][c] = *(const bf16x4*)(xr + col);
                 }
             }
         }
+    };
+    int i0 = blockIdx.x * 4 + w;
+    if (i0 < M) request(i0);
+    for (; i0 < M; i0 += stride * R) {
+        bf16x4 dl[R][NV], tl[R][NV];
+        float mean[R], rstd[R];
+        uint64_t di[R];
+        bool live[R];
+#pragma unroll
+        for (int rr = 0; rr < R; ++rr) {
+            mean[rr] = nmean[rr]; rstd[rr] = nrstd[rr]; di[rr] = ndi[rr]; live[rr] = nlive[rr];
+#pragma unroll
+            for (int c = 0; c < NV; ++c) { dl[rr][c] = ndl[rr][c]; tl[rr][c] = ntl[rr][c]; }
+        }
+        if (i0 + stride * R < M) request(i0 + stride * R);
 #pragma unroll
         for (int rr = 0; rr < R; ++rr) {
             if (!live[rr]) continue;                           // wave-uniform
@@ -260,7 +303,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
             for (int c = 0; c < NV; ++c) {
                 const int col = c * 256 + lane * 4;
                 if (col < H) {
-                    const float4 gm = *(const float4*)(gamma + col);
+                    const float4 gm = gam[c];
                     const float gmv[4] = {gm.x, gm.y, gm.z, gm.w};
                     bool k[4] = {true, true, true, true};
                     if (post_thr) mmb_keep4(post_stream, di[rr] * H + col, post_thr, k);
@@ -336,6 +379,245 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
             else atomicAdd(dbias2 + col, sd);
         }
     }
+}
+
+// --------------------------------------------------------------------------------------------
+// Round 3: the LayerNorm pair for H = NV * 256 (every shipped width: 256 ... 1024), written for the instruction stream.
+// tools/ubench/stream_rate.py put the round-1/2 kernels above at 2.4-2.8 TB/s on cold operands where a plain streaming kernel of the
+// same bytes reaches 5.2-5.5: (1) one trip per wave made a launch "all reads, then all stores"; (2) gamma / beta / mean / rstd / the
+// row maps were vector loads INSIDE the loop -- queued behind the next rows' requests in the in-order vmcnt queue, so every wait for
+// them was a wait for those rows; (3) ~590 instructions per backward row (per-column predicates, 64-bit dropout indices, fp32
+// selects, ds_bpermute reductions).  Here: rows are requested one trip ahead, everything wave-uniform (row maps, mean, rstd, the
+// dropout row) travels through the SCALAR path two trips ahead, gamma / beta sit in registers, dropout is decided on the packed
+// bf16 words with a per-lane seed (same words as mmb_keep4: pair index (row * H + col) / 2 in 32-bit arithmetic), arithmetic on
+// float pairs, reductions by DPP.  The kernels above stay as the path for every other H.
+// --------------------------------------------------------------------------------------------
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+
+template <int CTRL, int ROWS>
+__device__ __forceinline__ float dpp_get(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROWS, 0xF, false));
+}
+// sum over the 64 lanes, wave-uniform result: quad swaps, half-row and row mirrors, then the two row broadcasts; lane 63 holds the total
+__device__ __forceinline__ float wave_sum_dpp(float v) {
+    v += dpp_get<0xB1, 0xF>(v);        // quad_perm [1,0,3,2]
+    v += dpp_get<0x4E, 0xF>(v);        // quad_perm [2,3,0,1]
+    v += dpp_get<0x141, 0xF>(v);       // row_half_mirror
+    v += dpp_get<0x140, 0xF>(v);       // row_mirror: every lane of a row holds the row's sum
+    v += dpp_get<0x142, 0xA>(v);       // row_bcast15 into rows 1, 3
+    v += dpp_get<0x143, 0xC>(v);       // row_bcast31 into rows 2, 3
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+__device__ __forceinline__ f32x2 bf2_unpack(uint32_t w) {
+    return (f32x2){__builtin_bit_cast(float, w << 16), __builtin_bit_cast(float, w & 0xFFFF0000u)};
+}
+__device__ __forceinline__ uint32_t bf2_pack(f32x2 v) {
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
+}
+__device__ __forceinline__ f32x2 fma2(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
+
+template <int NV, bool DROP>
+__global__ __launch_bounds__(256) void ln_fwd_lean_kernel(const bf16_t* __restrict__ x, int ldx, const int* __restrict__ in_rows,
+                                                          bf16_t* __restrict__ y, int ldy, const int* __restrict__ out_rows,
+                                                          int M, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                          float eps, float* __restrict__ mean_out, float* __restrict__ rstd_out,
+                                                          uint32_t dstream, uint32_t dthr, float dscale, int drop_row0) {
+    constexpr int H = NV * 256;
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int step = gridDim.x * 4;
+    int i = blockIdx.x * 4 + w;                                  // wave-uniform: the row maps below are scalar loads
+    if (i >= M) return;
+    f32x2 gam[NV][2], bet[NV][2];
+#pragma unroll
+    for (int c = 0; c < NV; ++c) {
+        const float4 g = *(const float4*)(gamma + c * 256 + lane * 4), b = *(const float4*)(beta + c * 256 + lane * 4);
+        gam[c][0] = (f32x2){g.x, g.y}; gam[c][1] = (f32x2){g.z, g.w};
+        bet[c][0] = (f32x2){b.x, b.y}; bet[c][1] = (f32x2){b.z, b.w};
+    }
+    const uint32_t thr_pk = mmb_thr_packed(dthr);
+    const uint32_t lane_seed = (uint32_t)(lane * 2) * MMB_WEYL + dstream;
+    u32x2_t nx[NV];
+    auto request = [&](int src) {
+        const bf16_t* xr = x + (size_t)src * ldx + lane * 4;
+#pragma unroll
+        for (int c = 0; c < NV; ++c) nx[c] = *(const u32x2_t*)(xr + c * 256);
+    };
+    auto map_in = [&](int r) { r = min(r, M - 1); return in_rows ? in_rows[r] : r; };
+    auto map_out = [&](int r) { r = min(r, M - 1); return out_rows ? out_rows[r] : r; };
+    request(map_in(i));
+    int src1 = map_in(i + step), dst0 = map_out(i), dst1 = map_out(i + step);     // one and two trips ahead (scalar path)
+    for (; i < M; i += step) {
+        f32x2 v[NV][2], s2 = {0.f, 0.f};
+#pragma unroll
+        for (int c = 0; c < NV; ++c)
+#pragma unroll
+            for (int k = 0; k < 2; ++k) { v[c][k] = bf2_unpack(nx[c][k]); s2 += v[c][k]; }
+        if (i + step < M) request(src1);
+        const int dst = dst0;
+        dst0 = dst1;
+        src1 = map_in(i + 2 * step); dst1 = map_out(i + 2 * step);
+        const float mean = wave_sum_dpp(s2.x + s2.y) * (1.0f / H);
+        f32x2 q2 = {0.f, 0.f};
+#pragma unroll
+        for (int c = 0; c < NV; ++c)
+#pragma unroll
+            for (int k = 0; k < 2; ++k) { v[c][k] -= mean; q2 = fma2(v[c][k], v[c][k], q2); }
+        const float rstd = rsqrtf(wave_sum_dpp(q2.x + q2.y) * (1.0f / H) + eps);
+        bf16_t* yr = y + (size_t)dst * ldy + lane * 4;
+        const uint32_t row_seed = (uint32_t)(i + drop_row0) * (uint32_t)((H / 2) * MMB_WEYL) + lane_seed;
+#pragma unroll
+        for (int c = 0; c < NV; ++c) {
+            u32x2_t ow;
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                f32x2 o = fma2(v[c][k] * rstd, gam[c][k], bet[c][k]);
+                if (DROP) o *= dscale;
+                uint32_t pw = bf2_pack(o);
+                if (DROP) pw &= ~mmb_drop_mask2(mmb_pair_mix(row_seed + (uint32_t)(c * 128 + k) * MMB_WEYL), thr_pk);
+                ow[k] = pw;
+            }
+            *(u32x2_t*)(yr + c * 256) = ow;
+        }
+        if (lane == 0) { if (mean_out) mean_out[i] = mean; if (rstd_out) rstd_out[i] = rstd; }
+    }
+}
+
+template <int NV, bool POST, bool DX2, bool PRE, int WPB>
+__global__ __launch_bounds__(WPB * 64) void ln_bwd_lean_kernel(const bf16_t* __restrict__ dy, int lddy, const int* __restrict__ dy_rows,
+                                                          const bf16_t* __restrict__ x, int ldx, const int* __restrict__ x_rows,
+                                                          const float* __restrict__ mean_in, const float* __restrict__ rstd_in,
+                                                          const float* __restrict__ gamma, int M,
+                                                          bf16_t* __restrict__ dx, int lddx, const int* __restrict__ dx_rows,
+                                                          bf16_t* __restrict__ dx2, int lddx2,
+                                                          float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ dbias2,
+                                                          float* __restrict__ partial,
+                                                          uint32_t post_stream, uint32_t post_thr, float post_scale,
+                                                          uint32_t pre_stream, uint32_t pre_thr, float pre_scale,
+                                                          const int* __restrict__ drop_rows, int dy_row_limit) {
+    constexpr int H = NV * 256;
+    __shared__ float red[WPB][H];                              // WPB waves per workgroup: one column-sum epilogue per WPB waves
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int stride = gridDim.x * WPB;
+    const bool want_ad = DX2 || dbias2 != nullptr;
+    f32x2 gam[NV][2], ag[NV][2], ab[NV][2], ad[NV][2];
+#pragma unroll
+    for (int c = 0; c < NV; ++c) {
+        const float4 g = *(const float4*)(gamma + c * 256 + lane * 4);
+        gam[c][0] = (f32x2){g.x, g.y}; gam[c][1] = (f32x2){g.z, g.w};
+#pragma unroll
+        for (int k = 0; k < 2; ++k) { ag[c][k] = (f32x2){0.f, 0.f}; ab[c][k] = (f32x2){0.f, 0.f}; ad[c][k] = (f32x2){0.f, 0.f}; }
+    }
+    const uint32_t post_pk = mmb_thr_packed(post_thr), pre_pk = mmb_thr_packed(pre_thr);
+    const uint32_t lane_post = (uint32_t)(lane * 2) * MMB_WEYL + post_stream, lane_pre = (uint32_t)(lane * 2) * MMB_WEYL + pre_stream;
+    // everything wave-uniform about a row (scalar path); `dyr` < 0: the mapped dy row does not exist (dy_row_limit) -- zero gradient
+    struct Row { int dyr, xr, dxr; uint32_t dr; float mean, rstd; };
+    auto row_of = [&](int r) {
+        r = min(r, M - 1);
+        Row o;
+        const int d = dy_rows ? dy_rows[r] : r;
+        o.dyr = (dy_row_limit > 0 && d >= dy_row_limit) ? -1 : d;
+        o.xr = x_rows ? x_rows[r] : r;
+        o.dxr = dx_rows ? dx_rows[r] : r;
+        o.dr = drop_rows ? (uint32_t)drop_rows[r] : (uint32_t)r;
+        o.mean = mean_in[r]; o.rstd = rstd_in[r];
+        return o;
+    };
+    u32x2_t ndl[NV], ntl[NV];
+    auto request = [&](const Row& r) {
+        const bf16_t* xr = x + (size_t)r.xr * ldx + lane * 4;
+#pragma unroll
+        for (int c = 0; c < NV; ++c) ntl[c] = *(const u32x2_t*)(xr + c * 256);
+        if (r.dyr >= 0) {                                        // wave-uniform
+            const bf16_t* dyr = dy + (size_t)r.dyr * lddy + lane * 4;
+#pragma unroll
+            for (int c = 0; c < NV; ++c) ndl[c] = *(const u32x2_t*)(dyr + c * 256);
+        } else {
+#pragma unroll
+            for (int c = 0; c < NV; ++c) ndl[c] = (u32x2_t){0u, 0u};
+        }
+    };
+    int i = blockIdx.x * WPB + w;
+    if (i < M) {
+        Row r0 = row_of(i);
+        request(r0);
+        Row r1 = row_of(i + stride);
+        for (; i < M; i += stride) {
+            u32x2_t dl[NV], tl[NV];
+#pragma unroll
+            for (int c = 0; c < NV; ++c) { dl[c] = ndl[c]; tl[c] = ntl[c]; }
+            const Row r = r0;
+            r0 = r1;
+            if (i + stride < M) request(r0);
+            r1 = row_of(i + 2 * stride);
+            const uint32_t row_w = r.dr * (uint32_t)((H / 2) * MMB_WEYL);
+            const float nmr = -r.mean * r.rstd;
+            f32x2 g[NV][2], xh[NV][2], s1 = {0.f, 0.f}, s2 = {0.f, 0.f};
+#pragma unroll
+            for (int c = 0; c < NV; ++c)
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    uint32_t dw = dl[c][k];
+                    if (POST) dw &= ~mmb_drop_mask2(mmb_pair_mix(row_w + lane_post + (uint32_t)(c * 128 + k) * MMB_WEYL), post_pk);
+                    f32x2 dv = bf2_unpack(dw);
+                    if (POST) dv *= post_scale;
+                    xh[c][k] = fma2(bf2_unpack(tl[c][k]), (f32x2){r.rstd, r.rstd}, (f32x2){nmr, nmr});
+                    ag[c][k] = fma2(dv, xh[c][k], ag[c][k]);
+                    ab[c][k] += dv;
+                    g[c][k] = dv * gam[c][k];
+                    s1 += g[c][k];
+                    s2 = fma2(g[c][k], xh[c][k], s2);
+                }
+            const float m1 = wave_sum_dpp(s1.x + s1.y) * (1.0f / H), m2 = wave_sum_dpp(s2.x + s2.y) * (1.0f / H);
+            const float c1 = -m1 * r.rstd, c2 = -m2 * r.rstd;
+            bf16_t* dxr = dx + (size_t)r.dxr * lddx + lane * 4;
+            bf16_t* dx2r = DX2 ? dx2 + (size_t)i * lddx2 + lane * 4 : nullptr;
+#pragma unroll
+            for (int c = 0; c < NV; ++c) {
+                u32x2_t ow, ow2;
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    const f32x2 o = fma2(xh[c][k], (f32x2){c2, c2}, fma2(g[c][k], (f32x2){r.rstd, r.rstd}, (f32x2){c1, c1}));
+                    ow[k] = bf2_pack(o);
+                    if (DX2 && PRE) {
+                        const f32x2 o2 = o * pre_scale;
+                        const uint32_t dm = mmb_drop_mask2(mmb_pair_mix(row_w + lane_pre + (uint32_t)(c * 128 + k) * MMB_WEYL), pre_pk);
+                        ow2[k] = bf2_pack(o2) & ~dm;
+                        // the dense layer's bias gradient in fp32: selects on the dropped halves' flag bits.  (hipcc trap: written as
+                        // bit_cast(o2.y) & ~mask the second select read o2.x -- both lanes of the pair got the first element)
+                        const float klo = (dm & 0x8000u) ? 0.f : o2[0], khi = (dm & 0x80000000u) ? 0.f : o2[1];
+                        ad[c][k] += (f32x2){klo, khi};
+                    } else {
+                        if (DX2) ow2[k] = ow[k];
+                        if (want_ad) ad[c][k] += o;
+                    }
+                }
+                *(u32x2_t*)(dxr + c * 256) = ow;
+                if (DX2) *(u32x2_t*)(dx2r + c * 256) = ow2;
+            }
+        }
+    }
+    // workgroup reduction of the column sums (one quantity at a time through the same LDS block), then one store (or atomic) per column
+    auto fold = [&](f32x2 (&acc)[NV][2], int slot, float* out) {
+#pragma unroll
+        for (int c = 0; c < NV; ++c)
+#pragma unroll
+            for (int k = 0; k < 2; ++k) *(f32x2*)&red[w][c * 256 + lane * 4 + 2 * k] = acc[c][k];
+        __syncthreads();
+        for (int col = threadIdx.x; col < H; col += WPB * 64) {
+            float t = 0.f;
+#pragma unroll
+            for (int q = 0; q < WPB; ++q) t += red[q][col];
+            if (partial) partial[((size_t)blockIdx.x * 3 + slot) * H + col] = t;
+            else if (out) atomicAdd(out + col, t);
+        }
+        __syncthreads();
+    };
+    fold(ag, 0, dgamma);
+    fold(ab, 1, dbeta);
+    if (dbias2) fold(ad, 2, dbias2);
 }
 
 // Round 2: 16-byte-per-lane forms of the two LayerNorm kernels (half a wave per row, bf16x8 accesses, two rows in flight per wave)
@@ -1036,18 +1318,34 @@ uint32_t mmbert_dropout_thr16(float p) {
     return (uint32_t)t;
 }
 
+// the lean LayerNorm pair applies (H a multiple of 256; MMBERT_LN_GENERIC: A/B switch back to the general kernels)
+static inline bool ln_lean(int H) { return (H & 255) == 0 && H <= LN_MAXV * 256 && !getenv("MMBERT_LN_GENERIC"); }
+
 int mmbert_ln_fwd(hipStream_t stream, const void* x, int ldx, const int* in_rows, void* y, int ldy, const int* out_rows,
                   int M, int H, const float* gamma, const float* beta, float eps, float* mean, float* rstd,
                   uint32_t dstream, uint32_t dthr, float dscale, int drop_row0) {
     if (M <= 0) return 0;
     if (H > LN_MAXV * 256 || (H & 3) || (ldx & 3) || (ldy & 3)) return -1;
+    const char* cap_s = getenv("MMBERT_LN_FWD_BLOCKS");                                              // A/B switch, read per call
+    const int cap = cap_s ? atoi(cap_s) : 0;
+    if (ln_lean(H)) {
+        // H = NV * 256: the lean kernel, one row per wave and trip on a grid of <= 1024 workgroups (4 per CU: every wave resident,
+        // 4-5 trips per wave at the step's 14-18 k rows; swept 256 ... 4096 with tools/ubench/stream_rate.py)
+        const int NVL = H >> 8;
+        const dim3 grid(grid_for(M, 4, cap > 0 ? cap : 1024));
+#define LN_FWD_LEAN(NVV, DD) hipLaunchKernelGGL((ln_fwd_lean_kernel<NVV, DD>), grid, dim3(256), 0, stream, (const bf16_t*)x, ldx, in_rows, \
+                                                 (bf16_t*)y, ldy, out_rows, M, gamma, beta, eps, mean, rstd, dstream, dthr, dscale, drop_row0)
+        if (dthr) { if (NVL == 1) LN_FWD_LEAN(1, true); else if (NVL == 2) LN_FWD_LEAN(2, true); else if (NVL == 3) LN_FWD_LEAN(3, true); else LN_FWD_LEAN(4, true); }
+        else { if (NVL == 1) LN_FWD_LEAN(1, false); else if (NVL == 2) LN_FWD_LEAN(2, false); else if (NVL == 3) LN_FWD_LEAN(3, false); else LN_FWD_LEAN(4, false); }
+#undef LN_FWD_LEAN
+        MMB_CHECK_LAUNCH();
+        return 0;
+    }
     const int rows_env = getenv("MMBERT_LN_ROWS") ? atoi(getenv("MMBERT_LN_ROWS")) : 0;      // A/B switch: rows per wave (read per call)
     // rows per wave, measured at 18 400 x 768 (stand-alone, same box): 1 / 2 / 4 -> 18.3 / 14.9 / 20.9 us
     const int R = rows_env ? rows_env : (M >= 8192 ? 2 : 1);
     const int NV = (H + 255) / 256;
-    const char* cap_s = getenv("MMBERT_LN_FWD_BLOCKS");                                              // A/B switch, read per call
-    const int cap = cap_s ? atoi(cap_s) : 2048;
-#define LN_FWD_LAUNCH(NVV, RR) hipLaunchKernelGGL((ln_fwd_kernel<NVV, RR>), dim3(grid_for(M, 4 * RR, cap)), dim3(256), 0, stream, (const bf16_t*)x, ldx, in_rows, \
+#define LN_FWD_LAUNCH(NVV, RR) hipLaunchKernelGGL((ln_fwd_kernel<NVV, RR>), dim3(grid_for(M, 4 * RR, cap > 0 ? cap : 2048)), dim3(256), 0, stream, (const bf16_t*)x, ldx, in_rows, \
                                                   (bf16_t*)y, ldy, out_rows, M, H, gamma, beta, eps, mean, rstd, dstream, dthr, dscale, drop_row0)
     if (R >= 2) { if (NV == 1) LN_FWD_LAUNCH(1, 2); else if (NV == 2) LN_FWD_LAUNCH(2, 2); else if (NV == 3) LN_FWD_LAUNCH(3, 2); else LN_FWD_LAUNCH(4, 2); }
     else { if (NV == 1) LN_FWD_LAUNCH(1, 1); else if (NV == 2) LN_FWD_LAUNCH(2, 1); else if (NV == 3) LN_FWD_LAUNCH(3, 1); else LN_FWD_LAUNCH(4, 1); }
@@ -1057,8 +1355,19 @@ int mmbert_ln_fwd(hipStream_t stream, const void* x, int ldx, const int* in_rows
 }
 
 // (block cap swept in round 2 at 13 745 rows, encoder form: 256 / 512 / 1024 / 2048 / 4096 blocks -> 37.6 / 24.3 / 18.5 / 20.3 / 23.3 us)
-static inline int ln_bwd_blocks(int M) {
-    static const int cap_env = getenv("MMBERT_LN_BWD_BLOCKS") ? atoi(getenv("MMBERT_LN_BWD_BLOCKS")) : 0;     // A/B switch
+constexpr int LN_BWD_LEAN_WPB = 8;
+static inline int ln_bwd_lean_wpb() {
+    const char* wpb_s = getenv("MMBERT_LN_BWD_WPB");                                          // A/B switch, read per call
+    return (wpb_s ? atoi(wpb_s) : LN_BWD_LEAN_WPB) == 8 ? 8 : 4;
+}
+// workgroups of a backward launch (also the number of partial-sum rows the launch leaves in its workspace)
+static inline int ln_bwd_blocks(int M, int H) {
+    const char* cap_s = getenv("MMBERT_LN_BWD_BLOCKS");                                       // A/B switch, read per call
+    const int cap_env = cap_s ? atoi(cap_s) : 0;
+    if (ln_lean(H)) {
+        const int wpb = ln_bwd_lean_wpb();
+        return grid_for(M, wpb, cap_env > 0 ? cap_env : (wpb == 8 ? 256 : 512));
+    }
     return grid_for(M, 4, cap_env > 0 ? cap_env : 1024);
 }
 
@@ -1072,8 +1381,26 @@ int mmbert_ln_bwd(hipStream_t stream, const void* dy, int lddy, const int* dy_ro
     if (H > LN_MAXV * 256 || (H & 3) || (ldx & 3) || (lddy & 3) || (lddx & 3) || (lddx2 & 3)) return -1;
     if (dy_row_limit > 0 && !dy_rows) return -1;
     if (defer_reduce && !partial_ws) return -1;
-    const int nblocks = ln_bwd_blocks(M);
-    static const int rows_env = getenv("MMBERT_LN_BWD_ROWS") ? atoi(getenv("MMBERT_LN_BWD_ROWS")) : 0;      // A/B switch: rows per wave and trip
+    const int nblocks = ln_bwd_blocks(M, H);
+    if (ln_lean(H)) {
+        const int NVL = H >> 8;
+        const bool post = post_thr != 0, has2 = dx2 != nullptr, pre = has2 && pre_thr != 0;
+        // waves per workgroup (one column-sum epilogue per workgroup) and grid: swept with tools/ubench/stream_rate.py on cold operands at
+        // 14 000 / 18 400 rows -- 8 waves x 256 workgroups 21.6 / 25.8 us, 4 x 512 22.6 / 26.7, 4 x 1024 24.7 / 28.5, 16 x 256 22.6 / 26.7
+        const int wpb = ln_bwd_lean_wpb();
+#define LN_BWD_LEAN(NVV, PO, D2, PR, WW) hipLaunchKernelGGL((ln_bwd_lean_kernel<NVV, PO, D2, PR, WW>), dim3(nblocks), dim3(WW * 64), 0, stream, (const bf16_t*)dy, lddy, dy_rows, \
+        (const bf16_t*)x, ldx, x_rows, mean, rstd, gamma, M, (bf16_t*)dx, lddx, dx_rows, (bf16_t*)dx2, lddx2, dgamma, dbeta, dbias2, partial_ws, \
+        post_stream, post_thr, post_scale, pre_stream, pre_thr, pre_scale, drop_rows, dy_row_limit)
+#define LN_BWD_LEAN_W(NVV, WW) { if (post) { if (!has2) LN_BWD_LEAN(NVV, true, false, false, WW); else if (pre) LN_BWD_LEAN(NVV, true, true, true, WW); else LN_BWD_LEAN(NVV, true, true, false, WW); } \
+                                 else { if (!has2) LN_BWD_LEAN(NVV, false, false, false, WW); else if (pre) LN_BWD_LEAN(NVV, false, true, true, WW); else LN_BWD_LEAN(NVV, false, true, false, WW); } }
+#define LN_BWD_LEAN_NV(NVV) { if (wpb == 8) LN_BWD_LEAN_W(NVV, 8) else LN_BWD_LEAN_W(NVV, 4) }
+        if (NVL == 1) LN_BWD_LEAN_NV(1) else if (NVL == 2) LN_BWD_LEAN_NV(2) else if (NVL == 3) LN_BWD_LEAN_NV(3) else LN_BWD_LEAN_NV(4)
+#undef LN_BWD_LEAN_NV
+#undef LN_BWD_LEAN_W
+#undef LN_BWD_LEAN
+    } else {
+    const char* rows_s = getenv("MMBERT_LN_BWD_ROWS");                                             // A/B switch: rows per wave and trip (read per call)
+    const int rows_env = rows_s ? atoi(rows_s) : 0;
     // measured at 18 400 x 768 (stand-alone, same box): registers sized for 1024 columns (round 1: 142 VGPRs, 3 waves per SIMD) 35.0 us;
     // sized to the row (NV = 3: 116 VGPRs, 4 waves per SIMD = all 4096 waves of the launch resident) 28.5; two rows per trip 34.0
     const int R = rows_env ? rows_env : 1;
@@ -1085,6 +1412,7 @@ int mmbert_ln_bwd(hipStream_t stream, const void* dy, int lddy, const int* dy_ro
     if (R >= 2) { if (NV == 1) LN_BWD_LAUNCH(1, 2); else if (NV == 2) LN_BWD_LAUNCH(2, 2); else if (NV == 3) LN_BWD_LAUNCH(3, 2); else LN_BWD_LAUNCH(4, 2); }
     else { if (NV == 1) LN_BWD_LAUNCH(1, 1); else if (NV == 2) LN_BWD_LAUNCH(2, 1); else if (NV == 3) LN_BWD_LAUNCH(3, 1); else LN_BWD_LAUNCH(4, 1); }
 #undef LN_BWD_LAUNCH
+    }
     MMB_CHECK_LAUNCH();
     if (partial_ws && !defer_reduce) {
         LnReduceBatch b = {};
@@ -1097,7 +1425,7 @@ int mmbert_ln_bwd(hipStream_t stream, const void* dy, int lddy, const int* dy_ro
 }
 
 // floats the caller must provide as partial_ws for mmbert_ln_bwd (0 = use the atomic path)
-size_t mmbert_ln_bwd_workspace(int M, int H) { return (size_t)ln_bwd_blocks(M) * 3 * H; }
+size_t mmbert_ln_bwd_workspace(int M, int H) { return (size_t)ln_bwd_blocks(M, H) * 3 * H; }
 
 // Deferred reduction (mmbert_ln_bwd(..., defer_reduce = 1)): folds the partial sums of `items` (<= 32) earlier mmbert_ln_bwd calls
 // -- same M and H, each with its own partial_ws -- into their gradients in one launch.
@@ -1109,7 +1437,7 @@ int mmbert_ln_bwd_reduce(hipStream_t stream, int items, const float* const* part
     for (int i = 0; i < items; ++i) {
         b.out[i][0] = dgamma[i]; b.out[i][1] = dbeta[i]; b.out[i][2] = dbias2 ? dbias2[i] : nullptr; b.partial[i] = partial_ws[i];
     }
-    b.nblocks = ln_bwd_blocks(M); b.H = H; b.nq = 3; b.items = items;
+    b.nblocks = ln_bwd_blocks(M, H); b.H = H; b.nq = 3; b.items = items;
     hipLaunchKernelGGL(ln_bwd_reduce_batch_kernel, dim3((H + 63) / 64, items * 3, 8), dim3(256), 0, stream, b);
     MMB_CHECK_LAUNCH();
     return 0;
