@@ -1091,8 +1091,11 @@ static int dispatch_nt(hipStream_t s, const GemmNT& p) {
 // touches in one transposed read fall on 8 distinct 32-byte bank groups.
 // -------------------------------------------------------------------------------------------------
 struct TNProb { const bf16_t* A; const bf16_t* B; float* W; float* bias; int N, K, lda, ldb, tiles_k, tile0; long long slab_off; };
+// up to TN_MAXP problems per launch: the four dense layers of an encoder layer -- or of TWO layers (model._EncoderFn pairs them: 216
+// tiles fill the chip in one round without splitting the token axis, so no fp32 slabs and no reduce launch)
+#define TN_MAXP 8
 struct GemmTNG {
-    TNProb pr[4];
+    TNProb pr[TN_MAXP];
     float* slab; const float* alpha_dev;
     long long slab_stride;
     int nprob, total_tiles, M, splits, rows_per_split, accumulate;
@@ -1121,12 +1124,12 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_kernel(const GemmTNG g) {
     int t = xcd_remap(blockIdx.x, g.total_tiles);
     int pi = 0;
 #pragma unroll
-    for (int q = 1; q < 4; ++q) if (q < g.nprob && t >= g.pr[q].tile0) pi = q;
+    for (int q = 1; q < TN_MAXP; ++q) if (q < g.nprob && t >= g.pr[q].tile0) pi = q;
     const bf16_t* Ap = g.pr[0].A; const bf16_t* Bp = g.pr[0].B; float* Wp = g.pr[0].W; float* biasp = g.pr[0].bias;
     int N = g.pr[0].N, K = g.pr[0].K, lda = g.pr[0].lda, ldb = g.pr[0].ldb, tiles_k = g.pr[0].tiles_k, tile0 = g.pr[0].tile0;
     long long slab_off = g.pr[0].slab_off;
 #pragma unroll
-    for (int q = 1; q < 4; ++q)
+    for (int q = 1; q < TN_MAXP; ++q)
         if (pi == q) { Ap = g.pr[q].A; Bp = g.pr[q].B; Wp = g.pr[q].W; biasp = g.pr[q].bias; N = g.pr[q].N; K = g.pr[q].K; lda = g.pr[q].lda;
                        ldb = g.pr[q].ldb; tiles_k = g.pr[q].tiles_k; tile0 = g.pr[q].tile0; slab_off = g.pr[q].slab_off; }
     t -= tile0;
@@ -1322,17 +1325,17 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_kernel(const GemmTNG g) {
 }
 
 // W[i] += sum_{s >= 1} slab[s - 1][i] over the concatenated outputs of all problems of a launch (split 0 went to W directly)
-struct TNReduce { float* W[4]; long long off[5]; int nprob, splits, accumulate; long long slab_stride; };
+struct TNReduce { float* W[TN_MAXP]; long long off[TN_MAXP + 1]; int nprob, splits, accumulate; long long slab_stride; };
 __global__ void tn_reduce_kernel(const TNReduce r, const float* __restrict__ slab) {
     const long long total4 = r.off[r.nprob] >> 2;
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total4; i += (long long)gridDim.x * blockDim.x) {
         const long long e = i << 2;
         int pi = 0;
 #pragma unroll
-        for (int q = 1; q < 4; ++q) if (q < r.nprob && e >= r.off[q]) pi = q;
+        for (int q = 1; q < TN_MAXP; ++q) if (q < r.nprob && e >= r.off[q]) pi = q;
         float* W = r.W[0]; long long o = r.off[0];
 #pragma unroll
-        for (int q = 1; q < 4; ++q) if (pi == q) { W = r.W[q]; o = r.off[q]; }
+        for (int q = 1; q < TN_MAXP; ++q) if (pi == q) { W = r.W[q]; o = r.off[q]; }
         float4* dst = (float4*)(W + (e - o));
         float4 v = *dst;                                   // split 0 of the GEMM has stored its part here
         for (int s = 0; s + 1 < r.splits; ++s) {
@@ -1524,12 +1527,12 @@ size_t mmbert_gemm_tn_workspace(int M, int N, int K, int* splits_out) {
     return mmbert_gemm_tn_grouped_workspace(1, &N, &K, M, splits_out);
 }
 
-// up to 4 problems sharing M:  W_i[N_i,K_i] (+)= alpha * A_i^T . B_i ;  bias_i[N_i] += alpha * colsum(A_i) (bias_i may be null)
+// up to TN_MAXP (8) problems sharing M:  W_i[N_i,K_i] (+)= alpha * A_i^T . B_i ;  bias_i[N_i] += alpha * colsum(A_i) (bias_i may be null)
 int mmbert_gemm_tn_grouped(hipStream_t stream, int nprob, const void* const* A, const int* lda, const void* const* B, const int* ldb,
                            float* const* W, float* const* bias, const int* N, const int* K, int M,
                            int accumulate, float alpha, const float* alpha_dev, void* slab) {
     if (nprob <= 0 || M <= 0) return 0;
-    if (nprob > 4) return -1;
+    if (nprob > TN_MAXP) return -1;
     GemmTNG g;
     int splits, tiles;
     tn_plan(nprob, N, K, M, &splits, &tiles);
@@ -1546,8 +1549,8 @@ int mmbert_gemm_tn_grouped(hipStream_t stream, int nprob, const void* const* A, 
         tile0 += ((N[i] + 255) / 256) * q.tiles_k;
         off += (long long)N[i] * K[i];
     }
-    for (int i = nprob; i < 4; ++i) { g.pr[i] = g.pr[0]; g.pr[i].tile0 = 0x7fffffff; r.W[i] = nullptr; }
-    for (int i = nprob; i < 5; ++i) r.off[i] = off;
+    for (int i = nprob; i < TN_MAXP; ++i) { g.pr[i] = g.pr[0]; g.pr[i].tile0 = 0x7fffffff; r.W[i] = nullptr; }
+    for (int i = nprob; i <= TN_MAXP; ++i) r.off[i] = off;
     if (splits > 1 && !slab) return -3;
     g.slab = (float*)slab; g.alpha_dev = alpha_dev; g.slab_stride = off; g.nprob = nprob; g.total_tiles = tiles; g.M = M;
     g.splits = splits; g.rows_per_split = (((M + splits - 1) / splits) + 31) / 32 * 32; g.accumulate = accumulate; g.alpha = alpha;

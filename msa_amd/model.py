@@ -269,6 +269,7 @@ class _EncoderFn:
         # the end (with a data-parallel hook: per layer, before the layer's gradient slice is handed to the all-reduce); same-process
         # A/B against round 1's form (bias sums inside LayerNorm', one reduce launch per call): 16.58 vs 16.76 ms per step
         lnd = ops.LnDeferred(2 * L)
+        pair_wgrads, held = getattr(top, "pair_wgrads", True), None
         for i in reversed(range(L)):
             lw = top._lw[i]
             saved_i = saved[i]
@@ -317,7 +318,22 @@ class _EncoderFn:
             probs = [(du, y1, lw["g_W1"], lw["g_b1"]), (dz2d, g, lw["g_W2"], lw["g_b2"]),
                      (dqkv, x, lw["g_Wqkv"], lw["g_bqkv"]), (dz1d, actx, lw["g_Wo"], lw["g_bo"])]
             side = top._wgrad_stream()
-            if side is None:
+            if side is None and pair_wgrads:
+                # Two layers per launch: a layer's 108 tiles leave the chip half empty, so a single layer splits the token axis in two
+                # (fp32 slabs + a reduce launch, 12 us and 85 MB per layer); two layers' 216 tiles fill it in one round unsplit.  The
+                # upper layer of a pair just keeps its operands alive for one more layer (fresh buffers from the caching allocator)
+                if held is None and i > 0:
+                    held = (i, probs)
+                    continue
+                if held is not None:
+                    ops.gemm_tn_grouped(held[1] + probs)
+                    if top.grad_hook is not None:
+                        lnd.flush()
+                    top._layer_grads_done(held[0])
+                    held = None
+                else:
+                    ops.gemm_tn_grouped(probs)
+            elif side is None:
                 ops.gemm_tn_grouped(probs)
             else:
                 main = torch.cuda.current_stream()

@@ -161,7 +161,7 @@ _IntArr = {n: (ctypes.c_int * n) for n in range(1, 17)}
 
 
 def gemm_tn_grouped(problems, *, accumulate=True, alpha=1.0):
-    """problems: up to 4 tuples (A[M,N] bf16, B[M,K] bf16, W[N,K] fp32, bias[N] fp32 or None) sharing M:
+    """problems: up to 8 tuples (A[M,N] bf16, B[M,K] bf16, W[N,K] fp32, bias[N] fp32 or None) sharing M:
     one launch computes every W (+)= A^T @ B and bias += colsum(A)  (see mmbert_gemm_tn_grouped)."""
     lib = _lib.load()
     n = len(problems)

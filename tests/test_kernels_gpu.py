@@ -188,10 +188,13 @@ def test_gemm_tn(ops, M, N, K):
     assert_close(W, ref, 2e-3, 2e-3 * math.sqrt(M), "overwrite")
 
 
-def test_gemm_tn_fused_bias_and_grouped(ops):
+@pytest.mark.parametrize("shapes", [[(3072, 768), (768, 3072), (2304, 768), (768, 768)],
+                                    [(3072, 768), (768, 3072), (2304, 768), (768, 768), (1024, 256), (768, 768), (256, 1024), (520, 136)]])
+def test_gemm_tn_fused_bias_and_grouped(ops, shapes):
+    """Four problems (an encoder layer's dense layers) and eight (two layers: the paired launch of the encoder's backward) sharing M."""
     M = 1700
     probs, refs = [], []
-    for i, (N, K) in enumerate([(3072, 768), (768, 3072), (2304, 768), (768, 768)]):
+    for i, (N, K) in enumerate(shapes):
         A, B = bf(rnd(M, N, seed=70 + i, scale=0.1)), bf(rnd(M, K, seed=80 + i))
         W0, b0 = rnd(N, K, seed=90 + i), rnd(N, seed=95 + i)
         bias = b0.clone().to(DEV) if i % 2 == 0 else None
