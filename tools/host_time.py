@@ -23,6 +23,21 @@ for rep in range(3):
     torch.cuda.synchronize()
     t2 = time.perf_counter()
     print(f"enqueue {1e3 * (t1 - t0) / 8:.2f} ms/step, GPU done {1e3 * (t2 - t0) / 8:.2f} ms/step")
+# one step at a time from an empty queue: the host's own cost of a step (no back-pressure from a full queue), forward and backward apart
+import statistics
+fw, bw, op_ = [], [], []
+for i in range(12):
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    out, _ = model(**pool[i % 4]); loss = out[0].mean()
+    t1 = time.perf_counter()
+    loss.backward()
+    t2 = time.perf_counter()
+    opt.step(); sched.step(); opt.zero_grad()
+    t3 = time.perf_counter()
+    fw.append(t1 - t0); bw.append(t2 - t1); op_.append(t3 - t2)
+print(f"host cost of one step from an empty queue: forward {1e3 * statistics.median(fw):.2f} ms, backward {1e3 * statistics.median(bw):.2f} ms, "
+      f"optimizer {1e3 * statistics.median(op_):.2f} ms")
 import cProfile, pstats
 pr = cProfile.Profile(); pr.enable()
 for i in range(4): step(i)
