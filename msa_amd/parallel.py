@@ -38,8 +38,11 @@ class GradBucketer:
     an all-reduce in the low precision (which would also ACCUMULATE in it): every rank's slice is cast into a staging buffer, an
     all-to-all hands rank r the r-th chunk of every rank (on xGMI: all seven links at once, no ring), rank r adds the chunks in fp32
     in rank order, rounds the sum once, and an all-gather returns the sums -- every rank ends up with bit-identical values, each
-    rank's contribution is rounded once on the way in and the sum once on the way out.  Stage two of a bucket is issued as soon as a
-    later ``ready()`` / ``finish()`` finds its stage one complete, so both overlap the rest of backward."""
+    rank's contribution is rounded once on the way in and the sum once on the way out.  Stage two of a bucket is issued at a FIXED point
+    of the program -- right before the next bucket's stage one, or in ``finish()`` -- so that every rank issues its collectives in the
+    same order (a first version issued it as soon as a later ``ready()`` FOUND stage one complete: ranks that see the completion at
+    different calls interleave all-gathers and all-to-alls differently on one communicator -- a deadlock, met as a flaky gloo test);
+    by then stage one has had a whole bucket of backward to complete, so both stages still overlap the rest of backward."""
 
     def __init__(self, flat_grads: torch.Tensor, boundaries: Sequence[int], group=None, bucket_mb: float = 32.0,
                  skip: Sequence[Tuple[int, int]] = (), wire_dtype: Optional[torch.dtype] = None):
@@ -90,6 +93,7 @@ class GradBucketer:
         if self.wire_dtype is None or self.world == 1:
             self.handles.append(dist.all_reduce(self.flat[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
             return
+        self._advance()                                           # stage two of the buckets before this one: same point on every rank
         W, n = self.world, hi - lo
         chunk = (n + W - 1) // W
         send = torch.zeros(W * chunk, device=self.flat.device, dtype=self.wire_dtype)
@@ -98,13 +102,11 @@ class GradBucketer:
         h = dist.all_to_all_single(recv, send, group=self.group, async_op=True)
         self.stage1.append((h, lo, hi, recv, chunk, send))
 
-    def _advance(self, block: bool):
-        """Stage two (fp32 sum of the received chunks, all-gather of the rounded sums) of every bucket whose stage one is complete, in
-        issue order; ``block``: wait for stage one instead of polling it."""
+    def _advance(self):
+        """Stage two (fp32 sum of the received chunks, all-gather of the rounded sums) of every bucket in stage one, in issue order.
+        ``wait()`` blocks the host with gloo; with RCCL it only orders the current stream behind the all-to-all."""
         while self.stage1:
             h, lo, hi, recv, chunk, send = self.stage1[0]
-            if not block and not h.is_completed():
-                break
             h.wait()
             self.stage1.pop(0)
             W = self.world
@@ -125,13 +127,11 @@ class GradBucketer:
         end = self.bounds[k + 1]
         if end - self.done >= self.min_elems:
             self._issue(end)
-        if self.stage1:
-            self._advance(block=False)
 
     def finish(self, upto: Optional[int] = None):
         """Reduce whatever is left (up to element ``upto``: default everything) and wait for every outstanding collective."""
         self._issue(self.bounds[-1] if upto is None else upto)
-        self._advance(block=True)
+        self._advance()
         for h in self.handles:
             h.wait()
         for h2, lo, hi, out in self.stage2:
