@@ -238,7 +238,8 @@ def test_colsum(ops):
 
 
 # ------------------------------------------------------------------------------------ LayerNorm
-@pytest.mark.parametrize("M,H,eps", [(7, 128, 1e-12), (1000, 768, 1e-12), (513, 1024, 1e-5), (50, 64, 1e-5)])
+@pytest.mark.parametrize("M,H,eps", [(7, 128, 1e-12), (1000, 768, 1e-12), (513, 1024, 1e-5), (50, 64, 1e-5), (1, 768, 1e-12), (5, 256, 1e-5),
+                                     (18400, 768, 1e-12)])
 def test_ln_fwd_bwd(ops, M, H, eps):
     x, gamma, beta, dy = bf(rnd(M, H, seed=30)), 1 + 0.1 * rnd(H, seed=31), 0.1 * rnd(H, seed=32), bf(rnd(M, H, seed=33))
     xr = x.float().requires_grad_(True)
