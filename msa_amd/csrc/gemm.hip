@@ -997,9 +997,22 @@ static int launch_ntp_mi(hipStream_t s, const GemmNT& p) {
     static const int qg_env = getenv("MMBERT_NT_QUEUE_GLOBAL") ? atoi(getenv("MMBERT_NT_QUEUE_GLOBAL")) : 0;   // A/B switch: one counter
     q.queue_xcd = (qg_env || (cus & 7)) ? 0 : 1;
     if (tiles <= cus) q.tile_counter = q.tile_counter_next = nullptr;
-    // B panels that do not fit an XCD's L2 next to the A stream (> 3 MiB of weights: the vocabulary projection): grouped tile walk
-    static const int gm_env = getenv("MMBERT_NT_GROUP_M") ? atoi(getenv("MMBERT_NT_GROUP_M")) : -1;        // A/B switch
-    q.group_m = gm_env >= 0 ? gm_env : (((long long)p.N * p.K * 2 > (3ll << 20) && tiles > 4 * cus) ? 4 : 1);
+    // Tile walk (ntp_tile_mn).  An XCD's 32 workgroups own a contiguous chunk of the walk (xcd_remap), i.e. ceil(tiles_m / 8) row panels;
+    // with MORE tiles than CUs the order inside that chunk decides what its 4-MiB L2 sees:
+    //  * row-major (group_m = 1): 32 concurrent tiles = ~3 row panels x ALL column panels -- the whole weight matrix (3.5-4.7 MB at
+    //    N = 2304 / 3072) streams through the L2 once per 3 row panels, ~28 times per launch;
+    //  * one group per XCD (group_m = ceil(tiles_m / 8), round 3): the XCD sweeps the column panels with ALL its row panels, 32
+    //    concurrent tiles = 11 row panels x ~3 column panels -- every weight panel is fetched once per XCD, the 11 activation panels
+    //    (3.8 MB) stay around for the sweep.  Same-process A/B of the train step (tools/ab_step.py, MMBERT_NT_GROUP_M): group_m =
+    //    1 / 6 / 8 / 11 / 16 / 32 / 100 -> 15.56 / 15.34 / 15.30 / 14.98 / 15.30 / 15.18 / 15.16 ms; the rule below = 11 at 18 400 rows.
+    //  * the vocabulary projection (B = 47 MB, 9 960 tiles) keeps its groups of 4 row panels (round 2: 1 / 2 / 4 / 8 -> 871 / 855 / 844 /
+    //    875 us): its column sweep is 120 panels long, 11 row panels x 3 columns would re-stream the activations 40 times.
+    const char* gm_s = getenv("MMBERT_NT_GROUP_M");                                                        // A/B switch, read per call
+    const int gm_env = gm_s ? atoi(gm_s) : -1;
+    const bool huge_b = (long long)p.N * p.K * 2 > (8ll << 20);
+    q.group_m = 1;
+    if (tiles > cus) q.group_m = huge_b ? (tiles > 4 * cus ? 4 : 1) : (((p.M + BM - 1) / BM) + 7) / 8;
+    if (gm_env >= 0 && tiles > cus && !huge_b) q.group_m = gm_env;
     hipLaunchKernelGGL((gemm_ntp_kernel<EPI, MI, MI == 8>), dim3(tiles < cus ? tiles : cus), dim3(512), NTP_LDS_BYTES, s, q);
     MMB_CHECK_LAUNCH();
     return 0;
