@@ -998,15 +998,15 @@ static int launch_ntp_mi(hipStream_t s, const GemmNT& p) {
     q.queue_xcd = (qg_env || (cus & 7)) ? 0 : 1;
     if (tiles <= cus) q.tile_counter = q.tile_counter_next = nullptr;
     // Tile walk (ntp_tile_mn).  An XCD's 32 workgroups own a contiguous chunk of the walk (xcd_remap), i.e. ceil(tiles_m / 8) row panels;
-    // with MORE tiles than CUs the order inside that chunk decides what its 4-MiB L2 sees:
-    //  * row-major (group_m = 1): 32 concurrent tiles = ~3 row panels x ALL column panels -- the whole weight matrix (3.5-4.7 MB at
-    //    N = 2304 / 3072) streams through the L2 once per 3 row panels, ~28 times per launch;
-    //  * one group per XCD (group_m = ceil(tiles_m / 8), round 3): the XCD sweeps the column panels with ALL its row panels, 32
-    //    concurrent tiles = 11 row panels x ~3 column panels -- every weight panel is fetched once per XCD, the 11 activation panels
-    //    (3.8 MB) stay around for the sweep.  Same-process A/B of the train step (tools/ab_step.py, MMBERT_NT_GROUP_M): group_m =
-    //    1 / 6 / 8 / 11 / 16 / 32 / 100 -> 15.56 / 15.34 / 15.30 / 14.98 / 15.30 / 15.18 / 15.16 ms; the rule below = 11 at 18 400 rows.
+    // with MORE tiles than CUs the order inside that chunk decides which panels its 32 concurrent tiles share:
+    //  * row-major (group_m = 1): ~3 row panels x ALL column panels at a time -- a weight panel is wanted by 3 workgroups at once and the
+    //    whole weight matrix (3.5-4.7 MB at N = 2304 / 3072) passes through the 4-MiB L2 once per 3 row panels;
+    //  * one group per XCD (group_m = ceil(tiles_m / 8), round 3): the XCD sweeps the column panels with ALL its row panels, 11 row panels
+    //    x ~3 column panels at a time -- a weight panel is wanted by 11 workgroups at once and then never again on this XCD.  Same-process
+    //    A/B of the train step (tools/ab_step.py, MMBERT_NT_GROUP_M): group_m = 1 / 6 / 8 / 11 / 16 / 32 / 100 -> 15.56 / 15.34 / 15.30 /
+    //    14.98 / 15.30 / 15.18 / 15.16 ms; the rule below = 11 at 18 400 rows.  (Fetched bytes barely move -- DESIGN 3.1.)
     //  * the vocabulary projection (B = 47 MB, 9 960 tiles) keeps its groups of 4 row panels (round 2: 1 / 2 / 4 / 8 -> 871 / 855 / 844 /
-    //    875 us): its column sweep is 120 panels long, 11 row panels x 3 columns would re-stream the activations 40 times.
+    //    875 us): its column sweep is 120 panels long.
     const char* gm_s = getenv("MMBERT_NT_GROUP_M");                                                        // A/B switch, read per call
     const int gm_env = gm_s ? atoi(gm_s) : -1;
     const bool huge_b = (long long)p.N * p.K * 2 > (8ll << 20);

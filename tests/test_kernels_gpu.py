@@ -93,6 +93,18 @@ def test_gemm_nt256_exact_integers(ops, mode, M):
         lib.mmbert_gemm_nt_force(0)
 
 
+@pytest.mark.parametrize("M,N", [(18400, 2304), (14000, 3072), (5000, 3072), (9000, 1792)])
+def test_gemm_nt_grouped_tile_walk_exact(ops, M, N):
+    """More tiles than CUs: the persistent kernel walks them in one group per XCD (ceil(row tiles / 8) row panels swept over the column
+    panels, the last group short) -- every tile exactly once, checked on small integers (exact in bf16 and in the fp32 accumulators)."""
+    K = 256                                                   # (entries in {-1, 0, 1} x {0, 1}: |sums| <= 256, exact in the bf16 output too)
+    A = ((torch.arange(M)[:, None] * 5 + torch.arange(K)[None, :] * 3) % 3 - 1.0)
+    B = ((torch.arange(N)[:, None] * 2 + torch.arange(K)[None, :] * 11) % 2).float()
+    out = ops.gemm_nt(bf(A).to(DEV), bf(B).to(DEV))
+    ref = (A.to(DEV) @ B.to(DEV).t())
+    assert torch.equal(out.float(), ref)
+
+
 @pytest.mark.parametrize("M,N,K", [(300, 256, 4096), (77, 768, 30592), (130, 132, 1024)])
 def test_gemm_nt_splitk(ops, M, N, K):
     A, B = bf(rnd(M, K, seed=15, scale=0.1)), bf(rnd(N, K, seed=16, scale=0.1))
