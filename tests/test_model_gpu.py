@@ -6,6 +6,7 @@ regression logits 2e-2 absolute, MLM scores 3e-2 absolute, parameter-gradient co
 every parameter gradient within 4.5 % relative error (== cosine 0.999) of the oracle's, except
 ill-conditioned head gradients, which are bounded by 3x the deviation that bf16 STORAGE ALONE
 causes in the oracle itself (oracle.bf16_storage_emulation, a calibrator -- not a parity pin)."""
+import math
 import os
 
 import numpy as np
@@ -568,7 +569,9 @@ def test_training_without_returned_scores_equals_the_faithful_step(train):
         # activation gradient downstream is 2^-9 on that element (2.1e-3 of the largest entry seen on one weight, in suite order only).
         # So: 4e-3 of the largest entry, AND the whole tensor to 1e-3 in L2 (a wrong mask or row would move it by tens of percent)
         assert float((a - b).abs().max()) <= 4e-3 * scale + 1e-7, (n, float((a - b).abs().max()), scale)
-        assert float((a - b).norm()) <= 1e-3 * float(b.norm()) + 1e-7, (n, float((a - b).norm()), float(b.norm()))
+        # (absolute floor per ELEMENT, like the max-entry bound's: the CPC gradients at init are ~4e-8 per entry, what is left of
+        # cancelling terms, and the heads' atomics move them by as much -- a per-tensor floor made this line fail one suite run in three)
+        assert float((a - b).norm()) <= 1e-3 * float(b.norm()) + 2e-7 * math.sqrt(a.numel()), (n, float((a - b).norm()), float(b.norm()))
 
 
 def test_dropout_train_mode_is_seeded_and_unbiased():
