@@ -662,8 +662,16 @@ __global__ __launch_bounds__(512, 2) void gemm_ntp_kernel(const GemmNT p) {
     // draw of XCD x is tile number G + 8 k + x -- the same residue class the static walk gives that XCD, so xcd_remap()'s contiguous
     // chunk per XCD (and the grouped walk inside it) holds and only the order WITHIN an XCD's 32 CUs is dynamic.
     const int qx = p.queue_xcd ? (int)(blockIdx.x & 7) : 0, qs = p.queue_xcd ? 8 : 1;
+    // The fetch is an inline-asm atomic whose result is read only behind a COUNTED wait: hipcc's own atomicAdd goes through the
+    // wave-aggregation pass (s_bcnt + v_readfirstlane) and needs its result at once -- an s_waitcnt vmcnt(0) right behind the atomic,
+    // i.e. a drain of the stage loads in flight at the start of every epilogue (the dynamic queue cost 1.8 % of the step that way).
+    auto queue_fetch = [](int* counter) {
+        int r;
+        asm volatile("global_atomic_add %0, %1, %2, %3 sc0" : "=&v"(r) : "v"(0), "v"(1), "s"(counter) : "memory");
+        return r;
+    };
     if (p.tile_counter && tid == 0)
-        first_fetch = G + qs * atomicAdd(p.tile_counter + qx, 1) + qx;   // issued ahead of the prologue loads, parked behind them
+        first_fetch = queue_fetch(p.tile_counter + qx);                  // issued ahead of the prologue loads; read behind them (below)
     bf16x8 a0[MI], b0[4], a1[MI], b1[4];
     if constexpr (STAG) {
         issue(0, cur, 0); issue(1, cur, 64); issue(2, cur, 128);
@@ -743,7 +751,11 @@ __global__ __launch_bounds__(512, 2) void gemm_ntp_kernel(const GemmNT p) {
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsBias, LPTR(smem + 132096 + wave * 256), 4, l * 4, (n0 + wc * 64) * 4, 0, 0);
         }
     };
-    if (p.tile_counter && tid == 0) vq_write(first_fetch);
+    if (p.tile_counter && tid == 0) {
+        // the atomic is older than the prologue's stage loads (16 per wave, 12 in the staggered form): done once no more than those are outstanding
+        __builtin_amdgcn_s_waitcnt(mmb_waitcnt(STAG ? 12 : 16, 15));
+        vq_write(G + qs * first_fetch + qx);
+    }
     for (int v = blockIdx.x, vn = 0; v < ntiles; v = vn) {
         int tmi, tni;
         ntp_tile_mn(xcd_remap(v, ntiles), tiles_m, tiles_n, p.group_m, tmi, tni);
@@ -826,10 +838,7 @@ __global__ __launch_bounds__(512, 2) void gemm_ntp_kernel(const GemmNT p) {
         const __attribute__((address_space(4))) GemmNT& q = *(const __attribute__((address_space(4))) GemmNT*)kp;
         int fetched = 0;
         const bool fetcher = q.tile_counter && tid == 0 && vn < ntiles;     // the tile after the next one (if there is a next one)
-        if (fetcher) {
-            const int fx = q.queue_xcd ? (int)(blockIdx.x & 7) : 0;
-            fetched = G + (q.queue_xcd ? 8 : 1) * atomicAdd(q.tile_counter + fx, 1) + fx;
-        }
+        if (fetcher) fetched = queue_fetch(q.tile_counter + (q.queue_xcd ? (int)(blockIdx.x & 7) : 0));   // raw counter value, read at the end of the epilogue
         int elane = lane;
         asm volatile("" : "+v"(elane));
         const int efr = elane & 15, efq = elane >> 4;
@@ -948,7 +957,13 @@ __global__ __launch_bounds__(512, 2) void gemm_ntp_kernel(const GemmNT p) {
                 }
             }
         }
-        if (fetcher) vq_write(fetched);
+        if (fetcher) {
+            // the atomic is older than everything this epilogue issued: at least EST stores on an interior tile
+            if (interior) __builtin_amdgcn_s_waitcnt(mmb_waitcnt(EST, 15));
+            else __builtin_amdgcn_s_waitcnt(mmb_waitcnt(0, 15));
+            const int fx = q.queue_xcd ? (int)(blockIdx.x & 7) : 0;
+            vq_write(G + (q.queue_xcd ? 8 : 1) * fetched + fx);
+        }
 #ifdef MMB_STAMPS
         MMB_STAMP(sd)
         t_wait += sb - sa; t_loop += sc_ - sb; t_epi += sd - sc_; ++ntile;
