@@ -213,6 +213,13 @@ int mmbert_prologue(mmbert_stream_t stream, int nseg, const void* const* seg_ptr
                     int npass, const int* pass_len, int B, const int64_t* labels, int vocab,
                     float* key_bias, int* kv_len, int* valid, int* seq_cnt, int* idx, int* words, int* rank, float* key_bias_perm);
 
+/* Data parallel, compact exchange of the embedding lookup's row gradients (msa_amd/parallel.py::exchange_rows; there is no reference
+ * counterpart: REF:train.py:22,75 is single-GPU): block[pos(ids[i])][0..H) += rows[i], pos = index of ids[i] in the ascending list
+ * uni[0..U) (the union of touched table rows over all ranks); ids outside (0, V) or not in the list are skipped.  rows: bf16
+ * (rows_bf16 = 1) or fp32, row pitch ldr elements; block fp32 [U, H], zeroed by the caller. */
+int mmbert_rows_to_block(mmbert_stream_t stream, const int64_t* ids, const void* rows, int rows_bf16, int ldr, int n, int H,
+                         const int64_t* uni, int U, int V, float* block);
+
 /* out[dst_offset[k] + i] = src[k][i] (or fill[k] where src[k] is NULL), i < count[k], for up to 12 int64 segments in ONE launch: the
  * token ids / token types / MLM labels of a step's passes packed into the order of the token matrix (REF:trainer.py:49-64 hands
  * them over as separate tensors per pass). */

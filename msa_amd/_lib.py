@@ -65,6 +65,7 @@ SIGNATURES = {
     "mmbert_transpose_bf16": (I, [P, P, P, P, I, I]),
     "mmbert_gather_rows": (I, [P, I, P, P, P, P, P, P, I]),
     "mmbert_pack_i64": (I, [P, I, P, P, P, P, P]),
+    "mmbert_rows_to_block": (I, [P, P, P, I, I, I, I, P, I, I, P]),
     "mmbert_split_layout": (I, [P, P, P, I, I, I, I, I, P]),
 }
 

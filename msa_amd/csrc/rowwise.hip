@@ -1303,6 +1303,28 @@ static inline int grid_for(size_t work_items, int per_block, int cap = 2048) {
     return (int)(b > (size_t)cap ? cap : b);
 }
 
+// Compact exchange of embedding-row gradients (data parallel, parallel.exchange_rows): block[pos(ids[i])] += rows[i], pos = the index of
+// ids[i] in the ascending list `uni` (the union of touched table rows over all ranks); ids outside (0, V) or not in the list carry
+// nothing.  One workgroup per row, the binary search is wave-uniform; rows bf16 or fp32.  (Round 3: eleven ATen launches before.)
+__global__ __launch_bounds__(256) void rows_to_block_kernel(const int64_t* __restrict__ ids, const void* __restrict__ rows, int rows_bf16, int ldr,
+                                                            int n, int H, const int64_t* __restrict__ uni, int U, int V, float* __restrict__ block) {
+    const int i = blockIdx.x;
+    if (i >= n || U <= 0) return;
+    const long long id = ids[i];
+    if (id <= 0 || id >= V) return;
+    int lo = 0, hi = U - 1;
+    while (lo < hi) {                                          // first position with uni[pos] >= id
+        const int mid = (lo + hi) >> 1;
+        if (uni[mid] < id) lo = mid + 1; else hi = mid;
+    }
+    if (uni[lo] != id) return;
+    float* dst = block + (size_t)lo * H;
+    for (int c = threadIdx.x; c < H; c += 256) {
+        const float v = rows_bf16 ? bf2f(((const bf16_t*)rows)[(size_t)i * ldr + c]) : ((const float*)rows)[(size_t)i * ldr + c];
+        atomicAdd(dst + c, v);
+    }
+}
+
 extern "C" {
 
 uint32_t mmbert_rng_stream(uint64_t seed, uint32_t site) {
@@ -1653,6 +1675,15 @@ int mmbert_gather_rows(hipStream_t stream, int nseg, const void* const* src, voi
         a.s[k].vec16 = !((row_bytes[k] | src_pitch[k] | dst_pitch[k]) & 15) && !(((uintptr_t)src[k] | (uintptr_t)dst[k]) & 15);
     }
     hipLaunchKernelGGL(gather_rows_kernel, dim3(nrows, nseg), dim3(256), 0, stream, a, idx);
+    MMB_CHECK_LAUNCH();
+    return 0;
+}
+
+int mmbert_rows_to_block(hipStream_t stream, const int64_t* ids, const void* rows, int rows_bf16, int ldr, int n, int H,
+                         const int64_t* uni, int U, int V, float* block) {
+    if (n <= 0 || U <= 0) return 0;
+    if (!ids || !rows || !uni || !block || H <= 0 || ldr < H) return -1;
+    hipLaunchKernelGGL(rows_to_block_kernel, dim3(n), dim3(256), 0, stream, ids, rows, rows_bf16, ldr, n, H, uni, U, V, block);
     MMB_CHECK_LAUNCH();
     return 0;
 }

@@ -297,6 +297,17 @@ def embed_gather(ids, tts, word, type_, pos, T, out=None):
     return out
 
 
+def rows_to_block(ids, rows, union, vocab, block):
+    """block[pos(ids[i])] += rows[i] with pos = the index of ids[i] in the ascending int64 list ``union`` (mmbert_rows_to_block): the
+    local side of the data-parallel compact row exchange.  ids outside (0, vocab) or not in the list are skipped."""
+    ids = ids.reshape(-1).long().contiguous()
+    union = union.long().contiguous()
+    _lib.check(_lib.load().mmbert_rows_to_block(_stream(), ids.data_ptr(), rows.data_ptr(), 1 if rows.dtype == torch.bfloat16 else 0, rows.stride(0),
+                                                ids.numel(), rows.shape[1], union.data_ptr(), union.numel(), int(vocab), block.data_ptr()),
+               "mmbert_rows_to_block")
+    return block
+
+
 def embed_scatter(ids, tts, d, T, gword, gtype, gpos, vocab=None):
     """``gword`` None: position and token-type gradients only (the word rows are exchanged in compact form: parallel.DataParallel)."""
     lib = _lib.load()

@@ -304,9 +304,13 @@ def exchange_rows(ids: torch.Tensor, rows: torch.Tensor, vocab: int, group=None,
         union = gather_union(ids, vocab, group)
     block = torch.zeros((union.numel(), rows.shape[1]), device=rows.device, dtype=torch.float32)
     if union.numel():
-        mine = (ids > 0) & (ids < vocab)
-        pos = torch.searchsorted(union, ids.clamp(0, vocab - 1)).clamp(max=union.numel() - 1)
-        block.index_add_(0, pos, rows.to(torch.float32) * mine[:, None].to(torch.float32))
+        if rows.is_cuda and rows.dtype in (torch.bfloat16, torch.float32) and rows.stride(1) == 1:
+            from . import ops                                  # one kernel (mmbert_rows_to_block) for the eleven launches of the torch form
+            ops.rows_to_block(ids, rows, union, vocab, block)
+        else:
+            mine = (ids > 0) & (ids < vocab)
+            pos = torch.searchsorted(union, ids.clamp(0, vocab - 1)).clamp(max=union.numel() - 1)
+            block.index_add_(0, pos, rows.to(torch.float32) * mine[:, None].to(torch.float32))
         dist.all_reduce(block, op=dist.ReduceOp.SUM, group=group)
     return union, block
 

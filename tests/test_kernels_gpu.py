@@ -242,6 +242,28 @@ def test_gemm_tn_tied_vocab_rows(ops):
     assert_close(W, A.float().t() @ B.float(), 2e-3, 5e-2, "vocab rows")
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_rows_to_block_equals_the_torch_form(ops, dtype):
+    """mmbert_rows_to_block (the local side of the data-parallel compact row exchange) against searchsorted + index_add: duplicates,
+    the padding row 0, ids past the vocabulary and ids that are not in the union are all in the batch."""
+    V, H, n = 500, 768, 2400
+    g = torch.Generator().manual_seed(3)
+    ids = torch.randint(0, V + 40, (n,), generator=g)
+    ids[:5] = torch.tensor([0, 7, 7, V, V + 3])
+    rows = torch.randn(n, H, generator=g).to(dtype)
+    other = torch.randint(1, V, (300,), generator=g)
+    keep = (ids > 0) & (ids < V)
+    union = torch.unique(torch.cat((ids[keep][::2], other)))          # every second local row is NOT in the list
+    block = torch.zeros(union.numel(), H, device=DEV)
+    ops.rows_to_block(ids.to(DEV), rows.to(DEV), union.to(DEV), V, block)
+    ref = torch.zeros(union.numel(), H)
+    pos = torch.searchsorted(union, ids.clamp(0, V - 1)).clamp(max=union.numel() - 1)
+    hit = keep & (union[pos] == ids)
+    ref.index_add_(0, pos[hit], rows[hit].float())
+    assert_close(block, ref, 1e-5, 1e-5, "rows_to_block")
+    assert float(block.abs().sum()) > 0
+
+
 def test_colsum(ops):
     X = bf(rnd(1234, 768, seed=25))
     out = torch.ones(768, device=DEV)
