@@ -754,6 +754,7 @@ __global__ __launch_bounds__(512, 2) void gemm_ntp_kernel(const GemmNT p) {
     if (p.tile_counter && tid == 0) {
         // the atomic is older than the prologue's stage loads (16 per wave, 12 in the staggered form): done once no more than those are outstanding
         __builtin_amdgcn_s_waitcnt(mmb_waitcnt(STAG ? 12 : 16, 15));
+        asm volatile("" : "+v"(first_fetch) :: "memory");          // (the register holds the counter only behind the wait: no use may move above it)
         vq_write(G + qs * first_fetch + qx);
     }
     for (int v = blockIdx.x, vn = 0; v < ntiles; v = vn) {
@@ -961,6 +962,7 @@ __global__ __launch_bounds__(512, 2) void gemm_ntp_kernel(const GemmNT p) {
             // the atomic is older than everything this epilogue issued: at least EST stores on an interior tile
             if (interior) __builtin_amdgcn_s_waitcnt(mmb_waitcnt(EST, 15));
             else __builtin_amdgcn_s_waitcnt(mmb_waitcnt(0, 15));
+            asm volatile("" : "+v"(fetched) :: "memory");         // (as above)
             const int fx = q.queue_xcd ? (int)(blockIdx.x & 7) : 0;
             vq_write(G + (q.queue_xcd ? 8 : 1) * fetched + fx);
         }
