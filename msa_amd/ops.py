@@ -57,7 +57,8 @@ _tile_queues = {}
 # otherwise idle GPU the static schedule is the faster one -- round 2, same-process A/B of the train step, after the grouped walk
 # of the vocabulary projection went in: static 15.99 ms, per-XCD queue 16.06 (+0.4 %), ONE global counter 16.22 (+1.5 %: any CU
 # takes the next tile, the XCD's L2 loses its panels -- that kernel's fetch 1.27 -> 4.2 GB, 750 -> 940 us) -- so it is off by
-# default there.  MMBERT_NT_DYNAMIC=1 turns it on everywhere.
+# default there.  (Round 3: the queue's fetch no longer drains the load queue -- csrc/gemm.hip, queue_fetch -- and the same A/B reads
+# static 14.47 / per-XCD queue 14.47 ms: the queue is free now; the default stays static.)  MMBERT_NT_DYNAMIC=1 turns it on everywhere.
 dynamic_tile_queue = bool(int(__import__("os").environ.get("MMBERT_NT_DYNAMIC", "0")))
 
 

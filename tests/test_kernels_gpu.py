@@ -105,6 +105,28 @@ def test_gemm_nt_grouped_tile_walk_exact(ops, M, N):
     assert torch.equal(out.float(), ref)
 
 
+def test_gemm_nt_dynamic_tile_queue_is_bit_identical(ops):
+    """The persistent kernel drawing its tiles from the device-side queue (what DataParallel switches on for N > 1) against the
+    static walk: same tiles, same bits -- three launches in a row on one queue buffer (the last workgroup out hands it back
+    zeroed), a multi-round shape with a ragged last row panel and a bias + GELU epilogue with its second output."""
+    import msa_amd.ops as O
+    M, N, K = 18400 - 37, 3072, 768
+    A, B, bias = bf(rnd(M, K, seed=301, scale=0.1)).to(DEV), bf(rnd(N, K, seed=302, scale=0.1)).to(DEV), rnd(N, seed=303).to(DEV)
+    was = O.dynamic_tile_queue
+    try:
+        O.dynamic_tile_queue = False
+        aux0 = torch.empty((M, N), device=DEV, dtype=torch.bfloat16)
+        ref = ops.gemm_nt(A, B, bias=bias, gelu=True, aux=aux0)
+        O.dynamic_tile_queue = True
+        for rep in range(3):
+            aux1 = torch.empty((M, N), device=DEV, dtype=torch.bfloat16)
+            out = ops.gemm_nt(A, B, bias=bias, gelu=True, aux=aux1)
+            assert torch.equal(out, ref) and torch.equal(aux1, aux0), rep
+    finally:
+        O.dynamic_tile_queue = was
+    assert_close(ref, torch.nn.functional.gelu(A.float() @ B.float().t() + bias), 2e-2, 2e-2, "queue launch vs torch")
+
+
 @pytest.mark.parametrize("M,N,K", [(300, 256, 4096), (77, 768, 30592), (130, 132, 1024)])
 def test_gemm_nt_splitk(ops, M, N, K):
     A, B = bf(rnd(M, K, seed=15, scale=0.1)), bf(rnd(N, K, seed=16, scale=0.1))
