@@ -9,7 +9,7 @@ from msa_amd import ops
 dev = "cuda"
 blk = torch.randn(8192, 8192, device=dev).bfloat16()
 def timeit(fn, n=20):
-    for _ in range(3): fn()
+    for _ in range(25): fn()                                  # (the first timed configuration of a process reads ~20 us high after only 3)
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     for _ in range(4): torch.mm(blk, blk)
