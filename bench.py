@@ -81,6 +81,11 @@ def main():
     ap.add_argument("--no-early-word", action="store_true", help="A/B: the word-embedding table's gradient reduced with the tail (round-2 form)")
     ap.add_argument("--sync-prologue", action="store_true", help="A/B: the step prologue on the compute stream (model.async_prologue = False)")
     ap.add_argument("--scores-fp32", action="store_true", help="return the prediction scores as fp32 (model.scores_dtype = torch.float32)")
+    ap.add_argument("--no-reference-default", action="store_true", help="skip the secondary measurement of the reference's own default model "
+                    "(bert-large: 24-layer d=1024, T=P=40, batch 32: REF:train.py:28,32,38)")
+    ap.add_argument("--preset", choices=["headline", "reference-default"], default="headline",
+                    help="reference-default: measure ONLY the reference's default model and print its record (tools; never the driver's line)")
+    ap.add_argument("--rank-report", action="store_true", help="N > 1 diagnostics even on one process: per-rank step times, exposed tail (on by default for N > 1)")
     a = ap.parse_args()
 
     from msa_amd import ops, parallel
@@ -95,11 +100,58 @@ def main():
         sys.stdout.flush()
         saved_stdout = os.dup(1)
         os.dup2(2, 1)
+    rccl_log = None
+    if (int(os.environ.get("WORLD_SIZE", 1)) > 1 or a.force_dp) and "NCCL_DEBUG" not in os.environ:
+        # N > 1 must be diagnosable from ONE run: RCCL's own account of what it built (rings / trees, channels, transport per peer) and
+        # of what it picked per message size (algorithm / protocol / channels) goes to a per-process file; rank 0 condenses it into
+        # config.dp.rccl and onto stderr at the end (the full file stays in /tmp)
+        rccl_log = f"/tmp/mmbert_rccl_{os.getpid()}.log"
+        os.environ.update(NCCL_DEBUG="INFO", NCCL_DEBUG_SUBSYS=os.environ.get("NCCL_DEBUG_SUBSYS", "INIT,GRAPH,TUNING"), NCCL_DEBUG_FILE=rccl_log)
     rank, local, world = parallel.init_from_env(force=a.force_dp)
     if world != a.gpus:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {a.gpus}")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+
+    timing = {"nt": [], "tn": [], "attn_fwd": [], "attn_bwd": []}
+    record = [False]
+
+    def wrap(name, fn, flop_fn, shape_fn=None):
+        def inner(*args, **kw):
+            if not record[0]:
+                return fn(*args, **kw)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            out = fn(*args, **kw)
+            e1.record()
+            timing[name].append((flop_fn(*args, **kw), e0, e1, shape_fn(*args, **kw) if shape_fn else None))
+            return out
+        return inner
+
+    if not a.no_kernel_timing:
+        ops.gemm_nt = wrap("nt", ops.gemm_nt, lambda A, B, **kw: 2.0 * A.shape[0] * A.shape[1] * B.shape[0],
+                           lambda A, B, **kw: (A.shape[0], B.shape[0], A.shape[1]))
+        ops.gemm_tn = wrap("tn", ops.gemm_tn, lambda A, B, W, **kw: 2.0 * A.shape[0] * A.shape[1] * B.shape[1])
+        ops.gemm_tn_grouped = wrap("tn", ops.gemm_tn_grouped, lambda probs, **kw: sum(2.0 * p[0].shape[0] * p[0].shape[1] * p[1].shape[1] for p in probs))
+        # executed attention FLOPs: with the valid-first packing forward visits all queries x the unmasked keys, backward the
+        # unmasked rows only (lay.valid_host); otherwise the full S x S
+        def attn_fl(lay, bwd):
+            v = getattr(lay, "valid_host", None)
+            if v is None:
+                return sum(4.0 * n * n * 64 * lay.heads for n in lay.lens)
+            return sum(4.0 * (k if bwd else n) * k * 64 * lay.heads for n, k in zip(lay.lens, v))
+        ops.attn_fwd = wrap("attn_fwd", ops.attn_fwd, lambda qkv, kb, lay, H, **kw: attn_fl(lay, False))
+        ops.attn_bwd = wrap("attn_bwd", ops.attn_bwd, lambda qkv, c, d, l, kb, lay, H, **kw: 2.5 * attn_fl(lay, True))
+
+    if a.preset == "reference-default":
+        rec = reference_default_leg(a, dev, ops, wrap_state=(timing, record))
+        if saved_stdout is not None:
+            if torch.distributed.is_initialized():
+                torch.distributed.destroy_process_group()
+            sys.stdout.flush()
+            os.dup2(saved_stdout, 1)
+        print(json.dumps(rec), flush=True)
+        return
 
     H, L, I, V = a.hidden, a.layers, 4 * a.hidden, a.vocab
     torch.manual_seed(0)
@@ -123,46 +175,25 @@ def main():
     targs = default_args(train_batch_size=a.batch, learning_rate=5e-5)
     opt, sched = build_optimizer(model, targs, num_train_optimization_steps=10 * (a.steps + a.warmup))
     dp = (parallel.DataParallel(model, opt, bucket_mb=a.bucket_mb, force_dynamic_queue=a.force_dp, wire_dtype=torch.bfloat16 if a.dp_wire == "bf16" else None,
-                                early_word_embedding=not a.no_early_word) if (world > 1 or a.force_dp) else None)
+                                early_word_embedding=not a.no_early_word, equal_batch_shapes=True) if (world > 1 or a.force_dp) else None)
     pool = [batch_to(synthetic_batch(a.batch, a.text, a.pair, a.pair, vocab=V, seed=1 + i + 1000 * rank), dev) for i in range(4)]
 
-    timing = {"nt": [], "tn": [], "attn_fwd": [], "attn_bwd": []}
-    record = [False]
-
-    def wrap(name, fn, flop_fn):
-        def inner(*args, **kw):
-            if not record[0]:
-                return fn(*args, **kw)
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            out = fn(*args, **kw)
-            e1.record()
-            timing[name].append((flop_fn(*args, **kw), e0, e1))
-            return out
-        return inner
-
-    if not a.no_kernel_timing:
-        ops.gemm_nt = wrap("nt", ops.gemm_nt, lambda A, B, **kw: 2.0 * A.shape[0] * A.shape[1] * B.shape[0])
-        ops.gemm_tn = wrap("tn", ops.gemm_tn, lambda A, B, W, **kw: 2.0 * A.shape[0] * A.shape[1] * B.shape[1])
-        ops.gemm_tn_grouped = wrap("tn", ops.gemm_tn_grouped, lambda probs, **kw: sum(2.0 * p[0].shape[0] * p[0].shape[1] * p[1].shape[1] for p in probs))
-        # executed attention FLOPs: with the valid-first packing forward visits all queries x the unmasked keys, backward the
-        # unmasked rows only (lay.valid_host); otherwise the full S x S
-        def attn_fl(lay, bwd):
-            v = getattr(lay, "valid_host", None)
-            if v is None:
-                return sum(4.0 * n * n * 64 * lay.heads for n in lay.lens)
-            return sum(4.0 * (k if bwd else n) * k * 64 * lay.heads for n, k in zip(lay.lens, v))
-        ops.attn_fwd = wrap("attn_fwd", ops.attn_fwd, lambda qkv, kb, lay, H, **kw: attn_fl(lay, False))
-        ops.attn_bwd = wrap("attn_bwd", ops.attn_bwd, lambda qkv, c, d, l, kb, lay, H, **kw: 2.5 * attn_fl(lay, True))
-
     row_frac = []
+    tail_events = []       # instrumented leg only: (before, after) finish_backward on the compute stream = the EXPOSED part of the exchange
 
     def step(i):
         out, _ = model(**pool[i % len(pool)])
         out[0].mean().backward()
         row_frac.append(getattr(model, "last_backward_row_fraction", 1.0))      # (known on the host once backward has sized its launches)
         if dp is not None:
-            dp.finish_backward()
+            if record[0]:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                dp.finish_backward()
+                e1.record()
+                tail_events.append((e0, e1))
+            else:
+                dp.finish_backward()
         opt.step()
         sched.step()
         opt.zero_grad()
@@ -181,9 +212,20 @@ def main():
     for i in range(a.steps):
         last = step(a.warmup + i)
     torch.cuda.synchronize()
+    own_done = time.perf_counter() - t0                   # this rank's GPU is done (the contract's value is taken behind the barrier)
     barrier()
     elapsed = time.perf_counter() - t0
     main_row_frac = row_frac[-a.steps:]                   # (the secondary loops below append their own)
+    per_rank_ms = None
+    if world > 1 or a.rank_report:
+        # per-rank view of the SAME region: when this rank's GPU finished its K steps (before the barrier), i.e. who the others waited for
+        t_own = torch.tensor([own_done], device=dev, dtype=torch.float64)
+        if world > 1:
+            allt = [torch.zeros_like(t_own) for _ in range(world)]
+            torch.distributed.all_gather(allt, t_own)
+            per_rank_ms = [round(1e3 * float(x) / a.steps, 3) for x in allt]
+        else:
+            per_rank_ms = [round(1e3 * own_done / a.steps, 3)]
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
@@ -289,6 +331,12 @@ def main():
                  "seq_len": S, "tflop_per_sample": round(ffl / 1e12, 4),
                  "note": "declared extension (one pass over text|visual|speech; not in the reference, no reference parity): model.forward_fused"}
 
+    # Secondary: the reference's OWN default model (REF:train.py:28,32,38,70 -- bert-large-uncased: 24 layers, d = 1024, 16 heads, I = 4096,
+    # max_seq_length 40, pair length == text length, train_batch_size 32), same train step.  Never the headline (BASELINE.json quotes d = 768).
+    ref_default = None
+    if not a.no_reference_default and world == 1 and dp is None:
+        ref_default = reference_default_leg(a, dev, ops, wrap_state=(timing, record))
+
     samples = a.steps * a.batch * world
     value = samples / elapsed
     fps = 3.0 * flops_per_sample(L, H, I, V, a.text, a.pair, a.pair)
@@ -321,13 +369,19 @@ def main():
                                "gemm_tile_queue": "dynamic, one counter per XCD", "bucket_mb": a.bucket_mb, "wire_dtype": a.dp_wire,
                                "word_embedding_table": ("reduced right after the MLM head's backward; lookup rows exchanged in compact form"
                                                         if dp.early_word else "with the tail"),
-                               "all_reduce_calls_per_step": dp.bucketer.calls_per_step if hasattr(dp.bucketer, "calls_per_step") else None}
+                               "all_reduce_calls_per_step": dp.bucketer.calls_per_step if hasattr(dp.bucketer, "calls_per_step") else None,
+                               "per_rank_ms_per_step": per_rank_ms,
+                               "exposed_tail_us": exposed_tail(tail_events, world, dev),
+                               "exposed_tail_note": "GPU time of the compute stream inside finish_backward() (instrumented leg): what of the "
+                                                    "gradient exchange is NOT hidden under backward -- the last bucket, the compact row exchange, the waits"}
     if dense_ref is not None:
         res["dense_backward_reference"] = dense_ref
     if train_only is not None:
         res["train_only"] = train_only
     if fused is not None:
         res["fused1050"] = fused
+    if ref_default is not None:
+        res["reference_default"] = ref_default
     if saved_stdout is not None:
         import ctypes
         if torch.distributed.is_initialized():
@@ -337,13 +391,15 @@ def main():
         ctypes.CDLL(None).fflush(None)
         os.dup2(saved_stdout, 1)
         os.close(saved_stdout)
+    if dp is not None and rccl_log is not None and rank == 0:
+        res["config"]["dp"]["rccl"] = rccl_summary(rccl_log)
     if rank == 0:
         if not a.no_kernel_timing and timing["nt"]:
             kern = {}
             for k, lst in timing.items():
                 if lst:
-                    ms = sum(e0.elapsed_time(e1) for _, e0, e1 in lst)
-                    fl = sum(f for f, _, _ in lst)
+                    ms = sum(e0.elapsed_time(e1) for _, e0, e1, _ in lst)
+                    fl = sum(f for f, _, _, _ in lst)
                     kern[k] = (fl, ms, len(lst))
             fl, ms, n = kern["nt"]
             ach = fl / (ms * 1e-3) / 1e12
@@ -365,6 +421,109 @@ def main():
         if world == 1 and not a.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(a, L, H, I, V)
         print(json.dumps(res), flush=True)
+
+
+def reference_default_leg(a, dev, ops, wrap_state):
+    """The reference's default configuration (bert-large, T = P = 40, batch 32) through the same train step: samples/s, the persistent NT
+    family's in-situ rate at its {1024, 3072, 4096} shapes (HIP events, a second pass like the headline's roofline leg) and which
+    kernel / tile / tile walk every shape was dispatched to (mmbert_gemm_nt_describe)."""
+    from msa_amd.data import synthetic_batch, batch_to
+    from msa_amd.model import MMBertConfig, MMBertForPretraining
+    from msa_amd.trainer import build_optimizer, default_args
+    timing, record = wrap_state
+    L, H, heads, I, V, T, B = 24, 1024, 16, 4096, a.vocab, 40, 32
+    torch.manual_seed(0)
+    model = MMBertForPretraining(MMBertConfig(vocab_size=V, hidden_size=H, num_hidden_layers=L, num_attention_heads=heads, intermediate_size=I))
+    model.bert.set_joint_embeddings("mosei")
+    model.set_alpha_beta(1.0, 1.0)
+    model.to(dev)
+    model.train()
+    model.manual_seed(4321)
+    model.async_prologue = not a.sync_prologue
+    steps, warm = max(4, a.steps // 2), min(a.warmup, 3) + 1
+    opt, sched = build_optimizer(model, default_args(train_batch_size=B, learning_rate=5e-5), 10 * (2 * steps + warm))
+    pool = [batch_to(synthetic_batch(B, T, T, T, vocab=V, seed=50 + i), dev) for i in range(4)]
+
+    def step(i):
+        out, _ = model(**pool[i % len(pool)])
+        out[0].mean().backward()
+        opt.step(); sched.step(); opt.zero_grad()
+        return out[0]
+    for i in range(warm):
+        step(i)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        last = step(i)
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    rec = {"value": round(steps * B / el, 2), "unit": "samples/s", "ms_per_step": round(1e3 * el / steps, 3), "steps": steps,
+           "final_loss": round(float(last), 4),
+           "workload": f"REF:train.py:28,32,38 defaults: bert-large ({L}-layer d={H} heads={heads} I={I}), T=P={T} (S = {T}/{2 * T}/{2 * T}), batch {B}, "
+                       "train mode (dropout on), AdamW; pair-position MLM labels = copy of the text labels (REF:trainer.py:50,53)"}
+    S3 = T + 4 * T
+    fwd = 2 * S3 * L * (4 * H * H + 2 * H * I) + 4 * (T * T + 2 * (2 * T) ** 2) * H * L + 2 * S3 * H * H + 2 * S3 * H * V + 2 * T * (35 + 74) * H
+    rec["tflop_per_sample"] = round(3.0 * fwd / 1e12, 4)
+    rec["step_mfma_frac_dense"] = round(3.0 * fwd * rec["value"] / 2.5e15, 4)
+    if not a.no_kernel_timing:
+        marks = {k: len(v) for k, v in timing.items()}
+        mark = marks["nt"]
+        record[0] = True
+        for i in range(steps):
+            step(i)
+        torch.cuda.synchronize()
+        record[0] = False
+        by = {}
+        for fl, e0, e1, shp in timing["nt"][mark:]:
+            d = by.setdefault((shp[1], shp[2]), [0.0, 0.0, 0, 0])
+            d[0] += fl; d[1] += e0.elapsed_time(e1); d[2] += 1; d[3] = max(d[3], shp[0])
+        for k, n0 in marks.items():                              # (the headline's roofline records stay what they were)
+            del timing[k][n0:]
+        shapes = {}
+        tot_f = tot_ms = 0.0
+        for (N, K), (fl, ms, n, M) in sorted(by.items()):
+            big = ops.gemm_nt_describe(M, N, K)
+            if big["kernel"] != "persistent":
+                continue
+            tot_f += fl; tot_ms += ms
+            shapes[f"N{N}_K{K}"] = {"launches_per_step": round(n / steps, 1), "rows_max": M, "avg_us": round(1e3 * ms / n, 1),
+                                    "tflops": round(fl / (ms * 1e-3) / 1e12, 1), "dispatch": big}
+        if tot_ms:
+            rec["gemm_ntp"] = {"achieved": round(tot_f / (tot_ms * 1e-3) / 1e12, 1), "frac": round(tot_f / (tot_ms * 1e-3) / 2.5e15, 4), "shapes": shapes}
+    del model, opt, pool
+    torch.cuda.empty_cache()
+    return rec
+
+
+def exposed_tail(events, world, dev):
+    """Mean GPU microseconds inside finish_backward() per step, per rank (list over ranks)."""
+    if not events:
+        return None
+    torch.cuda.synchronize()
+    us = 1e3 * sum(e0.elapsed_time(e1) for e0, e1 in events) / len(events)
+    if world > 1:
+        t = torch.tensor([us], device=dev, dtype=torch.float64)
+        allt = [torch.zeros_like(t) for _ in range(world)]
+        torch.distributed.all_gather(allt, t)
+        return [round(float(x), 1) for x in allt]
+    return [round(us, 1)]
+
+
+def rccl_summary(path, limit=24):
+    """RCCL's own INFO lines, condensed: how many channels / rings / trees it built, the transports per peer, and the distinct
+    (collective, algorithm, protocol, channels) choices it logged -- also echoed to stderr so that the driver's log carries them."""
+    import re
+    try:
+        lines = open(path, errors="replace").read().splitlines()
+    except OSError as e:
+        return {"error": str(e)}
+    pick = [l for l in lines if re.search(r"(Channel \d+/\d+ *:|Ring \d+ *:|Trees? |nChannels|via P2P|via SHM|via NET|Algo|algorithm|protocol|Using network|comm 0x.* rank .* nranks|Connected all)", l)]
+    tuning = sorted({re.sub(r"^.*?NCCL INFO ", "", l) for l in lines if "TUNING" in l or re.search(r"(AllReduce|AllGather|AllToAll|ReduceScatter|Broadcast).*(Algo|algo|proto)", l)})
+    out = {"log": path, "lines": len(lines), "channels": len({m.group(1) for l in lines for m in [re.search(r"Channel (\d+)/\d+", l)] if m}),
+           "p2p_links": sum("via P2P" in l for l in lines), "shm_links": sum("via SHM" in l for l in lines),
+           "choices": tuning[:limit], "init": [re.sub(r"^.*?NCCL INFO ", "", l) for l in pick[:limit]]}
+    print("[bench] RCCL summary:", json.dumps(out)[:4000], file=sys.stderr, flush=True)
+    return out
 
 
 def csrc_digest():

@@ -12,7 +12,7 @@
  *     before capturing a graph), a cached CU count per device, and the two test / A-B knobs mmbert_gemm_nt_force and
  *     mmbert_gemm_tn_force_splits (atomics, default 0 = choose by shape; every choice computes the same product), and the
  *     measurement switches read from the environment once per process -- schedule choices only, the results do not depend
- *     on them: MMBERT_NT_GROUP_M, MMBERT_NT_QUEUE_GLOBAL, MMBERT_NT_TALL (tile walk / queue / tile height of the persistent GEMM),
+ *     on them: MMBERT_NT_GROUP_M, MMBERT_NT_GM_TABLE, MMBERT_NT_QUEUE_GLOBAL, MMBERT_NT_TALL (tile walk / queue / tile height of the persistent GEMM),
  *     MMBERT_LN_ROWS, MMBERT_LN_BWD_ROWS, MMBERT_LN_BWD_BLOCKS, MMBERT_LN_NV4 (LayerNorm rows per wave / grid / register sizing),
  *     MMBERT_ATTN_HEAD_FAST (grid order of the attention kernels; read per call), MMBERT_ATTN_EXTRA_LDS (occupancy experiments).
  * bf16 tensors are row-major `uint16` storage; "ld*" are leading dimensions in elements.
@@ -61,6 +61,12 @@ size_t mmbert_gemm_nt_splitk_workspace(int M, int N, int K);
  * with the tile height (256 or 224 rows) chosen by tile-round count, 3 = ring kernel 256x256, 4 = ring kernel
  * 224x256.  For tests and A/B benchmarking; results are identical up to fp32 summation order. */
 void mmbert_gemm_nt_force(int mode);
+/* Which kernel mmbert_gemm_nt launches for a shape on the current device (contiguous operands), without launching anything:
+ * out[0] kernel (0: 128x128-tile kernel, 1: 4-slot-ring kernel, one launch slot per tile, 2: persistent stream kernel), out[1] tile
+ * rows (128 / 224 / 256), out[2] tile columns, out[3] output tiles, out[4] workgroups launched, out[5] tile rounds x 100 over the
+ * device's CUs, out[6] group_m of the tile walk, out[7] CUs.  with_queue: as if a tile_queue were passed.  Host-only; bench.py
+ * reports it per shape of the reference's default model (REF:train.py:28,32,38), tests pin the headline shapes. */
+int mmbert_gemm_nt_describe(int M, int N, int K, int epi, int with_queue, int* out);
 /* Split count of the token axis in mmbert_gemm_tn / _grouped: 0 = by shape (default), > 0 forced.  A/B benchmarking. */
 void mmbert_gemm_tn_force_splits(int splits);
 

@@ -17,6 +17,7 @@ P, I, F, U32, SZ, U64 = C.c_void_p, C.c_int, C.c_float, C.c_uint32, C.c_size_t, 
 SIGNATURES = {
     "mmbert_gemm_nt": (I, [P, P, I, P, I, P, I, I, I, I, I, P, P, I, P, I, P, I, F, P, U32, U32, F, P]),
     "mmbert_gemm_nt_force": (None, [I]),
+    "mmbert_gemm_nt_describe": (I, [I, I, I, I, I, P]),
     "mmbert_gemm_nt_splitk": (I, [P, P, I, P, I, P, I, I, I, I, P, P, I]),
     "mmbert_gemm_nt_splitk_workspace": (SZ, [I, I, I]),
     "mmbert_gemm_tn_force_splits": (None, [I]),

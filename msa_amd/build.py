@@ -15,6 +15,15 @@ LIB = os.path.join(HERE, "libmmbert_hip.so")
 SOURCES = ["gemm.hip", "attention.hip", "rowwise.hip", "heads.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffast-math", "-fno-finite-math-only"]
+EXTRA = os.environ.get("MMBERT_HIPCC_FLAGS", "").split()
+
+
+def _check_defines(flags) -> None:
+    """The product library knows no -DMMB_* switch at all (MMB_STAMPS belongs to tools/stamp_*.py's own builds, the round-3
+    ablation switches to git tag r3-gemm-ablations): a typo must not yield a silently different library."""
+    bad = [f for f in flags if f.startswith("-DMMB_")]
+    if bad:
+        raise RuntimeError(f"msa_amd.build: refusing diagnostic defines in a product build: {bad}")
 
 
 def needs_build() -> bool:
@@ -28,13 +37,14 @@ def needs_build() -> bool:
 def build(force: bool = False, verbose: bool = True) -> str:
     if not force and not needs_build():
         return LIB
+    _check_defines([*FLAGS, *EXTRA, *os.environ.get("HIPCC_COMPILE_FLAGS_APPEND", "").split()])
     objs = []
     os.makedirs(os.path.join(HERE, "_obj"), exist_ok=True)
     procs = []
     for s in SOURCES:
         o = os.path.join(HERE, "_obj", s.replace(".hip", ".o"))
         objs.append(o)
-        cmd = [HIPCC, *FLAGS, "-c", os.path.join(CSRC, s), "-o", o]
+        cmd = [HIPCC, *FLAGS, *EXTRA, "-c", os.path.join(CSRC, s), "-o", o]
         if verbose:
             print(" ".join(cmd), flush=True)
         procs.append(subprocess.Popen(cmd))

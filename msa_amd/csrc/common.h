@@ -3,6 +3,14 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+// The only diagnostic switch the product sources know is MMB_STAMPS (tools/stamp_*.py: s_memtime stamps, never the shipped library).
+// The round-3 timing-only ablation switches of the NT GEMM's K step computed WRONG outputs by construction; they live on the git tag
+// r3-gemm-ablations and are refused here so that a stray -D can never produce a silently wrong product build.
+#if defined(MMB_EXP_NOMFMA) || defined(MMB_EXP_ALOADS) || defined(MMB_EXP_NOBLOADS) || defined(MMB_EXP_EXEC0) || defined(MMB_EXP_WAVEA) || \
+    defined(MMB_EXP_NOFRAGS) || defined(MMB_AB_FREE_HASH)
+#error "MMB_EXP_* / MMB_AB_* ablation switches are not part of the product sources (see git tag r3-gemm-ablations)"
+#endif
+
 typedef __bf16 bf16_t;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
@@ -66,9 +74,8 @@ __host__ __device__ __forceinline__ uint32_t mmb_hash32(uint32_t x) {
 // seed = pair_idx * MMB_WEYL + stream is linear in the index: callers that walk an index grid keep a per-lane seed and add
 // (wave-uniform) multiples of MMB_WEYL instead of multiplying per pair
 __host__ __device__ __forceinline__ uint32_t mmb_pair_mix(uint32_t x) {
-#ifdef MMB_AB_FREE_HASH          // timing experiment only (tools/ab_attn.py): what the attention kernels would gain from a free hash
-    return x;
-#endif
+    // (round 2 timed a "free hash" build of this function -- return x -- as an upper bound for any cheaper generator: attention forward
+    // -10.6 %, backward -6.2 %; that switch is gone from the product source, see the #error at the top)
     // both folds shift by 16: hipcc emits each as ONE v_xor_b32_sdwa (src1_sel:WORD_1) -- round 2's first fold (>> 15) was a shift
     // plus an xor, one VALU instruction more per element pair in every dropout site (round 3: attention forward 330 -> 314 VALU
     // instructions per 64-key tile and wave)

@@ -15,6 +15,9 @@
 // column, i.e. a column of the row-major LDS tile: ds_read_b64_tr_b16 (hardware transpose read).
 #include "common.h"
 #include <atomic>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
 #include <type_traits>
 
 #define EPI_BIAS 1
@@ -342,13 +345,6 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(const GemmNT p) {
         for (int i = 0; i < MI; ++i) af[i] = *(const bf16x8*)(a_rd + slot * 32768 + i * 1024);
     };
     auto mma = [&](const bf16x8 (&af)[MI], const bf16x8 (&bfr)[4]) {
-#ifdef MMB_EXP_NOMFMA
-#pragma unroll
-        for (int i = 0; i < MI; ++i) asm volatile("" :: "v"(af[i]));   // (ablation: no MFMAs; the fragments stay live)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) asm volatile("" :: "v"(bfr[j]));
-        return;
-#endif
 #pragma unroll
         for (int i = 0; i < MI; ++i)
 #pragma unroll
@@ -493,17 +489,9 @@ __device__ __forceinline__ void lds_read16f(f32x4& dst, uint32_t lds_addr) {
 //              of stage s+1 (phase a of step s+1, either group) has passed a barrier that pairs with or follows it.
 //         WAR: stage s+3 goes into the slot of stage s-1, whose last reads (phase b of step s-1) completed before their
 //              MFMAs, i.e. before that phase's second barrier in BOTH groups; phase b of step s lies behind it for both.
-// timing-only ablations of the K step (stamped builds only, tools/stamp_gemm.py STAMP_VARIANT=...): outputs wrong by construction
-#ifdef MMB_EXP_ALOADS
-#define NTP_ALOADS MMB_EXP_ALOADS
-#else
-#define NTP_ALOADS 2
-#endif
-#ifdef MMB_EXP_NOBLOADS
-#define NTP_BLOADS 0
-#else
-#define NTP_BLOADS 1
-#endif
+// (The timing-only ablations of this K step -- MFMAs / fragment reads / A or B loads switched off at compile time, EXEC = 0 loads, a
+// wave-uniform run-time branch around the A loads: DESIGN 3.1, profiles/r3_stamp_nt_ablation.log -- live on the git tag
+// r3-gemm-ablations, not in the product source; common.h refuses their -D switches.)
 template <int EPI, int MI, bool STAG>
 __global__ __launch_bounds__(512, 2) void gemm_ntp_kernel(const GemmNT p) {
 #if __HIP_DEVICE_COMPILE__   // the host pass only needs the launch stub (the body uses device-only builtins)
@@ -560,33 +548,15 @@ __global__ __launch_bounds__(512, 2) void gemm_ntp_kernel(const GemmNT p) {
     const auto rsB = __builtin_amdgcn_make_buffer_rsrc((void*)p.B, 0, (int)recB, 0x00020000);
     auto issue = [&](int slot, const Src& o, uint32_t kb) {      // kb: byte offset along K (wave-uniform)
         char* base = smem + slot * 32768 + wave * 2048;
-#ifdef MMB_EXP_EXEC0
-        // (ablation: what does an LDS-DMA instruction cost with EXEC = 0?  bit 0: all loads, bit 1: only the A loads of waves 6, 7)
-        __builtin_amdgcn_sched_barrier(0);
-        if ((MMB_EXP_EXEC0) & 1) asm volatile("s_mov_b64 exec, 0" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-#endif
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            // timing-only builds (round 3, -DMMB_EXP_ALOADS=1 / 0): every wave issues ONE of its two A-row loads per stage (24 LDS-DMA
-            // instructions per K step and CU instead of 32), or none (16): does the K step follow the instruction count?  Compile-time:
-            // a run-time switch around the loads made hipcc drain vmcnt at the joins (the K loop doubled)
-#ifdef MMB_EXP_WAVEA
-            if (wave < MMB_EXP_WAVEA)                          // (ablation: a wave-uniform RUN-TIME branch around the A loads: waves >= N issue none)
-#endif
-            if (i < NTP_ALOADS)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, LPTR(base + i * 1024), 16, o.a[i], kb, 0, 0);
-            if (NTP_BLOADS)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, LPTR(base + 16384 + i * 1024), 16, o.b[i], kb, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, LPTR(base + i * 1024), 16, o.a[i], kb, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, LPTR(base + 16384 + i * 1024), 16, o.b[i], kb, 0, 0);
         }
-#ifdef MMB_EXP_EXEC0
-        __builtin_amdgcn_sched_barrier(0);
-        asm volatile("s_mov_b64 exec, -1" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-#endif
     };
-    // s_waitcnt vmcnt(k stages x loads per stage and wave + e): 4 loads per stage in the product build
-#define NTP_WAIT(K_, E_, LG_) __builtin_amdgcn_s_waitcnt(mmb_waitcnt((2 * NTP_BLOADS + NTP_ALOADS) * (K_) + (E_), LG_));
+    // s_waitcnt vmcnt(k stages x loads per stage and wave + e)
+    constexpr int NTP_LOADS_PER_STAGE = 4;                         // issue(): 2 A-row + 2 B-row LDS-DMA instructions per wave and stage
+#define NTP_WAIT(K_, E_, LG_) __builtin_amdgcn_s_waitcnt(mmb_waitcnt(NTP_LOADS_PER_STAGE * (K_) + (E_), LG_));
 
     const int fr = lane & 15, fq = lane >> 4;
     const int lane_off = fr * 64 + ((fq ^ ((GT >> (2 * ((fr >> 2) & 3))) & 3)) << 4);
@@ -605,10 +575,6 @@ __global__ __launch_bounds__(512, 2) void gemm_ntp_kernel(const GemmNT p) {
     lds_cptr a_rd_hi = a_rd + 65536, b_rd_hi = b_rd + 65536;
     asm volatile("" : "+v"(a_rd_hi), "+v"(b_rd_hi));
     auto load_frags = [&](int slot, bf16x8 (&af)[MI], bf16x8 (&bfr)[4]) {
-#ifdef MMB_EXP_NOFRAGS
-        asm volatile("" : "+v"(af[0]), "+v"(bfr[0]));          // (ablation: no LDS fragment reads)
-        return;
-#endif
         const lds_cptr ab = slot < 2 ? a_rd : a_rd_hi;
         const lds_cptr bb = slot < 2 ? b_rd : b_rd_hi;
         const int so = (slot & 1) * 32768;
@@ -619,13 +585,6 @@ __global__ __launch_bounds__(512, 2) void gemm_ntp_kernel(const GemmNT p) {
     };
     f32x4 acc[MI][4];
     auto mma = [&](const bf16x8 (&af)[MI], const bf16x8 (&bfr)[4]) {
-#ifdef MMB_EXP_NOMFMA
-#pragma unroll
-        for (int i = 0; i < MI; ++i) asm volatile("" :: "v"(af[i]));   // (ablation: no MFMAs; the fragments stay live)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) asm volatile("" :: "v"(bfr[j]));
-        return;
-#endif
 #pragma unroll
         for (int i = 0; i < MI; ++i)
 #pragma unroll
@@ -1000,43 +959,112 @@ __global__ __launch_bounds__(512, 2) void gemm_ntp_kernel(const GemmNT p) {
 }
 
 constexpr int NTP_LDS_BYTES = 131072 + 1024 + 8 * 256;      // ring | tile-queue word (padded) | bias rows
+
+// ---- which kernel, which tile, which tile walk: ONE function of the shape (and of the test / A-B knobs), shared by the launch path
+// and by mmbert_gemm_nt_describe() (bench.py reports the choice per shape; tests pin it) ----
+enum { NTK_128 = 0, NTK_RING = 1, NTK_PERSIST = 2 };
+struct NTChoice { int kernel, bm, tiles, workgroups, group_m, use_queue; };
+
+static bool ntp_eligible(const GemmNT& p) {
+    return !(p.K & 127) && p.K >= 256 && (long long)p.M * p.lda < (1ll << 31) && (long long)p.N * p.ldb < (1ll << 31);
+}
+
+// Tile walk of the persistent kernel (ntp_tile_mn).  An XCD's 32 workgroups own a contiguous chunk of the walk (xcd_remap), i.e.
+// ceil(tiles_m / 8) row panels; with MORE tiles than CUs the order inside that chunk decides which panels its 32 concurrent tiles share:
+//  * row-major (group_m = 1): ~3 row panels x ALL column panels at a time -- a weight panel is wanted by 3 workgroups at once and the
+//    whole weight matrix (3.5-4.7 MB at N = 2304 / 3072) passes through the 4-MiB L2 once per 3 row panels;
+//  * one group per XCD (group_m = ceil(tiles_m / 8), round 3): the XCD sweeps the column panels with ALL its row panels, 11 row panels
+//    x ~3 column panels at a time -- a weight panel is wanted by 11 workgroups at once and then never again on this XCD.  Same-process
+//    A/B of the train step (tools/ab_step.py, MMBERT_NT_GROUP_M): group_m = 1 / 6 / 8 / 11 / 16 / 32 / 100 -> 15.56 / 15.34 / 15.30 /
+//    14.98 / 15.30 / 15.18 / 15.16 ms; the rule below = 11 at 18 400 rows.  (Fetched bytes barely move -- DESIGN 3.1.)
+//  * the vocabulary projection (B = 47 MB, 9 960 tiles) keeps its groups of 4 row panels (round 2: 1 / 2 / 4 / 8 -> 871 / 855 / 844 /
+//    875 us): its column sweep is 120 panels long.
+// A/B switches, read per call: MMBERT_NT_GROUP_M=g (every non-huge multi-round shape) and, round 4, MMBERT_NT_GM_TABLE="N:K:E=g;N:K:E=g"
+// (E = the epilogue flags: FFN-up and the GELU' input gradient share N and K; one shape at a time: the rule was decided on the step
+// total in round 3 and QKV paid for it).
+static int ntp_group_m(int M, int N, int K, int epi, int bm, int tiles, int cus) {
+    if (tiles <= cus) return 1;
+    const bool huge_b = (long long)N * K * 2 > (8ll << 20);
+    if (huge_b) return tiles > 4 * cus ? 4 : 1;
+    int gm = ((M + bm - 1) / bm + 7) / 8;
+    if (const char* t = getenv("MMBERT_NT_GM_TABLE")) {
+        for (const char* q = t; q && *q; ) {
+            int n = 0, k = 0, e = 0, g = 0;
+            if (sscanf(q, "%d:%d:%d=%d", &n, &k, &e, &g) == 4 && n == N && k == K && e == epi) return g;
+            q = strchr(q, ';');
+            if (q) ++q;
+        }
+    }
+    if (const char* gs = getenv("MMBERT_NT_GROUP_M")) { const int g = atoi(gs); if (g >= 0) gm = g; }
+    return gm;
+}
+
+static NTChoice nt_choose(const GemmNT& p, int epi) {
+    NTChoice c = {NTK_128, 128, ((p.M + 127) / 128) * ((p.N + 127) / 128), 0, 1, 0};
+    c.workgroups = c.tiles;
+    // shape dispatch: the 256-wide pipeline needs >= 4 stages of K and enough rows to fill its tiles
+    const bool big = (p.K >= 128) && (p.M >= 512) && (p.N >= 256) && !(p.N & 7) && !(p.ldc & 7) && !(p.ldr & 7) && !(p.ldaux & 7) && !(p.ldu & 7);
+    if (!((g_nt_force >= 2 && !(p.N & 7)) || (g_nt_force == 0 && big))) return c;
+    // Measured cost model (tools/stamp_gemm.py, tools/bench_gemm.py): a K step costs the same ~1270 clk for the 224- and
+    // the 256-row tile (LDS-bound), so what counts is the number of tile rounds over the CUs; the shorter tile also has
+    // the shorter epilogue.  224 rows unless that takes more rounds.  The persistent stream kernel (224-row form: the only
+    // one that fits the register file without spills) hides every prologue but the first and has the leaner epilogue
+    // (operand prefetch, 32-byte runs per lane): it won or tied on every shape of the step, single-round ones included.
+    const int cus = device_cus(), tn = (p.N + 255) / 256;
+    const int t256 = ((p.M + 255) / 256) * tn, t224 = ((p.M + 223) / 224) * tn;
+    const int r256 = (t256 + cus - 1) / cus, r224 = (t224 + cus - 1) / cus;
+    const bool can_persist = g_nt_persist && ntp_eligible(p);
+    bool persist, tall;
+    if (g_nt_bm == 0) {
+        // default: the 224-row form.  The 256-row staggered form (mode 6) wins 1-7 % on single-round and very wide shapes in
+        // isolation (tools/bench_gemm.py MODES=6,7; after the epilogue rewrite: N = 768 shapes -4..-6 %, vocabulary -6 %, QKV
+        // equal, GELU epilogues +8..9 %) but not in the train step, neither everywhere (797 vs 805 samples/s) nor chosen per
+        // launch by rounds x relative tile time (815 vs 820, two alternating runs on one box): not the default.
+        // ... except where the taller tile saves whole ROUNDS over the CUs (static tile shares: a launch costs ceil(tiles / CUs)
+        // tile times): backward runs on a data-dependent row count (model.py, SplitLayout), e.g. 14 400 rows x N = 3072 is 780
+        // tiles = 4 rounds at 224 rows but 684 = 3 rounds at 256.  A 256-row tile is priced at 1.1 of a 224-row one.
+        static const bool tall_ok = !(getenv("MMBERT_NT_TALL") && atoi(getenv("MMBERT_NT_TALL")) == 0);     // A/B switch
+        // Round 2 (profiles/r2_exp_nt_tile_heights.log): 192- and 160-row forms of this kernel were built and timed on the
+        // single-round N = 768 input-gradient shapes (13-14.4 k rows): a tile takes the SAME time at 160 / 192 / 224 / 256 rows
+        // (23.2-23.6, 52.7-53.6, 68.3-70.0 us) -- the K step issues its 32 stage loads whatever the tile height (all 256 A rows
+        // are staged) and that, not the MFMA count, is its length -- so only the round count matters and the two forms below
+        // stay.  A start stagger of the workgroups (to spread the epilogues' store bursts) was a loss on every shape, the
+        // 34-round vocabulary projection included (profiles/r2_exp_nt_start_stagger.log).
+        // (round 2, same-process A/B of the train step: taking the 256-row form whenever it needs no more rounds, for the
+        // epilogues without GELU / GELU', is 0.5-0.7 % SLOWER in situ although it wins 3-5 % per shape in isolation)
+        persist = can_persist;
+        tall = can_persist ? (tall_ok && (float)r256 * 1.1f < (float)r224) : !(r224 <= r256);
+    } else {
+        persist = can_persist && g_nt_force == 2 && g_nt_persist == 2;
+        tall = g_nt_bm != 224;
+    }
+    c.kernel = persist ? NTK_PERSIST : NTK_RING;
+    c.bm = tall ? 256 : 224;
+    c.tiles = tall ? t256 : t224;
+    c.workgroups = persist ? (c.tiles < cus ? c.tiles : cus) : c.tiles;
+    if (persist) {
+        c.group_m = ntp_group_m(p.M, p.N, p.K, epi, c.bm, c.tiles, cus);
+        c.use_queue = (p.tile_counter != nullptr) && c.tiles > cus;      // launches with no more tiles than workgroups need no queue
+    }
+    return c;
+}
+
 template <int EPI, int MI>
-static int launch_ntp_mi(hipStream_t s, const GemmNT& p) {
-    constexpr int BM = 32 * MI;
-    const int tiles = ((p.M + BM - 1) / BM) * ((p.N + 255) / 256);
+static int launch_ntp_mi(hipStream_t s, const GemmNT& p, const NTChoice& c) {
     static std::atomic<unsigned long long> attr_done{0};
     if (int e = mmb_allow_lds((const void*)gemm_ntp_kernel<EPI, MI, MI == 8>, NTP_LDS_BYTES, attr_done)) return e;
     const int cus = device_cus();
     GemmNT q = p;
     // Dynamic tile queue: the CALLER's 16 zero-initialised ints (mmbert_gemm_nt(..., tile_queue): 8 per-XCD fetch counters, exit
     // counter, padding); the kernel leaves them zero again (the last workgroup to exit resets them), so one 64-byte buffer serves
-    // every launch of a stream.  Launches with no more tiles than workgroups need no queue.
+    // every launch of a stream.
     static const int qg_env = getenv("MMBERT_NT_QUEUE_GLOBAL") ? atoi(getenv("MMBERT_NT_QUEUE_GLOBAL")) : 0;   // A/B switch: one counter
     q.queue_xcd = (qg_env || (cus & 7)) ? 0 : 1;
-    if (tiles <= cus) q.tile_counter = q.tile_counter_next = nullptr;
-    // Tile walk (ntp_tile_mn).  An XCD's 32 workgroups own a contiguous chunk of the walk (xcd_remap), i.e. ceil(tiles_m / 8) row panels;
-    // with MORE tiles than CUs the order inside that chunk decides which panels its 32 concurrent tiles share:
-    //  * row-major (group_m = 1): ~3 row panels x ALL column panels at a time -- a weight panel is wanted by 3 workgroups at once and the
-    //    whole weight matrix (3.5-4.7 MB at N = 2304 / 3072) passes through the 4-MiB L2 once per 3 row panels;
-    //  * one group per XCD (group_m = ceil(tiles_m / 8), round 3): the XCD sweeps the column panels with ALL its row panels, 11 row panels
-    //    x ~3 column panels at a time -- a weight panel is wanted by 11 workgroups at once and then never again on this XCD.  Same-process
-    //    A/B of the train step (tools/ab_step.py, MMBERT_NT_GROUP_M): group_m = 1 / 6 / 8 / 11 / 16 / 32 / 100 -> 15.56 / 15.34 / 15.30 /
-    //    14.98 / 15.30 / 15.18 / 15.16 ms; the rule below = 11 at 18 400 rows.  (Fetched bytes barely move -- DESIGN 3.1.)
-    //  * the vocabulary projection (B = 47 MB, 9 960 tiles) keeps its groups of 4 row panels (round 2: 1 / 2 / 4 / 8 -> 871 / 855 / 844 /
-    //    875 us): its column sweep is 120 panels long.
-    const char* gm_s = getenv("MMBERT_NT_GROUP_M");                                                        // A/B switch, read per call
-    const int gm_env = gm_s ? atoi(gm_s) : -1;
-    const bool huge_b = (long long)p.N * p.K * 2 > (8ll << 20);
-    q.group_m = 1;
-    if (tiles > cus) q.group_m = huge_b ? (tiles > 4 * cus ? 4 : 1) : (((p.M + BM - 1) / BM) + 7) / 8;
-    if (gm_env >= 0 && tiles > cus && !huge_b) q.group_m = gm_env;
-    hipLaunchKernelGGL((gemm_ntp_kernel<EPI, MI, MI == 8>), dim3(tiles < cus ? tiles : cus), dim3(512), NTP_LDS_BYTES, s, q);
+    if (!c.use_queue) q.tile_counter = q.tile_counter_next = nullptr;
+    q.group_m = c.group_m;
+    hipLaunchKernelGGL((gemm_ntp_kernel<EPI, MI, MI == 8>), dim3(c.workgroups), dim3(512), NTP_LDS_BYTES, s, q);
     MMB_CHECK_LAUNCH();
     return 0;
-}
-
-static bool ntp_eligible(const GemmNT& p) {
-    return !(p.K & 127) && p.K >= 256 && (long long)p.M * p.lda < (1ll << 31) && (long long)p.N * p.ldb < (1ll << 31);
 }
 
 // Round 2, tried and dropped: a "big tile" form of this kernel -- 320 / 384 x 256 output tile, ONE 4-wave workgroup per CU (one wave
@@ -1059,48 +1087,11 @@ static int launch_nt256_mi(hipStream_t s, const GemmNT& p) {
 }
 
 template <int EPI>
-static int launch_nt256(hipStream_t s, const GemmNT& p) {
-    // Measured cost model (tools/stamp_gemm.py, tools/bench_gemm.py): a K step costs the same ~1270 clk for the 224- and
-    // the 256-row tile (LDS-bound), so what counts is the number of tile rounds over the CUs; the shorter tile also has
-    // the shorter epilogue.  224 rows unless that takes more rounds.  The persistent stream kernel (224-row form: the only
-    // one that fits the register file without spills) hides every prologue but the first and has the leaner epilogue
-    // (operand prefetch, 32-byte runs per lane): it won or tied on every shape of the step, single-round ones included.
-    const int cus = device_cus(), tn = (p.N + 255) / 256;
-    const int r256 = (((p.M + 255) / 256) * tn + cus - 1) / cus;
-    const int r224 = (((p.M + 223) / 224) * tn + cus - 1) / cus;
-    const bool can_persist = g_nt_persist && ntp_eligible(p);
-    if (g_nt_bm == 0) {
-        // default: the 224-row form.  The 256-row staggered form (mode 6) wins 1-7 % on single-round and very wide shapes in
-        // isolation (tools/bench_gemm.py MODES=6,7; after the epilogue rewrite: N = 768 shapes -4..-6 %, vocabulary -6 %, QKV
-        // equal, GELU epilogues +8..9 %) but not in the train step, neither everywhere (797 vs 805 samples/s) nor chosen per
-        // launch by rounds x relative tile time (815 vs 820, two alternating runs on one box): not the default.
-        // ... except where the taller tile saves whole ROUNDS over the CUs (static tile shares: a launch costs ceil(tiles / CUs)
-        // tile times): backward runs on a data-dependent row count (model.py, SplitLayout), e.g. 14 400 rows x N = 3072 is 780
-        // tiles = 4 rounds at 224 rows but 684 = 3 rounds at 256.  A 256-row tile is priced at 1.1 of a 224-row one.
-        static const bool tall_ok = !(getenv("MMBERT_NT_TALL") && atoi(getenv("MMBERT_NT_TALL")) == 0);     // A/B switch
-        // Round 2 (profiles/r2_exp_nt_tile_heights.log): 192- and 160-row forms of this kernel were built and timed on the
-        // single-round N = 768 input-gradient shapes (13-14.4 k rows): a tile takes the SAME time at 160 / 192 / 224 / 256 rows
-        // (23.2-23.6, 52.7-53.6, 68.3-70.0 us) -- the K step issues its 32 stage loads whatever the tile height (all 256 A rows
-        // are staged) and that, not the MFMA count, is its length -- so only the round count matters and the two forms below
-        // stay.  A start stagger of the workgroups (to spread the epilogues' store bursts) was a loss on every shape, the
-        // 34-round vocabulary projection included (profiles/r2_exp_nt_start_stagger.log).
-        if (can_persist) {
-            // (round 2, same-process A/B of the train step: taking the 256-row form whenever it needs no more rounds, for the
-            // epilogues without GELU / GELU', is 0.5-0.7 % SLOWER in situ although it wins 3-5 % per shape in isolation)
-            return (tall_ok && (float)r256 * 1.1f < (float)r224) ? launch_ntp_mi<EPI, 8>(s, p) : launch_ntp_mi<EPI, 7>(s, p);
-        }
-        return r224 <= r256 ? launch_nt256_mi<EPI, 7>(s, p) : launch_nt256_mi<EPI, 8>(s, p);
-    }
-    if (can_persist && g_nt_force == 2 && g_nt_persist == 2) return g_nt_bm == 224 ? launch_ntp_mi<EPI, 7>(s, p) : launch_ntp_mi<EPI, 8>(s, p);
-    return g_nt_bm == 224 ? launch_nt256_mi<EPI, 7>(s, p) : launch_nt256_mi<EPI, 8>(s, p);
-}
-
-// shape dispatch: the 256^2 pipeline needs >= 4 stages of K and enough rows to fill its tiles
-template <int EPI>
 static int dispatch_nt(hipStream_t s, const GemmNT& p) {
-    const bool big = (p.K >= 128) && (p.M >= 512) && (p.N >= 256) && !(p.N & 7) && !(p.ldc & 7) && !(p.ldr & 7) && !(p.ldaux & 7) && !(p.ldu & 7);
-    if ((g_nt_force >= 2 && !(p.N & 7)) || (g_nt_force == 0 && big)) return launch_nt256<EPI>(s, p);
-    return launch_nt<EPI>(s, p);
+    const NTChoice c = nt_choose(p, EPI);
+    if (c.kernel == NTK_128) return launch_nt<EPI>(s, p);
+    if (c.kernel == NTK_PERSIST) return c.bm == 256 ? launch_ntp_mi<EPI, 8>(s, p, c) : launch_ntp_mi<EPI, 7>(s, p, c);
+    return c.bm == 256 ? launch_nt256_mi<EPI, 8>(s, p) : launch_nt256_mi<EPI, 7>(s, p);
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -1499,6 +1490,24 @@ int mmbert_gemm_nt(hipStream_t stream, const void* A, int lda, const void* B, in
         case EPI_BIAS | EPI_OUT_F32: return dispatch_nt<EPI_BIAS | EPI_OUT_F32>(stream, p);
         default: return -2;
     }
+}
+
+// Which kernel mmbert_gemm_nt would launch for this shape on the current device (contiguous operands assumed: ld = K / N), without
+// launching anything: out[0] = kernel (0: 128x128-tile kernel, 1: 4-slot-ring kernel with one launch slot per tile, 2: persistent stream
+// kernel), out[1] = tile rows (128 / 224 / 256), out[2] = tile columns, out[3] = output tiles, out[4] = workgroups launched,
+// out[5] = tile rounds x 100 over the device's CUs, out[6] = group_m of the tile walk, out[7] = CUs.  Host-only.
+int mmbert_gemm_nt_describe(int M, int N, int K, int epi, int with_queue, int* out) {
+    if (!out || M <= 0 || N <= 0 || K <= 0) return -1;
+    GemmNT p = {};
+    p.M = M; p.N = N; p.K = K; p.lda = K; p.ldb = K; p.ldc = N; p.ldr = (epi & (EPI_RESID)) ? N : 0; p.ldaux = (epi & EPI_GELU) ? N : 0;
+    p.ldu = (epi & EPI_GELU_BWD) ? N : 0;
+    static int dummy_queue[16];
+    p.tile_counter = with_queue ? dummy_queue : nullptr;
+    const NTChoice c = nt_choose(p, epi);
+    const int cus = device_cus();
+    out[0] = c.kernel; out[1] = c.bm; out[2] = c.kernel == NTK_128 ? 128 : 256; out[3] = c.tiles; out[4] = c.workgroups;
+    out[5] = (int)(100.0 * c.tiles / cus + 0.5); out[6] = c.group_m; out[7] = cus;
+    return 0;
 }
 
 // test / benchmarking hook: 0 = automatic shape dispatch, 1 = always the 128^2 kernel, 2 = always the 256^2 kernel

@@ -587,7 +587,9 @@ class _TrunkFn(torch.autograd.Function):
         lnd.flush()
         if top.defer_embed_rows:
             ops.embed_scatter(t.ids, t.tts, de0, T, None, w["g_type"], w["g_pos"], vocab=cfg.vocab_size)
-            top._deferred_embed_rows = (t.ids, de0)
+            # a LIST: every differentiated trunk backward between two finish_backward() calls hands over its rows (a second
+            # backward must not overwrite the first one's -- parallel.DataParallel exchanges all of them)
+            top.__dict__.setdefault("_deferred_embed_rows", []).append((t.ids, de0))
         else:
             ops.embed_scatter(t.ids, t.tts, de0, T, w["g_word"], w["g_type"], w["g_pos"])
         return None, None, None

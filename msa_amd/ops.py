@@ -103,6 +103,15 @@ def gemm_nt(A, B, *, out=None, bias=None, gelu=False, aux=None, resid=None, gelu
     return out
 
 
+def gemm_nt_describe(M: int, N: int, K: int, epi: int = 0, with_queue: bool = False) -> dict:
+    """Which kernel / tile / tile walk ``gemm_nt`` uses for a shape on the current device (mmbert_gemm_nt_describe; launches nothing)."""
+    import ctypes
+    out = (ctypes.c_int * 8)()
+    _lib.check(_lib.load().mmbert_gemm_nt_describe(int(M), int(N), int(K), int(epi), int(bool(with_queue)), out), "mmbert_gemm_nt_describe")
+    kern = {0: "128x128", 1: "ring", 2: "persistent"}[out[0]]
+    return dict(kernel=kern, tile=f"{out[1]}x{out[2]}", tiles=out[3], workgroups=out[4], rounds=out[5] / 100.0, group_m=out[6], cus=out[7])
+
+
 _slab_cache = {}
 
 

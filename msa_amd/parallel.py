@@ -156,7 +156,9 @@ class DataParallel:
     rank bit-identical)."""
 
     def __init__(self, model, optimizer=None, group=None, bucket_mb: float = 32.0, force_dynamic_queue: bool = False,
-                 wire_dtype: Optional[torch.dtype] = None, early_word_embedding: bool = True):
+                 wire_dtype: Optional[torch.dtype] = None, early_word_embedding: bool = True, equal_batch_shapes: bool = False):
+        """``equal_batch_shapes``: the caller guarantees that every rank's token-id tensor has the same element count in every step
+        (DeviceBatchBuilder / bench.py batches do) -- the id exchange then skips its size agreement (gather_union)."""
         if not dist.is_initialized():
             raise RuntimeError("torch.distributed is not initialised")
         self.model, self.group = model, group
@@ -190,8 +192,9 @@ class DataParallel:
         wname = "bert.embeddings.word_embeddings.weight"
         self._word = (flat.offset[wname], flat.offset[wname] + flat.vpad * model.config.hidden_size)
         self.early_word = bool(early_word_embedding) and self._word[1] <= flat.total and flat.order[-1] == wname
+        self.equal_batch_shapes = bool(equal_batch_shapes)
         self._word_started = False
-        self._union = None
+        self._unions = []            # one entry per differentiated forward since the last finish_backward(): (union, event) or None
         # the id exchange of step k + 1 must not queue behind the gradient collectives of step k (one communicator runs its
         # collectives in order): it gets a communicator of its own
         self._ids_group = dist.new_group(ranks=dist.get_process_group_ranks(group) if group is not None else None) if self.early_word else None
@@ -210,24 +213,31 @@ class DataParallel:
         """Start of a forward pass that will be differentiated: the token ids of the step (inputs) -> the union of touched table rows
         over all ranks, long before backward needs it (gather_union reads a size back: here the host is ahead of the GPU)."""
         if not self.bucketer.enabled:
-            self._union = None
+            self._unions.append(None)          # (a forward under no_sync(): if its backward is exchanged after all, the union is rebuilt)
             return
         if stream is not None:
             with torch.cuda.stream(stream):
-                self._union = gather_union(ids, self.model.config.vocab_size, self._ids_group)
-            self._union.record_stream(torch.cuda.current_stream())
-            self._union_event = torch.cuda.Event()
-            self._union_event.record(stream)
+                union = gather_union(ids, self.model.config.vocab_size, self._ids_group, self.equal_batch_shapes)
+            union.record_stream(torch.cuda.current_stream())
+            ev = torch.cuda.Event()
+            ev.record(stream)
         else:
-            self._union = gather_union(ids, self.model.config.vocab_size, self._ids_group)
-            self._union_event = None
+            union, ev = gather_union(ids, self.model.config.vocab_size, self._ids_group, self.equal_batch_shapes), None
+        self._unions.append((union, ev))
 
     def _on_heads_done(self):
         """The MLM head's backward is complete: the tied decoder's dense gradient of the word-embedding table is final (the lookup's
         rows stay out of the table: model.defer_embed_rows)."""
-        if self.bucketer.enabled and not self._word_started:
-            self.bucketer.reduce_range(*self._word)
-            self._word_started = True
+        if not self.bucketer.enabled:
+            return
+        if self._word_started:
+            # The table's all-reduce of this step is already in flight: a second MLM-head backward would add into the very slice a
+            # collective is reading and writing (and its sum would be reduced a second time).  One differentiated heads backward per
+            # finish_backward(); gradient accumulation goes through no_sync(), which keeps every micro-step but the last local.
+            raise RuntimeError("DataParallel: a second heads backward before finish_backward() -- wrap accumulation micro-steps in "
+                               "no_sync(), or construct DataParallel(early_word_embedding=False)")
+        self.bucketer.reduce_range(*self._word)
+        self._word_started = True
 
     @contextlib.contextmanager
     def no_sync(self):
@@ -242,28 +252,37 @@ class DataParallel:
 
     def _fold_rows_locally(self):
         """A micro-step without exchange: the lookup's rows go into the local table like any other gradient."""
-        pend = self.model.__dict__.pop("_deferred_embed_rows", None)
-        if pend is not None:
-            ids, rows = pend
+        for ids, rows in self.model.__dict__.pop("_deferred_embed_rows", None) or ():
             _scatter_rows(self.model._w["g_word"], ids, rows)
+        self._unions = []
 
     def finish_backward(self):
         """Call after ``loss.backward()`` and before ``optimizer.step()``."""
         bk = self.bucketer
-        pend = self.model.__dict__.pop("_deferred_embed_rows", None)
+        pend = self.model.__dict__.pop("_deferred_embed_rows", None) or []
+        unions, self._unions = self._unions, []
         started, self._word_started = self._word_started, False
         if not (self.early_word and started):
-            if pend is not None:                                   # (no early exchange happened: rows into the table, then the usual tail)
-                _scatter_rows(self.model._w["g_word"], *pend)
+            for ids, rows in pend:                                 # (no early exchange happened: rows into the table, then the usual tail)
+                _scatter_rows(self.model._w["g_word"], ids, rows)
             bk.finish()
             return
         # compact exchange of the lookup's rows, while the table's own all-reduce (started long ago) and the tail are in flight
         block = None
-        if pend is not None:
-            ids, rows = pend
-            union, self._union = self._union, None
-            if union is not None and getattr(self, "_union_event", None) is not None:
-                torch.cuda.current_stream().wait_event(self._union_event)
+        if pend:
+            # every trunk backward since the last call handed its rows over (one in the reference's loop; several when a caller
+            # differentiates more than one forward pass per step): ONE exchange of all of them
+            ids = pend[0][0].reshape(-1) if len(pend) == 1 else torch.cat([i.reshape(-1) for i, _ in pend])
+            rows = pend[0][1] if len(pend) == 1 else torch.cat([r for _, r in pend])
+            # the union must cover every id above.  It does when every one of those forwards registered its ids while the exchange
+            # was enabled (each union is identical on all ranks, so their merge is too); a forward under no_sync() whose backward is
+            # exchanged after all, or a backward without a registered forward, rebuilds it here (all ranks take the same branch: SPMD)
+            union = None
+            if unions and all(u is not None for u in unions) and len(unions) >= len(pend):
+                for u, ev in unions:
+                    if ev is not None:
+                        torch.cuda.current_stream().wait_event(ev)
+                union = unions[0][0] if len(unions) == 1 else torch.unique(torch.cat([u for u, _ in unions]))
             block = exchange_rows(ids, rows, self.model.config.vocab_size, self.group, union=union)
         bk.finish(upto=self._word[0])                               # the tail in front of the table + every outstanding collective
         bk.done = 0
@@ -281,14 +300,26 @@ def _scatter_rows(table: torch.Tensor, ids: torch.Tensor, rows: torch.Tensor):
     table.index_add_(0, ids.clamp(0, table.shape[0] - 1), rows.to(table.dtype) * keep[:, None].to(table.dtype))
 
 
-def gather_union(ids: torch.Tensor, vocab: int, group=None) -> torch.Tensor:
+def gather_union(ids: torch.Tensor, vocab: int, group=None, equal_sizes: bool = False) -> torch.Tensor:
     """The sorted union over all ranks of the table rows ``ids`` touches (ids outside (0, vocab) dropped): all-gather + unique, the
     same list on every rank.  ``torch.unique`` reads its output size back to the host, so call this where the host is AHEAD of the
     GPU anyway -- the ids are inputs of the step: DataParallel does it on the input stream at the start of forward, not at the
     end of backward where it would drain the queue."""
     W = dist.get_world_size(group)
     ids = ids.reshape(-1).long().contiguous()
-    allids = torch.empty(W * ids.numel(), dtype=torch.long, device=ids.device)
+    n = ids.numel()
+    if W > 1 and not equal_sizes:
+        # all_gather_into_tensor needs the same element count on every rank; a plain DataLoader pads each rank's batch to ITS longest
+        # text (pad_sequence) and may end on a short batch.  Agree on the maximum first and pad with id 0 (the padding row: dropped
+        # below).  One tiny MAX all-reduce + read-back, at a point where the host is ahead of the GPU anyway (torch.unique reads its
+        # size back too); DeviceBatchBuilder batches are equal by construction (equal_sizes=True skips it).
+        nmax = torch.tensor([n], dtype=torch.long, device=ids.device)
+        dist.all_reduce(nmax, op=dist.ReduceOp.MAX, group=group)
+        nmax = int(nmax.item())
+        if nmax != n:
+            ids = torch.cat((ids, ids.new_zeros(nmax - n)))
+            n = nmax
+    allids = torch.empty(W * n, dtype=torch.long, device=ids.device)
     dist.all_gather_into_tensor(allids, ids, group=group)
     return torch.unique(allids[(allids > 0) & (allids < vocab)])
 

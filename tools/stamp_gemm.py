@@ -14,6 +14,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 OUT = os.path.join(ROOT, "tools", "_stamp")
 VARIANT = os.environ.get("STAMP_VARIANT", "")            # e.g. "aloads1": -DMMB_EXP_ALOADS=1 (timing-only builds of round 3)
+if VARIANT:
+    # Round 4: the K-step ablation switches were taken out of the product kernel (a -D typo could yield a silently wrong library);
+    # common.h now #errors on them.  The sources that honour them are the git tag r3-gemm-ablations:
+    #     git worktree add /tmp/r3abl r3-gemm-ablations && (cd /tmp/r3abl && STAMP_VARIANT=... python tools/stamp_gemm.py --build)
+    sys.exit("STAMP_VARIANT builds need the sources of git tag r3-gemm-ablations (see the comment above this line)")
 LIB = os.path.join(OUT, f"libmmbert_hip_stamps{('_' + VARIANT) if VARIANT else ''}.so")
 EXTRA = {"": [], "aloads1": ["-DMMB_EXP_ALOADS=1"], "aloads0": ["-DMMB_EXP_ALOADS=0"], "noloads": ["-DMMB_EXP_ALOADS=0", "-DMMB_EXP_NOBLOADS"],
          "nomfma": ["-DMMB_EXP_NOMFMA"], "nofrags": ["-DMMB_EXP_NOFRAGS"], "nofrags_noloads": ["-DMMB_EXP_NOFRAGS", "-DMMB_EXP_ALOADS=0", "-DMMB_EXP_NOBLOADS"],

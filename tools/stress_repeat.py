@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Repeats one GPU test function in ONE process with allocator churn in between and prints every assertion message: finds tolerances that
 sit inside the run-to-run noise of the fp32 atomics (a bound that fails one suite run in three passes every isolated run).
-    cd tests && python ../tools/stress_test.py test_model_gpu test_training_without_returned_scores_equals_the_faithful_step 25 False True"""
+    cd tests && python ../tools/stress_repeat.py test_model_gpu test_training_without_returned_scores_equals_the_faithful_step 25 False True"""
 import importlib, os, sys
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, root); sys.path.insert(0, os.path.join(root, "tests"))
