@@ -96,10 +96,14 @@ def _make_bert_holder(cfg) -> nn.Module:
     return bert
 
 
-def _hf_init(module: nn.Module, std: float):
+def _hf_init(module: nn.Module, std: float, skip: Optional[nn.Module] = None):
     """HF ``_init_weights``: N(0, std) Linear/Embedding weights, zero biases, LayerNorm (1, 0),
-    zero padding row -- what ``init_weights()`` does at REF:MMBertForPretraining.py:22,347."""
+    zero padding row -- what ``init_weights()`` does at REF:MMBertForPretraining.py:22,347.  ``skip``: a submodule whose
+    (already initialised or loaded) weights are left alone."""
+    skipped = set(id(x) for x in skip.modules()) if skip is not None else ()
     for m in module.modules():
+        if id(m) in skipped:
+            continue
         if isinstance(m, nn.Linear):
             nn.init.normal_(m.weight, mean=0.0, std=std)
             if m.bias is not None:
@@ -1200,6 +1204,24 @@ class MMBertModel(_GpuModelBase):
             self.jointEmbeddings._owner = weakref.ref(top)
             top._flat = None
 
+    def _standalone_top(self, device):
+        """``MMBertModel(config)`` constructed on its own (REF:MMBertForPretraining.py:13-22 allows it): the kernels read parameters
+        from ONE flat storage that MMBertForPretraining lays out, so a standalone model adopts a private MMBertForPretraining around
+        itself on first use (its heads are never run; the tied decoder aliases the word embedding, so they cost ~3 H^2 floats).  This
+        module's parameters, ``state_dict()`` keys (no ``bert.`` prefix) and gradients stay its own."""
+        import weakref
+        top = self.__dict__.get("_private_top")
+        if top is None:
+            if not hasattr(self, "jointEmbeddings"):
+                raise RuntimeError("call .set_joint_embeddings(dataset) first (REF:train.py:72)")
+            top = MMBertForPretraining(self.config, _bert=self)
+            top.to(device)
+            top._seed, top._calls = self._seed, self._calls
+            object.__setattr__(self, "_private_top", top)           # not a registered submodule: `top.bert` already is `self`
+        self._owner = None                                          # (stays "standalone": a later .to() re-enters here)
+        self.jointEmbeddings._owner = weakref.ref(top)
+        return top
+
     def get_input_embeddings(self):
         return self.embeddings.word_embeddings
 
@@ -1209,13 +1231,18 @@ class MMBertModel(_GpuModelBase):
     def forward(self, input_ids=None, attention_mask=None, token_type_ids=None, position_ids=None, head_mask=None,
                 inputs_embeds=None, encoder_hidden_states=None, encoder_attention_mask=None, output_attentions=None,
                 output_hidden_states=None, joint=False):
-        if self._owner is None:
-            raise RuntimeError("MMBertModel runs as MMBertForPretraining.bert (it shares the flat parameter storage)")
-        top = self._owner()
         if input_ids is not None and inputs_embeds is not None:
             raise ValueError("You cannot specify both input_ids and inputs_embeds at the same time")
+        if input_ids is None and inputs_embeds is not None:
+            # REF:MMBertForPretraining.py:231-241 accepts pre-computed embeddings; no caller in the reference passes them and the
+            # embedding lookup is fused into the trunk here ("MMBertModel on its own")
+            raise NotImplementedError("MMBertModel: inputs_embeds is not supported on the HIP path (pass input_ids)")
         if input_ids is None:
             raise ValueError("You have to specify either input_ids or inputs_embeds")
+        top = self._owner() if self._owner is not None else self._standalone_top(
+            (input_ids[0] if isinstance(input_ids, (tuple, list)) else input_ids).device)
+        if top.training != self.training:
+            top.train(self.training)
         if joint:
             text, pair = input_ids
             tmask, pmask = attention_mask
@@ -1353,12 +1380,13 @@ class _HeadsFn(torch.autograd.Function):
 class MMBertForPretraining(_GpuModelBase):
     """REF:MMBertForPretraining.py:304-449."""
 
-    def __init__(self, config):
+    def __init__(self, config, _bert=None):
         super().__init__()
         import weakref
         self.config = config
         H = config.hidden_size
-        self.bert = MMBertModel(config, _owner=weakref.ref(self))
+        # (_bert: a standalone MMBertModel adopting this object as its private owner -- MMBertModel._standalone_top)
+        self.bert = _bert if _bert is not None else MMBertModel(config, _owner=weakref.ref(self))
         self.cls = MMBertPreTrainingHeads(config)
         self.cls._owner = weakref.ref(self)
         self.num_labels = 7
@@ -1384,7 +1412,7 @@ class MMBertForPretraining(_GpuModelBase):
         # heads through _HeadsFn (hand-written backward, csrc/heads.hip); False = the eager autograd form (_heads), in which
         # ap_loss / label_loss / nce and the relationship scores stay differentiable outputs
         self.fused_heads = os.environ.get("MMBERT_FUSED_HEADS", "1") != "0"
-        _hf_init(self, config.initializer_range)
+        _hf_init(self, config.initializer_range, skip=_bert)
         # weight tying (HF:728-731): decoder.weight IS the word embedding, decoder.bias IS predictions.bias
         self.cls.predictions.decoder.weight = self.bert.embeddings.word_embeddings.weight
 
@@ -1413,12 +1441,14 @@ class MMBertForPretraining(_GpuModelBase):
         return out
 
     @classmethod
-    def from_pretrained(cls, name_or_path, ignore_unexpected=False, **kw):
+    def from_pretrained(cls, name_or_path, ignore_unexpected=True, **kw):
         """Loads ``config.json`` + ``pytorch_model.bin`` / ``model.safetensors`` from a LOCAL directory (there is no network on the
         target boxes): ``BertForPreTraining`` / ``BertForMaskedLM`` / ``BertModel`` key names, current or legacy (``_checkpoint_keys``).
         LOUD about what did not arrive: a missing ``bert.embeddings.*`` / ``bert.encoder.*`` tensor raises (a silently fresh encoder
-        is never what the caller wants), as does any key of the file that matches nothing in the model (``ignore_unexpected=True``
-        downgrades that to a warning); heads the file does not have (``cls.*``, ``bert.pooler.*``) and the reference's own additions
+        is never what the caller wants); a key of the file that matches nothing in the model is reported in a WARNING and in
+        ``model.load_report["unexpected"]``, as HF's ``from_pretrained`` -- what the reference's flow calls, REF:train.py:70 -- does (a
+        checkpoint with extra heads or buffers that loaded under the reference loads here too; ``ignore_unexpected=False`` makes it an
+        error, round 3's default); heads the file does not have (``cls.*``, ``bert.pooler.*``) and the reference's own additions
         (jointEmbeddings, fusion head, CPC) keep their fresh initialisation, with a warning that names them -- HF's
         "newly initialized" message.  ``model.load_report`` = dict(missing=[...], unexpected=[...])."""
         import warnings
@@ -1450,7 +1480,7 @@ class MMBertForPretraining(_GpuModelBase):
         if unexpected:
             msg = f"{name_or_path}: {len(unexpected)} checkpoint tensor(s) match no parameter of MMBertForPretraining: {unexpected[:8]}{' ...' if len(unexpected) > 8 else ''}"
             if not ignore_unexpected:
-                raise ValueError(msg + " (from_pretrained(..., ignore_unexpected=True) loads the rest anyway)")
+                raise ValueError(msg + " (ignore_unexpected=False was requested; the default loads the rest and warns)")
             warnings.warn(msg)
         fresh = [k for k in missing if k.startswith(("cls.", "bert.pooler."))]
         if fresh:

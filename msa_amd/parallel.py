@@ -61,6 +61,9 @@ class GradBucketer:
         self.done = 0            # elements already handed to the collective
         self.next_slice = 0
         self.enabled = True
+        # world 1 short-circuits the wire-dtype exchange to a plain all-reduce; tests set this to run the all-to-all + fp32 sum +
+        # all-gather path over RCCL on the one GPU a test box has (tests/test_train_gpu.py)
+        self.force_wire_path = False
         self.calls = 0           # number of collectives issued since reset (observable in tests)
         self.elems = 0           # elements exchanged since reset
 
@@ -90,7 +93,7 @@ class GradBucketer:
     def _start(self, lo: int, hi: int):
         self.calls += 1
         self.elems += hi - lo
-        if self.wire_dtype is None or self.world == 1:
+        if self.wire_dtype is None or (self.world == 1 and not self.force_wire_path):
             self.handles.append(dist.all_reduce(self.flat[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
             return
         self._advance()                                           # stage two of the buckets before this one: same point on every rank

@@ -460,13 +460,15 @@ def test_from_pretrained_reads_legacy_and_prefixless_checkpoints_and_is_loud(tmp
     with pytest.raises(ValueError, match="bert.encoder.layer.1.output.LayerNorm.weight"):
         MMBertForPretraining.from_pretrained(_write_ckpt(tmp_path / "broken", conf, broken))
 
-    # (4) a key that matches nothing raises; ignore_unexpected=True downgrades it to a warning
+    # (4) a key that matches nothing: warned about and recorded, as HF's from_pretrained (what REF:train.py:70 calls) does;
+    # ignore_unexpected=False makes it an error
     extra = dict(hf, **{"bert.encoder.layer.0.attention.self.distance_embedding.weight": torch.zeros(3, 4)})
     path = _write_ckpt(tmp_path / "extra", conf, extra)
     with pytest.raises(ValueError, match="distance_embedding"):
-        MMBertForPretraining.from_pretrained(path)
+        MMBertForPretraining.from_pretrained(path, ignore_unexpected=False)
     with pytest.warns(UserWarning, match="distance_embedding"):
-        m = MMBertForPretraining.from_pretrained(path, ignore_unexpected=True)
+        m = MMBertForPretraining.from_pretrained(path)
+    assert m.load_report["unexpected"] == ["bert.encoder.layer.0.attention.self.distance_embedding.weight"]
     assert torch.equal(m.state_dict()["bert.pooler.dense.weight"], hf["bert.pooler.dense.weight"])
 
     # (5) decoder.bias as the only name of the tied prediction bias (BertForMaskedLM-style files) is not "missing"

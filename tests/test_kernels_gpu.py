@@ -127,6 +127,65 @@ def test_gemm_nt_dynamic_tile_queue_is_bit_identical(ops):
     assert_close(ref, torch.nn.functional.gelu(A.float() @ B.float().t() + bias), 2e-2, 2e-2, "queue launch vs torch")
 
 
+@pytest.mark.parametrize("mode", [0, 6])
+@pytest.mark.parametrize("epi", ["plain", "bias", "gelu", "resid_drop", "resid", "gelu_bwd", "bias_f32"])
+def test_gemm_nt_tile_queue_bit_identical_every_instantiation(ops, epi, mode):
+    """the queue's fetch is an inline-asm atomic whose result is read behind a hand-counted s_waitcnt (a compiler-inserted copy
+    of that register before the wait would read stale data -> duplicate or missing tiles), and the counts depend on the epilogue's
+    store count.  So: EVERY epilogue instantiation of the persistent kernel, both tile forms (mode 0: the default 224-row form; mode 6:
+    the 256-row staggered form), on a multi-round shape whose last row panel AND last column panel are ragged (edge tiles take the
+    E = 0 waits), queue against static walk: the same bits, twice in a row on one queue buffer."""
+    import msa_amd.ops as O
+    from msa_amd import _lib
+    M, N, K = 18400 - 37, 3072 - 40, 768
+    A, B = bf(rnd(M, K, seed=311, scale=0.1)).to(DEV), bf(rnd(N, K, seed=312, scale=0.1)).to(DEV)
+    bias, R = rnd(N, seed=313).to(DEV), bf(rnd(M, N, seed=314)).to(DEV)
+    kw = {"plain": {}, "bias": dict(bias=bias), "gelu": dict(bias=bias, gelu=True), "resid_drop": dict(bias=bias, resid=R, drop=ops.make_drop(0.1, 5, 9)),
+          "resid": dict(resid=R), "gelu_bwd": dict(gelu_bwd_u=R), "bias_f32": dict(bias=bias, out_f32=True)}[epi]
+    d = ops.gemm_nt_describe(M, N, K, with_queue=True)
+    was = O.dynamic_tile_queue
+    try:
+        _lib.load().mmbert_gemm_nt_force(mode)
+        d = ops.gemm_nt_describe(M, N, K, with_queue=True)
+        assert d["kernel"] == "persistent" and d["tiles"] > d["cus"] and d["tile"] == ("256x256" if mode == 6 else "224x256"), d
+        O.dynamic_tile_queue = False
+        aux0 = torch.empty((M, N), device=DEV, dtype=torch.bfloat16) if epi == "gelu" else None
+        ref = ops.gemm_nt(A, B, aux=aux0, **kw)
+        O.dynamic_tile_queue = True
+        for rep in range(2):
+            aux1 = torch.empty((M, N), device=DEV, dtype=torch.bfloat16) if epi == "gelu" else None
+            out = ops.gemm_nt(A, B, aux=aux1, **kw)
+            assert torch.equal(out, ref), (epi, mode, rep)
+            assert aux0 is None or torch.equal(aux1, aux0), (epi, mode, rep)
+    finally:
+        O.dynamic_tile_queue = was
+        _lib.load().mmbert_gemm_nt_force(0)
+
+
+def test_dropout_hash_pairwise_keep_correlations(ops):
+    """mmb_pair_mix is one xorshift16-multiply-xorshift16 round on a Weyl sequence and each 16-bit half of a word decides one
+    element, so rates alone do not show whether the two halves of a word, neighbouring pairs or neighbouring rows are independent.
+    Pearson correlation of the keep flags at p = 0.1 and 0.5 over 2^23 elements laid out as rows of H = 768: element 2i vs 2i + 1 (the
+    two halves of one word), pair i vs i + 1 (same half of neighbouring words), row r vs r + 1 (768 elements = 384 words apart), and
+    two different sites (streams) at the same index.  Independent bits give |rho| ~ 1 / sqrt(n) = 3.5e-4; bound 2e-3."""
+    H, rows = 768, 8192
+    n = H * rows
+    for p_drop in (0.1, 0.5):
+        k = ops.dropout_mask(n, ops.make_drop(p_drop, 12345, 77), DEV).float().view(rows, H)
+        k2 = ops.dropout_mask(n, ops.make_drop(p_drop, 12345, 78), DEV).float().view(rows, H)
+        rate = float(k.mean())
+        assert abs(rate - (1 - p_drop)) < 2e-3, (p_drop, rate)
+
+        def rho(a, b):
+            a, b = a.reshape(-1) - a.mean(), b.reshape(-1) - b.mean()
+            return float((a * b).mean() / (a.std() * b.std() + 1e-12))
+        checks = {"halves of one word": rho(k[:, 0::2], k[:, 1::2]), "low halves of neighbouring words": rho(k[:, 0:-2:2], k[:, 2::2]),
+                  "high half vs next word's low half": rho(k[:, 1:-1:2], k[:, 2::2]), "rows r, r + 1": rho(k[:-1], k[1:]),
+                  "rows r, r + 2": rho(k[:-2], k[2:]), "two sites": rho(k, k2)}
+        for what, r in checks.items():
+            assert abs(r) < 2e-3, (p_drop, what, r)
+
+
 @pytest.mark.parametrize("M,N,K", [(300, 256, 4096), (77, 768, 30592), (130, 132, 1024)])
 def test_gemm_nt_splitk(ops, M, N, K):
     A, B = bf(rnd(M, K, seed=15, scale=0.1)), bf(rnd(N, K, seed=16, scale=0.1))

@@ -11,6 +11,11 @@ M = int(os.environ.get("M", 18400))
 shapes = [("qkv", M, 2304, 768, "bias"), ("o", M, 768, 768, "resid"), ("w1", M, 3072, 768, "gelu"), ("w2", M, 768, 3072, "resid"),
           ("dgelu", M, 3072, 768, "gelu_bwd"), ("dy1", M, 768, 3072, "resid0"), ("dx", M, 768, 2304, "resid0"), ("dctx", M, 768, 768, "plain"),
           ("vocab", M, 30592, 768, "bias"), ("dvocab", M, 768, 30592, "plain")]
+if os.environ.get("SHAPESET") == "bert-large":            # the reference's default model (REF:train.py:28,32,38): H = 1024, I = 4096, M = 32 * 200
+    M = int(os.environ.get("M", 6400))
+    shapes = [("qkv", M, 3072, 1024, "bias"), ("o", M, 1024, 1024, "resid"), ("w1", M, 4096, 1024, "gelu"), ("w2", M, 1024, 4096, "resid"),
+              ("dgelu", M, 4096, 1024, "gelu_bwd"), ("dy1", M, 1024, 4096, "resid0"), ("dx", M, 1024, 3072, "resid0"), ("dctx", M, 1024, 1024, "plain"),
+              ("vocab", M, 30592, 1024, "bias")]
 rounds = int(os.environ.get("ROUNDS", 5))
 MODES = [int(x) for x in os.environ.get("MODES", "3,4").split(",")]
 NAMES = {0: "default", 1: "128sq", 2: "ring auto", 3: "ring256", 4: "ring224", 5: "pers auto", 6: "pers256", 7: "pers224"}
