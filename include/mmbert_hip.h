@@ -59,10 +59,12 @@ size_t mmbert_gemm_nt_splitk_workspace(int M, int N, int K);
 
 /* Kernel selection for mmbert_gemm_nt: 0 = by shape (default), 1 = 128x128 tile kernel, 2 = 4-stage-ring kernel
  * with the tile height (256 or 224 rows) chosen by tile-round count, 3 = ring kernel 256x256, 4 = ring kernel
- * 224x256.  For tests and A/B benchmarking; results are identical up to fp32 summation order. */
+ * 224x256, 5 / 6 / 7 = the persistent stream kernel (tile height by shape / 256 / 224 rows), 8 = the 8-phase kernel for every
+ * eligible shape (K % 128 == 0).  For tests and A/B benchmarking; results are identical up to fp32 summation order. */
 void mmbert_gemm_nt_force(int mode);
 /* Which kernel mmbert_gemm_nt launches for a shape on the current device (contiguous operands), without launching anything:
- * out[0] kernel (0: 128x128-tile kernel, 1: 4-slot-ring kernel, one launch slot per tile, 2: persistent stream kernel), out[1] tile
+ * out[0] kernel (0: 128x128-tile kernel, 1: 4-slot-ring kernel, one launch slot per tile, 2: persistent stream kernel, 3: the 256x256
+ * 8-phase kernel that takes every launch whose tiles fit the chip in one round), out[1] tile
  * rows (128 / 224 / 256), out[2] tile columns, out[3] output tiles, out[4] workgroups launched, out[5] tile rounds x 100 over the
  * device's CUs, out[6] group_m of the tile walk, out[7] CUs.  with_queue: as if a tile_queue were passed.  Host-only; bench.py
  * reports it per shape of the reference's default model (REF:train.py:28,32,38), tests pin the headline shapes. */

@@ -958,11 +958,282 @@ __global__ __launch_bounds__(512, 2) void gemm_ntp_kernel(const GemmNT p) {
 #endif
 }
 
+
+// -------------------------------------------------------------------------------------------------
+// NT, single-round shapes (round 4): the 256 x 256 "8-phase" structure of the CDNA4 guide (cdna_hip_programming.md S5), one tile per
+// workgroup.  VERDICT r3 asked for the guide's template as an in-tree yardstick (tools/yardstick/, profiles/r4_nt_yardstick.log): on cold
+// random operands it beat the persistent kernel below by 11-23 % on every shape whose tiles fit the chip in ONE round -- the N = 768
+// launches of the step: out-proj, FFN-down and all input gradients, 45 % of the family's time -- (and by 21-39 % on 4096^3 / 8192^3),
+// tied it on the multi-round K = 768 shapes (QKV, FFN-up, GELU' dgrad) and lost 3 % on the vocabulary projection, whose 34 rounds the
+// persistent kernel's cross-tile stream serves better.  What differs from the ring kernels and why it is faster in the K loop:
+//   * BK = 64: an LDS-DMA wave instruction moves 8 rows x 128 B -- whole cache lines (the 32-deep stages' 16 x 64-B pieces cost the
+//     texture path 25 % more per instruction) -- and a K tile of 64 has HALF the barriers per FLOP;
+//   * half-tiles are QUADRANT operands (A-half h = rows {wr*128 + h*64 ..}, B-half h = columns {wc*64 + h*32 ..}): every wave reads
+//     b0, a0 in phase 1, b1 in phase 2, a1 in phase 3, nothing in phase 4, so an LDS half-tile is free again one to two phases after
+//     its phase and the LDS-DMA stream runs 3 half-tiles ahead behind ONE counted vmcnt(6) per K tile;
+//   * two wave groups (wr = 0 / 1: one wave of each per SIMD) one barrier apart: one group's 16 MFMAs of a phase run under the other
+//     group's fragment reads and LDS-DMA issue; fragments are single-buffered (64 VGPRs), all 256 rows fit (210 VGPRs, no spills).
+// LDS image of a half-tile: [128 rows][64 k] bf16; 16-byte chunk c of row r sits at chunk c ^ key(r), key = (r >> 1) & 7 for A and
+// ((r >> 1) & 1) | (((r >> 3) & 3) << 1) for B (B rows are read in the permuted order that gives a lane 8 consecutive output columns,
+// as in gemm_ntp_kernel): every ds_read_b128 lane group hits 16 distinct 16-byte slots; swizzle on the per-lane SOURCE address.
+// Epilogue: straight from the accumulators, the persistent kernel's lane map (2 x 8 consecutive columns per row block and lane).
+// -------------------------------------------------------------------------------------------------
+template <int EPI>
+__global__ __launch_bounds__(512, 2) void gemm_nt8_kernel(const GemmNT p) {
+#if __HIP_DEVICE_COMPILE__
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // buffer d at d * 65536: A0h | A1h | B0h | B1h, 16 KiB each
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+    const int tiles_n = (p.N + 255) >> 8, tiles_m = (p.M + 255) >> 8;
+    const int tile = xcd_remap(blockIdx.x, tiles_m * tiles_n);
+    const int m0 = (tile / tiles_n) << 8, n0 = (tile % tiles_n) << 8;
+    const int nt = p.K >> 6;                                     // K tiles (K % 128 == 0: an even count)
+
+    // ---- staging: wave w issues pieces j = w and w + 8 of a half-tile (piece = local rows 8j .. 8j + 7, 1 KiB) ----
+    const auto rsA = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, (int)((uint32_t)p.M * (uint32_t)p.lda * 2u), 0x00020000);
+    const auto rsB = __builtin_amdgcn_make_buffer_rsrc((void*)p.B, 0, (int)((uint32_t)p.N * (uint32_t)p.ldb * 2u), 0x00020000);
+    uint32_t va[2][2], vb[2][2];                                 // [half][piece]: per-lane byte offsets into A / B (the K offset is scalar)
+    {
+        const int pos = lane & 7;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int j = wave + 8 * i, r = 8 * j + (lane >> 3);              // local row of the half-tile
+            const uint32_t chunk_a = (uint32_t)(pos ^ ((r >> 1) & 7));
+            const uint32_t chunk_b = (uint32_t)(pos ^ (((r >> 1) & 1) | (((r >> 3) & 3) << 1)));
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int ga = m0 + (r >> 6) * 128 + h * 64 + (r & 63);
+                const int gb = n0 + (r >> 5) * 64 + h * 32 + (r & 31);
+                va[h][i] = ((uint32_t)min(ga, p.M - 1) * (uint32_t)p.lda + chunk_a * 8u) * 2u;
+                vb[h][i] = ((uint32_t)min(gb, p.N - 1) * (uint32_t)p.ldb + chunk_b * 8u) * 2u;
+            }
+        }
+    }
+    // half-tile ids in the order of first use: 0 = B0h, 1 = A0h, 2 = B1h, 3 = A1h
+    auto stage = [&](int buf, int which, int kt) {
+        const uint32_t kb = (uint32_t)min(kt, nt - 1) * 128u;    // past the last tile: dead re-reads, the in-flight count stays constant
+        const int h = which >> 1;
+        char* base = smem + buf * 65536 + ((which & 1) ? 0 : 32768) + h * 16384 + wave * 1024;
+        if (which & 1) {
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, LPTR(base), 16, va[h][0], kb, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, LPTR(base + 8192), 16, va[h][1], kb, 0, 0);
+        } else {
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, LPTR(base), 16, vb[h][0], kb, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, LPTR(base + 8192), 16, vb[h][1], kb, 0, 0);
+        }
+    };
+
+    // ---- fragment reads ----
+    typedef const __attribute__((address_space(3))) char* lds_cptr;
+    typedef const __attribute__((address_space(3))) bf16x8* lds_frag;
+    const int fr = lane & 15, fq = lane >> 4;
+    const int swa = ((fq ^ (fr >> 1)) & 7) << 4;                                  // k step 0: chunk fq; k step 1: the same ^ 64 bytes
+    const int swb = ((fq ^ (((fr >> 1) & 1) | ((fr >> 2) << 1))) & 7) << 4;       // key of B row 8 (fr >> 2) + 4 j + (fr & 3)
+    const lds_cptr a_rd = (lds_cptr)LPTR(smem) + (wr * 64 + fr) * 128;
+    const lds_cptr b_rd = (lds_cptr)LPTR(smem) + 32768 + (wc * 32 + 8 * (fr >> 2) + (fr & 3)) * 128;
+    lds_cptr a_rd1 = a_rd + 65536, b_rd1 = b_rd + 65536;        // second buffer: ds offsets are 16-bit
+    asm volatile("" : "+v"(a_rd1), "+v"(b_rd1));
+
+    bf16x8 af[2][4], b0f[2][2], b1f[2][2];
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    auto read_a = [&](int buf, int h) {
+        const lds_cptr ab = buf ? a_rd1 : a_rd;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) af[ks][i] = *(lds_frag)(ab + h * 16384 + i * 2048 + (swa ^ (ks * 64)));
+    };
+    auto read_b = [&](int buf, int h, bf16x8 (&bf)[2][2]) {
+        const lds_cptr bb = buf ? b_rd1 : b_rd;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) bf[ks][j] = *(lds_frag)(bb + h * 16384 + j * 512 + (swb ^ (ks * 64)));
+    };
+    auto mma = [&](int qa, int qb, const bf16x8 (&bf)[2][2]) {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)     // operands swapped (B first): a lane holds 4 consecutive COLUMNS of one output row
+                    acc[qa * 4 + i][qb * 2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[ks][j], af[ks][i], acc[qa * 4 + i][qb * 2 + j], 0, 0, 0);
+    };
+
+    // ---- prologue: tile 0 (4 half-tiles, even buffer) and the first 3 half-tiles of tile 1 (odd buffer) ----
+    stage(0, 0, 0); stage(0, 1, 0); stage(0, 2, 0); stage(0, 3, 0);
+    stage(1, 0, 1); stage(1, 1, 1); stage(1, 2, 1);
+    __builtin_amdgcn_s_waitcnt(mmb_waitcnt(6, 15));               // tile 0 landed (this wave's pieces)
+    __builtin_amdgcn_s_barrier();
+    if (wr == 1) __builtin_amdgcn_s_barrier();                    // the stagger: group 1 runs one barrier behind group 0
+
+    // one phase: { LDS reads of this phase's quadrant operands ; one half-tile of LDS-DMA ; [counted waits] ; barrier ; MFMAs ; barrier }
+#define NT8_PHASE(READS, LGK_BEFORE_BARRIER, STAGE, VMWAIT, QA, QB, BF)                                              \
+    {                                                                                                               \
+        READS;                                                                                                      \
+        STAGE;                                                                                                      \
+        if (LGK_BEFORE_BARRIER >= 0) __builtin_amdgcn_s_waitcnt(mmb_waitcnt(63, LGK_BEFORE_BARRIER < 0 ? 0 : LGK_BEFORE_BARRIER)); \
+        if (VMWAIT >= 0) __builtin_amdgcn_s_waitcnt(mmb_waitcnt(VMWAIT < 0 ? 0 : VMWAIT, 15));                       \
+        __builtin_amdgcn_s_barrier();                                                                               \
+        __builtin_amdgcn_s_waitcnt(mmb_waitcnt(63, 0));                                                             \
+        __builtin_amdgcn_sched_barrier(0);                                                                          \
+        __builtin_amdgcn_s_setprio(1);                                                                              \
+        mma(QA, QB, BF);                                                                                            \
+        __builtin_amdgcn_s_setprio(0);                                                                              \
+        __builtin_amdgcn_s_barrier();                                                                               \
+        __builtin_amdgcn_sched_barrier(0);                                                                          \
+    }
+    // K tile t in buffer D (tile t + 1 in D ^ 1).  RAW: everything of tile t + 1 is issued by phase 1 of tile t and retired by the
+    // vmcnt(6) of phase 4 (3 half-tiles of tile t + 2 stay in flight), one phase before its first read.  WAR: b0 (read FIRST in phase 1
+    // and retired by lgkmcnt(8) before that phase's first barrier) is restaged in phase 2; a0 (phase 1) in phase 3; b1 (phase 2) in
+    // phase 4; a1 (phase 3) in phase 1 of the next tile -- two phases after their reads, which covers the group that runs a barrier behind.
+#define NT8_KTILE(D, T)                                                                                                      \
+    NT8_PHASE((read_b(D, 0, b0f), __builtin_amdgcn_sched_barrier(0), read_a(D, 0)), 8, stage(D ^ 1, 3, (T) + 1), -1, 0, 0, b0f) \
+    NT8_PHASE(read_b(D, 1, b1f), -1, stage(D, 0, (T) + 2), -1, 0, 1, b1f)                                                    \
+    NT8_PHASE(read_a(D, 1), -1, stage(D, 1, (T) + 2), -1, 1, 1, b1f)                                                         \
+    NT8_PHASE((void)0, -1, stage(D, 2, (T) + 2), 6, 1, 0, b0f)
+
+    for (int t = 0; t < nt; t += 2) {
+        NT8_KTILE(0, t)
+        NT8_KTILE(1, t + 1)
+    }
+#undef NT8_KTILE
+#undef NT8_PHASE
+    if (wr == 0) __builtin_amdgcn_s_barrier();                    // balances the stagger
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // the dead tail half-tiles
+
+    // ---- epilogue, straight from the accumulators: acc[i][2 h + (r >> 2)][r & 3] = C[m0 + wr*128 + 16 i + fr][n0 + wc*64 + 32 h + 8 fq + r] ----
+    // (every per-lane address comes from an opaque copy of the lane id so that nothing of it is kept alive across the K loop)
+    int elane = lane;
+    asm volatile("" : "+v"(elane));
+    const int efr = elane & 15, efq = elane >> 4;
+    const float alpha = p.alpha * (p.alpha_dev ? *p.alpha_dev : 1.0f);
+    const bool interior = (m0 + 256 <= p.M) && (n0 + 256 <= p.N);
+    const int mrow = m0 + wr * 128 + efr;                        // + 16 i
+    const int ncol = n0 + wc * 64 + efq * 8;                     // 8 columns here (h = 0) and 8 at + 32 (h = 1)
+    constexpr int PRE = 3;
+    bf16x8 pre[8][2];
+    auto load_pre = [&](int i) {
+        if constexpr (EPI & (EPI_RESID | EPI_GELU_BWD)) {
+            const bf16_t* src = (EPI & EPI_RESID) ? p.R : p.U;
+            const int ld = (EPI & EPI_RESID) ? p.ldr : p.ldu;
+            const bf16_t* rp = src + (size_t)min(mrow + 16 * i, p.M - 1) * ld;       // clamped in range: a half that is out of range is never stored
+            pre[i][0] = *(const bf16x8*)(rp + min(ncol, p.N - 8));
+            pre[i][1] = *(const bf16x8*)(rp + min(ncol + 32, p.N - 8));
+        }
+    };
+#pragma unroll
+    for (int i = 0; i < PRE; ++i) load_pre(i);
+    float bias[16];
+    if constexpr (EPI & EPI_BIAS) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const float* bp = p.bias + min(ncol + 32 * h, p.N - 8);
+            const float4 b0 = *(const float4*)bp, b1 = *(const float4*)(bp + 4);
+            bias[8 * h + 0] = b0.x; bias[8 * h + 1] = b0.y; bias[8 * h + 2] = b0.z; bias[8 * h + 3] = b0.w;
+            bias[8 * h + 4] = b1.x; bias[8 * h + 5] = b1.y; bias[8 * h + 6] = b1.z; bias[8 * h + 7] = b1.w;
+        }
+    }
+    // phase 1 (needs no residual data): scale, bias and the dropout decision, in place in the accumulators.  Dropout seeds are linear
+    // in the element index (common.h): pair(m, n) = m * N/2 + n/2 (mod 2^32) -- one multiply per lane, wave-uniform increments after it
+    const uint32_t dthr = (EPI & EPI_RESID) ? p.drop_thr16 : 0u;
+    const uint32_t dthr_s = dthr - 32768u;                       // the signed-compare form of mmb_keep16
+    const float dscale = (EPI & EPI_RESID) ? p.drop_scale : 1.0f;
+    const uint32_t halfN = (uint32_t)p.N >> 1;
+    const uint32_t seed0 = (EPI & EPI_RESID) ? ((uint32_t)mrow * halfN + ((uint32_t)ncol >> 1)) * MMB_WEYL + p.drop_stream : 0u;
+    const uint32_t seed_row = 16u * halfN * MMB_WEYL;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                float v = acc[i][2 * h + (r >> 2)][r & 3] * alpha;
+                if constexpr (EPI & EPI_BIAS) v += bias[8 * h + r];
+                acc[i][2 * h + (r >> 2)][r & 3] = v;
+            }
+            if constexpr (EPI & EPI_RESID) {
+                if (dthr) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {                // element pair k of the 8 columns: elements 2k, 2k + 1
+                        const uint32_t hb = mmb_pair_mix(seed0 + (uint32_t)i * seed_row + (uint32_t)(16 * h + k) * MMB_WEYL);
+                        f32x4& a4 = acc[i][2 * h + (k >> 1)];
+                        const bool keep0 = (int16_t)(uint16_t)(hb & 0xFFFFu) >= (int16_t)(uint16_t)dthr_s;
+                        const bool keep1 = (int16_t)(uint16_t)(hb >> 16) >= (int16_t)(uint16_t)dthr_s;
+                        a4[(2 * k) & 3] = keep0 ? a4[(2 * k) & 3] * dscale : 0.f;
+                        a4[(2 * k + 1) & 3] = keep1 ? a4[(2 * k + 1) & 3] * dscale : 0.f;
+                    }
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        if (i + PRE < 8) load_pre(i + PRE);
+        const int m = mrow + 16 * i;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int n = ncol + 32 * h;
+            float vv[8];
+#pragma unroll
+            for (int r = 0; r < 8; ++r) vv[r] = acc[i][2 * h + (r >> 2)][r & 3];
+            const bool ok = interior || (m < p.M && n + 8 <= p.N);
+            if constexpr (EPI & EPI_GELU) {
+                if (p.aux) {
+                    bf16x8 u;
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) u[r] = f2bf(vv[r]);
+                    if (ok) *(bf16x8*)(p.aux + (size_t)m * p.ldaux + n) = u;
+                }
+#pragma unroll
+                for (int r = 0; r < 8; ++r) vv[r] = gelu_erf(vv[r]);
+            }
+            if constexpr (EPI & EPI_GELU_BWD) {
+#pragma unroll
+                for (int r = 0; r < 8; ++r) vv[r] *= gelu_erf_grad(bf2f(pre[i][h][r]));
+            }
+            if constexpr (EPI & EPI_RESID) {
+#pragma unroll
+                for (int r = 0; r < 8; ++r) vv[r] += bf2f(pre[i][h][r]);
+            }
+            if constexpr (EPI & EPI_OUT_F32) {
+                float* c = (float*)p.C + (size_t)m * p.ldc + n;
+                if (ok) {
+                    *(float4*)c = make_float4(vv[0], vv[1], vv[2], vv[3]);
+                    *(float4*)(c + 4) = make_float4(vv[4], vv[5], vv[6], vv[7]);
+                }
+            } else {
+                bf16x8 o;
+#pragma unroll
+                for (int r = 0; r < 8; ++r) o[r] = f2bf(vv[r]);
+                if (ok) *(bf16x8*)((bf16_t*)p.C + (size_t)m * p.ldc + n) = o;
+            }
+        }
+    }
+#endif
+}
+
+template <int EPI>
+static int launch_nt8(hipStream_t s, const GemmNT& p) {
+    const int tiles = ((p.M + 255) / 256) * ((p.N + 255) / 256);
+    static std::atomic<unsigned long long> attr_done{0};
+    if (int e = mmb_allow_lds((const void*)gemm_nt8_kernel<EPI>, 131072, attr_done)) return e;
+    hipLaunchKernelGGL((gemm_nt8_kernel<EPI>), dim3(tiles), dim3(512), 131072, s, p);
+    MMB_CHECK_LAUNCH();
+    return 0;
+}
+
 constexpr int NTP_LDS_BYTES = 131072 + 1024 + 8 * 256;      // ring | tile-queue word (padded) | bias rows
 
 // ---- which kernel, which tile, which tile walk: ONE function of the shape (and of the test / A-B knobs), shared by the launch path
 // and by mmbert_gemm_nt_describe() (bench.py reports the choice per shape; tests pin it) ----
-enum { NTK_128 = 0, NTK_RING = 1, NTK_PERSIST = 2 };
+enum { NTK_128 = 0, NTK_RING = 1, NTK_PERSIST = 2, NTK_8PHASE = 3 };
 struct NTChoice { int kernel, bm, tiles, workgroups, group_m, use_queue; };
 
 static bool ntp_eligible(const GemmNT& p) {
@@ -1014,6 +1285,19 @@ static NTChoice nt_choose(const GemmNT& p, int epi) {
     const int t256 = ((p.M + 255) / 256) * tn, t224 = ((p.M + 223) / 224) * tn;
     const int r256 = (t256 + cus - 1) / cus, r224 = (t224 + cus - 1) / cus;
     const bool can_persist = g_nt_persist && ntp_eligible(p);
+    // Single-round launches go to the 8-phase kernel (round 4; see gemm_nt8_kernel): its 256-row tiles must fit the chip in one round.
+    // A/B switch, read per call: MMBERT_NT_8PHASE=0 keeps the persistent kernel; mmbert_gemm_nt_force(8) forces it for every eligible shape.
+    {
+        const char* e8 = getenv("MMBERT_NT_8PHASE");
+        const bool on8 = !(e8 && atoi(e8) == 0);
+        // ... unless they leave more than half the chip idle (the reference's default model: M = 6400, N = 1024 is 100 tiles): the 128 x 128
+        // kernel's 4 x as many tiles on 2 workgroups per CU are 6-14 % faster there (profiles/r4_bert_large_gemm_modes.log)
+        if (g_nt_force == 0 && on8 && 2 * t256 <= cus && c.tiles <= 2 * cus) return c;
+        if (ntp_eligible(p) && ((g_nt_force == 0 && on8 && t256 <= cus) || g_nt_force == 3)) {
+            c.kernel = NTK_8PHASE; c.bm = 256; c.tiles = t256; c.workgroups = t256;
+            return c;
+        }
+    }
     bool persist, tall;
     if (g_nt_bm == 0) {
         // default: the 224-row form.  The 256-row staggered form (mode 6) wins 1-7 % on single-round and very wide shapes in
@@ -1090,6 +1374,7 @@ template <int EPI>
 static int dispatch_nt(hipStream_t s, const GemmNT& p) {
     const NTChoice c = nt_choose(p, EPI);
     if (c.kernel == NTK_128) return launch_nt<EPI>(s, p);
+    if (c.kernel == NTK_8PHASE) return launch_nt8<EPI>(s, p);
     if (c.kernel == NTK_PERSIST) return c.bm == 256 ? launch_ntp_mi<EPI, 8>(s, p, c) : launch_ntp_mi<EPI, 7>(s, p, c);
     return c.bm == 256 ? launch_nt256_mi<EPI, 8>(s, p) : launch_nt256_mi<EPI, 7>(s, p);
 }
@@ -1521,7 +1806,8 @@ int mmbert_debug_set_nt_dbg(int v) {
 #endif
 void mmbert_gemm_nt_force(int mode) {
     // 0 auto | 1 128^2 | ring kernel, one launch slot per tile: 2 (tile height auto), 3 (256x256), 4 (224x256)
-    // | persistent stream kernel: 5 (tile height auto), 6 (256x256), 7 (224x256)
+    // | persistent stream kernel: 5 (tile height auto), 6 (256x256), 7 (224x256) | 8: the 8-phase kernel for every eligible shape
+    if (mode == 8) { g_nt_force.store(3); g_nt_bm.store(0); g_nt_persist.store(1); return; }
     g_nt_force.store(mode >= 2 ? 2 : mode);
     g_nt_bm.store((mode == 3 || mode == 6) ? 256 : (mode == 4 || mode == 7) ? 224 : 0);
     g_nt_persist.store((mode >= 2 && mode <= 4) ? 0 : (mode >= 6 ? 2 : 1));      // 2: forced persistent tile height

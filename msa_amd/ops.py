@@ -108,7 +108,7 @@ def gemm_nt_describe(M: int, N: int, K: int, epi: int = 0, with_queue: bool = Fa
     import ctypes
     out = (ctypes.c_int * 8)()
     _lib.check(_lib.load().mmbert_gemm_nt_describe(int(M), int(N), int(K), int(epi), int(bool(with_queue)), out), "mmbert_gemm_nt_describe")
-    kern = {0: "128x128", 1: "ring", 2: "persistent"}[out[0]]
+    kern = {0: "128x128", 1: "ring", 2: "persistent", 3: "8phase"}[out[0]]
     return dict(kernel=kern, tile=f"{out[1]}x{out[2]}", tiles=out[3], workgroups=out[4], rounds=out[5] / 100.0, group_m=out[6], cus=out[7])
 
 

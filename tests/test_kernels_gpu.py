@@ -54,10 +54,11 @@ def test_gemm_nt_plain_and_bias(ops, M, N, K):
     assert_close(ops.gemm_nt(A.to(DEV), B.to(DEV), bias=bias.to(DEV), out_f32=True, alpha=0.5), 0.5 * ref + bias, 1e-4, 1e-3, "f32 out")
 
 
-@pytest.mark.parametrize("mode", [1, 3, 4, 6, 7])
+@pytest.mark.parametrize("mode", [1, 3, 4, 6, 7, 8])
 @pytest.mark.parametrize("M,N,K", [(256, 256, 128), (700, 768, 768), (1150, 2304, 768), (520, 768, 3072), (2048, 30592, 128), (513, 260, 160)])
 def test_gemm_nt_both_kernels_all_epilogues(ops, mode, M, N, K):
-    """The 128^2 and the 256x256 / 224x256 (4-stage ring) kernels, forced, on ragged shapes: M, N not tile multiples, K = 32*odd."""
+    """The 128^2, the 256x256 / 224x256 (4-stage ring, persistent) and the 8-phase (mode 8: K % 128 == 0 shapes) kernels, forced, on ragged
+    shapes: M, N not tile multiples, K = 32*odd."""
     from msa_amd import _lib
     lib = _lib.load()
     lib.mmbert_gemm_nt_force(mode)
@@ -78,7 +79,7 @@ def test_gemm_nt_both_kernels_all_epilogues(ops, mode, M, N, K):
         lib.mmbert_gemm_nt_force(0)
 
 
-@pytest.mark.parametrize("mode,M", [(3, 384), (4, 384), (4, 450), (2, 18400 // 8), (6, 384), (7, 450), (7, 18400), (6, 18400), (5, 5000)])
+@pytest.mark.parametrize("mode,M", [(3, 384), (4, 384), (4, 450), (2, 18400 // 8), (6, 384), (7, 450), (7, 18400), (6, 18400), (5, 5000), (8, 450), (8, 18400), (0, 18400)])
 def test_gemm_nt256_exact_integers(ops, mode, M):
     from msa_amd import _lib
     lib = _lib.load()
@@ -91,6 +92,44 @@ def test_gemm_nt256_exact_integers(ops, mode, M):
         assert torch.equal(out.cpu(), A @ B.t())
     finally:
         lib.mmbert_gemm_nt_force(0)
+
+
+@pytest.mark.parametrize("K", [768, 2304, 3072])
+def test_gemm_nt_8phase_kernel_headline_shapes_every_epilogue(ops, K):
+    """Round 4: the 8-phase kernel (one 256 x 256 tile per workgroup, 64-deep K tiles, LDS-DMA half-tiles 3 ahead) takes every launch whose
+    tiles fit the chip in one round -- in the train step the N = 768 shapes: out-proj / FFN-down (+ bias + dropout + residual) and the
+    input gradients (+ residual, plain) at K = 768 / 2304 / 3072.  At the step's own size with a ragged last row panel (M = 18 400 - 37):
+    the default dispatch really picks it; every epilogue against fp32 torch on the bf16-rounded operands (dropout through the exported
+    mask); and against the persistent kernel (mode 7) to one bf16 ulp of the largest entry (the two differ in fp32 summation order)."""
+    from msa_amd import _lib
+    lib = _lib.load()
+    M, N = 18400 - 37, 768
+    d = ops.gemm_nt_describe(M, N, K)
+    assert d["kernel"] == "8phase" and d["tile"] == "256x256" and d["tiles"] <= d["cus"], d
+    A, B = bf(rnd(M, K, seed=21, scale=0.5)).to(DEV), bf(rnd(N, K, seed=22, scale=0.05)).to(DEV)
+    bias, R = rnd(N, seed=23).to(DEV), bf(rnd(M, N, seed=24)).to(DEV)
+    ref = A.float() @ B.float().t()
+    drop = ops.make_drop(0.1, 11, 5)
+    keep = ops.dropout_mask(M * N, drop, DEV).view(M, N).float()
+    u = R.float().requires_grad_(True)
+    torch.nn.functional.gelu(u).sum().backward()
+    cases = {"plain": ({}, ref), "bias": (dict(bias=bias), ref + bias), "resid": (dict(resid=R), ref + R.float()),
+             "bias_resid_drop": (dict(bias=bias, resid=R, drop=drop), (ref + bias) * keep * drop[2] + R.float()),
+             "gelu": (dict(bias=bias, gelu=True), torch.nn.functional.gelu(ref + bias)), "gelu_bwd": (dict(gelu_bwd_u=R), ref * u.grad),
+             "bias_f32": (dict(bias=bias, out_f32=True), ref + bias)}
+    for name, (kw, want) in cases.items():
+        got = ops.gemm_nt(A, B, **kw)
+        assert_close(got, want, 1e-2, 3e-2, name)
+        lib.mmbert_gemm_nt_force(7)
+        try:
+            other = ops.gemm_nt(A, B, **kw)
+        finally:
+            lib.mmbert_gemm_nt_force(0)
+        scale = float(other.float().abs().max())
+        assert float((got.float() - other.float()).abs().max()) <= 2.0 ** -7 * scale, name
+    aux = torch.empty((M, N), device=DEV, dtype=torch.bfloat16)                      # the GELU epilogue's second output
+    ops.gemm_nt(A, B, bias=bias, gelu=True, aux=aux)
+    assert_close(aux, ref + bias, 1e-2, 3e-2, "gelu aux")
 
 
 @pytest.mark.parametrize("M,N", [(18400, 2304), (14000, 3072), (5000, 3072), (9000, 1792)])

