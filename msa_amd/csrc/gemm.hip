@@ -20,6 +20,9 @@
 #include <cstring>
 #include <type_traits>
 
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+
 #define EPI_BIAS 1
 #define EPI_GELU 2       // out = gelu(v); optional aux = v (pre-activation, bf16)
 #define EPI_RESID 4      // out = dropout(v) + R
@@ -903,17 +906,26 @@ __global__ __launch_bounds__(512, 2) void gemm_ntp_kernel(const GemmNT p) {
 #pragma unroll
                     for (int r = 0; r < 8; ++r) vv[r] += bf2f(pre[i][h][r]);
                 }
+                // (round 4) The value to store is pinned in registers BEFORE the edge-tile predicate: hipcc otherwise sinks its computation --
+                // the use of the prefetched residual / GELU-input row included -- into the predicated block, the prefetch loads stay
+                // "pending" on the path around it, and the NEXT tile's first fragment reads (which reuse those registers) got an
+                // s_waitcnt vmcnt(3..0): a drain of this epilogue's stores at every tile seam of the residual and GELU' epilogues
+                // (rounds 1-3 shipped that: the GELU' input gradient, three rounds per launch, paid it twice per launch).
                 if constexpr (EPI & EPI_OUT_F32) {
                     float* c = (float*)q.C + (size_t)m * q.ldc + n;
+                    f32x4 lo = {vv[0], vv[1], vv[2], vv[3]}, hi = {vv[4], vv[5], vv[6], vv[7]};
+                    asm volatile("" : "+v"(lo), "+v"(hi));
                     if (ok) {
-                        *(float4*)c = make_float4(vv[0], vv[1], vv[2], vv[3]);
-                        *(float4*)(c + 4) = make_float4(vv[4], vv[5], vv[6], vv[7]);
+                        *(f32x4*)c = lo;
+                        *(f32x4*)(c + 4) = hi;
                     }
                 } else {
                     bf16x8 o;
 #pragma unroll
                     for (int r = 0; r < 8; ++r) o[r] = f2bf(vv[r]);
-                    if (ok) *(bf16x8*)((bf16_t*)q.C + (size_t)m * q.ldc + n) = o;
+                    u32x4 ow = __builtin_bit_cast(u32x4, o);
+                    asm volatile("" : "+v"(ow));
+                    if (ok) *(u32x4*)((bf16_t*)q.C + (size_t)m * q.ldc + n) = ow;
                 }
             }
         }
@@ -978,7 +990,9 @@ __global__ __launch_bounds__(512, 2) void gemm_ntp_kernel(const GemmNT p) {
 // as in gemm_ntp_kernel): every ds_read_b128 lane group hits 16 distinct 16-byte slots; swizzle on the per-lane SOURCE address.
 // Epilogue: straight from the accumulators, the persistent kernel's lane map (2 x 8 consecutive columns per row block and lane).
 // -------------------------------------------------------------------------------------------------
-template <int EPI>
+// MULTI = false: one tile per workgroup (launches of no more tiles than CUs -- the form the train step uses): no next-tile bookkeeping,
+// 40 registers fewer.  MULTI = true: the workgroup walks tiles b, b + G, ... and the half-tile stream crosses the tile seams.
+template <int EPI, bool MULTI>
 __global__ __launch_bounds__(512, 2) void gemm_nt8_kernel(const GemmNT p) {
 #if __HIP_DEVICE_COMPILE__
     extern __shared__ __attribute__((aligned(16))) char smem[];   // buffer d at d * 65536: A0h | A1h | B0h | B1h, 16 KiB each
@@ -986,41 +1000,53 @@ __global__ __launch_bounds__(512, 2) void gemm_nt8_kernel(const GemmNT p) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 2, wc = wave & 3;
     const int tiles_n = (p.N + 255) >> 8, tiles_m = (p.M + 255) >> 8;
-    const int tile = xcd_remap(blockIdx.x, tiles_m * tiles_n);
-    const int m0 = (tile / tiles_n) << 8, n0 = (tile % tiles_n) << 8;
-    const int nt = p.K >> 6;                                     // K tiles (K % 128 == 0: an even count)
+    const int ntiles = tiles_m * tiles_n, G = gridDim.x;
+    const int nt = p.K >> 6;                                     // K tiles (K % 128 == 0: an even count, >= 4)
 
     // ---- staging: wave w issues pieces j = w and w + 8 of a half-tile (piece = local rows 8j .. 8j + 7, 1 KiB) ----
+    // The half-tiles of ALL tiles of this workgroup form one stream (persistent form, launches of more tiles than CUs): the last two
+    // K tiles of a tile issue K tiles 0 and 1 of the workgroup's next tile, which land under its epilogue -- the phase / wait / buffer
+    // pattern does not change at the seam (nt is even, so K tile 0 always sits in buffer 0).
     const auto rsA = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, (int)((uint32_t)p.M * (uint32_t)p.lda * 2u), 0x00020000);
     const auto rsB = __builtin_amdgcn_make_buffer_rsrc((void*)p.B, 0, (int)((uint32_t)p.N * (uint32_t)p.ldb * 2u), 0x00020000);
-    uint32_t va[2][2], vb[2][2];                                 // [half][piece]: per-lane byte offsets into A / B (the K offset is scalar)
-    {
-        const int pos = lane & 7;
+    struct Src { uint32_t a[2][2], b[2][2]; };                   // [half][piece]: per-lane byte offsets into A / B (the K offset is scalar)
+    auto set_src = [&](int v, Src& o) {
+        int l = lane;
+        asm volatile("" : "+v"(l));                               // recomputed per call, nothing kept alive across the K loop
+        int tmi, tni;
+        ntp_tile_mn(xcd_remap(v, ntiles), tiles_m, tiles_n, p.group_m, tmi, tni);
+        const int tm0 = tmi << 8, tn0 = tni << 8;
+        const int pos = l & 7;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            const int j = wave + 8 * i, r = 8 * j + (lane >> 3);              // local row of the half-tile
+            const int j = wave + 8 * i, r = 8 * j + (l >> 3);                 // local row of the half-tile
             const uint32_t chunk_a = (uint32_t)(pos ^ ((r >> 1) & 7));
             const uint32_t chunk_b = (uint32_t)(pos ^ (((r >> 1) & 1) | (((r >> 3) & 3) << 1)));
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
-                const int ga = m0 + (r >> 6) * 128 + h * 64 + (r & 63);
-                const int gb = n0 + (r >> 5) * 64 + h * 32 + (r & 31);
-                va[h][i] = ((uint32_t)min(ga, p.M - 1) * (uint32_t)p.lda + chunk_a * 8u) * 2u;
-                vb[h][i] = ((uint32_t)min(gb, p.N - 1) * (uint32_t)p.ldb + chunk_b * 8u) * 2u;
+                const int ga = tm0 + (r >> 6) * 128 + h * 64 + (r & 63);
+                const int gb = tn0 + (r >> 5) * 64 + h * 32 + (r & 31);
+                o.a[h][i] = ((uint32_t)min(ga, p.M - 1) * (uint32_t)p.lda + chunk_a * 8u) * 2u;
+                o.b[h][i] = ((uint32_t)min(gb, p.N - 1) * (uint32_t)p.ldb + chunk_b * 8u) * 2u;
             }
         }
-    }
+    };
+    Src cur;
+    set_src(blockIdx.x, cur);
+    Src nxt_store;
+    Src& nxt = MULTI ? nxt_store : cur;                          // single-tile form: the "next tile" is this one again (dead re-reads)
+    if constexpr (MULTI) nxt_store = cur;
     // half-tile ids in the order of first use: 0 = B0h, 1 = A0h, 2 = B1h, 3 = A1h
-    auto stage = [&](int buf, int which, int kt) {
-        const uint32_t kb = (uint32_t)min(kt, nt - 1) * 128u;    // past the last tile: dead re-reads, the in-flight count stays constant
+    auto stage = [&](int buf, int which, const Src& o, int kt) {
+        const uint32_t kb = (uint32_t)kt * 128u;
         const int h = which >> 1;
         char* base = smem + buf * 65536 + ((which & 1) ? 0 : 32768) + h * 16384 + wave * 1024;
         if (which & 1) {
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, LPTR(base), 16, va[h][0], kb, 0, 0);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, LPTR(base + 8192), 16, va[h][1], kb, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, LPTR(base), 16, o.a[h][0], kb, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, LPTR(base + 8192), 16, o.a[h][1], kb, 0, 0);
         } else {
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, LPTR(base), 16, vb[h][0], kb, 0, 0);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, LPTR(base + 8192), 16, vb[h][1], kb, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, LPTR(base), 16, o.b[h][0], kb, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, LPTR(base + 8192), 16, o.b[h][1], kb, 0, 0);
         }
     };
 
@@ -1037,10 +1063,6 @@ __global__ __launch_bounds__(512, 2) void gemm_nt8_kernel(const GemmNT p) {
 
     bf16x8 af[2][4], b0f[2][2], b1f[2][2];
     f32x4 acc[8][4];
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     auto read_a = [&](int buf, int h) {
         const lds_cptr ab = buf ? a_rd1 : a_rd;
@@ -1056,25 +1078,28 @@ __global__ __launch_bounds__(512, 2) void gemm_nt8_kernel(const GemmNT p) {
 #pragma unroll
             for (int j = 0; j < 2; ++j) bf[ks][j] = *(lds_frag)(bb + h * 16384 + j * 512 + (swb ^ (ks * 64)));
     };
-    auto mma = [&](int qa, int qb, const bf16x8 (&bf)[2][2]) {
+    // (first: K tile 0 of an output tile -- its four phases touch the four accumulator quadrants once each -- starts from C = 0: no clearing pass)
+    auto mma = [&](int qa, int qb, const bf16x8 (&bf)[2][2], bool first) {
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j)     // operands swapped (B first): a lane holds 4 consecutive COLUMNS of one output row
-                    acc[qa * 4 + i][qb * 2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[ks][j], af[ks][i], acc[qa * 4 + i][qb * 2 + j], 0, 0, 0);
+                for (int j = 0; j < 2; ++j) {   // operands swapped (B first): a lane holds 4 consecutive COLUMNS of one output row
+                    f32x4& c = acc[qa * 4 + i][qb * 2 + j];
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[ks][j], af[ks][i], (first && ks == 0) ? (f32x4){0.f, 0.f, 0.f, 0.f} : c, 0, 0, 0);
+                }
     };
 
-    // ---- prologue: tile 0 (4 half-tiles, even buffer) and the first 3 half-tiles of tile 1 (odd buffer) ----
-    stage(0, 0, 0); stage(0, 1, 0); stage(0, 2, 0); stage(0, 3, 0);
-    stage(1, 0, 1); stage(1, 1, 1); stage(1, 2, 1);
-    __builtin_amdgcn_s_waitcnt(mmb_waitcnt(6, 15));               // tile 0 landed (this wave's pieces)
+    // ---- prologue: K tile 0 (4 half-tiles, even buffer) and the first 3 half-tiles of K tile 1 (odd buffer) of the first tile ----
+    stage(0, 0, cur, 0); stage(0, 1, cur, 0); stage(0, 2, cur, 0); stage(0, 3, cur, 0);
+    stage(1, 0, cur, 1); stage(1, 1, cur, 1); stage(1, 2, cur, 1);
+    __builtin_amdgcn_s_waitcnt(mmb_waitcnt(6, 15));               // K tile 0 landed (this wave's pieces)
     __builtin_amdgcn_s_barrier();
     if (wr == 1) __builtin_amdgcn_s_barrier();                    // the stagger: group 1 runs one barrier behind group 0
 
     // one phase: { LDS reads of this phase's quadrant operands ; one half-tile of LDS-DMA ; [counted waits] ; barrier ; MFMAs ; barrier }
-#define NT8_PHASE(READS, LGK_BEFORE_BARRIER, STAGE, VMWAIT, QA, QB, BF)                                              \
+#define NT8_PHASE(READS, LGK_BEFORE_BARRIER, STAGE, VMWAIT, QA, QB, BF, FIRST)                                       \
     {                                                                                                               \
         READS;                                                                                                      \
         STAGE;                                                                                                      \
@@ -1084,149 +1109,188 @@ __global__ __launch_bounds__(512, 2) void gemm_nt8_kernel(const GemmNT p) {
         __builtin_amdgcn_s_waitcnt(mmb_waitcnt(63, 0));                                                             \
         __builtin_amdgcn_sched_barrier(0);                                                                          \
         __builtin_amdgcn_s_setprio(1);                                                                              \
-        mma(QA, QB, BF);                                                                                            \
+        mma(QA, QB, BF, FIRST);                                                                                     \
         __builtin_amdgcn_s_setprio(0);                                                                              \
         __builtin_amdgcn_s_barrier();                                                                               \
         __builtin_amdgcn_sched_barrier(0);                                                                          \
     }
-    // K tile t in buffer D (tile t + 1 in D ^ 1).  RAW: everything of tile t + 1 is issued by phase 1 of tile t and retired by the
-    // vmcnt(6) of phase 4 (3 half-tiles of tile t + 2 stay in flight), one phase before its first read.  WAR: b0 (read FIRST in phase 1
-    // and retired by lgkmcnt(8) before that phase's first barrier) is restaged in phase 2; a0 (phase 1) in phase 3; b1 (phase 2) in
-    // phase 4; a1 (phase 3) in phase 1 of the next tile -- two phases after their reads, which covers the group that runs a barrier behind.
-#define NT8_KTILE(D, T)                                                                                                      \
-    NT8_PHASE((read_b(D, 0, b0f), __builtin_amdgcn_sched_barrier(0), read_a(D, 0)), 8, stage(D ^ 1, 3, (T) + 1), -1, 0, 0, b0f) \
-    NT8_PHASE(read_b(D, 1, b1f), -1, stage(D, 0, (T) + 2), -1, 0, 1, b1f)                                                    \
-    NT8_PHASE(read_a(D, 1), -1, stage(D, 1, (T) + 2), -1, 1, 1, b1f)                                                         \
-    NT8_PHASE((void)0, -1, stage(D, 2, (T) + 2), 6, 1, 0, b0f)
+    // K tile in buffer D; S1 / K1 = source and K tile of the half-tile that completes the NEXT K tile (A1h), S2 / K2 = those of the three
+    // half-tiles of the K tile after it.  RAW: everything of the next K tile is issued by phase 1 and retired by the vmcnt(6) of phase 4
+    // (3 half-tiles of the K tile after it stay in flight), one phase before its first read.  WAR: b0 (read FIRST in phase 1 and retired
+    // by lgkmcnt(8) before that phase's first barrier) is restaged in phase 2; a0 (phase 1) in phase 3; b1 (phase 2) in phase 4; a1
+    // (phase 3) in phase 1 of the next K tile -- two phases after their reads, which covers the group that runs a barrier behind.
+#define NT8_KTILE(D, S1, K1, S2, K2, FIRST)                                                                                   \
+    NT8_PHASE((read_b(D, 0, b0f), __builtin_amdgcn_sched_barrier(0), read_a(D, 0)), 8, stage(D ^ 1, 3, S1, K1), -1, 0, 0, b0f, FIRST) \
+    NT8_PHASE(read_b(D, 1, b1f), -1, stage(D, 0, S2, K2), -1, 0, 1, b1f, FIRST)                                               \
+    NT8_PHASE(read_a(D, 1), -1, stage(D, 1, S2, K2), -1, 1, 1, b1f, FIRST)                                                    \
+    NT8_PHASE((void)0, -1, stage(D, 2, S2, K2), 6, 1, 0, b0f, FIRST)
 
-    for (int t = 0; t < nt; t += 2) {
-        NT8_KTILE(0, t)
-        NT8_KTILE(1, t + 1)
+    for (int v = blockIdx.x; v < ntiles; v += MULTI ? G : ntiles) {
+        int tmi, tni;
+        ntp_tile_mn(xcd_remap(v, ntiles), tiles_m, tiles_n, p.group_m, tmi, tni);
+        const int m0 = tmi << 8, n0 = tni << 8;
+        if constexpr (MULTI) { if (v + G < ntiles) set_src(v + G, nxt_store); }    // past the last tile: dead re-reads of this tile's first K tiles
+        // Seam: K tile 0 of this tile was issued by the previous tile's last two K tiles (or by the prologue) and is followed, in
+        // vector-memory issue order, by the 6 LDS-DMAs of K tile 1's first three half-tiles and by the previous epilogue's loads and
+        // stores (any number of them) -- so "at most 6 outstanding" proves it landed on every path.  As a BUILTIN, so that hipcc's own
+        // scoreboard sees it: without it hipcc drains vmcnt(0) in front of this tile's first fragment reads (they alias the pending
+        // LDS-DMA destinations), i.e. waits for the previous epilogue's last store.
+        __builtin_amdgcn_s_waitcnt(mmb_waitcnt(6, 15));
+        NT8_KTILE(0, cur, 1, cur, 2, true)
+        NT8_KTILE(1, cur, 2, cur, 3, false)
+        for (int t = 2; t < nt - 2; t += 2) {
+            NT8_KTILE(0, cur, t + 1, cur, t + 2, false)
+            NT8_KTILE(1, cur, t + 2, cur, t + 3, false)
+        }
+        // the last two K tiles bring in K tiles 0 and 1 of the workgroup's next tile
+        NT8_KTILE(0, cur, nt - 1, nxt, 0, false)
+        NT8_KTILE(1, nxt, 0, nxt, 1, false)
+        if constexpr (MULTI) cur = nxt_store;
+
+        // ---- epilogue, straight from the accumulators: acc[i][2 h + (r >> 2)][r & 3] = C[m0 + wr*128 + 16 i + fr][n0 + wc*64 + 32 h + 8 fq + r];
+        // the next tile's first half-tiles are in flight / landed meanwhile.  Every per-lane address comes from an opaque copy of the lane
+        // id and every parameter from an opaque copy of the kernel-argument pointer, so that nothing of it is kept alive across the K loop
+        auto kp = __builtin_amdgcn_kernarg_segment_ptr();
+        asm volatile("" : "+s"(kp));
+        const __attribute__((address_space(4))) GemmNT& q = *(const __attribute__((address_space(4))) GemmNT*)kp;
+        int elane = lane;
+        asm volatile("" : "+v"(elane));
+        const int efr = elane & 15, efq = elane >> 4;
+        const float alpha = q.alpha * (q.alpha_dev ? *q.alpha_dev : 1.0f);
+        const bool interior = (m0 + 256 <= q.M) && (n0 + 256 <= q.N);
+        const int mrow = m0 + wr * 128 + efr;                        // + 16 i
+        const int ncol = n0 + wc * 64 + efq * 8;                     // 8 columns here (h = 0) and 8 at + 32 (h = 1)
+        constexpr int PRE = 3;
+        bf16x8 pre[8][2];
+        auto load_pre = [&](int i) {
+            if constexpr (EPI & (EPI_RESID | EPI_GELU_BWD)) {
+                const bf16_t* src = (EPI & EPI_RESID) ? q.R : q.U;
+                const int ld = (EPI & EPI_RESID) ? q.ldr : q.ldu;
+                const bf16_t* rp = src + (size_t)min(mrow + 16 * i, q.M - 1) * ld;   // clamped in range: a half that is out of range is never stored
+                pre[i][0] = *(const bf16x8*)(rp + min(ncol, q.N - 8));
+                pre[i][1] = *(const bf16x8*)(rp + min(ncol + 32, q.N - 8));
+            }
+        };
+#pragma unroll
+        for (int i = 0; i < PRE; ++i) load_pre(i);
+        float bias[16];
+        if constexpr (EPI & EPI_BIAS) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const float* bp = q.bias + min(ncol + 32 * h, q.N - 8);
+                const float4 b0 = *(const float4*)bp, b1 = *(const float4*)(bp + 4);
+                bias[8 * h + 0] = b0.x; bias[8 * h + 1] = b0.y; bias[8 * h + 2] = b0.z; bias[8 * h + 3] = b0.w;
+                bias[8 * h + 4] = b1.x; bias[8 * h + 5] = b1.y; bias[8 * h + 6] = b1.z; bias[8 * h + 7] = b1.w;
+            }
+        }
+        // phase 1 (needs no residual data): scale, bias and the dropout decision, in place in the accumulators.  Dropout seeds are linear
+        // in the element index (common.h): pair(m, n) = m * N/2 + n/2 (mod 2^32) -- one multiply per lane, wave-uniform increments after it
+        const uint32_t dthr = (EPI & EPI_RESID) ? q.drop_thr16 : 0u;
+        const uint32_t dthr_s = dthr - 32768u;                       // the signed-compare form of mmb_keep16
+        const float dscale = (EPI & EPI_RESID) ? q.drop_scale : 1.0f;
+        const uint32_t halfN = (uint32_t)q.N >> 1;
+        const uint32_t seed0 = (EPI & EPI_RESID) ? ((uint32_t)mrow * halfN + ((uint32_t)ncol >> 1)) * MMB_WEYL + q.drop_stream : 0u;
+        const uint32_t seed_row = 16u * halfN * MMB_WEYL;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+#pragma unroll
+                for (int r = 0; r < 8; ++r) {
+                    float v_ = acc[i][2 * h + (r >> 2)][r & 3] * alpha;
+                    if constexpr (EPI & EPI_BIAS) v_ += bias[8 * h + r];
+                    acc[i][2 * h + (r >> 2)][r & 3] = v_;
+                }
+                if constexpr (EPI & EPI_RESID) {
+                    if (dthr) {
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {                // element pair k of the 8 columns: elements 2k, 2k + 1
+                            const uint32_t hb = mmb_pair_mix(seed0 + (uint32_t)i * seed_row + (uint32_t)(16 * h + k) * MMB_WEYL);
+                            f32x4& a4 = acc[i][2 * h + (k >> 1)];
+                            const bool keep0 = (int16_t)(uint16_t)(hb & 0xFFFFu) >= (int16_t)(uint16_t)dthr_s;
+                            const bool keep1 = (int16_t)(uint16_t)(hb >> 16) >= (int16_t)(uint16_t)dthr_s;
+                            a4[(2 * k) & 3] = keep0 ? a4[(2 * k) & 3] * dscale : 0.f;
+                            a4[(2 * k + 1) & 3] = keep1 ? a4[(2 * k + 1) & 3] * dscale : 0.f;
+                        }
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            if (i + PRE < 8) load_pre(i + PRE);
+            const int m = mrow + 16 * i;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int n = ncol + 32 * h;
+                float vv[8];
+#pragma unroll
+                for (int r = 0; r < 8; ++r) vv[r] = acc[i][2 * h + (r >> 2)][r & 3];
+                const bool ok = interior || (m < q.M && n + 8 <= q.N);
+                if constexpr (EPI & EPI_GELU) {
+                    if (q.aux) {
+                        bf16x8 u;
+#pragma unroll
+                        for (int r = 0; r < 8; ++r) u[r] = f2bf(vv[r]);
+                        if (ok) *(bf16x8*)(q.aux + (size_t)m * q.ldaux + n) = u;
+                    }
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) vv[r] = gelu_erf(vv[r]);
+                }
+                if constexpr (EPI & EPI_GELU_BWD) {
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) vv[r] *= gelu_erf_grad(bf2f(pre[i][h][r]));
+                }
+                if constexpr (EPI & EPI_RESID) {
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) vv[r] += bf2f(pre[i][h][r]);
+                }
+                // The value to store is pinned in registers BEFORE the (edge-tile) predicate: hipcc otherwise sinks the whole computation
+                // -- the use of the prefetched residual row included -- into the predicated block, the prefetch loads stay "pending" on
+                // the path around it, and the NEXT tile's first fragment reads (which reuse those registers) get an s_waitcnt vmcnt(0):
+                // a drain of the previous epilogue's stores at every tile seam.
+                if constexpr (EPI & EPI_OUT_F32) {
+                    float* c = (float*)q.C + (size_t)m * q.ldc + n;
+                    f32x4 lo = {vv[0], vv[1], vv[2], vv[3]}, hi = {vv[4], vv[5], vv[6], vv[7]};
+                    asm volatile("" : "+v"(lo), "+v"(hi));
+                    if (ok) {
+                        *(f32x4*)c = lo;
+                        *(f32x4*)(c + 4) = hi;
+                    }
+                } else {
+                    bf16x8 o;
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) o[r] = f2bf(vv[r]);
+                    u32x4 ow = __builtin_bit_cast(u32x4, o);
+                    asm volatile("" : "+v"(ow));
+                    if (ok) *(u32x4*)((bf16_t*)q.C + (size_t)m * q.ldc + n) = ow;
+                }
+            }
+        }
     }
 #undef NT8_KTILE
 #undef NT8_PHASE
     if (wr == 0) __builtin_amdgcn_s_barrier();                    // balances the stagger
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // the dead tail half-tiles
-
-    // ---- epilogue, straight from the accumulators: acc[i][2 h + (r >> 2)][r & 3] = C[m0 + wr*128 + 16 i + fr][n0 + wc*64 + 32 h + 8 fq + r] ----
-    // (every per-lane address comes from an opaque copy of the lane id so that nothing of it is kept alive across the K loop)
-    int elane = lane;
-    asm volatile("" : "+v"(elane));
-    const int efr = elane & 15, efq = elane >> 4;
-    const float alpha = p.alpha * (p.alpha_dev ? *p.alpha_dev : 1.0f);
-    const bool interior = (m0 + 256 <= p.M) && (n0 + 256 <= p.N);
-    const int mrow = m0 + wr * 128 + efr;                        // + 16 i
-    const int ncol = n0 + wc * 64 + efq * 8;                     // 8 columns here (h = 0) and 8 at + 32 (h = 1)
-    constexpr int PRE = 3;
-    bf16x8 pre[8][2];
-    auto load_pre = [&](int i) {
-        if constexpr (EPI & (EPI_RESID | EPI_GELU_BWD)) {
-            const bf16_t* src = (EPI & EPI_RESID) ? p.R : p.U;
-            const int ld = (EPI & EPI_RESID) ? p.ldr : p.ldu;
-            const bf16_t* rp = src + (size_t)min(mrow + 16 * i, p.M - 1) * ld;       // clamped in range: a half that is out of range is never stored
-            pre[i][0] = *(const bf16x8*)(rp + min(ncol, p.N - 8));
-            pre[i][1] = *(const bf16x8*)(rp + min(ncol + 32, p.N - 8));
-        }
-    };
-#pragma unroll
-    for (int i = 0; i < PRE; ++i) load_pre(i);
-    float bias[16];
-    if constexpr (EPI & EPI_BIAS) {
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const float* bp = p.bias + min(ncol + 32 * h, p.N - 8);
-            const float4 b0 = *(const float4*)bp, b1 = *(const float4*)(bp + 4);
-            bias[8 * h + 0] = b0.x; bias[8 * h + 1] = b0.y; bias[8 * h + 2] = b0.z; bias[8 * h + 3] = b0.w;
-            bias[8 * h + 4] = b1.x; bias[8 * h + 5] = b1.y; bias[8 * h + 6] = b1.z; bias[8 * h + 7] = b1.w;
-        }
-    }
-    // phase 1 (needs no residual data): scale, bias and the dropout decision, in place in the accumulators.  Dropout seeds are linear
-    // in the element index (common.h): pair(m, n) = m * N/2 + n/2 (mod 2^32) -- one multiply per lane, wave-uniform increments after it
-    const uint32_t dthr = (EPI & EPI_RESID) ? p.drop_thr16 : 0u;
-    const uint32_t dthr_s = dthr - 32768u;                       // the signed-compare form of mmb_keep16
-    const float dscale = (EPI & EPI_RESID) ? p.drop_scale : 1.0f;
-    const uint32_t halfN = (uint32_t)p.N >> 1;
-    const uint32_t seed0 = (EPI & EPI_RESID) ? ((uint32_t)mrow * halfN + ((uint32_t)ncol >> 1)) * MMB_WEYL + p.drop_stream : 0u;
-    const uint32_t seed_row = 16u * halfN * MMB_WEYL;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-#pragma unroll
-            for (int r = 0; r < 8; ++r) {
-                float v = acc[i][2 * h + (r >> 2)][r & 3] * alpha;
-                if constexpr (EPI & EPI_BIAS) v += bias[8 * h + r];
-                acc[i][2 * h + (r >> 2)][r & 3] = v;
-            }
-            if constexpr (EPI & EPI_RESID) {
-                if (dthr) {
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) {                // element pair k of the 8 columns: elements 2k, 2k + 1
-                        const uint32_t hb = mmb_pair_mix(seed0 + (uint32_t)i * seed_row + (uint32_t)(16 * h + k) * MMB_WEYL);
-                        f32x4& a4 = acc[i][2 * h + (k >> 1)];
-                        const bool keep0 = (int16_t)(uint16_t)(hb & 0xFFFFu) >= (int16_t)(uint16_t)dthr_s;
-                        const bool keep1 = (int16_t)(uint16_t)(hb >> 16) >= (int16_t)(uint16_t)dthr_s;
-                        a4[(2 * k) & 3] = keep0 ? a4[(2 * k) & 3] * dscale : 0.f;
-                        a4[(2 * k + 1) & 3] = keep1 ? a4[(2 * k + 1) & 3] * dscale : 0.f;
-                    }
-                }
-            }
-        }
-    }
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        if (i + PRE < 8) load_pre(i + PRE);
-        const int m = mrow + 16 * i;
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int n = ncol + 32 * h;
-            float vv[8];
-#pragma unroll
-            for (int r = 0; r < 8; ++r) vv[r] = acc[i][2 * h + (r >> 2)][r & 3];
-            const bool ok = interior || (m < p.M && n + 8 <= p.N);
-            if constexpr (EPI & EPI_GELU) {
-                if (p.aux) {
-                    bf16x8 u;
-#pragma unroll
-                    for (int r = 0; r < 8; ++r) u[r] = f2bf(vv[r]);
-                    if (ok) *(bf16x8*)(p.aux + (size_t)m * p.ldaux + n) = u;
-                }
-#pragma unroll
-                for (int r = 0; r < 8; ++r) vv[r] = gelu_erf(vv[r]);
-            }
-            if constexpr (EPI & EPI_GELU_BWD) {
-#pragma unroll
-                for (int r = 0; r < 8; ++r) vv[r] *= gelu_erf_grad(bf2f(pre[i][h][r]));
-            }
-            if constexpr (EPI & EPI_RESID) {
-#pragma unroll
-                for (int r = 0; r < 8; ++r) vv[r] += bf2f(pre[i][h][r]);
-            }
-            if constexpr (EPI & EPI_OUT_F32) {
-                float* c = (float*)p.C + (size_t)m * p.ldc + n;
-                if (ok) {
-                    *(float4*)c = make_float4(vv[0], vv[1], vv[2], vv[3]);
-                    *(float4*)(c + 4) = make_float4(vv[4], vv[5], vv[6], vv[7]);
-                }
-            } else {
-                bf16x8 o;
-#pragma unroll
-                for (int r = 0; r < 8; ++r) o[r] = f2bf(vv[r]);
-                if (ok) *(bf16x8*)((bf16_t*)p.C + (size_t)m * p.ldc + n) = o;
-            }
-        }
-    }
 #endif
 }
 
-template <int EPI>
-static int launch_nt8(hipStream_t s, const GemmNT& p) {
-    const int tiles = ((p.M + 255) / 256) * ((p.N + 255) / 256);
+template <int EPI, bool MULTI>
+static int launch_nt8_form(hipStream_t s, const GemmNT& q, int workgroups) {
     static std::atomic<unsigned long long> attr_done{0};
-    if (int e = mmb_allow_lds((const void*)gemm_nt8_kernel<EPI>, 131072, attr_done)) return e;
-    hipLaunchKernelGGL((gemm_nt8_kernel<EPI>), dim3(tiles), dim3(512), 131072, s, p);
+    if (int e = mmb_allow_lds((const void*)gemm_nt8_kernel<EPI, MULTI>, 131072, attr_done)) return e;
+    hipLaunchKernelGGL((gemm_nt8_kernel<EPI, MULTI>), dim3(workgroups), dim3(512), 131072, s, q);
     MMB_CHECK_LAUNCH();
     return 0;
+}
+template <int EPI>
+static int launch_nt8(hipStream_t s, const GemmNT& p, int tiles, int workgroups, int group_m) {
+    GemmNT q = p;
+    q.group_m = group_m;
+    q.tile_counter = q.tile_counter_next = nullptr;
+    const char* f = getenv("MMBERT_NT_8PHASE_FORM");              // A/B switch, read per call: "multi" runs the multi-tile form everywhere
+    if (tiles > workgroups || (f && f[0] == 'm')) return launch_nt8_form<EPI, true>(s, q, workgroups);
+    return launch_nt8_form<EPI, false>(s, q, workgroups);
 }
 
 constexpr int NTP_LDS_BYTES = 131072 + 1024 + 8 * 256;      // ring | tile-queue word (padded) | bias rows
@@ -1234,6 +1298,7 @@ constexpr int NTP_LDS_BYTES = 131072 + 1024 + 8 * 256;      // ring | tile-queue
 // ---- which kernel, which tile, which tile walk: ONE function of the shape (and of the test / A-B knobs), shared by the launch path
 // and by mmbert_gemm_nt_describe() (bench.py reports the choice per shape; tests pin it) ----
 enum { NTK_128 = 0, NTK_RING = 1, NTK_PERSIST = 2, NTK_8PHASE = 3 };
+constexpr int NT8_DEFAULT_LEVEL = 1;
 struct NTChoice { int kernel, bm, tiles, workgroups, group_m, use_queue; };
 
 static bool ntp_eligible(const GemmNT& p) {
@@ -1285,16 +1350,21 @@ static NTChoice nt_choose(const GemmNT& p, int epi) {
     const int t256 = ((p.M + 255) / 256) * tn, t224 = ((p.M + 223) / 224) * tn;
     const int r256 = (t256 + cus - 1) / cus, r224 = (t224 + cus - 1) / cus;
     const bool can_persist = g_nt_persist && ntp_eligible(p);
-    // Single-round launches go to the 8-phase kernel (round 4; see gemm_nt8_kernel): its 256-row tiles must fit the chip in one round.
-    // A/B switch, read per call: MMBERT_NT_8PHASE=0 keeps the persistent kernel; mmbert_gemm_nt_force(8) forces it for every eligible shape.
+    // The 8-phase kernel (round 4; see gemm_nt8_kernel).  Level by MMBERT_NT_8PHASE (A/B switch, read per call; default below):
+    //   0 never | 1 launches whose 256-row tiles fit the chip in ONE round | 2 also multi-round launches (persistent form: the half-tile
+    //   stream runs across tile seams) except the vocabulary-sized ones | 3 those too.  It has no device tile queue: launches that
+    //   need one (data parallel, more tiles than CUs) keep the ring-persistent kernel.  mmbert_gemm_nt_force(8) forces it where eligible.
     {
         const char* e8 = getenv("MMBERT_NT_8PHASE");
-        const bool on8 = !(e8 && atoi(e8) == 0);
-        // ... unless they leave more than half the chip idle (the reference's default model: M = 6400, N = 1024 is 100 tiles): the 128 x 128
-        // kernel's 4 x as many tiles on 2 workgroups per CU are 6-14 % faster there (profiles/r4_bert_large_gemm_modes.log)
-        if (g_nt_force == 0 && on8 && 2 * t256 <= cus && c.tiles <= 2 * cus) return c;
-        if (ntp_eligible(p) && ((g_nt_force == 0 && on8 && t256 <= cus) || g_nt_force == 3)) {
-            c.kernel = NTK_8PHASE; c.bm = 256; c.tiles = t256; c.workgroups = t256;
+        const int lvl = e8 ? atoi(e8) : NT8_DEFAULT_LEVEL;
+        const bool huge_b = (long long)p.N * p.K * 2 > (8ll << 20);
+        // ... single-round launches that leave more than half the chip idle (the reference's default model: M = 6400, N = 1024 is 100
+        // tiles): the 128 x 128 kernel's 4 x as many tiles on 2 workgroups per CU are 6-14 % faster there (profiles/r4_bert_large_gemm_modes.log)
+        if (g_nt_force == 0 && lvl >= 1 && 2 * t256 <= cus && c.tiles <= 2 * cus) return c;
+        const bool multi_ok = (t256 > cus) && !p.tile_counter && (lvl >= 3 || (lvl >= 2 && !huge_b));
+        if (ntp_eligible(p) && ((g_nt_force == 0 && ((lvl >= 1 && t256 <= cus) || multi_ok)) || g_nt_force == 3)) {
+            c.kernel = NTK_8PHASE; c.bm = 256; c.tiles = t256; c.workgroups = t256 < cus ? t256 : cus;
+            c.group_m = ntp_group_m(p.M, p.N, p.K, epi, 256, t256, cus);
             return c;
         }
     }
@@ -1374,7 +1444,7 @@ template <int EPI>
 static int dispatch_nt(hipStream_t s, const GemmNT& p) {
     const NTChoice c = nt_choose(p, EPI);
     if (c.kernel == NTK_128) return launch_nt<EPI>(s, p);
-    if (c.kernel == NTK_8PHASE) return launch_nt8<EPI>(s, p);
+    if (c.kernel == NTK_8PHASE) return launch_nt8<EPI>(s, p, c.tiles, c.workgroups, c.group_m);
     if (c.kernel == NTK_PERSIST) return c.bm == 256 ? launch_ntp_mi<EPI, 8>(s, p, c) : launch_ntp_mi<EPI, 7>(s, p, c);
     return c.bm == 256 ? launch_nt256_mi<EPI, 8>(s, p) : launch_nt256_mi<EPI, 7>(s, p);
 }
@@ -1413,8 +1483,6 @@ __device__ __forceinline__ int tn_swz(int row) { return ((row & 3) | ((row >> 1)
 // ds_read_b64_tr_b16 through inline asm: behind the builtin hipcc cannot prove that the read does not
 // alias the LDS-DMA still in flight and drains vmcnt(0) in front of every stage's reads.  The asm form is
 // invisible to its scoreboard: the caller waits lgkmcnt(0) itself and fences with sched_barrier(0).
-typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
-typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 template <int OFF>
 __device__ __forceinline__ void tr_read(u32x2& dst, unsigned lds_addr) {
     // "memory": the read must stay behind the s_waitcnt / s_barrier that publish the LDS-DMA data (without it hipcc

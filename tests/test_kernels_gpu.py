@@ -132,16 +132,44 @@ def test_gemm_nt_8phase_kernel_headline_shapes_every_epilogue(ops, K):
     assert_close(aux, ref + bias, 1e-2, 3e-2, "gelu aux")
 
 
-@pytest.mark.parametrize("M,N", [(18400, 2304), (14000, 3072), (5000, 3072), (9000, 1792)])
-def test_gemm_nt_grouped_tile_walk_exact(ops, M, N):
-    """More tiles than CUs: the persistent kernel walks them in one group per XCD (ceil(row tiles / 8) row panels swept over the column
+@pytest.mark.parametrize("level", ["0", "3"])
+@pytest.mark.parametrize("M,N,K", [(18400, 2304, 256), (14000, 3072, 256), (5000, 3072, 256), (9000, 1792, 256), (18400 - 37, 2304, 768)])
+def test_gemm_nt_grouped_tile_walk_exact(ops, M, N, K, level, monkeypatch):
+    """More tiles than CUs: the persistent kernels (level 0: the 4-slot-ring kernel; level 3: the 8-phase kernel in its multi-tile form,
+    whose half-tile stream crosses the tile seams) walk them in one group per XCD (ceil(row tiles / 8) row panels swept over the column
     panels, the last group short) -- every tile exactly once, checked on small integers (exact in bf16 and in the fp32 accumulators)."""
-    K = 256                                                   # (entries in {-1, 0, 1} x {0, 1}: |sums| <= 256, exact in the bf16 output too)
-    A = ((torch.arange(M)[:, None] * 5 + torch.arange(K)[None, :] * 3) % 3 - 1.0)
+    monkeypatch.setenv("MMBERT_NT_8PHASE", level)
+    d = ops.gemm_nt_describe(M, N, K)
+    assert d["kernel"] == ("8phase" if level == "3" else "persistent"), d
+    assert d["tiles"] > d["cus"] or M <= 9000, d                 # (M = 5000 and M = 9000 x N = 1792 are one round of 256-row tiles)
+    A = ((torch.arange(M)[:, None] * 5 + torch.arange(K)[None, :] * 3) % 3 - 1.0)      # entries in {-1, 0, 1} x {0, 1}: |sums| <= K, exact in bf16 up to 256
     B = ((torch.arange(N)[:, None] * 2 + torch.arange(K)[None, :] * 11) % 2).float()
-    out = ops.gemm_nt(bf(A).to(DEV), bf(B).to(DEV))
+    out = ops.gemm_nt(bf(A).to(DEV), bf(B).to(DEV), out_f32=K > 256)
     ref = (A.to(DEV) @ B.to(DEV).t())
     assert torch.equal(out.float(), ref)
+
+
+@pytest.mark.parametrize("epi", ["bias", "gelu", "gelu_bwd", "resid_drop"])
+def test_gemm_nt_8phase_multi_tile_form_matches_ring_kernel(ops, epi, monkeypatch):
+    """The 8-phase kernel's multi-tile (persistent) form with the fused epilogues of the step's multi-round launches (QKV: bias; FFN-up:
+    bias + GELU + pre-activation; GELU' input gradient) and a ragged last row panel, against the ring-persistent kernel on the same
+    operands: one bf16 ulp of the largest entry (the two differ in fp32 summation order); reproducible run to run."""
+    M, N, K = 18400 - 37, 2304, 768
+    A, B = bf(rnd(M, K, seed=31, scale=0.5)).to(DEV), bf(rnd(N, K, seed=32, scale=0.05)).to(DEV)
+    bias, R = rnd(N, seed=33).to(DEV), bf(rnd(M, N, seed=34)).to(DEV)
+    kw = {"bias": dict(bias=bias), "gelu": dict(bias=bias, gelu=True), "gelu_bwd": dict(gelu_bwd_u=R),
+          "resid_drop": dict(bias=bias, resid=R, drop=ops.make_drop(0.1, 3, 4))}[epi]
+    res = {}
+    for level in ("0", "3"):
+        monkeypatch.setenv("MMBERT_NT_8PHASE", level)
+        aux = torch.empty((M, N), device=DEV, dtype=torch.bfloat16) if epi == "gelu" else None
+        res[level] = (ops.gemm_nt(A, B, aux=aux, **kw), aux)
+    again = ops.gemm_nt(A, B, **kw)
+    assert torch.equal(again, res["3"][0])
+    scale = float(res["0"][0].float().abs().max())
+    assert float((res["3"][0].float() - res["0"][0].float()).abs().max()) <= 2.0 ** -7 * scale
+    if epi == "gelu":
+        assert float((res["3"][1].float() - res["0"][1].float()).abs().max()) <= 2.0 ** -7 * float(res["0"][1].float().abs().max())
 
 
 def test_gemm_nt_dynamic_tile_queue_is_bit_identical(ops):
