@@ -101,10 +101,11 @@ def main():
         saved_stdout = os.dup(1)
         os.dup2(2, 1)
     rccl_log = None
-    if (int(os.environ.get("WORLD_SIZE", 1)) > 1 or a.force_dp) and "NCCL_DEBUG" not in os.environ:
+    if (int(os.environ.get("WORLD_SIZE", 1)) > 1 or a.force_dp) and os.environ.get("NCCL_DEBUG", "VERSION").upper() in ("VERSION", "WARN", ""):
         # N > 1 must be diagnosable from ONE run: RCCL's own account of what it built (rings / trees, channels, transport per peer) and
         # of what it picked per message size (algorithm / protocol / channels) goes to a per-process file; rank 0 condenses it into
-        # config.dp.rccl and onto stderr at the end (the full file stays in /tmp)
+        # config.dp.rccl and onto stderr at the end (the full file stays in /tmp).  (An NCCL_DEBUG of VERSION / WARN from the image's
+        # environment is raised to INFO; an INFO / TRACE the caller set is left alone -- it then goes wherever the caller sent it.)
         rccl_log = f"/tmp/mmbert_rccl_{os.getpid()}.log"
         os.environ.update(NCCL_DEBUG="INFO", NCCL_DEBUG_SUBSYS=os.environ.get("NCCL_DEBUG_SUBSYS", "INIT,GRAPH,TUNING"), NCCL_DEBUG_FILE=rccl_log)
     rank, local, world = parallel.init_from_env(force=a.force_dp)
@@ -521,9 +522,19 @@ def rccl_summary(path, limit=24):
         return {"error": str(e)}
     pick = [l for l in lines if re.search(r"(Channel \d+/\d+ *:|Ring \d+ *:|Trees? |nChannels|via P2P|via SHM|via NET|Algo|algorithm|protocol|Using network|comm 0x.* rank .* nranks|Connected all)", l)]
     tuning = sorted({re.sub(r"^.*?NCCL INFO ", "", l) for l in lines if "TUNING" in l or re.search(r"(AllReduce|AllGather|AllToAll|ReduceScatter|Broadcast).*(Algo|algo|proto)", l)})
+    # (one line per ring / tree / channel would crowd everything else out of the record: counts, plus the first two of each kind)
+    seen, brief = {}, []
+    for l in pick:
+        body = re.sub(r"^.*?NCCL INFO ", "", l)
+        kind = re.match(r"(Tree|Ring|Channel)\b", body)
+        if kind:
+            seen[kind.group(1)] = seen.get(kind.group(1), 0) + 1
+            if seen[kind.group(1)] > 2:
+                continue
+        brief.append(body)
     out = {"log": path, "lines": len(lines), "channels": len({m.group(1) for l in lines for m in [re.search(r"Channel (\d+)/\d+", l)] if m}),
            "p2p_links": sum("via P2P" in l for l in lines), "shm_links": sum("via SHM" in l for l in lines),
-           "choices": tuning[:limit], "init": [re.sub(r"^.*?NCCL INFO ", "", l) for l in pick[:limit]]}
+           "tree_ring_channel_lines": seen, "choices": tuning[:limit], "init": brief[:limit]}
     print("[bench] RCCL summary:", json.dumps(out)[:4000], file=sys.stderr, flush=True)
     return out
 

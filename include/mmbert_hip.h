@@ -270,7 +270,7 @@ int mmbert_heads_colsum(mmbert_stream_t stream, int nseg, const float* const* sr
  * as y = x W^T (w_inner_major = 0: forward layers, HF:457-463, REF:MMBertForPretraining.py:293-301,406-415, REF:MMBertEmbedding.py:22),
  * or [inner, N] applied as y = x W (w_inner_major = 1: the input gradients dX = dY W of the same layers).
  * mmbert_skinny_wgrad: for every op, dW[N, K] (ldw) += dY[M, N]^T . X[M, K] and db[N] += column sums of dY (db may be NULL).
- * nops <= 12, M <= 64, at most 4 sources per op; ops of one call must not write the same memory. */
+ * nops <= 12, M <= 128 (round 4; 64 before: the reference's default batch of 32 gives [96, H] pooled rows), at most 4 sources per op; ops of one call must not write the same memory. */
 typedef struct { const float* X; const float* W; int ldx, ldw, inner, row0, rows, w_inner_major; } mmbert_skinny_src;
 typedef struct { float* Y; const float* bias; int ldy, M, N, nsrc, act, accumulate; mmbert_skinny_src src[4]; } mmbert_skinny_op;
 typedef struct { const float* dY; const float* X; float* dW; float* db; int ldy, ldx, ldw, M, N, K; } mmbert_skinny_wgrad_op;

@@ -123,6 +123,106 @@ __global__ __launch_bounds__(256) void heads_loss_fwd_kernel(const float* __rest
     }
 }
 
+// The same terms for 16 < B <= 32 (round 4: the reference's default batch is 32, REF:train.py:38).  Two [32, H] arrays no longer fit LDS
+// at H = 1024, so the similarity matrix is built from RAW rows streamed in 128-column chunks (S = <x, xp> / (|x| |xp|): the
+// normalisation is applied to the sums) and the gradient phase reads this workgroup's 64 columns of both arrays from global memory
+// (L2-resident: 3 x 32 x H floats per array).  grid = (3, ceil(H / 64)) as above; thread (r = tid >> 3, q8 = tid & 7) owns S[r][4 q8 .. + 3].
+__global__ __launch_bounds__(256) void heads_loss_fwd32_kernel(const float* __restrict__ P, const float* __restrict__ XP, int B, int H, float beta,
+                                                               float* __restrict__ dXP, float* __restrict__ dPc, float* __restrict__ nce_part) {
+    __shared__ __attribute__((aligned(16))) float Xc[32][132];     // raw chunk of P_m   (rows >= B: zeros)
+    __shared__ __attribute__((aligned(16))) float Yc[32][132];     // raw chunk of XP_m
+    __shared__ float dS[32][33], SdS[32][33], nx[32], ny[32], dots[64], red[4];
+    const int m = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const float* Pm = P + (size_t)m * B * H; const float* XPm = XP + (size_t)m * B * H;
+    const int r = tid >> 3, q8 = tid & 7;
+    float s4[4] = {0.f, 0.f, 0.f, 0.f}, sa = 0.f, sc = 0.f;
+    for (int k0 = 0; k0 < H; k0 += 128) {
+        __syncthreads();
+        // stage: thread (row = tid >> 3, 16 columns at 16 (tid & 7)) of both arrays
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const int k = k0 + 16 * q8 + 4 * v;
+            const float4 z = {0.f, 0.f, 0.f, 0.f};
+            const bool in = r < B && k < H;                      // H % 4 == 0
+            const float4 x = in ? *(const float4*)(Pm + (size_t)r * H + k) : z, y = in ? *(const float4*)(XPm + (size_t)r * H + k) : z;
+            *(float4*)&Xc[r][16 * q8 + 4 * v] = x; *(float4*)&Yc[r][16 * q8 + 4 * v] = y;
+            sa += x.x * x.x + x.y * x.y + x.z * x.z + x.w * x.w; sc += y.x * y.x + y.y * y.y + y.z * y.z + y.w * y.w;
+        }
+        __syncthreads();
+#pragma unroll 4
+        for (int k = 0; k < 128; k += 4) {
+            const float4 x = *(const float4*)&Xc[r][k];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const float4 y = *(const float4*)&Yc[4 * q8 + c][k];
+                s4[c] += x.x * y.x + x.y * y.y + x.z * y.z + x.w * y.w;
+            }
+        }
+    }
+#pragma unroll
+    for (int o = 4; o >= 1; o >>= 1) { sa += __shfl_xor(sa, o, 64); sc += __shfl_xor(sc, o, 64); }   // a row's 8 threads are consecutive lanes
+    if (q8 == 0) { nx[r] = sqrtf(sa); ny[r] = sqrtf(sc); }
+    __syncthreads();
+    float sv[4], mx = -INFINITY;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const int cc = 4 * q8 + c;
+        const bool valid = r < B && cc < B;
+        sv[c] = valid ? s4[c] / (nx[r] * ny[cc]) : 0.f;
+        if (valid) mx = fmaxf(mx, sv[c]);
+    }
+#pragma unroll
+    for (int o = 4; o >= 1; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    float e[4], se = 0.f;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) { e[c] = (r < B && 4 * q8 + c < B) ? expf(sv[c] - mx) : 0.f; se += e[c]; }
+#pragma unroll
+    for (int o = 4; o >= 1; o >>= 1) se += __shfl_xor(se, o, 64);
+    const float neg = mx + logf(se), w = -beta / (float)B;
+    float part = 0.f;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const int cc = 4 * q8 + c;
+        const bool valid = r < B && cc < B;
+        const float ds = valid ? w * (e[c] / se - (cc == r ? 1.f : 0.f)) : 0.f;
+        dS[r][cc] = ds;
+        SdS[r][cc] = valid ? ds * sv[c] : 0.f;
+        if (valid && cc == r) part = (neg - sv[c]) / (float)B;
+    }
+    part = wave_sum(part);
+    if (lane == 0) red[wv] = part;
+    __syncthreads();
+    if (tid == 0 && blockIdx.y == 0) nce_part[m] = red[0] + red[1] + red[2] + red[3];
+    if (tid < 64) {                                     // <Xn[b], dXn[b]> (row sums of S o dS) and <XPn[b], dXPn[b]> (column sums)
+        const int b = tid & 31;
+        float t = 0.f;
+        for (int j2 = 0; j2 < 32; ++j2) t += tid < 32 ? SdS[b][j2] : SdS[j2][b];
+        dots[tid] = t;
+    }
+    __syncthreads();
+    // gradients of this workgroup's 64 columns: thread = (column c, 8 rows b = 8 wv ..)
+    const int k = blockIdx.y * 64 + lane;
+    if (k < H) {
+        float x[32], y[32];
+#pragma unroll
+        for (int j2 = 0; j2 < 32; ++j2) {
+            x[j2] = j2 < B ? Pm[(size_t)j2 * H + k] / nx[j2] : 0.f;
+            y[j2] = j2 < B ? XPm[(size_t)j2 * H + k] / ny[j2] : 0.f;
+        }
+#pragma unroll
+        for (int bb = 0; bb < 8; ++bb) {
+            const int b = 8 * wv + bb;
+            if (b < B) {
+                float a = 0.f, cc = 0.f;
+#pragma unroll
+                for (int j2 = 0; j2 < 32; ++j2) { a += dS[b][j2] * y[j2]; cc += dS[j2][b] * x[j2]; }
+                dPc[((size_t)m * B + b) * H + k] = (a - x[b] * dots[b]) / nx[b];
+                dXP[((size_t)m * B + b) * H + k] = (cc - y[b] * dots[32 + b]) / ny[b];
+            }
+        }
+    }
+}
+
 // single workgroup: 2-way CE of the alignment scores (REF :297-298, :428), the label loss (:430-441, num_labels 7 / 1), sums.
 //   rel [2B,2] (visual rows then speech rows), ap [2B] labels, lo [B] raw classifier output (tanh applied here when tanh_lo), sent [B]
 //   out: [ap_loss, label_loss, nce, heads_loss];  seeds: drel [2B,2], dlo [B] (gradient w.r.t. the PRE-tanh output when tanh_lo)
@@ -201,7 +301,7 @@ __global__ void heads_tanh_bwd_kernel(const float* __restrict__ dP, const float*
 
 
 // --------------------------------------------------------------------------------------------------------------------------------
-// The heads' dense layers themselves: fp32 products with at most 64 rows ([3B, H] pooled vectors against [H..3H, H] weights, B <= 16).
+// The heads' dense layers themselves: fp32 products with at most 128 rows ([3B, H] pooled vectors against [H..3H, H] weights, B <= 32).
 // Round 1 sent each through torch.addmm -> hipBLASLt: ~45 launches of 6-27 us per step for 0.9 GFLOP, plus the host cost of as many
 // library calls.  Here a launch is a LIST of independent products (one dependency level of the heads' graph), memory-bound on the
 // weights it streams once:
@@ -230,6 +330,10 @@ __global__ __launch_bounds__(256) void skinny_mm_kernel(const SkArgs a) {
     const SkOp& op = a.op[oi];
     int t = (int)blockIdx.x - op.tile0;
     const int chunks = op.pad_;                                    // 64-deep chunks over all sources of this op
+    // (round 4: M up to 128 = the reference's default batch 32 x 3 modalities: the tile index carries a 64-row block as its slowest part)
+    const int per_rb = ((op.N + 15) / 16) * chunks;
+    const int rb0 = (t / per_rb) * 64;
+    t -= (t / per_rb) * per_rb;
     const int n0 = (t / chunks) * 16;
     int ch = t - (t / chunks) * chunks, j = 0;
     while (j + 1 < op.nsrc && ch >= (op.src[j].inner + 63) / 64) { ch -= (op.src[j].inner + 63) / 64; ++j; }
@@ -240,7 +344,7 @@ __global__ __launch_bounds__(256) void skinny_mm_kernel(const SkArgs a) {
     float xv[16], wv[4];
 #pragma unroll
     for (int i = 0; i < 16; ++i) {                                 // X chunk: 64 rows x 64 inner (rows outside the source's range: 0)
-        const int idx = tid + 256 * i, row = idx >> 6, kk = idx & 63;
+        const int idx = tid + 256 * i, row = rb0 + (idx >> 6), kk = idx & 63;
         const int r = row - sc.row0;
         xv[i] = (r >= 0 && r < sc.rows && c0 + kk < sc.inner) ? sc.X[(size_t)r * sc.ldx + c0 + kk] : 0.f;
     }
@@ -276,7 +380,7 @@ __global__ __launch_bounds__(256) void skinny_mm_kernel(const SkArgs a) {
         const float b = (op.bias && j == 0 && ch == 0) ? op.bias[n] : 0.f;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int row = tg + 16 * r;
+            const int row = rb0 + tg + 16 * r;
             if (row < op.M) atomicAdd(op.Y + (size_t)row * op.ldy + n, acc[r] + b);
         }
     }
@@ -294,25 +398,29 @@ __global__ __launch_bounds__(256) void skinny_wgrad_kernel(const SkWArgs a) {
     const int t = (int)blockIdx.x - op.tile0;
     const int n0 = (t / op.tiles_k) * 16, k0 = (t % op.tiles_k) * 64;
     const int tid = threadIdx.x;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int idx = tid + 256 * i, m = idx >> 4, c = idx & 15;
-        dYs[m][c] = (m < op.M && n0 + c < op.N) ? op.dY[(size_t)m * op.ldy + n0 + c] : 0.f;
-    }
-#pragma unroll 4
-    for (int i = 0; i < 16; ++i) {
-        const int idx = tid + 256 * i, m = idx >> 6, kk = idx & 63;
-        Xs[m][kk] = (m < op.M && k0 + kk < op.K) ? op.X[(size_t)m * op.ldx + k0 + kk] : 0.f;
-    }
-    __syncthreads();
     const int tk4 = tid & 15, tn = tid >> 4;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     float bsum = 0.f;
-    for (int m = 0; m < op.M; ++m) {
-        const float dy = dYs[m][tn];
-        const float4 x4 = *(const float4*)&Xs[m][4 * tk4];
-        acc.x += dy * x4.x; acc.y += dy * x4.y; acc.z += dy * x4.z; acc.w += dy * x4.w;
-        bsum += dy;
+    for (int m0 = 0; m0 < op.M; m0 += 64) {                        // (round 4: M up to 128 rows, 64 at a time through LDS)
+        if (m0) __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int idx = tid + 256 * i, m = m0 + (idx >> 4), c = idx & 15;
+            dYs[idx >> 4][c] = (m < op.M && n0 + c < op.N) ? op.dY[(size_t)m * op.ldy + n0 + c] : 0.f;
+        }
+#pragma unroll 4
+        for (int i = 0; i < 16; ++i) {
+            const int idx = tid + 256 * i, m = m0 + (idx >> 6), kk = idx & 63;
+            Xs[idx >> 6][kk] = (m < op.M && k0 + kk < op.K) ? op.X[(size_t)m * op.ldx + k0 + kk] : 0.f;
+        }
+        __syncthreads();
+        const int mend = min(64, op.M - m0);
+        for (int m = 0; m < mend; ++m) {
+            const float dy = dYs[m][tn];
+            const float4 x4 = *(const float4*)&Xs[m][4 * tk4];
+            acc.x += dy * x4.x; acc.y += dy * x4.y; acc.z += dy * x4.z; acc.w += dy * x4.w;
+            bsum += dy;
+        }
     }
     const int n = n0 + tn;
     if (n < op.N) {
@@ -355,7 +463,15 @@ int mmbert_heads_loss_fwd(hipStream_t stream, const float* P, const float* XP, c
                           int B, int H, float beta, int tanh_lo, float* out5, float* dXP, float* dPc, float* drel, float* dlo, float* nce_part,
                           const float* mlm, int nmlm, float alpha) {
     if (B <= 0) return 0;
-    if (H > 1024 || (H & 3) || B > 16 || nmlm < 0 || (nmlm > 0 && !mlm)) return -1;
+    if (H > 1024 || (H & 3) || B > 32 || nmlm < 0 || (nmlm > 0 && !mlm)) return -1;
+    if (B > 16) {
+        hipLaunchKernelGGL(heads_loss_fwd32_kernel, dim3(3, (H + 63) / 64), dim3(256), 0, stream, P, XP, B, H, beta, dXP, dPc, nce_part);
+        MMB_CHECK_LAUNCH();
+        hipLaunchKernelGGL(heads_loss_finish_kernel, dim3(1), dim3(256), 0, stream, rel, ap, lo, sent, (const float*)nce_part, B, beta, tanh_lo, out5, drel, dlo,
+                           mlm, nmlm, alpha);
+        MMB_CHECK_LAUNCH();
+        return 0;
+    }
     const size_t lds = ((size_t)2 * 16 * (H + 4) + 512 + 32 + 32 + 4) * sizeof(float);
     constexpr int LDS_MAX = (2 * 16 * (1024 + 4) + 512 + 32 + 32 + 4) * (int)sizeof(float);     // the H = 1024 request: allowed once per device
     static std::atomic<unsigned long long> attr_done{0};
@@ -411,20 +527,20 @@ int mmbert_skinny_mm(hipStream_t stream, int nops, const mmbert_skinny_op* ops) 
     int tiles = 0;
     for (int i = 0; i < nops; ++i) {
         const mmbert_skinny_op& o = ops[i];
-        if (o.M < 0 || o.M > 64 || o.N <= 0 || o.nsrc < 1 || o.nsrc > SK_MAXSRC || !o.Y) return -1;
+        if (o.M < 0 || o.M > 128 || o.N <= 0 || o.nsrc < 1 || o.nsrc > SK_MAXSRC || !o.Y) return -1;
         SkOp& d = a.op[i];
         if (o.act != 0) return -1;                                 // (an activation cannot follow a sum that is still being added to)
         d.Y = o.Y; d.bias = o.bias; d.ldy = o.ldy; d.M = o.M; d.N = o.N; d.nsrc = o.nsrc; d.act = 0; d.accumulate = o.accumulate; d.tile0 = tiles;
         int chunks = 0;
         for (int j = 0; j < o.nsrc; ++j) {
             const mmbert_skinny_src& sc = o.src[j];
-            if (sc.rows < 0 || sc.row0 < 0 || sc.row0 + sc.rows > 64 || sc.inner <= 0 || !sc.X || !sc.W) return -1;
+            if (sc.rows < 0 || sc.row0 < 0 || sc.row0 + sc.rows > 128 || sc.inner <= 0 || !sc.X || !sc.W) return -1;
             d.src[j].X = sc.X; d.src[j].W = sc.W; d.src[j].ldx = sc.ldx; d.src[j].ldw = sc.ldw; d.src[j].inner = sc.inner;
             d.src[j].row0 = sc.row0; d.src[j].rows = sc.rows; d.src[j].w_inner_major = sc.w_inner_major;
             chunks += (sc.inner + 63) / 64;
         }
         d.pad_ = chunks;
-        tiles += ((o.N + 15) / 16) * chunks;
+        tiles += ((o.N + 15) / 16) * chunks * ((o.M + 63) / 64 > 0 ? (o.M + 63) / 64 : 1);
     }
     a.nops = nops;
     hipLaunchKernelGGL(skinny_mm_kernel, dim3(tiles), dim3(256), 0, stream, a);
@@ -439,7 +555,7 @@ int mmbert_skinny_wgrad(hipStream_t stream, int nops, const mmbert_skinny_wgrad_
     int tiles = 0;
     for (int i = 0; i < nops; ++i) {
         const mmbert_skinny_wgrad_op& o = ops[i];
-        if (o.M < 0 || o.M > 64 || o.N <= 0 || o.K <= 0 || !o.dY || !o.X || !o.dW) return -1;
+        if (o.M < 0 || o.M > 128 || o.N <= 0 || o.K <= 0 || !o.dY || !o.X || !o.dW) return -1;
         SkWOp& d = a.op[i];
         d.dY = o.dY; d.X = o.X; d.dW = o.dW; d.db = o.db; d.ldy = o.ldy; d.ldx = o.ldx; d.ldw = o.ldw; d.M = o.M; d.N = o.N; d.K = o.K;
         d.tile0 = tiles; d.tiles_k = (o.K + 63) / 64;

@@ -1292,7 +1292,7 @@ class MMBertPreTrainingHeads(nn.Module):
 
 class _HeadsFn(torch.autograd.Function):
     """heads_loss = ap_loss + label_loss - beta * nce and the auxiliary outputs from the [CLS] rows, with a hand-written
-    backward, entirely in csrc/heads.hip: the dense layers as lists of <= 64-row fp32 products (mmbert_skinny_mm / _wgrad, one
+    backward, entirely in csrc/heads.hip: the dense layers as lists of <= 128-row fp32 products (batch <= 32: the reference's default, REF:train.py:38; mmbert_skinny_mm / _wgrad, one
     launch per dependency level), the gates / CPC / losses and their gradients in between.  Same arithmetic as
     MMBertForPretraining._heads (the eager form, kept as the reference for tests and for configurations this path does not
     cover); 19 launches where the eager form needs ~250 (round 1: ~60, the dense layers through torch.addmm -> hipBLASLt).
@@ -1555,7 +1555,7 @@ class MMBertForPretraining(_GpuModelBase):
         """The heads on the [3B, H] [CLS] rows: the fused kernels (csrc/heads.hip) where they apply, else the eager form.
         (A captured hipGraph of the eager [B,H]-sized glue -- forward and backward, ~200 dependent launches -- was built and
         measured in round 1: no gain; the device time of the tiny kernels, not their dispatch, is the cost.)"""
-        fused = (self.fused_heads and sentiment is not None and first.is_cuda and self.num_labels in (1, 7) and B <= 16
+        fused = (self.fused_heads and sentiment is not None and first.is_cuda and self.num_labels in (1, 7) and B <= 32
                  and all(q.grad is not None for q in (self.attn.weight, self.vt.weight, self.classifier1_1.weight)))
         if fused:
             ap = torch.cat((ap_v.to(dev).view(-1), ap_s.to(dev).view(-1))).long()

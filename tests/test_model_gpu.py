@@ -1038,7 +1038,7 @@ def test_hidden_states_match_reference_golden(golden_dir):
                     # pooled = tanh(pooler(hidden[L-1][:, 0])) is what the heads consume
 
 
-@pytest.mark.parametrize("B,H,num_labels", [(4, 128, 7), (16, 768, 7), (2, 1024, 1), (5, 192, 7)])
+@pytest.mark.parametrize("B,H,num_labels", [(4, 128, 7), (16, 768, 7), (2, 1024, 1), (5, 192, 7), (32, 1024, 7), (21, 768, 1), (17, 128, 7)])
 def test_fused_heads_match_oracle_in_fp32(B, H, num_labels):
     """csrc/heads.hip (+ the dense products around it: model._HeadsFn, hand-derived backward) against the ORACLE's restatement of
     the same objective (oracle.heads_from_cls -> fusion_objective, the functions the pinned pretraining_forward runs) on the
