@@ -167,7 +167,13 @@ int mmbert_attn_bwd(mmbert_stream_t stream, const void* qkv, const void* ctx, co
                     const int* qtile_seq, const int* qtile_r0, int nqtiles,      /* query tiles: mmbert_attn_tile_rows(0) rows */
                     const int* tile_seq, const int* tile_r0, int ntiles,         /* key tiles:   mmbert_attn_tile_rows(1) rows */
                     uint32_t dstream, uint32_t dthr, float dscale, const int* kv_len,
-                    const int* qtile_qshift, const int* qtile_qend, int split);
+                    const int* qtile_qshift, const int* qtile_qend, int split,
+                    const int* q_limit);     /* optional, per sequence: query rows at index >= q_limit[s] have dO == 0 exactly (see below) */
+/* q_limit[s] = 1 + the largest query index (packed row - seq_start[s]) of the int32 row list `rows` inside sequence s (0: none): the
+ * rows that CAN have a non-zero output gradient.  For the top encoder layer those are the MLM-labelled rows and the [CLS] rows
+ * (REF:MMBertForPretraining.py:381-384, 406-415 read nothing else), all within a sequence's first rows, so its attention backward
+ * stops every query loop there: dQ = 0 beyond, and those rows add exact zeros to dK / dV.  seq_start ascending. */
+int mmbert_attn_q_limit(mmbert_stream_t stream, const int* rows, int n, const int* seq_start, int nseq, int* q_limit);
 int mmbert_attn_dropout_mask(mmbert_stream_t stream, uint8_t* out, int S, unsigned elem_base, int head, uint32_t rng_stream, uint32_t thr16);
 
 /* ---- vocabulary cross-entropy (ignore_index -100), per-pass means ----

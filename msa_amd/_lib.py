@@ -42,7 +42,8 @@ SIGNATURES = {
     "mmbert_attn_tile_rows": (I, [I]),
     "mmbert_attn_kv_len": (I, [P, P, P, P, I, P]),
     "mmbert_attn_fwd": (I, [P, P, P, P, P, P, I, I, P, P, P, P, P, I, U32, U32, F, P, P, P]),
-    "mmbert_attn_bwd": (I, [P, P, P, P, P, P, P, P, P, I, I, P, P, P, P, P, I, P, P, I, U32, U32, F, P, P, P, I]),
+    "mmbert_attn_bwd": (I, [P, P, P, P, P, P, P, P, P, I, I, P, P, P, P, P, I, P, P, I, U32, U32, F, P, P, P, I, P]),
+    "mmbert_attn_q_limit": (I, [P, P, I, P, I, P]),
     "mmbert_attn_dropout_mask": (I, [P, P, I, C.c_uint, I, U32, U32]),
     "mmbert_ce_fwd": (I, [P, P, I, I, P, I, P, I, P, P, P, I]),
     "mmbert_ce_bwd": (I, [P, P, I, I, P, I, P, I, P, P, P, P, I, P, I, I]),

@@ -39,6 +39,10 @@ struct AttnArgs {
     // split (valid-first) layout, all optional: the QUERY rows of tile t sit at packed row tile_qshift[t] + (index in the sequence)
     // and end at index tile_qend[t]; split != 0: a sequence owns only its first kv_len[s] rows at seq_start[s] (dK/dV kernel)
     const int* tile_qshift; const int* tile_qend; int split;
+    // backward, optional, per sequence: the query rows at index >= q_limit[s] have an exactly-zero output gradient (dO row == 0, hence
+    // delta == 0 and dS == 0): dQ is zero there and they add nothing to dK / dV, so both kernels stop their query range at it
+    // (round 4: the top encoder layer, whose output gradient lives on the MLM-labelled rows and the [CLS] rows only)
+    const int* q_limit;
     int H, heads;
     float scale;
     uint32_t dstream, dthr; float dscale;
@@ -381,6 +385,20 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnArgs a) {
     const int qshift = a.tile_qshift ? a.tile_qshift[tix] : start;
     const int Sq = a.tile_qend ? a.tile_qend[tix] : S;
     const int Skv = a.kv_len ? min(S, a.kv_len[seq]) : S;
+    if (a.q_limit && r0 >= a.q_limit[seq]) {                 // every dO row of this tile is zero: dQ = 0 (q_limit, see AttnArgs)
+        const int fr_ = lane & 15, g_ = lane >> 4;
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb) {
+            const int q = r0 + wave * 32 + qb * 16 + fr_;
+            if (q < Sq) {
+                bf16_t* drow = a.dqkv + (size_t)(qshift + q) * a.ld_qkv + head * 64;
+                const bf16x4 z = {(bf16_t)0.0f, (bf16_t)0.0f, (bf16_t)0.0f, (bf16_t)0.0f};
+#pragma unroll
+                for (int d = 0; d < 4; ++d) *(bf16x4*)(drow + d * 16 + 4 * g_) = z;
+            }
+        }
+        return;
+    }
     const bool wave_active = r0 + wave * 32 < Sq;            // (128-row tiles: S = 550 leaves waves 2, 3 of the fifth tile without rows)
     const int Spad = (S + 3) & ~3;
     const int fr = lane & 15, g = lane >> 4;
@@ -558,7 +576,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnArgs a) 
     // stores its zeros and leaves before any staging.
     const int Skv = a.kv_len ? min(S, a.kv_len[seq]) : S;
     // split layout: the sequence owns only its first Skv rows here, and only those queries can have a gradient
-    const int Sq = a.split ? Skv : S, Skw = a.split ? Skv : S;
+    const int Sq0 = a.split ? Skv : S, Skw = a.split ? Skv : S;
+    const int Sq = a.q_limit ? min(Sq0, a.q_limit[seq]) : Sq0;      // queries past q_limit have dO == 0: nothing to add (see AttnArgs)
     if (r0 >= Skv) {
         const int fr_ = lane & 15, g_ = lane >> 4;
 #pragma unroll
@@ -629,7 +648,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnArgs a) 
     const unsigned saddr2[2] = {lds0 + 16 * g, lds0 + 16 * g + DKV_BUF};   // lse / delta: 4 consecutive query rows per lane group
     const bool odd = lane & 1;
     const int ntile = (Sq + 63) >> 6;
-    stage(0, 0);
+    if (ntile > 0) stage(0, 0);                              // (q_limit may leave a sequence without any query: zeros are stored below)
     auto tile_body = [&](auto buf_c, int t) {
         constexpr int buf = decltype(buf_c)::value;
         constexpr int BO = 0;                                // buffer base lives in the address registers
@@ -772,6 +791,20 @@ __global__ void attn_kv_len_kernel(const float* __restrict__ key_bias, const int
     if (threadIdx.x == 0) out[s] = last < 0 ? S : last + 1;
 }
 
+// q_limit[s] = 1 + the largest query index (packed row - seq_start[s]) among `rows` that falls into sequence s; 0 for a sequence
+// without any (out is zeroed by the launcher).  seq_start ascending.
+__global__ void attn_q_limit_kernel(const int* __restrict__ rows, int n, const int* __restrict__ seq_start, int nseq, int* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int r = rows[i];
+    int lo = 0, hi = nseq - 1;
+    while (lo < hi) {                                        // last sequence whose start is <= r
+        const int mid = (lo + hi + 1) >> 1;
+        if (seq_start[mid] <= r) lo = mid; else hi = mid - 1;
+    }
+    atomicMax(out + lo, r - seq_start[lo] + 1);
+}
+
 extern "C" {
 
 static int fill_args(AttnArgs& a, const void* qkv, int H, int heads, const float* key_bias, const int* bias_start, const int* seq_start, const int* seq_len,
@@ -782,7 +815,7 @@ static int fill_args(AttnArgs& a, const void* qkv, int H, int heads, const float
     a.seq_start = seq_start; a.seq_len = seq_len; a.elem_base = elem_base; a.tile_seq = tile_seq; a.tile_r0 = tile_r0;
     a.lse = lse; a.scale = 0.125f; a.dstream = dstream; a.dthr = dthr; a.dscale = dscale;
     a.ctx = nullptr; a.dctx = nullptr; a.dqkv = nullptr; a.delta = nullptr; a.kv_len = kv_len;
-    a.tile_qshift = nullptr; a.tile_qend = nullptr; a.split = 0;
+    a.tile_qshift = nullptr; a.tile_qend = nullptr; a.split = 0; a.q_limit = nullptr;
     const char* hf = getenv("MMBERT_ATTN_HEAD_FAST");                 // A/B switch, read per call
     a.head_fast = hf ? atoi(hf) : 1;
     return 0;
@@ -807,12 +840,13 @@ int mmbert_attn_fwd(hipStream_t stream, const void* qkv, void* ctx, float* lse, 
 int mmbert_attn_bwd(hipStream_t stream, const void* qkv, const void* ctx, const void* dctx, void* dqkv, const float* lse, float* delta,
                     const float* key_bias, const int* bias_start, int H, int heads, const int* seq_start, const int* seq_len, const unsigned* elem_base,
                     const int* qtile_seq, const int* qtile_r0, int nqtiles, const int* tile_seq, const int* tile_r0, int ntiles,
-                    uint32_t dstream, uint32_t dthr, float dscale, const int* kv_len, const int* qtile_qshift, const int* qtile_qend, int split) {
+                    uint32_t dstream, uint32_t dthr, float dscale, const int* kv_len, const int* qtile_qshift, const int* qtile_qend, int split,
+                    const int* q_limit) {
     if (ntiles <= 0 || nqtiles <= 0) return 0;
     if ((qtile_qshift == nullptr) != (qtile_qend == nullptr) || (split && !kv_len)) return -1;
     AttnArgs a;
     if (fill_args(a, qkv, H, heads, key_bias, bias_start, seq_start, seq_len, elem_base, tile_seq, tile_r0, (float*)lse, dstream, dthr, dscale, kv_len)) return -1;
-    a.ctx = (bf16_t*)ctx; a.dctx = (const bf16_t*)dctx; a.dqkv = (bf16_t*)dqkv; a.delta = delta;
+    a.ctx = (bf16_t*)ctx; a.dctx = (const bf16_t*)dctx; a.dqkv = (bf16_t*)dqkv; a.delta = delta; a.q_limit = q_limit;
     {
         AttnArgs q = a;
         q.tile_seq = qtile_seq; q.tile_r0 = qtile_r0; q.tile_qshift = qtile_qshift; q.tile_qend = qtile_qend;
@@ -834,6 +868,15 @@ int mmbert_debug_set_attn_stamps(void* buf) {
     return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_attn_stamps), &buf, sizeof(buf));
 }
 #endif
+
+int mmbert_attn_q_limit(hipStream_t stream, const int* rows, int n, const int* seq_start, int nseq, int* q_limit) {
+    if (nseq <= 0) return 0;
+    if (hipMemsetAsync(q_limit, 0, (size_t)nseq * sizeof(int), stream) != hipSuccess) return (int)hipGetLastError();
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(attn_q_limit_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, rows, n, seq_start, nseq, q_limit);
+    MMB_CHECK_LAUNCH();
+    return 0;
+}
 
 int mmbert_attn_kv_len(hipStream_t stream, const float* key_bias, const int* bias_start, const int* seq_len, int nseq, int* kv_len) {
     if (nseq <= 0) return 0;

@@ -992,14 +992,19 @@ __global__ __launch_bounds__(512, 2) void gemm_ntp_kernel(const GemmNT p) {
 // -------------------------------------------------------------------------------------------------
 // MULTI = false: one tile per workgroup (launches of no more tiles than CUs -- the form the train step uses): no next-tile bookkeeping,
 // 40 registers fewer.  MULTI = true: the workgroup walks tiles b, b + G, ... and the half-tile stream crosses the tile seams.
-template <int EPI, bool MULTI>
+// MQ = 16-row blocks per quadrant along M: 4 (256-row tile) or 2 (128-row tile: A half-tiles of 64 rows, ONE LDS-DMA piece per wave;
+// for launches whose 256-row tiles would leave more than half the chip idle -- the reference's default model, M = 6400 x N = 1024).
+template <int EPI, bool MULTI, int MQ>
 __global__ __launch_bounds__(512, 2) void gemm_nt8_kernel(const GemmNT p) {
 #if __HIP_DEVICE_COMPILE__
     extern __shared__ __attribute__((aligned(16))) char smem[];   // buffer d at d * 65536: A0h | A1h | B0h | B1h, 16 KiB each
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 2, wc = wave & 3;
-    const int tiles_n = (p.N + 255) >> 8, tiles_m = (p.M + 255) >> 8;
+    constexpr int BMT = 64 * MQ;                                 // tile rows
+    constexpr int AP = MQ / 2;                                   // LDS-DMA pieces per wave and A half-tile (B half-tiles: always 2)
+    constexpr int INFL = 4 + AP;                                 // this wave's LDS-DMAs of the three half-tiles that stay in flight (B0h, A0h, B1h)
+    const int tiles_n = (p.N + 255) >> 8, tiles_m = (p.M + BMT - 1) / BMT;
     const int ntiles = tiles_m * tiles_n, G = gridDim.x;
     const int nt = p.K >> 6;                                     // K tiles (K % 128 == 0: an even count, >= 4)
 
@@ -1015,7 +1020,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt8_kernel(const GemmNT p) {
         asm volatile("" : "+v"(l));                               // recomputed per call, nothing kept alive across the K loop
         int tmi, tni;
         ntp_tile_mn(xcd_remap(v, ntiles), tiles_m, tiles_n, p.group_m, tmi, tni);
-        const int tm0 = tmi << 8, tn0 = tni << 8;
+        const int tm0 = tmi * BMT, tn0 = tni << 8;
         const int pos = l & 7;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
@@ -1024,7 +1029,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt8_kernel(const GemmNT p) {
             const uint32_t chunk_b = (uint32_t)(pos ^ (((r >> 1) & 1) | (((r >> 3) & 3) << 1)));
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
-                const int ga = tm0 + (r >> 6) * 128 + h * 64 + (r & 63);
+                const int ga = tm0 + (r / (16 * MQ)) * (32 * MQ) + h * (16 * MQ) + (r % (16 * MQ));   // (piece i = 1 of a 64-row A half: never issued)
                 const int gb = tn0 + (r >> 5) * 64 + h * 32 + (r & 31);
                 o.a[h][i] = ((uint32_t)min(ga, p.M - 1) * (uint32_t)p.lda + chunk_a * 8u) * 2u;
                 o.b[h][i] = ((uint32_t)min(gb, p.N - 1) * (uint32_t)p.ldb + chunk_b * 8u) * 2u;
@@ -1043,7 +1048,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt8_kernel(const GemmNT p) {
         char* base = smem + buf * 65536 + ((which & 1) ? 0 : 32768) + h * 16384 + wave * 1024;
         if (which & 1) {
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, LPTR(base), 16, o.a[h][0], kb, 0, 0);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, LPTR(base + 8192), 16, o.a[h][1], kb, 0, 0);
+            if constexpr (AP == 2) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, LPTR(base + 8192), 16, o.a[h][1], kb, 0, 0);
         } else {
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, LPTR(base), 16, o.b[h][0], kb, 0, 0);
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, LPTR(base + 8192), 16, o.b[h][1], kb, 0, 0);
@@ -1056,20 +1061,20 @@ __global__ __launch_bounds__(512, 2) void gemm_nt8_kernel(const GemmNT p) {
     const int fr = lane & 15, fq = lane >> 4;
     const int swa = ((fq ^ (fr >> 1)) & 7) << 4;                                  // k step 0: chunk fq; k step 1: the same ^ 64 bytes
     const int swb = ((fq ^ (((fr >> 1) & 1) | ((fr >> 2) << 1))) & 7) << 4;       // key of B row 8 (fr >> 2) + 4 j + (fr & 3)
-    const lds_cptr a_rd = (lds_cptr)LPTR(smem) + (wr * 64 + fr) * 128;
+    const lds_cptr a_rd = (lds_cptr)LPTR(smem) + (wr * (16 * MQ) + fr) * 128;
     const lds_cptr b_rd = (lds_cptr)LPTR(smem) + 32768 + (wc * 32 + 8 * (fr >> 2) + (fr & 3)) * 128;
     lds_cptr a_rd1 = a_rd + 65536, b_rd1 = b_rd + 65536;        // second buffer: ds offsets are 16-bit
     asm volatile("" : "+v"(a_rd1), "+v"(b_rd1));
 
-    bf16x8 af[2][4], b0f[2][2], b1f[2][2];
-    f32x4 acc[8][4];
+    bf16x8 af[2][MQ], b0f[2][2], b1f[2][2];
+    f32x4 acc[2 * MQ][4];
 
     auto read_a = [&](int buf, int h) {
         const lds_cptr ab = buf ? a_rd1 : a_rd;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-            for (int i = 0; i < 4; ++i) af[ks][i] = *(lds_frag)(ab + h * 16384 + i * 2048 + (swa ^ (ks * 64)));
+            for (int i = 0; i < MQ; ++i) af[ks][i] = *(lds_frag)(ab + h * 16384 + i * 2048 + (swa ^ (ks * 64)));
     };
     auto read_b = [&](int buf, int h, bf16x8 (&bf)[2][2]) {
         const lds_cptr bb = buf ? b_rd1 : b_rd;
@@ -1083,10 +1088,10 @@ __global__ __launch_bounds__(512, 2) void gemm_nt8_kernel(const GemmNT p) {
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < MQ; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {   // operands swapped (B first): a lane holds 4 consecutive COLUMNS of one output row
-                    f32x4& c = acc[qa * 4 + i][qb * 2 + j];
+                    f32x4& c = acc[qa * MQ + i][qb * 2 + j];
                     c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[ks][j], af[ks][i], (first && ks == 0) ? (f32x4){0.f, 0.f, 0.f, 0.f} : c, 0, 0, 0);
                 }
     };
@@ -1094,7 +1099,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt8_kernel(const GemmNT p) {
     // ---- prologue: K tile 0 (4 half-tiles, even buffer) and the first 3 half-tiles of K tile 1 (odd buffer) of the first tile ----
     stage(0, 0, cur, 0); stage(0, 1, cur, 0); stage(0, 2, cur, 0); stage(0, 3, cur, 0);
     stage(1, 0, cur, 1); stage(1, 1, cur, 1); stage(1, 2, cur, 1);
-    __builtin_amdgcn_s_waitcnt(mmb_waitcnt(6, 15));               // K tile 0 landed (this wave's pieces)
+    __builtin_amdgcn_s_waitcnt(mmb_waitcnt(INFL, 15));            // K tile 0 landed (this wave's pieces)
     __builtin_amdgcn_s_barrier();
     if (wr == 1) __builtin_amdgcn_s_barrier();                    // the stagger: group 1 runs one barrier behind group 0
 
@@ -1120,22 +1125,22 @@ __global__ __launch_bounds__(512, 2) void gemm_nt8_kernel(const GemmNT p) {
     // by lgkmcnt(8) before that phase's first barrier) is restaged in phase 2; a0 (phase 1) in phase 3; b1 (phase 2) in phase 4; a1
     // (phase 3) in phase 1 of the next K tile -- two phases after their reads, which covers the group that runs a barrier behind.
 #define NT8_KTILE(D, S1, K1, S2, K2, FIRST)                                                                                   \
-    NT8_PHASE((read_b(D, 0, b0f), __builtin_amdgcn_sched_barrier(0), read_a(D, 0)), 8, stage(D ^ 1, 3, S1, K1), -1, 0, 0, b0f, FIRST) \
+    NT8_PHASE((read_b(D, 0, b0f), __builtin_amdgcn_sched_barrier(0), read_a(D, 0)), 2 * MQ, stage(D ^ 1, 3, S1, K1), -1, 0, 0, b0f, FIRST) \
     NT8_PHASE(read_b(D, 1, b1f), -1, stage(D, 0, S2, K2), -1, 0, 1, b1f, FIRST)                                               \
     NT8_PHASE(read_a(D, 1), -1, stage(D, 1, S2, K2), -1, 1, 1, b1f, FIRST)                                                    \
-    NT8_PHASE((void)0, -1, stage(D, 2, S2, K2), 6, 1, 0, b0f, FIRST)
+    NT8_PHASE((void)0, -1, stage(D, 2, S2, K2), INFL, 1, 0, b0f, FIRST)
 
     for (int v = blockIdx.x; v < ntiles; v += MULTI ? G : ntiles) {
         int tmi, tni;
         ntp_tile_mn(xcd_remap(v, ntiles), tiles_m, tiles_n, p.group_m, tmi, tni);
-        const int m0 = tmi << 8, n0 = tni << 8;
+        const int m0 = tmi * BMT, n0 = tni << 8;
         if constexpr (MULTI) { if (v + G < ntiles) set_src(v + G, nxt_store); }    // past the last tile: dead re-reads of this tile's first K tiles
         // Seam: K tile 0 of this tile was issued by the previous tile's last two K tiles (or by the prologue) and is followed, in
         // vector-memory issue order, by the 6 LDS-DMAs of K tile 1's first three half-tiles and by the previous epilogue's loads and
         // stores (any number of them) -- so "at most 6 outstanding" proves it landed on every path.  As a BUILTIN, so that hipcc's own
         // scoreboard sees it: without it hipcc drains vmcnt(0) in front of this tile's first fragment reads (they alias the pending
         // LDS-DMA destinations), i.e. waits for the previous epilogue's last store.
-        __builtin_amdgcn_s_waitcnt(mmb_waitcnt(6, 15));
+        __builtin_amdgcn_s_waitcnt(mmb_waitcnt(INFL, 15));
         NT8_KTILE(0, cur, 1, cur, 2, true)
         NT8_KTILE(1, cur, 2, cur, 3, false)
         for (int t = 2; t < nt - 2; t += 2) {
@@ -1157,11 +1162,11 @@ __global__ __launch_bounds__(512, 2) void gemm_nt8_kernel(const GemmNT p) {
         asm volatile("" : "+v"(elane));
         const int efr = elane & 15, efq = elane >> 4;
         const float alpha = q.alpha * (q.alpha_dev ? *q.alpha_dev : 1.0f);
-        const bool interior = (m0 + 256 <= q.M) && (n0 + 256 <= q.N);
-        const int mrow = m0 + wr * 128 + efr;                        // + 16 i
+        const bool interior = (m0 + BMT <= q.M) && (n0 + 256 <= q.N);
+        const int mrow = m0 + wr * (32 * MQ) + efr;                  // + 16 i
         const int ncol = n0 + wc * 64 + efq * 8;                     // 8 columns here (h = 0) and 8 at + 32 (h = 1)
         constexpr int PRE = 3;
-        bf16x8 pre[8][2];
+        bf16x8 pre[2 * MQ][2];
         auto load_pre = [&](int i) {
             if constexpr (EPI & (EPI_RESID | EPI_GELU_BWD)) {
                 const bf16_t* src = (EPI & EPI_RESID) ? q.R : q.U;
@@ -1192,7 +1197,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt8_kernel(const GemmNT p) {
         const uint32_t seed0 = (EPI & EPI_RESID) ? ((uint32_t)mrow * halfN + ((uint32_t)ncol >> 1)) * MMB_WEYL + q.drop_stream : 0u;
         const uint32_t seed_row = 16u * halfN * MMB_WEYL;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
+        for (int i = 0; i < 2 * MQ; ++i) {
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
 #pragma unroll
@@ -1217,8 +1222,8 @@ __global__ __launch_bounds__(512, 2) void gemm_nt8_kernel(const GemmNT p) {
             }
         }
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            if (i + PRE < 8) load_pre(i + PRE);
+        for (int i = 0; i < 2 * MQ; ++i) {
+            if (i + PRE < 2 * MQ) load_pre(i + PRE);
             const int m = mrow + 16 * i;
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
@@ -1275,22 +1280,23 @@ __global__ __launch_bounds__(512, 2) void gemm_nt8_kernel(const GemmNT p) {
 #endif
 }
 
-template <int EPI, bool MULTI>
+template <int EPI, bool MULTI, int MQ>
 static int launch_nt8_form(hipStream_t s, const GemmNT& q, int workgroups) {
     static std::atomic<unsigned long long> attr_done{0};
-    if (int e = mmb_allow_lds((const void*)gemm_nt8_kernel<EPI, MULTI>, 131072, attr_done)) return e;
-    hipLaunchKernelGGL((gemm_nt8_kernel<EPI, MULTI>), dim3(workgroups), dim3(512), 131072, s, q);
+    if (int e = mmb_allow_lds((const void*)gemm_nt8_kernel<EPI, MULTI, MQ>, 131072, attr_done)) return e;
+    hipLaunchKernelGGL((gemm_nt8_kernel<EPI, MULTI, MQ>), dim3(workgroups), dim3(512), 131072, s, q);
     MMB_CHECK_LAUNCH();
     return 0;
 }
 template <int EPI>
-static int launch_nt8(hipStream_t s, const GemmNT& p, int tiles, int workgroups, int group_m) {
+static int launch_nt8(hipStream_t s, const GemmNT& p, int bm, int tiles, int workgroups, int group_m) {
     GemmNT q = p;
     q.group_m = group_m;
     q.tile_counter = q.tile_counter_next = nullptr;
+    if (bm == 128) return launch_nt8_form<EPI, false, 2>(s, q, workgroups);    // (128-row tiles: single-round launches only)
     const char* f = getenv("MMBERT_NT_8PHASE_FORM");              // A/B switch, read per call: "multi" runs the multi-tile form everywhere
-    if (tiles > workgroups || (f && f[0] == 'm')) return launch_nt8_form<EPI, true>(s, q, workgroups);
-    return launch_nt8_form<EPI, false>(s, q, workgroups);
+    if (tiles > workgroups || (f && f[0] == 'm')) return launch_nt8_form<EPI, true, 4>(s, q, workgroups);
+    return launch_nt8_form<EPI, false, 4>(s, q, workgroups);
 }
 
 constexpr int NTP_LDS_BYTES = 131072 + 1024 + 8 * 256;      // ring | tile-queue word (padded) | bias rows
@@ -1360,7 +1366,16 @@ static NTChoice nt_choose(const GemmNT& p, int epi) {
         const bool huge_b = (long long)p.N * p.K * 2 > (8ll << 20);
         // ... single-round launches that leave more than half the chip idle (the reference's default model: M = 6400, N = 1024 is 100
         // tiles): the 128 x 128 kernel's 4 x as many tiles on 2 workgroups per CU are 6-14 % faster there (profiles/r4_bert_large_gemm_modes.log)
-        if (g_nt_force == 0 && lvl >= 1 && 2 * t256 <= cus && c.tiles <= 2 * cus) return c;
+        if (g_nt_force == 0 && lvl >= 1 && 2 * t256 <= cus) {
+            // (round 4, later) ... better still: the 8-phase kernel on 128-row tiles when those fit the chip in one round
+            const int t128 = ((p.M + 127) / 128) * tn;
+            static const bool bm128_ok = !(getenv("MMBERT_NT_8PHASE_BM128") && atoi(getenv("MMBERT_NT_8PHASE_BM128")) == 0);     // A/B switch
+            if (bm128_ok && ntp_eligible(p) && t128 <= cus && 2 * t128 >= cus) {      // (fewer than half the CUs: the 128 x 128 kernel's finer tiles)
+                c.kernel = NTK_8PHASE; c.bm = 128; c.tiles = t128; c.workgroups = t128; c.group_m = 1;
+                return c;
+            }
+            if (c.tiles <= 2 * cus) return c;
+        }
         const bool multi_ok = (t256 > cus) && !p.tile_counter && (lvl >= 3 || (lvl >= 2 && !huge_b));
         if (ntp_eligible(p) && ((g_nt_force == 0 && ((lvl >= 1 && t256 <= cus) || multi_ok)) || g_nt_force == 3)) {
             c.kernel = NTK_8PHASE; c.bm = 256; c.tiles = t256; c.workgroups = t256 < cus ? t256 : cus;
@@ -1444,7 +1459,7 @@ template <int EPI>
 static int dispatch_nt(hipStream_t s, const GemmNT& p) {
     const NTChoice c = nt_choose(p, EPI);
     if (c.kernel == NTK_128) return launch_nt<EPI>(s, p);
-    if (c.kernel == NTK_8PHASE) return launch_nt8<EPI>(s, p, c.tiles, c.workgroups, c.group_m);
+    if (c.kernel == NTK_8PHASE) return launch_nt8<EPI>(s, p, c.bm, c.tiles, c.workgroups, c.group_m);
     if (c.kernel == NTK_PERSIST) return c.bm == 256 ? launch_ntp_mi<EPI, 8>(s, p, c) : launch_ntp_mi<EPI, 7>(s, p, c);
     return c.bm == 256 ? launch_nt256_mi<EPI, 8>(s, p) : launch_nt256_mi<EPI, 7>(s, p);
 }

@@ -398,7 +398,11 @@ class _EncoderFn:
             dz1d_c = dz1_c
         dctx = torch.zeros((ra, H), device=dy.device, dtype=torch.bfloat16)
         dctx.index_copy_(0, R, ops.gemm_nt(dz1d_c, lw["WoT"]))
-        dqkv = ops.attn_bwd(qkv, actx, dctx, lse, key_bias, layout, H, drop=d_att, kv_len=kv_len)
+        # only the rows R of this layer's attention output have a gradient: the query loops of its backward stop at the last of them
+        # in every sequence (the labelled text rows and [CLS] sit in a sequence's first rows: one 64-row query tile instead of ~7).
+        # Exact: a query row with dO = 0 has delta = 0 and dS = 0 (round 4; model.top_layer_query_limit = False switches it off)
+        qlim = ops.attn_q_limit(R32, layout) if getattr(top, "top_layer_query_limit", True) else None
+        dqkv = ops.attn_bwd(qkv, actx, dctx, lse, key_bias, layout, H, drop=d_att, kv_len=kv_len, q_limit=qlim)
         dz1 = torch.zeros((ra, H), device=dy.device, dtype=torch.bfloat16)
         dz1.index_copy_(0, R, dz1_c)
         out = ops.gemm_nt(dqkv, lw["WqkvT"], resid=dz1)

@@ -700,7 +700,17 @@ def attn_fwd(qkv, key_bias, layout: SeqLayout, H, *, drop: Drop = None, ctx=None
     return ctx, lse
 
 
-def attn_bwd(qkv, ctx, dctx, lse, key_bias, layout: SeqLayout, H, *, drop: Drop = None, dqkv=None, kv_len=None):
+def attn_q_limit(rows32, layout):
+    """Per sequence of ``layout``: 1 + the largest query index among the packed rows ``rows32`` (int32) -- what ``attn_bwd(q_limit=...)``
+    takes when only those rows have a non-zero output gradient (mmbert_attn_q_limit)."""
+    ns = layout.seq_len.numel()
+    out = torch.empty(ns, device=rows32.device, dtype=torch.int32)
+    _lib.check(_lib.load().mmbert_attn_q_limit(_stream(), rows32.data_ptr(), rows32.numel(), layout.seq_start.data_ptr(), ns, out.data_ptr()),
+               "mmbert_attn_q_limit")
+    return out
+
+
+def attn_bwd(qkv, ctx, dctx, lse, key_bias, layout: SeqLayout, H, *, drop: Drop = None, dqkv=None, kv_len=None, q_limit=None):
     lib = _lib.load()
     M = qkv.shape[0]
     if dqkv is None:
@@ -721,7 +731,7 @@ def attn_bwd(qkv, ctx, dctx, lse, key_bias, layout: SeqLayout, H, *, drop: Drop 
                                    layout.elem_base.data_ptr(), q_seq.data_ptr(), q_r0.data_ptr(), nq,
                                    layout.tile_seq.data_ptr(), layout.tile_r0.data_ptr(), layout.ntiles,
                                    d[0], d[1], d[2], _ptr(kv_len), _ptr(getattr(layout, "qtile_qshift", None)), _ptr(getattr(layout, "qtile_qend", None)),
-                                   1 if split else 0), "mmbert_attn_bwd")
+                                   1 if split else 0, _ptr(q_limit)), "mmbert_attn_bwd")
     return dqkv
 
 

@@ -132,6 +132,34 @@ def test_gemm_nt_8phase_kernel_headline_shapes_every_epilogue(ops, K):
     assert_close(aux, ref + bias, 1e-2, 3e-2, "gelu aux")
 
 
+@pytest.mark.parametrize("K", [1024, 4096])
+def test_gemm_nt_8phase_128_row_tiles_reference_default_shapes(ops, K):
+    """The 8-phase kernel on 128-row tiles (MQ = 2: A half-tiles of 64 rows, one LDS-DMA piece per wave, 5 in flight): what the
+    reference's default model (bert-large, batch 32 x (40 + 80 + 80) = 6400 rows, N = 1024: REF:train.py:28,32,38) dispatches to,
+    where 256-row tiles would leave 60 % of the chip idle.  Ragged last row panel; every epilogue against fp32 torch."""
+    M, N = 6400 - 37, 1024
+    d = ops.gemm_nt_describe(M, N, K)
+    assert d["kernel"] == "8phase" and d["tile"] == "128x256" and d["tiles"] <= d["cus"], d
+    A, B = bf(rnd(M, K, seed=71, scale=0.5)).to(DEV), bf(rnd(N, K, seed=72, scale=0.05)).to(DEV)
+    bias, R = rnd(N, seed=73).to(DEV), bf(rnd(M, N, seed=74)).to(DEV)
+    ref = A.float() @ B.float().t()
+    drop = ops.make_drop(0.1, 13, 6)
+    keep = ops.dropout_mask(M * N, drop, DEV).view(M, N).float()
+    u = R.float().requires_grad_(True)
+    torch.nn.functional.gelu(u).sum().backward()
+    cases = {"plain": ({}, ref), "bias": (dict(bias=bias), ref + bias), "resid": (dict(resid=R), ref + R.float()),
+             "bias_resid_drop": (dict(bias=bias, resid=R, drop=drop), (ref + bias) * keep * drop[2] + R.float()),
+             "gelu": (dict(bias=bias, gelu=True), torch.nn.functional.gelu(ref + bias)), "gelu_bwd": (dict(gelu_bwd_u=R), ref * u.grad),
+             "bias_f32": (dict(bias=bias, out_f32=True), ref + bias)}
+    for name, (kw, want) in cases.items():
+        assert_close(ops.gemm_nt(A, B, **kw), want, 1e-2, 4e-2, name)
+    # exact on small integers (every tile once, the right rows)
+    Ai = ((torch.arange(M)[:, None] * 5 + torch.arange(K)[None, :] * 3) % 3 - 1.0)
+    Bi = ((torch.arange(N)[:, None] * 2 + torch.arange(K)[None, :] * 11) % 2).float()
+    out = ops.gemm_nt(bf(Ai).to(DEV), bf(Bi).to(DEV), out_f32=True)
+    assert torch.equal(out, Ai.to(DEV) @ Bi.to(DEV).t())
+
+
 @pytest.mark.parametrize("level", ["0", "3"])
 @pytest.mark.parametrize("M,N,K", [(18400, 2304, 256), (14000, 3072, 256), (5000, 3072, 256), (9000, 1792, 256), (18400 - 37, 2304, 768)])
 def test_gemm_nt_grouped_tile_walk_exact(ops, M, N, K, level, monkeypatch):
@@ -586,6 +614,50 @@ def test_attention_skips_trailing_masked_keys_exactly(ops, p):
     assert bool(torch.isfinite(d1.float()).all())
     # the gradients of fully masked trailing keys are exact zeros
     assert float(d1[320:550, H:].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("p", [0.0, 0.1])
+def test_attention_backward_query_limit_is_exact(ops, p):
+    """Round 4: ``attn_bwd(q_limit=...)`` -- per sequence, the query rows at index >= q_limit[s] have an exactly-zero output gradient
+    (the top encoder layer: only the MLM-labelled rows and [CLS] have one), so dQ is zero there and they add exact zeros to dK / dV;
+    both backward kernels stop their query range at it.  dctx zero past the last "labelled" row of every sequence; limits from
+    mmbert_attn_q_limit on the row list (a sequence with no such row gets 0: all-zero gradients); results BIT-identical to the run
+    without the limit, with and without dropout, with masked-out trailing keys (kv_len) on top."""
+    lens, heads, H = [550, 300, 50, 200, 130, 64], 2, 128
+    M = sum(lens)
+    starts = [sum(lens[:i]) for i in range(len(lens))]
+    qkv = bf(rnd(M, 3 * H, seed=61)).to(DEV)
+    dctx = bf(rnd(M, H, seed=62))
+    # rows with a gradient: a few among the first 50 rows of each sequence (text positions), none in sequence 3
+    g = torch.Generator().manual_seed(63)
+    rows = []
+    for i, (s0, n) in enumerate(zip(starts, lens)):
+        if i == 3:
+            continue
+        k = torch.randperm(min(50, n), generator=g)[:7] + s0
+        rows.append(torch.cat((k, torch.tensor([s0]))))
+    rows = torch.cat(rows)
+    keep = torch.zeros(M, dtype=torch.bool)
+    keep[rows] = True
+    dctx = (dctx.float() * keep[:, None]).to(torch.bfloat16).to(DEV)
+    bias = torch.zeros(M)
+    bias[starts[0] + 400:starts[0] + 550] = -10000.0
+    layout = ops.SeqLayout(lens, heads, DEV)
+    kb = ops.pad_key_bias(bias.to(DEV), layout)
+    kv = ops.attn_kv_len(kb, layout)
+    qlim = ops.attn_q_limit(rows.int().to(DEV), layout)
+    want = [0] * len(lens)
+    for r in rows.tolist():
+        i = max(j for j, s0 in enumerate(starts) if s0 <= r)
+        want[i] = max(want[i], r - starts[i] + 1)
+    assert qlim.cpu().tolist() == want and want[3] == 0 and max(want) <= 50
+    drop = ops.make_drop(p, 31, 3)
+    ctx, lse = ops.attn_fwd(qkv, kb, layout, H, drop=drop, kv_len=kv)
+    d0 = ops.attn_bwd(qkv, ctx, dctx, lse, kb, layout, H, drop=drop, kv_len=kv)
+    d1 = ops.attn_bwd(qkv, ctx, dctx, lse, kb, layout, H, drop=drop, kv_len=kv, q_limit=qlim)
+    assert torch.equal(d0, d1) and bool(torch.isfinite(d1.float()).all())
+    assert float(d1[starts[3]:starts[3] + lens[3]].abs().max()) == 0.0            # the sequence without any gradient row
+    assert float(d1[:, H:].abs().max()) > 0.0
 
 
 @pytest.mark.parametrize("mode", ["split", "dedupe", "drop"])
