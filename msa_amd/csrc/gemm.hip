@@ -1376,7 +1376,16 @@ static NTChoice nt_choose(const GemmNT& p, int epi) {
             }
             if (c.tiles <= 2 * cus) return c;
         }
-        const bool multi_ok = (t256 > cus) && !p.tile_counter && (lvl >= 3 || (lvl >= 2 && !huge_b));
+        bool shape_on = false;                                   // MMBERT_NT_8PHASE_MULTI="N:K:E;..." : the multi-tile form for single shapes (A/B)
+        if (const char* t = getenv("MMBERT_NT_8PHASE_MULTI")) {
+            for (const char* q = t; q && *q; ) {
+                int n = 0, k = 0, e = 0;
+                if (sscanf(q, "%d:%d:%d", &n, &k, &e) == 3 && n == p.N && k == p.K && e == epi) shape_on = true;
+                q = strchr(q, ';');
+                if (q) ++q;
+            }
+        }
+        const bool multi_ok = (t256 > cus) && !p.tile_counter && (lvl >= 3 || (lvl >= 2 && !huge_b) || shape_on);
         if (ntp_eligible(p) && ((g_nt_force == 0 && ((lvl >= 1 && t256 <= cus) || multi_ok)) || g_nt_force == 3)) {
             c.kernel = NTK_8PHASE; c.bm = 256; c.tiles = t256; c.workgroups = t256 < cus ? t256 : cus;
             c.group_m = ntp_group_m(p.M, p.N, p.K, epi, 256, t256, cus);
