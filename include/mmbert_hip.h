@@ -76,8 +76,9 @@ void mmbert_gemm_tn_force_splits(int splits);
  *   W[N,K] (fp32, contiguous: ldw == K) = (accumulate ? W : 0) + alpha * alpha_dev[0] * A[M,N]^T . B[M,K]
  *   bias_out[N] (optional)             += alpha * alpha_dev[0] * column sums of A      (the bias gradient)
  * The token axis may be split into fp32 slabs (deterministic reduce): `slab` must hold *_workspace() bytes.
- * The grouped form runs up to 8 problems that share M in ONE launch (the four dense layers of one or two
- * encoder layers); host arrays of length nprob. */
+ * The grouped form runs up to 48 problems that share M in ONE call (the four dense layers of one, two or -- round 4, when nothing needs a
+ * layer's weight gradients before the optimizer -- up to twelve encoder layers); host arrays of length nprob.  A call of more tiles than
+ * CUs never splits the token axis and goes out as whole rounds of CUs-many tiles, one launch per round. */
 size_t mmbert_gemm_tn_workspace(int M, int N, int K, int* splits_out);
 int mmbert_gemm_tn(mmbert_stream_t stream, const void* A, int lda, const void* B, int ldb, float* W, int ldw,
                    int M, int N, int K, int accumulate, float alpha, const float* alpha_dev, void* slab, float* bias_out);

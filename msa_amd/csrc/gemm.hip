@@ -1492,14 +1492,18 @@ static int dispatch_nt(hipStream_t s, const GemmNT& p) {
 // -------------------------------------------------------------------------------------------------
 struct TNProb { const bf16_t* A; const bf16_t* B; float* W; float* bias; int N, K, lda, ldb, tiles_k, tile0; long long slab_off; };
 // up to TN_MAXP problems per launch: the four dense layers of an encoder layer -- or of TWO layers (model._EncoderFn pairs them: 216
-// tiles fill the chip in one round without splitting the token axis, so no fp32 slabs and no reduce launch)
-#define TN_MAXP 8
+// tiles fill the chip in one round without splitting the token axis, so no fp32 slabs and no reduce launch) -- or, round 4, of up to
+// TWELVE layers at once: without a gradient hook (one GPU) nothing needs a layer's weight gradients before the optimizer, so the model
+// defers them all to ONE call at the end of backward, which goes out as whole rounds of CUs-many tiles (11 layers = 1188 tiles = 4 full
+// launches + one of 164, against 5 paired launches at 216 of 256 CUs plus a split single layer).  48 x 64 B = 3 KiB of kernel arguments.
+#define TN_MAXP 48
 struct GemmTNG {
     TNProb pr[TN_MAXP];
     float* slab; const float* alpha_dev;
     long long slab_stride;
     int nprob, total_tiles, M, splits, rows_per_split, accumulate;
     float alpha;
+    int tile_base;
 };
 
 __device__ __forceinline__ int tn_swz(int row) { return ((row & 3) | ((row >> 1) & 4)) << 1; }
@@ -1519,17 +1523,25 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_kernel(const GemmTNG g) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wk = wave >> 1, wn = wave & 1;                       // 8 waves as 4(k) x 2(n): a wave owns 64(k) x 128(n)
-    int t = xcd_remap(blockIdx.x, g.total_tiles);
+  {
+    // (round 4) a launch covers the tiles [tile_base, tile_base + gridDim.x) of the problem list: the deferred multi-layer form goes out
+    // as whole ROUNDS of CUs-many tiles, one launch per round (a tile loop inside the kernel cost 18-89 spilled VGPRs: the accumulators
+    // and the epilogue's accumulate operands leave no room for anything carried across tiles)
+    int t = g.tile_base + xcd_remap(blockIdx.x, gridDim.x);
+    const int ln = lane;
+    // the problem table is read from the kernel-argument segment through a (wave-uniform) computed index: scalar loads, no select
+    // chain over up to 48 entries and no private copy of the 3-KiB struct
+    const __attribute__((address_space(4))) GemmTNG& gq = *(const __attribute__((address_space(4))) GemmTNG*)__builtin_amdgcn_kernarg_segment_ptr();
     int pi = 0;
-#pragma unroll
-    for (int q = 1; q < TN_MAXP; ++q) if (q < g.nprob && t >= g.pr[q].tile0) pi = q;
-    const bf16_t* Ap = g.pr[0].A; const bf16_t* Bp = g.pr[0].B; float* Wp = g.pr[0].W; float* biasp = g.pr[0].bias;
-    int N = g.pr[0].N, K = g.pr[0].K, lda = g.pr[0].lda, ldb = g.pr[0].ldb, tiles_k = g.pr[0].tiles_k, tile0 = g.pr[0].tile0;
-    long long slab_off = g.pr[0].slab_off;
-#pragma unroll
-    for (int q = 1; q < TN_MAXP; ++q)
-        if (pi == q) { Ap = g.pr[q].A; Bp = g.pr[q].B; Wp = g.pr[q].W; biasp = g.pr[q].bias; N = g.pr[q].N; K = g.pr[q].K; lda = g.pr[q].lda;
-                       ldb = g.pr[q].ldb; tiles_k = g.pr[q].tiles_k; tile0 = g.pr[q].tile0; slab_off = g.pr[q].slab_off; }
+    {
+        int lo = 0, hi = g.nprob - 1;                              // tile0 ascending: the last problem that starts at or before t
+        while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (gq.pr[mid].tile0 <= t) lo = mid; else hi = mid - 1; }
+        pi = lo;
+    }
+    const __attribute__((address_space(4))) TNProb& pr = gq.pr[pi];
+    const bf16_t* Ap = pr.A; const bf16_t* Bp = pr.B; float* Wp = pr.W; float* biasp = pr.bias;
+    const int N = pr.N, K = pr.K, lda = pr.lda, ldb = pr.ldb, tiles_k = pr.tiles_k, tile0 = pr.tile0;
+    const long long slab_off = pr.slab_off;
     t -= tile0;
     const int n0 = (t / tiles_k) << 8, k0 = (t % tiles_k) << 8;
     const int split = blockIdx.y;
@@ -1538,16 +1550,16 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_kernel(const GemmTNG g) {
     const int ns = (mend - mbeg + 31) >> 5;                        // may be <= 0 for a trailing empty split
     const bool do_bias = (biasp != nullptr) && (k0 == 0) && (wk == 0);
 
-    // ---- staging (LDS-DMA, lane-linear destination, swizzle on the source chunk) ----
+    // ---- staging (LDS-DMA, ln-linear destination, swizzle on the source chunk) ----
     // A and B stage tiles: 32 rows x 512 B = 16 wave-instructions each (2 rows per instruction); wave w issues 2w, 2w+1
     int s_row[2], a_col[2], b_col[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-        s_row[i] = (wave * 2 + i) * 2 + (lane >> 5);
-        a_col[i] = min(n0 + (((lane & 31) ^ tn_swz(s_row[i])) << 3), N - 8);
-        b_col[i] = min(k0 + (((lane & 31) ^ tn_swz(s_row[i])) << 3), K - 8);
+        s_row[i] = (wave * 2 + i) * 2 + (ln >> 5);
+        a_col[i] = min(n0 + (((ln & 31) ^ tn_swz(s_row[i])) << 3), N - 8);
+        b_col[i] = min(k0 + (((ln & 31) ^ tn_swz(s_row[i])) << 3), K - 8);
     }
-    // buffer addressing (descriptor + constant per-lane offset + scalar row-block offset): no per-stage 64-bit VALU address
+    // buffer addressing (descriptor + constant per-ln offset + scalar row-block offset): no per-stage 64-bit VALU address
     // arithmetic; token rows past M read as zeros through the range check
     const auto rsA = __builtin_amdgcn_make_buffer_rsrc((void*)Ap, 0, (int)((uint32_t)g.M * (uint32_t)lda * 2u), 0x00020000);
     const auto rsB = __builtin_amdgcn_make_buffer_rsrc((void*)Bp, 0, (int)((uint32_t)g.M * (uint32_t)ldb * 2u), 0x00020000);
@@ -1577,8 +1589,8 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_kernel(const GemmTNG g) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) accb[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    // ---- transposed-read addresses: lane (g4 = lane>>4, q = (lane>>2)&3, pp = lane&3) supplies row 8*g4+q (+4), 4 columns at 4*pp ----
-    const int g4 = lane >> 4, r0 = 8 * g4 + ((lane >> 2) & 3), pp = lane & 3;
+    // ---- transposed-read addresses: ln (g4 = ln>>4, q = (ln>>2)&3, pp = ln&3) supplies row 8*g4+q (+4), 4 columns at 4*pp ----
+    const int g4 = ln >> 4, r0 = 8 * g4 + ((ln >> 2) & 3), pp = ln & 3;
     const unsigned lds0 = (unsigned)(uintptr_t)LPTR(smem);
     unsigned offA[8], offB[4];
 #pragma unroll
@@ -1684,14 +1696,14 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_kernel(const GemmTNG g) {
 #endif
 
     const float alpha = g.alpha * (g.alpha_dev ? *g.alpha_dev : 1.0f);
-    const int fr = lane & 15, fq = lane >> 4;
+    const int fr = ln & 15, fq = ln >> 4;
     // split 0 writes (or accumulates into) the weight gradient itself, splits 1.. write fp32 slabs that tn_reduce_kernel adds to it
     // afterwards: one slab write, one slab read and one launch-wide pass less than "all splits to slabs" (order stays fixed)
     float* out = split > 0 ? g.slab + (size_t)(split - 1) * g.slab_stride + slab_off : Wp;
     const bool accum = (split == 0) && g.accumulate;
     // (accumulating form: the eight reads of a k block are issued TOGETHER, clamped in range, then added and stored -- as first written
     // every float4 was read, waited for with vmcnt(0) -- which also waits for the previous store --, added and stored: 32 dependent
-    // round trips per lane at the end of every tile; same-process A/B of the step: -0.15 %)
+    // round trips per ln at the end of every tile; same-process A/B of the step: -0.15 %)
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int k = k0 + wk * 64 + i * 16 + fq * 4;
@@ -1732,6 +1744,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_kernel(const GemmTNG g) {
         o[0] = ts1 - ts0; o[1] = (unsigned long long)ns; o[2] = te - ts1; o[3] = 1; o[4] = tr0; o[5] = tr1;
     }
 #endif
+  }
 }
 
 // W[i] += sum_{s >= 1} slab[s - 1][i] over the concatenated outputs of all problems of a launch (split 0 went to W directly)
@@ -1740,12 +1753,10 @@ __global__ void tn_reduce_kernel(const TNReduce r, const float* __restrict__ sla
     const long long total4 = r.off[r.nprob] >> 2;
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total4; i += (long long)gridDim.x * blockDim.x) {
         const long long e = i << 2;
-        int pi = 0;
-#pragma unroll
-        for (int q = 1; q < TN_MAXP; ++q) if (q < r.nprob && e >= r.off[q]) pi = q;
-        float* W = r.W[0]; long long o = r.off[0];
-#pragma unroll
-        for (int q = 1; q < TN_MAXP; ++q) if (pi == q) { W = r.W[q]; o = r.off[q]; }
+        int lo = 0, hi = r.nprob - 1;                      // off ascending: the last problem that starts at or before e (per lane)
+        while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (r.off[mid] <= e) lo = mid; else hi = mid - 1; }
+        float* W = r.W[lo];
+        const long long o = r.off[lo];
         float4* dst = (float4*)(W + (e - o));
         float4 v = *dst;                                   // split 0 of the GEMM has stored its part here
         for (int s = 0; s + 1 < r.splits; ++s) {
@@ -1935,6 +1946,7 @@ static int tn_plan(int nprob, const int* N, const int* K, int M, int* splits_out
         if (cost[sp] <= 1.03 * best_cost) { best = sp; break; }
     int splits = best;
     if (g_tn_splits.load() > 0) splits = g_tn_splits.load();
+    if (tiles >= slots) splits = 1;                                // (enough tiles to fill the chip: the persistent walk, no slabs)
     if (splits > max_splits) splits = max_splits;
     if (splits < 1) splits = 1;
     *splits_out = splits; *tiles_out = tiles;
@@ -1985,7 +1997,18 @@ int mmbert_gemm_tn_grouped(hipStream_t stream, int nprob, const void* const* A, 
     g.splits = splits; g.rows_per_split = (((M + splits - 1) / splits) + 31) / 32 * 32; g.accumulate = accumulate; g.alpha = alpha;
     static std::atomic<unsigned long long> attr_done{0};
     if (int e = mmb_allow_lds((const void*)gemm_tn_kernel, 131072, attr_done)) return e;
-    hipLaunchKernelGGL(gemm_tn_kernel, dim3(tiles, splits), dim3(512), 131072, stream, g);
+    // more tiles than CUs (only the deferred multi-layer launches; never split): whole rounds of CUs-many tiles, one launch per round
+    const int cus_ = device_cus();
+    if (splits == 1 && tiles > cus_) {
+        for (int base = 0; base < tiles; base += cus_) {
+            g.tile_base = base;
+            hipLaunchKernelGGL(gemm_tn_kernel, dim3(tiles - base < cus_ ? tiles - base : cus_, 1), dim3(512), 131072, stream, g);
+            MMB_CHECK_LAUNCH();
+        }
+    } else {
+        g.tile_base = 0;
+        hipLaunchKernelGGL(gemm_tn_kernel, dim3(tiles, splits), dim3(512), 131072, stream, g);
+    }
     MMB_CHECK_LAUNCH();
     if (splits > 1) {
         r.nprob = nprob; r.splits = splits; r.accumulate = accumulate; r.slab_stride = off;

@@ -274,6 +274,8 @@ class _EncoderFn:
         # A/B against round 1's form (bias sums inside LayerNorm', one reduce launch per call): 16.58 vs 16.76 ms per step
         lnd = ops.LnDeferred(2 * L)
         pair_wgrads, held = getattr(top, "pair_wgrads", True), None
+        # (model.defer_wgrads, opt-in: measured +-0 in the step, see the comment at its use)
+        defer_wgrads, deferred = (top.grad_hook is None and getattr(top, "defer_wgrads", False)), []
         for i in reversed(range(L)):
             lw = top._lw[i]
             saved_i = saved[i]
@@ -322,6 +324,17 @@ class _EncoderFn:
             probs = [(du, y1, lw["g_W1"], lw["g_b1"]), (dz2d, g, lw["g_W2"], lw["g_b2"]),
                      (dqkv, x, lw["g_Wqkv"], lw["g_bqkv"]), (dz1d, actx, lw["g_Wo"], lw["g_bo"])]
             side = top._wgrad_stream()
+            if side is None and defer_wgrads:
+                # One GPU (no gradient hook): nothing needs this layer's weight gradients before the optimizer, so ALL dense layers'
+                # weight gradients can go out as ONE call at the end of backward, in whole rounds of 256 tiles (11 layers = 1188
+                # tiles = 4.64 rounds; the paired launches below fill 216 of 256 CUs each and layer 0, alone, splits the token axis
+                # into slabs + a reduce).  The operands just stay alive until then (~190 MB per layer).  Round 4, same-process A/B of
+                # the train step: 14.010 ms against 13.989 for the paired form (profiles/r4_ab_deferred_wgrads.log) -- filling the 40
+                # idle CUs buys nothing: with 256 instead of 216 CUs multiplying, every tile takes proportionally longer (the chip
+                # holds its clock down under this load: DESIGN 3.1), as the balanced-atomics and side-stream forms had hinted.  Opt-in.
+                deferred.extend(probs)
+                top._layer_grads_done(i)
+                continue
             if side is None and pair_wgrads:
                 # Two layers per launch: a layer's 108 tiles leave the chip half empty, so a single layer splits the token axis in two
                 # (fp32 slabs + a reduce launch, 12 us and 85 MB per layer); two layers' 216 tiles fill it in one round unsplit.  The
@@ -352,6 +365,8 @@ class _EncoderFn:
                 lnd.flush()                                # ... and after its LayerNorm sums
             top._layer_grads_done(i)
         lnd.flush()
+        for c in range(0, len(deferred), 48):                 # (mmbert_gemm_tn_grouped: up to 48 problems = 12 layers per launch)
+            ops.gemm_tn_grouped(deferred[c:c + 48])
         side = top._wgrad_stream()
         if side is not None:
             torch.cuda.current_stream().wait_stream(side)     # optimizer / all-reduce tail see complete gradients

@@ -166,12 +166,12 @@ def gemm_tn(A, B, W, *, accumulate=True, alpha=1.0, alpha_dev=None, bias_out=Non
     return W
 
 
-_PtrArr = {n: (ctypes.c_void_p * n) for n in range(1, 17)}
-_IntArr = {n: (ctypes.c_int * n) for n in range(1, 17)}
+_PtrArr = {n: (ctypes.c_void_p * n) for n in range(1, 49)}
+_IntArr = {n: (ctypes.c_int * n) for n in range(1, 49)}
 
 
 def gemm_tn_grouped(problems, *, accumulate=True, alpha=1.0):
-    """problems: up to 8 tuples (A[M,N] bf16, B[M,K] bf16, W[N,K] fp32, bias[N] fp32 or None) sharing M:
+    """problems: up to 48 tuples (round 4: the deferred weight gradients of up to 12 layers; 8 before) (A[M,N] bf16, B[M,K] bf16, W[N,K] fp32, bias[N] fp32 or None) sharing M:
     one launch computes every W (+)= A^T @ B and bias += colsum(A)  (see mmbert_gemm_tn_grouped)."""
     lib = _lib.load()
     n = len(problems)

@@ -400,6 +400,34 @@ def test_gemm_tn_fused_bias_and_grouped(ops, shapes):
     assert_close(bias, 1.0 + 0.5 * A.float().sum(0), 2e-3, 2e-2, "single bias")
 
 
+def test_gemm_tn_grouped_many_layers_in_whole_rounds(ops):
+    """Round 4: up to 48 problems per call (the deferred weight gradients of up to 12 encoder layers: nothing needs them before the
+    optimizer on one GPU).  More tiles than CUs -> no token split, whole rounds of CUs-many tiles, one launch per round.  Five "layers"
+    of four problems each (540 tiles of 256 x 256 = 2.1 rounds) on small-integer operands: every weight gradient and every
+    ones-operand bias gradient EXACT in fp32, accumulated onto a non-zero start; the planner reports no slabs."""
+    import ctypes
+    from msa_amd import _lib
+    M = 1184
+    shapes = [(3072, 768), (768, 3072), (2304, 768), (768, 768)] * 5
+    n = len(shapes)
+    Ns, Ks = (ctypes.c_int * n)(*[a for a, _ in shapes]), (ctypes.c_int * n)(*[b for _, b in shapes])
+    sp = ctypes.c_int(-1)
+    assert _lib.load().mmbert_gemm_tn_grouped_workspace(n, Ns, Ks, M, ctypes.byref(sp)) == 0 and sp.value == 1
+    probs, refs = [], []
+    for i, (N, K) in enumerate(shapes):
+        A = ((torch.arange(M)[:, None] * (3 + i) + torch.arange(N)[None, :] * 5) % 3 - 1.0)          # {-1, 0, 1}
+        B = ((torch.arange(M)[:, None] * 2 + torch.arange(K)[None, :] * (7 + i)) % 2).float()        # {0, 1}: |sums| <= M, exact in fp32
+        W0 = torch.full((N, K), float(i + 1))
+        b0 = torch.full((N,), -2.0) if i % 2 == 0 else None
+        probs.append((bf(A).to(DEV), bf(B).to(DEV), W0.clone().to(DEV), b0.clone().to(DEV) if b0 is not None else None))
+        refs.append((W0 + A.t() @ B, (b0 + A.sum(0)) if b0 is not None else None))
+    ops.gemm_tn_grouped(probs)
+    for i, ((A, B, W, bias), (rw, rb)) in enumerate(zip(probs, refs)):
+        assert torch.equal(W.cpu(), rw), i
+        if bias is not None:
+            assert torch.equal(bias.cpu(), rb), i
+
+
 def test_gemm_tn_exact_integers(ops):
     M, N, K = 192, 128, 128
     A = ((torch.arange(M)[:, None] * 5 + torch.arange(N)[None, :] * 3) % 7 - 3.0)

@@ -637,6 +637,35 @@ def test_train_mode_step_matches_oracle_with_replayed_masks(case, shortcuts):
     print("train-mode worst gradient cosine", worst)
 
 
+def test_deferred_weight_gradients_equal_the_per_layer_launches():
+    """Round 4: without a gradient hook (one GPU) every dense layer's weight gradients go out in ONE call at the end of backward
+    (model.defer_wgrads, whole rounds of tiles) instead of per layer pair: the same products on the same operands -- every parameter
+    gradient equal to the paired form's up to the fp32 accumulation order of the token split that the deferred form no longer has
+    (layer 0 alone splits the token axis in the paired form).  Train mode (dropout on), five layers."""
+    cfg = dict(hidden=256, layers=5, heads=4, intermediate=1024, vocab=4096, dataset="mosei", alpha=1.0, beta=1.0)
+    batch = batch_to(synthetic_batch(4, 24, 200, 130, dataset="mosei", vocab=cfg["vocab"], seed=52), DEV)
+    from msa_amd import ops as _ops
+    grads, calls = {}, {}
+    for defer in (True, False):
+        m = build(cfg, train=True)
+        m.manual_seed(12)
+        m.defer_wgrads = defer
+        seen, orig = [], _ops.gemm_tn_grouped
+        _ops.gemm_tn_grouped = lambda probs, *a, _o=orig, _c=seen, **k: (_c.append(len(probs)), _o(probs, *a, **k))[1]
+        try:
+            out, _ = m(**batch)
+            out[0].mean().backward()
+            torch.cuda.synchronize()
+        finally:
+            _ops.gemm_tn_grouped = orig
+        grads[defer], calls[defer] = {n: q.grad.float().clone() for n, q in m.named_parameters()}, seen
+    assert 16 in calls[True] and 8 in calls[False] and 16 not in calls[False], calls       # 4 dense layers behind the sparse top layer: one call of 16
+    for n in grads[True]:
+        if "attention.self.key.bias" in n:
+            continue
+        same_grads(grads[True][n], grads[False][n], n)
+
+
 def test_sparse_mlm_backward_equals_dense_backward():
     """The MLM head's backward over the labelled rows only (default) against the dense backward over all rows: the
     CE gradient of an unlabelled row is exactly zero, so every parameter gradient must agree up to fp32 summation order."""
