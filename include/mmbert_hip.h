@@ -9,8 +9,8 @@
  *   - allocates no device memory, synchronises nothing and keeps no per-call state (graph-capturable): every workspace,
  *     the tile queue of the persistent GEMM included, is passed in by the caller.  Process-global and documented as such:
  *     the one-time per-device opt-in of kernels to > 64 KiB of LDS (hipFuncSetAttribute on first use -- warm each kernel up once
- *     before capturing a graph), a cached CU count per device, and the two test / A-B knobs mmbert_gemm_nt_force and
- *     mmbert_gemm_tn_force_splits (atomics, default 0 = choose by shape; every choice computes the same product), and the
+ *     before capturing a graph), a cached CU count per device, and the test / A-B knobs mmbert_gemm_nt_force,
+ *     mmbert_gemm_tn_force_splits and mmbert_gemm_tn_force_form (atomics, default 0 = choose by shape; every choice computes the same product), and the
  *     measurement switches read from the environment once per process -- schedule choices only, the results do not depend
  *     on them: MMBERT_NT_GROUP_M, MMBERT_NT_GM_TABLE, MMBERT_NT_QUEUE_GLOBAL, MMBERT_NT_TALL (tile walk / queue / tile height of the persistent GEMM),
  *     MMBERT_LN_ROWS, MMBERT_LN_BWD_ROWS, MMBERT_LN_BWD_BLOCKS, MMBERT_LN_NV4 (LayerNorm rows per wave / grid / register sizing),
@@ -71,6 +71,10 @@ void mmbert_gemm_nt_force(int mode);
 int mmbert_gemm_nt_describe(int M, int N, int K, int epi, int with_queue, int* out);
 /* Split count of the token axis in mmbert_gemm_tn / _grouped: 0 = by shape (default), > 0 forced.  A/B benchmarking. */
 void mmbert_gemm_tn_force_splits(int splits);
+/* K loop of mmbert_gemm_tn / _grouped: 0 = the 4-slot ring of 32-token stages (default), 1 = the 8-phase form (64-token K tiles).  The
+ * weight gradients are bit-identical (same 32-token summation blocks), the bias gradients agree up to fp32 summation order.  Tests and
+ * A/B benchmarking (the environment variable MMBERT_TN_8PHASE, read per call, overrides it). */
+void mmbert_gemm_tn_force_form(int form);
 
 /* Weight gradients autograd computes for nn.Linear (REF:trainer.py:83):
  *   W[N,K] (fp32, contiguous: ldw == K) = (accumulate ? W : 0) + alpha * alpha_dev[0] * A[M,N]^T . B[M,K]

@@ -21,6 +21,7 @@ SIGNATURES = {
     "mmbert_gemm_nt_splitk": (I, [P, P, I, P, I, P, I, I, I, I, P, P, I]),
     "mmbert_gemm_nt_splitk_workspace": (SZ, [I, I, I]),
     "mmbert_gemm_tn_force_splits": (None, [I]),
+    "mmbert_gemm_tn_force_form": (None, [I]),
     "mmbert_gemm_tn_workspace": (SZ, [I, I, I, P]),
     "mmbert_gemm_tn": (I, [P, P, I, P, I, P, I, I, I, I, I, F, P, P, P]),
     "mmbert_gemm_tn_grouped_workspace": (SZ, [I, P, P, I, P]),

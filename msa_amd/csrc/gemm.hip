@@ -1747,6 +1747,281 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_kernel(const GemmTNG g) {
   }
 }
 
+// -------------------------------------------------------------------------------------------------
+// TN in the 8-phase structure (round 4, second half): the weight gradients are the deepest products of the step (the reduction runs
+// over ~14 000 tokens = 216 K tiles of 64) and the ring kernel above spends 1 473 clk per 32-token stage where its MFMAs need 1 024.
+// Same tile (256 x 256, 8 waves, one workgroup per CU, same problem table / splits / slabs / accumulate semantics, same 32-token
+// summation blocks: the weight gradients are BIT-IDENTICAL to gemm_tn_kernel's), the K loop of gemm_nt8_kernel:
+//   * K tile = 64 tokens; half-tiles of [64 tokens][128 columns] (256-byte rows: an LDS-DMA wave instruction moves 4 token rows x
+//     two whole cache lines) are the unit of staging, waiting and re-use; order of first use Y0h, X0h, Y1h, X1h;
+//   * waves 2 (wr) x 4 (wc): a wave owns k columns {ha*128 + wr*64 ..+63} (X, 4 blocks of 16 per half) x n columns
+//     {hb*128 + wc*32 ..+31} (dY, 2 blocks per half) -- the halves are CONTIGUOUS 128-column panels, the wave interleave sits inside;
+//   * phases: (X0h,Y0h) (X0h,Y1h) (X1h,Y1h) (X1h,Y0h), 16 MFMAs each; two wave groups one barrier apart; the stream runs three
+//     half-tiles ahead behind one counted vmcnt(6) per K tile;
+//   * fragments by ds_read_b64_tr_b16 (48 per K tile and wave), conflict-free with the chunk XOR of the ring kernel (tn_swz) on
+//     256-byte rows: the 8 token rows a 32-lane half touches fall on 8 distinct 32-byte bank groups;
+//   * bias gradients on the VALU instead of an all-ones MFMA: a bias tile (k0 == 0) sums the dY fragments it reads anyway, wave
+//     (wr, wc) the k-step ks = wr of its own 32 columns: 20 VALU operations per phase beside 16 MFMAs; lanes, then the two wr waves
+//     (through LDS) are added in a fixed order: one atomic per column, reproducible.
+// Token rows past the split's end read as zeros through the buffer range check (num_records = mend rows), so ragged ends need no
+// masking in registers.
+// -------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(512, 2) void gemm_tn8_kernel(const GemmTNG g) {
+#if __HIP_DEVICE_COMPILE__
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // buffer d at d * 65536: X0h | X1h | Y0h | Y1h, 16 KiB each
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+    int t_lin = g.tile_base + xcd_remap(blockIdx.x, gridDim.x);
+    const __attribute__((address_space(4))) GemmTNG& gq = *(const __attribute__((address_space(4))) GemmTNG*)__builtin_amdgcn_kernarg_segment_ptr();
+    int pi = 0;
+    {
+        int lo = 0, hi = g.nprob - 1;                              // tile0 ascending: the last problem that starts at or before t
+        while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (gq.pr[mid].tile0 <= t_lin) lo = mid; else hi = mid - 1; }
+        pi = lo;
+    }
+    const __attribute__((address_space(4))) TNProb& pr = gq.pr[pi];
+    const bf16_t* Ap = pr.A; const bf16_t* Bp = pr.B; float* Wp = pr.W; float* biasp = pr.bias;
+    const int N = pr.N, K = pr.K, lda = pr.lda, ldb = pr.ldb, tiles_k = pr.tiles_k;
+    const long long slab_off = pr.slab_off;
+    t_lin -= pr.tile0;
+    const int n0 = (t_lin / tiles_k) << 8, k0 = (t_lin % tiles_k) << 8;
+    const int split = blockIdx.y;
+    const int mbeg = split * g.rows_per_split;
+    const int mend = min(g.M, mbeg + g.rows_per_split);
+    const int nt = (mend - mbeg + 63) >> 6;                        // K tiles of 64 tokens; <= 0 for a trailing empty split
+    const bool do_bias = (biasp != nullptr) && (k0 == 0);
+
+    // ---- staging: piece j (token rows 4j .. 4j+3 of the half-tile, 1 KiB) by wave j & 7; lane -> (row lane >> 4, chunk lane & 15) ----
+    const auto rsY = __builtin_amdgcn_make_buffer_rsrc((void*)Ap, 0, (int)((uint32_t)max(mend, 0) * (uint32_t)lda * 2u), 0x00020000);
+    const auto rsX = __builtin_amdgcn_make_buffer_rsrc((void*)Bp, 0, (int)((uint32_t)max(mend, 0) * (uint32_t)ldb * 2u), 0x00020000);
+    uint32_t y_off[2], x_off[2];
+    {
+        const int row4 = lane >> 4, pos = lane & 15;
+        const int key = (row4 | (((wave >> 1) & 1) << 2)) << 1;    // tn_swz(4 j + row4), the same for both pieces of a wave (j = wave, wave + 8)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int cy = min(n0 + h * 128 + ((pos ^ key) << 3), N - 8);
+            const int cx = min(k0 + h * 128 + ((pos ^ key) << 3), K - 8);
+            y_off[h] = ((uint32_t)row4 * (uint32_t)lda + (uint32_t)cy) * 2u;
+            x_off[h] = ((uint32_t)row4 * (uint32_t)ldb + (uint32_t)cx) * 2u;
+        }
+    }
+    // half-tile ids in the order of first use: 0 = Y0h, 1 = X0h, 2 = Y1h, 3 = X1h
+    auto stage = [&](int buf, int which, int kt) {
+        const int h = which >> 1;
+        const uint32_t row = (uint32_t)(mbeg + kt * 64 + 4 * wave);
+        char* base = smem + buf * 65536 + ((which & 1) ? 0 : 32768) + h * 16384 + wave * 1024;
+        if (which & 1) {
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, LPTR(base), 16, x_off[h], row * (uint32_t)ldb * 2u, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, LPTR(base + 8192), 16, x_off[h], (row + 32u) * (uint32_t)ldb * 2u, 0, 0);
+        } else {
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsY, LPTR(base), 16, y_off[h], row * (uint32_t)lda * 2u, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsY, LPTR(base + 8192), 16, y_off[h], (row + 32u) * (uint32_t)lda * 2u, 0, 0);
+        }
+    };
+
+    // ---- transposed-read addresses: lane (g4 = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3) supplies token row 8 g4 + q (+ 4), 4 columns at 4 pp ----
+    const int g4 = lane >> 4, r0 = 8 * g4 + ((lane >> 2) & 3), pp = lane & 3;
+    const int keyr = tn_swz(r0);
+    const unsigned lds0 = (unsigned)(uintptr_t)LPTR(smem);
+    unsigned adX[2][4], adY[2][2];                                 // [buffer][16-column block]; ds offsets (half, k step, + 4 rows) are immediates
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int chunk = wr * 8 + 2 * i + (pp >> 1);
+        adX[0][i] = lds0 + r0 * 256 + ((chunk ^ keyr) << 4) + ((pp & 1) << 3);
+        adX[1][i] = adX[0][i] + 65536;
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int chunk = wc * 4 + 2 * j + (pp >> 1);
+        adY[0][j] = lds0 + 32768 + r0 * 256 + ((chunk ^ keyr) << 4) + ((pp & 1) << 3);
+        adY[1][j] = adY[0][j] + 65536;
+    }
+
+    u32x2 xlo[2][4], xhi[2][4], y0lo[2][2], y0hi[2][2], y1lo[2][2], y1hi[2][2];
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float bsum[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
+
+    auto read_x_ks = [&](auto buf_c, auto h_c, auto ks_c) {
+        constexpr int D = decltype(buf_c)::value, OFF = decltype(h_c)::value * 16384 + decltype(ks_c)::value * 8192, KS = decltype(ks_c)::value;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { tr_read<OFF>(xlo[KS][i], adX[D][i]); tr_read<OFF + 1024>(xhi[KS][i], adX[D][i]); }
+    };
+    auto read_y = [&](auto buf_c, auto h_c, u32x2 (&lo)[2][2], u32x2 (&hi)[2][2]) {
+        constexpr int D = decltype(buf_c)::value, OFF = decltype(h_c)::value * 16384;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                if (ks == 0) { tr_read<OFF>(lo[0][j], adY[D][j]); tr_read<OFF + 1024>(hi[0][j], adY[D][j]); }
+                else         { tr_read<OFF + 8192>(lo[1][j], adY[D][j]); tr_read<OFF + 8192 + 1024>(hi[1][j], adY[D][j]); }
+            }
+    };
+    auto mma = [&](int qa, int qb, const u32x2 (&ylo)[2][2], const u32x2 (&yhi)[2][2]) {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 yf[2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) { const u32x4 v = {ylo[ks][j][0], ylo[ks][j][1], yhi[ks][j][0], yhi[ks][j][1]}; yf[j] = __builtin_bit_cast(bf16x8, v); }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const u32x4 v = {xlo[ks][i][0], xlo[ks][i][1], xhi[ks][i][0], xhi[ks][i][1]};
+                const bf16x8 xf = __builtin_bit_cast(bf16x8, v);
+#pragma unroll
+                for (int j = 0; j < 2; ++j)     // D[row <-> k_out (X^T as the first operand)][col <-> n_out (dY as the second)]
+                    acc[qa * 4 + i][qb * 2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf, yf[j], acc[qa * 4 + i][qb * 2 + j], 0, 0, 0);
+            }
+        }
+    };
+    // bias tiles: this wave's k step (ks = wr) of the dY half just read, summed per lane (8 tokens of one column) in a fixed order
+    auto bias_add = [&](int hb, const u32x2 (&ylo)[2][2], const u32x2 (&yhi)[2][2]) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const uint32_t w0 = wr ? ylo[1][j][0] : ylo[0][j][0], w1 = wr ? ylo[1][j][1] : ylo[0][j][1];
+            const uint32_t w2 = wr ? yhi[1][j][0] : yhi[0][j][0], w3 = wr ? yhi[1][j][1] : yhi[0][j][1];
+            float s = bsum[hb][j];
+            s += __builtin_bit_cast(float, w0 << 16); s += __builtin_bit_cast(float, w0 & 0xFFFF0000u);
+            s += __builtin_bit_cast(float, w1 << 16); s += __builtin_bit_cast(float, w1 & 0xFFFF0000u);
+            s += __builtin_bit_cast(float, w2 << 16); s += __builtin_bit_cast(float, w2 & 0xFFFF0000u);
+            s += __builtin_bit_cast(float, w3 << 16); s += __builtin_bit_cast(float, w3 & 0xFFFF0000u);
+            bsum[hb][j] = s;
+        }
+    };
+
+#ifdef MMB_STAMPS
+    unsigned long long ts0 = 0, ts1 = 0, tr0 = 0, tr1 = 0;
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tr0) :: "memory");
+    MMB_STAMP(ts0)
+#endif
+    typedef std::integral_constant<int, 0> I0; typedef std::integral_constant<int, 1> I1;
+    // one phase: { transposed reads of this phase's quadrant operands ; one half-tile of LDS-DMA ; [counted vmcnt] ; barrier ; lgkmcnt(0) ;
+    //              MFMAs (+ the bias sums) ; barrier } -- RAW / WAR argument as in gemm_nt8_kernel (the half-tile stream and the phase in
+    // which a half-tile is read are the same); the Y0h reads are retired (lgkmcnt(8): only the second k step of X0h behind them) before
+    // phase 1's first barrier, because Y0h is restaged in phase 2.
+#define TN8_PHASE(READS, STAGE, VMWAIT, QA, QB, YLO, YHI, BIAS_HB)                                                    \
+    {                                                                                                                \
+        READS;                                                                                                       \
+        STAGE;                                                                                                       \
+        if (VMWAIT >= 0) __builtin_amdgcn_s_waitcnt(mmb_waitcnt(VMWAIT < 0 ? 0 : VMWAIT, 15));                        \
+        __builtin_amdgcn_s_barrier();                                                                                \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                           \
+        __builtin_amdgcn_sched_barrier(0);                                                                           \
+        __builtin_amdgcn_s_setprio(1);                                                                               \
+        mma(QA, QB, YLO, YHI);                                                                                       \
+        if (BIAS_HB >= 0) { if (do_bias) bias_add(BIAS_HB < 0 ? 0 : BIAS_HB, YLO, YHI); }                             \
+        __builtin_amdgcn_s_setprio(0);                                                                               \
+        __builtin_amdgcn_s_barrier();                                                                                \
+        __builtin_amdgcn_sched_barrier(0);                                                                           \
+    }
+#define TN8_KTILE(DC, D, T)                                                                                                          \
+    TN8_PHASE((read_y(DC{}, I0{}, y0lo, y0hi), read_x_ks(DC{}, I0{}, I0{}), ({ asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory"); }), \
+               read_x_ks(DC{}, I0{}, I1{})), stage(D ^ 1, 3, (T) + 1), -1, 0, 0, y0lo, y0hi, 0)                                       \
+    TN8_PHASE(read_y(DC{}, I1{}, y1lo, y1hi), stage(D, 0, (T) + 2), -1, 0, 1, y1lo, y1hi, 1)                                          \
+    TN8_PHASE((read_x_ks(DC{}, I1{}, I0{}), read_x_ks(DC{}, I1{}, I1{})), stage(D, 1, (T) + 2), -1, 1, 1, y1lo, y1hi, -1)             \
+    TN8_PHASE((void)0, stage(D, 2, (T) + 2), 6, 1, 0, y0lo, y0hi, -1)
+
+    if (nt > 0) {
+        stage(0, 0, 0); stage(0, 1, 0); stage(0, 2, 0); stage(0, 3, 0);
+        stage(1, 0, 1); stage(1, 1, 1); stage(1, 2, 1);
+        __builtin_amdgcn_s_waitcnt(mmb_waitcnt(6, 15));            // K tile 0 landed (this wave's pieces)
+        __builtin_amdgcn_s_barrier();
+        if (wr == 1) __builtin_amdgcn_s_barrier();                 // the stagger: group 1 runs one barrier behind group 0
+        int t = 0;
+        while (true) {
+            TN8_KTILE(I0, 0, t) if (++t >= nt) break;
+            TN8_KTILE(I1, 1, t) if (++t >= nt) break;
+        }
+        if (wr == 0) __builtin_amdgcn_s_barrier();                 // balances the stagger
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // the dead tail half-tiles (token rows past the end: zeros, no traffic)
+    }
+#undef TN8_KTILE
+#undef TN8_PHASE
+#ifdef MMB_STAMPS
+    MMB_STAMP(ts1)
+#endif
+
+    // ---- epilogue: acc[ha*4 + i][hb*2 + j][r] = W[n0 + hb*128 + wc*32 + 16 j + fr][k0 + ha*128 + wr*64 + 16 i + 4 fq + r] ----
+    const float alpha = g.alpha * (g.alpha_dev ? *g.alpha_dev : 1.0f);
+    const int fr = lane & 15, fq = lane >> 4;
+    float* out = split > 0 ? g.slab + (size_t)(split - 1) * g.slab_stride + slab_off : Wp;
+    const bool accum = (split == 0) && g.accumulate;
+#pragma unroll
+    for (int ib = 0; ib < 8; ib += 2) {                            // two k blocks at a time: their eight accumulate reads are issued together
+        float4 old[2][4];
+        if (accum) {
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int kc = min(k0 + ((ib + u) >> 2) * 128 + wr * 64 + ((ib + u) & 3) * 16 + fq * 4, K - 4);
+#pragma unroll
+                for (int jb = 0; jb < 4; ++jb) {
+                    const int nc = min(n0 + (jb >> 1) * 128 + wc * 32 + (jb & 1) * 16 + fr, N - 1);
+                    old[u][jb] = *(const float4*)(out + (size_t)nc * K + kc);
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int k = k0 + ((ib + u) >> 2) * 128 + wr * 64 + ((ib + u) & 3) * 16 + fq * 4;
+            if (k >= K) continue;
+#pragma unroll
+            for (int jb = 0; jb < 4; ++jb) {
+                const int n = n0 + (jb >> 1) * 128 + wc * 32 + (jb & 1) * 16 + fr;
+                if (n >= N) continue;
+                const f32x4 a = acc[ib + u][jb];
+                float4 v = make_float4(a[0] * alpha, a[1] * alpha, a[2] * alpha, a[3] * alpha);
+                if (accum) { v.x += old[u][jb].x; v.y += old[u][jb].y; v.z += old[u][jb].z; v.w += old[u][jb].w; }
+                *(float4*)(out + (size_t)n * K + k) = v;
+            }
+        }
+    }
+    if (do_bias) {                                                 // workgroup-uniform
+        float* red = (float*)smem;                                 // [wc][hb][j][fr]: the wr = 1 waves' sums (the ring is dead: vmcnt(0) above + this barrier)
+        float v[2][2];
+#pragma unroll
+        for (int hb = 0; hb < 2; ++hb)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                float s = bsum[hb][j];
+                s += __shfl_xor(s, 16, 64);
+                s += __shfl_xor(s, 32, 64);
+                v[hb][j] = s;
+            }
+        __syncthreads();
+        if (wr == 1 && fq == 0) {
+#pragma unroll
+            for (int hb = 0; hb < 2; ++hb)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) red[((wc * 2 + hb) * 2 + j) * 16 + fr] = v[hb][j];
+        }
+        __syncthreads();
+        if (wr == 0 && fq == 0) {
+#pragma unroll
+            for (int hb = 0; hb < 2; ++hb)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int n = n0 + hb * 128 + wc * 32 + j * 16 + fr;
+                    if (n < N) atomicAdd(biasp + n, (v[hb][j] + red[((wc * 2 + hb) * 2 + j) * 16 + fr]) * alpha);
+                }
+        }
+    }
+#ifdef MMB_STAMPS
+    if (g_stamps && tid == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tr1) :: "memory");
+        unsigned long long te;
+        MMB_STAMP(te)
+        unsigned long long* o = g_stamps + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x)) * 6;
+        o[0] = ts1 - ts0; o[1] = (unsigned long long)(nt > 0 ? 2 * nt : 0); o[2] = te - ts1; o[3] = 1; o[4] = tr0; o[5] = tr1;
+    }
+#endif
+#endif
+}
+
 // W[i] += sum_{s >= 1} slab[s - 1][i] over the concatenated outputs of all problems of a launch (split 0 went to W directly)
 struct TNReduce { float* W[TN_MAXP]; long long off[TN_MAXP + 1]; int nprob, splits, accumulate; long long slab_stride; };
 __global__ void tn_reduce_kernel(const TNReduce r, const float* __restrict__ slab) {
@@ -1918,6 +2193,11 @@ void mmbert_gemm_nt_force(int mode) {
 
 static std::atomic<int> g_tn_splits{0};   // 0 = by shape; > 0 forces the split count of the token axis (A/B benchmarking)
 void mmbert_gemm_tn_force_splits(int splits) { g_tn_splits.store(splits); }
+// 0 = the 4-slot ring of 32-token stages (gemm_tn_kernel, default), 1 = the 8-phase K loop (gemm_tn8_kernel): 7.7 % fewer cycles per token,
+// -4.5 % stand-alone, +-0 (headline) ... +0.6 % (bert-large) in the train step -- the chip answers the denser MFMA stream with a lower clock
+// (profiles/r4_stamp_tn8.log, r4_ab_tn8.log): opt-in
+static std::atomic<int> g_tn_form{0};
+void mmbert_gemm_tn_force_form(int form) { g_tn_form.store(form != 0); }
 
 static int tn_plan(int nprob, const int* N, const int* K, int M, int* splits_out, int* tiles_out) {
     int tiles = 0;
@@ -1995,19 +2275,25 @@ int mmbert_gemm_tn_grouped(hipStream_t stream, int nprob, const void* const* A, 
     if (splits > 1 && !slab) return -3;
     g.slab = (float*)slab; g.alpha_dev = alpha_dev; g.slab_stride = off; g.nprob = nprob; g.total_tiles = tiles; g.M = M;
     g.splits = splits; g.rows_per_split = (((M + splits - 1) / splits) + 31) / 32 * 32; g.accumulate = accumulate; g.alpha = alpha;
-    static std::atomic<unsigned long long> attr_done{0};
+    static std::atomic<unsigned long long> attr_done{0}, attr_done8{0};
     if (int e = mmb_allow_lds((const void*)gemm_tn_kernel, 131072, attr_done)) return e;
+    if (int e = mmb_allow_lds((const void*)gemm_tn8_kernel, 131072, attr_done8)) return e;
+    // which K loop: the ring form unless the 8-phase form (gemm_tn8_kernel) is asked for (mmbert_gemm_tn_force_form / MMBERT_TN_8PHASE=1, A/B
+    // switch read per call); both give the same bits in the weight gradients
+    int form = g_tn_form.load();
+    if (const char* e8 = getenv("MMBERT_TN_8PHASE")) form = atoi(e8) != 0;
+    auto kern = form ? gemm_tn8_kernel : gemm_tn_kernel;
     // more tiles than CUs (only the deferred multi-layer launches; never split): whole rounds of CUs-many tiles, one launch per round
     const int cus_ = device_cus();
     if (splits == 1 && tiles > cus_) {
         for (int base = 0; base < tiles; base += cus_) {
             g.tile_base = base;
-            hipLaunchKernelGGL(gemm_tn_kernel, dim3(tiles - base < cus_ ? tiles - base : cus_, 1), dim3(512), 131072, stream, g);
+            hipLaunchKernelGGL(kern, dim3(tiles - base < cus_ ? tiles - base : cus_, 1), dim3(512), 131072, stream, g);
             MMB_CHECK_LAUNCH();
         }
     } else {
         g.tile_base = 0;
-        hipLaunchKernelGGL(gemm_tn_kernel, dim3(tiles, splits), dim3(512), 131072, stream, g);
+        hipLaunchKernelGGL(kern, dim3(tiles, splits), dim3(512), 131072, stream, g);
     }
     MMB_CHECK_LAUNCH();
     if (splits > 1) {

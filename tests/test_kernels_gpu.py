@@ -428,6 +428,42 @@ def test_gemm_tn_grouped_many_layers_in_whole_rounds(ops):
             assert torch.equal(bias.cpu(), rb), i
 
 
+@pytest.mark.parametrize("M,splits", [(1700, 0), (1700, 3), (70, 0), (4129, 2), (33, 0)])
+def test_gemm_tn_8phase_form_gives_the_ring_forms_bits(ops, M, splits):
+    """Round 4: the weight-gradient kernel's K loop in the 8-phase structure (gemm_tn8_kernel: 64-token K tiles, half-tile stream)
+    against the 4-slot ring of 32-token stages (gemm_tn_kernel).  Same 32-token summation blocks, same slabs: the weight gradients must be
+    BIT-identical -- ragged token counts (the range check zero-fills past the split's end), forced token splits, tiles that hang over N
+    and K, accumulate on and off; the bias gradients (VALU sums there, an all-ones MFMA here) agree to fp32 rounding."""
+    from msa_amd import _lib
+    lib = _lib.load()
+    shapes = [(3072, 768), (768, 3072), (2304, 768), (768, 768), (520, 136), (256, 1024)]
+    data = []
+    for i, (N, K) in enumerate(shapes):
+        data.append((bf(rnd(M, N, seed=170 + i, scale=0.1)).to(DEV), bf(rnd(M, K, seed=180 + i)).to(DEV), rnd(N, K, seed=190 + i), rnd(N, seed=195 + i)))
+    outs = {}
+    try:
+        lib.mmbert_gemm_tn_force_splits(splits)
+        for form in (0, 1):
+            lib.mmbert_gemm_tn_force_form(form)
+            for accumulate in (True, False):
+                probs = [(A, B, W0.clone().to(DEV), (b0.clone().to(DEV) if i % 3 != 2 else None)) for i, (A, B, W0, b0) in enumerate(data)]
+                ops.gemm_tn_grouped(probs, accumulate=accumulate, alpha=0.5)
+                torch.cuda.synchronize()
+                outs[(form, accumulate)] = [(p[2].cpu(), p[3].cpu() if p[3] is not None else None) for p in probs]
+    finally:
+        lib.mmbert_gemm_tn_force_form(0)
+        lib.mmbert_gemm_tn_force_splits(0)
+    for accumulate in (True, False):
+        for i, ((w0, b0), (w1, b1)) in enumerate(zip(outs[(0, accumulate)], outs[(1, accumulate)])):
+            assert torch.equal(w0, w1), (accumulate, i, float((w0 - w1).abs().max()))
+            if b0 is not None:
+                assert float((b0 - b1).abs().max()) <= 1e-5 * max(1.0, float(b0.abs().max())) * math.sqrt(M), (accumulate, i)
+        A, B, W0, b0 = data[4]
+        ref = (W0 if accumulate else 0) + 0.5 * (A.float().t() @ B.float()).cpu()
+        assert_close(outs[(1, accumulate)][4][0], ref, 2e-3, 2e-3 * math.sqrt(M), "8-phase W")
+        assert_close(outs[(1, accumulate)][4][1], b0 + 0.5 * A.float().sum(0).cpu(), 2e-3, 2e-2, "8-phase bias")
+
+
 def test_gemm_tn_exact_integers(ops):
     M, N, K = 192, 128, 128
     A = ((torch.arange(M)[:, None] * 5 + torch.arange(N)[None, :] * 3) % 7 - 3.0)
