@@ -966,7 +966,9 @@ __global__ __launch_bounds__(256) void ce_row_kernel(const void* __restrict__ lo
 // --------------------------------------------------------------------------------------------
 // Flat AdamW over the model's contiguous fp32 parameter / gradient / moment buffers.
 // flags[block of 256 elements]: 0 = no weight decay, 1 = weight decay, 2 = frozen (the
-// reference's never-differentiated parameters keep grad None and are skipped by the optimizer).
+// reference's never-differentiated parameters keep grad None and are skipped by the optimizer);
+// + 4 = "the next backward OVERWRITES this block's gradient" (flat.FlatParams lazy zero: the fused zero_grad
+// leaves the block alone -- torch's zero_grad(set_to_none=True) does not touch the old gradient either).
 // mode 0 = transformers-2.8 AdamW (decay after the update), 1 = torch.optim.AdamW.
 // Also writes the bf16 working copy and (optionally) zeroes the gradient: zero_grad fused.
 // --------------------------------------------------------------------------------------------
@@ -976,7 +978,8 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, float
                                                     float gscale, int mode, int zero_grad) {
     const size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
     if (i >= n) return;
-    const uint8_t f = flags[i >> 8];
+    const uint8_t fb = flags[i >> 8];
+    const uint8_t f = fb & 3;
     float4 P = *(float4*)(p + i);
     if (f != 2) {
         float4 G = *(float4*)(g + i), Mm = *(float4*)(m + i), Vv = *(float4*)(v + i);
@@ -1000,7 +1003,7 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, float
         *(float4*)(m + i) = make_float4(ma[0], ma[1], ma[2], ma[3]);
         *(float4*)(v + i) = make_float4(va[0], va[1], va[2], va[3]);
     }
-    if (zero_grad) *(float4*)(g + i) = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (zero_grad && !(fb & 4)) *(float4*)(g + i) = make_float4(0.f, 0.f, 0.f, 0.f);
     if (pb) { bf16x4 o = {f2bf(P.x), f2bf(P.y), f2bf(P.z), f2bf(P.w)}; *(bf16x4*)(pb + i) = o; }
 }
 

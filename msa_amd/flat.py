@@ -149,9 +149,82 @@ class FlatParams:
         self._ndesc, self._ntiles = len(descs), tile0
         self._version = -1
         self.grads_dirty = False             # set by backward, cleared by the fused zero_grad in AdamW
+        # ---- lazy zero (round 4): gradients that ONE weight-gradient launch per backward produces whole (the encoder's dense weights,
+        # the tied word-embedding table) need no zero fill between optimizer steps -- the first launch of the next backward overwrites
+        # them (accumulate = 0) instead of reading zeros and adding.  What torch does with zero_grad(set_to_none=True): the old gradient
+        # is simply dropped.  ``lazy`` = the registered gradient views by id; ``stale`` = the ids whose buffer holds a DROPPED gradient.
+        self.lazy: Dict[int, Tuple[torch.Tensor, List[str]]] = {}
+        self.stale: set = set()
+        self.lazy_detached = False
         self.refresh()
 
     # ------------------------------------------------------------------------------------------
+    def register_lazy(self, gview: torch.Tensor, names: List[str]):
+        """``gview``: a contiguous view of ``grads`` covering whole 256-element blocks, written whole by one weight-gradient launch per
+        backward; ``names``: the parameters inside it (their .grad is None while the buffer is stale)."""
+        o = (gview.data_ptr() - self.grads.data_ptr()) // 4
+        if not (gview.is_contiguous() and o % ALIGN == 0 and gview.numel() % ALIGN == 0):
+            return                                               # (odd widths: not whole blocks -- stays with the zero fill)
+        self.lazy[id(gview)] = (gview, list(names))
+
+    def lazy_block_mask(self) -> torch.Tensor:
+        """uint8 per 256-element block: 4 where the optimizer's fused zero_grad must leave the gradient alone."""
+        m = torch.zeros(self.total // ALIGN, dtype=torch.uint8)
+        for g, _ in self.lazy.values():
+            o = (g.data_ptr() - self.grads.data_ptr()) // 4
+            m[o // ALIGN:(o + g.numel()) // ALIGN] = 4
+        return m
+
+    def take_accumulate(self, gviews) -> bool:
+        """The ``accumulate`` flag of a weight-gradient launch that writes ``gviews`` whole: False iff all of them hold a dropped
+        gradient (the launch overwrites them); a mixed set is settled first (zero fill of the stale ones)."""
+        if not self.stale:
+            return True
+        ids = [id(g) for g in gviews]
+        st = [i in self.stale for i in ids]
+        if not any(st):
+            return True
+        if not all(st):
+            for g, s_ in zip(gviews, st):
+                if s_:
+                    g.zero_()
+        self.stale.difference_update(ids)
+        return not all(st)
+
+    def settle(self, gviews=None):
+        """Zero-fills the gradients that are still stale (all, or those of ``gviews``): before anything but an overwriting launch
+        reads or adds to them -- the optimizer itself when no backward wrote them, the embedding scatter when no MLM loss ran."""
+        if not self.stale:
+            return
+        ids = list(self.stale) if gviews is None else [id(g) for g in gviews if id(g) in self.stale]
+        for i in ids:
+            self.lazy[i][0].zero_()
+            self.stale.discard(i)
+
+    def drop_lazy(self):
+        """After the optimizer's fused zero_grad: the lazy gradients are dropped, not zeroed."""
+        self.stale = set(self.lazy)
+
+    def detach_lazy(self):
+        """zero_grad(): .grad of the parameters whose buffer is stale reads None (torch's set_to_none), until the next backward."""
+        if self.lazy_detached or not self.stale:
+            return
+        for i in self.stale:
+            for n in self.lazy[i][1]:
+                self.named[n].grad = None
+        self.lazy_detached = True
+
+    def attach_lazy(self):
+        if not self.lazy_detached:
+            return
+        for _, names in self.lazy.values():
+            for n in names:
+                p = self.named[n]
+                if p.grad is None:
+                    o = self.offset[n]
+                    p.grad = self.grads[o:o + self.numel[n]].view(p.shape)
+        self.lazy_detached = False
+
     def view32(self, name: str, shape=None) -> torch.Tensor:
         o, k = self.offset[name], self.numel[name]
         t = self.params[o:o + k]
@@ -199,7 +272,11 @@ class FlatParams:
     def owns(self, model: torch.nn.Module) -> bool:
         """Cheap per-forward check (three sentinel parameters) that the module's parameters still
         alias this storage; re-attaches ``.grad`` views dropped by ``zero_grad(set_to_none=True)``."""
-        sentinels = (self.order[0], self.order[len(self.order) // 2], self.order[-1])
+        if not hasattr(self, "_sentinels"):
+            lazy_names = {n for _, names in self.lazy.values() for n in names}          # (their .grad is None between zero_grad and backward)
+            cand = [n for n in self.order if n not in lazy_names]
+            self._sentinels = (cand[0], cand[len(cand) // 2], cand[-1])
+        sentinels = self._sentinels
         for n in sentinels:
             p = self.named[n]
             if p.data_ptr() != self.params.data_ptr() + 4 * self.offset[n]:
@@ -209,4 +286,5 @@ class FlatParams:
                 o = self.offset[n]
                 if p.grad is None or p.grad.data_ptr() != self.grads.data_ptr() + 4 * o:
                     p.grad = self.grads[o:o + self.numel[n]].view(p.shape)
+            self.lazy_detached = False
         return True

@@ -219,6 +219,12 @@ class _JointFn(torch.autograd.Function):
         return de1, None, None, None, None, None, None, None
 
 
+def _wgrad(top, probs):
+    """One weight-gradient launch for ``probs`` = [(dY, X, gW (view of the flat gradient buffer), gb)]: it OVERWRITES gradients the
+    optimizer has dropped (lazy zero, flat.FlatParams.take_accumulate) and accumulates otherwise."""
+    ops.gemm_tn_grouped(probs, accumulate=top._flat.take_accumulate([q[2] for q in probs]))
+
+
 class _EncoderFn:
     """L x BertLayer (HF:374-416) over the packed token matrix: the forward / backward bodies that _TrunkFn runs between the
     embedding stage and the heads (plain functions: the whole trunk is ONE autograd node, so no [tokens, H] tensor crosses
@@ -263,6 +269,7 @@ class _EncoderFn:
         H = top.config.hidden_size
         L = top.config.num_hidden_layers
         top._flat.grads_dirty = True
+        top._flat.attach_lazy()
         # split (valid-first) layout: the rows behind rows_a have exactly-zero gradients in every layer (see _encode), so the
         # whole backward -- dgrads, weight gradients, LayerNorm', attention -- runs on the leading rows_a rows only
         M_all = saved[0][0].shape[0]
@@ -343,20 +350,20 @@ class _EncoderFn:
                     held = (i, probs)
                     continue
                 if held is not None:
-                    ops.gemm_tn_grouped(held[1] + probs)
+                    _wgrad(top, held[1] + probs)
                     if top.grad_hook is not None:
                         lnd.flush()
                     top._layer_grads_done(held[0])
                     held = None
                 else:
-                    ops.gemm_tn_grouped(probs)
+                    _wgrad(top, probs)
             elif side is None:
-                ops.gemm_tn_grouped(probs)
+                _wgrad(top, probs)
             else:
                 main = torch.cuda.current_stream()
                 side.wait_stream(main)
                 with torch.cuda.stream(side):
-                    ops.gemm_tn_grouped(probs)
+                    _wgrad(top, probs)
                 for t in (du, y1, dz2d, g, dqkv, x, dz1d, actx):
                     t.record_stream(side)                  # the caching allocator must not hand these out while the side stream reads them
                 if top.grad_hook is not None:
@@ -366,7 +373,7 @@ class _EncoderFn:
             top._layer_grads_done(i)
         lnd.flush()
         for c in range(0, len(deferred), 48):                 # (mmbert_gemm_tn_grouped: up to 48 problems = 12 layers per launch)
-            ops.gemm_tn_grouped(deferred[c:c + 48])
+            _wgrad(top, deferred[c:c + 48])
         side = top._wgrad_stream()
         if side is not None:
             torch.cuda.current_stream().wait_stream(side)     # optimizer / all-reduce tail see complete gradients
@@ -422,8 +429,8 @@ class _EncoderFn:
         dz1.index_copy_(0, R, dz1_c)
         out = ops.gemm_nt(dqkv, lw["WqkvT"], resid=dz1)
         # (bias gradients b1 / b2 / bo: column sums of the bf16 gradients on the ones-operand MFMA, as in the dense layers)
-        ops.gemm_tn_grouped([(du_c, y1_c, lw["g_W1"], lw["g_b1"]), (dz2d_c, g_c, lw["g_W2"], lw["g_b2"]), (dz1d_c, actx_c, lw["g_Wo"], lw["g_bo"])])
-        ops.gemm_tn_grouped([(dqkv, x, lw["g_Wqkv"], lw["g_bqkv"])])
+        _wgrad(top, [(du_c, y1_c, lw["g_W1"], lw["g_b1"]), (dz2d_c, g_c, lw["g_W2"], lw["g_b2"]), (dz1d_c, actx_c, lw["g_Wo"], lw["g_bo"])])
+        _wgrad(top, [(dqkv, x, lw["g_Wqkv"], lw["g_bqkv"])])
         return out
 
 
@@ -559,6 +566,8 @@ class _TrunkFn(torch.autograd.Function):
         npass = len(lens)
         layout = split if split is not None else plan["layout"]
         compact, t.compact = t.compact, None                      # (rows in the caller's order, their gradients): set by the MLM head
+        top._flat.settle([w["g_word_pad"]])                       # no MLM-head launch has overwritten a dropped table gradient (no labelled row):
+                                                                  # zero it before the embedding rows are added / the slice is reduced
         if top.head_grad_hook is not None:
             top.head_grad_hook()                                  # every gradient of the heads is final, the tied decoder's included
         dy_rows = None
@@ -765,11 +774,13 @@ class _MLMHeadFn(torch.autograd.Function):
         V = ctx.top.config.vocab_size
         if dloss is None:
             return None
+        ctx.top._flat.grads_dirty = True
+        ctx.top._flat.attach_lazy()
         gs = dloss.contiguous().float()
         if ctx.compact:
             y_c, pre_c, t0_c, mean_c, rstd_c, t_c, logits_c, labels_c, bounds_c, inv, lse, sel = ctx.saved_tensors
             dl = ops.ce_bwd(logits_c, V, labels_c, bounds_c, ctx.nseg, inv, gs, lse, logits_c)       # in place: the scores go nowhere
-            ops.gemm_tn(dl, t_c, w["g_word_pad"], bias_out=w["g_pred_bias"])
+            ops.gemm_tn(dl, t_c, w["g_word_pad"], bias_out=w["g_pred_bias"], accumulate=ctx.top._flat.take_accumulate([w["g_word_pad"]]))
             dt = ops.gemm_nt_splitk(dl, w["wordT"])
             dt0 = ops.ln_bwd(dt, t0_c, mean_c, rstd_c, w["mlm_ln_g"], w["g_mlm_ln_g"], w["g_mlm_ln_b"])
             dpre = ops.gelu_bwd(dt0, pre_c)
@@ -788,7 +799,7 @@ class _MLMHeadFn(torch.autograd.Function):
                 dl = torch.empty((n, logits.shape[1]), device=y.device, dtype=torch.bfloat16)
                 ops.ce_bwd(logits, V, labels, seg_bounds, ctx.nseg, inv, gs, lse, dl, rows=idx)
                 t_c, t0_c, pre_c, y_c, mean_c, rstd_c = ops.gather_rows([t, t0, pre, y, mean, rstd], idx)      # one launch
-                ops.gemm_tn(dl, t_c, w["g_word_pad"], bias_out=w["g_pred_bias"])
+                ops.gemm_tn(dl, t_c, w["g_word_pad"], bias_out=w["g_pred_bias"], accumulate=ctx.top._flat.take_accumulate([w["g_word_pad"]]))
                 dt = ops.gemm_nt_splitk(dl, w["wordT"])                     # K = vocabulary, a few hundred rows: split-K
                 dt0 = ops.ln_bwd(dt, t0_c, mean_c, rstd_c, w["mlm_ln_g"], w["g_mlm_ln_g"], w["g_mlm_ln_b"])
                 dpre = ops.gelu_bwd(dt0, pre_c)
@@ -797,7 +808,7 @@ class _MLMHeadFn(torch.autograd.Function):
         # dense path: dlogits with the per-pass upstream gradients folded in; in place unless the scores were handed to the caller
         dl = torch.empty(logits.shape, device=logits.device, dtype=torch.bfloat16) if (ctx.keep_logits or logits.dtype != torch.bfloat16) else logits
         ops.ce_bwd(logits, V, labels, seg_bounds, ctx.nseg, inv, gs, lse, dl)
-        ops.gemm_tn(dl, t, w["g_word_pad"], bias_out=w["g_pred_bias"])          # tied decoder weight + prediction bias gradient
+        ops.gemm_tn(dl, t, w["g_word_pad"], bias_out=w["g_pred_bias"], accumulate=ctx.top._flat.take_accumulate([w["g_word_pad"]]))   # tied decoder weight + prediction bias gradient
         dt = ops.gemm_nt(dl, w["wordT"])
         dt0 = ops.ln_bwd(dt, t0, mean, rstd, w["mlm_ln_g"], w["g_mlm_ln_g"], w["g_mlm_ln_b"])
         dpre = ops.gelu_bwd(dt0, pre)
@@ -899,6 +910,8 @@ class _GpuModelBase(nn.Module):
         if not pre:
             raise RuntimeError("flat storage is built from MMBertForPretraining")
         self._lw = []
+        f.settle()
+        f.lazy.clear()
         for i in range(L):
             p = f"bert.encoder.layer.{i}."
             d = {}
@@ -917,6 +930,11 @@ class _GpuModelBase(nn.Module):
                 d[tag + "ln2_g"] = f.span(buf, p + "output.LayerNorm.weight", H, (H,))
                 d[tag + "ln2_b"] = f.span(buf, p + "output.LayerNorm.bias", H, (H,))
             d["WqkvT"], d["WoT"], d["W1T"], d["W2T"] = f.tview(p + "qkv"), f.tview(p + "o"), f.tview(p + "w1"), f.tview(p + "w2")
+            # lazy zero (flat.FlatParams): every backward writes these whole with ONE weight-gradient launch each (_wgrad)
+            f.register_lazy(d["g_Wqkv"], [p + "attention.self." + x + ".weight" for x in ("query", "key", "value")])
+            f.register_lazy(d["g_Wo"], [p + "attention.output.dense.weight"])
+            f.register_lazy(d["g_W1"], [p + "intermediate.dense.weight"])
+            f.register_lazy(d["g_W2"], [p + "output.dense.weight"])
             self._lw.append(d)
         w = {}
         e = "bert.embeddings."
@@ -944,6 +962,7 @@ class _GpuModelBase(nn.Module):
         w["g_Wt"] = f.span(f.grads, c + "transform.dense.weight", H * H, (H, H))
         w["word_h"] = f.span(f.half, e + "word_embeddings.weight", f.vpad * H, (f.vpad, H))
         w["WtT"], w["wordT"] = f.tview("transform"), f.tview("word")
+        f.register_lazy(w["g_word_pad"], [e + "word_embeddings.weight"])     # the tied decoder's weight gradient: the MLM head's first launch
         self._w = w
 
     # ---- pass packing --------------------------------------------------------------------------

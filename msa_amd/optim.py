@@ -32,6 +32,9 @@ class AdamW:
             raise NotImplementedError("correct_bias=False is not used by the reference")
         self.betas, self.eps, self.mode = betas, eps, {"hf": 0, "torch": 1}[mode]
         self.grad_scale = 1.0               # set to 1/world_size by parallel.DataParallel
+        # The dense weights' gradients (3/4 of the parameters) are not zero-filled between steps: the next backward's weight-gradient
+        # launches overwrite them (flat.FlatParams lazy zero; torch's zero_grad(set_to_none=True) semantics).  False: fill with zeros.
+        self.lazy_zero = True
         self._flat = None
         self._steps = 0
 
@@ -72,6 +75,8 @@ class AdamW:
                     raise NotImplementedError(f"{name}: packed neighbours must share one weight-decay setting")
                 flags[b0:b1] = f
         flags[flags == 3] = 2
+        if self.lazy_zero:
+            flags |= flat.lazy_block_mask()  # + 4: the fused zero_grad leaves these blocks to the next backward's overwriting launches
         self._flags = flags.to(flat.device)
         self._m = torch.zeros_like(flat.params)
         self._v = torch.zeros_like(flat.params)
@@ -82,12 +87,16 @@ class AdamW:
             self._bind()
         flat = self._flat
         self._steps += 1
+        flat.settle()                        # a lazy gradient no backward has written since the last step counts as zero
+        flat.attach_lazy()
         ops.adamw(flat.params, flat.grads, self._m, self._v, flat.half, self._flags, lr=self.lr, beta1=self.betas[0],
                   beta2=self.betas[1], eps=self.eps, wd=self.wd, step=self._steps, gscale=self.grad_scale, mode=self.mode,
                   zero_grad=True)
         flat.refresh_transposes()
         flat.mark_synced()
         flat.grads_dirty = False
+        if self.lazy_zero:
+            flat.drop_lazy()
 
     def zero_grad(self, set_to_none: bool = False):
         flat = self._flat
@@ -100,6 +109,10 @@ class AdamW:
         if flat.grads_dirty:                 # step() already zeroed the buffer in the same kernel
             flat.grads.zero_()
             flat.grads_dirty = False
+            flat.stale.clear()
+            flat.attach_lazy()
+        else:
+            flat.detach_lazy()               # the dropped gradients read None (torch: set_to_none) until the next backward writes them
 
     def state_dict(self):
         return dict(steps=self._steps, m=None if self._flat is None else self._m, v=None if self._flat is None else self._v,

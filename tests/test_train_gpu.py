@@ -91,7 +91,16 @@ def test_fused_adamw_hf_mode_matches_oracle_on_model_grads():
         grp["lr"] = 1e-3
     opt.step()
     torch.cuda.synchronize()
-    assert float(flat.grads.abs().max()) == 0.0 and not flat.grads_dirty
+    # fused zero_grad: everything zero except the LAZY blocks (the dense weights and the tied table: 3/4 of the parameters), whose old
+    # gradient is dropped -- flagged stale, to be overwritten by the next backward -- and zero-filled only on demand
+    assert not flat.grads_dirty and flat.stale == set(flat.lazy) and len(flat.lazy) == 4 * CFG["layers"] + 1
+    keep = torch.ones(flat.total, dtype=torch.bool)
+    for gv, _ in flat.lazy.values():
+        o = (gv.data_ptr() - flat.grads.data_ptr()) // 4
+        keep[o:o + gv.numel()] = False
+    assert float(flat.grads[keep.to(DEV)].abs().max()) == 0.0 and float(flat.grads.abs().max()) > 0.0
+    flat.settle()
+    assert float(flat.grads.abs().max()) == 0.0 and not flat.stale
     for n, p in m.named_parameters():
         o, k = flat.offset[n], flat.numel[n]
         pr, gr = p0[o:o + k].clone(), g0[o:o + k]
@@ -104,6 +113,65 @@ def test_fused_adamw_hf_mode_matches_oracle_on_model_grads():
     # the transposed copies follow too: a second forward must see the new weights everywhere
     out2, _ = m(**batch)
     assert abs(float(out2[0]) - float(out[0])) > 1e-4
+
+
+def test_lazy_zero_of_the_dense_weight_gradients_is_invisible():
+    """Round 4: AdamW's fused zero_grad leaves the dense weights' gradients (and the tied table's) alone; the next backward's
+    weight-gradient launches OVERWRITE them (torch's zero_grad(set_to_none=True): the old gradient is dropped, never read).  With the
+    learning rate at 0 the parameters never move, so every gradient below has a reference computed from a zero-filled buffer:
+    (1) the first backward after a step overwrites; (2) a second micro-batch accumulates; (3) between zero_grad() and the next backward
+    the dropped gradients read None, after it they are the flat views again; (4) a batch without any MLM label leaves the tied table's
+    gradient = the embedding rows alone (zero-filled on demand); (5) after a backward that never reaches the encoder (heads only) the
+    optimizer sees zeros there: its first moments just decay."""
+    from msa_amd import trainer as T
+    from msa_amd import model as MM
+    batches = [batch_to(synthetic_batch(2, 16, 40, 24, vocab=CFG["vocab"], seed=30 + i), DEV) for i in range(3)]
+    nolabel = dict(batches[2]); nolabel["masked_labels"] = tuple(torch.full_like(x, -100) for x in nolabel["masked_labels"])
+    m = build()
+    m.eval()
+    opt, sched = T.build_optimizer(m, T.default_args(learning_rate=1e-3), 10)
+    for grp in opt.param_groups:
+        grp["lr"] = 0.0
+    def fb(b):
+        out, _ = m(**b); out[0].mean().backward()
+    m._ensure_ready(torch.device(DEV, 0))
+    flat = m._flat
+    ref = {}
+    for k, b in (("b0", batches[0]), ("b1", batches[1]), ("nolabel", nolabel)):       # references: zero-filled start, nothing stale
+        flat.grads.zero_(); fb(b); ref[k] = flat.grads.clone()
+    close = lambda a, b_: float((a - b_).norm() / b_.norm()) < 1e-5                   # (biases / LayerNorm sums go through fp32 atomics)
+    p0 = flat.params.clone()
+    opt.step(); opt.zero_grad()
+    assert torch.equal(flat.params, p0)
+    wq = m.bert.encoder.layer[0].attention.self.query.weight
+    assert flat.stale == set(flat.lazy) and wq.grad is None and m.bert.embeddings.word_embeddings.weight.grad is None
+    assert m.bert.encoder.layer[0].attention.self.query.bias.grad is not None
+    assert float(flat.grads.abs().max()) > 0.0                                       # the dropped gradients are still in the buffer
+    fb(batches[0])                                                                    # (1) overwrites them
+    assert not flat.stale and close(flat.grads, ref["b0"])
+    assert wq.grad is not None and wq.grad.data_ptr() == flat.grads.data_ptr() + 4 * flat.offset["bert.encoder.layer.0.attention.self.query.weight"]
+    fb(batches[1])                                                                    # (2) accumulates
+    assert close(flat.grads, ref["b0"] + ref["b1"])
+    opt.step(); opt.zero_grad()
+    fb(nolabel)                                                                       # (4)
+    assert not flat.stale and close(flat.grads, ref["nolabel"])
+    o, k = flat.offset["bert.embeddings.word_embeddings.weight"], flat.numel["bert.embeddings.word_embeddings.weight"]
+    assert float(flat.grads[o:o + k].abs().max()) > 0.0 and int((flat.grads[o:o + k].view(-1, CFG["hidden"]).abs().sum(1) > 0).sum()) < 200
+    opt.step(); opt.zero_grad()
+    first = torch.randn(6, CFG["hidden"], device=DEV, generator=torch.Generator(DEV).manual_seed(7)).requires_grad_(True)
+    hl, *_ = MM._HeadsFn.apply(first, m, torch.tensor([0, 1, 1, 0], device=DEV), torch.tensor([0.5, -1.0], device=DEV))
+    hl.backward()                                                                     # (5) the trunk's backward never runs
+    lo = flat.offset["bert.encoder.layer.1.output.dense.weight"]
+    m_before = opt._m[lo:lo + 4096].clone()
+    assert float(m_before.abs().max()) > 0.0 and flat.stale
+    opt.step()
+    assert torch.equal(opt._m[lo:lo + 4096], m_before * opt.betas[0])
+    # ... and the zero-filling optimizer (lazy_zero = False before the first step) leaves nothing stale
+    m2 = build(); m2.eval()
+    opt2, _ = T.build_optimizer(m2, T.default_args(learning_rate=1e-3), 10)
+    opt2.lazy_zero = False
+    out, _ = m2(**batches[0]); out[0].mean().backward(); opt2.step()
+    assert not m2._flat.stale and float(m2._flat.grads.abs().max()) == 0.0
 
 
 def _dp_worker(rank, world, port, q):
