@@ -265,8 +265,12 @@ int mmbert_active_rows(mmbert_stream_t stream, const int64_t* labels, int M, int
 int mmbert_heads_gate_fwd(mmbert_stream_t stream, const float* P, const float* Apre, const float* const* vw3, const float* const* vb3, int B, int H, float* g, float* C);
 int mmbert_heads_loss_fwd(mmbert_stream_t stream, const float* P, const float* XP, const float* rel, const int64_t* ap, const float* lo, const float* sent,
                           int B, int H, float beta, int tanh_lo, float* out5, float* dXP, float* dPc, float* drel, float* dlo, float* nce_part,
-                          const float* mlm, int nmlm, float alpha);
+                          const float* mlm, int nmlm, float alpha, float* loss_out /* optional: out5[4] once more */, float* aux_out /* optional: out5[0..2] */);
 int mmbert_heads_scale(mmbert_stream_t stream, float* x, size_t n, const float* s);
+/* The start of the heads' backward in one launch: dst[i] = src[i] * s[0] (i < n: the seeds scaled by the upstream gradient, out of place),
+ * zero[j] = 0 (j < nzero: the buffers the backward products are summed into), dmlm[k] = s[0] * coef (k < nmlm <= 256: the gradient handed to
+ * the per-pass MLM losses, coef = alpha / passes; REF:MMBertForPretraining.py:427,443). */
+int mmbert_heads_seed(mmbert_stream_t stream, const float* src, size_t n, const float* s, float* dst, float* zero, size_t nzero, float* dmlm, int nmlm, float coef);
 int mmbert_heads_gate_bwd(mmbert_stream_t stream, const float* dC, const float* P, const float* Apre, const float* g, const float* const* vw3, const float* dPc,
                           int B, int H, float* dP, float* dApre, float* E, float* dg);
 int mmbert_heads_tanh(mmbert_stream_t stream, float* x, size_t n);            /* x = tanh(x) in place (the pooler's activation, HF:457-463) */
@@ -300,6 +304,12 @@ int mmbert_cast_f32_bf16(mmbert_stream_t stream, const float* x, void* y, size_t
 int mmbert_cast_bf16_f32(mmbert_stream_t stream, const void* x, float* y, size_t n);
 /* descs: device array of {int64 src_off, int64 dst_off, int rows, cols, dst_ld, tile0} (64x64 tiles) */
 int mmbert_transpose_cast(mmbert_stream_t stream, const float* src, void* dst, const void* descs, int ndesc, int total_tiles);
+/* Row list of a sparse backward in one launch: out[i] = map[i < n ? rows[i] : extra[i - n]] written as int64 (out64) and int32 (out32);
+ * rows come as int32 (rows32) or int64 (rows64, used when rows32 is NULL); map (int64, e.g. the valid-first packing's inverse) may be NULL.
+ * Replaces the cast / cat / index_select / cast chain in front of the top encoder layer's sparse backward (REF: autograd of
+ * MMBertForPretraining.py:406-445 -- only the MLM-labelled rows and the [CLS] rows of the last layer's output carry a gradient). */
+int mmbert_compact_rows(mmbert_stream_t stream, const int* rows32, const int64_t* rows64, int n, const int64_t* extra, int nextra, const int64_t* map,
+                        int64_t* out64, int* out32);
 /* Batched row gather: dst_k[i] = src_k[idx[i]] for i < nrows and up to 12 matrices k that share the row list idx (int32, device); rows
  * are row_bytes[k] bytes (a multiple of 4) at byte pitches src_pitch[k] / dst_pitch[k].  The sparse backward paths use it to pull
  * the labelled rows out of every saved activation in one launch. */

@@ -52,8 +52,9 @@ SIGNATURES = {
     "mmbert_prologue": (I, [P, I, P, P, P, P, P, P, P, I, P, I, P, I, P, P, P, P, P, P, P, P]),
     "mmbert_split_rows": (I, [P, P, P, P, P, P, I, I, I, P, P, P, P, P]),
     "mmbert_heads_gate_fwd": (I, [P, P, P, P, P, I, I, P, P]),
-    "mmbert_heads_loss_fwd": (I, [P, P, P, P, P, P, P, I, I, F, I, P, P, P, P, P, P, P, I, F]),
+    "mmbert_heads_loss_fwd": (I, [P, P, P, P, P, P, P, I, I, F, I, P, P, P, P, P, P, P, I, F, P, P]),
     "mmbert_heads_scale": (I, [P, P, SZ, P]),
+    "mmbert_heads_seed": (I, [P, P, SZ, P, P, P, SZ, P, I, F]),
     "mmbert_heads_gate_bwd": (I, [P, P, P, P, P, P, P, I, I, P, P, P, P]),
     "mmbert_heads_tanh": (I, [P, P, SZ]),
     "mmbert_heads_tanh_bwd": (I, [P, P, P, P, SZ]),
@@ -67,6 +68,7 @@ SIGNATURES = {
     "mmbert_transpose_cast": (I, [P, P, P, P, I, I]),
     "mmbert_transpose_bf16": (I, [P, P, P, P, I, I]),
     "mmbert_gather_rows": (I, [P, I, P, P, P, P, P, P, I]),
+    "mmbert_compact_rows": (I, [P, P, P, I, P, I, P, P, P]),
     "mmbert_pack_i64": (I, [P, I, P, P, P, P, P]),
     "mmbert_rows_to_block": (I, [P, P, P, I, I, I, I, P, I, I, P]),
     "mmbert_split_layout": (I, [P, P, P, I, I, I, I, I, P]),

@@ -229,7 +229,8 @@ __global__ __launch_bounds__(256) void heads_loss_fwd32_kernel(const float* __re
 __global__ __launch_bounds__(256) void heads_loss_finish_kernel(const float* __restrict__ rel, const int64_t* __restrict__ ap, const float* __restrict__ lo,
                                                                 const float* __restrict__ sent, const float* __restrict__ nce_part, int B, float beta,
                                                                 int tanh_lo, float* __restrict__ out, float* __restrict__ drel, float* __restrict__ dlo,
-                                                                const float* __restrict__ mlm, int nmlm, float alpha) {
+                                                                const float* __restrict__ mlm, int nmlm, float alpha,
+                                                                float* __restrict__ loss_out, float* __restrict__ aux_out) {
     __shared__ float red[4];
     const int tid = threadIdx.x;
     float ce = 0.f, se = 0.f;
@@ -256,7 +257,12 @@ __global__ __launch_bounds__(256) void heads_loss_finish_kernel(const float* __r
         out[0] = ce; out[1] = se; out[2] = nce; out[3] = heads;
         float ms = 0.f;                                  // joint = alpha * mean(mlm) + heads   (REF :427, :443)
         for (int i = 0; i < nmlm; ++i) ms += mlm[i];
-        out[4] = nmlm > 0 ? alpha * (ms / (float)nmlm) + heads : heads;
+        const float joint = nmlm > 0 ? alpha * (ms / (float)nmlm) + heads : heads;
+        out[4] = joint;
+        // the same values once more in buffers of their own: what the caller returns (a slice of `out` would be a VIEW, and autograd
+        // refuses in-place operations on view outputs of a custom function; round 3 cloned the slices: two copy launches)
+        if (loss_out) *loss_out = joint;
+        if (aux_out) { aux_out[0] = ce; aux_out[1] = se; aux_out[2] = nce; }
     }
 }
 
@@ -264,6 +270,18 @@ __global__ __launch_bounds__(256) void heads_loss_finish_kernel(const float* __r
 __global__ void heads_scale_kernel(float* __restrict__ x, size_t n, const float* __restrict__ s) {
     const float f = *s;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) x[i] *= f;
+}
+
+// the start of the heads' backward in ONE launch (round 4; before: a clone of the seeds, heads_scale in place, a zero fill and a multiply):
+// dst[i] = src[i] * *s (the seeds are kept: backward may run twice), zero[j] = 0 (the buffers the backward products are summed into),
+// dmlm[k] = *s * coef (the upstream gradient of the per-pass MLM losses: alpha / passes)
+__global__ void heads_seed_kernel(const float* __restrict__ src, size_t n, const float* __restrict__ s, float* __restrict__ dst,
+                                  float* __restrict__ zero, size_t nzero, float* __restrict__ dmlm, int nmlm, float coef) {
+    const float f = *s;
+    const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x, stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = tid; i < n; i += stride) dst[i] = src[i] * f;
+    for (size_t i = tid; i < nzero; i += stride) zero[i] = 0.f;
+    if (tid < (size_t)nmlm) dmlm[tid] = f * coef;
 }
 
 // gate backward; one workgroup per (m, b) row:
@@ -461,14 +479,14 @@ int mmbert_heads_gate_fwd(hipStream_t stream, const float* P, const float* Apre,
 
 int mmbert_heads_loss_fwd(hipStream_t stream, const float* P, const float* XP, const float* rel, const int64_t* ap, const float* lo, const float* sent,
                           int B, int H, float beta, int tanh_lo, float* out5, float* dXP, float* dPc, float* drel, float* dlo, float* nce_part,
-                          const float* mlm, int nmlm, float alpha) {
+                          const float* mlm, int nmlm, float alpha, float* loss_out, float* aux_out) {
     if (B <= 0) return 0;
     if (H > 1024 || (H & 3) || B > 32 || nmlm < 0 || (nmlm > 0 && !mlm)) return -1;
     if (B > 16) {
         hipLaunchKernelGGL(heads_loss_fwd32_kernel, dim3(3, (H + 63) / 64), dim3(256), 0, stream, P, XP, B, H, beta, dXP, dPc, nce_part);
         MMB_CHECK_LAUNCH();
         hipLaunchKernelGGL(heads_loss_finish_kernel, dim3(1), dim3(256), 0, stream, rel, ap, lo, sent, (const float*)nce_part, B, beta, tanh_lo, out5, drel, dlo,
-                           mlm, nmlm, alpha);
+                           mlm, nmlm, alpha, loss_out, aux_out);
         MMB_CHECK_LAUNCH();
         return 0;
     }
@@ -479,7 +497,7 @@ int mmbert_heads_loss_fwd(hipStream_t stream, const float* P, const float* XP, c
     hipLaunchKernelGGL(heads_loss_fwd_kernel, dim3(3, (H + 63) / 64), dim3(256), lds, stream, P, XP, B, H, beta, dXP, dPc, nce_part);
     MMB_CHECK_LAUNCH();
     hipLaunchKernelGGL(heads_loss_finish_kernel, dim3(1), dim3(256), 0, stream, rel, ap, lo, sent, (const float*)nce_part, B, beta, tanh_lo, out5, drel, dlo,
-                       mlm, nmlm, alpha);
+                       mlm, nmlm, alpha, loss_out, aux_out);
     MMB_CHECK_LAUNCH();
     return 0;
 }
@@ -487,6 +505,16 @@ int mmbert_heads_loss_fwd(hipStream_t stream, const float* P, const float* XP, c
 int mmbert_heads_scale(hipStream_t stream, float* x, size_t n, const float* s) {
     if (n == 0) return 0;
     hipLaunchKernelGGL(heads_scale_kernel, dim3((unsigned)((n + 255) / 256 < 256 ? (n + 255) / 256 : 256)), dim3(256), 0, stream, x, n, s);
+    MMB_CHECK_LAUNCH();
+    return 0;
+}
+
+int mmbert_heads_seed(hipStream_t stream, const float* src, size_t n, const float* s, float* dst, float* zero, size_t nzero, float* dmlm, int nmlm, float coef) {
+    const size_t m = n > nzero ? n : nzero;
+    if (m == 0 && nmlm <= 0) return 0;
+    if (nmlm > 256) return -1;
+    const size_t blocks = (m + 255) / 256;
+    hipLaunchKernelGGL(heads_seed_kernel, dim3((unsigned)(blocks < 1 ? 1 : (blocks < 512 ? blocks : 512))), dim3(256), 0, stream, src, n, s, dst, zero, nzero, dmlm, nmlm, coef);
     MMB_CHECK_LAUNCH();
     return 0;
 }

@@ -679,11 +679,13 @@ __global__ __launch_bounds__(256) void embed_gather_kernel(const int64_t* __rest
 __global__ __launch_bounds__(256) void embed_scatter_kernel(const int64_t* __restrict__ ids, const int64_t* __restrict__ tts,
                                                             const bf16_t* __restrict__ d, int ldd, int n, int T, int H, int V,
                                                             float* __restrict__ gword, float* __restrict__ gtype, float* __restrict__ gpos) {
+    // (round 4) blockIdx.y = a slice of the sequences: T workgroups alone left 4/5 of the chip idle behind 48 dependent row reads each
+    // (47 us at the headline shape, on the critical path in front of the optimizer); a position row then takes gridDim.y adds instead of one
     const int p = blockIdx.x;
     for (int col = threadIdx.x * 4; col < H; col += 1024) {
         float ps[4] = {0.f, 0.f, 0.f, 0.f}, t0[4] = {0.f, 0.f, 0.f, 0.f}, t1[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 8
-        for (int i = p; i < n; i += T) {
+#pragma unroll 4
+        for (int i = p + (int)blockIdx.y * T; i < n; i += T * (int)gridDim.y) {
             const long id = ids[i];
             const bool tt = tts ? (tts[i] != 0) : false;
             const bf16x4 v = *(const bf16x4*)(d + (size_t)i * ldd + col);
@@ -1481,7 +1483,9 @@ int mmbert_embed_scatter(hipStream_t stream, const int64_t* ids, const int64_t* 
                          float* gword, float* gtype, float* gpos) {
     if (n <= 0) return 0;
     if (H > LN_MAXV * 256 || (H & 3) || (ldd & 3) || T <= 0) return -1;
-    hipLaunchKernelGGL(embed_scatter_kernel, dim3(T < n ? T : n), dim3(256), 0, stream, ids, tts, (const bf16_t*)d, ldd, n, T, H, V, gword, gtype, gpos);
+    const int seqs = (n + T - 1) / T;
+    const int slices = seqs >= 32 ? 8 : (seqs >= 8 ? 4 : 1);
+    hipLaunchKernelGGL(embed_scatter_kernel, dim3(T < n ? T : n, slices), dim3(256), 0, stream, ids, tts, (const bf16_t*)d, ldd, n, T, H, V, gword, gtype, gpos);
     MMB_CHECK_LAUNCH();
     return 0;
 }
@@ -1661,6 +1665,27 @@ int mmbert_transpose_cast(hipStream_t stream, const float* src, void* dst, const
 int mmbert_transpose_bf16(hipStream_t stream, const void* src, void* dst, const void* descs, int ndesc, int total_tiles) {
     if (ndesc <= 0 || total_tiles <= 0) return 0;
     hipLaunchKernelGGL(transpose_cast_kernel<bf16_t>, dim3(total_tiles), dim3(256), 0, stream, (const bf16_t*)src, (bf16_t*)dst, (const TransDesc*)descs, ndesc);
+    MMB_CHECK_LAUNCH();
+    return 0;
+}
+
+// out[i] = map[ i < n ? rows[i] : extra[i - n] ]  as int64 AND int32 (map optional): the row list of the top encoder layer's sparse
+// backward -- labelled rows, then the [CLS] rows, in the encoder's packed order -- in one launch (round 3: an int32->int64 cast, a cat,
+// an index_select through the packing's inverse map and an int64->int32 cast)
+__global__ void compact_rows_kernel(const int* __restrict__ a32, const int64_t* __restrict__ a64, int n, const int64_t* __restrict__ extra, int nextra,
+                                    const int64_t* __restrict__ map, int64_t* __restrict__ out64, int* __restrict__ out32) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n + nextra) return;
+    int64_t r = i < n ? (a32 ? (int64_t)a32[i] : a64[i]) : extra[i - n];
+    if (map) r = map[r];
+    out64[i] = r;
+    out32[i] = (int)r;
+}
+int mmbert_compact_rows(hipStream_t stream, const int* rows32, const int64_t* rows64, int n, const int64_t* extra, int nextra, const int64_t* map,
+                        int64_t* out64, int* out32) {
+    if (n < 0 || nextra < 0 || (n > 0 && !rows32 && !rows64) || (nextra > 0 && !extra)) return -1;
+    if (n + nextra == 0) return 0;
+    hipLaunchKernelGGL(compact_rows_kernel, dim3((n + nextra + 255) / 256), dim3(256), 0, stream, rows32, rows64, n, extra, nextra, map, out64, out32);
     MMB_CHECK_LAUNCH();
     return 0;
 }

@@ -292,10 +292,10 @@ class _EncoderFn:
             x, qkv, actx, lse, z1, m1, r1, y1, u, g, z2, m2, r2, d_att, d_h1, d_h2 = saved_i
             if i == L - 1 and (top_rows is not None or compact is not None):
                 R = None
+                R32 = None
                 if compact is not None:
-                    R, dy_c = compact
-                    if getattr(layout, "split", False):
-                        R = layout.inv.index_select(0, R)
+                    rows_l, rows_f, dy_c = compact                # labelled rows (int32 / int64), [CLS] rows (int64), their gradients stacked
+                    R, R32 = ops.compact_rows(rows_l, rows_f, layout.inv if getattr(layout, "split", False) else None)
                 elif top_rows is not None:
                     Ro = _EncoderFn._sparse_rows(top_rows, None, ra)          # rows in the caller's order
                     if Ro is not None:
@@ -303,7 +303,7 @@ class _EncoderFn:
                         src_rows = Ro if dy_rows is not None else R            # dy is in the caller's order iff it comes with a map
                         (dy_c,) = ops.gather_rows([dy], src_rows.int())
                 if R is not None:
-                    dy = _EncoderFn._last_layer_sparse(top, lw, layout, key_bias, kv_len, saved_i, dy_c, R, H, ra)
+                    dy = _EncoderFn._last_layer_sparse(top, lw, layout, key_bias, kv_len, saved_i, dy_c, R, H, ra, R32)
                     dy_rows = None
                     top._layer_grads_done(i)
                     continue
@@ -394,14 +394,15 @@ class _EncoderFn:
         return R
 
     @staticmethod
-    def _last_layer_sparse(top, lw, layout, key_bias, kv_len, saved_i, dy_c, R, H, ra):
+    def _last_layer_sparse(top, lw, layout, key_bias, kv_len, saved_i, dy_c, R, H, ra, R32=None):
         """Backward of the top encoder layer when only the rows R of its output carry a gradient: the output sublayer (LayerNorm',
         FFN-down and FFN-up input gradients, their weight gradients), LayerNorm' and the output projection of the attention
         sublayer run on those rows only (gathered operands, the dropout masks of the ORIGINAL rows); attention's backward is
         dense again (every unmasked key receives a gradient), as is everything below."""
         cfg = top.config
         x, qkv, actx, lse, z1, m1, r1, y1, u, g, z2, m2, r2, d_att, d_h1, d_h2 = saved_i
-        R32 = R.int()
+        if R32 is None:
+            R32 = R.int()
         # the rows R of every saved activation this path reads, in ONE launch (9 index_select launches before)
         m2_c, r2_c, u_c, m1_c, r1_c, y1_c, g_c, actx_c = ops.gather_rows([m2, r2, u, m1, r1, y1, g, actx], R32)
         dy = dy_c
@@ -711,7 +712,7 @@ class _MLMHeadFn(torch.autograd.Function):
                 ctx.top, ctx.nseg, ctx.compact, ctx.M = top, nseg, True, M
                 ctx.set_materialize_grads(False)
                 ctx.save_for_backward(y_c, pre_c, t0_c, mean_c, rstd_c, t_c, logits_c, labels_c, bounds_c, inv, lse, sel)
-                return loss.clone(), None, first
+                return loss, None, first
         pre = torch.empty_like(y) if keep else None
         t0 = ops.gemm_nt(y, w["Wt"], bias=w["bt"], gelu=True, aux=pre)
         t, mean, rstd = ops.ln_fwd(t0, w["mlm_ln_g"], w["mlm_ln_b"], cfg.layer_norm_eps, stats=keep)
@@ -733,23 +734,29 @@ class _MLMHeadFn(torch.autograd.Function):
         out_logits = logits if want_scores else None
         if out_logits is not None:
             ctx.mark_non_differentiable(out_logits)
-        return loss.clone(), out_logits, first
+        return loss, out_logits, first
 
     @staticmethod
     def backward(ctx, dloss, _unused, dfirst=None):
-        res = _MLMHeadFn._backward(ctx, dloss)
+        t = ctx.trunk
+        # room for the [CLS] rows behind the labelled rows' gradients: the compact hand-over to the trunk is then ONE row list and ONE matrix
+        # without a cat (the rows' gradients are written in place by the last product, the [CLS] rows by one converting copy)
+        nf = t.top_rows[1].numel() if (t is not None and t.top_rows is not None and dfirst is not None) else 0
+        res = _MLMHeadFn._backward(ctx, dloss, extra_rows=nf)
         nones = (None,) * 9
-        if isinstance(res, tuple):                            # (labelled rows int64, their gradients [n, H] bf16): the sparse paths
-            sel, dyl = res
-            t = ctx.trunk
-            if t is not None and t.top_rows is not None and dfirst is not None and _MLMHeadFn._compact_ok(ctx, t, sel.numel(), dfirst):
+        if isinstance(res, tuple):                            # (labelled rows int32 or int64, their gradients [n (+ nf), H] bf16): the sparse paths
+            sel, dy_all = res
+            n = sel.numel()
+            dyl = dy_all[:n]
+            if nf and _MLMHeadFn._compact_ok(ctx, t, n, dfirst):
                 first = t.top_rows[1]
                 df = dfirst if dfirst.shape[0] == first.numel() else dfirst.view(-1, first.numel(), dfirst.shape[1]).sum(0)   # ([CLS] rows repeated: fused)
-                t.compact = (torch.cat((sel, first)), torch.cat((dyl, df.to(dyl.dtype))))
+                dy_all[n:].copy_(df)
+                t.compact = (sel, first, dy_all)
                 return (_zero_dummy(ctx.M, dyl.shape[1], dyl.dtype, dyl.device),) + nones
             dy = torch.zeros((ctx.M, dyl.shape[1]), device=dyl.device, dtype=dyl.dtype)
-            if sel.numel():
-                dy.index_copy_(0, sel, dyl)
+            if n:
+                dy.index_copy_(0, sel.long(), dyl)
         else:
             dy = res
         if dfirst is not None:                                # a [CLS] row may also carry a label: add, after the copy
@@ -769,7 +776,7 @@ class _MLMHeadFn(torch.autograd.Function):
         return 4 * (n + first.numel()) <= ra and int(host[1]) == 0 and n == _active_row_count(t.top_rows[0])
 
     @staticmethod
-    def _backward(ctx, dloss):
+    def _backward(ctx, dloss, extra_rows=0):
         w = ctx.top._w
         V = ctx.top.config.vocab_size
         if dloss is None:
@@ -785,7 +792,9 @@ class _MLMHeadFn(torch.autograd.Function):
             dt0 = ops.ln_bwd(dt, t0_c, mean_c, rstd_c, w["mlm_ln_g"], w["g_mlm_ln_g"], w["g_mlm_ln_b"])
             dpre = ops.gelu_bwd(dt0, pre_c)
             ops.gemm_tn(dpre, y_c, w["g_Wt"], bias_out=w["g_bt"])
-            return sel, ops.gemm_nt(dpre, w["WtT"])
+            dy_all = torch.empty((sel.numel() + extra_rows, y_c.shape[1]), device=y_c.device, dtype=torch.bfloat16)
+            ops.gemm_nt(dpre, w["WtT"], out=dy_all[:sel.numel()])
+            return sel, dy_all
         y, pre, t0, mean, rstd, t, logits, labels, seg_bounds, inv, lse = ctx.saved_tensors
         M = y.shape[0]
         if ctx.rows is not None:
@@ -793,9 +802,8 @@ class _MLMHeadFn(torch.autograd.Function):
             n = _active_row_count(ctx.rows)
             if 2 * n <= M:
                 if n == 0:
-                    return idx_all[:0].long(), y.new_zeros((0, y.shape[1]))
+                    return idx_all[:0], y.new_zeros((extra_rows, y.shape[1]))
                 idx = idx_all[:n]
-                sel = idx.long()
                 dl = torch.empty((n, logits.shape[1]), device=y.device, dtype=torch.bfloat16)
                 ops.ce_bwd(logits, V, labels, seg_bounds, ctx.nseg, inv, gs, lse, dl, rows=idx)
                 t_c, t0_c, pre_c, y_c, mean_c, rstd_c = ops.gather_rows([t, t0, pre, y, mean, rstd], idx)      # one launch
@@ -804,7 +812,9 @@ class _MLMHeadFn(torch.autograd.Function):
                 dt0 = ops.ln_bwd(dt, t0_c, mean_c, rstd_c, w["mlm_ln_g"], w["g_mlm_ln_g"], w["g_mlm_ln_b"])
                 dpre = ops.gelu_bwd(dt0, pre_c)
                 ops.gemm_tn(dpre, y_c, w["g_Wt"], bias_out=w["g_bt"])
-                return sel, ops.gemm_nt(dpre, w["WtT"])
+                dy_all = torch.empty((n + extra_rows, y.shape[1]), device=y.device, dtype=torch.bfloat16)
+                ops.gemm_nt(dpre, w["WtT"], out=dy_all[:n])
+                return idx, dy_all
         # dense path: dlogits with the per-pass upstream gradients folded in; in place unless the scores were handed to the caller
         dl = torch.empty(logits.shape, device=logits.device, dtype=torch.bfloat16) if (ctx.keep_logits or logits.dtype != torch.bfloat16) else logits
         ops.ce_bwd(logits, V, labels, seg_bounds, ctx.nseg, inv, gs, lse, dl)
@@ -1367,16 +1377,15 @@ class _HeadsFn(torch.autograd.Function):
         tanh_lo = top.num_labels == 1
         if mlm is not None:
             mlm = mlm.detach().float().contiguous()
-        out4, seeds = ops.heads_loss_fwd(P, XP, rel, ap, lo, sent, B, top.beta, tanh_lo, mlm=mlm, alpha=top.alpha)
+        out4, seeds, loss, aux = ops.heads_loss_fwd(P, XP, rel, ap, lo, sent, B, top.beta, tanh_lo, mlm=mlm, alpha=top.alpha)
         ctx.top, ctx.B = top, B
         ctx.nmlm, ctx.alpha = (0 if mlm is None else mlm.numel()), float(top.alpha)
         ctx.save_for_backward(first, P, Apre, g, Cc, T, seeds)
         logits_out = torch.tanh(lo) if tanh_lo else lo
         ctx.mark_non_differentiable(t_rel, rel, logits_out)
         ctx.set_materialize_grads(False)
-        aux = out4[:3].clone()
         ctx.mark_non_differentiable(aux)
-        return out4[4 if mlm is not None else 3].clone(), aux, logits_out, t_rel, rel
+        return loss, aux, logits_out, t_rel, rel
 
     @staticmethod
     def backward(ctx, d, *_unused):
@@ -1391,11 +1400,11 @@ class _HeadsFn(torch.autograd.Function):
         qs = (top.cpc_zt.net, top.cpc_zv.net, top.cpc_za.net)
         n = 3 * B * H
         dev = first.device
-        seeds = seeds.clone()                                                        # backward may run twice (retain_graph)
-        ops.heads_scale(seeds, d.reshape(1).float().contiguous())
+        # one launch: the seeds scaled by the upstream gradient (out of place: backward may run twice), the zero fill of dT | dC | dfirst
+        # (the backward products are summed into them) and the gradient of the per-pass MLM losses
+        seeds, zb, dmlm = ops.heads_seed(seeds, d.reshape(1).float().contiguous(), 7 * B * H, ctx.nmlm, (ctx.alpha / ctx.nmlm) if ctx.nmlm else 0.0)
         dXP, dPc = seeds[:n].view(3, B, H), seeds[n:2 * n].view(3 * B, H)
         dlo, drel = seeds[2 * n:2 * n + B].view(B, 1), seeds[2 * n + B:].view(2 * B, 2)
-        zb = torch.zeros(B * H + 3 * B * H + 3 * B * H, device=dev, dtype=torch.float32)             # dT | dC | dfirst: summed into
         dT, dC, dfirst = zb[:B * H].view(B, H), zb[B * H:4 * B * H].view(B, 3 * H), zb[4 * B * H:].view(3 * B, H)
         ops.skinny_mm([(dT, None, 0, False, [(dXP[0], qs[0].weight, 1, 0), (dXP[1], qs[1].weight, 1, 0), (dXP[2], qs[2].weight, 1, 0),
                                             (dlo, c2.weight, 1, 0)])])
@@ -1411,7 +1420,6 @@ class _HeadsFn(torch.autograd.Function):
                             (dpre, first, pool.weight.grad, pool.bias.grad), (drel, first[B:], al.weight.grad, al.bias.grad)])
         E3, dg3 = E.view(3, B, H), dg.view(3, B, 1)
         ops.heads_colsum([(E3[m], vs3[m].weight.grad) for m in range(3)] + [(dg3[m], vs3[m].bias.grad) for m in range(3)])
-        dmlm = (d.reshape(1).float() * (ctx.alpha / ctx.nmlm)).expand(ctx.nmlm) if ctx.nmlm else None
         return dfirst, None, None, None, dmlm
 
 

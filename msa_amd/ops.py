@@ -747,12 +747,12 @@ def ce_fwd(logits, V, labels, seg_bounds, nseg):
     lib = _lib.load()
     M = logits.shape[0]
     inv = torch.empty(4, device=logits.device, dtype=torch.float32)
-    loss = torch.empty(4, device=logits.device, dtype=torch.float32)
+    loss = torch.empty(nseg, device=logits.device, dtype=torch.float32)   # exactly nseg (<= 4) entries are written: returned as it is, not as a view
     lse = torch.empty(M, device=logits.device, dtype=torch.float32)
     assert logits.dtype in (torch.bfloat16, torch.float32)
     _lib.check(lib.mmbert_ce_fwd(_stream(), logits.data_ptr(), logits.stride(0), V, labels.data_ptr(), M, seg_bounds.data_ptr(), nseg,
                                  inv.data_ptr(), loss.data_ptr(), lse.data_ptr(), 1 if logits.dtype == torch.float32 else 0), "mmbert_ce_fwd")
-    return loss[:nseg], inv, lse
+    return loss, inv, lse
 
 
 def ce_bwd(logits, V, labels, seg_bounds, nseg, inv, gscale, lse, dlogits, rows=None):
@@ -823,8 +823,9 @@ def heads_gate_fwd(P, Apre, vws, vbs, B):
 
 
 def heads_loss_fwd(P, XP, rel, ap, lo, sent, B, beta, tanh_lo, mlm=None, alpha=1.0):
-    """returns (out5, seeds) with out5 = [ap_loss, label_loss, nce, heads_loss, alpha * mean(mlm) + heads_loss] and
-    seeds = [dXP (3BH) | dPc (3BH) | dlo (B) | drel (4B)] for an upstream gradient of 1."""
+    """returns (out5, seeds, loss, aux) with out5 = [ap_loss, label_loss, nce, heads_loss, alpha * mean(mlm) + heads_loss],
+    seeds = [dXP (3BH) | dPc (3BH) | dlo (B) | drel (4B)] for an upstream gradient of 1, loss = out5[4] (0-dim) and aux = out5[:3] in
+    buffers of their own (no views: what an autograd function may return)."""
     H = P.shape[1]
     n = 3 * B * H
     seeds = torch.empty(2 * n + 5 * B, device=P.device, dtype=torch.float32)
@@ -832,15 +833,28 @@ def heads_loss_fwd(P, XP, rel, ap, lo, sent, B, beta, tanh_lo, mlm=None, alpha=1
     if mlm is not None:
         assert mlm.dtype == torch.float32 and mlm.is_contiguous()
     part = torch.empty(3, device=P.device, dtype=torch.float32)
+    loss = torch.empty((), device=P.device, dtype=torch.float32)
+    aux = torch.empty(3, device=P.device, dtype=torch.float32)
     base = seeds.data_ptr()
     _lib.check(_lib.load().mmbert_heads_loss_fwd(_stream(), P.data_ptr(), XP.data_ptr(), rel.data_ptr(), ap.data_ptr(), lo.data_ptr(), sent.data_ptr(),
                                                  B, H, float(beta), int(tanh_lo), out4.data_ptr(), base, base + 4 * n, base + 4 * (2 * n + B), base + 4 * 2 * n,
-                                                 part.data_ptr(), _ptr(mlm), 0 if mlm is None else mlm.numel(), float(alpha)), "mmbert_heads_loss_fwd")
-    return out4, seeds
+                                                 part.data_ptr(), _ptr(mlm), 0 if mlm is None else mlm.numel(), float(alpha),
+                                                 loss.data_ptr(), aux.data_ptr()), "mmbert_heads_loss_fwd")
+    return out4, seeds, loss, aux
 
 
 def heads_scale(x, s):
     _lib.check(_lib.load().mmbert_heads_scale(_stream(), x.data_ptr(), x.numel(), s.data_ptr()), "mmbert_heads_scale")
+
+
+def heads_seed(seeds, d, nzero, nmlm, coef):
+    """(seeds * d, a zero-filled fp32 buffer of nzero elements, d * coef expanded to nmlm elements or None) in one launch (mmbert_heads_seed)."""
+    buf = torch.empty(seeds.numel() + nzero + nmlm, device=seeds.device, dtype=torch.float32)
+    n = seeds.numel()
+    base = buf.data_ptr()
+    _lib.check(_lib.load().mmbert_heads_seed(_stream(), seeds.data_ptr(), n, d.data_ptr(), base, base + 4 * n, nzero, base + 4 * (n + nzero), nmlm, float(coef)),
+               "mmbert_heads_seed")
+    return buf[:n], buf[n:n + nzero], (buf[n + nzero:] if nmlm else None)
 
 
 def heads_gate_bwd(dC, P, Apre, g, vws, dPc, B):
@@ -862,6 +876,18 @@ def heads_tanh_bwd(dP, P):
     dpre = torch.empty_like(P)
     _lib.check(_lib.load().mmbert_heads_tanh_bwd(_stream(), dP.data_ptr(), P.data_ptr(), dpre.data_ptr(), P.numel()), "mmbert_heads_tanh_bwd")
     return dpre
+
+
+def compact_rows(rows, extra, row_map=None):
+    """(int64, int32) lists ``map[cat(rows, extra)]`` in one launch (mmbert_compact_rows): rows int32 or int64, extra int64, row_map int64 or None."""
+    n, ne = rows.numel(), extra.numel()
+    out64 = torch.empty(n + ne, device=extra.device, dtype=torch.int64)
+    out32 = torch.empty(n + ne, device=extra.device, dtype=torch.int32)
+    assert rows.dtype in (torch.int32, torch.int64) and extra.dtype == torch.int64 and rows.is_contiguous() and extra.is_contiguous()
+    assert row_map is None or (row_map.dtype == torch.int64 and row_map.is_contiguous())
+    r32, r64 = (rows.data_ptr(), None) if rows.dtype == torch.int32 else (None, rows.data_ptr())
+    _lib.check(_lib.load().mmbert_compact_rows(_stream(), r32, r64, n, extra.data_ptr(), ne, _ptr(row_map), out64.data_ptr(), out32.data_ptr()), "mmbert_compact_rows")
+    return out64, out32
 
 
 def gather_rows(srcs, idx32):
