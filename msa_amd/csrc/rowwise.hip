@@ -679,23 +679,33 @@ __global__ __launch_bounds__(256) void embed_gather_kernel(const int64_t* __rest
 __global__ __launch_bounds__(256) void embed_scatter_kernel(const int64_t* __restrict__ ids, const int64_t* __restrict__ tts,
                                                             const bf16_t* __restrict__ d, int ldd, int n, int T, int H, int V,
                                                             float* __restrict__ gword, float* __restrict__ gtype, float* __restrict__ gpos) {
-    // (round 4) blockIdx.y = a slice of the sequences: T workgroups alone left 4/5 of the chip idle behind 48 dependent row reads each
-    // (47 us at the headline shape, on the critical path in front of the optimizer); a position row then takes gridDim.y adds instead of one
+    // (round 4) The loop over the sequences was one dependent memory round trip per row (id -> branch -> atomics: 47 us for 48 rows per
+    // workgroup, on the critical path in front of the optimizer): the rows now come in BATCHES of 8 whose loads are issued together, and
+    // blockIdx.y takes every gridDim.y-th batch -- one slice by default: more slices LOSE (every slice adds its token-type sums to the
+    // same two rows: T x slices same-address atomics per element; 8 slices with a row per trip: 85 us), the rest is the word rows' atomics.
     const int p = blockIdx.x;
     for (int col = threadIdx.x * 4; col < H; col += 1024) {
         float ps[4] = {0.f, 0.f, 0.f, 0.f}, t0[4] = {0.f, 0.f, 0.f, 0.f}, t1[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 4
-        for (int i = p + (int)blockIdx.y * T; i < n; i += T * (int)gridDim.y) {
-            const long id = ids[i];
-            const bool tt = tts ? (tts[i] != 0) : false;
-            const bf16x4 v = *(const bf16x4*)(d + (size_t)i * ldd + col);
-            const bool word = gword != nullptr && id > 0 && id < V;
+        for (int i0 = p + (int)blockIdx.y * 8 * T; i0 < n; i0 += 8 * T * (int)gridDim.y) {
+            long id[8]; bool tt[8]; bf16x4 v[8];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float f = bf2f(v[r]);
-                ps[r] += f;
-                if (tt) t1[r] += f; else t0[r] += f;
-                if (word) atomicAdd(gword + (size_t)id * H + col + r, f);
+            for (int u = 0; u < 8; ++u) {
+                const int i = min(i0 + u * T, n - 1);              // (clamped: a row past the end is loaded and not used)
+                id[u] = ids[i];
+                tt[u] = tts ? (tts[i] != 0) : false;
+                v[u] = *(const bf16x4*)(d + (size_t)i * ldd + col);
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                if (i0 + u * T >= n) break;
+                const bool word = gword != nullptr && id[u] > 0 && id[u] < V;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float f = bf2f(v[u][r]);
+                    ps[r] += f;
+                    if (tt[u]) t1[r] += f; else t0[r] += f;
+                    if (word) atomicAdd(gword + (size_t)id[u] * H + col + r, f);
+                }
             }
         }
 #pragma unroll
@@ -1484,7 +1494,9 @@ int mmbert_embed_scatter(hipStream_t stream, const int64_t* ids, const int64_t* 
     if (n <= 0) return 0;
     if (H > LN_MAXV * 256 || (H & 3) || (ldd & 3) || T <= 0) return -1;
     const int seqs = (n + T - 1) / T;
-    const int slices = seqs >= 32 ? 8 : (seqs >= 8 ? 4 : 1);
+    int slices = 1;        // measured at the headline shape (tools/bench_embed_scatter.py): 1 / 2 / 4 / 8 slices = 37.8 / 39.1 / 49.0 / 59.2 us (47 before the batches)
+    (void)seqs;
+    if (const char* e = getenv("MMBERT_EMBED_SLICES")) { const int v = atoi(e); if (v >= 1 && v <= 64) slices = v; }   // A/B switch, read per call
     hipLaunchKernelGGL(embed_scatter_kernel, dim3(T < n ? T : n, slices), dim3(256), 0, stream, ids, tts, (const bf16_t*)d, ldd, n, T, H, V, gword, gtype, gpos);
     MMB_CHECK_LAUNCH();
     return 0;

@@ -567,6 +567,7 @@ class _TrunkFn(torch.autograd.Function):
         npass = len(lens)
         layout = split if split is not None else plan["layout"]
         compact, t.compact = t.compact, None                      # (rows in the caller's order, their gradients): set by the MLM head
+        top._join_heads_backward()                                # (safety net: normally joined by the MLM head's backward)
         top._flat.settle([w["g_word_pad"]])                       # no MLM-head launch has overwritten a dropped table gradient (no labelled row):
                                                                   # zero it before the embedding rows are added / the slice is reduced
         if top.head_grad_hook is not None:
@@ -748,6 +749,8 @@ class _MLMHeadFn(torch.autograd.Function):
             sel, dy_all = res
             n = sel.numel()
             dyl = dy_all[:n]
+            if dfirst is not None:
+                ctx.top._join_heads_backward()
             if nf and _MLMHeadFn._compact_ok(ctx, t, n, dfirst):
                 first = t.top_rows[1]
                 df = dfirst if dfirst.shape[0] == first.numel() else dfirst.view(-1, first.numel(), dfirst.shape[1]).sum(0)   # ([CLS] rows repeated: fused)
@@ -760,6 +763,7 @@ class _MLMHeadFn(torch.autograd.Function):
         else:
             dy = res
         if dfirst is not None:                                # a [CLS] row may also carry a label: add, after the copy
+            ctx.top._join_heads_backward()
             if dy is None:
                 dy = torch.zeros((ctx.M, dfirst.shape[1]), device=dfirst.device, dtype=torch.bfloat16)
             dy.index_add_(0, ctx.first_rows, dfirst.to(dy.dtype))
@@ -858,6 +862,18 @@ class _GpuModelBase(nn.Module):
         if s is None:
             s = self._side_stream = torch.cuda.Stream()
         return s
+
+    def _heads_stream(self):
+        s = self.__dict__.get("_heads_side_stream")
+        if s is None:
+            s = self.__dict__["_heads_side_stream"] = torch.cuda.Stream()
+        return s
+
+    def _join_heads_backward(self):
+        """The current stream waits for the heads' backward chain if it ran on the side stream (overlap_heads_backward)."""
+        ev = self.__dict__.pop("_heads_join", None)
+        if ev is not None:
+            torch.cuda.current_stream().wait_event(ev)
 
     @property
     def input_stream(self):
@@ -1400,9 +1416,42 @@ class _HeadsFn(torch.autograd.Function):
         qs = (top.cpc_zt.net, top.cpc_zv.net, top.cpc_za.net)
         n = 3 * B * H
         dev = first.device
+        d1 = d.reshape(1).float().contiguous()
+        coef = (ctx.alpha / ctx.nmlm) if ctx.nmlm else 0.0
+        # (round 4, opt-in: model.overlap_heads_backward) The heads' backward -- ten launches of 5-30 us in a dependency chain -- and the MLM
+        # head's sparse backward -- eleven more -- are independent until the [CLS] rows' gradient joins the labelled rows': with the joint
+        # loss assembled here (mlm given) the MLM head's backward is the next node, so this chain can run on a side stream beside it.  Only
+        # the gradient of the per-pass MLM losses (d * alpha / passes) is produced on the current stream; the consumer of dfirst joins
+        # (_join_heads_backward: _MLMHeadFn.backward, and _TrunkFn.backward as a safety net).
+        side = top._heads_stream() if (ctx.nmlm and getattr(top, "overlap_heads_backward", False)) else None
+        if side is not None:
+            main = torch.cuda.current_stream()
+            _, _, dmlm = ops.heads_seed(seeds[:0], d1, 0, ctx.nmlm, coef)
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                dfirst = _HeadsFn._backward_chain(ctx, top, first, P, Apre, g, Cc, T, seeds, d1, 0, 0.0)[0]
+            for t_ in (first, P, Apre, g, Cc, T, seeds, d1):
+                t_.record_stream(side)
+            dfirst.record_stream(main)
+            ev = torch.cuda.Event()
+            ev.record(side)
+            top.__dict__["_heads_join"] = ev
+            return dfirst, None, None, None, dmlm
+        dfirst, dmlm = _HeadsFn._backward_chain(ctx, top, first, P, Apre, g, Cc, T, seeds, d1, ctx.nmlm, coef)
+        return dfirst, None, None, None, dmlm
+
+    @staticmethod
+    def _backward_chain(ctx, top, first, P, Apre, g, Cc, T, seeds, d1, nmlm, coef):
+        B = ctx.B
+        H = P.shape[1]
+        pool, al, at = top.bert.pooler.dense, top.cls.align, top.attn
+        vs3 = (top.vt, top.vv, top.vs)
+        c1, c2 = top.classifier1_1, top.classifier1_2
+        qs = (top.cpc_zt.net, top.cpc_zv.net, top.cpc_za.net)
+        n = 3 * B * H
         # one launch: the seeds scaled by the upstream gradient (out of place: backward may run twice), the zero fill of dT | dC | dfirst
         # (the backward products are summed into them) and the gradient of the per-pass MLM losses
-        seeds, zb, dmlm = ops.heads_seed(seeds, d.reshape(1).float().contiguous(), 7 * B * H, ctx.nmlm, (ctx.alpha / ctx.nmlm) if ctx.nmlm else 0.0)
+        seeds, zb, dmlm = ops.heads_seed(seeds, d1, 7 * B * H, nmlm, coef)
         dXP, dPc = seeds[:n].view(3, B, H), seeds[n:2 * n].view(3 * B, H)
         dlo, drel = seeds[2 * n:2 * n + B].view(B, 1), seeds[2 * n + B:].view(2 * B, 2)
         dT, dC, dfirst = zb[:B * H].view(B, H), zb[B * H:4 * B * H].view(B, 3 * H), zb[4 * B * H:].view(3 * B, H)
@@ -1420,7 +1469,7 @@ class _HeadsFn(torch.autograd.Function):
                             (dpre, first, pool.weight.grad, pool.bias.grad), (drel, first[B:], al.weight.grad, al.bias.grad)])
         E3, dg3 = E.view(3, B, H), dg.view(3, B, 1)
         ops.heads_colsum([(E3[m], vs3[m].weight.grad) for m in range(3)] + [(dg3[m], vs3[m].bias.grad) for m in range(3)])
-        return dfirst, None, None, None, dmlm
+        return dfirst, dmlm
 
 
 class MMBertForPretraining(_GpuModelBase):

@@ -174,6 +174,31 @@ def test_lazy_zero_of_the_dense_weight_gradients_is_invisible():
     assert not m2._flat.stale and float(m2._flat.grads.abs().max()) == 0.0
 
 
+def test_heads_backward_on_a_side_stream_gives_the_same_gradients():
+    """Round 4 (opt-in, model.overlap_heads_backward): the heads' backward chain runs on a side stream beside the MLM head's sparse
+    backward and joins where the [CLS] rows' gradient is consumed.  Same gradients as in line (fp32 atomics aside), three steps in a row
+    (the caching allocator must not hand the chain's operands out while the side stream reads them)."""
+    m = build()
+    m.eval()
+    batches = [batch_to(synthetic_batch(2, 16, 40, 24, vocab=CFG["vocab"], seed=50 + i), DEV) for i in range(3)]
+    m._ensure_ready(torch.device(DEV, 0))
+    flat = m._flat
+    got = {}
+    for overlap in (False, True, False, True):
+        m.overlap_heads_backward = overlap
+        gs = []
+        for b in batches:
+            flat.grads.zero_(); flat.stale.clear()
+            out, _ = m(**b)
+            out[0].mean().backward()
+            torch.cuda.synchronize()
+            gs.append(flat.grads.clone())
+        got.setdefault(overlap, []).append(gs)
+    m.overlap_heads_backward = False
+    for a, b_ in zip(got[False][0] + got[False][1], got[True][0] + got[True][1]):
+        assert float(a.abs().max()) > 0 and float((a - b_).norm() / a.norm()) < 1e-5
+
+
 def _dp_worker(rank, world, port, q):
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)         # 1-GPU box: both ranks share cuda:0, gloo moves the bytes
