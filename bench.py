@@ -463,6 +463,9 @@ def reference_default_leg(a, dev, ops, wrap_state):
            "final_loss": round(float(last), 4),
            "workload": f"REF:train.py:28,32,38 defaults: bert-large ({L}-layer d={H} heads={heads} I={I}), T=P={T} (S = {T}/{2 * T}/{2 * T}), batch {B}, "
                        "train mode (dropout on), AdamW; pair-position MLM labels = copy of the text labels (REF:trainer.py:50,53)"}
+    from msa_amd.model import _auto_defer_wgrads
+    rec["weight_gradients"] = ("all layers in one call of whole 256-tile rounds at the end of backward" if _auto_defer_wgrads(H, I, L, dev)
+                               else "one launch per layer pair") + " (chosen by shape: model._auto_defer_wgrads)"
     S3 = T + 4 * T
     fwd = 2 * S3 * L * (4 * H * H + 2 * H * I) + 4 * (T * T + 2 * (2 * T) ** 2) * H * L + 2 * S3 * H * H + 2 * S3 * H * V + 2 * T * (35 + 74) * H
     rec["tflop_per_sample"] = round(3.0 * fwd / 1e12, 4)

@@ -219,6 +219,25 @@ class _JointFn(torch.autograd.Function):
         return de1, None, None, None, None, None, None, None
 
 
+_cu_count = {}
+
+
+def _auto_defer_wgrads(H, I, L, x_dev) -> bool:
+    """Whether the encoder's weight gradients go out as ONE call of whole 256-tile rounds at the end of backward instead of one launch per
+    layer pair: yes when the deferred call fills its rounds clearly better than a pair's launch does.  Measured (same process):
+    12-layer d = 768 -- a pair is 216 tiles on 256 CUs (0.84), eleven layers 4.64 rounds (0.93) -- +-0 (profiles/r4_ab_deferred_wgrads.log);
+    bert-large, the reference's default -- a pair is 384 tiles = 1.5 rounds (0.75), 23 layers 17.25 rounds (0.96) -- deferred -2.2 % of the
+    step (19.55 -> 19.12 ms, profiles/r4_ab_refdef_wgrads.log).  Costs the layers' operands staying alive (~0.2 GB per layer)."""
+    key = str(x_dev)
+    cus = _cu_count.get(key)
+    if cus is None:
+        cus = _cu_count[key] = int(torch.cuda.get_device_properties(x_dev).multi_processor_count)
+    c = lambda n: (n + 255) // 256
+    t = 2 * c(I) * c(H) + c(3 * H) * c(H) + c(H) * c(H)            # 256 x 256 tiles of a layer's four weight gradients
+    fill = lambda tiles: tiles / float(((tiles + cus - 1) // cus) * cus)
+    return L > 2 and fill((L - 1) * t) >= fill(2 * t) + 0.15
+
+
 def _wgrad(top, probs):
     """One weight-gradient launch for ``probs`` = [(dY, X, gW (view of the flat gradient buffer), gb)]: it OVERWRITES gradients the
     optimizer has dropped (lazy zero, flat.FlatParams.take_accumulate) and accumulates otherwise."""
@@ -281,8 +300,11 @@ class _EncoderFn:
         # A/B against round 1's form (bias sums inside LayerNorm', one reduce launch per call): 16.58 vs 16.76 ms per step
         lnd = ops.LnDeferred(2 * L)
         pair_wgrads, held = getattr(top, "pair_wgrads", True), None
-        # (model.defer_wgrads, opt-in: measured +-0 in the step, see the comment at its use)
-        defer_wgrads, deferred = (top.grad_hook is None and getattr(top, "defer_wgrads", False)), []
+        # (model.defer_wgrads: None = by shape (_auto_defer_wgrads), True / False forced; see the comment at its use)
+        dw = getattr(top, "defer_wgrads", None)
+        if dw is None:
+            dw = _auto_defer_wgrads(H, top.config.intermediate_size, L, x_dev=saved[0][0].device)
+        defer_wgrads, deferred = (top.grad_hook is None and bool(dw)), []
         for i in reversed(range(L)):
             lw = top._lw[i]
             saved_i = saved[i]
@@ -338,7 +360,8 @@ class _EncoderFn:
                 # into slabs + a reduce).  The operands just stay alive until then (~190 MB per layer).  Round 4, same-process A/B of
                 # the train step: 14.010 ms against 13.989 for the paired form (profiles/r4_ab_deferred_wgrads.log) -- filling the 40
                 # idle CUs buys nothing: with 256 instead of 216 CUs multiplying, every tile takes proportionally longer (the chip
-                # holds its clock down under this load: DESIGN 3.1), as the balanced-atomics and side-stream forms had hinted.  Opt-in.
+                # holds its clock down under this load: DESIGN 3.1), as the balanced-atomics and side-stream forms had hinted.  Where a
+                # pair's launch fills its rounds badly (bert-large: 384 tiles = 1.5 rounds) the deferred call wins: _auto_defer_wgrads.
                 deferred.extend(probs)
                 top._layer_grads_done(i)
                 continue
