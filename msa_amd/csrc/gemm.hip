@@ -1002,8 +1002,9 @@ __global__ __launch_bounds__(512, 2) void gemm_nt8_kernel(const GemmNT p) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 2, wc = wave & 3;
     constexpr int BMT = 64 * MQ;                                 // tile rows
-    constexpr int AP = MQ / 2;                                   // LDS-DMA pieces per wave and A half-tile (B half-tiles: always 2)
-    constexpr int INFL = 4 + AP;                                 // this wave's LDS-DMAs of the three half-tiles that stay in flight (B0h, A0h, B1h)
+    // LDS-DMA pieces per wave and A half-tile (B half-tiles: always 2): MQ / 2 -- for the 192-row tile (MQ = 3: an A half-tile is 96 rows =
+    // 12 pieces over 8 waves) TWO for waves 0-3 and ONE for waves 4-7.  The counted vmcnt waits are per wave, so the two classes run two
+    // compile-time copies of everything below the set-up (`body`): a run-time branch around one LDS-DMA inside the loop makes hipcc drain.
     const int tiles_n = (p.N + 255) >> 8, tiles_m = (p.M + BMT - 1) / BMT;
     const int ntiles = tiles_m * tiles_n, G = gridDim.x;
     const int nt = p.K >> 6;                                     // K tiles (K % 128 == 0: an even count, >= 4)
@@ -1042,13 +1043,14 @@ __global__ __launch_bounds__(512, 2) void gemm_nt8_kernel(const GemmNT p) {
     Src& nxt = MULTI ? nxt_store : cur;                          // single-tile form: the "next tile" is this one again (dead re-reads)
     if constexpr (MULTI) nxt_store = cur;
     // half-tile ids in the order of first use: 0 = B0h, 1 = A0h, 2 = B1h, 3 = A1h
-    auto stage = [&](int buf, int which, const Src& o, int kt) {
+    auto stage_c = [&](auto apw_c, int buf, int which, const Src& o, int kt) {
+        constexpr int APW = decltype(apw_c)::value;
         const uint32_t kb = (uint32_t)kt * 128u;
         const int h = which >> 1;
         char* base = smem + buf * 65536 + ((which & 1) ? 0 : 32768) + h * 16384 + wave * 1024;
         if (which & 1) {
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, LPTR(base), 16, o.a[h][0], kb, 0, 0);
-            if constexpr (AP == 2) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, LPTR(base + 8192), 16, o.a[h][1], kb, 0, 0);
+            if constexpr (APW == 2) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, LPTR(base + 8192), 16, o.a[h][1], kb, 0, 0);
         } else {
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, LPTR(base), 16, o.b[h][0], kb, 0, 0);
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, LPTR(base + 8192), 16, o.b[h][1], kb, 0, 0);
@@ -1096,6 +1098,9 @@ __global__ __launch_bounds__(512, 2) void gemm_nt8_kernel(const GemmNT p) {
                 }
     };
 
+    auto body = [&](auto apw_c) {
+    constexpr int INFL = 4 + decltype(apw_c)::value;             // this wave's LDS-DMAs of the three half-tiles that stay in flight (B0h, A0h, B1h)
+    auto stage = [&](int buf, int which, const Src& o, int kt) { stage_c(apw_c, buf, which, o, kt); };
     // ---- prologue: K tile 0 (4 half-tiles, even buffer) and the first 3 half-tiles of K tile 1 (odd buffer) of the first tile ----
     stage(0, 0, cur, 0); stage(0, 1, cur, 0); stage(0, 2, cur, 0); stage(0, 3, cur, 0);
     stage(1, 0, cur, 1); stage(1, 1, cur, 1); stage(1, 2, cur, 1);
@@ -1275,6 +1280,12 @@ __global__ __launch_bounds__(512, 2) void gemm_nt8_kernel(const GemmNT p) {
     }
 #undef NT8_KTILE
 #undef NT8_PHASE
+    };
+    if constexpr (MQ == 3) {
+        if (wave < 4) body(std::integral_constant<int, 2>{}); else body(std::integral_constant<int, 1>{});
+    } else {
+        body(std::integral_constant<int, MQ / 2>{});
+    }
     if (wr == 0) __builtin_amdgcn_s_barrier();                    // balances the stagger
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // the dead tail half-tiles
 #endif
@@ -1294,6 +1305,7 @@ static int launch_nt8(hipStream_t s, const GemmNT& p, int bm, int tiles, int wor
     q.group_m = group_m;
     q.tile_counter = q.tile_counter_next = nullptr;
     if (bm == 128) return launch_nt8_form<EPI, false, 2>(s, q, workgroups);    // (128-row tiles: single-round launches only)
+    if (bm == 192) return launch_nt8_form<EPI, false, 3>(s, q, workgroups);    // (192-row tiles: single-round launches only)
     const char* f = getenv("MMBERT_NT_8PHASE_FORM");              // A/B switch, read per call: "multi" runs the multi-tile form everywhere
     if (tiles > workgroups || (f && f[0] == 'm')) return launch_nt8_form<EPI, true, 4>(s, q, workgroups);
     return launch_nt8_form<EPI, false, 4>(s, q, workgroups);
@@ -1383,6 +1395,17 @@ static NTChoice nt_choose(const GemmNT& p, int epi) {
                 if (sscanf(q, "%d:%d:%d", &n, &k, &e) == 3 && n == p.N && k == p.K && e == epi) shape_on = true;
                 q = strchr(q, ';');
                 if (q) ++q;
+            }
+        }
+        // (round 4, second half) single-round launches whose 192-row tiles ALSO fit the chip in one round -- the input gradients at ~13 850
+        // packed rows: 165 tiles of 256 rows on 256 CUs, 219 of 192 -- take the 192-row tile: 3/4 of the MFMAs and 7/8 of the LDS-DMAs per
+        // K tile on more of the chip (MMBERT_NT_8PHASE_BM192=0: A/B switch, read per call)
+        {
+            const int t192 = ((p.M + 191) / 192) * tn;
+            const char* e192 = getenv("MMBERT_NT_8PHASE_BM192");
+            if (g_nt_force == 0 && lvl >= 1 && ntp_eligible(p) && t192 <= cus && 2 * t256 > cus && !(e192 && atoi(e192) == 0)) {
+                c.kernel = NTK_8PHASE; c.bm = 192; c.tiles = t192; c.workgroups = t192; c.group_m = ntp_group_m(p.M, p.N, p.K, epi, 192, t192, cus);
+                return c;
             }
         }
         const bool multi_ok = (t256 > cus) && !p.tile_counter && (lvl >= 3 || (lvl >= 2 && !huge_b) || shape_on);

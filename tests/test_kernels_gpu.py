@@ -132,6 +132,41 @@ def test_gemm_nt_8phase_kernel_headline_shapes_every_epilogue(ops, K):
     assert_close(aux, ref + bias, 1e-2, 3e-2, "gelu aux")
 
 
+@pytest.mark.parametrize("K", [768, 2304, 3072])
+def test_gemm_nt_8phase_192_row_tiles_input_gradient_shapes(ops, K, monkeypatch):
+    """Round 4: the 8-phase kernel on 192-row tiles (MQ = 3: an A half-tile is 96 rows = 12 LDS-DMA pieces, two for waves 0-3 and one for
+    waves 4-7 -- two compile-time copies of the K loop with their own counted vmcnt) for single-round launches whose 192-row tiles also
+    fit the chip in one round: the input gradients at ~13 850 packed rows (165 tiles of 256 rows, 219 of 192).  Ragged last row panel;
+    the default dispatch picks it; every epilogue against fp32 torch, to one bf16 ulp of the largest entry against the 256-row form
+    (MMBERT_NT_8PHASE_BM192=0), and exact on small integers."""
+    M, N = 13850 - 37, 768
+    d = ops.gemm_nt_describe(M, N, K)
+    assert d["kernel"] == "8phase" and d["tile"] == "192x256" and d["tiles"] == 72 * 3 <= d["cus"], d
+    A, B = bf(rnd(M, K, seed=31, scale=0.5)).to(DEV), bf(rnd(N, K, seed=32, scale=0.05)).to(DEV)
+    bias, R = rnd(N, seed=33).to(DEV), bf(rnd(M, N, seed=34)).to(DEV)
+    ref = A.float() @ B.float().t()
+    drop = ops.make_drop(0.1, 17, 3)
+    keep = ops.dropout_mask(M * N, drop, DEV).view(M, N).float()
+    u = R.float().requires_grad_(True)
+    torch.nn.functional.gelu(u).sum().backward()
+    cases = {"plain": ({}, ref), "bias": (dict(bias=bias), ref + bias), "resid": (dict(resid=R), ref + R.float()),
+             "bias_resid_drop": (dict(bias=bias, resid=R, drop=drop), (ref + bias) * keep * drop[2] + R.float()),
+             "gelu": (dict(bias=bias, gelu=True), torch.nn.functional.gelu(ref + bias)), "gelu_bwd": (dict(gelu_bwd_u=R), ref * u.grad),
+             "bias_f32": (dict(bias=bias, out_f32=True), ref + bias)}
+    for name, (kw, want) in cases.items():
+        got = ops.gemm_nt(A, B, **kw)
+        assert_close(got, want, 1e-2, 3e-2, name)
+        monkeypatch.setenv("MMBERT_NT_8PHASE_BM192", "0")
+        assert ops.gemm_nt_describe(M, N, K)["tile"] == "256x256"
+        other = ops.gemm_nt(A, B, **kw)
+        monkeypatch.delenv("MMBERT_NT_8PHASE_BM192")
+        assert float((got.float() - other.float()).abs().max()) <= 2.0 ** -7 * float(other.float().abs().max()), name
+    Ai = ((torch.arange(M)[:, None] * 5 + torch.arange(K)[None, :] * 3) % 3 - 1.0)
+    Bi = ((torch.arange(N)[:, None] * 2 + torch.arange(K)[None, :] * 11) % 2).float()
+    out = ops.gemm_nt(bf(Ai).to(DEV), bf(Bi).to(DEV), out_f32=True)
+    assert torch.equal(out, Ai.to(DEV) @ Bi.to(DEV).t())
+
+
 @pytest.mark.parametrize("K", [1024, 4096])
 def test_gemm_nt_8phase_128_row_tiles_reference_default_shapes(ops, K):
     """The 8-phase kernel on 128-row tiles (MQ = 2: A half-tiles of 64 rows, one LDS-DMA piece per wave, 5 in flight): what the
