@@ -992,7 +992,7 @@ __global__ __launch_bounds__(512, 2) void gemm_ntp_kernel(const GemmNT p) {
 // -------------------------------------------------------------------------------------------------
 // MULTI = false: one tile per workgroup (launches of no more tiles than CUs -- the form the train step uses): no next-tile bookkeeping,
 // 40 registers fewer.  MULTI = true: the workgroup walks tiles b, b + G, ... and the half-tile stream crosses the tile seams.
-// MQ = 16-row blocks per quadrant along M: 4 (256-row tile) or 2 (128-row tile: A half-tiles of 64 rows, ONE LDS-DMA piece per wave;
+// MQ = 16-row blocks per quadrant along M: 4 (256-row tile), 3 (192 rows), 7 = 4 in A half 0 and 3 in A half 1 (224 rows) or 2 (128-row tile: A half-tiles of 64 rows, ONE LDS-DMA piece per wave;
 // for launches whose 256-row tiles would leave more than half the chip idle -- the reference's default model, M = 6400 x N = 1024).
 template <int EPI, bool MULTI, int MQ>
 __global__ __launch_bounds__(512, 2) void gemm_nt8_kernel(const GemmNT p) {
@@ -1001,7 +1001,9 @@ __global__ __launch_bounds__(512, 2) void gemm_nt8_kernel(const GemmNT p) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 2, wc = wave & 3;
-    constexpr int BMT = 64 * MQ;                                 // tile rows
+    // MQ encodes the 16-row blocks a wave owns in A half 0 / A half 1: 4 -> (4, 4) 256 rows, 3 -> (3, 3) 192, 2 -> (2, 2) 128, 7 -> (4, 3) 224
+    constexpr int MQ0 = (MQ == 7) ? 4 : MQ, MQ1 = (MQ == 7) ? 3 : MQ, NB = MQ0 + MQ1;
+    constexpr int BMT = 32 * NB;                                 // tile rows
     // LDS-DMA pieces per wave and A half-tile (B half-tiles: always 2): MQ / 2 -- for the 192-row tile (MQ = 3: an A half-tile is 96 rows =
     // 12 pieces over 8 waves) TWO for waves 0-3 and ONE for waves 4-7.  The counted vmcnt waits are per wave, so the two classes run two
     // compile-time copies of everything below the set-up (`body`): a run-time branch around one LDS-DMA inside the loop makes hipcc drain.
@@ -1030,7 +1032,8 @@ __global__ __launch_bounds__(512, 2) void gemm_nt8_kernel(const GemmNT p) {
             const uint32_t chunk_b = (uint32_t)(pos ^ (((r >> 1) & 1) | (((r >> 3) & 3) << 1)));
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
-                const int ga = tm0 + (r / (16 * MQ)) * (32 * MQ) + h * (16 * MQ) + (r % (16 * MQ));   // (piece i = 1 of a 64-row A half: never issued)
+                const int mqh = h ? MQ1 : MQ0;                  // (a piece past the half-tile's 32 * mqh rows is never issued)
+                const int ga = tm0 + (r / (16 * mqh)) * (16 * NB) + (h ? 16 * MQ0 : 0) + (r % (16 * mqh));
                 const int gb = tn0 + (r >> 5) * 64 + h * 32 + (r & 31);
                 o.a[h][i] = ((uint32_t)min(ga, p.M - 1) * (uint32_t)p.lda + chunk_a * 8u) * 2u;
                 o.b[h][i] = ((uint32_t)min(gb, p.N - 1) * (uint32_t)p.ldb + chunk_b * 8u) * 2u;
@@ -1050,7 +1053,9 @@ __global__ __launch_bounds__(512, 2) void gemm_nt8_kernel(const GemmNT p) {
         char* base = smem + buf * 65536 + ((which & 1) ? 0 : 32768) + h * 16384 + wave * 1024;
         if (which & 1) {
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, LPTR(base), 16, o.a[h][0], kb, 0, 0);
-            if constexpr (APW == 2) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, LPTR(base + 8192), 16, o.a[h][1], kb, 0, 0);
+            // second piece of this A half-tile: every wave (128 rows), no wave (64 rows), or this wave's class (96 rows)
+            const int mqh = h ? MQ1 : MQ0;
+            if (mqh == 4 || (mqh == 3 && APW == 2)) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, LPTR(base + 8192), 16, o.a[h][1], kb, 0, 0);
         } else {
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, LPTR(base), 16, o.b[h][0], kb, 0, 0);
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, LPTR(base + 8192), 16, o.b[h][1], kb, 0, 0);
@@ -1063,20 +1068,22 @@ __global__ __launch_bounds__(512, 2) void gemm_nt8_kernel(const GemmNT p) {
     const int fr = lane & 15, fq = lane >> 4;
     const int swa = ((fq ^ (fr >> 1)) & 7) << 4;                                  // k step 0: chunk fq; k step 1: the same ^ 64 bytes
     const int swb = ((fq ^ (((fr >> 1) & 1) | ((fr >> 2) << 1))) & 7) << 4;       // key of B row 8 (fr >> 2) + 4 j + (fr & 3)
-    const lds_cptr a_rd = (lds_cptr)LPTR(smem) + (wr * (16 * MQ) + fr) * 128;
+    const lds_cptr a_rd = (lds_cptr)LPTR(smem) + (wr * (16 * MQ0) + fr) * 128;    // (half 1 of the 224-row tile: wave row 1 starts 16 * MQ1 rows in, see read_a)
     const lds_cptr b_rd = (lds_cptr)LPTR(smem) + 32768 + (wc * 32 + 8 * (fr >> 2) + (fr & 3)) * 128;
     lds_cptr a_rd1 = a_rd + 65536, b_rd1 = b_rd + 65536;        // second buffer: ds offsets are 16-bit
     asm volatile("" : "+v"(a_rd1), "+v"(b_rd1));
 
-    bf16x8 af[2][MQ], b0f[2][2], b1f[2][2];
-    f32x4 acc[2 * MQ][4];
+    bf16x8 af[2][MQ0], b0f[2][2], b1f[2][2];
+    f32x4 acc[NB][4];
 
     auto read_a = [&](int buf, int h) {
-        const lds_cptr ab = buf ? a_rd1 : a_rd;
+        lds_cptr ab = buf ? a_rd1 : a_rd;
+        if (MQ0 != MQ1 && h) ab += wr * (16 * (MQ1 - MQ0) * 128);     // (wave-uniform: half 1's wave rows are 16 * MQ1 apart, not 16 * MQ0)
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-            for (int i = 0; i < MQ; ++i) af[ks][i] = *(lds_frag)(ab + h * 16384 + i * 2048 + (swa ^ (ks * 64)));
+            for (int i = 0; i < MQ0; ++i)
+                if (i < (h ? MQ1 : MQ0)) af[ks][i] = *(lds_frag)(ab + h * 16384 + i * 2048 + (swa ^ (ks * 64)));
     };
     auto read_b = [&](int buf, int h, bf16x8 (&bf)[2][2]) {
         const lds_cptr bb = buf ? b_rd1 : b_rd;
@@ -1090,16 +1097,18 @@ __global__ __launch_bounds__(512, 2) void gemm_nt8_kernel(const GemmNT p) {
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-            for (int i = 0; i < MQ; ++i)
+            for (int i = 0; i < MQ0; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {   // operands swapped (B first): a lane holds 4 consecutive COLUMNS of one output row
-                    f32x4& c = acc[qa * MQ + i][qb * 2 + j];
+                    if (i >= (qa ? MQ1 : MQ0)) continue;
+                    f32x4& c = acc[qa * MQ0 + i][qb * 2 + j];
                     c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[ks][j], af[ks][i], (first && ks == 0) ? (f32x4){0.f, 0.f, 0.f, 0.f} : c, 0, 0, 0);
                 }
     };
 
     auto body = [&](auto apw_c) {
-    constexpr int INFL = 4 + decltype(apw_c)::value;             // this wave's LDS-DMAs of the three half-tiles that stay in flight (B0h, A0h, B1h)
+    // this wave's LDS-DMAs of the three half-tiles that stay in flight (B0h, A0h, B1h): 4 + its pieces of A half 0
+    constexpr int INFL = 4 + (MQ0 == 4 ? 2 : (MQ0 == 2 ? 1 : decltype(apw_c)::value));
     auto stage = [&](int buf, int which, const Src& o, int kt) { stage_c(apw_c, buf, which, o, kt); };
     // ---- prologue: K tile 0 (4 half-tiles, even buffer) and the first 3 half-tiles of K tile 1 (odd buffer) of the first tile ----
     stage(0, 0, cur, 0); stage(0, 1, cur, 0); stage(0, 2, cur, 0); stage(0, 3, cur, 0);
@@ -1130,7 +1139,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt8_kernel(const GemmNT p) {
     // by lgkmcnt(8) before that phase's first barrier) is restaged in phase 2; a0 (phase 1) in phase 3; b1 (phase 2) in phase 4; a1
     // (phase 3) in phase 1 of the next K tile -- two phases after their reads, which covers the group that runs a barrier behind.
 #define NT8_KTILE(D, S1, K1, S2, K2, FIRST)                                                                                   \
-    NT8_PHASE((read_b(D, 0, b0f), __builtin_amdgcn_sched_barrier(0), read_a(D, 0)), 2 * MQ, stage(D ^ 1, 3, S1, K1), -1, 0, 0, b0f, FIRST) \
+    NT8_PHASE((read_b(D, 0, b0f), __builtin_amdgcn_sched_barrier(0), read_a(D, 0)), 2 * MQ0, stage(D ^ 1, 3, S1, K1), -1, 0, 0, b0f, FIRST) \
     NT8_PHASE(read_b(D, 1, b1f), -1, stage(D, 0, S2, K2), -1, 0, 1, b1f, FIRST)                                               \
     NT8_PHASE(read_a(D, 1), -1, stage(D, 1, S2, K2), -1, 1, 1, b1f, FIRST)                                                    \
     NT8_PHASE((void)0, -1, stage(D, 2, S2, K2), INFL, 1, 0, b0f, FIRST)
@@ -1168,10 +1177,10 @@ __global__ __launch_bounds__(512, 2) void gemm_nt8_kernel(const GemmNT p) {
         const int efr = elane & 15, efq = elane >> 4;
         const float alpha = q.alpha * (q.alpha_dev ? *q.alpha_dev : 1.0f);
         const bool interior = (m0 + BMT <= q.M) && (n0 + 256 <= q.N);
-        const int mrow = m0 + wr * (32 * MQ) + efr;                  // + 16 i
+        const int mrow = m0 + wr * (16 * NB) + efr;                  // + 16 i
         const int ncol = n0 + wc * 64 + efq * 8;                     // 8 columns here (h = 0) and 8 at + 32 (h = 1)
         constexpr int PRE = 3;
-        bf16x8 pre[2 * MQ][2];
+        bf16x8 pre[NB][2];
         auto load_pre = [&](int i) {
             if constexpr (EPI & (EPI_RESID | EPI_GELU_BWD)) {
                 const bf16_t* src = (EPI & EPI_RESID) ? q.R : q.U;
@@ -1202,7 +1211,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt8_kernel(const GemmNT p) {
         const uint32_t seed0 = (EPI & EPI_RESID) ? ((uint32_t)mrow * halfN + ((uint32_t)ncol >> 1)) * MMB_WEYL + q.drop_stream : 0u;
         const uint32_t seed_row = 16u * halfN * MMB_WEYL;
 #pragma unroll
-        for (int i = 0; i < 2 * MQ; ++i) {
+        for (int i = 0; i < NB; ++i) {
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
 #pragma unroll
@@ -1227,8 +1236,8 @@ __global__ __launch_bounds__(512, 2) void gemm_nt8_kernel(const GemmNT p) {
             }
         }
 #pragma unroll
-        for (int i = 0; i < 2 * MQ; ++i) {
-            if (i + PRE < 2 * MQ) load_pre(i + PRE);
+        for (int i = 0; i < NB; ++i) {
+            if (i + PRE < NB) load_pre(i + PRE);
             const int m = mrow + 16 * i;
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
@@ -1281,10 +1290,10 @@ __global__ __launch_bounds__(512, 2) void gemm_nt8_kernel(const GemmNT p) {
 #undef NT8_KTILE
 #undef NT8_PHASE
     };
-    if constexpr (MQ == 3) {
+    if constexpr (MQ0 == 3 || MQ1 == 3) {                          // a 96-row A half-tile: waves 0-3 issue two of its pieces, waves 4-7 one
         if (wave < 4) body(std::integral_constant<int, 2>{}); else body(std::integral_constant<int, 1>{});
     } else {
-        body(std::integral_constant<int, MQ / 2>{});
+        body(std::integral_constant<int, MQ0 / 2>{});
     }
     if (wr == 0) __builtin_amdgcn_s_barrier();                    // balances the stagger
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // the dead tail half-tiles
@@ -1306,6 +1315,7 @@ static int launch_nt8(hipStream_t s, const GemmNT& p, int bm, int tiles, int wor
     q.tile_counter = q.tile_counter_next = nullptr;
     if (bm == 128) return launch_nt8_form<EPI, false, 2>(s, q, workgroups);    // (128-row tiles: single-round launches only)
     if (bm == 192) return launch_nt8_form<EPI, false, 3>(s, q, workgroups);    // (192-row tiles: single-round launches only)
+    if (bm == 224) return launch_nt8_form<EPI, false, 7>(s, q, workgroups);    // (224-row tiles: single-round launches only)
     const char* f = getenv("MMBERT_NT_8PHASE_FORM");              // A/B switch, read per call: "multi" runs the multi-tile form everywhere
     if (tiles > workgroups || (f && f[0] == 'm')) return launch_nt8_form<EPI, true, 4>(s, q, workgroups);
     return launch_nt8_form<EPI, false, 4>(s, q, workgroups);
@@ -1405,6 +1415,15 @@ static NTChoice nt_choose(const GemmNT& p, int epi) {
             const char* e192 = getenv("MMBERT_NT_8PHASE_BM192");
             if (g_nt_force == 0 && lvl >= 1 && ntp_eligible(p) && t192 <= cus && 2 * t256 > cus && !(e192 && atoi(e192) == 0)) {
                 c.kernel = NTK_8PHASE; c.bm = 192; c.tiles = t192; c.workgroups = t192; c.group_m = ntp_group_m(p.M, p.N, p.K, epi, 192, t192, cus);
+                return c;
+            }
+            // ... 224-row tiles (A half 0 = 128 rows, A half 1 = 96) where 192-row ones do not fit but these do -- the forward N = 768 shapes
+            // at 18 400 rows: 216 tiles of 256 rows, 249 of 224 -- are built, exact, and +0.6 % SLOWER in the step (14.031 -> 14.114 ms,
+            // profiles/r4_ab_8phase_bm224.log): 12 % less work per tile on 15 % more CUs does not pay, where 25 % less on 33 % more (the
+            // 192-row case above) does.  Opt-in: MMBERT_NT_8PHASE_BM224=1 (A/B switch, read per call).
+            const char* e224 = getenv("MMBERT_NT_8PHASE_BM224");
+            if (g_nt_force == 0 && lvl >= 1 && ntp_eligible(p) && t224 <= cus && t224 > t256 && 2 * t256 > cus && (e224 && atoi(e224) == 1)) {
+                c.kernel = NTK_8PHASE; c.bm = 224; c.tiles = t224; c.workgroups = t224; c.group_m = ntp_group_m(p.M, p.N, p.K, epi, 224, t224, cus);
                 return c;
             }
         }

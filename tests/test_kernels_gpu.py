@@ -95,7 +95,7 @@ def test_gemm_nt256_exact_integers(ops, mode, M):
 
 
 @pytest.mark.parametrize("K", [768, 2304, 3072])
-def test_gemm_nt_8phase_kernel_headline_shapes_every_epilogue(ops, K):
+def test_gemm_nt_8phase_kernel_headline_shapes_every_epilogue(ops, K, monkeypatch):
     """Round 4: the 8-phase kernel (one 256 x 256 tile per workgroup, 64-deep K tiles, LDS-DMA half-tiles 3 ahead) takes every launch whose
     tiles fit the chip in one round -- in the train step the N = 768 shapes: out-proj / FFN-down (+ bias + dropout + residual) and the
     input gradients (+ residual, plain) at K = 768 / 2304 / 3072.  At the step's own size with a ragged last row panel (M = 18 400 - 37):
@@ -130,6 +130,42 @@ def test_gemm_nt_8phase_kernel_headline_shapes_every_epilogue(ops, K):
     aux = torch.empty((M, N), device=DEV, dtype=torch.bfloat16)                      # the GELU epilogue's second output
     ops.gemm_nt(A, B, bias=bias, gelu=True, aux=aux)
     assert_close(aux, ref + bias, 1e-2, 3e-2, "gelu aux")
+
+
+@pytest.mark.parametrize("K", [768, 3072])
+def test_gemm_nt_8phase_224_row_tiles_forward_shapes(ops, K, monkeypatch):
+    """Round 4: 224-row tiles (A half 0 = 128 rows: two LDS-DMA pieces per wave; A half 1 = 96 rows: two for waves 0-3, one for waves 4-7;
+    a wave owns 4 + 3 row blocks) for single-round launches where 192-row tiles do not fit the chip but these do: the forward N = 768
+    shapes (out-proj, FFN-down) at 18 400 rows -- 249 tiles instead of 216.  Opt-in (MMBERT_NT_8PHASE_BM224=1: measured +0.6 % in the
+    step).  Ragged last row panel; every epilogue against fp32 torch and to one bf16 ulp of the largest entry against the 256-row
+    form; exact on small integers."""
+    M, N = 18400 - 37, 768
+    monkeypatch.setenv("MMBERT_NT_8PHASE_BM224", "1")
+    d = ops.gemm_nt_describe(M, N, K)
+    assert d["kernel"] == "8phase" and d["tile"] == "224x256" and d["tiles"] == 82 * 3 <= d["cus"], d
+    A, B = bf(rnd(M, K, seed=41, scale=0.5)).to(DEV), bf(rnd(N, K, seed=42, scale=0.05)).to(DEV)
+    bias, R = rnd(N, seed=43).to(DEV), bf(rnd(M, N, seed=44)).to(DEV)
+    ref = A.float() @ B.float().t()
+    drop = ops.make_drop(0.1, 19, 2)
+    keep = ops.dropout_mask(M * N, drop, DEV).view(M, N).float()
+    u = R.float().requires_grad_(True)
+    torch.nn.functional.gelu(u).sum().backward()
+    cases = {"plain": ({}, ref), "bias": (dict(bias=bias), ref + bias), "resid": (dict(resid=R), ref + R.float()),
+             "bias_resid_drop": (dict(bias=bias, resid=R, drop=drop), (ref + bias) * keep * drop[2] + R.float()),
+             "gelu": (dict(bias=bias, gelu=True), torch.nn.functional.gelu(ref + bias)), "gelu_bwd": (dict(gelu_bwd_u=R), ref * u.grad),
+             "bias_f32": (dict(bias=bias, out_f32=True), ref + bias)}
+    for name, (kw, want) in cases.items():
+        got = ops.gemm_nt(A, B, **kw)
+        assert_close(got, want, 1e-2, 3e-2, name)
+        monkeypatch.setenv("MMBERT_NT_8PHASE_BM224", "0")
+        assert ops.gemm_nt_describe(M, N, K)["tile"] == "256x256"
+        other = ops.gemm_nt(A, B, **kw)
+        monkeypatch.setenv("MMBERT_NT_8PHASE_BM224", "1")
+        assert float((got.float() - other.float()).abs().max()) <= 2.0 ** -7 * float(other.float().abs().max()), name
+    Ai = ((torch.arange(M)[:, None] * 5 + torch.arange(K)[None, :] * 3) % 3 - 1.0)
+    Bi = ((torch.arange(N)[:, None] * 2 + torch.arange(K)[None, :] * 11) % 2).float()
+    out = ops.gemm_nt(bf(Ai).to(DEV), bf(Bi).to(DEV), out_f32=True)
+    assert torch.equal(out, Ai.to(DEV) @ Bi.to(DEV).t())
 
 
 @pytest.mark.parametrize("K", [768, 2304, 3072])
