@@ -14,7 +14,9 @@
  *     measurement switches read from the environment once per process -- schedule choices only, the results do not depend
  *     on them: MMBERT_NT_GROUP_M, MMBERT_NT_GM_TABLE, MMBERT_NT_QUEUE_GLOBAL, MMBERT_NT_TALL (tile walk / queue / tile height of the persistent GEMM),
  *     MMBERT_LN_ROWS, MMBERT_LN_BWD_ROWS, MMBERT_LN_BWD_BLOCKS, MMBERT_LN_NV4 (LayerNorm rows per wave / grid / register sizing),
- *     MMBERT_ATTN_HEAD_FAST (grid order of the attention kernels; read per call), MMBERT_ATTN_EXTRA_LDS (occupancy experiments).
+ *     MMBERT_ATTN_HEAD_FAST (grid order of the attention kernels; read per call), MMBERT_ATTN_EXTRA_LDS (occupancy experiments),
+ *     MMBERT_NT_8PHASE / _BM128 / _BM192 / _BM224 / _FORM / _MULTI (which launches the 8-phase NT kernel takes and on which tile height),
+ *     MMBERT_TN_8PHASE (the weight-gradient kernel's K loop), MMBERT_EMBED_SLICES (grid of the embedding scatter).
  * bf16 tensors are row-major `uint16` storage; "ld*" are leading dimensions in elements.
  * REF: = /root/reference/<file>:<line>;  HF: = transformers models/bert/modeling_bert.py (5.15.0).
  */
