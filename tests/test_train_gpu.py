@@ -584,8 +584,15 @@ def test_trained_state_gradients_match_oracle_without_calibrator():
                 assert r["rel_err"] < 0.5 and r["rel_err"] * r["norm"] < 1e-4, (n, r)
         else:
             # pooler, gate (attn, vt / vv / vs), classifier1_1 / 1_2 measured <= 2.3 %; the alignment head's weight 7.9 % (its
-            # gradient sums +-0.5 / B residuals over nearly identical [CLS] rows: norm 0.23 against 12-34 for the others)
-            assert r["rel_err"] < (0.12 if n.startswith("cls.align") else 0.08), (n, r)
+            # gradient sums +-0.5 / B residuals over nearly identical [CLS] rows: norm 0.23 against 12-34 for the others).  Late round 4:
+            # 26 steps at lr 5e-4 do not reach ONE state -- the trajectory is chaotic in the fp32 atomics' order: seven runs of this test
+            # ended with |d align| = 0.085 ... 3.1 and a joint loss of 5.6 ... 11.7 on the unseen batch (tools/_dbg_trained.py) -- while
+            # the ABSOLUTE error of the alignment gradient stayed at 0.014-0.018 in all of them (0.6 % ... 19.6 % relative): one bf16
+            # rounding of the [CLS] rows, as for CPC above.  So: 12 % relative or 0.03 absolute (1e-3 of the pooler's gradient norm).
+            if n.startswith("cls.align"):
+                assert r["rel_err"] < 0.12 or r["rel_err"] * r["norm"] < 0.03, (n, r)
+            else:
+                assert r["rel_err"] < 0.08, (n, r)
 
 
 def _nccl_world1_worker(port, q):
