@@ -199,7 +199,7 @@ def test_heads_backward_on_a_side_stream_gives_the_same_gradients():
     lo, k = flat.offset["bert.pooler.dense.weight"], flat.numel["bert.pooler.dense.weight"]
     # Run-to-run differences of the SAME configuration are bimodal here: the fp32 atomic order of the heads' products can flip a bf16
     # rounding where the [CLS] rows' gradient joins the encoder's (1e-6 or 1.3e-4 in L2 on the second batch, in line against in line:
-    # tools/_dbg_overlap.py) -- hence the bound of the other "same function, other launch path" comparisons, not a multiple of the noise
+    # tools/dbg_overlap.py) -- hence the bound of the other "same function, other launch path" comparisons, not a multiple of the noise
     for a, b_ in zip(got[False][0] + got[False][1], got[True][0] + got[True][1]):
         assert float(a.abs().max()) > 0 and rel(a, b_) < 2e-3, rel(a, b_)
         # the side chain's own products (fp32 only, summed with atomics over 64-deep chunks)
@@ -586,7 +586,7 @@ def test_trained_state_gradients_match_oracle_without_calibrator():
             # pooler, gate (attn, vt / vv / vs), classifier1_1 / 1_2 measured <= 2.3 %; the alignment head's weight 7.9 % (its
             # gradient sums +-0.5 / B residuals over nearly identical [CLS] rows: norm 0.23 against 12-34 for the others).  Late round 4:
             # 26 steps at lr 5e-4 do not reach ONE state -- the trajectory is chaotic in the fp32 atomics' order: seven runs of this test
-            # ended with |d align| = 0.085 ... 3.1 and a joint loss of 5.6 ... 11.7 on the unseen batch (tools/_dbg_trained.py) -- while
+            # ended with |d align| = 0.085 ... 3.1 and a joint loss of 5.6 ... 11.7 on the unseen batch (tools/dbg_trained.py) -- while
             # the ABSOLUTE error of the alignment gradient stayed at 0.014-0.018 in all of them (0.6 % ... 19.6 % relative): one bf16
             # rounding of the [CLS] rows, as for CPC above.  So: 12 % relative or 0.03 absolute (1e-3 of the pooler's gradient norm).
             if n.startswith("cls.align"):

@@ -1,3 +1,5 @@
+"""Diagnostic: trainer.train_epoch for NM micro-batches with and without the lazy zero of the dense weights' gradients (AdamW.lazy_zero),
+three runs each, all pairwise parameter distances: lazy against zero-filled must look like zero-filled against zero-filled."""
 import os, sys, torch
 sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), "tests"))
 import test_train_gpu as TT

@@ -1,3 +1,6 @@
+"""Diagnostic: the gradients of three batches with the heads' backward in line / on the side stream (model.overlap_heads_backward), per
+pair the parameters that differ most -- and, with INLINE_ONLY=1, in line against in line: the run-to-run differences are bimodal (one bf16
+rounding where the [CLS] rows' gradient joins the encoder's), which is what the bound of test_heads_backward_on_a_side_stream_... allows for."""
 import os, sys, torch
 sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), "tests"))
 import test_train_gpu as TT

@@ -1,3 +1,6 @@
+"""Diagnostic: the parameters after NM micro-batches of trainer.train_epoch (MLM masking on, dropout on), twice on ordinary memory and once
+with every torch.empty poisoned (tools/poison_empty.py): a kernel that reads memory it never wrote would move the poisoned run away from
+the clean ones by more than they differ from each other (they do differ: the trajectory is chaotic in the fp32 atomics' order)."""
 import os, sys, torch
 sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), "tests")); sys.path.insert(0, os.path.join(os.getcwd(), "tools"))
 import test_train_gpu as TT

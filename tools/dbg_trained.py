@@ -1,3 +1,6 @@
+"""Diagnostic: test_trained_state_gradients_match_oracle_without_calibrator repeated on clean / poisoned torch.empty memory, printing the
+state each run ended in (the alignment head's gradient norm and error, the joint loss on the unseen batch): 26 steps at lr 5e-4 do not
+reach one state.    python tools/dbg_trained.py clean poison clean poison"""
 import os, sys, json, torch
 sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), "tests")); sys.path.insert(0, os.path.join(os.getcwd(), "tools"))
 import test_train_gpu as TT
