@@ -1315,7 +1315,10 @@ static int launch_nt8(hipStream_t s, const GemmNT& p, int bm, int tiles, int wor
     q.tile_counter = q.tile_counter_next = nullptr;
     if (bm == 128) return launch_nt8_form<EPI, false, 2>(s, q, workgroups);    // (128-row tiles: single-round launches only)
     if (bm == 192) return launch_nt8_form<EPI, false, 3>(s, q, workgroups);    // (192-row tiles: single-round launches only)
-    if (bm == 224) return launch_nt8_form<EPI, false, 7>(s, q, workgroups);    // (224-row tiles: single-round launches only)
+    if (bm == 224) {
+        if (tiles > workgroups) return launch_nt8_form<EPI, true, 7>(s, q, workgroups);      // multi-tile form on 224-row tiles (A/B: MMBERT_NT_8PHASE_M224)
+        return launch_nt8_form<EPI, false, 7>(s, q, workgroups);
+    }
     const char* f = getenv("MMBERT_NT_8PHASE_FORM");              // A/B switch, read per call: "multi" runs the multi-tile form everywhere
     if (tiles > workgroups || (f && f[0] == 'm')) return launch_nt8_form<EPI, true, 4>(s, q, workgroups);
     return launch_nt8_form<EPI, false, 4>(s, q, workgroups);
@@ -1424,6 +1427,31 @@ static NTChoice nt_choose(const GemmNT& p, int epi) {
             const char* e224 = getenv("MMBERT_NT_8PHASE_BM224");
             if (g_nt_force == 0 && lvl >= 1 && ntp_eligible(p) && t224 <= cus && t224 > t256 && 2 * t256 > cus && (e224 && atoi(e224) == 1)) {
                 c.kernel = NTK_8PHASE; c.bm = 224; c.tiles = t224; c.workgroups = t224; c.group_m = ntp_group_m(p.M, p.N, p.K, epi, 224, t224, cus);
+                return c;
+            }
+        }
+        // (round 4, last) The multi-round shapes -- QKV, FFN-up + GELU, the GELU' input gradient; not the vocabulary-sized ones -- on the
+        // MULTI-TILE 8-phase form with 224-row tiles (A half 0 = 128 rows, A half 1 = 96: MQ = 7): the ring kernel's round count (2.92 /
+        // 3.89 / 2.9 rounds at the headline shapes, where the 256-row multi-tile form started the same number of rounds of 14 % more work
+        // each and lost 1.1-1.3 %) with the 8-phase K loop.  Bit-identical to the ring kernel's results, 2-6 % faster per launch stand-alone --
+        // and in the step: same process on four boxes -1.95 % (13.734 -> 13.466 ms), +0.14 %, +0.5 %, +1.5 %; alternating 600-step processes on a fifth +0.8 % (profiles/r4_ab_8phase_m224.log):
+        // what the K loop saves in cycles comes back as time only where the box has power to spare.  OPT-IN:
+        // MMBERT_NT_8PHASE_M224=1; MMBERT_NT_8PHASE_M224_SKIP="N:K:E;..." leaves single shapes on the ring kernel (A/B switches, read per
+        // call).  No device tile queue: data-parallel runs keep the ring kernel.
+        {
+            const char* em = getenv("MMBERT_NT_8PHASE_M224");
+            bool skip = false;
+            if (const char* t = getenv("MMBERT_NT_8PHASE_M224_SKIP")) {
+                for (const char* q = t; q && *q; ) {
+                    int n = 0, k = 0, e = 0;
+                    if (sscanf(q, "%d:%d:%d", &n, &k, &e) == 3 && n == p.N && k == p.K && e == epi) skip = true;
+                    q = strchr(q, ';');
+                    if (q) ++q;
+                }
+            }
+            if ((em && atoi(em) == 1) && !skip && lvl >= 1 && g_nt_force == 0 && ntp_eligible(p) && t224 > cus && t256 > cus && !huge_b && !p.tile_counter) {
+                c.kernel = NTK_8PHASE; c.bm = 224; c.tiles = t224; c.workgroups = cus;
+                c.group_m = ntp_group_m(p.M, p.N, p.K, epi, 224, t224, cus);
                 return c;
             }
         }

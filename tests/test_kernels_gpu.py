@@ -231,15 +231,29 @@ def test_gemm_nt_8phase_128_row_tiles_reference_default_shapes(ops, K):
     assert torch.equal(out, Ai.to(DEV) @ Bi.to(DEV).t())
 
 
-@pytest.mark.parametrize("level", ["0", "3"])
+@pytest.mark.parametrize("level", ["0", "3", "m224"])
 @pytest.mark.parametrize("M,N,K", [(18400, 2304, 256), (14000, 3072, 256), (5000, 3072, 256), (9000, 1792, 256), (18400 - 37, 2304, 768)])
 def test_gemm_nt_grouped_tile_walk_exact(ops, M, N, K, level, monkeypatch):
-    """More tiles than CUs: the persistent kernels (level 0: the 4-slot-ring kernel; level 3: the 8-phase kernel in its multi-tile form,
-    whose half-tile stream crosses the tile seams) walk them in one group per XCD (ceil(row tiles / 8) row panels swept over the column
-    panels, the last group short) -- every tile exactly once, checked on small integers (exact in bf16 and in the fp32 accumulators)."""
-    monkeypatch.setenv("MMBERT_NT_8PHASE", level)
+    """More tiles than CUs: the persistent kernels (level 0: the 4-slot-ring kernel; level 3: the 8-phase kernel in its multi-tile form
+    on 256-row tiles, whose half-tile stream crosses the tile seams; m224: the same form on 224-row tiles, MMBERT_NT_8PHASE_M224=1)
+    walk them in one group per XCD (ceil(row tiles / 8) row panels swept over the column panels, the last group short) -- every tile
+    exactly once, checked on small integers (exact in bf16 and in the fp32 accumulators)."""
+    if level == "m224":
+        if K % 128:
+            pytest.skip("the 8-phase kernel needs K % 128 == 0")
+        monkeypatch.setenv("MMBERT_NT_8PHASE_M224", "1")
+    else:
+        monkeypatch.setenv("MMBERT_NT_8PHASE", level)
+        monkeypatch.setenv("MMBERT_NT_8PHASE_M224", "0")
     d = ops.gemm_nt_describe(M, N, K)
-    assert d["kernel"] == ("8phase" if level == "3" else "persistent"), d
+    if level == "m224":
+        assert d["kernel"] == "8phase", d
+        if (M, N) in ((18400, 2304), (14000, 3072), (18400 - 37, 2304)):
+            assert d["tile"] == "224x256" and d["tiles"] > d["cus"], d
+        else:
+            assert d["tiles"] <= d["cus"], d                         # one round: the single-tile forms
+    else:
+        assert d["kernel"] == ("8phase" if level == "3" else "persistent"), d
     assert d["tiles"] > d["cus"] or M <= 9000, d                 # (M = 5000 and M = 9000 x N = 1792 are one round of 256-row tiles)
     A = ((torch.arange(M)[:, None] * 5 + torch.arange(K)[None, :] * 3) % 3 - 1.0)      # entries in {-1, 0, 1} x {0, 1}: |sums| <= K, exact in bf16 up to 256
     B = ((torch.arange(N)[:, None] * 2 + torch.arange(K)[None, :] * 11) % 2).float()
@@ -259,16 +273,27 @@ def test_gemm_nt_8phase_multi_tile_form_matches_ring_kernel(ops, epi, monkeypatc
     kw = {"bias": dict(bias=bias), "gelu": dict(bias=bias, gelu=True), "gelu_bwd": dict(gelu_bwd_u=R),
           "resid_drop": dict(bias=bias, resid=R, drop=ops.make_drop(0.1, 3, 4))}[epi]
     res = {}
-    for level in ("0", "3"):
-        monkeypatch.setenv("MMBERT_NT_8PHASE", level)
+    for level in ("0", "3", "m224"):
+        if level == "m224":                                      # late round 4 (opt-in): multi-tile form on 224-row tiles
+            monkeypatch.delenv("MMBERT_NT_8PHASE", raising=False)
+            monkeypatch.setenv("MMBERT_NT_8PHASE_M224", "1")
+            d = ops.gemm_nt_describe(M, N, K, epi={"bias": 1, "gelu": 3, "gelu_bwd": 8, "resid_drop": 5}[epi])
+            assert d["kernel"] == "8phase" and d["tile"] == "224x256" and d["tiles"] > d["cus"], d
+        else:
+            monkeypatch.setenv("MMBERT_NT_8PHASE", level)
+            monkeypatch.setenv("MMBERT_NT_8PHASE_M224", "0")
         aux = torch.empty((M, N), device=DEV, dtype=torch.bfloat16) if epi == "gelu" else None
         res[level] = (ops.gemm_nt(A, B, aux=aux, **kw), aux)
     again = ops.gemm_nt(A, B, **kw)
-    assert torch.equal(again, res["3"][0])
+    assert torch.equal(again, res["m224"][0])
+    monkeypatch.delenv("MMBERT_NT_8PHASE_M224")
     scale = float(res["0"][0].float().abs().max())
     assert float((res["3"][0].float() - res["0"][0].float()).abs().max()) <= 2.0 ** -7 * scale
+    # 224-row tiles against the ring kernel's 224-row tiles: the same K order per element -> the same bits
+    assert torch.equal(res["m224"][0], res["0"][0]), float((res["m224"][0].float() - res["0"][0].float()).abs().max())
     if epi == "gelu":
         assert float((res["3"][1].float() - res["0"][1].float()).abs().max()) <= 2.0 ** -7 * float(res["0"][1].float().abs().max())
+        assert torch.equal(res["m224"][1], res["0"][1])
 
 
 def test_gemm_nt_dynamic_tile_queue_is_bit_identical(ops):
