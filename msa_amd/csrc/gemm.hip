@@ -1421,11 +1421,11 @@ static NTChoice nt_choose(const GemmNT& p, int epi) {
                 return c;
             }
             // ... 224-row tiles (A half 0 = 128 rows, A half 1 = 96) where 192-row ones do not fit but these do -- the forward N = 768 shapes
-            // at 18 400 rows: 216 tiles of 256 rows, 249 of 224 -- are built, exact, and +0.6 % SLOWER in the step (14.031 -> 14.114 ms,
-            // profiles/r4_ab_8phase_bm224.log): 12 % less work per tile on 15 % more CUs does not pay, where 25 % less on 33 % more (the
-            // 192-row case above) does.  Opt-in: MMBERT_NT_8PHASE_BM224=1 (A/B switch, read per call).
+            // at 18 400 rows: 216 tiles of 256 rows, 249 of 224.  Measured six times on several boxes (profiles/r4_ab_8phase_bm224.log): same
+            // process with 8-step windows +0.6 %; with 40-step windows -0.4, -0.5, -0.6, -0.7, -0.8 %; alternating 600-step processes
+            // -0.7 ... -0.9 %: on by default (MMBERT_NT_8PHASE_BM224=0: A/B switch, read per call).
             const char* e224 = getenv("MMBERT_NT_8PHASE_BM224");
-            if (g_nt_force == 0 && lvl >= 1 && ntp_eligible(p) && t224 <= cus && t224 > t256 && 2 * t256 > cus && (e224 && atoi(e224) == 1)) {
+            if (g_nt_force == 0 && lvl >= 1 && ntp_eligible(p) && t224 <= cus && t224 > t256 && 2 * t256 > cus && !(e224 && atoi(e224) == 0)) {
                 c.kernel = NTK_8PHASE; c.bm = 224; c.tiles = t224; c.workgroups = t224; c.group_m = ntp_group_m(p.M, p.N, p.K, epi, 224, t224, cus);
                 return c;
             }

@@ -104,6 +104,7 @@ def test_gemm_nt_8phase_kernel_headline_shapes_every_epilogue(ops, K, monkeypatc
     from msa_amd import _lib
     lib = _lib.load()
     M, N = 18400 - 37, 768
+    monkeypatch.setenv("MMBERT_NT_8PHASE_BM224", "0")           # (the default at this row count is the 224-row form, tested below)
     d = ops.gemm_nt_describe(M, N, K)
     assert d["kernel"] == "8phase" and d["tile"] == "256x256" and d["tiles"] <= d["cus"], d
     A, B = bf(rnd(M, K, seed=21, scale=0.5)).to(DEV), bf(rnd(N, K, seed=22, scale=0.05)).to(DEV)
@@ -136,11 +137,10 @@ def test_gemm_nt_8phase_kernel_headline_shapes_every_epilogue(ops, K, monkeypatc
 def test_gemm_nt_8phase_224_row_tiles_forward_shapes(ops, K, monkeypatch):
     """Round 4: 224-row tiles (A half 0 = 128 rows: two LDS-DMA pieces per wave; A half 1 = 96 rows: two for waves 0-3, one for waves 4-7;
     a wave owns 4 + 3 row blocks) for single-round launches where 192-row tiles do not fit the chip but these do: the forward N = 768
-    shapes (out-proj, FFN-down) at 18 400 rows -- 249 tiles instead of 216.  Opt-in (MMBERT_NT_8PHASE_BM224=1: measured +0.6 % in the
-    step).  Ragged last row panel; every epilogue against fp32 torch and to one bf16 ulp of the largest entry against the 256-row
-    form; exact on small integers."""
+    shapes (out-proj, FFN-down) at 18 400 rows -- 249 tiles instead of 216; the default there (-0.4 ... -0.9 % of the step).  Ragged last
+    row panel; every epilogue against fp32 torch and to one bf16 ulp of the largest entry against the 256-row form; exact on small
+    integers."""
     M, N = 18400 - 37, 768
-    monkeypatch.setenv("MMBERT_NT_8PHASE_BM224", "1")
     d = ops.gemm_nt_describe(M, N, K)
     assert d["kernel"] == "8phase" and d["tile"] == "224x256" and d["tiles"] == 82 * 3 <= d["cus"], d
     A, B = bf(rnd(M, K, seed=41, scale=0.5)).to(DEV), bf(rnd(N, K, seed=42, scale=0.05)).to(DEV)
@@ -160,7 +160,7 @@ def test_gemm_nt_8phase_224_row_tiles_forward_shapes(ops, K, monkeypatch):
         monkeypatch.setenv("MMBERT_NT_8PHASE_BM224", "0")
         assert ops.gemm_nt_describe(M, N, K)["tile"] == "256x256"
         other = ops.gemm_nt(A, B, **kw)
-        monkeypatch.setenv("MMBERT_NT_8PHASE_BM224", "1")
+        monkeypatch.delenv("MMBERT_NT_8PHASE_BM224")
         assert float((got.float() - other.float()).abs().max()) <= 2.0 ** -7 * float(other.float().abs().max()), name
     Ai = ((torch.arange(M)[:, None] * 5 + torch.arange(K)[None, :] * 3) % 3 - 1.0)
     Bi = ((torch.arange(N)[:, None] * 2 + torch.arange(K)[None, :] * 11) % 2).float()
@@ -193,9 +193,11 @@ def test_gemm_nt_8phase_192_row_tiles_input_gradient_shapes(ops, K, monkeypatch)
         got = ops.gemm_nt(A, B, **kw)
         assert_close(got, want, 1e-2, 3e-2, name)
         monkeypatch.setenv("MMBERT_NT_8PHASE_BM192", "0")
+        monkeypatch.setenv("MMBERT_NT_8PHASE_BM224", "0")
         assert ops.gemm_nt_describe(M, N, K)["tile"] == "256x256"
         other = ops.gemm_nt(A, B, **kw)
         monkeypatch.delenv("MMBERT_NT_8PHASE_BM192")
+        monkeypatch.delenv("MMBERT_NT_8PHASE_BM224")
         assert float((got.float() - other.float()).abs().max()) <= 2.0 ** -7 * float(other.float().abs().max()), name
     Ai = ((torch.arange(M)[:, None] * 5 + torch.arange(K)[None, :] * 3) % 3 - 1.0)
     Bi = ((torch.arange(N)[:, None] * 2 + torch.arange(K)[None, :] * 11) % 2).float()
