@@ -73,7 +73,7 @@ void mmbert_gemm_nt_force(int mode);
 int mmbert_gemm_nt_describe(int M, int N, int K, int epi, int with_queue, int* out);
 /* Split count of the token axis in mmbert_gemm_tn / _grouped: 0 = by shape (default), > 0 forced.  A/B benchmarking. */
 void mmbert_gemm_tn_force_splits(int splits);
-/* K loop of mmbert_gemm_tn / _grouped: 0 = the 4-slot ring of 32-token stages (default), 1 = the 8-phase form (64-token K tiles).  The
+/* K loop of mmbert_gemm_tn / _grouped: 1 = the 8-phase form (64-token K tiles, default), 0 = the 4-slot ring of 32-token stages.  The
  * weight gradients are bit-identical (same 32-token summation blocks), the bias gradients agree up to fp32 summation order.  Tests and
  * A/B benchmarking (the environment variable MMBERT_TN_8PHASE, read per call, overrides it). */
 void mmbert_gemm_tn_force_form(int form);

@@ -1433,11 +1433,13 @@ static NTChoice nt_choose(const GemmNT& p, int epi) {
         // (round 4, last) The multi-round shapes -- QKV, FFN-up + GELU, the GELU' input gradient; not the vocabulary-sized ones -- on the
         // MULTI-TILE 8-phase form with 224-row tiles (A half 0 = 128 rows, A half 1 = 96: MQ = 7): the ring kernel's round count (2.92 /
         // 3.89 / 2.9 rounds at the headline shapes, where the 256-row multi-tile form started the same number of rounds of 14 % more work
-        // each and lost 1.1-1.3 %) with the 8-phase K loop.  Bit-identical to the ring kernel's results, 2-6 % faster per launch stand-alone --
-        // and in the step: same process on four boxes -1.95 % (13.734 -> 13.466 ms), +0.14 %, +0.5 %, +1.5 %; alternating 600-step processes on a fifth +0.8 % (profiles/r4_ab_8phase_m224.log):
-        // what the K loop saves in cycles comes back as time only where the box has power to spare.  OPT-IN:
-        // MMBERT_NT_8PHASE_M224=1; MMBERT_NT_8PHASE_M224_SKIP="N:K:E;..." leaves single shapes on the ring kernel (A/B switches, read per
-        // call).  No device tile queue: data-parallel runs keep the ring kernel.
+        // each) with the 8-phase K loop.  Bit-identical to the ring kernel's results, 2-6 % faster per launch stand-alone.  In the step its
+        // first A/Bs (same process, 8-step windows, on top of the ring weight-gradient kernel) read -1.95 ... +1.5 % by box; with 40-step
+        // windows and with alternating 600-step processes, on top of the 8-phase weight-gradient kernel: -2.3 / -2.3 / -2.5 %
+        // (profiles/r4_ab_8phase_m224.log); the vocabulary projection on it as well: -0.3 / -0.5 %.  Default (= 2); MMBERT_NT_8PHASE_M224=0
+        // switches it off, =1 leaves the vocabulary-sized shapes on the ring kernel,
+        // MMBERT_NT_8PHASE_M224_SKIP="N:K:E;..." leaves single shapes on the ring kernel (A/B switches, read per call).  No device tile
+        // queue: data-parallel runs keep the ring kernel for these launches.
         {
             const char* em = getenv("MMBERT_NT_8PHASE_M224");
             bool skip = false;
@@ -1449,7 +1451,8 @@ static NTChoice nt_choose(const GemmNT& p, int epi) {
                     if (q) ++q;
                 }
             }
-            if ((em && atoi(em) == 1) && !skip && lvl >= 1 && g_nt_force == 0 && ntp_eligible(p) && t224 > cus && t256 > cus && !huge_b && !p.tile_counter) {
+            const int m224 = em ? atoi(em) : 2;
+            if (m224 >= 1 && !skip && lvl >= 1 && g_nt_force == 0 && ntp_eligible(p) && t224 > cus && t256 > cus && (!huge_b || m224 >= 2) && !p.tile_counter) {
                 c.kernel = NTK_8PHASE; c.bm = 224; c.tiles = t224; c.workgroups = cus;
                 c.group_m = ntp_group_m(p.M, p.N, p.K, epi, 224, t224, cus);
                 return c;
@@ -2263,10 +2266,11 @@ void mmbert_gemm_nt_force(int mode) {
 
 static std::atomic<int> g_tn_splits{0};   // 0 = by shape; > 0 forces the split count of the token axis (A/B benchmarking)
 void mmbert_gemm_tn_force_splits(int splits) { g_tn_splits.store(splits); }
-// 0 = the 4-slot ring of 32-token stages (gemm_tn_kernel, default), 1 = the 8-phase K loop (gemm_tn8_kernel): 7.7 % fewer cycles per token,
-// -4.5 % stand-alone, +-0 (headline) ... +0.6 % (bert-large) in the train step -- the chip answers the denser MFMA stream with a lower clock
-// (profiles/r4_stamp_tn8.log, r4_ab_tn8.log): opt-in
-static std::atomic<int> g_tn_form{0};
+// 1 = the 8-phase K loop (gemm_tn8_kernel, default), 0 = the 4-slot ring of 32-token stages (gemm_tn_kernel).  7.7 % fewer cycles per token,
+// -4.5 % stand-alone; in the train step its first A/Bs (same process, 8-step windows) read +-0 -- the chip answers the denser MFMA stream with a
+// lower clock, and a short window right behind a switch still carries the other variant's clock state --; with 40-step windows -0.6 / -0.8 %,
+// with alternating 600-step processes -0.84 % (profiles/r4_stamp_tn8.log, r4_ab_tn8.log)
+static std::atomic<int> g_tn_form{1};
 void mmbert_gemm_tn_force_form(int form) { g_tn_form.store(form != 0); }
 
 static int tn_plan(int nprob, const int* N, const int* K, int M, int* splits_out, int* tiles_out) {
@@ -2348,7 +2352,7 @@ int mmbert_gemm_tn_grouped(hipStream_t stream, int nprob, const void* const* A, 
     static std::atomic<unsigned long long> attr_done{0}, attr_done8{0};
     if (int e = mmb_allow_lds((const void*)gemm_tn_kernel, 131072, attr_done)) return e;
     if (int e = mmb_allow_lds((const void*)gemm_tn8_kernel, 131072, attr_done8)) return e;
-    // which K loop: the ring form unless the 8-phase form (gemm_tn8_kernel) is asked for (mmbert_gemm_tn_force_form / MMBERT_TN_8PHASE=1, A/B
+    // which K loop: the 8-phase form (gemm_tn8_kernel) unless the ring form is asked for (mmbert_gemm_tn_force_form / MMBERT_TN_8PHASE=0, A/B
     // switch read per call); both give the same bits in the weight gradients
     int form = g_tn_form.load();
     if (const char* e8 = getenv("MMBERT_TN_8PHASE")) form = atoi(e8) != 0;

@@ -224,18 +224,19 @@ _cu_count = {}
 
 def _auto_defer_wgrads(H, I, L, x_dev) -> bool:
     """Whether the encoder's weight gradients go out as ONE call of whole 256-tile rounds at the end of backward instead of one launch per
-    layer pair: yes when the deferred call fills its rounds clearly better than a pair's launch does.  Measured (same process):
-    12-layer d = 768 -- a pair is 216 tiles on 256 CUs (0.84), eleven layers 4.64 rounds (0.93) -- +-0 (profiles/r4_ab_deferred_wgrads.log);
-    bert-large, the reference's default -- a pair is 384 tiles = 1.5 rounds (0.75), 23 layers 17.25 rounds (0.96) -- deferred -2.2 % of the
-    step (19.55 -> 19.12 ms, profiles/r4_ab_refdef_wgrads.log).  Costs the layers' operands staying alive (~0.2 GB per layer)."""
+    layer pair (only without a gradient hook: one GPU): yes as soon as the one call has at least a full round of tiles.  Measured:
+    bert-large, the reference's default -- a pair is 384 tiles = 1.5 rounds (0.75 full), 23 layers 17.25 rounds (0.96) -- -2.2 % of the step
+    (19.55 -> 19.12 ms, profiles/r4_ab_refdef_wgrads.log); 12-layer d = 768 -- a pair is 216 tiles on 256 CUs (0.84), eleven layers 4.64
+    rounds (0.93) -- read +-0 in its first A/B (8-step windows, profiles/r4_ab_deferred_wgrads.log) and -0.6 / -0.8 % with 40-step windows,
+    -0.7 % with alternating 600-step processes (profiles/r4_ab_tn8_defer.log).  Costs the layers' operands staying alive (~0.2 GB per
+    layer).  MMBERT_DEFER_WGRADS=0/1 and model.defer_wgrads override it."""
     key = str(x_dev)
     cus = _cu_count.get(key)
     if cus is None:
         cus = _cu_count[key] = int(torch.cuda.get_device_properties(x_dev).multi_processor_count)
     c = lambda n: (n + 255) // 256
     t = 2 * c(I) * c(H) + c(3 * H) * c(H) + c(H) * c(H)            # 256 x 256 tiles of a layer's four weight gradients
-    fill = lambda tiles: tiles / float(((tiles + cus - 1) // cus) * cus)
-    return L > 2 and fill((L - 1) * t) >= fill(2 * t) + 0.15
+    return L > 2 and (L - 1) * t >= cus
 
 
 def _wgrad(top, probs):
@@ -302,6 +303,8 @@ class _EncoderFn:
         pair_wgrads, held = getattr(top, "pair_wgrads", True), None
         # (model.defer_wgrads: None = by shape (_auto_defer_wgrads), True / False forced; see the comment at its use)
         dw = getattr(top, "defer_wgrads", None)
+        if dw is None and os.environ.get("MMBERT_DEFER_WGRADS"):     # A/B switch for whole-process comparisons (bench.py builds its own model)
+            dw = os.environ["MMBERT_DEFER_WGRADS"] != "0"
         if dw is None:
             dw = _auto_defer_wgrads(H, top.config.intermediate_size, L, x_dev=saved[0][0].device)
         defer_wgrads, deferred = (top.grad_hook is None and bool(dw)), []

@@ -237,13 +237,12 @@ def test_gemm_nt_8phase_128_row_tiles_reference_default_shapes(ops, K):
 @pytest.mark.parametrize("M,N,K", [(18400, 2304, 256), (14000, 3072, 256), (5000, 3072, 256), (9000, 1792, 256), (18400 - 37, 2304, 768)])
 def test_gemm_nt_grouped_tile_walk_exact(ops, M, N, K, level, monkeypatch):
     """More tiles than CUs: the persistent kernels (level 0: the 4-slot-ring kernel; level 3: the 8-phase kernel in its multi-tile form
-    on 256-row tiles, whose half-tile stream crosses the tile seams; m224: the same form on 224-row tiles, MMBERT_NT_8PHASE_M224=1)
+    on 256-row tiles, whose half-tile stream crosses the tile seams; m224: the same form on 224-row tiles, the default since late round 4)
     walk them in one group per XCD (ceil(row tiles / 8) row panels swept over the column panels, the last group short) -- every tile
     exactly once, checked on small integers (exact in bf16 and in the fp32 accumulators)."""
     if level == "m224":
         if K % 128:
             pytest.skip("the 8-phase kernel needs K % 128 == 0")
-        monkeypatch.setenv("MMBERT_NT_8PHASE_M224", "1")
     else:
         monkeypatch.setenv("MMBERT_NT_8PHASE", level)
         monkeypatch.setenv("MMBERT_NT_8PHASE_M224", "0")
@@ -276,9 +275,9 @@ def test_gemm_nt_8phase_multi_tile_form_matches_ring_kernel(ops, epi, monkeypatc
           "resid_drop": dict(bias=bias, resid=R, drop=ops.make_drop(0.1, 3, 4))}[epi]
     res = {}
     for level in ("0", "3", "m224"):
-        if level == "m224":                                      # late round 4 (opt-in): multi-tile form on 224-row tiles
+        if level == "m224":                                      # late round 4 (default): multi-tile form on 224-row tiles
             monkeypatch.delenv("MMBERT_NT_8PHASE", raising=False)
-            monkeypatch.setenv("MMBERT_NT_8PHASE_M224", "1")
+            monkeypatch.delenv("MMBERT_NT_8PHASE_M224", raising=False)
             d = ops.gemm_nt_describe(M, N, K, epi={"bias": 1, "gelu": 3, "gelu_bwd": 8, "resid_drop": 5}[epi])
             assert d["kernel"] == "8phase" and d["tile"] == "224x256" and d["tiles"] > d["cus"], d
         else:
@@ -288,7 +287,6 @@ def test_gemm_nt_8phase_multi_tile_form_matches_ring_kernel(ops, epi, monkeypatc
         res[level] = (ops.gemm_nt(A, B, aux=aux, **kw), aux)
     again = ops.gemm_nt(A, B, **kw)
     assert torch.equal(again, res["m224"][0])
-    monkeypatch.delenv("MMBERT_NT_8PHASE_M224")
     scale = float(res["0"][0].float().abs().max())
     assert float((res["3"][0].float() - res["0"][0].float()).abs().max()) <= 2.0 ** -7 * scale
     # 224-row tiles against the ring kernel's 224-row tiles: the same K order per element -> the same bits
@@ -296,6 +294,23 @@ def test_gemm_nt_8phase_multi_tile_form_matches_ring_kernel(ops, epi, monkeypatc
     if epi == "gelu":
         assert float((res["3"][1].float() - res["0"][1].float()).abs().max()) <= 2.0 ** -7 * float(res["0"][1].float().abs().max())
         assert torch.equal(res["m224"][1], res["0"][1])
+
+
+def test_gemm_nt_vocabulary_projection_on_the_multi_tile_8phase_form(ops, monkeypatch):
+    """The vocabulary projection (N = 30 592: 120 column panels, tile walk in groups of 4 row panels) through the default dispatch -- the
+    multi-tile 8-phase form on 224-row tiles -- against the ring-persistent kernel (MMBERT_NT_8PHASE_M224=0): the same bits, bf16 and
+    fp32 scores, ragged last row panel; and against fp32 torch on a row sample."""
+    M, N, K = 4600 - 37, 30592, 768
+    A, B, bias = bf(rnd(M, K, seed=401, scale=0.5)).to(DEV), bf(rnd(N, K, seed=402, scale=0.05)).to(DEV), rnd(N, seed=403).to(DEV)
+    d = ops.gemm_nt_describe(M, N, K, epi=1)
+    assert d["kernel"] == "8phase" and d["tile"] == "224x256" and d["tiles"] > 4 * d["cus"] and d["group_m"] == 4, d
+    got, got32 = ops.gemm_nt(A, B, bias=bias), ops.gemm_nt(A, B, bias=bias, out_f32=True)
+    monkeypatch.setenv("MMBERT_NT_8PHASE_M224", "0")
+    assert ops.gemm_nt_describe(M, N, K, epi=1)["kernel"] == "persistent"
+    ref, ref32 = ops.gemm_nt(A, B, bias=bias), ops.gemm_nt(A, B, bias=bias, out_f32=True)
+    assert torch.equal(got, ref) and torch.equal(got32, ref32)
+    rows = torch.arange(0, M, 97, device=DEV)
+    assert_close(got32[rows], A[rows].float() @ B.float().t() + bias, 1e-2, 3e-2, "vocabulary rows")
 
 
 def test_gemm_nt_dynamic_tile_queue_is_bit_identical(ops):
@@ -549,7 +564,7 @@ def test_gemm_tn_8phase_form_gives_the_ring_forms_bits(ops, M, splits):
                 torch.cuda.synchronize()
                 outs[(form, accumulate)] = [(p[2].cpu(), p[3].cpu() if p[3] is not None else None) for p in probs]
     finally:
-        lib.mmbert_gemm_tn_force_form(0)
+        lib.mmbert_gemm_tn_force_form(1)
         lib.mmbert_gemm_tn_force_splits(0)
     for accumulate in (True, False):
         for i, ((w0, b0), (w1, b1)) in enumerate(zip(outs[(0, accumulate)], outs[(1, accumulate)])):

@@ -47,4 +47,4 @@ for name, nl, sets in cases:
     t0, t1 = sorted(res[0])[2], sorted(res[1])[2]
     print(f"M {M} {name:24s} ring {t0*1e3:7.1f} us {fl(nl)/t0/1e9:6.0f} TF/s | 8-phase {t1*1e3:7.1f} us {fl(nl)/t1/1e9:6.0f} TF/s | ratio {t1/t0:.3f}", flush=True)
     del ps
-lib.mmbert_gemm_tn_force_form(0)
+lib.mmbert_gemm_tn_force_form(1)
