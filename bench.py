@@ -405,8 +405,9 @@ def main():
             fl, ms, n = kern["nt"]
             ach = fl / (ms * 1e-3) / 1e12
             traffic, traffic_src = pmc_traffic_per_launch(("gemm_ntp_kernel", "gemm_nt8_kernel"))
-            res["roofline"] = {"bound": "mfma", "kernel": "the NT GEMM family behind mmbert_gemm_nt (bf16 MFMA 16x16x32, all fused epilogues): gemm_nt8_kernel (256x256 tile, 64-deep "
-                                                          "K tiles, 8 phases, LDS-DMA half-tiles 3 ahead) + gemm_ntp_kernel (224/256x256 tile stream through a 4-slot LDS-DMA ring)",
+            res["roofline"] = {"bound": "mfma", "kernel": "the NT GEMM family behind mmbert_gemm_nt (bf16 MFMA 16x16x32, all fused epilogues): gemm_nt8_kernel (64-deep K tiles, "
+                                                          "8 phases, LDS-DMA half-tiles 3 ahead: one 192/224/256x256 tile per workgroup for single-round launches, a stream of 224x256 "
+                                                          "tiles for multi-round ones) + gemm_ntp_kernel (224/256x256 tile stream through a 4-slot LDS-DMA ring: data-parallel runs)",
                                "achieved": round(ach, 1), "peak": 2500.0, "unit": "TFLOP/s", "frac": round(ach / 2500.0, 4),
                                "traffic": traffic, "traffic_source": traffic_src, "launches": n, "avg_launch_us": round(1e3 * ms / n, 2),
                                "share_of_step_time": round(ms * 1e-3 / elapsed_instr, 3),

@@ -12,7 +12,7 @@ variants = []
 for a in sys.argv[1:]:
     name, _, envs = a.partition(":")
     variants.append((name, dict(e.split("=", 1) for e in envs.split(",") if e)))
-steps, rounds = int(os.environ.get("STEPS", 6)), int(os.environ.get("ROUNDS", 5))
+steps, rounds = int(os.environ.get("STEPS", 20)), int(os.environ.get("ROUNDS", 4))      # long windows: see tools/ab_step.py
 dev = torch.device("cuda", 0)
 torch.manual_seed(0)
 L, H, heads, I, V, T, B = 24, 1024, 16, 4096, 30522, 40, 32

@@ -16,7 +16,10 @@ variants = []
 for a in sys.argv[1:]:
     name, _, envs = a.partition(":")
     variants.append((name, dict(e.split("=", 1) for e in envs.split(",") if e)))
-steps, rounds = int(os.environ.get("STEPS", 8)), int(os.environ.get("ROUNDS", 5))
+# 40-step windows (0.55 s): an 8-step window right behind a switch of variants still carries the previous variant's clock / power state --
+# variants that differ in power draw read +-1-2 % wrong that way (round 4: three "+-0" results turned into -0.7 ... -2.5 % with longer
+# windows and with alternating 600-step processes)
+steps, rounds = int(os.environ.get("STEPS", 40)), int(os.environ.get("ROUNDS", 4))
 dev = torch.device("cuda", 0)
 torch.manual_seed(0)
 model = MMBertForPretraining(MMBertConfig())
