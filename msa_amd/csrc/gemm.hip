@@ -1110,10 +1110,32 @@ __global__ __launch_bounds__(512, 2) void gemm_nt8_kernel(const GemmNT p) {
     // this wave's LDS-DMAs of the three half-tiles that stay in flight (B0h, A0h, B1h): 4 + its pieces of A half 0
     constexpr int INFL = 4 + (MQ0 == 4 ? 2 : (MQ0 == 2 ? 1 : decltype(apw_c)::value));
     auto stage = [&](int buf, int which, const Src& o, int kt) { stage_c(apw_c, buf, which, o, kt); };
+    // ---- dynamic tile queue (multi-tile form, data-parallel runs: RCCL's channel kernels hold CUs, a static share would strand tiles) --
+    // gemm_ntp_kernel's protocol: per XCD the k-th draw of XCD x is tile G + 8 k + x (the static walk's residue class: the XCD's chunk of
+    // the grouped walk holds); thread 0 draws with an inline-asm returning atomic that is only read behind counted waits (hipcc's own
+    // atomicAdd drains vmcnt(0)) and parks the result in an LDS word behind the ring; every wave picks it up a K tile later.
+    const int qx = (MULTI && p.queue_xcd) ? (int)(blockIdx.x & 7) : 0, qs = (MULTI && p.queue_xcd) ? 8 : 1;
+    auto queue_fetch = [](int* counter) {
+        int r;
+        asm volatile("global_atomic_add %0, %1, %2, %3 sc0" : "=&v"(r) : "v"(0), "v"(1), "s"(counter) : "memory");
+        return r;
+    };
+    auto vq_write = [&](int value) {
+        const uint32_t vq_addr = (uint32_t)(size_t)LPTR(smem) + 131072u;
+        asm volatile("ds_write_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" :: "v"(vq_addr), "v"(value) : "memory");
+    };
+    int first_fetch = 0;
+    if constexpr (MULTI) { if (p.tile_counter && tid == 0) first_fetch = queue_fetch(p.tile_counter + qx); }     // older than every prologue load
     // ---- prologue: K tile 0 (4 half-tiles, even buffer) and the first 3 half-tiles of K tile 1 (odd buffer) of the first tile ----
     stage(0, 0, cur, 0); stage(0, 1, cur, 0); stage(0, 2, cur, 0); stage(0, 3, cur, 0);
     stage(1, 0, cur, 1); stage(1, 1, cur, 1); stage(1, 2, cur, 1);
     __builtin_amdgcn_s_waitcnt(mmb_waitcnt(INFL, 15));            // K tile 0 landed (this wave's pieces)
+    if constexpr (MULTI) {
+        if (p.tile_counter && tid == 0) {                           // (the atomic is older than the loads the wait above has retired)
+            asm volatile("" : "+v"(first_fetch) :: "memory");
+            vq_write(G + qs * first_fetch + qx);
+        }
+    }
     __builtin_amdgcn_s_barrier();
     if (wr == 1) __builtin_amdgcn_s_barrier();                    // the stagger: group 1 runs one barrier behind group 0
 
@@ -1144,11 +1166,10 @@ __global__ __launch_bounds__(512, 2) void gemm_nt8_kernel(const GemmNT p) {
     NT8_PHASE(read_a(D, 1), -1, stage(D, 1, S2, K2), -1, 1, 1, b1f, FIRST)                                                    \
     NT8_PHASE((void)0, -1, stage(D, 2, S2, K2), INFL, 1, 0, b0f, FIRST)
 
-    for (int v = blockIdx.x; v < ntiles; v += MULTI ? G : ntiles) {
+    for (int v = blockIdx.x, vn = ntiles; v < ntiles; v = vn) {
         int tmi, tni;
         ntp_tile_mn(xcd_remap(v, ntiles), tiles_m, tiles_n, p.group_m, tmi, tni);
         const int m0 = tmi * BMT, n0 = tni << 8;
-        if constexpr (MULTI) { if (v + G < ntiles) set_src(v + G, nxt_store); }    // past the last tile: dead re-reads of this tile's first K tiles
         // Seam: K tile 0 of this tile was issued by the previous tile's last two K tiles (or by the prologue) and is followed, in
         // vector-memory issue order, by the 6 LDS-DMAs of K tile 1's first three half-tiles and by the previous epilogue's loads and
         // stores (any number of them) -- so "at most 6 outstanding" proves it landed on every path.  As a BUILTIN, so that hipcc's own
@@ -1156,7 +1177,28 @@ __global__ __launch_bounds__(512, 2) void gemm_nt8_kernel(const GemmNT p) {
         // LDS-DMA destinations), i.e. waits for the previous epilogue's last store.
         __builtin_amdgcn_s_waitcnt(mmb_waitcnt(INFL, 15));
         NT8_KTILE(0, cur, 1, cur, 2, true)
+        // the workgroup's next tile: b + G (static) or the queue's word, written a K tile or more ago and 8 barriers behind us; its source
+        // offsets are first used by the last two K tiles.  Past the last tile: dead re-reads of this tile's first K tiles.
+        int fetched = 0;
+        if constexpr (MULTI) {
+            if (p.tile_counter) {
+                int qv;
+                const uint32_t vq_addr = (uint32_t)(size_t)LPTR(smem) + 131072u;
+                asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(qv) : "v"(vq_addr) : "memory");
+                vn = __builtin_amdgcn_readfirstlane(qv);
+                if (tid == 0 && vn < ntiles) fetched = queue_fetch(p.tile_counter + qx);    // the tile after the next one; complete behind K tile 1's vmcnt
+            } else {
+                vn = v + G;
+            }
+            if (vn < ntiles) set_src(vn, nxt_store);
+        }
         NT8_KTILE(1, cur, 2, cur, 3, false)
+        if constexpr (MULTI) {
+            if (p.tile_counter && tid == 0 && vn < ntiles) {        // (every wave has read the word: that was 8 barriers ago)
+                asm volatile("" : "+v"(fetched) :: "memory");
+                vq_write(G + qs * fetched + qx);
+            }
+        }
         for (int t = 2; t < nt - 2; t += 2) {
             NT8_KTILE(0, cur, t + 1, cur, t + 2, false)
             NT8_KTILE(1, cur, t + 2, cur, t + 3, false)
@@ -1297,14 +1339,26 @@ __global__ __launch_bounds__(512, 2) void gemm_nt8_kernel(const GemmNT p) {
     }
     if (wr == 0) __builtin_amdgcn_s_barrier();                    // balances the stagger
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // the dead tail half-tiles
+    if constexpr (MULTI) {    // the last workgroup to leave hands the queue back zeroed (its draws are complete: vmcnt(0) above) for the stream's next launch
+        auto kpe = __builtin_amdgcn_kernarg_segment_ptr();
+        asm volatile("" : "+s"(kpe));
+        const __attribute__((address_space(4))) GemmNT& qe = *(const __attribute__((address_space(4))) GemmNT*)kpe;
+        if (qe.tile_counter && tid == 0) {
+            if (atomicAdd(qe.tile_counter_next, 1) == (int)gridDim.x - 1) {
+                for (int x = 0; x < 8; ++x) atomicExch(qe.tile_counter + x, 0);
+                atomicExch(qe.tile_counter_next, 0);
+            }
+        }
+    }
 #endif
 }
 
 template <int EPI, bool MULTI, int MQ>
 static int launch_nt8_form(hipStream_t s, const GemmNT& q, int workgroups) {
     static std::atomic<unsigned long long> attr_done{0};
-    if (int e = mmb_allow_lds((const void*)gemm_nt8_kernel<EPI, MULTI, MQ>, 131072, attr_done)) return e;
-    hipLaunchKernelGGL((gemm_nt8_kernel<EPI, MULTI, MQ>), dim3(workgroups), dim3(512), 131072, s, q);
+    constexpr int LDS = 131072 + (MULTI ? 64 : 0);              // (+ the tile-queue word of the multi-tile form)
+    if (int e = mmb_allow_lds((const void*)gemm_nt8_kernel<EPI, MULTI, MQ>, LDS, attr_done)) return e;
+    hipLaunchKernelGGL((gemm_nt8_kernel<EPI, MULTI, MQ>), dim3(workgroups), dim3(512), LDS, s, q);
     MMB_CHECK_LAUNCH();
     return 0;
 }
@@ -1312,7 +1366,10 @@ template <int EPI>
 static int launch_nt8(hipStream_t s, const GemmNT& p, int bm, int tiles, int workgroups, int group_m) {
     GemmNT q = p;
     q.group_m = group_m;
-    q.tile_counter = q.tile_counter_next = nullptr;
+    // the device tile queue: only the multi-tile 224-row form draws from it (data-parallel runs), one counter per XCD as in gemm_ntp_kernel
+    const bool use_queue = p.tile_counter && bm == 224 && tiles > workgroups && !(workgroups & 7);
+    if (!use_queue) q.tile_counter = q.tile_counter_next = nullptr;
+    q.queue_xcd = 1;
     if (bm == 128) return launch_nt8_form<EPI, false, 2>(s, q, workgroups);    // (128-row tiles: single-round launches only)
     if (bm == 192) return launch_nt8_form<EPI, false, 3>(s, q, workgroups);    // (192-row tiles: single-round launches only)
     if (bm == 224) {
@@ -1438,8 +1495,9 @@ static NTChoice nt_choose(const GemmNT& p, int epi) {
         // windows and with alternating 600-step processes, on top of the 8-phase weight-gradient kernel: -2.3 / -2.3 / -2.5 %
         // (profiles/r4_ab_8phase_m224.log); the vocabulary projection on it as well: -0.3 / -0.5 %.  Default (= 2); MMBERT_NT_8PHASE_M224=0
         // switches it off, =1 leaves the vocabulary-sized shapes on the ring kernel,
-        // MMBERT_NT_8PHASE_M224_SKIP="N:K:E;..." leaves single shapes on the ring kernel (A/B switches, read per call).  No device tile
-        // queue: data-parallel runs keep the ring kernel for these launches.
+        // MMBERT_NT_8PHASE_M224_SKIP="N:K:E;..." leaves single shapes on the ring kernel (A/B switches, read per call).  With a caller's
+        // tile queue (data-parallel runs) the same form draws its tiles from it (gemm_ntp_kernel's protocol; MMBERT_NT_8PHASE_QUEUE=0: the
+        // ring kernel for those launches).
         {
             const char* em = getenv("MMBERT_NT_8PHASE_M224");
             bool skip = false;
@@ -1452,7 +1510,10 @@ static NTChoice nt_choose(const GemmNT& p, int epi) {
                 }
             }
             const int m224 = em ? atoi(em) : 2;
-            if (m224 >= 1 && !skip && lvl >= 1 && g_nt_force == 0 && ntp_eligible(p) && t224 > cus && t256 > cus && (!huge_b || m224 >= 2) && !p.tile_counter) {
+            static const int q8_env = getenv("MMBERT_NT_8PHASE_QUEUE") ? atoi(getenv("MMBERT_NT_8PHASE_QUEUE")) : 1;   // 0: launches with a tile queue keep the ring kernel
+            if (m224 >= 1 && !skip && lvl >= 1 && g_nt_force == 0 && ntp_eligible(p) && t224 > cus && t256 > cus && (!huge_b || m224 >= 2) &&
+                (!p.tile_counter || (q8_env && !(cus & 7)))) {
+                c.use_queue = p.tile_counter != nullptr;
                 c.kernel = NTK_8PHASE; c.bm = 224; c.tiles = t224; c.workgroups = cus;
                 c.group_m = ntp_group_m(p.M, p.N, p.K, epi, 224, t224, cus);
                 return c;

@@ -335,14 +335,16 @@ def test_gemm_nt_dynamic_tile_queue_is_bit_identical(ops):
     assert_close(ref, torch.nn.functional.gelu(A.float() @ B.float().t() + bias), 2e-2, 2e-2, "queue launch vs torch")
 
 
-@pytest.mark.parametrize("mode", [0, 6])
+@pytest.mark.parametrize("mode", [0, 6, 7])
 @pytest.mark.parametrize("epi", ["plain", "bias", "gelu", "resid_drop", "resid", "gelu_bwd", "bias_f32"])
 def test_gemm_nt_tile_queue_bit_identical_every_instantiation(ops, epi, mode):
     """the queue's fetch is an inline-asm atomic whose result is read behind a hand-counted s_waitcnt (a compiler-inserted copy
     of that register before the wait would read stale data -> duplicate or missing tiles), and the counts depend on the epilogue's
-    store count.  So: EVERY epilogue instantiation of the persistent kernel, both tile forms (mode 0: the default 224-row form; mode 6:
-    the 256-row staggered form), on a multi-round shape whose last row panel AND last column panel are ragged (edge tiles take the
-    E = 0 waits), queue against static walk: the same bits, twice in a row on one queue buffer."""
+    store count.  So: EVERY epilogue instantiation of the persistent kernels that draw from the queue -- mode 0: the default, since late
+    round 4 the multi-tile 8-phase form on 224-row tiles (gemm_nt8_kernel<EPI, true, 7>: the draw sits between K tiles 0 and 1, its
+    result is published behind K tile 1's counted wait); mode 7 / 6: the ring kernel's 224-row form and 256-row staggered form -- on a
+    multi-round shape whose last row panel AND last column panel are ragged (edge tiles take the E = 0 waits), queue against static
+    walk: the same bits, twice in a row on one queue buffer."""
     import msa_amd.ops as O
     from msa_amd import _lib
     M, N, K = 18400 - 37, 3072 - 40, 768
@@ -355,7 +357,7 @@ def test_gemm_nt_tile_queue_bit_identical_every_instantiation(ops, epi, mode):
     try:
         _lib.load().mmbert_gemm_nt_force(mode)
         d = ops.gemm_nt_describe(M, N, K, with_queue=True)
-        assert d["kernel"] == "persistent" and d["tiles"] > d["cus"] and d["tile"] == ("256x256" if mode == 6 else "224x256"), d
+        assert d["kernel"] == ("8phase" if mode == 0 else "persistent") and d["tiles"] > d["cus"] and d["tile"] == ("256x256" if mode == 6 else "224x256"), d
         O.dynamic_tile_queue = False
         aux0 = torch.empty((M, N), device=DEV, dtype=torch.bfloat16) if epi == "gelu" else None
         ref = ops.gemm_nt(A, B, aux=aux0, **kw)
