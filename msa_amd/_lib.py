@@ -9,7 +9,9 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libmmbert_hip.so")
+# (MMBERT_LIB_PATH: a diagnostic override -- another BUILD of the same library, for whole-process A/Bs of kernel changes that have no
+# run-time switch: tools/r4_s2_altlib.sh; the stamp tools set LIB_PATH directly)
+LIB_PATH = os.environ.get("MMBERT_LIB_PATH") or os.path.join(HERE, "libmmbert_hip.so")
 
 P, I, F, U32, SZ, U64 = C.c_void_p, C.c_int, C.c_float, C.c_uint32, C.c_size_t, C.c_uint64
 

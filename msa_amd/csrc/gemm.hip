@@ -629,7 +629,10 @@ __global__ __launch_bounds__(512, 2) void gemm_ntp_kernel(const GemmNT p) {
     // i.e. a drain of the stage loads in flight at the start of every epilogue (the dynamic queue cost 1.8 % of the step that way).
     auto queue_fetch = [](int* counter) {
         int r;
-        asm volatile("global_atomic_add %0, %1, %2, %3 sc0" : "=&v"(r) : "v"(0), "v"(1), "s"(counter) : "memory");
+        // (s_nop 4: hipcc may hand the counter's address over in SGPRs it has just restored with v_readlane -- a VALU write of an SGPR needs 5 wait
+        // states before a vector-memory instruction reads it, and the hazard recognizer does not look inside inline asm: without the nops
+        // one build of the GELU' instantiation drew from a stale address and faulted)
+        asm volatile("s_nop 4\n\tglobal_atomic_add %0, %1, %2, %3 sc0" : "=&v"(r) : "v"(0), "v"(1), "s"(counter) : "memory");
         return r;
     };
     if (p.tile_counter && tid == 0)
@@ -1010,6 +1013,10 @@ __global__ __launch_bounds__(512, 2) void gemm_nt8_kernel(const GemmNT p) {
     const int tiles_n = (p.N + 255) >> 8, tiles_m = (p.M + BMT - 1) / BMT;
     const int ntiles = tiles_m * tiles_n, G = gridDim.x;
     const int nt = p.K >> 6;                                     // K tiles (K % 128 == 0: an even count, >= 4)
+    // alpha * alpha_dev[0], ONCE per workgroup and before anything is in flight: read in the epilogue (where this kernel first had it) the
+    // optional device scalar is a vector load behind a branch, and hipcc waits vmcnt(0) at the join whether or not it was issued -- every
+    // epilogue began by waiting for the next tile's in-flight LDS-DMAs (or the single-tile form's dead re-reads): one exposed memory latency per tile
+    const float alpha_all = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, p.alpha * (p.alpha_dev ? *p.alpha_dev : 1.0f))));   // (an SGPR)
 
     // ---- staging: wave w issues pieces j = w and w + 8 of a half-tile (piece = local rows 8j .. 8j + 7, 1 KiB) ----
     // The half-tiles of ALL tiles of this workgroup form one stream (persistent form, launches of more tiles than CUs): the last two
@@ -1117,7 +1124,10 @@ __global__ __launch_bounds__(512, 2) void gemm_nt8_kernel(const GemmNT p) {
     const int qx = (MULTI && p.queue_xcd) ? (int)(blockIdx.x & 7) : 0, qs = (MULTI && p.queue_xcd) ? 8 : 1;
     auto queue_fetch = [](int* counter) {
         int r;
-        asm volatile("global_atomic_add %0, %1, %2, %3 sc0" : "=&v"(r) : "v"(0), "v"(1), "s"(counter) : "memory");
+        // (s_nop 4: hipcc may hand the counter's address over in SGPRs it has just restored with v_readlane -- a VALU write of an SGPR needs 5 wait
+        // states before a vector-memory instruction reads it, and the hazard recognizer does not look inside inline asm: without the nops
+        // one build of the GELU' instantiation drew from a stale address and faulted)
+        asm volatile("s_nop 4\n\tglobal_atomic_add %0, %1, %2, %3 sc0" : "=&v"(r) : "v"(0), "v"(1), "s"(counter) : "memory");
         return r;
     };
     auto vq_write = [&](int value) {
@@ -1177,6 +1187,20 @@ __global__ __launch_bounds__(512, 2) void gemm_nt8_kernel(const GemmNT p) {
         // LDS-DMA destinations), i.e. waits for the previous epilogue's last store.
         __builtin_amdgcn_s_waitcnt(mmb_waitcnt(INFL, 15));
         NT8_KTILE(0, cur, 1, cur, 2, true)
+        // Bias row of this wave's 64 columns: ONE 4-byte-per-lane LDS-DMA into a wave-private 256 B behind the ring (gemm_ntp_kernel's way),
+        // issued here -- older than K tile 1's LDS-DMAs, so K tile 1's counted wait retires it -- and read with DS instructions in the
+        // epilogue.  (As register loads issued IN the epilogue, the way this kernel first did it, the four bias loads return only behind
+        // the 14 LDS-DMAs of the next tile's first two K tiles -- or, single-tile form, behind the dead re-reads --: vector memory retires
+        // in issue order, and every bias epilogue began with one exposed memory latency, `s_waitcnt vmcnt(4) ... vmcnt(0)`.)
+        if constexpr (EPI & EPI_BIAS) {
+            int l = lane;
+            asm volatile("" : "+v"(l));
+            auto kpb = __builtin_amdgcn_kernarg_segment_ptr();
+            asm volatile("" : "+s"(kpb));
+            const __attribute__((address_space(4))) GemmNT& qb = *(const __attribute__((address_space(4))) GemmNT*)kpb;
+            const auto rsBias = __builtin_amdgcn_make_buffer_rsrc((void*)qb.bias, 0, qb.N * 4, 0x00020000);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsBias, LPTR(smem + 131136 + wave * 256), 4, l * 4, (n0 + wc * 64) * 4, 0, 0);
+        }
         // the workgroup's next tile: b + G (static) or the queue's word, written a K tile or more ago and 8 barriers behind us; its source
         // offsets are first used by the last two K tiles.  Past the last tile: dead re-reads of this tile's first K tiles.
         int fetched = 0;
@@ -1217,7 +1241,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt8_kernel(const GemmNT p) {
         int elane = lane;
         asm volatile("" : "+v"(elane));
         const int efr = elane & 15, efq = elane >> 4;
-        const float alpha = q.alpha * (q.alpha_dev ? *q.alpha_dev : 1.0f);
+        const float alpha = alpha_all;
         const bool interior = (m0 + BMT <= q.M) && (n0 + 256 <= q.N);
         const int mrow = m0 + wr * (16 * NB) + efr;                  // + 16 i
         const int ncol = n0 + wc * 64 + efq * 8;                     // 8 columns here (h = 0) and 8 at + 32 (h = 1)
@@ -1235,14 +1259,15 @@ __global__ __launch_bounds__(512, 2) void gemm_nt8_kernel(const GemmNT p) {
 #pragma unroll
         for (int i = 0; i < PRE; ++i) load_pre(i);
         float bias[16];
-        if constexpr (EPI & EPI_BIAS) {
+        if constexpr (EPI & EPI_BIAS) {      // columns efq*8 .. +7 and + 32 .. of the wave's 64: two 32-byte pieces of its LDS bias row (inline asm: invisible to hipcc's
+            const uint32_t baddr = (uint32_t)(size_t)LPTR(smem) + 131136u + wave * 256u + efq * 32u;     // scoreboard, which would drain vmcnt(0) for the LDS-DMAs in flight)
+            f32x4 b4[4];
+            lds_read16f<0>(b4[0], baddr); lds_read16f<16>(b4[1], baddr); lds_read16f<128>(b4[2], baddr); lds_read16f<144>(b4[3], baddr);
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(b4[0]), "+v"(b4[1]), "+v"(b4[2]), "+v"(b4[3]) :: "memory");
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const float* bp = q.bias + min(ncol + 32 * h, q.N - 8);
-                const float4 b0 = *(const float4*)bp, b1 = *(const float4*)(bp + 4);
-                bias[8 * h + 0] = b0.x; bias[8 * h + 1] = b0.y; bias[8 * h + 2] = b0.z; bias[8 * h + 3] = b0.w;
-                bias[8 * h + 4] = b1.x; bias[8 * h + 5] = b1.y; bias[8 * h + 6] = b1.z; bias[8 * h + 7] = b1.w;
-            }
+            for (int c = 0; c < 4; ++c)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) bias[4 * c + r] = b4[c][r];
         }
         // phase 1 (needs no residual data): scale, bias and the dropout decision, in place in the accumulators.  Dropout seeds are linear
         // in the element index (common.h): pair(m, n) = m * N/2 + n/2 (mod 2^32) -- one multiply per lane, wave-uniform increments after it
@@ -1356,7 +1381,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt8_kernel(const GemmNT p) {
 template <int EPI, bool MULTI, int MQ>
 static int launch_nt8_form(hipStream_t s, const GemmNT& q, int workgroups) {
     static std::atomic<unsigned long long> attr_done{0};
-    constexpr int LDS = 131072 + (MULTI ? 64 : 0);              // (+ the tile-queue word of the multi-tile form)
+    constexpr int LDS = 131072 + 64 + 8 * 256;                  // ring | tile-queue word of the multi-tile form (padded) | bias rows
     if (int e = mmb_allow_lds((const void*)gemm_nt8_kernel<EPI, MULTI, MQ>, LDS, attr_done)) return e;
     hipLaunchKernelGGL((gemm_nt8_kernel<EPI, MULTI, MQ>), dim3(workgroups), dim3(512), LDS, s, q);
     MMB_CHECK_LAUNCH();
