@@ -1392,11 +1392,14 @@ static int launch_nt8(hipStream_t s, const GemmNT& p, int bm, int tiles, int wor
     GemmNT q = p;
     q.group_m = group_m;
     // the device tile queue: only the multi-tile 224-row form draws from it (data-parallel runs), one counter per XCD as in gemm_ntp_kernel
-    const bool use_queue = p.tile_counter && bm == 224 && tiles > workgroups && !(workgroups & 7);
+    const bool use_queue = p.tile_counter && tiles > workgroups && !(workgroups & 7);
     if (!use_queue) q.tile_counter = q.tile_counter_next = nullptr;
     q.queue_xcd = 1;
     if (bm == 128) return launch_nt8_form<EPI, false, 2>(s, q, workgroups);    // (128-row tiles: single-round launches only)
-    if (bm == 192) return launch_nt8_form<EPI, false, 3>(s, q, workgroups);    // (192-row tiles: single-round launches only)
+    if (bm == 192) {
+        if (tiles > workgroups) return launch_nt8_form<EPI, true, 3>(s, q, workgroups);      // multi-tile form on 192-row tiles (where that height starts fewer row-rounds)
+        return launch_nt8_form<EPI, false, 3>(s, q, workgroups);
+    }
     if (bm == 224) {
         if (tiles > workgroups) return launch_nt8_form<EPI, true, 7>(s, q, workgroups);      // multi-tile form on 224-row tiles (A/B: MMBERT_NT_8PHASE_M224)
         return launch_nt8_form<EPI, false, 7>(s, q, workgroups);
@@ -1538,9 +1541,24 @@ static NTChoice nt_choose(const GemmNT& p, int epi) {
             static const int q8_env = getenv("MMBERT_NT_8PHASE_QUEUE") ? atoi(getenv("MMBERT_NT_8PHASE_QUEUE")) : 1;   // 0: launches with a tile queue keep the ring kernel
             if (m224 >= 1 && !skip && lvl >= 1 && g_nt_force == 0 && ntp_eligible(p) && t224 > cus && t256 > cus && (!huge_b || m224 >= 2) &&
                 (!p.tile_counter || (q8_env && !(cus & 7)))) {
+                // Tile height of the multi-tile form: 224 rows unless another height is clearly cheaper in started rounds x time per tile
+                // (K-tile clocks of the three forms: 192 rows 1 680 -- LDS-DMA bound --, 224 rows 1 800, 256 rows 2 048 -- MFMA bound).  At the
+                // headline shapes 224 wins everywhere (QKV 3 rounds, FFN-up 4, GELU' input gradient 3); it would not with a few hundred rows
+                // more in backward (14 400 valid rows x N = 3072: 780 tiles of 224 rows = 4 rounds, 684 of 256 = 3) or at other models'
+                // shapes (bert-large QKV, 6 400 x 3072: 348 tiles of 224 rows = 2 rounds, 408 of 192 = 2 rounds of smaller tiles).
+                // MMBERT_NT_8PHASE_MH=192|224|256 forces a height (A/B switch, read per call).
+                const int t192 = ((p.M + 191) / 192) * tn;
+                const long long c192 = (long long)((t192 + cus - 1) / cus) * 1680, c224 = (long long)r224 * 1800, c256 = (long long)r256 * 2048;
+                int h = 224, th = t224;
+                if (100 * c256 < 97 * c224 && c256 <= c192) { h = 256; th = t256; }
+                else if (100 * c192 < 97 * c224 && c192 < c256) { h = 192; th = t192; }
+                if (const char* mh = getenv("MMBERT_NT_8PHASE_MH")) {
+                    const int v = atoi(mh);
+                    if (v == 192 && t192 > cus) { h = 192; th = t192; } else if (v == 224) { h = 224; th = t224; } else if (v == 256) { h = 256; th = t256; }
+                }
                 c.use_queue = p.tile_counter != nullptr;
-                c.kernel = NTK_8PHASE; c.bm = 224; c.tiles = t224; c.workgroups = cus;
-                c.group_m = ntp_group_m(p.M, p.N, p.K, epi, 224, t224, cus);
+                c.kernel = NTK_8PHASE; c.bm = h; c.tiles = th; c.workgroups = cus;
+                c.group_m = ntp_group_m(p.M, p.N, p.K, epi, h, th, cus);
                 return c;
             }
         }

@@ -294,6 +294,31 @@ def test_gemm_nt_8phase_multi_tile_form_matches_ring_kernel(ops, epi, monkeypatc
     if epi == "gelu":
         assert float((res["3"][1].float() - res["0"][1].float()).abs().max()) <= 2.0 ** -7 * float(res["0"][1].float().abs().max())
         assert torch.equal(res["m224"][1], res["0"][1])
+    # the other tile heights of the multi-tile form (chosen by started rounds x time per tile; forced here): the K order per element is the
+    # same at every height -> the ring kernel's bits again; and the 192-row form (two wave classes) on the device tile queue
+    import msa_amd.ops as O
+    for mh in ("192", "256"):
+        monkeypatch.setenv("MMBERT_NT_8PHASE_MH", mh)
+        d = ops.gemm_nt_describe(M, N, K, epi={"bias": 1, "gelu": 3, "gelu_bwd": 8, "resid_drop": 5}[epi])
+        assert d["kernel"] == "8phase" and d["tile"] == mh + "x256" and d["tiles"] > d["cus"], d
+        aux = torch.empty((M, N), device=DEV, dtype=torch.bfloat16) if epi == "gelu" else None
+        out = ops.gemm_nt(A, B, aux=aux, **kw)
+        assert torch.equal(out, res["0"][0]), mh
+        assert aux is None or torch.equal(aux, res["0"][1]), mh
+        if mh == "192":
+            was = O.dynamic_tile_queue
+            try:
+                O.dynamic_tile_queue = True
+                for rep in range(2):
+                    aux = torch.empty((M, N), device=DEV, dtype=torch.bfloat16) if epi == "gelu" else None
+                    assert torch.equal(ops.gemm_nt(A, B, aux=aux, **kw), res["0"][0]), (mh, "queue", rep)
+            finally:
+                O.dynamic_tile_queue = was
+    monkeypatch.delenv("MMBERT_NT_8PHASE_MH")
+    # the height rule itself (host-only): more valid rows in backward -> 256-row tiles save a round; bert-large's QKV -> 192-row tiles
+    assert ops.gemm_nt_describe(14400, 3072, 768, epi=8)["tile"] == "256x256"
+    assert ops.gemm_nt_describe(13850, 3072, 768, epi=8)["tile"] == "224x256"
+    assert ops.gemm_nt_describe(6400, 3072, 1024, epi=1)["tile"] == "192x256"
 
 
 def test_gemm_nt_vocabulary_projection_on_the_multi_tile_8phase_form(ops, monkeypatch):
