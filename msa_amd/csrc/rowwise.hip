@@ -721,37 +721,43 @@ __global__ __launch_bounds__(256) void embed_scatter_kernel(const int64_t* __res
 // JointEmbeddings pair projection: out[out_row0 + b*(T+P) + T + p] = relu(W . feat[b,p] + bias)
 // feat fp32 [B*P, D]; W fp32 [H, D].
 // --------------------------------------------------------------------------------------------
-// Tiled: one workgroup = 64 feature rows x 64 hidden columns, both operands staged through LDS in 64-deep chunks of D (odd row
-// pitch: conflict-free), a thread owns a 4 x 4 block (4 consecutive columns: 8-byte bf16x4 stores, 128 B contiguous per row and
-// 16 lanes).  (Round 1's form -- 16 rows per workgroup, every thread streaming its own W row from global memory -- took 27 / 54 us
-// for D = 35 / 74 at 8000 rows: 17 GFLOP/s.)
+// Tiled: one workgroup = 128 feature rows x 64 hidden columns, both operands staged through LDS in 32-deep chunks of D, K-MAJOR
+// ([k][row] / [k][column], pitch a multiple of 4 floats), so that a thread's 8 rows and 4 columns of one k come by three ds_read_b128
+// and feed 32 FMAs (round 2's form: 64 x 64 tile, 4 x 4 per thread, eight scalar LDS reads per 16 FMAs -- LDS-bound: 28 / 43 us for
+// D = 35 / 74 at 8000 rows, the first kernels of every forward pass; now 23 / 35 us, tools/bench_pair_proj.py -- the scalar-FMA floor is
+// 5.5 / 11.6 us, an fp32-MFMA form would be the next step).  k ascends as before: the same fp32 sums.  (Round 1's form -- 16
+// rows per workgroup, every thread streaming its own W row from global memory -- took 27 / 54 us: 17 GFLOP/s.)
 __global__ __launch_bounds__(256) void pair_proj_fwd_kernel(const float* __restrict__ feat, int n_rows, int P, int D,
                                                             const float* __restrict__ W, const float* __restrict__ bias, int H,
                                                             bf16_t* __restrict__ out, int ldo, int T) {
-    __shared__ float Fs[64][65];
-    __shared__ float Ws[64][65];
-    const int row0 = blockIdx.x * 64, h0 = blockIdx.y * 64;
+    constexpr int RT = 128, CT = 64, KC = 32;
+    __shared__ __attribute__((aligned(16))) float Fs[KC][RT + 4];
+    __shared__ __attribute__((aligned(16))) float Ws[KC][CT + 4];
+    const int row0 = blockIdx.x * RT, h0 = blockIdx.y * CT;
     const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
-    float acc[4][4];
+    float acc[8][4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < 8; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
-    for (int k0 = 0; k0 < D; k0 += 64) {
+    for (int k0 = 0; k0 < D; k0 += KC) {
 #pragma unroll 4
-        for (int i = 0; i < 16; ++i) {
-            const int idx = tid + 256 * i, r = idx >> 6, k = idx & 63;
-            Fs[r][k] = (row0 + r < n_rows && k0 + k < D) ? feat[(size_t)(row0 + r) * D + k0 + k] : 0.f;
-            Ws[r][k] = (h0 + r < H && k0 + k < D) ? W[(size_t)(h0 + r) * D + k0 + k] : 0.f;
+        for (int i = 0; i < RT * KC / 256; ++i) {                  // consecutive threads: consecutive k of one row (128-byte runs)
+            const int idx = tid + 256 * i, r = idx >> 5, k = idx & 31;
+            Fs[k][r] = (row0 + r < n_rows && k0 + k < D) ? feat[(size_t)(row0 + r) * D + k0 + k] : 0.f;
+        }
+#pragma unroll 4
+        for (int i = 0; i < CT * KC / 256; ++i) {
+            const int idx = tid + 256 * i, c = idx >> 5, k = idx & 31;
+            Ws[k][c] = (h0 + c < H && k0 + k < D) ? W[(size_t)(h0 + c) * D + k0 + k] : 0.f;
         }
         __syncthreads();
-        const int kn = min(64, D - k0);
+        const int kn = min(KC, D - k0);
         for (int k = 0; k < kn; ++k) {
-            float f[4], w[4];
+            const float4 f0 = *(const float4*)&Fs[k][ty * 8], f1 = *(const float4*)&Fs[k][ty * 8 + 4], w4 = *(const float4*)&Ws[k][tx * 4];
+            const float f[8] = {f0.x, f0.y, f0.z, f0.w, f1.x, f1.y, f1.z, f1.w}, w[4] = {w4.x, w4.y, w4.z, w4.w};
 #pragma unroll
-            for (int i = 0; i < 4; ++i) { f[i] = Fs[ty * 4 + i][k]; w[i] = Ws[tx * 4 + i][k]; }
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < 8; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) acc[i][j] += f[i] * w[j];
         }
@@ -762,8 +768,8 @@ __global__ __launch_bounds__(256) void pair_proj_fwd_kernel(const float* __restr
     const float4 b4 = (h + 3 < H) ? *(const float4*)(bias + h) : make_float4(bias[h], h + 1 < H ? bias[h + 1] : 0.f, h + 2 < H ? bias[h + 2] : 0.f, 0.f);
     const float bv[4] = {b4.x, b4.y, b4.z, b4.w};
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int row = row0 + ty * 4 + i;
+    for (int i = 0; i < 8; ++i) {
+        const int row = row0 + ty * 8 + i;
         if (row >= n_rows) continue;
         const int b_ = row / P, p_ = row - b_ * P;
         bf16_t* o = out + (size_t)(b_ * (T + P) + T + p_) * ldo + h;
@@ -1507,7 +1513,7 @@ int mmbert_pair_proj_fwd(hipStream_t stream, const float* feat, int B, int P, in
     const int n = B * P;
     if (n <= 0) return 0;
     if (D < 1 || H < 1) return -1;
-    hipLaunchKernelGGL(pair_proj_fwd_kernel, dim3((n + 63) / 64, (H + 63) / 64), dim3(256), 0, stream, feat, n, P, D, W, bias, H, (bf16_t*)out, ldo, T);
+    hipLaunchKernelGGL(pair_proj_fwd_kernel, dim3((n + 127) / 128, (H + 63) / 64), dim3(256), 0, stream, feat, n, P, D, W, bias, H, (bf16_t*)out, ldo, T);
     MMB_CHECK_LAUNCH();
     return 0;
 }
