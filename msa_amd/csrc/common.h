@@ -35,6 +35,21 @@ static inline int mmb_allow_lds(const void* fn, int bytes, std::atomic<unsigned 
     return 0;
 }
 
+// CU count of the current device (cached per device: a process may drive several)
+static inline int mmb_device_cus() {
+    static std::atomic<int> cus[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+    int c = cus[dev].load(std::memory_order_relaxed);
+    if (!c) {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return 256;
+        c = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+        cus[dev].store(c, std::memory_order_relaxed);
+    }
+    return c;
+}
+
 // address-space casts for the LDS-DMA builtin
 #define GPTR(p) ((const void __attribute__((address_space(1)))*)(p))
 #define LPTR(p) ((void __attribute__((address_space(3)))*)(p))

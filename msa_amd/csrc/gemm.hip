@@ -434,20 +434,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(const GemmNT p) {
 static std::atomic<int> g_nt_force{0};   // 0 auto, 1 force 128^2, 2 force the 256-wide kernels
 static std::atomic<int> g_nt_bm{0};      // 0 auto, 256 / 224 forced
 static std::atomic<int> g_nt_persist{1}; // persistent stream kernel where eligible (0: launch-per-tile ring kernel)
-static int device_cus() {
-    // per-device cache of the CU count (a process may drive several devices)
-    static std::atomic<int> cus[64];
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
-    int c = cus[dev].load(std::memory_order_relaxed);
-    if (!c) {
-        hipDeviceProp_t prop;
-        if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return 256;
-        c = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-        cus[dev].store(c, std::memory_order_relaxed);
-    }
-    return c;
-}
+static int device_cus() { return mmb_device_cus(); }    // (common.h: cached per device)
 
 // -------------------------------------------------------------------------------------------------
 // NT, persistent form of the ring kernel (the default for large shapes with K % 128 == 0).

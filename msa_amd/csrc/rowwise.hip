@@ -721,101 +721,261 @@ __global__ __launch_bounds__(256) void embed_scatter_kernel(const int64_t* __res
 // JointEmbeddings pair projection: out[out_row0 + b*(T+P) + T + p] = relu(W . feat[b,p] + bias)
 // feat fp32 [B*P, D]; W fp32 [H, D].
 // --------------------------------------------------------------------------------------------
-// Tiled: one workgroup = 128 feature rows x 64 hidden columns, both operands staged through LDS in 32-deep chunks of D, K-MAJOR
-// ([k][row] / [k][column], pitch a multiple of 4 floats), so that a thread's 8 rows and 4 columns of one k come by three ds_read_b128
-// and feed 32 FMAs (round 2's form: 64 x 64 tile, 4 x 4 per thread, eight scalar LDS reads per 16 FMAs -- LDS-bound: 28 / 43 us for
-// D = 35 / 74 at 8000 rows, the first kernels of every forward pass; now 23 / 35 us, tools/bench_pair_proj.py -- the scalar-FMA floor is
-// 5.5 / 11.6 us, an fp32-MFMA form would be the next step).  k ascends as before: the same fp32 sums.  (Round 1's form -- 16
-// rows per workgroup, every thread streaming its own W row from global memory -- took 27 / 54 us: 17 GFLOP/s.)
+// On the fp32 MFMA (v_mfma_f32_16x16x4_f32: exact fp32 products summed as an fmaf chain over ascending k, as the scalar kernels
+// before it summed): one workgroup = 128 hidden columns x 64 feature rows, 4 waves of 64 x 32 (4 x 2 MFMA tiles),
+// M = hidden column, N = feature row, so that a lane ends with 4 consecutive columns of one row.  Both operand tiles are copied to LDS
+// as they lie in memory (row-major, k padded to a multiple of 4 with zeros; row pitch = 2 mod 16 floats: the 16 rows x 2 k of a
+// half-wave's ds_read_b32 fall in 32 different banks).  D beyond 128 runs in chunks of 128.  The sums are fmaf chains over ascending k.
+// (Round 1: 16 rows per workgroup, every thread streaming its own W row from global memory, 27 / 54 us for D = 35 / 74 at 8000 rows;
+// round 2: 64 x 64 tile with scalar LDS reads, 28 / 43 us; round 4: 128 x 64 tile, K-major LDS, three ds_read_b128 per 32 FMAs,
+// 23 / 35 us stand-alone, 30 / 43 us in the step's trace, against a scalar-FMA floor of 5.5 / 11.6 us; this form: 15 / 25 us by
+// rocprofv3 (tools/r4_s3_pairprof.sh, profiles/r4_pair_proj.log).)
+template <int KSHIFT>
 __global__ __launch_bounds__(256) void pair_proj_fwd_kernel(const float* __restrict__ feat, int n_rows, int P, int D,
                                                             const float* __restrict__ W, const float* __restrict__ bias, int H,
-                                                            bf16_t* __restrict__ out, int ldo, int T) {
-    constexpr int RT = 128, CT = 64, KC = 32;
-    __shared__ __attribute__((aligned(16))) float Fs[KC][RT + 4];
-    __shared__ __attribute__((aligned(16))) float Ws[KC][CT + 4];
-    const int row0 = blockIdx.x * RT, h0 = blockIdx.y * CT;
-    const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
-    float acc[8][4];
+                                                            bf16_t* __restrict__ out, int ldo, int T, int KC, int pitch) {
+#if defined(__gfx950__)
+    extern __shared__ __attribute__((aligned(16))) float pair_sm[];
+    float* Ws = pair_sm;                         // [128][pitch]
+    float* Fs = pair_sm + 128 * pitch;           // [64][pitch]
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, c = lane & 15, g = lane >> 4;
+    const int row0 = blockIdx.x * 64, h0 = blockIdx.y * 128;
+    const int wh = (wave & 1) * 64, wr = (wave >> 1) * 32;
+    f32x4 acc[4][2];
 #pragma unroll
-    for (int i = 0; i < 8; ++i)
+    for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
+        for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // the bias of the lane's 16 columns, fetched first (clamped in range; unused past H): its latency passes under the staging
+    float bcol[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) bcol[i][q] = bias[min(h0 + wh + 16 * i + 4 * g + q, H - 1)];
+    // staging: a wave copies whole rows, lane = k (64 or 128 lanes of k per row), up to 32 rows in flight per wave (batches of 8 were
+    // a memory round trip each).  Per-lane 32-bit offsets on the two base pointers: with wave-uniform row pointers hipcc runs out of
+    // SGPRs, parks them in VGPR lanes and ends up waiting for every load before it issues the next (48 round trips, 20 us)
+    constexpr int kw = 1 << KSHIFT, rstep = 256 >> KSHIFT;
+    const int kl = tid & (kw - 1), rsub = tid >> KSHIFT;
     for (int k0 = 0; k0 < D; k0 += KC) {
-#pragma unroll 4
-        for (int i = 0; i < RT * KC / 256; ++i) {                  // consecutive threads: consecutive k of one row (128-byte runs)
-            const int idx = tid + 256 * i, r = idx >> 5, k = idx & 31;
-            Fs[k][r] = (row0 + r < n_rows && k0 + k < D) ? feat[(size_t)(row0 + r) * D + k0 + k] : 0.f;
-        }
-#pragma unroll 4
-        for (int i = 0; i < CT * KC / 256; ++i) {
-            const int idx = tid + 256 * i, c = idx >> 5, k = idx & 31;
-            Ws[k][c] = (h0 + c < H && k0 + k < D) ? W[(size_t)(h0 + c) * D + k0 + k] : 0.f;
-        }
-        __syncthreads();
-        const int kn = min(KC, D - k0);
-        for (int k = 0; k < kn; ++k) {
-            const float4 f0 = *(const float4*)&Fs[k][ty * 8], f1 = *(const float4*)&Fs[k][ty * 8 + 4], w4 = *(const float4*)&Ws[k][tx * 4];
-            const float f[8] = {f0.x, f0.y, f0.z, f0.w, f1.x, f1.y, f1.z, f1.w}, w[4] = {w4.x, w4.y, w4.z, w4.w};
+        const int kc = min(KC, D - k0), kc4 = (kc + 3) & ~3;
+        if (k0) __syncthreads();
+        const float kmask = kl < kc ? 1.f : 0.f;
+        const int kg = min(k0 + kl, D - 1);                             // always in range: the load is not predicated (a product, not a
+        const bool kst = kl < kc4;                                       // select, zeroes the padding: see pair_wgrad_kernel)
+        auto stage = [&](const float* __restrict__ base, int g0, int lim, int lrow0, auto nrows_c) {
+            constexpr int N = decltype(nrows_c)::value / rstep, NB = N < 32 ? N : 32;
+#pragma unroll 1
+            for (int ub = 0; ub < N; ub += NB) {
+                float v[NB];
 #pragma unroll
-            for (int i = 0; i < 8; ++i)
+                for (int u = 0; u < NB; ++u) {
+                    const int gr = g0 + rsub + (ub + u) * rstep;
+                    v[u] = base[(uint32_t)(min(gr, lim - 1) * D + kg)];
+                }
+                if (kst) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) acc[i][j] += f[i] * w[j];
-        }
+                    for (int u = 0; u < NB; ++u) {
+                        const int r = rsub + (ub + u) * rstep;
+                        pair_sm[(lrow0 + r) * pitch + kl] = v[u] * (g0 + r < lim ? kmask : 0.f);
+                    }
+                }
+            }
+        };
+        stage(W, h0, H, 0, std::integral_constant<int, 128>{});
+        stage(feat, row0, n_rows, 128, std::integral_constant<int, 64>{});
         __syncthreads();
+        const float* wa = Ws + (wh + c) * pitch + g;
+        const float* fb = Fs + (wr + c) * pitch + g;
+        float av[4], bv[2];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) av[i] = wa[16 * i * pitch];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) bv[j] = fb[16 * j * pitch];
+        for (int kk = 0; kk < kc4; kk += 4) {
+            float an[4], bn[2];
+            const int kn = kk + 4 < kc4 ? kk + 4 : kk;                  // the next step's fragments are read under this step's MFMAs
+#pragma unroll
+            for (int i = 0; i < 4; ++i) an[i] = wa[16 * i * pitch + kn];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) bn[j] = fb[16 * j * pitch + kn];
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) av[i] = an[i];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) bv[j] = bn[j];
+        }
     }
-    const int h = h0 + tx * 4;
-    if (h >= H) return;
-    const float4 b4 = (h + 3 < H) ? *(const float4*)(bias + h) : make_float4(bias[h], h + 1 < H ? bias[h + 1] : 0.f, h + 2 < H ? bias[h + 2] : 0.f, 0.f);
-    const float bv[4] = {b4.x, b4.y, b4.z, b4.w};
+    // acc[i][j][q] = column h0 + wh + 16 i + 4 g + q of row row0 + wr + 16 j + c.  Stored from there a wave-instruction is 16 rows x 32
+    // bytes, and the kernel is bound by issuing those (20 us at 8000 rows whatever D); so the tile goes through LDS (bf16, [64][128 + 8])
+    // and leaves as whole 256-byte rows, 16 bytes per lane
+    if (h0 + 128 <= H && !(ldo & 7)) {
+        __syncthreads();
+        bf16_t* Os = (bf16_t*)pair_sm;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int row = row0 + ty * 8 + i;
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                bf16x4 ov = {f2bf(fmaxf(acc[i][j][0] + bcol[i][0], 0.f)), f2bf(fmaxf(acc[i][j][1] + bcol[i][1], 0.f)),
+                             f2bf(fmaxf(acc[i][j][2] + bcol[i][2], 0.f)), f2bf(fmaxf(acc[i][j][3] + bcol[i][3], 0.f))};
+                *(bf16x4*)(Os + (wr + 16 * j + c) * 136 + wh + 16 * i + 4 * g) = ov;
+            }
+        __syncthreads();
+#pragma unroll
+        for (int ps = 0; ps < 4; ++ps) {
+            const int rl = (tid >> 4) + 16 * ps, row = row0 + rl;
+            if (row >= n_rows) continue;
+            const int b_ = row / P, p_ = row - b_ * P;
+            *(bf16x8*)(out + (size_t)(b_ * (T + P) + T + p_) * ldo + h0 + 8 * (tid & 15)) = *(const bf16x8*)(Os + rl * 136 + 8 * (tid & 15));
+        }
+        return;
+    }
+    // acc[i][j][q] = column h0 + wh + 16 i + 4 g + q of row row0 + wr + 16 j + c
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int row = row0 + wr + 16 * j + c;
         if (row >= n_rows) continue;
         const int b_ = row / P, p_ = row - b_ * P;
-        bf16_t* o = out + (size_t)(b_ * (T + P) + T + p_) * ldo + h;
-        if (h + 3 < H && !(ldo & 3)) {
-            bf16x4 ov = {f2bf(fmaxf(acc[i][0] + bv[0], 0.f)), f2bf(fmaxf(acc[i][1] + bv[1], 0.f)), f2bf(fmaxf(acc[i][2] + bv[2], 0.f)), f2bf(fmaxf(acc[i][3] + bv[3], 0.f))};
-            *(bf16x4*)o = ov;
-        } else {
+        bf16_t* orow = out + (size_t)(b_ * (T + P) + T + p_) * ldo;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) if (h + j < H) o[j] = f2bf(fmaxf(acc[i][j] + bv[j], 0.f));
+        for (int i = 0; i < 4; ++i) {
+            const int h = h0 + wh + 16 * i + 4 * g;
+            if (h + 3 < H && !(ldo & 3)) {
+                bf16x4 ov = {f2bf(fmaxf(acc[i][j][0] + bcol[i][0], 0.f)), f2bf(fmaxf(acc[i][j][1] + bcol[i][1], 0.f)),
+                             f2bf(fmaxf(acc[i][j][2] + bcol[i][2], 0.f)), f2bf(fmaxf(acc[i][j][3] + bcol[i][3], 0.f))};
+                *(bf16x4*)(orow + h) = ov;
+            } else {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) if (h + q < H) orow[h + q] = f2bf(fmaxf(acc[i][j][q] + bcol[i][q], 0.f));
+            }
         }
     }
+#endif
 }
 
-// backward: dpre = dJ * (J > 0); dW[h][k] += sum_rows dpre[row][h]*feat[row][k]; db[h] += sum dpre.
-// A tokens-contracted product like every other weight gradient, so it runs on the MFMA TN kernel (mmbert_gemm_tn):
-//   pair_prep : dpre (bf16, compact [rows, H]) and the features as TWO bf16 images side by side, [rows, hi(DP) | lo(DP)] with
-//               hi = bf16(x), lo = bf16(x - hi): the fp32 inputs keep ~16 mantissa bits through the bf16 MFMA
-//   gemm_tn   : Wtmp[H, 2 DP] = dpre^T . [hi | lo],  db += column sums of dpre (the kernel's fused bias gradient)
-//   pair_fold : dW[h][k] += Wtmp[h][k] + Wtmp[h][DP + k]
-// (The first version was a scalar-FMA kernel with one atomicAdd per weight and row chunk: 300 us for D = 74, 8000 rows.)
-__global__ __launch_bounds__(256) void pair_prep_kernel(const float* __restrict__ feat, int n_rows, int P, int D, int DP,
-                                                        const bf16_t* __restrict__ J, const bf16_t* __restrict__ dJ, int ld, int T, int H,
-                                                        bf16_t* __restrict__ dpre, bf16_t* __restrict__ featb) {
-    const int r = blockIdx.x;
-    if (r >= n_rows) return;
-    const size_t off = (size_t)((r / P) * (T + P) + T + (r % P)) * ld;
-    for (int c = threadIdx.x * 8; c < H; c += 256 * 8) {
-        const bf16x8 jv = *(const bf16x8*)(J + off + c);
-        bf16x8 dv = *(const bf16x8*)(dJ + off + c);
+// backward: dpre = dJ * (J > 0); dW[h][k] += sum_rows dpre[row][h]*feat[row][k]; db[h] += sum_rows dpre[row][h].
+// A tokens-contracted product with a tiny output ([H, D], D = 35 / 74) and fp32 features: it runs on the fp32 MFMA
+// (v_mfma_f32_16x16x4_f32: exact fp32 products, an fmaf chain over the rows), operands straight from global memory in fragment order:
+//   * contraction = rows, 4 per MFMA (lane group g = lane >> 4 holds row r + g); M = 16 hidden columns, N = 16 feature columns;
+//   * the A fragment of M-tile i takes column hb + 4 m + i from lane m, so ONE 8-byte load per lane of J and of dJ (columns
+//     hb + 4 m .. + 3 of its row: 128 contiguous bytes per row and instruction) feeds the four M-tiles of a wave's 64 columns;
+//   * feature column D is the constant 1: the bias gradient is column D of the product, no separate column sum;
+//   * a workgroup = 64 hidden columns x one range of rows, its 4 waves a quarter of the range each, summed through LDS in wave order;
+//     the per-range partial tiles go to a slab [S][H][D + 1] and pair_wgrad_reduce_kernel adds them to dW / db in range order
+//     (deterministic: no atomics).
+// (Round 1: a scalar-FMA kernel with one atomicAdd per weight and row chunk, 300 us for D = 74 at 8000 rows; rounds 2-4: a bf16 hi / lo
+// split of the features through the grouped TN kernel, four launches and 49 us; this form: two launches, 26 + 4.5 us.)
+struct PairBwdArgs { const float* feat; const bf16_t* J; const bf16_t* dJ; float* slab; int n, P, D, T, H, ld, rows_per_wg, ntiles; };
+constexpr int PAIR_NT = 5;                       // feature-column tiles (16 columns) per workgroup: D + 1 <= 80 in one pass, more on grid.z
+
+__global__ __launch_bounds__(256) void pair_wgrad_kernel(const PairBwdArgs a) {
+#if defined(__gfx950__)
+    __shared__ float red[3][PAIR_NT * 16][64];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, c = lane & 15, g = lane >> 4;
+    const int hb = blockIdx.x * 64, s = blockIdx.y, jt0 = blockIdx.z * PAIR_NT;
+    const int njt = min(PAIR_NT, a.ntiles - jt0);
+    const int rpw = a.rows_per_wg >> 2;                                  // rows per wave: a multiple of 16
+    const int r0 = s * a.rows_per_wg + wave * rpw, r1 = min(r0 + rpw, a.n);
+    const int hcol = hb + 4 * c;
+    const bool hok = hcol + 3 < a.H;
+    struct Stage { bf16x4 j, d; float f[PAIR_NT]; };
+    auto load = [&](Stage& st, int r) {
+        const bool ok = r < r1;
+        const int rc = ok ? r : 0;
+        const int b_ = rc / a.P, p_ = rc - b_ * a.P;
+        const size_t off = (size_t)(b_ * (a.T + a.P) + a.T + p_) * a.ld + (hok ? hcol : 0);
+        st.j = *(const bf16x4*)(a.J + off);
+        st.d = *(const bf16x4*)(a.dJ + off);
+        const float* fr = a.feat + (size_t)rc * a.D;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) if (!(bf2f(jv[e]) > 0.f)) dv[e] = (bf16_t)0.0f;
-        *(bf16x8*)(dpre + (size_t)r * H + c) = dv;
+        for (int j = 0; j < PAIR_NT; ++j) {
+            const int k = (jt0 + j) * 16 + c;
+            // (arithmetic, not a select, on the loaded value: hipcc sinks a load whose only use is one arm of a select into a branch
+            // of its own, and every such branch ends in s_waitcnt vmcnt(0) -- the ring would hold one load at a time)
+            const float live = (ok && j < njt) ? 1.0f : 0.0f;
+            st.f[j] = fmaf(fr[min(k, a.D - 1)], k < a.D ? live : 0.0f, k == a.D ? live : 0.0f);
+        }
+        if (!(ok && hok)) { st.d = (bf16x4){(bf16_t)0.0f, (bf16_t)0.0f, (bf16_t)0.0f, (bf16_t)0.0f}; }
+    };
+    f32x4 acc[PAIR_NT][4];
+#pragma unroll
+    for (int j = 0; j < PAIR_NT; ++j)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[j][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // four steps of 4 rows in flight per wave (one wave per SIMD: nothing else hides the memory latency); the ring is unrolled so
+    // that a stage is refilled in place -- rotating it through register copies would wait for the newest load in every step
+    Stage st[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) load(st[u], r0 + 4 * u + g);
+#pragma unroll 1
+    for (int r = r0; r < r1; r += 16) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            float av[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) av[i] = bf2f(st[u].j[i]) > 0.f ? bf2f(st[u].d[i]) : 0.f;
+            float fv[PAIR_NT];
+#pragma unroll
+            for (int j = 0; j < PAIR_NT; ++j) fv[j] = st[u].f[j];
+            load(st[u], r + 16 + 4 * u + g);
+#pragma unroll
+            for (int j = 0; j < PAIR_NT; ++j)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], fv[j], acc[j][i], 0, 0, 0);
+        }
     }
-    for (int k = threadIdx.x; k < DP; k += 256) {
-        const float x = k < D ? feat[(size_t)r * D + k] : 0.f;
-        const bf16_t hi = f2bf(x);
-        featb[(size_t)r * 2 * DP + k] = hi;
-        featb[(size_t)r * 2 * DP + DP + k] = f2bf(x - bf2f(hi));
+    // waves 1-3 hand their tiles to wave 0, which adds them in wave order and writes the workgroup's partial product
+    if (wave) {
+#pragma unroll
+        for (int j = 0; j < PAIR_NT; ++j)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) red[wave - 1][(j * 4 + i) * 4 + q][lane] = acc[j][i][q];
     }
+    __syncthreads();
+    if (wave == 0) {
+        const int W1 = a.D + 1;
+        float* out = a.slab + (size_t)s * a.H * W1;
+#pragma unroll
+        for (int j = 0; j < PAIR_NT; ++j) {
+            const int k = (jt0 + j) * 16 + c;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int e = (j * 4 + i) * 4 + q;
+                    const float v = ((acc[j][i][q] + red[0][e][lane]) + red[1][e][lane]) + red[2][e][lane];
+                    const int h = hb + 4 * (4 * g + q) + i;              // D tile: row m = 4 g + q of M-tile i is column hb + 4 m + i
+                    if (j < njt && k < W1 && h < a.H) out[(size_t)h * W1 + k] = v;
+                }
+        }
+    }
+#endif
 }
 
-__global__ void pair_fold_kernel(const float* __restrict__ wtmp, int H, int D, int DP, float* __restrict__ dW) {
+// dW[h][k] += sum_s slab[s][h][k] (k < D), db[h] += sum_s slab[s][h][D], ranges in ascending order
+__global__ void pair_wgrad_reduce_kernel(const float* __restrict__ slab, int S, int H, int D, float* __restrict__ dW, float* __restrict__ db) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= H * D) return;
-    const int h = i / D, k = i - h * D;
-    dW[i] += wtmp[(size_t)h * 2 * DP + k] + wtmp[(size_t)h * 2 * DP + DP + k];
+    const int W1 = D + 1;
+    if (i >= H * W1) return;
+    float t = 0.f;
+    int s_ = 0;
+    for (; s_ + 8 <= S; s_ += 8) {                                     // eight loads in flight, added in range order
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = slab[(size_t)(s_ + u) * H * W1 + i];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) t += v[u];
+    }
+    for (; s_ < S; ++s_) t += slab[(size_t)s_ * H * W1 + i];
+    const int h = i / W1, k = i - h * W1;
+    if (k < D) dW[(size_t)h * D + k] += t; else db[h] += t;
 }
 
 // --------------------------------------------------------------------------------------------
@@ -1513,25 +1673,38 @@ int mmbert_pair_proj_fwd(hipStream_t stream, const float* feat, int B, int P, in
     const int n = B * P;
     if (n <= 0) return 0;
     if (D < 1 || H < 1) return -1;
-    hipLaunchKernelGGL(pair_proj_fwd_kernel, dim3((n + 127) / 128, (H + 63) / 64), dim3(256), 0, stream, feat, n, P, D, W, bias, H, (bf16_t*)out, ldo, T);
+    const int KC = D < 128 ? (D + 3) & ~3 : 128;                 // k chunk in LDS (a multiple of 4); row pitch = 2 mod 16 floats
+    const int pitch = KC + ((18 - (KC & 15)) & 15);
+    const int lds = 192 * pitch * (int)sizeof(float);             // <= 99 840 bytes
+    static std::atomic<unsigned long long> attr_done{0};
+    if (KC <= 64) {                                                // 64 lanes of k per row (four rows per wave-instruction pair) or 128
+        hipLaunchKernelGGL(pair_proj_fwd_kernel<6>, dim3((n + 63) / 64, (H + 127) / 128), dim3(256), lds, stream, feat, n, P, D, W, bias, H, (bf16_t*)out, ldo, T,
+                           KC, pitch);
+    } else {
+        if (int e = mmb_allow_lds((const void*)pair_proj_fwd_kernel<7>, 192 * 130 * (int)sizeof(float), attr_done)) return e;
+        hipLaunchKernelGGL(pair_proj_fwd_kernel<7>, dim3((n + 63) / 64, (H + 127) / 128), dim3(256), lds, stream, feat, n, P, D, W, bias, H, (bf16_t*)out, ldo, T,
+                           KC, pitch);
+    }
     MMB_CHECK_LAUNCH();
     return 0;
 }
 
-// workspace layout: dpre bf16 [n, H] | featb bf16 [n, 2 DP] | Wtmp fp32 [H, 2 DP] | slab of the TN kernel
-static void pair_ws_layout(int n, int D, int H, size_t* o_featb, size_t* o_wtmp, size_t* o_slab, size_t* total) {
-    const int DP = (D + 7) / 8 * 8;
-    auto up = [](size_t x) { return (x + 255) / 256 * 256; };
-    size_t o = up((size_t)n * H * 2);
-    *o_featb = o; o += up((size_t)n * 2 * DP * 2);
-    *o_wtmp = o;  o += up((size_t)H * 2 * DP * 4);
-    *o_slab = o;  o += up(mmbert_gemm_tn_workspace(n, H, 2 * DP, nullptr));
-    *total = o;
+// workspace: the slab [S][H][D + 1] fp32 of per-row-range partial products.  S row ranges (a multiple of 16 rows each) so that the
+// launch has about one workgroup per CU, i.e. one wave per SIMD: twenty independent accumulators keep the matrix pipe busy from one wave
+static void pair_bwd_split(int n, int D, int H, int* rows_per_wg, int* S) {
+    const int htiles = (H + 63) / 64, zt = ((D + 1 + 15) / 16 + PAIR_NT - 1) / PAIR_NT;
+    int want = (mmb_device_cus() + htiles * zt - 1) / (htiles * zt);
+    if (want < 1) want = 1;
+    int rp = ((n + want - 1) / want + 63) / 64 * 64;             // a multiple of 64: 16 per wave and ring turn
+    if (rp < 64) rp = 64;
+    *rows_per_wg = rp;
+    *S = (n + rp - 1) / rp;
 }
 size_t mmbert_pair_proj_bwd_workspace(int B, int P, int D, int H) {
-    size_t a, b, c, t;
-    pair_ws_layout(B * P, D, H, &a, &b, &c, &t);
-    return t;
+    if (B <= 0 || P <= 0 || D < 1 || H < 1) return 0;
+    int rp, S;
+    pair_bwd_split(B * P, D, H, &rp, &S);
+    return (size_t)S * H * (D + 1) * sizeof(float);
 }
 
 int mmbert_pair_proj_bwd(hipStream_t stream, const float* feat, int B, int P, int D, const void* J, const void* dJ, int ld, int T,
@@ -1539,16 +1712,15 @@ int mmbert_pair_proj_bwd(hipStream_t stream, const float* feat, int B, int P, in
     const int n = B * P;
     if (n <= 0) return 0;
     if (!workspace || (H & 7) || (ld & 7) || D < 1) return -1;
-    const int DP = (D + 7) / 8 * 8;
-    size_t o_featb, o_wtmp, o_slab, total;
-    pair_ws_layout(n, D, H, &o_featb, &o_wtmp, &o_slab, &total);
-    char* ws = (char*)workspace;
-    bf16_t* dpre = (bf16_t*)ws; bf16_t* featb = (bf16_t*)(ws + o_featb); float* wtmp = (float*)(ws + o_wtmp);
-    hipLaunchKernelGGL(pair_prep_kernel, dim3(n), dim3(256), 0, stream, feat, n, P, D, DP, (const bf16_t*)J, (const bf16_t*)dJ, ld, T, H, dpre, featb);
+    PairBwdArgs a = {};
+    a.feat = feat; a.J = (const bf16_t*)J; a.dJ = (const bf16_t*)dJ; a.slab = (float*)workspace;
+    a.n = n; a.P = P; a.D = D; a.T = T; a.H = H; a.ld = ld;
+    int S;
+    pair_bwd_split(n, D, H, &a.rows_per_wg, &S);
+    a.ntiles = (D + 1 + 15) / 16;
+    hipLaunchKernelGGL(pair_wgrad_kernel, dim3((H + 63) / 64, S, (a.ntiles + PAIR_NT - 1) / PAIR_NT), dim3(256), 0, stream, a);
     MMB_CHECK_LAUNCH();
-    const int rc = mmbert_gemm_tn(stream, dpre, H, featb, 2 * DP, wtmp, 2 * DP, n, H, 2 * DP, 0, 1.0f, nullptr, ws + o_slab, db);
-    if (rc) return rc;
-    hipLaunchKernelGGL(pair_fold_kernel, dim3((H * D + 255) / 256), dim3(256), 0, stream, wtmp, H, D, DP, dW);
+    hipLaunchKernelGGL(pair_wgrad_reduce_kernel, dim3((H * (D + 1) + 255) / 256), dim3(256), 0, stream, (const float*)workspace, S, H, D, dW, db);
     MMB_CHECK_LAUNCH();
     return 0;
 }
