@@ -131,6 +131,10 @@ size_t mmbert_ln_bwd_workspace(int M, int H);
  * gradients (+=).  The calls must share M and H.  Host arrays of `items` pointers; dbias2 (or single entries of it) may be NULL. */
 int mmbert_ln_bwd_reduce(mmbert_stream_t stream, int items, const float* const* partial_ws, float* const* dgamma, float* const* dbeta,
                          float* const* dbias2, int M, int H);
+/* The same for calls that share H only: call i had M[i] rows (host array).  One list can then hold the LayerNorm' calls of the sparse
+ * start of backward (a few hundred rows), of the dense layers and of the embedding stage. */
+int mmbert_ln_bwd_reduce_rows(mmbert_stream_t stream, int items, const float* const* partial_ws, float* const* dgamma, float* const* dbeta,
+                              float* const* dbias2, const int* M, int H);
 
 /* ---- embeddings ----
  * gather: out[i] = word[ids[i]] + type[tts[i]] + pos[i % T]     HF:96-102 via REF:MMBertForPretraining.py:264

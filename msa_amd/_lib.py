@@ -36,6 +36,7 @@ SIGNATURES = {
     "mmbert_ln_fwd": (I, [P, P, I, P, P, I, P, I, I, P, P, F, P, P, U32, U32, F, I]),
     "mmbert_ln_bwd": (I, [P, P, I, P, P, I, P, P, P, P, I, I, P, I, P, P, I, P, P, P, U32, U32, F, U32, U32, F, P, P, I, I]),
     "mmbert_ln_bwd_reduce": (I, [P, I, P, P, P, P, I, I]),
+    "mmbert_ln_bwd_reduce_rows": (I, [P, I, P, P, P, P, P, I]),
     "mmbert_ln_bwd_workspace": (SZ, [I, I]),
     "mmbert_embed_gather": (I, [P, P, P, P, P, P, I, I, I, I, P, I]),
     "mmbert_embed_scatter": (I, [P, P, P, P, I, I, I, I, I, P, P, P]),

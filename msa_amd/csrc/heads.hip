@@ -421,15 +421,29 @@ __global__ __launch_bounds__(256) void skinny_wgrad_kernel(const SkWArgs a) {
     float bsum = 0.f;
     for (int m0 = 0; m0 < op.M; m0 += 64) {                        // (round 4: M up to 128 rows, 64 at a time through LDS)
         if (m0) __syncthreads();
+        // all 20 loads of the block are issued before the first LDS store, from addresses clamped into range and zeroed by a
+        // PRODUCT: as "in range ? load : 0" hipcc put every load into a branch of its own that ended in s_waitcnt vmcnt(0) --
+        // 20 memory round trips in a row per block (the kernel took 32 us)
+        float dyv[4], xv[16];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int idx = tid + 256 * i, m = m0 + (idx >> 4), c = idx & 15;
-            dYs[idx >> 4][c] = (m < op.M && n0 + c < op.N) ? op.dY[(size_t)m * op.ldy + n0 + c] : 0.f;
+            dyv[i] = op.dY[(size_t)min(m, op.M - 1) * op.ldy + min(n0 + c, op.N - 1)];
         }
-#pragma unroll 4
+#pragma unroll
         for (int i = 0; i < 16; ++i) {
             const int idx = tid + 256 * i, m = m0 + (idx >> 6), kk = idx & 63;
-            Xs[idx >> 6][kk] = (m < op.M && k0 + kk < op.K) ? op.X[(size_t)m * op.ldx + k0 + kk] : 0.f;
+            xv[i] = op.X[(size_t)min(m, op.M - 1) * op.ldx + min(k0 + kk, op.K - 1)];
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {                                // (the products here, behind the last load: hipcc keeps a product next to its load)
+            const int idx = tid + 256 * i, m = m0 + (idx >> 4), c = idx & 15;
+            dYs[idx >> 4][c] = dyv[i] * ((m < op.M && n0 + c < op.N) ? 1.f : 0.f);
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int idx = tid + 256 * i, m = m0 + (idx >> 6), kk = idx & 63;
+            Xs[idx >> 6][kk] = xv[i] * ((m < op.M && k0 + kk < op.K) ? 1.f : 0.f);
         }
         __syncthreads();
         const int mend = min(64, op.M - m0);
@@ -444,8 +458,14 @@ __global__ __launch_bounds__(256) void skinny_wgrad_kernel(const SkWArgs a) {
     if (n < op.N) {
         float* w = op.dW + (size_t)n * op.ldw + k0 + 4 * tk4;
         const float v[4] = {acc.x, acc.y, acc.z, acc.w};
+        if (k0 + 4 * tk4 + 3 < op.K && !((size_t)w & 15)) {            // one 16-byte read-modify-write (four scalar ones waited for each other)
+            float4 o = *(const float4*)w;
+            o.x += v[0]; o.y += v[1]; o.z += v[2]; o.w += v[3];
+            *(float4*)w = o;
+        } else {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) if (k0 + 4 * tk4 + e < op.K) w[e] += v[e];
+            for (int e = 0; e < 4; ++e) if (k0 + 4 * tk4 + e < op.K) w[e] += v[e];
+        }
         if (op.db && k0 == 0 && tk4 == 0) op.db[n] += bsum;
     }
 }

@@ -631,7 +631,7 @@ __global__ __launch_bounds__(WPB * 64) void ln_bwd_lean_kernel(const bf16_t* __r
 // passes of one launch sequence (same H, same block count) are folded into their gradients by ONE launch.
 // grid (ceil(H/64), items * 3, 8): a workgroup = 64 columns x 4 interleaved row groups over 1/8 of the partials, LDS-reduced, then
 // ONE atomic per column per workgroup (8 adders per address: no contention to speak of).
-struct LnReduceBatch { float* out[32][3]; const float* partial[32]; int nblocks, H, nq, items; };
+struct LnReduceBatch { float* out[32][3]; const float* partial[32]; int nblocks[32]; int H, nq, items; };   // (nblocks per item: the calls of one launch may differ in rows)
 __global__ __launch_bounds__(256) void ln_bwd_reduce_batch_kernel(const LnReduceBatch b) {
     __shared__ float red[4][64];
     const int col = blockIdx.x * 64 + (threadIdx.x & 63), sub = threadIdx.x >> 6;
@@ -639,8 +639,9 @@ __global__ __launch_bounds__(256) void ln_bwd_reduce_batch_kernel(const LnReduce
     float* out = b.out[item][k];
     if (out == nullptr) return;
     const float* partial = b.partial[item];
-    const int per = (b.nblocks + gridDim.z - 1) / gridDim.z;
-    const int b0 = blockIdx.z * per, b1 = min(b.nblocks, b0 + per);
+    const int nblocks = b.nblocks[item];
+    const int per = (nblocks + gridDim.z - 1) / gridDim.z;
+    const int b0 = blockIdx.z * per, b1 = min(nblocks, b0 + per);
     float s = 0.f;
     if (col < b.H)
         for (int q = b0 + sub; q < b1; q += 4) s += partial[((size_t)q * b.nq + k) * b.H + col];
@@ -1620,7 +1621,7 @@ int mmbert_ln_bwd(hipStream_t stream, const void* dy, int lddy, const int* dy_ro
     if (partial_ws && !defer_reduce) {
         LnReduceBatch b = {};
         b.out[0][0] = dgamma; b.out[0][1] = dbeta; b.out[0][2] = dbias2; b.partial[0] = partial_ws;
-        b.nblocks = nblocks; b.H = H; b.nq = 3; b.items = 1;
+        b.nblocks[0] = nblocks; b.H = H; b.nq = 3; b.items = 1;
         hipLaunchKernelGGL(ln_bwd_reduce_batch_kernel, dim3((H + 63) / 64, 3, 8), dim3(256), 0, stream, b);
         MMB_CHECK_LAUNCH();
     }
@@ -1631,19 +1632,33 @@ int mmbert_ln_bwd(hipStream_t stream, const void* dy, int lddy, const int* dy_ro
 size_t mmbert_ln_bwd_workspace(int M, int H) { return (size_t)ln_bwd_blocks(M, H) * 3 * H; }
 
 // Deferred reduction (mmbert_ln_bwd(..., defer_reduce = 1)): folds the partial sums of `items` (<= 32) earlier mmbert_ln_bwd calls
-// -- same M and H, each with its own partial_ws -- into their gradients in one launch.
-int mmbert_ln_bwd_reduce(hipStream_t stream, int items, const float* const* partial_ws, float* const* dgamma, float* const* dbeta,
-                         float* const* dbias2, int M, int H) {
-    if (items <= 0 || M <= 0) return 0;
+// -- same H, each with its own partial_ws -- into their gradients in one launch.  mmbert_ln_bwd_reduce: all calls had M rows;
+// mmbert_ln_bwd_reduce_rows: call i had M[i] rows (the sparse start of backward, the dense layers and the embedding stage in one list).
+static int ln_bwd_reduce_launch(hipStream_t stream, int items, const float* const* partial_ws, float* const* dgamma, float* const* dbeta,
+                                float* const* dbias2, const int* Ms, int M_all, int H) {
+    if (items <= 0) return 0;
     if (items > 32) return -1;
     LnReduceBatch b = {};
     for (int i = 0; i < items; ++i) {
-        b.out[i][0] = dgamma[i]; b.out[i][1] = dbeta[i]; b.out[i][2] = dbias2 ? dbias2[i] : nullptr; b.partial[i] = partial_ws[i];
+        const int M = Ms ? Ms[i] : M_all;
+        b.out[i][0] = M > 0 ? dgamma[i] : nullptr; b.out[i][1] = M > 0 ? dbeta[i] : nullptr; b.out[i][2] = (M > 0 && dbias2) ? dbias2[i] : nullptr;
+        b.partial[i] = partial_ws[i];
+        b.nblocks[i] = M > 0 ? ln_bwd_blocks(M, H) : 0;
     }
-    b.nblocks = ln_bwd_blocks(M, H); b.H = H; b.nq = 3; b.items = items;
+    b.H = H; b.nq = 3; b.items = items;
     hipLaunchKernelGGL(ln_bwd_reduce_batch_kernel, dim3((H + 63) / 64, items * 3, 8), dim3(256), 0, stream, b);
     MMB_CHECK_LAUNCH();
     return 0;
+}
+int mmbert_ln_bwd_reduce(hipStream_t stream, int items, const float* const* partial_ws, float* const* dgamma, float* const* dbeta,
+                         float* const* dbias2, int M, int H) {
+    if (M <= 0) return 0;
+    return ln_bwd_reduce_launch(stream, items, partial_ws, dgamma, dbeta, dbias2, nullptr, M, H);
+}
+int mmbert_ln_bwd_reduce_rows(hipStream_t stream, int items, const float* const* partial_ws, float* const* dgamma, float* const* dbeta,
+                              float* const* dbias2, const int* M, int H) {
+    if (!M) return -1;
+    return ln_bwd_reduce_launch(stream, items, partial_ws, dgamma, dbeta, dbias2, M, 0, H);
 }
 
 int mmbert_embed_gather(hipStream_t stream, const int64_t* ids, const int64_t* tts, const float* word, const float* type, const float* pos,

@@ -281,7 +281,7 @@ class _EncoderFn:
         return x, saved
 
     @staticmethod
-    def run_backward(top, layout, key_bias, kv_len, saved, dy, dy_rows, top_rows, compact=None):
+    def run_backward(top, layout, key_bias, kv_len, saved, dy, dy_rows, top_rows, compact=None, lnd=None):
         """``dy``: gradient of the encoder output -- in the encoder's own row order, or (``dy_rows`` = the int32 row list
         ops.SplitLayout.perm32[:rows_a]) in the caller's order, read through the map by the top layer's LayerNorm'.  ``compact`` =
         (rows in the caller's order int64, their gradients [n, H] bf16): the only rows of the output that carry a gradient, handed
@@ -299,7 +299,11 @@ class _EncoderFn:
         # LayerNorm' leaves its gamma / beta partial sums in a workspace; ONE reduce launch folds all layers' sums into the gradients at
         # the end (with a data-parallel hook: per layer, before the layer's gradient slice is handed to the all-reduce); same-process
         # A/B against round 1's form (bias sums inside LayerNorm', one reduce launch per call): 16.58 vs 16.76 ms per step
-        lnd = ops.LnDeferred(2 * L)
+        # (lnd handed in by the trunk's backward: ITS collector, which already holds the MLM head's call and goes on through the
+        # embedding stage -- one reduce launch for all of them; it flushes at its end)
+        own_lnd = lnd is None
+        if own_lnd:
+            lnd = ops.LnDeferred(2 * L)
         pair_wgrads, held = getattr(top, "pair_wgrads", True), None
         # (model.defer_wgrads: None = by shape (_auto_defer_wgrads), True / False forced; see the comment at its use)
         dw = getattr(top, "defer_wgrads", None)
@@ -328,7 +332,9 @@ class _EncoderFn:
                         src_rows = Ro if dy_rows is not None else R            # dy is in the caller's order iff it comes with a map
                         (dy_c,) = ops.gather_rows([dy], src_rows.int())
                 if R is not None:
-                    dy = _EncoderFn._last_layer_sparse(top, lw, layout, key_bias, kv_len, saved_i, dy_c, R, H, ra, R32)
+                    dy = _EncoderFn._last_layer_sparse(top, lw, layout, key_bias, kv_len, saved_i, dy_c, R, H, ra, R32, lnd)
+                    if top.grad_hook is not None:
+                        lnd.flush()
                     dy_rows = None
                     top._layer_grads_done(i)
                     continue
@@ -397,7 +403,8 @@ class _EncoderFn:
             if top.grad_hook is not None:
                 lnd.flush()                                # ... and after its LayerNorm sums
             top._layer_grads_done(i)
-        lnd.flush()
+        if own_lnd:
+            lnd.flush()
         for c in range(0, len(deferred), 48):                 # (mmbert_gemm_tn_grouped: up to 48 problems = 12 layers per launch)
             _wgrad(top, deferred[c:c + 48])
         side = top._wgrad_stream()
@@ -420,7 +427,7 @@ class _EncoderFn:
         return R
 
     @staticmethod
-    def _last_layer_sparse(top, lw, layout, key_bias, kv_len, saved_i, dy_c, R, H, ra, R32=None):
+    def _last_layer_sparse(top, lw, layout, key_bias, kv_len, saved_i, dy_c, R, H, ra, R32=None, lnd=None):
         """Backward of the top encoder layer when only the rows R of its output carry a gradient: the output sublayer (LayerNorm',
         FFN-down and FFN-up input gradients, their weight gradients), LayerNorm' and the output projection of the attention
         sublayer run on those rows only (gathered operands, the dropout masks of the ORIGINAL rows); attention's backward is
@@ -434,7 +441,7 @@ class _EncoderFn:
         dy = dy_c
         dz2d_c = torch.empty_like(dy_c) if d_h2[1] else None
         dz2_c = ops.ln_bwd(dy_c, z2, m2_c, r2_c, lw["ln2_g"], lw["g_ln2_g"], lw["g_ln2_b"], x_rows=R32, dx2=dz2d_c, pre_drop=d_h2,
-                           drop_rows=R32)
+                           drop_rows=R32, deferred=lnd)
         if dz2d_c is None:
             dz2d_c = dz2_c
         du_c = ops.gemm_nt(dz2d_c, lw["W2T"], gelu_bwd_u=u_c)
@@ -442,7 +449,7 @@ class _EncoderFn:
         dy1_c = ops.gemm_nt_splitk(du_c, lw["W1T"], resid=dz2_c) if du_c.shape[0] <= 1024 else ops.gemm_nt(du_c, lw["W1T"], resid=dz2_c)
         dz1d_c = torch.empty_like(dy_c) if d_h1[1] else None
         dz1_c = ops.ln_bwd(dy1_c, z1, m1_c, r1_c, lw["ln1_g"], lw["g_ln1_g"], lw["g_ln1_b"], x_rows=R32, dx2=dz1d_c, pre_drop=d_h1,
-                           drop_rows=R32)
+                           drop_rows=R32, deferred=lnd)
         if dz1d_c is None:
             dz1d_c = dz1_c
         dctx = torch.zeros((ra, H), device=dy.device, dtype=torch.bfloat16)
@@ -596,7 +603,12 @@ class _TrunkFn(torch.autograd.Function):
         top._join_heads_backward()                                # (safety net: normally joined by the MLM head's backward)
         top._flat.settle([w["g_word_pad"]])                       # no MLM-head launch has overwritten a dropped table gradient (no labelled row):
                                                                   # zero it before the embedding rows are added / the slice is reduced
+        # ONE collector for the LayerNorm' gamma / beta sums of the whole backward -- the MLM head's call (already in it), the sparse top
+        # layer's two, the dense layers', the embedding stage's: one reduce launch at the end instead of seven (a data-parallel hook
+        # flushes it wherever it needs final gradients)
+        lnd = top._shared_lnd()
         if top.head_grad_hook is not None:
+            lnd.flush()
             top.head_grad_hook()                                  # every gradient of the heads is final, the tied decoder's included
         dy_rows = None
         if compact is None:
@@ -604,7 +616,7 @@ class _TrunkFn(torch.autograd.Function):
             if split is not None:
                 dy_rows = split.perm32[:split.rows_a]             # dy is in the caller's order: the top LayerNorm' reads it through the map
         dx = _EncoderFn.run_backward(top, layout, t.key_bias, None if split is not None else t.kv_len, ctx.saved, dy, dy_rows, t.top_rows,
-                                     compact)
+                                     compact, lnd)
         ctx.saved = None
         if split is not None:
             top.last_backward_row_fraction = float(split.rows_a) / split.tokens
@@ -615,7 +627,6 @@ class _TrunkFn(torch.autograd.Function):
         dJ = torch.empty_like(J)
         de0 = torch.empty_like(e0)
         joint = sorted(ctx.joff)
-        lnd = ops.LnDeferred(8)                                  # the partial sums of same-sized launches are folded by one reduce each
         for n, k in enumerate(joint):
             S = lens[k]
             lo = ctx.joff[k]
@@ -626,7 +637,6 @@ class _TrunkFn(torch.autograd.Function):
             else:
                 ops.ln_bwd(dx[bounds[k]:bounds[k + 1]], J[lo:lo + B * S], m_, r_, w["joint_ln_g"], w["g_joint_ln_g"], w["g_joint_ln_b"],
                            dx=dJ[lo:lo + B * S], post_drop=t.d_joint[k], deferred=lnd)
-        lnd.flush()                                              # (dJ complete before the projection's backward reads it: same stream)
         for n, k in enumerate(joint):
             S = lens[k]
             lo = ctx.joff[k]
@@ -814,12 +824,15 @@ class _MLMHeadFn(torch.autograd.Function):
         ctx.top._flat.grads_dirty = True
         ctx.top._flat.attach_lazy()
         gs = dloss.contiguous().float()
+        # the transform LayerNorm's gamma / beta sums join the trunk's collector when the trunk's backward follows (it flushes), else
+        # they are folded right here
+        lnd = ctx.top._shared_lnd() if (ctx.trunk is not None and ctx.needs_input_grad[0]) else None
         if ctx.compact:
             y_c, pre_c, t0_c, mean_c, rstd_c, t_c, logits_c, labels_c, bounds_c, inv, lse, sel = ctx.saved_tensors
             dl = ops.ce_bwd(logits_c, V, labels_c, bounds_c, ctx.nseg, inv, gs, lse, logits_c)       # in place: the scores go nowhere
             ops.gemm_tn(dl, t_c, w["g_word_pad"], bias_out=w["g_pred_bias"], accumulate=ctx.top._flat.take_accumulate([w["g_word_pad"]]))
             dt = ops.gemm_nt_splitk(dl, w["wordT"])
-            dt0 = ops.ln_bwd(dt, t0_c, mean_c, rstd_c, w["mlm_ln_g"], w["g_mlm_ln_g"], w["g_mlm_ln_b"])
+            dt0 = ops.ln_bwd(dt, t0_c, mean_c, rstd_c, w["mlm_ln_g"], w["g_mlm_ln_g"], w["g_mlm_ln_b"], deferred=lnd)
             dpre = ops.gelu_bwd(dt0, pre_c)
             ops.gemm_tn(dpre, y_c, w["g_Wt"], bias_out=w["g_bt"])
             dy_all = torch.empty((sel.numel() + extra_rows, y_c.shape[1]), device=y_c.device, dtype=torch.bfloat16)
@@ -839,7 +852,7 @@ class _MLMHeadFn(torch.autograd.Function):
                 t_c, t0_c, pre_c, y_c, mean_c, rstd_c = ops.gather_rows([t, t0, pre, y, mean, rstd], idx)      # one launch
                 ops.gemm_tn(dl, t_c, w["g_word_pad"], bias_out=w["g_pred_bias"], accumulate=ctx.top._flat.take_accumulate([w["g_word_pad"]]))
                 dt = ops.gemm_nt_splitk(dl, w["wordT"])                     # K = vocabulary, a few hundred rows: split-K
-                dt0 = ops.ln_bwd(dt, t0_c, mean_c, rstd_c, w["mlm_ln_g"], w["g_mlm_ln_g"], w["g_mlm_ln_b"])
+                dt0 = ops.ln_bwd(dt, t0_c, mean_c, rstd_c, w["mlm_ln_g"], w["g_mlm_ln_g"], w["g_mlm_ln_b"], deferred=lnd)
                 dpre = ops.gelu_bwd(dt0, pre_c)
                 ops.gemm_tn(dpre, y_c, w["g_Wt"], bias_out=w["g_bt"])
                 dy_all = torch.empty((n + extra_rows, y.shape[1]), device=y.device, dtype=torch.bfloat16)
@@ -850,7 +863,7 @@ class _MLMHeadFn(torch.autograd.Function):
         ops.ce_bwd(logits, V, labels, seg_bounds, ctx.nseg, inv, gs, lse, dl)
         ops.gemm_tn(dl, t, w["g_word_pad"], bias_out=w["g_pred_bias"], accumulate=ctx.top._flat.take_accumulate([w["g_word_pad"]]))   # tied decoder weight + prediction bias gradient
         dt = ops.gemm_nt(dl, w["wordT"])
-        dt0 = ops.ln_bwd(dt, t0, mean, rstd, w["mlm_ln_g"], w["g_mlm_ln_g"], w["g_mlm_ln_b"])
+        dt0 = ops.ln_bwd(dt, t0, mean, rstd, w["mlm_ln_g"], w["g_mlm_ln_g"], w["g_mlm_ln_b"], deferred=lnd)
         dpre = ops.gelu_bwd(dt0, pre)
         ops.gemm_tn(dpre, y, w["g_Wt"], bias_out=w["g_bt"])
         return ops.gemm_nt(dpre, w["WtT"])
@@ -900,6 +913,13 @@ class _GpuModelBase(nn.Module):
         ev = self.__dict__.pop("_heads_join", None)
         if ev is not None:
             torch.cuda.current_stream().wait_event(ev)
+
+    def _shared_lnd(self):
+        """The one ``ops.LnDeferred`` collector of a backward pass (MLM head -> trunk: see ``_TrunkFn.backward``)."""
+        l = self.__dict__.get("_lnd")
+        if l is None:
+            l = self.__dict__["_lnd"] = ops.LnDeferred(32)
+        return l
 
     @property
     def input_stream(self):

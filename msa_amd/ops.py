@@ -260,40 +260,47 @@ _lnd_cache = {}
 
 
 class LnDeferred:
-    """Collects the partial-sum workspaces of several ``ln_bwd(..., deferred=self)`` calls that share M and H (an encoder's 2 per
-    layer) and folds them into their gradients with ONE ``mmbert_ln_bwd_reduce`` launch per ``slots`` calls: ``flush()``.
-    ``slots``: how many calls the caller expects before its flush (2 x layers for an encoder backward; at most 32 per launch).  The
-    workspace is ONE persistent buffer per (device, stream) that grows on demand -- not a fresh 32-slot allocation per backward
-    (300 MB at the headline shape where 24 slots are used, and churn in the caching allocator when M changes with the data)."""
+    """Collects the partial-sum workspaces of several ``ln_bwd(..., deferred=self)`` calls that share H -- an encoder's 2 per layer,
+    and (round 4) calls of other row counts too: the MLM head's and the sparse top layer's few hundred rows, the embedding stage --
+    and folds them into their gradients with ONE ``mmbert_ln_bwd_reduce_rows`` launch per ``slots`` calls: ``flush()``.
+    ``slots``: how many calls the caller expects before its flush (at most 32 per launch).  The workspace is ONE persistent buffer
+    per (device, stream) that grows on demand -- not a fresh allocation per backward (300 MB at the headline shape where 24 slots
+    are used, and churn in the caching allocator when M changes with the data)."""
 
     def __init__(self, slots: int = 32):
-        self.items, self.key, self.ws = [], None, None
+        self.items, self.H, self.ws, self.used = [], None, None, 0
         self.slots = max(1, min(32, int(slots)))
 
     def slot(self, M, H, device, dgamma, dbeta, dbias2) -> int:
-        key = (M, H)
-        if self.key is not None and (key != self.key or len(self.items) == self.slots):
+        if self.H is not None and (H != self.H or len(self.items) == self.slots):
             self.flush()
-        self.key = key
+        self.H = H
         per = _lib.load().mmbert_ln_bwd_workspace(M, H)
-        if not self.items:                                   # (a buffer in use by queued launches is never replaced mid-collection)
-            ck = (device, _stream())
-            ws = _lnd_cache.get(ck)
-            if ws is None or ws.numel() < self.slots * per:
-                ws = _lnd_cache[ck] = torch.empty(self.slots * per, device=device, dtype=torch.float32)
-            self.ws = ws
-        ptr = self.ws.data_ptr() + 4 * per * len(self.items)
-        self.items.append((ptr, dgamma.data_ptr(), dbeta.data_ptr(), dbias2.data_ptr() if dbias2 is not None else None))
+        ck = (device, _stream())
+        if not self.items:
+            self.ws, self.used = _lnd_cache.get(ck), 0
+        if self.ws is None or self.ws.numel() < self.used + per:
+            # (a buffer in use by queued launches is replaced only once its reduce is queued behind them: same stream, so the caching
+            # allocator cannot hand it out earlier)
+            self.flush()
+            self.H = H
+            want = max(self.slots * per, 2 * (self.ws.numel() if self.ws is not None else 0))
+            self.ws, self.used = torch.empty(want, device=device, dtype=torch.float32), 0
+            _lnd_cache[ck] = self.ws
+        ptr = self.ws.data_ptr() + 4 * self.used
+        self.used += per
+        self.items.append((ptr, dgamma.data_ptr(), dbeta.data_ptr(), dbias2.data_ptr() if dbias2 is not None else None, int(M)))
         return ptr
 
     def flush(self):
         n = len(self.items)
         if n:
-            M, H = self.key
             PA = ctypes.c_void_p * n
             cols = list(zip(*self.items))
-            _lib.check(_lib.load().mmbert_ln_bwd_reduce(_stream(), n, PA(*cols[0]), PA(*cols[1]), PA(*cols[2]), PA(*cols[3]), M, H), "mmbert_ln_bwd_reduce")
-        self.items, self.key = [], None
+            Ms = (ctypes.c_int * n)(*cols[4])
+            _lib.check(_lib.load().mmbert_ln_bwd_reduce_rows(_stream(), n, PA(*cols[0]), PA(*cols[1]), PA(*cols[2]), PA(*cols[3]), Ms, self.H),
+                       "mmbert_ln_bwd_reduce_rows")
+        self.items, self.H, self.used = [], None, 0
 
 
 def embed_gather(ids, tts, word, type_, pos, T, out=None):
