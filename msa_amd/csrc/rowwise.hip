@@ -909,7 +909,10 @@ __global__ __launch_bounds__(256) void pair_wgrad_kernel(const PairBwdArgs a) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) acc[j][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
     // four steps of 4 rows in flight per wave (one wave per SIMD: nothing else hides the memory latency); the ring is unrolled so
-    // that a stage is refilled in place -- rotating it through register copies would wait for the newest load in every step
+    // that a stage is refilled in place -- rotating it through register copies would wait for the newest load in every step.
+    // (hipcc still moves a stage's loads from the end of one turn to the top of the next; inline-asm loads behind counted waits ran
+    // 21 instead of 26 us, and with eight stages the register allocator copied an asm output before its wait: the load landed in a
+    // register that by then held an address -- a memory fault.  Asynchronous asm outputs are not worth 5 us: plain loads stay.)
     Stage st[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) load(st[u], r0 + 4 * u + g);
@@ -925,9 +928,11 @@ __global__ __launch_bounds__(256) void pair_wgrad_kernel(const PairBwdArgs a) {
             for (int j = 0; j < PAIR_NT; ++j) fv[j] = st[u].f[j];
             load(st[u], r + 16 + 4 * u + g);
 #pragma unroll
-            for (int j = 0; j < PAIR_NT; ++j)
+            for (int j = 0; j < PAIR_NT; ++j) {
+                if (j >= njt) continue;                               // (wave-uniform: D = 35 has three column tiles, not five)
 #pragma unroll
                 for (int i = 0; i < 4; ++i) acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], fv[j], acc[j][i], 0, 0, 0);
+            }
         }
     }
     // waves 1-3 hand their tiles to wave 0, which adds them in wave order and writes the workgroup's partial product
