@@ -44,25 +44,30 @@ __global__ void split_rows_kernel(const int64_t* __restrict__ row_seq, const int
 #define SL_MAXSEQ 1024
 __global__ __launch_bounds__(1024) void split_layout_kernel(const int* __restrict__ lens, const int* __restrict__ valid, int nseq, int rows, int xs,
                                                             int nf_max, int nq_max, int* __restrict__ out) {
-    __shared__ int v[SL_MAXSEQ], ln[SL_MAXSEQ], rk[SL_MAXSEQ], sa[SL_MAXSEQ], sb[SL_MAXSEQ], seq_of_rank[SL_MAXSEQ];
+    __shared__ int v[SL_MAXSEQ], ln[SL_MAXSEQ], rk[SL_MAXSEQ], sa[SL_MAXSEQ], sb[SL_MAXSEQ], seq_of_rank[SL_MAXSEQ], ntr[SL_MAXSEQ];
     __shared__ int tot[3];
     const int tid = threadIdx.x;
+    if (tid < 3) tot[tid] = 0;
     for (int s = tid; s < nseq; s += 1024) { ln[s] = lens[s]; v[s] = min(valid[s], lens[s]); }
     __syncthreads();
-    for (int s = tid; s < nseq; s += 1024) {                   // stable rank of -v
-        int r = 0;
+    // Every sequence's thread walks the others itself -- stable rank of -v and both exclusive prefix sums in one pass of independent
+    // LDS reads.  (Thread 0 alone used to run the two prefix sums and the two tile totals as dependent LDS chains: 4 x nseq steps
+    // of a read-add-write each, most of the kernel's 23 us in front of every forward pass.)
+    for (int s = tid; s < nseq; s += 1024) {
+        int r = 0, a = 0, b = 0;
         const int vs = v[s];
-        for (int t = 0; t < nseq; ++t) r += (v[t] > vs || (v[t] == vs && t < s)) ? 1 : 0;
+        for (int t = 0; t < nseq; ++t) {
+            const int vt = v[t];
+            r += (vt > vs || (vt == vs && t < s)) ? 1 : 0;
+            if (t < s) { a += vt; b += ln[t] - vt; }
+        }
         rk[s] = r;
         seq_of_rank[r] = s;
+        sa[s] = a; sb[s] = b;
+        if (s == nseq - 1) tot[2] = a + vs;
     }
-    if (tid == 0) {                                            // prefix sums (nseq <= 1024: a serial pass is a few microseconds)
-        int a = 0;
-        for (int s = 0; s < nseq; ++s) { sa[s] = a; a += v[s]; }
-        int b = a;
-        for (int s = 0; s < nseq; ++s) { sb[s] = b; b += ln[s] - v[s]; }
-        tot[2] = a;
-    }
+    __syncthreads();
+    for (int s = tid; s < nseq; s += 1024) sb[s] += tot[2];
     __syncthreads();
     int* f_seq = out; int* f_r0 = out + nf_max; int* f_sh = out + 2 * nf_max; int* f_end = out + 3 * nf_max;
     int* q_seq = out + 4 * nf_max; int* q_r0 = q_seq + nq_max; int* q_sh = q_seq + 2 * nq_max; int* q_end = q_seq + 3 * nq_max;
@@ -71,17 +76,22 @@ __global__ __launch_bounds__(1024) void split_layout_kernel(const int* __restric
     // position of tile (s, k) of a list with nt[.] tiles per sequence: tiles of earlier groups, then inside the group by (k, rank % xs)
     auto place = [&](bool regionB, int base, int* cnt_out) {
         auto nt = [&](int s) { const int c = regionB ? ln[s] - v[s] : v[s]; return (c + rows - 1) / rows; };
-        int total = 0;
-        for (int s = tid; s < nseq; s += 1024) {
+        for (int s = tid; s < nseq; s += 1024) {                 // tiles per sequence in RANK order (one division per sequence), and their total
             const int n = nt(s);
+            ntr[rk[s]] = n;
+            if (n) atomicAdd(cnt_out, n);
+        }
+        __syncthreads();
+        for (int s = tid; s < nseq; s += 1024) {
+            const int r = rk[s], n = ntr[r];
             if (n == 0) continue;
-            const int r = rk[s], g = r / xs, m = r - g * xs;
+            const int g = r / xs, m = r - g * xs;
             int before_groups = 0;
-            for (int r2 = 0; r2 < g * xs; ++r2) before_groups += nt(seq_of_rank[r2]);
+            for (int r2 = 0; r2 < g * xs; ++r2) before_groups += ntr[r2];
             for (int k = 0; k < n; ++k) {
                 int pos = before_groups;
                 for (int m2 = 0; m2 < xs && g * xs + m2 < nseq; ++m2) {
-                    const int n2 = nt(seq_of_rank[g * xs + m2]);
+                    const int n2 = ntr[g * xs + m2];
                     pos += min(n2, k) + ((n2 > k && m2 < m) ? 1 : 0);
                 }
                 const int first = regionB ? v[s] : 0, shift = regionB ? sb[s] - v[s] : sa[s], end = regionB ? ln[s] : v[s];
@@ -89,7 +99,7 @@ __global__ __launch_bounds__(1024) void split_layout_kernel(const int* __restric
                 if (!regionB) { q_seq[pos] = s; q_r0[pos] = k * rows; q_sh[pos] = shift; q_end[pos] = end; }
             }
         }
-        if (tid == 0) { for (int s = 0; s < nseq; ++s) total += nt(s); *cnt_out = total; }
+        __syncthreads();                                          // (ntr is rewritten by the next region; the total is complete)
     };
     place(false, 0, &tot[0]);
     __syncthreads();
@@ -1239,14 +1249,22 @@ __global__ __launch_bounds__(256) void transpose_cast_kernel(const SRC* __restri
     bf16_t* o = dst + ds.dst_off;
     const bool full = r0 + 64 <= ds.rows && c0 + 64 <= ds.cols && r0 + 64 <= ds.dst_ld && !(ds.cols & 3) && !(ds.dst_ld & 7) && !(ds.src_off & 3) && !(ds.dst_off & 7);
     if (full) {                                  // interior tile: 16-byte reads along a source row, 16-byte writes along a destination row
-        for (int e = threadIdx.x; e < 1024; e += 256) {
-            const int r = e >> 4, c = (e & 15) << 2;
+        // the thread's four reads are issued together (as a loop hipcc left it rolled: read, wait, LDS store, four times -- four
+        // memory round trips per 8-KB tile; the launch took 100 us for 340 MB)
+        typedef typename std::conditional<sizeof(SRC) == 4, float4, bf16x4>::type V4;
+        V4 v4[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int e = threadIdx.x + 256 * q, r = e >> 4, c = (e & 15) << 2;
+            v4[q] = *(const V4*)(s + (size_t)(r0 + r) * ds.cols + c0 + c);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int e = threadIdx.x + 256 * q, r = e >> 4, c = (e & 15) << 2;
             if constexpr (sizeof(SRC) == 4) {
-                const float4 v = *(const float4*)(s + (size_t)(r0 + r) * ds.cols + c0 + c);
-                t[r][c] = v.x; t[r][c + 1] = v.y; t[r][c + 2] = v.z; t[r][c + 3] = v.w;
+                t[r][c] = v4[q].x; t[r][c + 1] = v4[q].y; t[r][c + 2] = v4[q].z; t[r][c + 3] = v4[q].w;
             } else {
-                const bf16x4 v = *(const bf16x4*)(s + (size_t)(r0 + r) * ds.cols + c0 + c);
-                t[r][c] = bf2f(v[0]); t[r][c + 1] = bf2f(v[1]); t[r][c + 2] = bf2f(v[2]); t[r][c + 3] = bf2f(v[3]);
+                t[r][c] = bf2f(v4[q][0]); t[r][c + 1] = bf2f(v4[q][1]); t[r][c + 2] = bf2f(v4[q][2]); t[r][c + 3] = bf2f(v4[q][3]);
             }
         }
         __syncthreads();
