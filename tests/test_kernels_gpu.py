@@ -670,6 +670,37 @@ def test_ln_fwd_bwd(ops, M, H, eps):
     assert_close(dbeta, b_.grad, 1e-3, 1e-3 * math.sqrt(M), "dbeta")
 
 
+def test_ln_bwd_deferred_reduce_over_calls_of_different_row_counts(ops):
+    """One ops.LnDeferred over LayerNorm' calls of different M (the MLM head's few hundred rows, the encoder layers' thousands, the
+    embedding stage) -- one mmbert_ln_bwd_reduce_rows launch -- gives every call the gamma / beta sums of its own immediate reduce; more
+    calls than slots, and a workspace that has to grow mid-collection, flush on their own."""
+    H = 768
+    Ms = [360, 13850, 13850, 37, 8000, 800, 1]
+    gamma = (1 + 0.1 * rnd(H, seed=70)).to(DEV)
+    calls = []
+    for q, M in enumerate(Ms):
+        x, dy = bf(rnd(M, H, seed=71 + 2 * q)).to(DEV), bf(rnd(M, H, seed=72 + 2 * q)).to(DEV)
+        _, mean, rstd = ops.ln_fwd(x, gamma, torch.zeros(H, device=DEV), 1e-12)
+        calls.append((x, dy, mean, rstd))
+    ref = []
+    for x, dy, mean, rstd in calls:
+        dg, db = torch.zeros(H, device=DEV), torch.zeros(H, device=DEV)
+        dx = ops.ln_bwd(dy, x, mean, rstd, gamma, dg, db)
+        ref.append((dx, dg, db))
+    for slots in (32, 3):
+        ops._lnd_cache.clear()                                     # (the persistent workspace starts small again: it has to grow)
+        lnd = ops.LnDeferred(slots)
+        got = []
+        for x, dy, mean, rstd in calls:
+            dg, db = torch.zeros(H, device=DEV), torch.zeros(H, device=DEV)
+            got.append((ops.ln_bwd(dy, x, mean, rstd, gamma, dg, db, deferred=lnd), dg, db))
+        lnd.flush()
+        for q, ((dx, dg, db), (rx, rg, rb)) in enumerate(zip(got, ref)):
+            assert torch.equal(dx, rx), f"call {q}: dx differs"
+            assert_close(dg, rg.cpu(), 1e-5, 1e-5 * math.sqrt(Ms[q]), f"call {q} dgamma (slots {slots})")
+            assert_close(db, rb.cpu(), 1e-5, 1e-5 * math.sqrt(Ms[q]), f"call {q} dbeta (slots {slots})")
+
+
 @pytest.mark.parametrize("M,H,n", [(40, 128, 24), (40, 768, 24), (3000, 256, 2500), (2100, 1024, 2050)])
 def test_ln_row_maps_and_dropouts(ops, M, H, n):
     """Row maps on every operand, the post-LN dropout (embedding form) and the branch dropout + second output + bias gradient (encoder
@@ -989,6 +1020,11 @@ def test_pair_proj(ops, D):
     ops.pair_proj_bwd(feat.to(DEV), out, dJ.to(DEV), T, dW, db)
     assert_close(dW, Wr.grad, 1e-3, 1e-3, "pair dW")
     assert_close(db, br.grad, 1e-3, 1e-3, "pair db")
+    dW2, db2 = torch.zeros(H, D, device=DEV), torch.zeros(H, device=DEV)      # per-row-range slabs added in range order: reproducible
+    ops.pair_proj_bwd(feat.to(DEV), out, dJ.to(DEV), T, dW2, db2)
+    assert torch.equal(dW, dW2) and torch.equal(db, db2)
+    ops.pair_proj_bwd(feat.to(DEV), out, dJ.to(DEV), T, dW2, db2)             # and it ACCUMULATES (+=)
+    assert_close(dW2, 2 * Wr.grad, 1e-3, 2e-3, "pair dW accumulated")
 
 
 def test_cross_entropy_segments(ops):
