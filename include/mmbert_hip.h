@@ -316,6 +316,16 @@ int mmbert_transpose_cast(mmbert_stream_t stream, const float* src, void* dst, c
  * MMBertForPretraining.py:406-445 -- only the MLM-labelled rows and the [CLS] rows of the last layer's output carry a gradient). */
 int mmbert_compact_rows(mmbert_stream_t stream, const int* rows32, const int64_t* rows64, int n, const int64_t* extra, int nextra, const int64_t* map,
                         int64_t* out64, int* out32);
+/* The same, and the list's INVERSE for mmbert_scatter_rows_zero: inv_stamp[out[i]] = (int64) stamp << 32 | i.  inv_stamp is a persistent
+ * int64 array over all rows of the matrices the list indexes, zero-filled ONCE by its owner and never cleared: an entry counts only while
+ * its upper half equals the stamp of the current call (stamp != 0, a new one per call). */
+int mmbert_compact_rows_inv(mmbert_stream_t stream, const int* rows32, const int64_t* rows64, int n, const int64_t* extra, int nextra, const int64_t* map,
+                            int64_t* out64, int* out32, int64_t* inv_stamp, unsigned stamp);
+/* Back to full height: dst_k[r] = src_k[i] where inv_stamp[r] = stamp << 32 | i with i < nlist, zero otherwise, for r < nrows and up to 4
+ * matrices k (rows of row_bytes[k] bytes; pointers, pitches and row_bytes multiples of 16).  One launch for the zero fill + index_copy_
+ * pairs that hand the sparse top layer's gradients (attention output, pre-LayerNorm sum) to the dense kernels below it. */
+int mmbert_scatter_rows_zero(mmbert_stream_t stream, int nseg, const void* const* src, void* const* dst, const long long* src_pitch,
+                             const long long* dst_pitch, const int* row_bytes, const int64_t* inv_stamp, unsigned stamp, int nlist, int nrows);
 /* Batched row gather: dst_k[i] = src_k[idx[i]] for i < nrows and up to 12 matrices k that share the row list idx (int32, device); rows
  * are row_bytes[k] bytes (a multiple of 4) at byte pitches src_pitch[k] / dst_pitch[k].  The sparse backward paths use it to pull
  * the labelled rows out of every saved activation in one launch. */

@@ -72,6 +72,8 @@ SIGNATURES = {
     "mmbert_transpose_bf16": (I, [P, P, P, P, I, I]),
     "mmbert_gather_rows": (I, [P, I, P, P, P, P, P, P, I]),
     "mmbert_compact_rows": (I, [P, P, P, I, P, I, P, P, P]),
+    "mmbert_compact_rows_inv": (I, [P, P, P, I, P, I, P, P, P, P, C.c_uint]),
+    "mmbert_scatter_rows_zero": (I, [P, I, P, P, P, P, P, P, C.c_uint, I, I]),
     "mmbert_pack_i64": (I, [P, I, P, P, P, P, P]),
     "mmbert_rows_to_block": (I, [P, P, P, I, I, I, I, P, I, I, P]),
     "mmbert_split_layout": (I, [P, P, P, I, I, I, I, I, P]),

@@ -1911,20 +1911,69 @@ int mmbert_transpose_bf16(hipStream_t stream, const void* src, void* dst, const 
 // out[i] = map[ i < n ? rows[i] : extra[i - n] ]  as int64 AND int32 (map optional): the row list of the top encoder layer's sparse
 // backward -- labelled rows, then the [CLS] rows, in the encoder's packed order -- in one launch (round 3: an int32->int64 cast, a cat,
 // an index_select through the packing's inverse map and an int64->int32 cast)
+// (inv_stamp, optional: the INVERSE of the list for mmbert_scatter_rows_zero -- inv_stamp[out[i]] = stamp << 32 | i in a persistent
+// int64 array over all rows that is never cleared: an entry counts only while its upper half equals the current call's stamp)
 __global__ void compact_rows_kernel(const int* __restrict__ a32, const int64_t* __restrict__ a64, int n, const int64_t* __restrict__ extra, int nextra,
-                                    const int64_t* __restrict__ map, int64_t* __restrict__ out64, int* __restrict__ out32) {
+                                    const int64_t* __restrict__ map, int64_t* __restrict__ out64, int* __restrict__ out32,
+                                    long long* __restrict__ inv_stamp, long long stamp_hi) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n + nextra) return;
     int64_t r = i < n ? (a32 ? (int64_t)a32[i] : a64[i]) : extra[i - n];
     if (map) r = map[r];
     out64[i] = r;
     out32[i] = (int)r;
+    if (inv_stamp) inv_stamp[r] = stamp_hi | (long long)i;
+}
+static int compact_rows_launch(hipStream_t stream, const int* rows32, const int64_t* rows64, int n, const int64_t* extra, int nextra, const int64_t* map,
+                               int64_t* out64, int* out32, long long* inv_stamp, unsigned stamp) {
+    if (n < 0 || nextra < 0 || (n > 0 && !rows32 && !rows64) || (nextra > 0 && !extra)) return -1;
+    if (n + nextra == 0) return 0;
+    hipLaunchKernelGGL(compact_rows_kernel, dim3((n + nextra + 255) / 256), dim3(256), 0, stream, rows32, rows64, n, extra, nextra, map, out64, out32,
+                       inv_stamp, (long long)((unsigned long long)stamp << 32));
+    MMB_CHECK_LAUNCH();
+    return 0;
 }
 int mmbert_compact_rows(hipStream_t stream, const int* rows32, const int64_t* rows64, int n, const int64_t* extra, int nextra, const int64_t* map,
                         int64_t* out64, int* out32) {
-    if (n < 0 || nextra < 0 || (n > 0 && !rows32 && !rows64) || (nextra > 0 && !extra)) return -1;
-    if (n + nextra == 0) return 0;
-    hipLaunchKernelGGL(compact_rows_kernel, dim3((n + nextra + 255) / 256), dim3(256), 0, stream, rows32, rows64, n, extra, nextra, map, out64, out32);
+    return compact_rows_launch(stream, rows32, rows64, n, extra, nextra, map, out64, out32, nullptr, 0u);
+}
+int mmbert_compact_rows_inv(hipStream_t stream, const int* rows32, const int64_t* rows64, int n, const int64_t* extra, int nextra, const int64_t* map,
+                            int64_t* out64, int* out32, int64_t* inv_stamp, unsigned stamp) {
+    if (!inv_stamp || stamp == 0u) return -1;
+    return compact_rows_launch(stream, rows32, rows64, n, extra, nextra, map, out64, out32, (long long*)inv_stamp, stamp);
+}
+
+// dst_k[r] = src_k[i] where the stamped inverse says row r is entry i of the current list, ZERO otherwise, for r < nrows and up to 4
+// matrices k: a zero fill and an index_copy_ per matrix in one launch (the sparse top layer's gradients going back to full height).
+struct ScatterSeg { const char* src; char* dst; long long src_pitch, dst_pitch; int row_bytes; };
+struct ScatterArgs { ScatterSeg s[4]; };
+__global__ __launch_bounds__(256) void scatter_rows_zero_kernel(const ScatterArgs a, const long long* __restrict__ inv_stamp, long long stamp_hi, int nlist) {
+    const ScatterSeg s = a.s[blockIdx.y];
+    const int r = blockIdx.x;
+    const long long v = inv_stamp[r];
+    const int i = (int)(v & 0xffffffffll);
+    const bool hit = (v & ~0xffffffffll) == stamp_hi && i < nlist;
+    char* dst = s.dst + (long long)r * s.dst_pitch;
+    const char* src = s.src + (long long)(hit ? i : 0) * s.src_pitch;
+    for (int b = threadIdx.x * 16; b < s.row_bytes; b += 256 * 16) {
+        uint4 x = {0u, 0u, 0u, 0u};
+        if (hit) x = *(const uint4*)(src + b);
+        *(uint4*)(dst + b) = x;
+    }
+}
+int mmbert_scatter_rows_zero(hipStream_t stream, int nseg, const void* const* src, void* const* dst, const long long* src_pitch, const long long* dst_pitch,
+                             const int* row_bytes, const int64_t* inv_stamp, unsigned stamp, int nlist, int nrows) {
+    if (nseg <= 0 || nrows <= 0) return 0;
+    if (nseg > 4 || !inv_stamp || stamp == 0u || nlist < 0) return -1;
+    ScatterArgs a = {};
+    for (int k = 0; k < nseg; ++k) {
+        if (!dst[k] || (nlist > 0 && !src[k]) || row_bytes[k] <= 0 || ((row_bytes[k] | src_pitch[k] | dst_pitch[k]) & 15) ||
+            (((uintptr_t)src[k] | (uintptr_t)dst[k]) & 15)) return -1;
+        a.s[k].src = (const char*)src[k]; a.s[k].dst = (char*)dst[k]; a.s[k].src_pitch = src_pitch[k]; a.s[k].dst_pitch = dst_pitch[k];
+        a.s[k].row_bytes = row_bytes[k];
+    }
+    hipLaunchKernelGGL(scatter_rows_zero_kernel, dim3(nrows, nseg), dim3(256), 0, stream, a, (const long long*)inv_stamp,
+                       (long long)((unsigned long long)stamp << 32), nlist);
     MMB_CHECK_LAUNCH();
     return 0;
 }

@@ -324,7 +324,11 @@ class _EncoderFn:
                 R32 = None
                 if compact is not None:
                     rows_l, rows_f, dy_c = compact                # labelled rows (int32 / int64), [CLS] rows (int64), their gradients stacked
-                    R, R32 = ops.compact_rows(rows_l, rows_f, layout.inv if getattr(layout, "split", False) else None)
+                    # (with the list's stamped inverse: the two gradients that go back to full height below do so in one launch)
+                    rinv = top.__dict__.get("_row_inverse")
+                    if rinv is None or rinv.table.numel() < M_all or rinv.table.device != rows_f.device:
+                        rinv = top.__dict__["_row_inverse"] = ops.RowInverse(M_all, rows_f.device)
+                    R, R32 = ops.compact_rows(rows_l, rows_f, layout.inv if getattr(layout, "split", False) else None, inverse=rinv)
                 elif top_rows is not None:
                     Ro = _EncoderFn._sparse_rows(top_rows, None, ra)          # rows in the caller's order
                     if Ro is not None:
@@ -332,7 +336,8 @@ class _EncoderFn:
                         src_rows = Ro if dy_rows is not None else R            # dy is in the caller's order iff it comes with a map
                         (dy_c,) = ops.gather_rows([dy], src_rows.int())
                 if R is not None:
-                    dy = _EncoderFn._last_layer_sparse(top, lw, layout, key_bias, kv_len, saved_i, dy_c, R, H, ra, R32, lnd)
+                    dy = _EncoderFn._last_layer_sparse(top, lw, layout, key_bias, kv_len, saved_i, dy_c, R, H, ra, R32, lnd,
+                                                       rinv if compact is not None else None)
                     if top.grad_hook is not None:
                         lnd.flush()
                     dy_rows = None
@@ -427,7 +432,7 @@ class _EncoderFn:
         return R
 
     @staticmethod
-    def _last_layer_sparse(top, lw, layout, key_bias, kv_len, saved_i, dy_c, R, H, ra, R32=None, lnd=None):
+    def _last_layer_sparse(top, lw, layout, key_bias, kv_len, saved_i, dy_c, R, H, ra, R32=None, lnd=None, rinv=None):
         """Backward of the top encoder layer when only the rows R of its output carry a gradient: the output sublayer (LayerNorm',
         FFN-down and FFN-up input gradients, their weight gradients), LayerNorm' and the output projection of the attention
         sublayer run on those rows only (gathered operands, the dropout masks of the ORIGINAL rows); attention's backward is
@@ -452,15 +457,20 @@ class _EncoderFn:
                            drop_rows=R32, deferred=lnd)
         if dz1d_c is None:
             dz1d_c = dz1_c
-        dctx = torch.zeros((ra, H), device=dy.device, dtype=torch.bfloat16)
-        dctx.index_copy_(0, R, ops.gemm_nt(dz1d_c, lw["WoT"]))
+        dctx_c = ops.gemm_nt(dz1d_c, lw["WoT"])
+        if rinv is not None:                                      # both full-height gradients in ONE launch (zero fill + index_copy_, twice, before)
+            dctx, dz1 = ops.scatter_rows_zero([dctx_c, dz1_c], rinv, ra)
+        else:
+            dctx = torch.zeros((ra, H), device=dy.device, dtype=torch.bfloat16)
+            dctx.index_copy_(0, R, dctx_c)
         # only the rows R of this layer's attention output have a gradient: the query loops of its backward stop at the last of them
         # in every sequence (the labelled text rows and [CLS] sit in a sequence's first rows: one 64-row query tile instead of ~7).
         # Exact: a query row with dO = 0 has delta = 0 and dS = 0 (round 4; model.top_layer_query_limit = False switches it off)
         qlim = ops.attn_q_limit(R32, layout) if getattr(top, "top_layer_query_limit", True) else None
         dqkv = ops.attn_bwd(qkv, actx, dctx, lse, key_bias, layout, H, drop=d_att, kv_len=kv_len, q_limit=qlim)
-        dz1 = torch.zeros((ra, H), device=dy.device, dtype=torch.bfloat16)
-        dz1.index_copy_(0, R, dz1_c)
+        if rinv is None:
+            dz1 = torch.zeros((ra, H), device=dy.device, dtype=torch.bfloat16)
+            dz1.index_copy_(0, R, dz1_c)
         out = ops.gemm_nt(dqkv, lw["WqkvT"], resid=dz1)
         # (bias gradients b1 / b2 / bo: column sums of the bf16 gradients on the ones-operand MFMA, as in the dense layers)
         _wgrad(top, [(du_c, y1_c, lw["g_W1"], lw["g_b1"]), (dz2d_c, g_c, lw["g_W2"], lw["g_b2"]), (dz1d_c, actx_c, lw["g_Wo"], lw["g_bo"])])

@@ -885,16 +885,54 @@ def heads_tanh_bwd(dP, P):
     return dpre
 
 
-def compact_rows(rows, extra, row_map=None):
-    """(int64, int32) lists ``map[cat(rows, extra)]`` in one launch (mmbert_compact_rows): rows int32 or int64, extra int64, row_map int64 or None."""
+class RowInverse:
+    """The stamped inverse of a row list over ``nrows`` rows (mmbert_compact_rows_inv / mmbert_scatter_rows_zero): one persistent int64
+    array, zero-filled once, and a stamp that ``next()`` advances per list -- entries of earlier lists simply stop counting."""
+
+    def __init__(self, nrows, device):
+        self.table = torch.zeros(nrows, device=device, dtype=torch.int64)
+        self.stamp, self.nlist = 0, 0
+
+    def next(self, nlist):
+        self.stamp = self.stamp % 0xFFFFFFF0 + 1                 # never 0 (the zero fill); a wrap after 4e9 lists meets no live entry
+        self.nlist = nlist
+        return self.stamp
+
+
+def compact_rows(rows, extra, row_map=None, inverse: "RowInverse" = None):
+    """(int64, int32) lists ``map[cat(rows, extra)]`` in one launch (mmbert_compact_rows): rows int32 or int64, extra int64, row_map int64
+    or None.  ``inverse``: a RowInverse that receives the list's inverse (for ``scatter_rows_zero``)."""
     n, ne = rows.numel(), extra.numel()
     out64 = torch.empty(n + ne, device=extra.device, dtype=torch.int64)
     out32 = torch.empty(n + ne, device=extra.device, dtype=torch.int32)
     assert rows.dtype in (torch.int32, torch.int64) and extra.dtype == torch.int64 and rows.is_contiguous() and extra.is_contiguous()
     assert row_map is None or (row_map.dtype == torch.int64 and row_map.is_contiguous())
     r32, r64 = (rows.data_ptr(), None) if rows.dtype == torch.int32 else (None, rows.data_ptr())
-    _lib.check(_lib.load().mmbert_compact_rows(_stream(), r32, r64, n, extra.data_ptr(), ne, _ptr(row_map), out64.data_ptr(), out32.data_ptr()), "mmbert_compact_rows")
+    if inverse is None:
+        _lib.check(_lib.load().mmbert_compact_rows(_stream(), r32, r64, n, extra.data_ptr(), ne, _ptr(row_map), out64.data_ptr(), out32.data_ptr()), "mmbert_compact_rows")
+    else:
+        _lib.check(_lib.load().mmbert_compact_rows_inv(_stream(), r32, r64, n, extra.data_ptr(), ne, _ptr(row_map), out64.data_ptr(), out32.data_ptr(),
+                                                       inverse.table.data_ptr(), inverse.next(n + ne)), "mmbert_compact_rows_inv")
     return out64, out32
+
+
+def scatter_rows_zero(srcs, inverse: "RowInverse", nrows):
+    """[zeros(nrows, ...).index_copy_(0, list, t) for t in srcs] in ONE launch (mmbert_scatter_rows_zero): ``srcs`` = up to 4 2-D tensors
+    (unit inner stride, rows a multiple of 16 bytes) whose row i belongs at row list[i] of the output, ``inverse`` the RowInverse that
+    ``compact_rows`` filled for that list."""
+    n = len(srcs)
+    assert 0 < n <= 4 and nrows <= inverse.table.numel() and inverse.stamp != 0
+    outs = [torch.empty((nrows, t.shape[1]), device=t.device, dtype=t.dtype) for t in srcs]
+    if nrows == 0:
+        return outs
+    for t in srcs:
+        assert t.dim() == 2 and t.stride(1) == 1 and t.shape[0] == inverse.nlist
+    LA = ctypes.c_longlong * n
+    rb = [t.shape[1] * t.element_size() for t in srcs]
+    _lib.check(_lib.load().mmbert_scatter_rows_zero(_stream(), n, _PtrArr[n](*[t.data_ptr() for t in srcs]), _PtrArr[n](*[o.data_ptr() for o in outs]),
+                                                    LA(*[t.stride(0) * t.element_size() for t in srcs]), LA(*rb), _IntArr[n](*rb),
+                                                    inverse.table.data_ptr(), inverse.stamp, inverse.nlist, nrows), "mmbert_scatter_rows_zero")
+    return outs
 
 
 def gather_rows(srcs, idx32):

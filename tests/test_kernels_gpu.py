@@ -1108,6 +1108,31 @@ def test_transpose_cast_and_casts(ops):
     assert torch.equal(dst, dst2)
 
 
+def test_compact_rows_and_scatter_rows_zero(ops):
+    """mmbert_compact_rows(_inv) + mmbert_scatter_rows_zero: the row list map[cat(rows, extra)] in both integer widths, and its stamped
+    inverse taking compact rows back to full height in one launch = zeros().index_copy_() per matrix; a second list on the same
+    RowInverse must not see the first one's entries (nothing is cleared in between: the stamp ends their validity)."""
+    g = torch.Generator().manual_seed(77)
+    M, H = 700, 128
+    inv_map = torch.randperm(M, generator=g).to(DEV)
+    rinv = ops.RowInverse(M, DEV)
+    for n, ne, width in ((40, 6, torch.int32), (3, 2, torch.int64), (0, 5, torch.int32)):
+        pick = torch.randperm(M, generator=g)[:n + ne]
+        rows, extra = pick[:n].to(width).to(DEV), pick[n:].long().to(DEV)
+        ref = inv_map[torch.cat((rows.long(), extra))]
+        r64, r32 = ops.compact_rows(rows, extra, inv_map)
+        assert torch.equal(r64, ref) and torch.equal(r32, ref.int())
+        q64, q32 = ops.compact_rows(rows, extra, inv_map, inverse=rinv)
+        assert torch.equal(q64, ref) and torch.equal(q32, ref.int())
+        a, b = bf(rnd(n + ne, H, seed=78)).to(DEV), rnd(n + ne, 36, seed=79).to(DEV)
+        nrows = M - 50                                               # (the list may point past the rows asked for: those are left out)
+        fa, fb = ops.scatter_rows_zero([a, b], rinv, nrows)
+        keep = ref < nrows
+        ra_, rb_ = torch.zeros(nrows, H, device=DEV, dtype=torch.bfloat16), torch.zeros(nrows, 36, device=DEV)
+        ra_.index_copy_(0, ref[keep], a[keep]); rb_.index_copy_(0, ref[keep], b[keep])
+        assert torch.equal(fa, ra_) and torch.equal(fb, rb_)
+
+
 def test_gather_rows_batched(ops):
     """mmbert_gather_rows: one row list, several matrices (bf16 / fp32 rows of different widths, 1-D vectors, a strided view)."""
     g = torch.Generator().manual_seed(70)
