@@ -804,6 +804,25 @@ __global__ void attn_q_limit_kernel(const int* __restrict__ rows, int n, const i
     }
     atomicMax(out + lo, r - seq_start[lo] + 1);
 }
+// the same in ONE workgroup for up to 1024 sequences: the limits are built in LDS and every entry of out is written (no memset launch
+// in front; the top layer's row list is a few hundred rows)
+__global__ __launch_bounds__(256) void attn_q_limit_wg_kernel(const int* __restrict__ rows, int n, const int* __restrict__ seq_start, int nseq,
+                                                              int* __restrict__ out) {
+    __shared__ int lim[1024], st[1024];
+    for (int s = threadIdx.x; s < nseq; s += 256) { lim[s] = 0; st[s] = seq_start[s]; }
+    __syncthreads();
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const int r = rows[i];
+        int lo = 0, hi = nseq - 1;
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (st[mid] <= r) lo = mid; else hi = mid - 1;
+        }
+        atomicMax(&lim[lo], r - st[lo] + 1);
+    }
+    __syncthreads();
+    for (int s = threadIdx.x; s < nseq; s += 256) out[s] = lim[s];
+}
 
 extern "C" {
 
@@ -871,6 +890,11 @@ int mmbert_debug_set_attn_stamps(void* buf) {
 
 int mmbert_attn_q_limit(hipStream_t stream, const int* rows, int n, const int* seq_start, int nseq, int* q_limit) {
     if (nseq <= 0) return 0;
+    if (nseq <= 1024 && n <= 16384) {
+        hipLaunchKernelGGL(attn_q_limit_wg_kernel, dim3(1), dim3(256), 0, stream, rows, n < 0 ? 0 : n, seq_start, nseq, q_limit);
+        MMB_CHECK_LAUNCH();
+        return 0;
+    }
     if (hipMemsetAsync(q_limit, 0, (size_t)nseq * sizeof(int), stream) != hipSuccess) return (int)hipGetLastError();
     if (n <= 0) return 0;
     hipLaunchKernelGGL(attn_q_limit_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, rows, n, seq_start, nseq, q_limit);
