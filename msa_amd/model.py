@@ -1106,6 +1106,9 @@ class _GpuModelBase(nn.Module):
         bert = self._bert()
         dev = passes[0]["ids"].device
         self._ensure_ready(dev)
+        lnd = self.__dict__.get("_lnd")
+        if lnd is not None and lnd.items and torch.is_grad_enabled():
+            lnd.drop()                 # a backward pass that raised half-way left its LayerNorm' sums behind: no pass is in flight at a forward
         B, T = passes[0]["ids"].shape
         cfg = self.config
         if T > cfg.max_position_embeddings:

@@ -292,6 +292,10 @@ class LnDeferred:
         self.items.append((ptr, dgamma.data_ptr(), dbeta.data_ptr(), dbias2.data_ptr() if dbias2 is not None else None, int(M)))
         return ptr
 
+    def drop(self):
+        """Forget collected calls without folding them (the leftovers of a backward pass that raised half-way)."""
+        self.items, self.H, self.used = [], None, 0
+
     def flush(self):
         n = len(self.items)
         if n:

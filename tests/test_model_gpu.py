@@ -669,6 +669,55 @@ def test_deferred_weight_gradients_equal_the_per_layer_launches():
         same_grads(grads[True][n], grads[False][n], n)
 
 
+def test_one_layernorm_reduce_per_backward_and_no_leftovers_after_a_failed_one():
+    """Round 4: every LayerNorm' of a backward pass (MLM head, sparse top layer, dense layers, embedding stage) shares ONE collector:
+    ONE mmbert_ln_bwd_reduce_rows launch per backward (the trunk's flush at its end) instead of one per call, the
+    same gamma / beta gradients as with a reduce per call; sums a half-finished backward left behind are dropped by the next forward,
+    not folded into its gradients."""
+    cfg = dict(hidden=256, layers=3, heads=4, intermediate=1024, vocab=4096, dataset="mosei", alpha=1.0, beta=1.0)
+    batch = batch_to(synthetic_batch(4, 24, 200, 130, dataset="mosei", vocab=cfg["vocab"], seed=53), DEV)
+    from msa_amd import ops as _ops
+    ln_names = lambda m: [n for n, _ in m.named_parameters() if "LayerNorm" in n]
+    grads, flushes = {}, {}
+    for shared in (True, False):
+        m = build(cfg, train=False)
+        calls, orig_flush, orig_slot = [], _ops.LnDeferred.flush, _ops.LnDeferred.slot
+        _ops.LnDeferred.flush = lambda self, _o=orig_flush, _c=calls: (_c.append(len(self.items)), _o(self))[1]
+        if not shared:                                             # a reduce per call: flush right behind every slot
+            orig_ln = _ops.ln_bwd
+            _ops.ln_bwd = lambda *a, _o=orig_ln, **k: (lambda r, d: (d.flush() if d is not None else None, r)[1])(_o(*a, **k), k.get("deferred"))
+        try:
+            if shared:
+                out, _ = m(**batch)                                # (a first pass grows the collector's workspace, which may flush early)
+                out[0].mean().backward()
+                m._flat.grads.zero_()
+                calls.clear()
+                lnd = m._shared_lnd()                              # leftovers of a backward that "raised": a stale call in the collector
+                H = cfg["hidden"]
+                x = torch.randn(50, H, device=DEV).bfloat16()
+                _, mean, rstd = _ops.ln_fwd(x, torch.ones(H, device=DEV), torch.zeros(H, device=DEV), 1e-12)
+                stale_g, stale_b = torch.zeros(H, device=DEV), torch.zeros(H, device=DEV)
+                _ops.ln_bwd(x, x, mean, rstd, torch.ones(H, device=DEV), stale_g, stale_b, deferred=lnd)
+                assert len(lnd.items) == 1
+            out, _ = m(**batch)
+            if shared:
+                assert len(m._shared_lnd().items) == 0             # dropped at the forward
+            out[0].mean().backward()
+            torch.cuda.synchronize()
+        finally:
+            _ops.LnDeferred.flush = orig_flush
+            if not shared:
+                _ops.ln_bwd = orig_ln
+        if shared:
+            assert float(stale_g.abs().max()) == 0.0 and float(stale_b.abs().max()) == 0.0
+        grads[shared] = {n: dict(m.named_parameters())[n].grad.float().clone() for n in ln_names(m)}
+        flushes[shared] = [c for c in calls if c]
+    assert len(flushes[True]) == 1 and sum(flushes[True]) == sum(flushes[False]) and len(flushes[False]) == sum(flushes[False]), flushes
+    for n in grads[True]:
+        assert float(grads[True][n].abs().max()) > 0
+        same_grads(grads[True][n], grads[False][n], n)
+
+
 def test_sparse_mlm_backward_equals_dense_backward():
     """The MLM head's backward over the labelled rows only (default) against the dense backward over all rows: the
     CE gradient of an unlabelled row is exactly zero, so every parameter gradient must agree up to fp32 summation order."""
