@@ -5,22 +5,31 @@ drains, and how many of those drains follow a single load.  LDS-DMA loads (globa
 double-buffered loops drain by design.
 
     python tools/scan_serialized_loads.py [min_serialized=2]
-"""
+
+tests/test_isa_cpu.py pins the kernels that round 4 fixed (``scan_source``)."""
 import os, re, subprocess, sys, tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from msa_amd.build import HIPCC, FLAGS  # noqa: E402
 
-thr = int(sys.argv[1]) if len(sys.argv) > 1 else 2
-src_dir = os.path.join(ROOT, "msa_amd", "csrc")
-for name in sorted(os.listdir(src_dir)):
-    if not name.endswith(".hip"):
-        continue
+SRC_DIR = os.path.join(ROOT, "msa_amd", "csrc")
+
+
+def _demangle(names):
+    try:
+        out = subprocess.run(["c++filt"], input="\n".join(names), capture_output=True, text=True).stdout.split("\n")
+        return dict(zip(names, out)) if len(out) >= len(names) else {n: n for n in names}
+    except OSError:
+        return {n: n for n in names}
+
+
+def scan_source(name):
+    """{demangled kernel name: (loads, full drains, drains that follow a single load)} for msa_amd/csrc/<name>."""
     with tempfile.TemporaryDirectory() as td:
         out = os.path.join(td, name + ".s")
         flags = [f for f in FLAGS if f != "-fPIC"]
-        subprocess.run([HIPCC, *flags, "-S", "--cuda-device-only", os.path.join(src_dir, name), "-o", out], check=True,
+        subprocess.run([HIPCC, *flags, "-S", "--cuda-device-only", os.path.join(SRC_DIR, name), "-o", out], check=True,
                        stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
         lines = open(out).read().split("\n")
     kern, res, since = None, {}, 0
@@ -41,10 +50,15 @@ for name in sorted(os.listdir(src_dir)):
             if since == 1:
                 res[kern][2] += 1
             since = 0
-    for k, v in res.items():
-        if v[2] >= thr:
-            try:
-                dem = subprocess.run(["c++filt", k], capture_output=True, text=True).stdout.strip() or k
-            except OSError:
-                dem = k
-            print(f"{name:14s} loads {v[0]:3d}  vmcnt(0) {v[1]:3d}  single-load-then-drain {v[2]:3d}  {dem[:110]}")
+    dem = _demangle(list(res))
+    return {dem[k]: tuple(v) for k, v in res.items()}
+
+
+if __name__ == "__main__":
+    thr = int(sys.argv[1]) if len(sys.argv) > 1 else 2
+    for name in sorted(os.listdir(SRC_DIR)):
+        if not name.endswith(".hip"):
+            continue
+        for k, v in scan_source(name).items():
+            if v[2] >= thr:
+                print(f"{name:14s} loads {v[0]:3d}  vmcnt(0) {v[1]:3d}  single-load-then-drain {v[2]:3d}  {k[:110]}")
