@@ -81,6 +81,7 @@ def main():
     ap.add_argument("--no-early-word", action="store_true", help="A/B: the word-embedding table's gradient reduced with the tail (round-2 form)")
     ap.add_argument("--sync-prologue", action="store_true", help="A/B: the step prologue on the compute stream (model.async_prologue = False)")
     ap.add_argument("--scores-fp32", action="store_true", help="return the prediction scores as fp32 (model.scores_dtype = torch.float32)")
+    ap.add_argument("--no-scores-fp32", action="store_true", help="skip the secondary measurement with fp32 prediction scores (the reference's dtype)")
     ap.add_argument("--no-reference-default", action="store_true", help="skip the secondary measurement of the reference's own default model "
                     "(bert-large: 24-layer d=1024, T=P=40, batch 32: REF:train.py:28,32,38)")
     ap.add_argument("--preset", choices=["headline", "reference-default"], default="headline",
@@ -247,29 +248,50 @@ def main():
         elapsed_instr = time.perf_counter() - ti0
         record[0] = False
 
+    def timed_leg(fn, nwarm=None):
+        """A secondary leg: ``nwarm`` untimed calls of ``fn(i)``, then the contract's bracket (synchronize + barrier on both sides,
+        max over ranks) around a.steps calls.  Returns seconds."""
+        for i in range(min(a.warmup, 3) + 1 if nwarm is None else nwarm):
+            fn(i)
+        torch.cuda.synchronize()
+        barrier()
+        tl0 = time.perf_counter()
+        for i in range(a.steps):
+            fn(i)
+        torch.cuda.synchronize()
+        barrier()
+        el = time.perf_counter() - tl0
+        if world > 1:
+            t = torch.tensor([el], device=dev, dtype=torch.float64)
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+            el = float(t)
+        return el
+
+    def leg_record(el, **extra):
+        return dict({"value": round(a.steps * a.batch * world / el, 2), "unit": "samples/s", "ms_per_step": round(1e3 * el / a.steps, 3)}, **extra)
+
     # For reference: the same step with every exact-zero short cut switched off (attention visits the masked-out keys, backward
     # runs on all rows and densely through the top layer); identical gradients up to fp32 summation order, never the headline.
     dense_ref = None
     if not a.no_dense_reference and (model.skip_masked_keys or model.skip_padded_backward or model.sparse_top_layer_backward):
         saved_flags = (model.skip_masked_keys, model.skip_padded_backward, model.sparse_top_layer_backward)
         model.skip_masked_keys = model.skip_padded_backward = model.sparse_top_layer_backward = False
-        for i in range(min(a.warmup, 3) + 1):
-            step(i)
-        torch.cuda.synchronize()
-        barrier()
-        td0 = time.perf_counter()
-        for i in range(a.steps):
-            step(i)
-        torch.cuda.synchronize()
-        barrier()
-        delapsed = time.perf_counter() - td0
-        if world > 1:
-            t = torch.tensor([delapsed], device=dev, dtype=torch.float64)
-            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-            delapsed = float(t)
+        delapsed = timed_leg(step)
         model.skip_masked_keys, model.skip_padded_backward, model.sparse_top_layer_backward = saved_flags
-        dense_ref = {"value": round(a.steps * a.batch * world / delapsed, 2), "unit": "samples/s", "ms_per_step": round(1e3 * delapsed / a.steps, 3),
-                     "note": "same step with the exact-zero short cuts off: all keys, all rows in backward (MLM-head backward still on labelled rows)"}
+        dense_ref = leg_record(delapsed, note="same step with the exact-zero short cuts off: all keys, all rows in backward (MLM-head backward still on labelled rows)")
+
+    # Secondary: the prediction scores in the REFERENCE's dtype.  REF:MMBertForPretraining.py:445-449 returns fp32 score tensors; the
+    # headline step returns bf16 views of the materialised logits (config.scores_dtype).  model.scores_dtype = torch.float32 makes the
+    # vocabulary GEMM store its fp32 accumulators instead: bit-identical losses and gradients (test_scores_dtype_float32_for_numpy_consumers),
+    # twice the bytes written by that launch.
+    scores_fp32 = None
+    if not a.no_scores_fp32 and model.scores_dtype != torch.float32:
+        saved_dtype = model.scores_dtype
+        model.scores_dtype = torch.float32
+        sel = timed_leg(step)
+        model.scores_dtype = saved_dtype
+        scores_fp32 = leg_record(sel, note="model.scores_dtype = torch.float32: the six returned prediction-score tensors in the reference's dtype "
+                                           "(REF:MMBertForPretraining.py:445-449); same losses and gradients as the headline step")
 
     # Secondary: the train step as trainer.py consumes it -- model.return_scores = False: the six prediction-score tensors that
     # the reference's forward returns and its trainer never reads are not produced, so the MLM head runs on the labelled rows
@@ -278,23 +300,9 @@ def main():
     train_only = None
     if not a.no_train_only:
         model.return_scores = False
-        for i in range(min(a.warmup, 3) + 1):
-            step(i)
-        torch.cuda.synchronize()
-        barrier()
-        tt0 = time.perf_counter()
-        for i in range(a.steps):
-            step(i)
-        torch.cuda.synchronize()
-        barrier()
-        telapsed = time.perf_counter() - tt0
-        if world > 1:
-            t = torch.tensor([telapsed], device=dev, dtype=torch.float64)
-            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-            telapsed = float(t)
+        telapsed = timed_leg(step)
         model.return_scores = True
-        train_only = {"value": round(a.steps * a.batch * world / telapsed, 2), "unit": "samples/s", "ms_per_step": round(1e3 * telapsed / a.steps, 3),
-                      "note": "model.return_scores = False: losses and gradients as in the headline step, the returned prediction scores are None"}
+        train_only = leg_record(telapsed, note="model.return_scores = False: losses and gradients as in the headline step, the returned prediction scores are None")
 
     # Secondary: the same train step on the fused single sequence text | visual | speech (S = T + V + A = 1050), the shape
     # BASELINE.json's metric name quotes.  The reference never builds that sequence (its step is the three passes above), so
@@ -312,25 +320,11 @@ def main():
             sched.step()
             opt.zero_grad()
 
-        for i in range(min(a.warmup, 3) + 1):
-            fstep(i)
-        torch.cuda.synchronize()
-        barrier()
-        tf0 = time.perf_counter()
-        for i in range(a.steps):
-            fstep(i)
-        torch.cuda.synchronize()
-        barrier()
-        felapsed = time.perf_counter() - tf0
-        if world > 1:
-            t = torch.tensor([felapsed], device=dev, dtype=torch.float64)
-            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-            felapsed = float(t)
+        felapsed = timed_leg(fstep)
         S = a.text + 2 * a.pair
         ffl = 3.0 * (2 * S * L * (4 * H * H + 2 * H * I) + 4 * S * S * H * L + 2 * S * H * H + 2 * S * H * V + 2 * a.pair * (35 + 74) * H)
-        fused = {"value": round(a.steps * a.batch * world / felapsed, 2), "unit": "samples/s", "ms_per_step": round(1e3 * felapsed / a.steps, 3),
-                 "seq_len": S, "tflop_per_sample": round(ffl / 1e12, 4),
-                 "note": "declared extension (one pass over text|visual|speech; not in the reference, no reference parity): model.forward_fused"}
+        fused = leg_record(felapsed, seq_len=S, tflop_per_sample=round(ffl / 1e12, 4),
+                           note="declared extension (one pass over text|visual|speech; not in the reference, no reference parity): model.forward_fused")
 
     # Secondary: the reference's OWN default model (REF:train.py:28,32,38,70 -- bert-large-uncased: 24 layers, d = 1024, 16 heads, I = 4096,
     # max_seq_length 40, pair length == text length, train_batch_size 32), same train step.  Never the headline (BASELINE.json quotes d = 768).
@@ -350,6 +344,9 @@ def main():
     fp = flop_parts(L, H, I, V, a.text, a.pair, a.pair)
     head_bwd = 2.0 * fp["head"] * (0.15 * 3 * a.text / tokens)
     fps_exec = (fp["proj"] + fp["attn"] * f + fp["head"] + fp["joint"]) + 2.0 * (fp["proj"] * f + fp["attn"] * f * f + fp["joint"] * f) + head_bwd
+    # ... and what the dense_backward_reference leg executes: every row and every key (f = 1); its MLM-head backward still runs on the
+    # labelled rows only (round 4 divided the DENSE count by that leg's time: 15 % too much)
+    fps_exec_dense = (fp["proj"] + fp["attn"] + fp["head"] + fp["joint"]) + 2.0 * (fp["proj"] + fp["attn"] + fp["joint"]) + head_bwd
     res = {
         "metric": "train-step samples/sec", "value": round(value, 2), "unit": "samples/s", "n_gpus": world, "steps": a.steps,
         "warmup": a.warmup, "ms_per_step": round(1e3 * elapsed / a.steps, 3),
@@ -359,6 +356,7 @@ def main():
                                f"{L}-layer d={H} heads={a.heads} vocab={V}, T={a.text} A={a.pair} V={a.pair}, dropout on, AdamW",
                    "per_gpu_batch": a.batch, "global_batch": a.batch * world, "parallelism": f"dp{world}",
                    "tflop_per_sample": round(fps / 1e12, 4), "tflop_per_sample_executed": round(fps_exec / 1e12, 4),
+                   "scores_dtype": {torch.bfloat16: "bf16", torch.float32: "fp32"}[model.scores_dtype],
                    "mlm_backward": "labelled rows only (exact: unlabelled rows have zero CE gradient)",
                    "backward_row_fraction": round(f, 4),
                    "backward_rows": "rows behind a sequence's last unmasked key and without a label have zero gradients in every layer: backward skips them (exact)"},
@@ -377,6 +375,10 @@ def main():
                                                     "gradient exchange is NOT hidden under backward -- the last bucket, the compact row exchange, the waits"}
     if dense_ref is not None:
         res["dense_backward_reference"] = dense_ref
+    if dense_ref is not None:
+        dense_ref["tflop_per_sample_executed"] = round(fps_exec_dense / 1e12, 4)
+    if scores_fp32 is not None:
+        res["scores_fp32"] = scores_fp32
     if train_only is not None:
         res["train_only"] = train_only
     if fused is not None:
@@ -413,9 +415,9 @@ def main():
                                "share_of_step_time": round(ms * 1e-3 / elapsed_instr, 3),
                                "timed_in": f"a second pass of the same {a.steps} steps with an event pair around every GEMM / attention launch (ms_per_step_instrumented)",
                                # whole-step MFMA fractions of 2.5 PF, side by side: FLOPs actually executed by the headline step, and the
-                               # dense algorithmic count at the speed of the step with every exact-zero short cut switched off
+                               # FLOPs executed by the step with every exact-zero short cut switched off at that step's speed
                                "frac_step_executed": round(fps_exec * value / world / 2.5e15, 4),
-                               "frac_step_dense_shortcuts_off": (round(fps * dense_ref["value"] / world / 2.5e15, 4) if dense_ref else None)}
+                               "frac_step_dense_shortcuts_off": (round(fps_exec_dense * dense_ref["value"] / world / 2.5e15, 4) if dense_ref else None)}
             for k in ("tn", "attn_fwd", "attn_bwd"):
                 if k in kern:
                     fl2, ms2, n2 = kern[k]

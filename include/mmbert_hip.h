@@ -9,14 +9,13 @@
  *   - allocates no device memory, synchronises nothing and keeps no per-call state (graph-capturable): every workspace,
  *     the tile queue of the persistent GEMM included, is passed in by the caller.  Process-global and documented as such:
  *     the one-time per-device opt-in of kernels to > 64 KiB of LDS (hipFuncSetAttribute on first use -- warm each kernel up once
- *     before capturing a graph), a cached CU count per device, and the test / A-B knobs mmbert_gemm_nt_force,
- *     mmbert_gemm_tn_force_splits and mmbert_gemm_tn_force_form (atomics, default 0 = choose by shape; every choice computes the same product), and the
- *     measurement switches read from the environment once per process -- schedule choices only, the results do not depend
- *     on them: MMBERT_NT_GROUP_M, MMBERT_NT_GM_TABLE, MMBERT_NT_QUEUE_GLOBAL, MMBERT_NT_TALL (tile walk / queue / tile height of the persistent GEMM),
- *     MMBERT_LN_ROWS, MMBERT_LN_BWD_ROWS, MMBERT_LN_BWD_BLOCKS, MMBERT_LN_NV4 (LayerNorm rows per wave / grid / register sizing),
- *     MMBERT_ATTN_HEAD_FAST (grid order of the attention kernels; read per call), MMBERT_ATTN_EXTRA_LDS (occupancy experiments),
- *     MMBERT_NT_8PHASE / _BM128 / _BM192 / _BM224 / _FORM / _MULTI (which launches the 8-phase NT kernel takes and on which tile height),
- *     MMBERT_TN_8PHASE (the weight-gradient kernel's K loop), MMBERT_EMBED_SLICES (grid of the embedding scatter).
+ *     before capturing a graph), a cached CU count per device, and the two test / A-B knobs mmbert_gemm_nt_force and
+ *     mmbert_gemm_tn_force_splits (atomics, default 0 = choose by shape; every choice computes the same product).
+ *   - reads NO environment variable (round 5: the ~25 MMBERT_* measurement switches of rounds 1-4 are gone with the kernels and
+ *     schedules they selected between; the rules they settled are in csrc/gemm.hip nt_choose / tn_plan).  The switches that remain
+ *     belong to the Python host side and are read once at import / model construction (msa_amd/_lib.py, ops.py, model.py, build.py):
+ *     MMBERT_LIB_PATH (another build of this library), MMBERT_NT_DYNAMIC=1 (tile queue on every stream), MMBERT_DEFER_WGRADS=0/1,
+ *     MMBERT_FUSED_HEADS=0, MMBERT_DETERMINISTIC=1 (model.deterministic), MMBERT_HIPCC_FLAGS (build only).
  * bf16 tensors are row-major `uint16` storage; "ld*" are leading dimensions in elements.
  * REF: = /root/reference/<file>:<line>;  HF: = transformers models/bert/modeling_bert.py (5.15.0).
  */
@@ -59,32 +58,27 @@ int mmbert_gemm_nt_splitk(mmbert_stream_t stream, const void* A, int lda, const 
                           int M, int N, int K, void* workspace, const void* R, int ldr);
 size_t mmbert_gemm_nt_splitk_workspace(int M, int N, int K);
 
-/* Kernel selection for mmbert_gemm_nt: 0 = by shape (default), 1 = 128x128 tile kernel, 2 = 4-stage-ring kernel
- * with the tile height (256 or 224 rows) chosen by tile-round count, 3 = ring kernel 256x256, 4 = ring kernel
- * 224x256, 5 / 6 / 7 = the persistent stream kernel (tile height by shape / 256 / 224 rows), 8 = the 8-phase kernel for every
- * eligible shape (K % 128 == 0).  For tests and A/B benchmarking; results are identical up to fp32 summation order. */
+/* Kernel selection for mmbert_gemm_nt: 0 = by shape (default), 1 = the 128x128-tile kernel, 8 = the 8-phase kernel wherever it is
+ * eligible (K % 128 == 0, K >= 256, N % 8 == 0; tile height by the shape rules), 128 / 192 / 224 / 256 = the 8-phase kernel on that
+ * tile height (one tile per workgroup, or -- more tiles than CUs -- its multi-tile form; 128-row tiles always one tile per workgroup).
+ * For tests and A/B benchmarking; results are identical up to fp32 summation order, and bit-identical between the tile heights. */
 void mmbert_gemm_nt_force(int mode);
 /* Which kernel mmbert_gemm_nt launches for a shape on the current device (contiguous operands), without launching anything:
- * out[0] kernel (0: 128x128-tile kernel, 1: 4-slot-ring kernel, one launch slot per tile, 2: persistent stream kernel, 3: the 256x256
- * 8-phase kernel that takes every launch whose tiles fit the chip in one round), out[1] tile
- * rows (128 / 224 / 256), out[2] tile columns, out[3] output tiles, out[4] workgroups launched, out[5] tile rounds x 100 over the
+ * out[0] kernel (0: the 128x128-tile kernel, 3: the 8-phase kernel), out[1] tile rows (128 / 192 / 224 / 256), out[2] tile columns,
+ * out[3] output tiles, out[4] workgroups launched (fewer than tiles: the multi-tile form), out[5] tile rounds x 100 over the
  * device's CUs, out[6] group_m of the tile walk, out[7] CUs.  with_queue: as if a tile_queue were passed.  Host-only; bench.py
  * reports it per shape of the reference's default model (REF:train.py:28,32,38), tests pin the headline shapes. */
 int mmbert_gemm_nt_describe(int M, int N, int K, int epi, int with_queue, int* out);
-/* Split count of the token axis in mmbert_gemm_tn / _grouped: 0 = by shape (default), > 0 forced.  A/B benchmarking. */
+/* Split count of the token axis in mmbert_gemm_tn / _grouped: 0 = by shape (default), > 0 forced.  Tests and A/B benchmarking. */
 void mmbert_gemm_tn_force_splits(int splits);
-/* K loop of mmbert_gemm_tn / _grouped: 1 = the 8-phase form (64-token K tiles, default), 0 = the 4-slot ring of 32-token stages.  The
- * weight gradients are bit-identical (same 32-token summation blocks), the bias gradients agree up to fp32 summation order.  Tests and
- * A/B benchmarking (the environment variable MMBERT_TN_8PHASE, read per call, overrides it). */
-void mmbert_gemm_tn_force_form(int form);
 
 /* Weight gradients autograd computes for nn.Linear (REF:trainer.py:83):
  *   W[N,K] (fp32, contiguous: ldw == K) = (accumulate ? W : 0) + alpha * alpha_dev[0] * A[M,N]^T . B[M,K]
  *   bias_out[N] (optional)             += alpha * alpha_dev[0] * column sums of A      (the bias gradient)
  * The token axis may be split into fp32 slabs (deterministic reduce): `slab` must hold *_workspace() bytes.
  * The grouped form runs up to 48 problems that share M in ONE call (the four dense layers of one, two or -- round 4, when nothing needs a
- * layer's weight gradients before the optimizer -- up to twelve encoder layers); host arrays of length nprob.  A call of more tiles than
- * CUs never splits the token axis and goes out as whole rounds of CUs-many tiles, one launch per round. */
+ * layer's weight gradients before the optimizer -- up to twelve encoder layers); host arrays of length nprob.  A call of more than 8
+ * problems and more tiles than CUs never splits the token axis and goes out as whole rounds of CUs-many tiles, one launch per round. */
 size_t mmbert_gemm_tn_workspace(int M, int N, int K, int* splits_out);
 int mmbert_gemm_tn(mmbert_stream_t stream, const void* A, int lda, const void* B, int ldb, float* W, int ldw,
                    int M, int N, int K, int accumulate, float alpha, const float* alpha_dev, void* slab, float* bias_out);
@@ -299,9 +293,13 @@ int mmbert_skinny_mm(mmbert_stream_t stream, int nops, const mmbert_skinny_op* o
 int mmbert_skinny_wgrad(mmbert_stream_t stream, int nops, const mmbert_skinny_wgrad_op* ops);
 
 /* ---- optimizer: flat AdamW (REF:train.py:76-97; mode 0 = transformers-2.8 AdamW, 1 = torch.optim.AdamW) ----
- * flags[i/256]: 0 no decay, 1 decay, 2 frozen.  n % 256 == 0.  Also refreshes the bf16 copy, and zeroes g. */
+ * flags[i/256]: 0 no decay, 1 decay, 2 frozen; + 4 = "the next backward overwrites this block's gradient": zero_grad leaves it alone.
+ * n % 256 == 0.  Also refreshes the bf16 copy, and zeroes g.  The hyper-parameters are DOUBLES, as the Python floats of the reference's
+ * optimizer are: 1 - beta, the bias corrections 1 - beta^step and the step size are formed in double and rounded to fp32 once, the way
+ * `exp_avg_sq.mul_(beta2).addcmul_(1 - beta2, grad, grad)` hands a double scalar to an fp32 tensor (round 5: formed in fp32, 1 - 0.999f
+ * was 1.3e-5 off -- found by the hand-computed vector tests/golden/hf_adamw_hand.py). */
 int mmbert_adamw(mmbert_stream_t stream, float* p, float* g, float* m, float* v, void* p_bf16, const uint8_t* flags, size_t n,
-                 float lr, float beta1, float beta2, float eps, float wd, int step, float gscale, int mode, int zero_grad);
+                 double lr, double beta1, double beta2, double eps, double wd, int step, double gscale, int mode, int zero_grad);
 
 /* du = dy * gelu_erf'(u), contiguous bf16 (BertPredictionHeadTransform backward, HF:476-480) */
 int mmbert_gelu_bwd(mmbert_stream_t stream, const void* dy, const void* u, void* du, size_t n);

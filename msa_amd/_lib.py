@@ -9,11 +9,11 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-# (MMBERT_LIB_PATH: a diagnostic override -- another BUILD of the same library, for whole-process A/Bs of kernel changes that have no
-# run-time switch: tools/r4_s2_altlib.sh; the stamp tools set LIB_PATH directly)
+# (MMBERT_LIB_PATH: a diagnostic override -- another BUILD of the same library, for whole-process A/Bs of kernel changes: the library
+# itself has no run-time switches; tools/ab_lib.sh; the stamp tools set LIB_PATH directly)
 LIB_PATH = os.environ.get("MMBERT_LIB_PATH") or os.path.join(HERE, "libmmbert_hip.so")
 
-P, I, F, U32, SZ, U64 = C.c_void_p, C.c_int, C.c_float, C.c_uint32, C.c_size_t, C.c_uint64
+P, I, F, D, U32, SZ, U64 = C.c_void_p, C.c_int, C.c_float, C.c_double, C.c_uint32, C.c_size_t, C.c_uint64
 
 # name -> (restype, argtypes); must list every symbol of include/mmbert_hip.h
 SIGNATURES = {
@@ -23,7 +23,6 @@ SIGNATURES = {
     "mmbert_gemm_nt_splitk": (I, [P, P, I, P, I, P, I, I, I, I, P, P, I]),
     "mmbert_gemm_nt_splitk_workspace": (SZ, [I, I, I]),
     "mmbert_gemm_tn_force_splits": (None, [I]),
-    "mmbert_gemm_tn_force_form": (None, [I]),
     "mmbert_gemm_tn_workspace": (SZ, [I, I, I, P]),
     "mmbert_gemm_tn": (I, [P, P, I, P, I, P, I, I, I, I, I, F, P, P, P]),
     "mmbert_gemm_tn_grouped_workspace": (SZ, [I, P, P, I, P]),
@@ -64,7 +63,7 @@ SIGNATURES = {
     "mmbert_heads_colsum": (I, [P, I, P, P, P, P, P]),
     "mmbert_skinny_mm": (I, [P, I, P]),
     "mmbert_skinny_wgrad": (I, [P, I, P]),
-    "mmbert_adamw": (I, [P, P, P, P, P, P, P, SZ, F, F, F, F, F, I, F, I, I]),
+    "mmbert_adamw": (I, [P, P, P, P, P, P, P, SZ, D, D, D, D, D, I, D, I, I]),
     "mmbert_gelu_bwd": (I, [P, P, P, P, SZ]),
     "mmbert_cast_f32_bf16": (I, [P, P, P, SZ]),
     "mmbert_cast_bf16_f32": (I, [P, P, P, SZ]),
@@ -96,9 +95,6 @@ def load() -> C.CDLL:
         fn = getattr(lib, name)          # AttributeError if the symbol is missing -> loud
         fn.restype = res
         fn.argtypes = args
-    mode = os.environ.get("MMBERT_NT_MODE")          # A/B benchmarking only: kernel selection of mmbert_gemm_nt
-    if mode:
-        lib.mmbert_gemm_nt_force(int(mode))
     _lib = lib
     return lib
 

@@ -1177,9 +1177,11 @@ __global__ __launch_bounds__(256) void ce_row_kernel(const void* __restrict__ lo
 // mode 0 = transformers-2.8 AdamW (decay after the update), 1 = torch.optim.AdamW.
 // Also writes the bf16 working copy and (optionally) zeroes the gradient: zero_grad fused.
 // --------------------------------------------------------------------------------------------
+// The scalar coefficients arrive ready-made (mmbert_adamw forms them in double): omb1 / omb2 = 1 - beta1 / 1 - beta2; step_size =
+// lr sqrt(bc2) / bc1 (mode 0) or lr / bc1 (mode 1); rsbc2 = 1 / sqrt(bc2) (mode 1); lrwd = lr * wd.
 __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
                                                     bf16_t* __restrict__ pb, const uint8_t* __restrict__ flags, size_t n,
-                                                    float lr, float beta1, float beta2, float eps, float wd, float bc1, float bc2,
+                                                    float beta1, float beta2, float omb1, float omb2, float eps, float step_size, float rsbc2, float lrwd,
                                                     float gscale, int mode, int zero_grad) {
     const size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
     if (i >= n) return;
@@ -1189,18 +1191,18 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, float
     if (f != 2) {
         float4 G = *(float4*)(g + i), Mm = *(float4*)(m + i), Vv = *(float4*)(v + i);
         float pa[4] = {P.x, P.y, P.z, P.w}, ga[4] = {G.x, G.y, G.z, G.w}, ma[4] = {Mm.x, Mm.y, Mm.z, Mm.w}, va[4] = {Vv.x, Vv.y, Vv.z, Vv.w};
-        const float decay = (f == 1) ? wd : 0.f;
+        const float decay = (f == 1) ? lrwd : 0.f;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const float gr = ga[r] * gscale;
-            if (mode == 1) pa[r] *= (1.0f - lr * decay);
-            ma[r] = beta1 * ma[r] + (1.0f - beta1) * gr;
-            va[r] = beta2 * va[r] + (1.0f - beta2) * gr * gr;
+            if (mode == 1) pa[r] *= (1.0f - decay);
+            ma[r] = beta1 * ma[r] + omb1 * gr;
+            va[r] = beta2 * va[r] + omb2 * gr * gr;
             if (mode == 0) {
-                pa[r] -= (lr * sqrtf(bc2) / bc1) * ma[r] / (sqrtf(va[r]) + eps);
-                pa[r] -= lr * decay * pa[r];
+                pa[r] -= step_size * ma[r] / (sqrtf(va[r]) + eps);
+                pa[r] -= decay * pa[r];
             } else {
-                pa[r] -= (lr / bc1) * ma[r] / (sqrtf(va[r]) / sqrtf(bc2) + eps);
+                pa[r] -= step_size * ma[r] / (sqrtf(va[r]) * rsbc2 + eps);
             }
         }
         P = make_float4(pa[0], pa[1], pa[2], pa[3]);
@@ -1556,16 +1558,15 @@ uint32_t mmbert_dropout_thr16(float p) {
     return (uint32_t)t;
 }
 
-// the lean LayerNorm pair applies (H a multiple of 256; MMBERT_LN_GENERIC: A/B switch back to the general kernels)
-static inline bool ln_lean(int H) { return (H & 255) == 0 && H <= LN_MAXV * 256 && !getenv("MMBERT_LN_GENERIC"); }
+// the lean LayerNorm pair applies (H a multiple of 256)
+static inline bool ln_lean(int H) { return (H & 255) == 0 && H <= LN_MAXV * 256; }
 
 int mmbert_ln_fwd(hipStream_t stream, const void* x, int ldx, const int* in_rows, void* y, int ldy, const int* out_rows,
                   int M, int H, const float* gamma, const float* beta, float eps, float* mean, float* rstd,
                   uint32_t dstream, uint32_t dthr, float dscale, int drop_row0) {
     if (M <= 0) return 0;
     if (H > LN_MAXV * 256 || (H & 3) || (ldx & 3) || (ldy & 3)) return -1;
-    const char* cap_s = getenv("MMBERT_LN_FWD_BLOCKS");                                              // A/B switch, read per call
-    const int cap = cap_s ? atoi(cap_s) : 0;
+    constexpr int cap = 0;
     if (ln_lean(H)) {
         // H = NV * 256: the lean kernel, one row per wave and trip on a grid of <= 1024 workgroups (4 per CU: every wave resident,
         // 4-5 trips per wave at the step's 14-18 k rows; swept 256 ... 4096 with tools/ubench/stream_rate.py)
@@ -1579,9 +1580,8 @@ int mmbert_ln_fwd(hipStream_t stream, const void* x, int ldx, const int* in_rows
         MMB_CHECK_LAUNCH();
         return 0;
     }
-    const int rows_env = getenv("MMBERT_LN_ROWS") ? atoi(getenv("MMBERT_LN_ROWS")) : 0;      // A/B switch: rows per wave (read per call)
     // rows per wave, measured at 18 400 x 768 (stand-alone, same box): 1 / 2 / 4 -> 18.3 / 14.9 / 20.9 us
-    const int R = rows_env ? rows_env : (M >= 8192 ? 2 : 1);
+    const int R = M >= 8192 ? 2 : 1;
     const int NV = (H + 255) / 256;
 #define LN_FWD_LAUNCH(NVV, RR) hipLaunchKernelGGL((ln_fwd_kernel<NVV, RR>), dim3(grid_for(M, 4 * RR, cap > 0 ? cap : 2048)), dim3(256), 0, stream, (const bf16_t*)x, ldx, in_rows, \
                                                   (bf16_t*)y, ldy, out_rows, M, H, gamma, beta, eps, mean, rstd, dstream, dthr, dscale, drop_row0)
@@ -1594,14 +1594,10 @@ int mmbert_ln_fwd(hipStream_t stream, const void* x, int ldx, const int* in_rows
 
 // (block cap swept in round 2 at 13 745 rows, encoder form: 256 / 512 / 1024 / 2048 / 4096 blocks -> 37.6 / 24.3 / 18.5 / 20.3 / 23.3 us)
 constexpr int LN_BWD_LEAN_WPB = 8;
-static inline int ln_bwd_lean_wpb() {
-    const char* wpb_s = getenv("MMBERT_LN_BWD_WPB");                                          // A/B switch, read per call
-    return (wpb_s ? atoi(wpb_s) : LN_BWD_LEAN_WPB) == 8 ? 8 : 4;
-}
+static inline int ln_bwd_lean_wpb() { return LN_BWD_LEAN_WPB; }
 // workgroups of a backward launch (also the number of partial-sum rows the launch leaves in its workspace)
 static inline int ln_bwd_blocks(int M, int H) {
-    const char* cap_s = getenv("MMBERT_LN_BWD_BLOCKS");                                       // A/B switch, read per call
-    const int cap_env = cap_s ? atoi(cap_s) : 0;
+    constexpr int cap_env = 0;
     if (ln_lean(H)) {
         const int wpb = ln_bwd_lean_wpb();
         return grid_for(M, wpb, cap_env > 0 ? cap_env : (wpb == 8 ? 256 : 512));
@@ -1637,13 +1633,10 @@ int mmbert_ln_bwd(hipStream_t stream, const void* dy, int lddy, const int* dy_ro
 #undef LN_BWD_LEAN_W
 #undef LN_BWD_LEAN
     } else {
-    const char* rows_s = getenv("MMBERT_LN_BWD_ROWS");                                             // A/B switch: rows per wave and trip (read per call)
-    const int rows_env = rows_s ? atoi(rows_s) : 0;
     // measured at 18 400 x 768 (stand-alone, same box): registers sized for 1024 columns (round 1: 142 VGPRs, 3 waves per SIMD) 35.0 us;
     // sized to the row (NV = 3: 116 VGPRs, 4 waves per SIMD = all 4096 waves of the launch resident) 28.5; two rows per trip 34.0
-    const int R = rows_env ? rows_env : 1;
-    static const int nv4_env = getenv("MMBERT_LN_NV4") ? atoi(getenv("MMBERT_LN_NV4")) : 0;               // A/B switch: round-1 register sizing
-    const int NV = nv4_env ? 4 : (H + 255) / 256;
+    const int R = 1;
+    const int NV = (H + 255) / 256;
 #define LN_BWD_LAUNCH(NVV, RR) hipLaunchKernelGGL((ln_bwd_kernel<NVV, RR>), dim3(nblocks), dim3(256), 0, stream, (const bf16_t*)dy, lddy, dy_rows, \
         (const bf16_t*)x, ldx, x_rows, mean, rstd, gamma, M, H, (bf16_t*)dx, lddx, dx_rows, (bf16_t*)dx2, lddx2, dgamma, dbeta, dbias2, partial_ws, \
         post_stream, post_thr, post_scale, pre_stream, pre_thr, pre_scale, drop_rows, dy_row_limit)
@@ -1708,10 +1701,7 @@ int mmbert_embed_scatter(hipStream_t stream, const int64_t* ids, const int64_t* 
                          float* gword, float* gtype, float* gpos) {
     if (n <= 0) return 0;
     if (H > LN_MAXV * 256 || (H & 3) || (ldd & 3) || T <= 0) return -1;
-    const int seqs = (n + T - 1) / T;
-    int slices = 1;        // measured at the headline shape (tools/bench_embed_scatter.py): 1 / 2 / 4 / 8 slices = 37.8 / 39.1 / 49.0 / 59.2 us (47 before the batches)
-    (void)seqs;
-    if (const char* e = getenv("MMBERT_EMBED_SLICES")) { const int v = atoi(e); if (v >= 1 && v <= 64) slices = v; }   // A/B switch, read per call
+    constexpr int slices = 1;   // grid.y slices of the sequences; measured at the headline shape: 1 / 2 / 4 / 8 = 37.8 / 39.1 / 49.0 / 59.2 us (same-address atomics on the two token-type rows)
     hipLaunchKernelGGL(embed_scatter_kernel, dim3(T < n ? T : n, slices), dim3(256), 0, stream, ids, tts, (const bf16_t*)d, ldd, n, T, H, V, gword, gtype, gpos);
     MMB_CHECK_LAUNCH();
     return 0;
@@ -1858,12 +1848,15 @@ int mmbert_active_rows(hipStream_t stream, const int64_t* labels, int M, int V, 
 }
 
 int mmbert_adamw(hipStream_t stream, float* p, float* g, float* m, float* v, void* p_bf16, const uint8_t* flags, size_t n,
-                 float lr, float beta1, float beta2, float eps, float wd, int step, float gscale, int mode, int zero_grad) {
+                 double lr, double beta1, double beta2, double eps, double wd, int step, double gscale, int mode, int zero_grad) {
     if (n == 0) return 0;
     if (n & 255) return -1;
-    const float bc1 = 1.0f - powf(beta1, (float)step), bc2 = 1.0f - powf(beta2, (float)step);
+    // every derived coefficient in double, rounded to fp32 once (the reference's optimizer computes them as Python floats)
+    const double bc1 = 1.0 - pow(beta1, (double)step), bc2 = 1.0 - pow(beta2, (double)step);
+    const double step_size = mode == 0 ? lr * sqrt(bc2) / bc1 : lr / bc1;
     hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, stream, p, g, m, v, (bf16_t*)p_bf16, flags, n,
-                       lr, beta1, beta2, eps, wd, bc1, bc2, gscale, mode, zero_grad);
+                       (float)beta1, (float)beta2, (float)(1.0 - beta1), (float)(1.0 - beta2), (float)eps, (float)step_size, (float)(1.0 / sqrt(bc2)),
+                       (float)(lr * wd), (float)gscale, mode, zero_grad);
     MMB_CHECK_LAUNCH();
     return 0;
 }

@@ -220,23 +220,39 @@ class _JointFn(torch.autograd.Function):
 
 
 _cu_count = {}
+_defer_fits = {}
+_DEFER_ENV = os.environ.get("MMBERT_DEFER_WGRADS")          # "0" / "1": whole-process A/B override, read ONCE at import (model.defer_wgrads overrides per model)
 
 
-def _auto_defer_wgrads(H, I, L, x_dev) -> bool:
+def _auto_defer_wgrads(H, I, L, x_dev, rows=None) -> bool:
     """Whether the encoder's weight gradients go out as ONE call of whole 256-tile rounds at the end of backward instead of one launch per
     layer pair (only without a gradient hook: one GPU): yes as soon as the one call has at least a full round of tiles.  Measured:
     bert-large, the reference's default -- a pair is 384 tiles = 1.5 rounds (0.75 full), 23 layers 17.25 rounds (0.96) -- -2.2 % of the step
     (19.55 -> 19.12 ms, profiles/r4_ab_refdef_wgrads.log); 12-layer d = 768 -- a pair is 216 tiles on 256 CUs (0.84), eleven layers 4.64
-    rounds (0.93) -- read +-0 in its first A/B (8-step windows, profiles/r4_ab_deferred_wgrads.log) and -0.6 / -0.8 % with 40-step windows,
-    -0.7 % with alternating 600-step processes (profiles/r4_ab_tn8_defer.log).  Costs the layers' operands staying alive (~0.2 GB per
-    layer).  MMBERT_DEFER_WGRADS=0/1 and model.defer_wgrads override it."""
+    rounds (0.93) -- -0.6 / -0.8 % with 40-step windows, -0.7 % with alternating 600-step processes (profiles/r4_ab_tn8_defer.log).
+    The price is memory: the eight operands of every dense layer -- rows x (2 I + 8 H) bf16, 0.34 GB per layer at the headline shape, 3.7 GB
+    for eleven layers -- stay alive until the end of backward.  ``rows`` (the backward's row count) given: the deferral is taken only
+    while that fits into HALF of what the device still has (the driver's free memory + torch's cached-but-free blocks; one query per
+    (shape, depth), cached) -- a configuration that fits with the paired launches must not run out of memory because of a 0.7 %
+    scheduling gain.  MMBERT_DEFER_WGRADS=0/1 (read at import) and model.defer_wgrads = True / False override the rule."""
     key = str(x_dev)
     cus = _cu_count.get(key)
     if cus is None:
         cus = _cu_count[key] = int(torch.cuda.get_device_properties(x_dev).multi_processor_count)
     c = lambda n: (n + 255) // 256
     t = 2 * c(I) * c(H) + c(3 * H) * c(H) + c(H) * c(H)            # 256 x 256 tiles of a layer's four weight gradients
-    return L > 2 and (L - 1) * t >= cus
+    if not (L > 2 and (L - 1) * t >= cus):
+        return False
+    if rows is None:
+        return True
+    fk = (key, H, I, L, -(-int(rows) // 2048))                       # (row counts vary from batch to batch: 2048-row classes)
+    fits = _defer_fits.get(fk)
+    if fits is None:
+        need = L * (fk[4] * 2048) * (2 * I + 8 * H) * 2
+        free, _total = torch.cuda.mem_get_info(x_dev)
+        cached = torch.cuda.memory_reserved(x_dev) - torch.cuda.memory_allocated(x_dev)
+        fits = _defer_fits[fk] = need <= 0.5 * (free + cached)
+    return fits
 
 
 def _wgrad(top, probs):
@@ -307,10 +323,10 @@ class _EncoderFn:
         pair_wgrads, held = getattr(top, "pair_wgrads", True), None
         # (model.defer_wgrads: None = by shape (_auto_defer_wgrads), True / False forced; see the comment at its use)
         dw = getattr(top, "defer_wgrads", None)
-        if dw is None and os.environ.get("MMBERT_DEFER_WGRADS"):     # A/B switch for whole-process comparisons (bench.py builds its own model)
-            dw = os.environ["MMBERT_DEFER_WGRADS"] != "0"
+        if dw is None and _DEFER_ENV:
+            dw = _DEFER_ENV != "0"
         if dw is None:
-            dw = _auto_defer_wgrads(H, top.config.intermediate_size, L, x_dev=saved[0][0].device)
+            dw = _auto_defer_wgrads(H, top.config.intermediate_size, L, x_dev=saved[0][0].device, rows=ra)
         defer_wgrads, deferred = (top.grad_hook is None and bool(dw)), []
         for i in reversed(range(L)):
             lw = top._lw[i]
@@ -1221,8 +1237,7 @@ class _GpuModelBase(nn.Module):
         # the GPU busy while the lengths travel and the host packs the layout), write the caller's order, and one gather packs.
         rank = pro.rank
         # (the device-built packing of the default training step needs no host wait at all: it always comes first)
-        on_device = (pending is not None and not infer and not drop and getattr(self, "device_split_layout", True) and len(lens) * B <= 1024
-                     and os.environ.get("MMBERT_ATTN_LPT", "1") != "0" and os.environ.get("MMBERT_ATTN_XCD_GROUP", "1") != "0")
+        on_device = pending is not None and not infer and not drop and getattr(self, "device_split_layout", True) and len(lens) * B <= 1024
         t.late_split = side is None and not on_device
         t.split = None
         get_split = lambda: self._split_layout(plan, kv_len, pending, infer, drop, rank)
@@ -1284,8 +1299,7 @@ class _GpuModelBase(nn.Module):
             return None
         lay = plan["layout"]
         valid_host, flag, ev = pending
-        if (not infer and not drop and getattr(self, "device_split_layout", True) and len(lay.lens) <= 1024
-                and os.environ.get("MMBERT_ATTN_LPT", "1") != "0" and os.environ.get("MMBERT_ATTN_XCD_GROUP", "1") != "0"):
+        if not infer and not drop and getattr(self, "device_split_layout", True) and len(lay.lens) <= 1024:
             # the training step that returns its scores: every row is kept, so nothing about the packing has to be known on the HOST
             # before backward -- the maps and tile lists are built by two kernels from the prologue's device-side counts, the forward
             # pass has no host round trip (round 2 / early round 3: numpy on the prologue's words; async_prologue hid the wait)

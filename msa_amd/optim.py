@@ -32,11 +32,34 @@ class AdamW:
             raise NotImplementedError("correct_bias=False is not used by the reference")
         self.betas, self.eps, self.mode = betas, eps, {"hf": 0, "torch": 1}[mode]
         self.grad_scale = 1.0               # set to 1/world_size by parallel.DataParallel
-        # The dense weights' gradients (3/4 of the parameters) are not zero-filled between steps: the next backward's weight-gradient
-        # launches overwrite them (flat.FlatParams lazy zero; torch's zero_grad(set_to_none=True) semantics).  False: fill with zeros.
-        self.lazy_zero = True
+        self._lazy_zero = True
         self._flat = None
         self._steps = 0
+
+    # The dense weights' gradients (3/4 of the parameters) are not zero-filled between steps: the next backward's weight-gradient
+    # launches overwrite them (flat.FlatParams lazy zero; torch's zero_grad(set_to_none=True) semantics).  False: fill with zeros.
+    # A plain switch at ANY time (as an attribute it was baked into the kernel's flag array at the first step, and turning it
+    # off later left the fused zero_grad skipping blocks whose gradients were then accumulated into for ever): the setter rebuilds the
+    # flag array, and only blocks this optimizer owns ever carry the "leave it to the next backward" bit.
+    @property
+    def lazy_zero(self) -> bool:
+        return self._lazy_zero
+
+    @lazy_zero.setter
+    def lazy_zero(self, on: bool):
+        on = bool(on)
+        if on != self._lazy_zero:
+            self._lazy_zero = on
+            if self._flat is not None:
+                self._build_flags()
+
+    def _build_flags(self):
+        flags = self._base_flags.clone()
+        if self._lazy_zero:
+            lazy = self._flat.lazy_block_mask().to(flags.dtype)
+            lazy[flags == 2] = 0                 # frozen / not owned by this optimizer: never stepped, so never dropped either
+            flags |= lazy                        # + 4: the fused zero_grad leaves these blocks to the next backward's overwriting launches
+        self._flags = flags.to(self._flat.device)
 
     # the scheduler scales every group's lr by the same factor; the kernel takes one lr
     @property
@@ -75,12 +98,11 @@ class AdamW:
                     raise NotImplementedError(f"{name}: packed neighbours must share one weight-decay setting")
                 flags[b0:b1] = f
         flags[flags == 3] = 2
-        if self.lazy_zero:
-            flags |= flat.lazy_block_mask()  # + 4: the fused zero_grad leaves these blocks to the next backward's overwriting launches
-        self._flags = flags.to(flat.device)
+        self._base_flags = flags
         self._m = torch.zeros_like(flat.params)
         self._v = torch.zeros_like(flat.params)
         self._flat = flat
+        self._build_flags()
 
     def step(self):
         if self._flat is None:

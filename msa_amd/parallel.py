@@ -198,6 +198,7 @@ class DataParallel:
         self.equal_batch_shapes = bool(equal_batch_shapes)
         self._word_started = False
         self._unions = []            # one entry per differentiated forward since the last finish_backward(): (union, event) or None
+        self._unions_cut = False     # entries were dropped (bounded list, _on_ids)
         # the id exchange of step k + 1 must not queue behind the gradient collectives of step k (one communicator runs its
         # collectives in order): it gets a communicator of its own
         self._ids_group = dist.new_group(ranks=dist.get_process_group_ranks(group) if group is not None else None) if self.early_word else None
@@ -215,6 +216,14 @@ class DataParallel:
     def _on_ids(self, ids: torch.Tensor, stream=None):
         """Start of a forward pass that will be differentiated: the token ids of the step (inputs) -> the union of touched table rows
         over all ranks, long before backward needs it (gather_union reads a size back: here the host is ahead of the GPU)."""
+        # A differentiated forward whose backward never comes (a validation pass with grad enabled) would leave its union -- a GPU tensor
+        # -- here for ever (ADVICE r4): the list is bounded by the backwards that can still claim an entry.  Dropping an entry is safe:
+        # finish_backward() rebuilds the union when it finds fewer of them than pending backwards (every rank runs the same program,
+        # so every rank drops the same entries).
+        cap = 4 + 2 * len(self.model.__dict__.get("_deferred_embed_rows") or ())
+        if len(self._unions) >= cap:
+            del self._unions[:len(self._unions) - cap + 1]
+            self._unions_cut = True            # the list no longer holds every forward: finish_backward() rebuilds the union
         if not self.bucketer.enabled:
             self._unions.append(None)          # (a forward under no_sync(): if its backward is exchanged after all, the union is rebuilt)
             return
@@ -257,13 +266,14 @@ class DataParallel:
         """A micro-step without exchange: the lookup's rows go into the local table like any other gradient."""
         for ids, rows in self.model.__dict__.pop("_deferred_embed_rows", None) or ():
             _scatter_rows(self.model._w["g_word"], ids, rows)
-        self._unions = []
+        self._unions, self._unions_cut = [], False
 
     def finish_backward(self):
         """Call after ``loss.backward()`` and before ``optimizer.step()``."""
         bk = self.bucketer
         pend = self.model.__dict__.pop("_deferred_embed_rows", None) or []
         unions, self._unions = self._unions, []
+        cut, self._unions_cut = self._unions_cut, False
         started, self._word_started = self._word_started, False
         if not (self.early_word and started):
             for ids, rows in pend:                                 # (no early exchange happened: rows into the table, then the usual tail)
@@ -281,7 +291,7 @@ class DataParallel:
             # was enabled (each union is identical on all ranks, so their merge is too); a forward under no_sync() whose backward is
             # exchanged after all, or a backward without a registered forward, rebuilds it here (all ranks take the same branch: SPMD)
             union = None
-            if unions and all(u is not None for u in unions) and len(unions) >= len(pend):
+            if unions and not cut and all(u is not None for u in unions) and len(unions) >= len(pend):
                 for u, ev in unions:
                     if ev is not None:
                         torch.cuda.current_stream().wait_event(ev)

@@ -26,10 +26,10 @@ def _find(table, prefix):
 
 def test_rowwise_kernels_keep_their_loads_in_flight(scan):
     t = scan("rowwise.hip")
-    for prefix, min_loads in (("pair_proj_fwd_kernel<6>", 48), ("pair_proj_fwd_kernel<7>", 48), ("pair_wgrad_kernel", 28), ("ce_count_kernel", 8),
-                              ("split_layout_kernel", 2)):
+    # (only "no load waits alone" is pinned: the LOAD COUNT of a kernel is hipcc's business and moves with ROCm versions -- ADVICE r4)
+    for prefix in ("pair_proj_fwd_kernel<6>", "pair_proj_fwd_kernel<7>", "pair_wgrad_kernel", "ce_count_kernel", "split_layout_kernel"):
         for loads, drains, serialized in _find(t, prefix):
-            assert loads >= min_loads and serialized == 0, (prefix, loads, drains, serialized)
+            assert loads > 0 and serialized == 0, (prefix, loads, drains, serialized)
     for prefix in ("transpose_cast_kernel<float>", "transpose_cast_kernel<__bf16>", "_Z21transpose_cast_kernelIDF16b"):
         for loads, drains, serialized in [v for k, v in t.items() if prefix in k]:
             assert serialized <= 1, (prefix, loads, drains, serialized)    # (the edge-tile path reads one element at a time)
@@ -38,6 +38,6 @@ def test_rowwise_kernels_keep_their_loads_in_flight(scan):
 def test_heads_kernels_keep_their_loads_in_flight(scan):
     t = scan("heads.hip")
     (loads, drains, serialized), = _find(t, "skinny_wgrad_kernel")
-    assert loads >= 24 and serialized <= 6, (loads, drains, serialized)     # the 20 loads of a block together; the scalar edge paths remain
+    assert loads > 0 and serialized <= 6, (loads, drains, serialized)       # the 20 loads of a block together; the scalar edge paths remain
     (loads, drains, serialized), = _find(t, "skinny_mm_kernel")
     assert serialized <= 1, (loads, drains, serialized)

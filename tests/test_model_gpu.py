@@ -123,9 +123,11 @@ def hip_dropout_masks(m, B, lens, split):
     return masks, dict(hidden_dropout=q(ph), attn_dropout=q(pa), joint_dropout=q(pj))
 
 
-def check_against_oracle(cfg, B, T, Pv, Pa, seed, loss_tol=3e-3, train=False, flags=None, model_seed=7):
+def check_against_oracle(cfg, B, T, Pv, Pa, seed, loss_tol=3e-3, train=False, flags=None, model_seed=7, score_tol=3e-2, logit_tol=2e-2,
+                         grad_tol=0.045, score_mean_tol=None, head_grad_tol=None):
     """``train``: the whole step in TRAIN mode (all three dropouts on, REF:trainer.py:40,66,83) -- the HIP model runs first, its masks
-    are rebuilt (hip_dropout_masks) and the oracle replays them.  ``flags``: model switches set before the call."""
+    are rebuilt (hip_dropout_masks) and the oracle replays them.  ``flags``: model switches set before the call.  The default
+    tolerances are the L = 2 ones of the file header; deep models pass the bounds re-derived at depth (test_bert_base_12_layers_match_oracle)."""
     batch = synthetic_batch(B, T, Pv, Pa, dataset=cfg["dataset"], vocab=cfg["vocab"], seed=seed)
     m = build(cfg, train=train)
     for k, v in (flags or {}).items():
@@ -153,21 +155,22 @@ def check_against_oracle(cfg, B, T, Pv, Pa, seed, loss_tol=3e-3, train=False, fl
         tol = max(loss_tol, 3.0 * rel(eout[i].detach(), oout[i].detach()))
         assert rel(out[i].detach(), oout[i].detach()) < tol, (name, float(out[i]), float(oout[i]), tol)
     assert out[1] is None and out[2] is None and out[3] is None
-    assert float((logits.float().cpu() - ologits.detach()).abs().max()) < 2e-2
+    assert float((logits.float().cpu() - ologits.detach()).abs().max()) < logit_tol
     V = cfg["vocab"]
     for k in (7, 9, 11):
         assert tuple(out[k].shape) == tuple(oout[k].shape)
-        d = (out[k].float().cpu() - oout[k].detach()).abs().max()
-        assert float(d) < 3e-2, (k, float(d))
+        d = (out[k].float().cpu() - oout[k].detach()).abs()
+        assert float(d.max()) < score_tol, (k, float(d.max()))
+        assert score_mean_tol is None or float(d.mean()) < score_mean_tol, (k, float(d.mean()))
     for k in (8, 10, 12):
-        assert float((out[k].float().cpu() - oout[k].detach()).abs().max()) < 2e-2
+        assert float((out[k].float().cpu() - oout[k].detach()).abs().max()) < logit_tol
     out[0].mean().backward()
     torch.cuda.synchronize()
-    worst = compare_gradients(m, p, pe)
+    worst = compare_gradients(m, p, pe, grad_tol, head_grad_tol)
     return m, out, worst
 
 
-def compare_gradients(m, p, pe):
+def compare_gradients(m, p, pe, grad_tol=0.045, head_grad_tol=None):
     """Every parameter gradient of the HIP model ``m`` against the oracle's (``p``; ``pe`` = the oracle under bf16 storage emulation,
     the calibrator for the ill-conditioned head gradients).  Returns (worst cosine, its name)."""
     worst = (1.0, None)
@@ -190,8 +193,12 @@ def compare_gradients(m, p, pe):
         # ... and a gradient whose norm is three orders below the other head gradients (the CPC biases at initialisation: ~5e-5
         # against 0.4-1.3, see DESIGN numerics) is noise at bf16 precision on BOTH sides (the emulated oracle itself moves it by
         # 30-55 %): bounded absolutely, 2e-4
-        assert dev < max(0.045, 3.0 * dev_emul) or float((g - og).norm()) < 2e-4, (n, dev, dev_emul, float(og.norm()))
-        if dev > 0.045:
+        # (head_grad_tol: the [B, H]-sized head gradients -- pooler, gates, classifier, align -- at depth: sums over the batch of per-sample
+        # terms that partly cancel; L = 12, batch 8: 12 %, measured <= 9.9 % in eval mode, test_bert_base_12_layers_batch8_gradients_without_calibrator)
+        enc_side = n.startswith(("bert.embeddings", "bert.encoder", "bert.jointEmbeddings", "cls.predictions"))
+        tol_n = grad_tol if enc_side or head_grad_tol is None else head_grad_tol
+        assert dev < max(tol_n, 3.0 * dev_emul) or float((g - og).norm()) < 2e-4, (n, dev, dev_emul, float(og.norm()))
+        if dev > grad_tol:
             loose.append((n, round(dev, 3), round(dev_emul, 3)))
         cos = float(torch.nn.functional.cosine_similarity(g.reshape(1, -1), og.reshape(1, -1)))
         if cos < worst[0]:
@@ -420,13 +427,22 @@ def test_fused_sequence_packs_over_a_row_set():
         print(mode, "worst gradient deviation relative to the largest entry", worst)
 
 
-def test_backward_on_unmasked_rows_only_equals_full_backward():
+@pytest.mark.parametrize("size", ["small", "timed_depth"])
+def test_backward_on_unmasked_rows_only_equals_full_backward(size):
     """The valid-first packing (ops.SplitLayout): rows behind a sequence's last unmasked key and without a label have zero
     gradients in every layer, so backward runs on the other rows only.  Same model, same batch (heavy padding: pair lengths
     from half to full), dropout off: losses and scores identical, every parameter gradient equal to the full backward up to
-    fp32 summation order; a label placed on a padded row switches the short cut off (and the gradients still agree)."""
-    cfg = dict(hidden=256, layers=2, heads=4, intermediate=1024, vocab=4096, dataset="mosei", alpha=1.0, beta=1.0)
-    batch = synthetic_batch(4, 24, 200, 130, dataset="mosei", vocab=cfg["vocab"], seed=31)
+    fp32 summation order; a label placed on a padded row switches the short cut off (and the gradients still agree).
+    ``timed_depth`` (round 5): the same proof at the BENCHMARKED model -- 12 layers, d = 768, 12 heads, T = 50, A = V = 500 (batch 4:
+    4 600 packed rows) -- where the induction "zero in every layer" runs over twelve layers and the skipped rows meet the 192- / 224-row
+    GEMM tiles and the one-call weight gradients of the timed step."""
+    if size == "small":
+        cfg = dict(hidden=256, layers=2, heads=4, intermediate=1024, vocab=4096, dataset="mosei", alpha=1.0, beta=1.0)
+        T, Pv, Pa = 24, 200, 130
+    else:
+        cfg = dict(hidden=768, layers=12, heads=12, intermediate=3072, vocab=30522, dataset="mosei", alpha=1.0, beta=1.0)
+        T, Pv, Pa = 50, 500, 500
+    batch = synthetic_batch(4, T, Pv, Pa, dataset="mosei", vocab=cfg["vocab"], seed=31)
     dbatch = batch_to(batch, DEV)
     res = {}
     for skip in (True, False):
@@ -474,7 +490,7 @@ def test_backward_on_unmasked_rows_only_equals_full_backward():
             lay = seen[0]
             assert lay is not None and lay.rows_a < 0.95 * lay.tokens            # still a saving: only two sequences grew
             B_ = 4
-            assert lay.valid_host[B_ + 0] == 24 + 200 and lay.valid_host[1] == 24  # the two labelled sequences keep all their rows
+            assert lay.valid_host[B_ + 0] == T + Pv and lay.valid_host[1] == T     # the two labelled sequences keep all their rows
         res2[skip] = (out, {n: q.grad.detach().float().clone() for n, q in m.named_parameters()})
     for i in (0, 4, 5, 6):
         assert abs(float(res2[True][0][i]) - float(res2[False][0][i])) <= 1e-6 * abs(float(res2[False][0][i]))
@@ -638,6 +654,59 @@ def test_train_mode_step_matches_oracle_with_replayed_masks(case, shortcuts):
     # the short cuts really ran when asked for (and only then)
     assert (m.last_split is not None) == shortcuts and len(calls) == (1 if shortcuts else 0), (m.last_split, calls)
     print("train-mode worst gradient cosine", worst)
+
+
+@pytest.mark.parametrize("shortcuts", [True, False])
+def test_train_mode_step_at_the_timed_depth_matches_oracle_with_replayed_masks(shortcuts):
+    """Round 5: the replay test above at the configuration bench.py TIMES -- 12 layers, d = 768, 12 heads, I = 3072, vocabulary 30 522,
+    T = 50, A = V = 500, model.train() with dropout 0.1 / 0.1 / 0.5 (REF:trainer.py:40,66,83) -- at batch 8 (9 200 packed rows: the
+    smallest batch at which nt_choose's cost rule sends FFN-up + GELU and the GELU' input gradient to the MULTI-TILE 8-phase form on
+    224-row tiles, the form that carries the timed step; at batch 2 every launch is single-round, at batch 6 the rule takes 192-row
+    tiles).  Every
+    dropout site 8i + k for i < 12 is replayed in the oracle; asserted besides the numbers: the weight gradients of all dense layers
+    went out in ONE call (model._auto_defer_wgrads: 11 layers x 4 problems behind the sparse top layer, 12 x 4 with the short cuts
+    off) and mmbert_gemm_nt dispatched a forward and a backward shape to the multi-tile 8-phase form on 224-row tiles."""
+    cfg = dict(hidden=768, layers=12, heads=12, intermediate=3072, vocab=30522, dataset="mosei", alpha=1.0, beta=1.0)
+    flags = {} if shortcuts else dict(skip_padded_backward=False, sparse_top_layer_backward=False)
+    from msa_amd import model as MM
+    from msa_amd import ops as _ops
+    calls, orig = [], MM._EncoderFn._last_layer_sparse
+    MM._EncoderFn._last_layer_sparse = staticmethod(lambda *a, _o=orig, _c=calls: (_c.append(1), _o(*a))[1])
+    tn_calls, tn_orig = [], _ops.gemm_tn_grouped
+    nt_shapes, nt_orig = set(), _ops.gemm_nt
+
+    def nt_spy(A, B, **k):
+        epi = (1 if k.get("bias") is not None else 0) | (2 if k.get("gelu") else 0) | (4 if k.get("resid") is not None else 0) | \
+              (8 if k.get("gelu_bwd_u") is not None else 0) | (16 if k.get("out_f32") else 0)
+        nt_shapes.add((A.shape[0], B.shape[0], A.shape[1], epi))
+        return nt_orig(A, B, **k)
+
+    try:
+        _ops.gemm_tn_grouped = lambda probs, *a, _o=tn_orig, _c=tn_calls, **k: (_c.append(len(probs)), _o(probs, *a, **k))[1]
+        _ops.gemm_nt = nt_spy
+        # tolerances at L = 12 (re-derived at depth, test_bert_base_12_layers_match_oracle): losses 4e-3, scores 8e-2 max / 8e-3 mean (a bf16
+        # score of magnitude >= 8 carries 3e-2 of rounding alone), regression logits 3e-2, encoder-side gradients max(6 %, 3 x the bf16-storage
+        # calibrator), the [B, H]-sized head gradients max(12 %, 3 x calibrator) as in the eval-mode L = 12 batch-8 test
+        m, out, worst = check_against_oracle(cfg, 8, 50, 500, 500, seed=8, train=True, flags=flags, loss_tol=4e-3, score_tol=8e-2,
+                                             score_mean_tol=8e-3, logit_tol=3e-2, grad_tol=0.06, head_grad_tol=0.12)
+    finally:
+        MM._EncoderFn._last_layer_sparse = staticmethod(orig)
+        _ops.gemm_tn_grouped = tn_orig
+        _ops.gemm_nt = nt_orig
+    assert (m.last_split is not None) == shortcuts and len(calls) == (1 if shortcuts else 0), (m.last_split, calls)
+    assert (44 if shortcuts else 48) in tn_calls and 8 not in tn_calls, tn_calls           # one call for all dense layers, no paired launches
+    multi = {}
+    for (M, N, K, epi) in nt_shapes:
+        d = _ops.gemm_nt_describe(M, N, K, epi)
+        if d["kernel"] == "8phase" and d["tiles"] > d["workgroups"] and N < 30000:
+            multi[(N, K, epi)] = (M, d["tile"])
+    print("multi-tile 8-phase launches (N, K, epilogue) -> (rows, tile):", multi)
+    assert multi.get((3072, 768, 3), (0, ""))[1] == "224x256", multi                       # FFN-up + bias + GELU (+ pre-activation store), forward
+    # the GELU' input gradient, backward: on all 9 200 rows with the short cuts off (224-row tiles), on the ~ 7 000 unmasked ones with them
+    # on (whatever height the rule takes there)
+    assert (3072, 768, 8) in multi and (shortcuts or multi[(3072, 768, 8)][1] == "224x256"), multi
+    assert (2304, 768, 1) in multi, multi                                                  # QKV + bias
+    print("train-mode worst gradient cosine at L = 12", worst)
 
 
 def test_deferred_weight_gradients_equal_the_per_layer_launches():

@@ -204,6 +204,27 @@ def test_hf_adamw_differs_from_torch_only_in_documented_ways():
     close(p1, p2, rtol=1e-5, atol=1e-6)
 
 
+def test_hf_adamw_matches_the_hand_computed_vector():
+    """G11 (round 5): the oracle's mode "hf" against a known-answer vector computed by hand from the published transformers-2.8.0
+    update rule (tests/golden/hf_adamw_hand.py: 40-digit decimal arithmetic, no optimizer implementation) -- three steps of three
+    scalar trajectories in float64: parameters, first and second moments.  With this the optimizer bench.py and the 52-step loop
+    run (trainer mode "hf") is pinned by vectors, not by reading."""
+    from tests.golden import hf_adamw_hand as G
+    for name, (p0, wd, grads, ps, ms, vs) in G.TRAJECTORIES.items():
+        p = torch.tensor([p0], dtype=torch.float64)
+        m, v = torch.zeros(1, dtype=torch.float64), torch.zeros(1, dtype=torch.float64)
+        for t, g in enumerate(grads, 1):
+            O.adamw_step(p, torch.tensor([g], dtype=torch.float64), m, v, t, G.LR, wd, beta1=G.BETA1, beta2=G.BETA2, eps=G.EPS, mode="hf")
+            assert abs(float(p) - ps[t - 1]) <= 1e-13 * abs(ps[t - 1]), (name, t, float(p), ps[t - 1])
+            assert abs(float(m) - ms[t - 1]) <= 1e-13 * abs(ms[t - 1]) and abs(float(v) - vs[t - 1]) <= 1e-13 * vs[t - 1], (name, t)
+        # ... and the torch rule does NOT give these numbers (eps inside the bias correction, decay first): the vector discriminates
+        q = torch.tensor([p0], dtype=torch.float64)
+        m, v = torch.zeros(1, dtype=torch.float64), torch.zeros(1, dtype=torch.float64)
+        for t, g in enumerate(grads, 1):
+            O.adamw_step(q, torch.tensor([g], dtype=torch.float64), m, v, t, G.LR, wd, beta1=G.BETA1, beta2=G.BETA2, eps=G.EPS, mode="torch")
+        assert abs(float(q) - ps[-1]) > 1e-7 * abs(ps[-1]), name
+
+
 def test_schedule_and_step_rule():
     assert [O.should_step(s, 1) for s in range(4)] == [False, True, False, True]
     assert [O.should_step(s, 1, quirk=False) for s in range(3)] == [True, True, True]

@@ -1,10 +1,12 @@
 #!/usr/bin/env python3
-"""Same-process, interleaved A/B of the headline train step under environment toggles (box-to-box clocks differ by 5-10 %, so only
+"""Same-process, interleaved A/B of the headline train step under in-process toggles (box-to-box clocks differ by 5-10 %, so only
 ratios measured in one process count).
 
-    python tools/ab_step.py base: legacy:MMBERT_LN_DEFER=0            # each variant = name:ENV=VAL[,ENV=VAL...]
+    python tools/ab_step.py base: paired:attr.defer_wgrads=False nt256:nt_mode=256      # each variant = name:KEY=VAL[,KEY=VAL...]
 
-Only toggles that are read per call take effect (python-side os.environ reads, or C getenv per call)."""
+Keys: attr.NAME=<python literal> (a model attribute), ops.NAME=<literal> (a msa_amd.ops module attribute), nt_mode=<mmbert_gemm_nt_force
+mode>, tn_splits=<mmbert_gemm_tn_force_splits>.  The library reads no environment variable (round 5); two BUILDS of it are compared with
+alternating processes (tools/ab_lib.sh, MMBERT_LIB_PATH)."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch

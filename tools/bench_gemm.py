@@ -17,8 +17,8 @@ if os.environ.get("SHAPESET") == "bert-large":            # the reference's defa
               ("dgelu", M, 4096, 1024, "gelu_bwd"), ("dy1", M, 1024, 4096, "resid0"), ("dx", M, 1024, 3072, "resid0"), ("dctx", M, 1024, 1024, "plain"),
               ("vocab", M, 30592, 1024, "bias")]
 rounds = int(os.environ.get("ROUNDS", 5))
-MODES = [int(x) for x in os.environ.get("MODES", "3,4").split(",")]
-NAMES = {8: "8phase", 0: "default", 1: "128sq", 2: "ring auto", 3: "ring256", 4: "ring224", 5: "pers auto", 6: "pers256", 7: "pers224"}
+MODES = [int(x) for x in os.environ.get("MODES", "0,256").split(",")]        # mmbert_gemm_nt_force modes
+NAMES = {0: "default", 1: "128sq", 8: "8phase", 128: "8ph128", 192: "8ph192", 224: "8ph224", 256: "8ph256"}
 only = os.environ.get("SHAPES")
 if only:
     shapes = [sh for sh in shapes if sh[0] in only.split(",")]

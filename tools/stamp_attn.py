@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Diagnostic: where a wave of the attention forward kernel spends its cycles (s_memtime stamps, -DMMB_STAMPS build of
-tools/stamp_gemm.py --build).  Per wave and 64-key tile: wait (s_waitcnt vmcnt(0) + tile barrier), qk (staging issue, bias read,
+tools/build_stamped.py).  Per wave and 64-key tile: wait (s_waitcnt vmcnt(0) + tile barrier), qk (staging issue, bias read,
 S^T MFMAs, V read issue), softmax (max, exp2, pack, denominators, dropout), pv (LDS wait + O MFMAs).  MFMAs are asynchronous: a
 phase's MFMA time shows up where the NEXT dependent instruction waits.  Only shares are read (the stamps fence the schedule)."""
 import os, sys, ctypes
