@@ -81,6 +81,8 @@ def main():
     ap.add_argument("--no-early-word", action="store_true", help="A/B: the word-embedding table's gradient reduced with the tail (round-2 form)")
     ap.add_argument("--sync-prologue", action="store_true", help="A/B: the step prologue on the compute stream (model.async_prologue = False)")
     ap.add_argument("--scores-fp32", action="store_true", help="return the prediction scores as fp32 (model.scores_dtype = torch.float32)")
+    ap.add_argument("--no-deterministic", action="store_true", help="skip the secondary measurement in deterministic mode")
+    ap.add_argument("--deterministic", action="store_true", help="run the HEADLINE in deterministic mode (model.deterministic = True)")
     ap.add_argument("--no-scores-fp32", action="store_true", help="skip the secondary measurement with fp32 prediction scores (the reference's dtype)")
     ap.add_argument("--no-reference-default", action="store_true", help="skip the secondary measurement of the reference's own default model "
                     "(bert-large: 24-layer d=1024, T=P=40, batch 32: REF:train.py:28,32,38)")
@@ -174,6 +176,8 @@ def main():
     model.return_scores = True            # the reference returns the six score tensors; keep them materialised
     if a.scores_fp32:
         model.scores_dtype = torch.float32
+    if a.deterministic:
+        model.deterministic = True
     targs = default_args(train_batch_size=a.batch, learning_rate=5e-5)
     opt, sched = build_optimizer(model, targs, num_train_optimization_steps=10 * (a.steps + a.warmup))
     dp = (parallel.DataParallel(model, opt, bucket_mb=a.bucket_mb, force_dynamic_queue=a.force_dp, wire_dtype=torch.bfloat16 if a.dp_wire == "bf16" else None,
@@ -293,6 +297,20 @@ def main():
         scores_fp32 = leg_record(sel, note="model.scores_dtype = torch.float32: the six returned prediction-score tensors in the reference's dtype "
                                            "(REF:MMBertForPretraining.py:445-449); same losses and gradients as the headline step")
 
+    # Secondary: model.deterministic = True -- ordered sums instead of fp32 atomics (CE loss sums, the heads' skinny products, bias /
+    # LayerNorm partial sums, the embedding scatter through sorted keys): bit-identical losses and gradients run to run
+    # (tests/test_train_gpu.py::test_deterministic_mode_gives_bit_identical_steps); what it costs in the step is this leg against the headline.
+    det_leg = None
+    if not a.no_deterministic:
+        was_det = model.deterministic
+        model.deterministic = True
+        try:
+            dl = timed_leg(step)
+        finally:
+            model.deterministic = was_det
+        det_leg = leg_record(dl, note="model.deterministic = True (mmbert_set_deterministic): every fp32 sum in a schedule-independent order; "
+                                      "bit-identical losses and gradients run to run")
+
     # Secondary: the train step as trainer.py consumes it -- model.return_scores = False: the six prediction-score tensors that
     # the reference's forward returns and its trainer never reads are not produced, so the MLM head runs on the labelled rows
     # only (forward too) and the encoder leaves out the rows that only those scores would read.  Same losses and gradients
@@ -379,6 +397,9 @@ def main():
         dense_ref["tflop_per_sample_executed"] = round(fps_exec_dense / 1e12, 4)
     if scores_fp32 is not None:
         res["scores_fp32"] = scores_fp32
+    if det_leg is not None:
+        res["deterministic"] = det_leg
+    res["config"]["deterministic"] = bool(a.deterministic)
     if train_only is not None:
         res["train_only"] = train_only
     if fused is not None:

@@ -133,11 +133,12 @@ int mmbert_ln_bwd_reduce_rows(mmbert_stream_t stream, int items, const float* co
 /* ---- embeddings ----
  * gather: out[i] = word[ids[i]] + type[tts[i]] + pos[i % T]     HF:96-102 via REF:MMBertForPretraining.py:264
  * scatter: the matching scatter-add of the gradient (row 0 of word excluded: padding_idx, HF:58); gword may be NULL (position and
- *          token-type gradients only). */
+ *          token-type gradients only).  type_slab (may be NULL; required in deterministic mode): 2 * T * H floats -- the token-type sums
+ *          are then stored per position and folded in position order instead of added with atomics. */
 int mmbert_embed_gather(mmbert_stream_t stream, const int64_t* ids, const int64_t* tts, const float* word, const float* type,
                         const float* pos, int n, int T, int H, int V, void* out, int ldo);
 int mmbert_embed_scatter(mmbert_stream_t stream, const int64_t* ids, const int64_t* tts, const void* d, int ldd, int n, int T, int H, int V,
-                         float* gword, float* gtype, float* gpos);
+                         float* gword, float* gtype, float* gpos, float* type_slab);
 
 /* JointEmbeddings pair projection relu(W.feat + b) written after the text rows of each sample:
  * out[(b*(T+P) + T + p)] (REF:MMBertEmbedding.py:61-68); bwd accumulates dW, db. */
@@ -290,7 +291,29 @@ typedef struct { const float* X; const float* W; int ldx, ldw, inner, row0, rows
 typedef struct { float* Y; const float* bias; int ldy, M, N, nsrc, act, accumulate; mmbert_skinny_src src[4]; } mmbert_skinny_op;
 typedef struct { const float* dY; const float* X; float* dW; float* db; int ldy, ldx, ldw, M, N, K; } mmbert_skinny_wgrad_op;
 int mmbert_skinny_mm(mmbert_stream_t stream, int nops, const mmbert_skinny_op* ops);
+/* The same products in DETERMINISTIC form (mmbert_set_deterministic(1) makes mmbert_skinny_mm refuse with -4 and callers use this):
+ * every workgroup stores its partial tile into the caller's slab (mmbert_skinny_mm_workspace() bytes) and a second launch adds
+ * bias + the chunks in ascending order -- one add per output element. */
+size_t mmbert_skinny_mm_workspace(int nops, const mmbert_skinny_op* ops);
+int mmbert_skinny_mm_ordered(mmbert_stream_t stream, int nops, const mmbert_skinny_op* ops, void* workspace);
 int mmbert_skinny_wgrad(mmbert_stream_t stream, int nops, const mmbert_skinny_wgrad_op* ops);
+
+/* ---- deterministic mode (round 5) ----
+ * mmbert_set_deterministic(1): every fp32 sum of the library is formed in an order that does not depend on how workgroups are scheduled --
+ * the CE loss sums (an ordered one-workgroup sum instead of an atomic per row), the weight-gradient kernel (no token split: one adder per
+ * bias column), the LayerNorm partial-sum fold and mmbert_colsum (one adder per address), mmbert_skinny_mm (-> _ordered).  The two
+ * scatter-adds with data-dependent collisions -- mmbert_embed_scatter's word / token-type rows and mmbert_rows_to_block -- have no ordered
+ * form of their own: a deterministic caller uses mmbert_id_runs_sum_rows;
+ * mmbert_embed_scatter then takes a slab for its token-type sums and refuses a word table (-4).  Process-global like the force
+ * knobs; the same seeded step then gives bit-identical losses and gradients run to run (tests/test_train_gpu.py); default 0. */
+void mmbert_set_deterministic(int on);
+int mmbert_get_deterministic(void);
+/* dst[row_of(id)][0..H) += the sum of src[i][0..H) over all rows i with ids[i] == id, for every id, each sum formed in a fixed association
+ * (ascending i) and landing with ONE add per destination element.  row_of(id) = id (uni == NULL) or the id's index in the ascending list
+ * uni[0..U); ids outside (0, V) or not in the list are skipped.  src bf16 (src_bf16 = 1) or fp32 with row pitch lds; dst fp32 with row
+ * pitch ldd; H % 4 == 0, H <= 4096, n <= 8192.  No sort, no host read. */
+int mmbert_id_runs_sum_rows(mmbert_stream_t stream, const void* src, int src_bf16, int lds, const int64_t* ids, int n,
+                            int H, int V, const int64_t* uni, int U, float* dst, int ldd);
 
 /* ---- optimizer: flat AdamW (REF:train.py:76-97; mode 0 = transformers-2.8 AdamW, 1 = torch.optim.AdamW) ----
  * flags[i/256]: 0 no decay, 1 decay, 2 frozen; + 4 = "the next backward overwrites this block's gradient": zero_grad leaves it alone.

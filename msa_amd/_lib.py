@@ -38,7 +38,7 @@ SIGNATURES = {
     "mmbert_ln_bwd_reduce_rows": (I, [P, I, P, P, P, P, P, I]),
     "mmbert_ln_bwd_workspace": (SZ, [I, I]),
     "mmbert_embed_gather": (I, [P, P, P, P, P, P, I, I, I, I, P, I]),
-    "mmbert_embed_scatter": (I, [P, P, P, P, I, I, I, I, I, P, P, P]),
+    "mmbert_embed_scatter": (I, [P, P, P, P, I, I, I, I, I, P, P, P, P]),
     "mmbert_pair_proj_fwd": (I, [P, P, I, I, I, P, P, I, P, I, I]),
     "mmbert_pair_proj_bwd": (I, [P, P, I, I, I, P, P, I, I, P, P, I, P]),
     "mmbert_pair_proj_bwd_workspace": (SZ, [I, I, I, I]),
@@ -62,6 +62,11 @@ SIGNATURES = {
     "mmbert_heads_tanh_bwd": (I, [P, P, P, P, SZ]),
     "mmbert_heads_colsum": (I, [P, I, P, P, P, P, P]),
     "mmbert_skinny_mm": (I, [P, I, P]),
+    "mmbert_skinny_mm_workspace": (SZ, [I, P]),
+    "mmbert_skinny_mm_ordered": (I, [P, I, P, P]),
+    "mmbert_set_deterministic": (None, [I]),
+    "mmbert_get_deterministic": (I, []),
+    "mmbert_id_runs_sum_rows": (I, [P, P, I, I, P, I, I, I, P, I, P, I]),
     "mmbert_skinny_wgrad": (I, [P, I, P]),
     "mmbert_adamw": (I, [P, P, P, P, P, P, P, SZ, D, D, D, D, D, I, D, I, I]),
     "mmbert_gelu_bwd": (I, [P, P, P, P, SZ]),

@@ -50,6 +50,13 @@ static inline int mmb_device_cus() {
     return c;
 }
 
+// mmbert_set_deterministic (rowwise.hip defines the flag; one .so): 1 = every fp32 sum of the library is formed in an order that does not
+// depend on how workgroups are scheduled -- slabs + ordered reduces (or a single adder per address) instead of fp32 atomics whose arrival
+// order varies: the CE loss sums, the heads' skinny products, the weight-gradient kernel's bias sums (no token split), the LayerNorm
+// partial-sum fold, column sums; the embedding scatter and the data-parallel row block go through mmbert_segment_sum_rows.
+extern std::atomic<int> g_mmb_deterministic;
+static inline bool mmb_deterministic() { return g_mmb_deterministic.load(std::memory_order_relaxed) != 0; }
+
 // address-space casts for the LDS-DMA builtin
 #define GPTR(p) ((const void __attribute__((address_space(1)))*)(p))
 #define LPTR(p) ((void __attribute__((address_space(3)))*)(p))

@@ -1290,6 +1290,9 @@ static int tn_plan(int nprob, const int* N, const int* K, int M, int* splits_out
     // more than 8 problems = the deferred multi-layer call (model._auto_defer_wgrads): whole rounds of CUs-many tiles, never split.  Up to
     // 8 problems keep the cost model's answer (the dense tied-decoder gradient, 360 tiles at M ~ 18 k: 2 splits)
     if (tiles >= slots && nprob > 8) splits = 1;
+    // deterministic mode: every split of a bias tile adds its column sums with one atomic per column -- with ONE split that is a single
+    // adder per address (ordered); the weight gradients themselves go through slabs + an ordered reduce either way
+    if (mmb_deterministic()) splits = 1;
     if (g_tn_splits.load() > 0) splits = g_tn_splits.load();       // the forced count wins (tests, A/B runs)
     if (splits > max_splits) splits = max_splits;
     if (splits < 1) splits = 1;
@@ -1377,6 +1380,7 @@ int mmbert_colsum(hipStream_t stream, const void* X, int ldx, int M, int N, floa
     const int gx = (N / 8 + 63) / 64;
     int gy = (2048 + gx - 1) / gx;
     int rows = (M + gy - 1) / gy; if (rows < 32) rows = 32;
+    if (mmb_deterministic()) rows = M;                            // one workgroup per column block: a single adder per address
     gy = (M + rows - 1) / rows;
     hipLaunchKernelGGL(colsum_kernel, dim3(gx, gy), dim3(256), 0, stream, (const bf16_t*)X, M, N, ldx, out, alpha, alpha_dev, rows);
     MMB_CHECK_LAUNCH();

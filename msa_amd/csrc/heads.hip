@@ -334,8 +334,11 @@ __global__ void heads_tanh_bwd_kernel(const float* __restrict__ dP, const float*
 #define SK_MAXSRC 4
 struct SkSrc { const float* X; const float* W; int ldx, ldw, inner, row0, rows, w_inner_major; };
 struct SkOp { float* Y; const float* bias; int ldy, M, N, nsrc, act, accumulate, tile0, pad_; SkSrc src[SK_MAXSRC]; };
-struct SkArgs { SkOp op[SK_MAXOPS]; int nops; };
+struct SkArgs { SkOp op[SK_MAXOPS]; int nops; long long ws_off[SK_MAXOPS + 1]; float* ws; };
 
+// ORDERED (deterministic mode, mmbert_skinny_mm_ordered): a workgroup STORES its partial tile into the caller's slab
+// ws[op][chunk][row][n] instead of adding it to Y with atomics; skinny_mm_fold_kernel then adds bias and the chunks in ascending order.
+template <bool ORDERED>
 __global__ __launch_bounds__(256) void skinny_mm_kernel(const SkArgs a) {
     // One workgroup = one 16-column output tile x ONE 64-deep chunk of one source: a few hundred to a few thousand independent
     // workgroups per launch, each a single round trip to memory (a first version walked all chunks of a tile in one workgroup:
@@ -354,6 +357,7 @@ __global__ __launch_bounds__(256) void skinny_mm_kernel(const SkArgs a) {
     t -= (t / per_rb) * per_rb;
     const int n0 = (t / chunks) * 16;
     int ch = t - (t / chunks) * chunks, j = 0;
+    const int ch_all = ch;                                          // chunk index over all sources of this op
     while (j + 1 < op.nsrc && ch >= (op.src[j].inner + 63) / 64) { ch -= (op.src[j].inner + 63) / 64; ++j; }
     const SkSrc& sc = op.src[j];
     const int c0 = ch * 64;
@@ -399,9 +403,30 @@ __global__ __launch_bounds__(256) void skinny_mm_kernel(const SkArgs a) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int row = rb0 + tg + 16 * r;
-            if (row < op.M) atomicAdd(op.Y + (size_t)row * op.ldy + n, acc[r] + b);
+            if (row >= op.M) continue;
+            if constexpr (ORDERED) a.ws[a.ws_off[oi] + ((size_t)ch_all * op.M + row) * op.N + n] = acc[r];
+            else atomicAdd(op.Y + (size_t)row * op.ldy + n, acc[r] + b);
         }
     }
+}
+
+// Y[row][n] += bias[n] + sum over the chunks (ascending) of the slab: one thread per output element, one add per element
+__global__ __launch_bounds__(256) void skinny_mm_fold_kernel(const SkArgs a) {
+    const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+    int oi = 0;
+    long long base = 0;
+    for (int q = 0; q < a.nops; ++q) {
+        const long long cnt = (long long)a.op[q].M * a.op[q].N;
+        if (e >= base + cnt) { base += cnt; oi = q + 1; } else break;
+    }
+    if (oi >= a.nops) return;
+    const SkOp& op = a.op[oi];
+    const long long r = e - base;
+    const int row = (int)(r / op.N), n = (int)(r - (long long)row * op.N);
+    float t = op.bias ? op.bias[n] : 0.f;
+    const float* w = a.ws + a.ws_off[oi] + (size_t)row * op.N + n;
+    for (int c = 0; c < op.pad_; ++c) t += w[(size_t)c * op.M * op.N];
+    op.Y[(size_t)row * op.ldy + n] += t;
 }
 
 struct SkWOp { const float* dY; const float* X; float* dW; float* db; int ldy, ldx, ldw, M, N, K, tile0, tiles_k; };
@@ -568,11 +593,11 @@ struct mmbert_skinny_src { const float* X; const float* W; int ldx, ldw, inner, 
 struct mmbert_skinny_op { float* Y; const float* bias; int ldy, M, N, nsrc, act, accumulate; mmbert_skinny_src src[4]; };
 struct mmbert_skinny_wgrad_op { const float* dY; const float* X; float* dW; float* db; int ldy, ldx, ldw, M, N, K; };
 
-int mmbert_skinny_mm(hipStream_t stream, int nops, const mmbert_skinny_op* ops) {
-    if (nops <= 0) return 0;
+static int skinny_mm_args(int nops, const mmbert_skinny_op* ops, SkArgs& a, int& tiles, long long& elems) {
     if (nops > SK_MAXOPS) return -1;
-    SkArgs a = {};
-    int tiles = 0;
+    a = SkArgs{};
+    tiles = 0; elems = 0;
+    long long ws = 0;
     for (int i = 0; i < nops; ++i) {
         const mmbert_skinny_op& o = ops[i];
         if (o.M < 0 || o.M > 128 || o.N <= 0 || o.nsrc < 1 || o.nsrc > SK_MAXSRC || !o.Y) return -1;
@@ -589,9 +614,45 @@ int mmbert_skinny_mm(hipStream_t stream, int nops, const mmbert_skinny_op* ops) 
         }
         d.pad_ = chunks;
         tiles += ((o.N + 15) / 16) * chunks * ((o.M + 63) / 64 > 0 ? (o.M + 63) / 64 : 1);
+        a.ws_off[i] = ws;
+        ws += (long long)chunks * o.M * o.N;
+        elems += (long long)o.M * o.N;
     }
+    a.ws_off[nops] = ws;
     a.nops = nops;
-    hipLaunchKernelGGL(skinny_mm_kernel, dim3(tiles), dim3(256), 0, stream, a);
+    return 0;
+}
+
+int mmbert_skinny_mm(hipStream_t stream, int nops, const mmbert_skinny_op* ops) {
+    if (nops <= 0) return 0;
+    if (mmb_deterministic()) return -4;                            // deterministic mode: mmbert_skinny_mm_ordered (needs the caller's slab)
+    SkArgs a;
+    int tiles;
+    long long elems;
+    if (skinny_mm_args(nops, ops, a, tiles, elems)) return -1;
+    hipLaunchKernelGGL(skinny_mm_kernel<false>, dim3(tiles), dim3(256), 0, stream, a);
+    MMB_CHECK_LAUNCH();
+    return 0;
+}
+
+size_t mmbert_skinny_mm_workspace(int nops, const mmbert_skinny_op* ops) {
+    SkArgs a;
+    int tiles;
+    long long elems;
+    if (nops <= 0 || skinny_mm_args(nops, ops, a, tiles, elems)) return 0;
+    return (size_t)a.ws_off[nops] * sizeof(float);
+}
+
+int mmbert_skinny_mm_ordered(hipStream_t stream, int nops, const mmbert_skinny_op* ops, void* workspace) {
+    if (nops <= 0) return 0;
+    SkArgs a;
+    int tiles;
+    long long elems;
+    if (skinny_mm_args(nops, ops, a, tiles, elems) || !workspace) return -1;
+    a.ws = (float*)workspace;
+    hipLaunchKernelGGL(skinny_mm_kernel<true>, dim3(tiles), dim3(256), 0, stream, a);
+    MMB_CHECK_LAUNCH();
+    hipLaunchKernelGGL(skinny_mm_fold_kernel, dim3((unsigned)((elems + 255) / 256)), dim3(256), 0, stream, a);
     MMB_CHECK_LAUNCH();
     return 0;
 }

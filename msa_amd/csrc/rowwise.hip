@@ -8,6 +8,8 @@
 // maps (int32) where a kernel gathers or scatters rows of the packed token matrix.
 #include "common.h"
 
+std::atomic<int> g_mmb_deterministic{0};     // mmbert_set_deterministic (common.h: every translation unit of the library reads it)
+
 // Row maps of the valid-first packing (ops.SplitLayout): packed row of every original row (inv) and back (perm), from the
 // per-sequence unmasked length `valid`, the region starts and the row -> (sequence, position) tables.  mode 0: masked-out rows
 // go to region B in order; 1: all masked-out rows of a sequence share its ONE region-B row (inference); 2: they are left out
@@ -642,9 +644,9 @@ __global__ __launch_bounds__(WPB * 64) void ln_bwd_lean_kernel(const bf16_t* __r
 // grid (ceil(H/64), items * 3, 8): a workgroup = 64 columns x 4 interleaved row groups over 1/8 of the partials, LDS-reduced, then
 // ONE atomic per column per workgroup (8 adders per address: no contention to speak of).
 struct LnReduceBatch { float* out[32][3]; const float* partial[32]; int nblocks[32]; int H, nq, items; };   // (nblocks per item: the calls of one launch may differ in rows)
-__global__ __launch_bounds__(256) void ln_bwd_reduce_batch_kernel(const LnReduceBatch b) {
-    __shared__ float red[4][64];
-    const int col = blockIdx.x * 64 + (threadIdx.x & 63), sub = threadIdx.x >> 6;
+__global__ __launch_bounds__(1024) void ln_bwd_reduce_batch_kernel(const LnReduceBatch b) {
+    __shared__ float red[16][64];
+    const int col = blockIdx.x * 64 + (threadIdx.x & 63), sub = threadIdx.x >> 6, nsub = (int)blockDim.x >> 6;
     const int item = blockIdx.y / b.nq, k = blockIdx.y - item * b.nq;
     float* out = b.out[item][k];
     if (out == nullptr) return;
@@ -654,10 +656,14 @@ __global__ __launch_bounds__(256) void ln_bwd_reduce_batch_kernel(const LnReduce
     const int b0 = blockIdx.z * per, b1 = min(nblocks, b0 + per);
     float s = 0.f;
     if (col < b.H)
-        for (int q = b0 + sub; q < b1; q += 4) s += partial[((size_t)q * b.nq + k) * b.H + col];
+        for (int q = b0 + sub; q < b1; q += nsub) s += partial[((size_t)q * b.nq + k) * b.H + col];
     red[sub][threadIdx.x & 63] = s;
     __syncthreads();
-    if (sub == 0 && col < b.H) atomicAdd(out + col, red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
+    if (sub == 0 && col < b.H) {
+        float t = red[0][threadIdx.x];
+        for (int q = 1; q < nsub; ++q) t += red[q][threadIdx.x];
+        atomicAdd(out + col, t);                                   // (deterministic mode: one z slice -- the only adder of this address)
+    }
 }
 
 // --------------------------------------------------------------------------------------------
@@ -689,7 +695,10 @@ __global__ __launch_bounds__(256) void embed_gather_kernel(const int64_t* __rest
 // word rows, which rarely collide, take an atomic per row.
 __global__ __launch_bounds__(256) void embed_scatter_kernel(const int64_t* __restrict__ ids, const int64_t* __restrict__ tts,
                                                             const bf16_t* __restrict__ d, int ldd, int n, int T, int H, int V,
-                                                            float* __restrict__ gword, float* __restrict__ gtype, float* __restrict__ gpos) {
+                                                            float* __restrict__ gword, float* __restrict__ gtype, float* __restrict__ gpos,
+                                                            float* __restrict__ type_slab) {
+    // type_slab (deterministic mode, one slice): the position's two token-type sums are STORED to type_slab[p][0 / 1][col] and folded in
+    // position order by embed_type_fold_kernel, instead of T workgroups adding to the same two rows in arrival order.
     // (round 4) The loop over the sequences was one dependent memory round trip per row (id -> branch -> atomics: 47 us for 48 rows per
     // workgroup, on the critical path in front of the optimizer): the rows now come in BATCHES of 8 whose loads are issued together, and
     // blockIdx.y takes every gridDim.y-th batch -- one slice by default: more slices LOSE (every slice adds its token-type sums to the
@@ -721,9 +730,12 @@ __global__ __launch_bounds__(256) void embed_scatter_kernel(const int64_t* __res
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            atomicAdd(gpos + (size_t)p * H + col + r, ps[r]);
-            if (t0[r] != 0.f) atomicAdd(gtype + col + r, t0[r]);
-            if (t1[r] != 0.f) atomicAdd(gtype + H + col + r, t1[r]);
+            atomicAdd(gpos + (size_t)p * H + col + r, ps[r]);       // (one slice: the only adder of this address)
+            if (type_slab) { type_slab[((size_t)p * 2) * H + col + r] = t0[r]; type_slab[((size_t)p * 2 + 1) * H + col + r] = t1[r]; }
+            else {
+                if (t0[r] != 0.f) atomicAdd(gtype + col + r, t0[r]);
+                if (t1[r] != 0.f) atomicAdd(gtype + H + col + r, t1[r]);
+            }
         }
     }
 }
@@ -1064,6 +1076,137 @@ __global__ void ce_count_kernel(const int64_t* __restrict__ labels, int M, int V
     }
 }
 
+// Deterministic mode: loss_sum[seg] = sum over the labelled rows of (row_lse - logit[label]) * inv_count[seg] in a FIXED order (thread t
+// takes rows t, t + 1024, ... ascending; then a fixed-shape tree over the 1024 partial sums) instead of one atomic per row in arrival order.
+template <bool F32>
+__global__ __launch_bounds__(1024) void ce_loss_sum_ordered_kernel(const void* __restrict__ logits_, int ldv, int V, const int64_t* __restrict__ labels, int M,
+                                                                   const int* __restrict__ seg_bounds, int nseg, const float* __restrict__ inv_count,
+                                                                   const float* __restrict__ row_lse, float* __restrict__ loss_sum) {
+    __shared__ float red[4][1024];
+    const int b1 = nseg > 1 ? seg_bounds[1] : 0x7fffffff, b2 = nseg > 2 ? seg_bounds[2] : 0x7fffffff, b3 = nseg > 3 ? seg_bounds[3] : 0x7fffffff;
+    float c[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int i0 = threadIdx.x; i0 < M; i0 += 1024 * 8) {            // eight rows per thread and trip: their label loads go out together
+        int64_t lab[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) lab[u] = labels[min(i0 + u * 1024, M - 1)];
+        float lg[8], ls[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = min(i0 + u * 1024, M - 1);
+            const int64_t l = (lab[u] >= 0 && lab[u] < V) ? lab[u] : 0;     // (clamped: always a valid address; unlabelled rows are masked below)
+            lg[u] = F32 ? bf2f(f2bf(((const float*)logits_)[(size_t)i * ldv + l])) : bf2f(((const bf16_t*)logits_)[(size_t)i * ldv + l]);
+            ls[u] = row_lse[i];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {                                // ascending rows: the order of a thread's sum is fixed
+            const int i = i0 + u * 1024;
+            const bool ok = i < M && lab[u] >= 0 && lab[u] < V;
+            const int sg = (i >= b1 ? 1 : 0) + (i >= b2 ? 1 : 0) + (i >= b3 ? 1 : 0);
+            const float v = ok ? (ls[u] - lg[u]) * inv_count[sg] : 0.f;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) c[q] += (sg == q) ? v : 0.f;
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) red[q][threadIdx.x] = c[q];
+    __syncthreads();
+    for (int w = 512; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) red[q][threadIdx.x] += red[q][threadIdx.x + w];
+        }
+        __syncthreads();
+    }
+    if ((int)threadIdx.x < nseg) loss_sum[threadIdx.x] = red[threadIdx.x][0];
+}
+
+// Deterministic scatter-add of rows keyed by an id: dst[row_of(id)][:] += sum of src[i][:] over all rows i that carry that id, added in a
+// FIXED association -- row group g (of G = blockDim / (H / 4)) sums the id's rows number g, g + G, ... (ascending i), then the G partial
+// sums are added in the order g = 0 .. G - 1 -- with exactly one add per destination element, whatever the scheduling.  One workgroup
+// per row i: it scans all n ids (a few KB, L2-resident), leaves at once unless i is the FIRST row of its id, and otherwise collects the
+// id's rows in ascending order in LDS (wave 0, ballot compaction) and sums them.  No sort, no compaction on the host, nothing read back.
+// row_of(id) = id (uni == null: the word-embedding table) or the id's index in the ascending list `uni` (the data-parallel row block);
+// ids outside (0, V) or not in the list are skipped.  n <= 8192 (the LDS list).  Replaces the atomics of mmbert_embed_scatter's word rows
+// and of mmbert_rows_to_block in deterministic mode.
+#define RUNS_MAXN 8192
+__global__ __launch_bounds__(1024) void id_runs_sum_rows_kernel(const void* __restrict__ src, int src_bf16, int lds, const int64_t* __restrict__ ids,
+                                                                int n, int H, int V, const int64_t* __restrict__ uni, int U,
+                                                                float* __restrict__ dst, int ldd) {
+    __shared__ int list[RUNS_MAXN];
+    __shared__ float red[1024 * 4];
+    __shared__ int s_count, s_earlier;
+    const int i0 = blockIdx.x, tid = threadIdx.x, nthr = blockDim.x;
+    const long long key = ids[i0];
+    if (key <= 0 || key >= V) return;
+    if (tid == 0) { s_count = 0; s_earlier = 0; }
+    __syncthreads();
+    int earlier = 0;
+    for (int j = tid; j < i0; j += nthr) earlier |= (ids[j] == key) ? 1 : 0;
+    if (earlier) s_earlier = 1;                                    // (benign: every writer stores 1)
+    __syncthreads();
+    if (s_earlier) return;
+    long long dr = key;
+    if (uni) {
+        int lo = 0, hi = U - 1;
+        while (lo < hi) { const int mid = (lo + hi) >> 1; if (uni[mid] < key) lo = mid + 1; else hi = mid; }
+        if (U <= 0 || uni[lo] != key) return;
+        dr = lo;
+    }
+    if (tid < 64) {                                                // wave 0: the id's rows from i0 on, ascending, into the list
+        int count = 0;
+        for (int base = i0; base < n; base += 64) {
+            const int j = base + tid;
+            const bool hit = j < n && ids[j] == key;
+            const unsigned long long m = __ballot(hit);
+            if (hit) list[count + __popcll(m & ((1ull << tid) - 1ull))] = j;
+            count += __popcll(m);
+        }
+        if (tid == 0) s_count = count;
+    }
+    __syncthreads();
+    const int cnt = s_count;
+    const int CT = H >> 2, G = nthr / CT;                          // column threads, row groups
+    const int g = tid / CT, c = tid - g * CT;
+    float a[4] = {0.f, 0.f, 0.f, 0.f};
+    if (g < G) {
+#pragma unroll 4
+        for (int k = g; k < cnt; k += G) {
+            const size_t r = (size_t)list[k];
+            if (src_bf16) {
+                const bf16x4 x = *(const bf16x4*)((const bf16_t*)src + r * lds + 4 * c);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) a[q] += bf2f(x[q]);
+            } else {
+                const float4 x = *(const float4*)((const float*)src + r * lds + 4 * c);
+                a[0] += x.x; a[1] += x.y; a[2] += x.z; a[3] += x.w;
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) red[(g * CT + c) * 4 + q] = a[q];
+    }
+    __syncthreads();
+    if (g == 0) {
+        float4* d = (float4*)(dst + (size_t)dr * ldd + 4 * c);
+        float4 o = *d;
+        float t[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int gg = 0; gg < G; ++gg)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) t[q] += red[(gg * CT + c) * 4 + q];
+        o.x += t[0]; o.y += t[1]; o.z += t[2]; o.w += t[3];
+        *d = o;
+    }
+}
+
+// token-type rows of the embedding scatter, deterministic mode: gtype[t][col] += sum over the positions p (ascending) of the per-position
+// partial sums the scatter kernel left in slab[p][t][col]
+__global__ void embed_type_fold_kernel(const float* __restrict__ slab, int T, int H, float* __restrict__ gtype) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= 2 * H) return;
+    float t = 0.f;
+    for (int p = 0; p < T; ++p) t += slab[(size_t)p * 2 * H + e];
+    gtype[e] += t;
+}
+
 #define CE_MAXC 16
 // One workgroup per row, the row held in registers (<= 16 x 16 B per lane).
 //   MODE 0 (forward): row_lse[i] = logsumexp(row); loss_sum[seg] += (lse - logit[label]) * inv_count[seg]
@@ -1144,7 +1287,7 @@ __global__ __launch_bounds__(256) void ce_row_kernel(const void* __restrict__ lo
         if (tid == 0) {
             const float lse = mx + __logf(red[0] + red[1] + red[2] + red[3]);
             row_lse[i] = lse;
-            atomicAdd(loss_sum + s, (lse - lab_logit) * inv_count[s]);
+            if (loss_sum) atomicAdd(loss_sum + s, (lse - lab_logit) * inv_count[s]);      // (null: deterministic mode, ce_loss_sum_ordered_kernel)
         }
     } else {
         const float lse = row_lse[i];
@@ -1649,7 +1792,7 @@ int mmbert_ln_bwd(hipStream_t stream, const void* dy, int lddy, const int* dy_ro
         LnReduceBatch b = {};
         b.out[0][0] = dgamma; b.out[0][1] = dbeta; b.out[0][2] = dbias2; b.partial[0] = partial_ws;
         b.nblocks[0] = nblocks; b.H = H; b.nq = 3; b.items = 1;
-        hipLaunchKernelGGL(ln_bwd_reduce_batch_kernel, dim3((H + 63) / 64, 3, 8), dim3(256), 0, stream, b);
+        hipLaunchKernelGGL(ln_bwd_reduce_batch_kernel, dim3((H + 63) / 64, 3, mmb_deterministic() ? 1 : 8), dim3(mmb_deterministic() ? 1024 : 256), 0, stream, b);
         MMB_CHECK_LAUNCH();
     }
     return 0;
@@ -1673,7 +1816,7 @@ static int ln_bwd_reduce_launch(hipStream_t stream, int items, const float* cons
         b.nblocks[i] = M > 0 ? ln_bwd_blocks(M, H) : 0;
     }
     b.H = H; b.nq = 3; b.items = items;
-    hipLaunchKernelGGL(ln_bwd_reduce_batch_kernel, dim3((H + 63) / 64, items * 3, 8), dim3(256), 0, stream, b);
+    hipLaunchKernelGGL(ln_bwd_reduce_batch_kernel, dim3((H + 63) / 64, items * 3, mmb_deterministic() ? 1 : 8), dim3(mmb_deterministic() ? 1024 : 256), 0, stream, b);
     MMB_CHECK_LAUNCH();
     return 0;
 }
@@ -1698,12 +1841,19 @@ int mmbert_embed_gather(hipStream_t stream, const int64_t* ids, const int64_t* t
 }
 
 int mmbert_embed_scatter(hipStream_t stream, const int64_t* ids, const int64_t* tts, const void* d, int ldd, int n, int T, int H, int V,
-                         float* gword, float* gtype, float* gpos) {
+                         float* gword, float* gtype, float* gpos, float* type_slab) {
     if (n <= 0) return 0;
     if (H > LN_MAXV * 256 || (H & 3) || (ldd & 3) || T <= 0) return -1;
+    // deterministic mode: the word rows cannot come from this kernel (a word at several positions: atomics in arrival order -- the caller
+    // uses mmbert_sorted_runs_sum_rows) and the token-type sums need the slab (2 * T * H floats)
+    if (mmb_deterministic() && (gword != nullptr || type_slab == nullptr)) return -4;
     constexpr int slices = 1;   // grid.y slices of the sequences; measured at the headline shape: 1 / 2 / 4 / 8 = 37.8 / 39.1 / 49.0 / 59.2 us (same-address atomics on the two token-type rows)
-    hipLaunchKernelGGL(embed_scatter_kernel, dim3(T < n ? T : n, slices), dim3(256), 0, stream, ids, tts, (const bf16_t*)d, ldd, n, T, H, V, gword, gtype, gpos);
+    hipLaunchKernelGGL(embed_scatter_kernel, dim3(T < n ? T : n, slices), dim3(256), 0, stream, ids, tts, (const bf16_t*)d, ldd, n, T, H, V, gword, gtype, gpos, type_slab);
     MMB_CHECK_LAUNCH();
+    if (type_slab) {
+        hipLaunchKernelGGL(embed_type_fold_kernel, dim3((2 * H + 255) / 256), dim3(256), 0, stream, type_slab, T < n ? T : n, H, gtype);
+        MMB_CHECK_LAUNCH();
+    }
     return 0;
 }
 
@@ -1770,12 +1920,34 @@ int mmbert_ce_fwd(hipStream_t stream, const void* logits, int ldv, int V, const 
     if (nseg < 1 || nseg > 4 || (ldv & 7) || ldv > CE_MAXC * 256 * 8 || V > ldv) return -1;
     hipLaunchKernelGGL(ce_count_kernel, dim3(1), dim3(1024), 0, stream, labels, M, V, seg_bounds, nseg, inv_count, loss_sum);
     MMB_CHECK_LAUNCH();
+    const bool det = mmb_deterministic();
+    float* ls = det ? nullptr : loss_sum;
     if (logits_f32)
-        hipLaunchKernelGGL((ce_row_kernel<0, true>), dim3(M), dim3(256), 0, stream, logits, ldv, V, labels, seg_bounds, nseg, inv_count, loss_sum,
+        hipLaunchKernelGGL((ce_row_kernel<0, true>), dim3(M), dim3(256), 0, stream, logits, ldv, V, labels, seg_bounds, nseg, inv_count, ls,
                            row_lse, (const float*)nullptr, (bf16_t*)nullptr, 0, (const int*)nullptr);
     else
-        hipLaunchKernelGGL((ce_row_kernel<0, false>), dim3(M), dim3(256), 0, stream, logits, ldv, V, labels, seg_bounds, nseg, inv_count, loss_sum,
+        hipLaunchKernelGGL((ce_row_kernel<0, false>), dim3(M), dim3(256), 0, stream, logits, ldv, V, labels, seg_bounds, nseg, inv_count, ls,
                            row_lse, (const float*)nullptr, (bf16_t*)nullptr, 0, (const int*)nullptr);
+    MMB_CHECK_LAUNCH();
+    if (det) {
+        if (logits_f32) hipLaunchKernelGGL((ce_loss_sum_ordered_kernel<true>), dim3(1), dim3(1024), 0, stream, logits, ldv, V, labels, M, seg_bounds, nseg, inv_count, row_lse, loss_sum);
+        else hipLaunchKernelGGL((ce_loss_sum_ordered_kernel<false>), dim3(1), dim3(1024), 0, stream, logits, ldv, V, labels, M, seg_bounds, nseg, inv_count, row_lse, loss_sum);
+        MMB_CHECK_LAUNCH();
+    }
+    return 0;
+}
+
+void mmbert_set_deterministic(int on) { g_mmb_deterministic.store(on != 0); }
+int mmbert_get_deterministic(void) { return g_mmb_deterministic.load(); }
+
+int mmbert_id_runs_sum_rows(hipStream_t stream, const void* src, int src_bf16, int lds, const int64_t* ids, int n,
+                            int H, int V, const int64_t* uni, int U, float* dst, int ldd) {
+    if (n <= 0) return 0;
+    if ((H & 3) || H > 4096 || n > RUNS_MAXN || (lds & 3) || (ldd & 3) || !src || !ids || !dst) return -1;
+    const int CT = H >> 2;
+    int G = 1024 / CT; if (G > 8) G = 8; if (G < 1) G = 1;
+    int threads = G * CT; if (threads < 64) threads = 64;
+    hipLaunchKernelGGL(id_runs_sum_rows_kernel, dim3(n), dim3(threads), 0, stream, src, src_bf16, lds, ids, n, H, V, uni, U, dst, ldd);
     MMB_CHECK_LAUNCH();
     return 0;
 }

@@ -1584,6 +1584,19 @@ class MMBertForPretraining(_GpuModelBase):
         # weight tying (HF:728-731): decoder.weight IS the word embedding, decoder.bias IS predictions.bias
         self.cls.predictions.decoder.weight = self.bert.embeddings.word_embeddings.weight
 
+    # ``model.deterministic = True``: every fp32 sum of the step is formed in an order that does not depend on how workgroups are
+    # scheduled (slabs + ordered reduces, sorted-key segment sums, a single adder per address) instead of fp32 atomics in arrival order:
+    # the same seeded step gives bit-identical losses and gradients run to run, and two launch paths of the same function agree more
+    # tightly (tests/test_train_gpu.py).  Process-global (the library's mmbert_set_deterministic; MMBERT_DETERMINISTIC=1 sets it at
+    # import); costs ~ a dozen small launches per step.
+    @property
+    def deterministic(self) -> bool:
+        return ops.deterministic()
+
+    @deterministic.setter
+    def deterministic(self, on: bool):
+        ops.set_deterministic(bool(on))
+
     # ---- construction helpers ------------------------------------------------------------------
     @staticmethod
     def _checkpoint_keys(sd):

@@ -318,11 +318,40 @@ def embed_gather(ids, tts, word, type_, pos, T, out=None):
     return out
 
 
+def set_deterministic(on: bool) -> None:
+    """Process-global (mmbert_set_deterministic): ordered sums instead of fp32 atomics everywhere in the library; the scatter-adds with
+    data-dependent collisions (embed_scatter's word / token-type rows, rows_to_block) switch to sorted keys + segment_sum_rows here."""
+    _lib.load().mmbert_set_deterministic(1 if on else 0)
+
+
+def deterministic() -> bool:
+    return bool(_lib.load().mmbert_get_deterministic())
+
+
+if os.environ.get("MMBERT_DETERMINISTIC", "0") not in ("", "0"):         # read once at import; model.deterministic = True does the same
+    set_deterministic(True)
+
+
+def scatter_add_rows_ordered(keys, src, dst, vocab, union=None):
+    """dst[row_of(key_i)] += src[i] for every row i, DETERMINISTICALLY (mmbert_id_runs_sum_rows): the rows of one key are summed in a fixed
+    association (ascending i) and land with one add per destination element.  row_of(key) = key, or its index in the ascending ``union``;
+    keys outside (0, vocab) or not in the union are skipped.  One launch, nothing is sorted or read back by the host."""
+    keys = keys.reshape(-1).long().contiguous()
+    _lib.check(_lib.load().mmbert_id_runs_sum_rows(_stream(), src.data_ptr(), 1 if src.dtype == torch.bfloat16 else 0, src.stride(0), keys.data_ptr(),
+                                                   keys.numel(), src.shape[1], int(vocab), _ptr(union), 0 if union is None else union.numel(),
+                                                   dst.data_ptr(), dst.stride(0)), "mmbert_id_runs_sum_rows")
+    return dst
+
+
 def rows_to_block(ids, rows, union, vocab, block):
     """block[pos(ids[i])] += rows[i] with pos = the index of ids[i] in the ascending int64 list ``union`` (mmbert_rows_to_block): the
     local side of the data-parallel compact row exchange.  ids outside (0, vocab) or not in the list are skipped."""
     ids = ids.reshape(-1).long().contiguous()
     union = union.long().contiguous()
+    if deterministic():
+        if union.numel():
+            scatter_add_rows_ordered(ids, rows, block, vocab, union=union)
+        return block
     _lib.check(_lib.load().mmbert_rows_to_block(_stream(), ids.data_ptr(), rows.data_ptr(), 1 if rows.dtype == torch.bfloat16 else 0, rows.stride(0),
                                                 ids.numel(), rows.shape[1], union.data_ptr(), union.numel(), int(vocab), block.data_ptr()),
                "mmbert_rows_to_block")
@@ -334,8 +363,16 @@ def embed_scatter(ids, tts, d, T, gword, gtype, gpos, vocab=None):
     lib = _lib.load()
     n = ids.numel()
     V, H = gword.shape if gword is not None else (int(vocab), d.shape[1])
+    slab = None
+    if deterministic():
+        # position sums: a single adder per address in the kernel; token-type sums: per-position partials in a slab, folded in position
+        # order; word rows (a word at several positions would be atomics in arrival order): sorted keys + ordered run sums
+        slab = _ws_f32(2 * T * H, d.device)
+        if gword is not None:
+            scatter_add_rows_ordered(ids, d, gword, V)
+            gword = None
     _lib.check(lib.mmbert_embed_scatter(_stream(), ids.data_ptr(), _ptr(tts), d.data_ptr(), d.stride(0), n, T, H, V,
-                                        _ptr(gword), gtype.data_ptr(), gpos.data_ptr()), "mmbert_embed_scatter")
+                                        _ptr(gword), gtype.data_ptr(), gpos.data_ptr(), _ptr(slab)), "mmbert_embed_scatter")
 
 
 def _pair_rows(T, Pn, ld, seq_len, offset):
@@ -1031,7 +1068,12 @@ def skinny_mm(oplist):
             assert (W.shape == (inner, Y.shape[1])) if wim else (W.shape == (Y.shape[1], inner)), (W.shape, inner, Y.shape, wim)
             sc.X, sc.W, sc.ldx, sc.ldw, sc.inner, sc.row0, sc.rows, sc.w_inner_major = X.data_ptr(), W.data_ptr(), X.stride(0), W.stride(0), inner, row0, X.shape[0], 1 if wim else 0
             keep.append((X, W))
-    _lib.check(_lib.load().mmbert_skinny_mm(_stream(), n, ctypes.cast(arr, ctypes.c_void_p)), "mmbert_skinny_mm")
+    lib = _lib.load()
+    if deterministic():
+        ws = _ws_f32((lib.mmbert_skinny_mm_workspace(n, ctypes.cast(arr, ctypes.c_void_p)) + 3) // 4, oplist[0][0].device)
+        _lib.check(lib.mmbert_skinny_mm_ordered(_stream(), n, ctypes.cast(arr, ctypes.c_void_p), ws.data_ptr()), "mmbert_skinny_mm_ordered")
+        return
+    _lib.check(lib.mmbert_skinny_mm(_stream(), n, ctypes.cast(arr, ctypes.c_void_p)), "mmbert_skinny_mm")
 
 
 def skinny_wgrad(oplist):

@@ -1228,3 +1228,54 @@ def test_attention_with_more_than_65535_tiles(ops):
         ref.backward(dctx[i * S:(i + 1) * S].float())
         assert_close(ctx[i * S:(i + 1) * S], ref, 2e-2, 2e-2, f"ctx seq{i}")
         assert_close(dqkv[i * S:(i + 1) * S], x.grad, 3e-2, 3e-2, f"dqkv seq{i}")
+
+
+def test_deterministic_forms_equal_the_atomic_forms(ops):
+    """Round 5 (mmbert_set_deterministic): the ordered forms compute the same sums as the atomic ones -- the heads' skinny products through
+    their slab + fold (mmbert_skinny_mm_ordered), the CE loss sums through the ordered one-workgroup sum, the embedding scatter and the
+    data-parallel row block through sorted keys + mmbert_segment_sum_rows -- and give the same bits twice in a row."""
+    was = ops.deterministic()
+    try:
+        H, B = 768, 48
+        X, W, W2, bias = rnd(B, H, seed=501).to(DEV), rnd(2304, H, seed=502, scale=0.05).to(DEV), rnd(H, 512, seed=503, scale=0.05).to(DEV), rnd(2304, seed=504).to(DEV)
+        Y0 = rnd(B, 2304, seed=505).to(DEV)
+
+        def skinny():
+            Y, Z = Y0.clone(), torch.zeros(B, 512, device=DEV)
+            ops.skinny_mm([(Y, bias, 0, True, [(X, W, False, 0)]), (Z, None, 0, False, [(X[:16], W2, True, 8), (X[16:40], W2, True, 0)])])
+            return Y, Z
+        V, M = 1000, 1500
+        logits = bf(rnd(M, 1024, seed=506)).to(DEV)
+        labels = torch.full((M,), -100, dtype=torch.long)
+        labels[::7] = torch.arange(0, M, 7) % V
+        bounds = torch.tensor([0, 400, 900, M], dtype=torch.int32, device=DEV)
+
+        def ce():
+            return ops.ce_fwd(logits, V, labels.to(DEV), bounds, 3)[0].clone()
+        n, T = 600, 50
+        g = torch.Generator().manual_seed(7)
+        ids = torch.randint(0, 300, (n,), generator=g).to(DEV)
+        tts = (torch.arange(n) % 3 == 0).long().to(DEV)
+        d = bf(rnd(n, H, seed=507)).to(DEV)
+
+        def scatter():
+            gw, gt, gp = torch.zeros(300, H, device=DEV), torch.zeros(2, H, device=DEV), torch.zeros(512, H, device=DEV)
+            ops.embed_scatter(ids, tts, d, T, gw, gt, gp)
+            return gw, gt, gp
+        union = torch.unique(ids[::2][ids[::2] > 0])
+        rows32 = rnd(n, H, seed=508).to(DEV)
+
+        def block():
+            blk = torch.zeros(union.numel(), H, device=DEV)
+            return ops.rows_to_block(ids, rows32, union, 300, blk)
+        ops.set_deterministic(False)
+        ref = [*skinny(), ce(), *scatter(), block()]
+        ops.set_deterministic(True)
+        got, again = [*skinny(), ce(), *scatter(), block()], [*skinny(), ce(), *scatter(), block()]
+        names = ["skinny Y", "skinny Z", "ce loss sums", "word rows", "type rows", "position rows", "row block"]  # (ids 0 = padding: skipped by both forms)
+        for nm, r, a, b in zip(names, ref, got, again):
+            assert torch.equal(a, b), nm
+            assert_close(a, r, 1e-5, 1e-4, nm)
+        assert float(got[0].abs().sum()) > 0 and float(got[3].abs().sum()) > 0 and float(got[6].abs().sum()) > 0
+    finally:
+        ops.set_deterministic(was)

@@ -753,3 +753,76 @@ def test_layer_gradient_slices_are_final_when_their_hook_fires():
             assert torch.equal(snap, flat.grads[lo:hi]), (shortcuts, i, float((snap - flat.grads[lo:hi]).abs().max()))
         assert len(head_snap) == 1 and torch.equal(head_snap[0], flat.grads[wlo:whi]) and float(head_snap[0].abs().sum()) > 0.0
         assert len(m.__dict__.get("_deferred_embed_rows", [])) == 1
+
+
+@pytest.mark.parametrize("size", ["small5", "headline"])
+def test_deterministic_mode_gives_bit_identical_steps(size):
+    """Round 5, model.deterministic = True (the library's mmbert_set_deterministic): ordered sums instead of fp32 atomics -- the CE loss sums,
+    the heads' skinny products, the weight-gradient kernel's bias sums, the LayerNorm partial-sum fold, the embedding scatter through
+    sorted keys + segment sums.  The same seeded TRAIN-mode step (dropout on) of two freshly built models gives BIT-IDENTICAL losses,
+    regression logits, and flat gradient buffers; two optimizer steps later the parameters are bit-identical too.  And two launch paths
+    of the same function (all layers' weight gradients in one call / per layer pair; the exact-zero short cuts on / off) agree within the
+    ORIGINAL same-function bound again -- 2e-3 in L2 (test_model_gpu.same_grads had to go to 5e-3 in round 4 for the atomics' order).
+    small5: five layers (a pair launch and a single-layer launch in the paired form); headline: the benchmarked model at batch 4."""
+    from msa_amd import ops as _ops
+    from msa_amd import trainer as T_
+    if size == "small5":
+        cfg, shape = dict(hidden=256, layers=5, heads=4, intermediate=1024, vocab=4096, dataset="mosei", alpha=1.0, beta=1.0), (4, 24, 200, 130)
+    else:
+        cfg, shape = dict(hidden=768, layers=12, heads=12, intermediate=3072, vocab=30522, dataset="mosei", alpha=1.0, beta=1.0), (4, 50, 500, 500)
+    batch = batch_to(synthetic_batch(*shape, dataset="mosei", vocab=cfg["vocab"], seed=91), DEV)
+
+    def run(flags=None, steps=0):
+        m = build(cfg, dropout=0.1)
+        m.train()
+        m.manual_seed(31)
+        for k, v in (flags or {}).items():
+            if k == "training":
+                m.train(v)
+            else:
+                setattr(m, k, v)
+        out, logits = m(**batch)
+        out[0].mean().backward()
+        torch.cuda.synchronize()
+        res = dict(losses=[out[i].detach().clone() for i in (0, 4, 5, 6)], logits=logits.detach().clone(), grads=m._flat.grads.clone(),
+                   named={n: q.grad.detach().float().clone() for n, q in m.named_parameters() if q.grad is not None})
+        if steps:
+            opt, sched = T_.build_optimizer(m, T_.default_args(train_batch_size=shape[0], learning_rate=1e-3), 10, mode="hf")
+            sched.step()
+            opt.step(); opt.zero_grad()
+            for _ in range(steps - 1):
+                o, _l = m(**batch)
+                o[0].mean().backward()
+                opt.step(); sched.step(); opt.zero_grad()
+            torch.cuda.synchronize()
+            res["params"] = m._flat.params.clone()
+        return res
+    was = _ops.deterministic()
+    try:
+        _ops.set_deterministic(True)
+        a, b = run(steps=2), run(steps=2)
+        for x, y in zip(a["losses"], b["losses"]):
+            assert torch.equal(x, y), (float(x), float(y))
+        assert torch.equal(a["logits"], b["logits"])
+        diff = [n for n in a["named"] if not torch.equal(a["named"][n], b["named"][n])]
+        assert not diff, diff[:8]
+        assert torch.equal(a["grads"], b["grads"]) and torch.equal(a["params"], b["params"])
+        # same function, other launch paths, at the ORIGINAL tolerance: the weight gradients per layer pair instead of in one call (train
+        # mode, the same masks), and -- in EVAL mode, where the packed row order does not select other dropout masks -- the exact-zero
+        # short cuts off
+        ulps = 2.0 ** -7 if size == "small5" else 2.0 ** -6       # (one flipped bf16 rounding of an addend; two at twelve layers)
+
+        def close(o, ref, tag):
+            for i in range(4):
+                assert abs(float(o["losses"][i]) - float(ref["losses"][i])) <= 1e-6 * abs(float(ref["losses"][i])), (tag, i)
+            for n, g in ref["named"].items():
+                if "attention.self.key.bias" in n:
+                    continue
+                d = o["named"][n] - g
+                assert float(d.abs().max()) <= ulps * float(g.abs().max()) + 2e-7, (tag, n, float(d.abs().max()), float(g.abs().max()))
+                assert float(d.norm()) <= 2e-3 * float(g.norm()) + 2e-7 * float(g.numel()) ** 0.5, (tag, n, float(d.norm()), float(g.norm()))
+        close(run(dict(defer_wgrads=False)), a, "paired weight gradients")
+        ev = dict(training=False)
+        close(run(dict(ev, skip_padded_backward=False, sparse_top_layer_backward=False)), run(ev), "short cuts off (eval)")
+    finally:
+        _ops.set_deterministic(was)
