@@ -188,7 +188,8 @@ int mmbert_attn_dropout_mask(mmbert_stream_t stream, uint8_t* out, int S, unsign
  * inv_count[s] = 1/#valid rows.  bwd: dlogits = d(sum_s gscale[s]*loss_sum[s])/d(logits) (may alias logits). */
 int mmbert_ce_fwd(mmbert_stream_t stream, const void* logits, int ldv, int V, const int64_t* labels, int M,
                   const int* seg_bounds, int nseg, float* inv_count, float* loss_sum, float* row_lse,
-                  int logits_f32 /* logits are fp32 (rounded to bf16 as loaded: same losses as the bf16 form) */);
+                  int logits_f32 /* logits are fp32 (rounded to bf16 as loaded: same losses as the bf16 form) */,
+                  float* row_loss /* M floats, may be NULL; required in deterministic mode: the rows' loss terms, summed in a fixed order */);
 int mmbert_ce_bwd(mmbert_stream_t stream, const void* logits, int ldv, int V, const int64_t* labels, int M,
                   const int* seg_bounds, int nseg, const float* inv_count, const float* gscale, const float* row_lse, void* dlogits, int ldd,
                   const int* rows /* NULL: all M rows; else a row list: dlogits row j = gradient of row rows[j] */, int nrows,

@@ -48,7 +48,7 @@ SIGNATURES = {
     "mmbert_attn_bwd": (I, [P, P, P, P, P, P, P, P, P, I, I, P, P, P, P, P, I, P, P, I, U32, U32, F, P, P, P, I, P]),
     "mmbert_attn_q_limit": (I, [P, P, I, P, I, P]),
     "mmbert_attn_dropout_mask": (I, [P, P, I, C.c_uint, I, U32, U32]),
-    "mmbert_ce_fwd": (I, [P, P, I, I, P, I, P, I, P, P, P, I]),
+    "mmbert_ce_fwd": (I, [P, P, I, I, P, I, P, I, P, P, P, I, P]),
     "mmbert_ce_bwd": (I, [P, P, I, I, P, I, P, I, P, P, P, P, I, P, I, I]),
     "mmbert_active_rows": (I, [P, P, I, I, P, P]),
     "mmbert_prologue": (I, [P, I, P, P, P, P, P, P, P, I, P, I, P, I, P, P, P, P, P, P, P, P]),

@@ -794,7 +794,7 @@ static int dispatch_nt(hipStream_t s, const GemmNT& p) {
 // Workgroup = 512 threads, output tile 256(n) x 256(k), one workgroup per CU: a CU issues a 16-byte-per-lane LDS-DMA every ~30-37 clk at
 // best, and a 256 x 128 tile (rounds 1-2) needed 48 of them per 1024 MFMA clocks -- load-issue bound at 58 % of the MFMA rate.
 // -------------------------------------------------------------------------------------------------
-struct TNProb { const bf16_t* A; const bf16_t* B; float* W; float* bias; int N, K, lda, ldb, tiles_k, tile0; long long slab_off; };
+struct TNProb { const bf16_t* A; const bf16_t* B; float* W; float* bias; int N, K, lda, ldb, tiles_k, tile0; long long slab_off; long long bias_off; };
 // up to TN_MAXP problems per launch: the four dense layers of an encoder layer -- or of TWO layers (model._EncoderFn pairs them: 216
 // tiles fill the chip in one round without splitting the token axis, so no fp32 slabs and no reduce launch) -- or, round 4, of up to
 // TWELVE layers at once: without a gradient hook (one GPU) nothing needs a layer's weight gradients before the optimizer, so the model
@@ -804,6 +804,7 @@ struct TNProb { const bf16_t* A; const bf16_t* B; float* W; float* bias; int N, 
 struct GemmTNG {
     TNProb pr[TN_MAXP];
     float* slab; const float* alpha_dev;
+    float* bias_slab; long long bias_stride;   // deterministic mode with a token split: the splits >= 1 STORE their bias sums here (tn_reduce folds them in split order)
     long long slab_stride;
     int nprob, total_tiles, M, splits, rows_per_split, accumulate;
     float alpha;
@@ -857,7 +858,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn8_kernel(const GemmTNG g) {
     const __attribute__((address_space(4))) TNProb& pr = gq.pr[pi];
     const bf16_t* Ap = pr.A; const bf16_t* Bp = pr.B; float* Wp = pr.W; float* biasp = pr.bias;
     const int N = pr.N, K = pr.K, lda = pr.lda, ldb = pr.ldb, tiles_k = pr.tiles_k;
-    const long long slab_off = pr.slab_off;
+    const long long slab_off = pr.slab_off, bias_off = pr.bias_off;
     t_lin -= pr.tile0;
     const int n0 = (t_lin / tiles_k) << 8, k0 = (t_lin % tiles_k) << 8;
     const int split = blockIdx.y;
@@ -1079,7 +1080,12 @@ __global__ __launch_bounds__(512, 2) void gemm_tn8_kernel(const GemmTNG g) {
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
                     const int n = n0 + hb * 128 + wc * 32 + j * 16 + fr;
-                    if (n < N) atomicAdd(biasp + n, (v[hb][j] + red[((wc * 2 + hb) * 2 + j) * 16 + fr]) * alpha);
+                    if (n >= N) continue;
+                    const float bv = (v[hb][j] + red[((wc * 2 + hb) * 2 + j) * 16 + fr]) * alpha;
+                    // one adder per column: split 0 (the only split of an unsplit launch).  The other splits add in arrival order -- or, in
+                    // deterministic mode, store their sums for tn_reduce_kernel to fold in split order
+                    if (split > 0 && gq.bias_slab) gq.bias_slab[(size_t)(split - 1) * gq.bias_stride + bias_off + n] = bv;
+                    else atomicAdd(biasp + n, bv);
                 }
         }
     }
@@ -1097,8 +1103,20 @@ __global__ __launch_bounds__(512, 2) void gemm_tn8_kernel(const GemmTNG g) {
 }
 
 // W[i] += sum_{s >= 1} slab[s - 1][i] over the concatenated outputs of all problems of a launch (split 0 went to W directly)
-struct TNReduce { float* W[TN_MAXP]; long long off[TN_MAXP + 1]; int nprob, splits, accumulate; long long slab_stride; };
+struct TNReduce { float* W[TN_MAXP]; long long off[TN_MAXP + 1]; int nprob, splits, accumulate; long long slab_stride;
+                  float* bias[TN_MAXP]; long long boff[TN_MAXP + 1]; const float* bias_slab; long long bias_stride; };
 __global__ void tn_reduce_kernel(const TNReduce r, const float* __restrict__ slab) {
+    if (r.bias_slab) {                                      // deterministic mode: bias[n] += the bias sums of splits 1, 2, ... in that order
+        const long long nb = r.boff[r.nprob];
+        for (long long e = blockIdx.x * (long long)blockDim.x + threadIdx.x; e < nb; e += (long long)gridDim.x * blockDim.x) {
+            int lo = 0, hi = r.nprob - 1;
+            while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (r.boff[mid] <= e) lo = mid; else hi = mid - 1; }
+            if (!r.bias[lo]) continue;
+            float v = r.bias[lo][e - r.boff[lo]];
+            for (int s = 0; s + 1 < r.splits; ++s) v += r.bias_slab[(size_t)s * r.bias_stride + e];
+            r.bias[lo][e - r.boff[lo]] = v;
+        }
+    }
     const long long total4 = r.off[r.nprob] >> 2;
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total4; i += (long long)gridDim.x * blockDim.x) {
         const long long e = i << 2;
@@ -1290,9 +1308,6 @@ static int tn_plan(int nprob, const int* N, const int* K, int M, int* splits_out
     // more than 8 problems = the deferred multi-layer call (model._auto_defer_wgrads): whole rounds of CUs-many tiles, never split.  Up to
     // 8 problems keep the cost model's answer (the dense tied-decoder gradient, 360 tiles at M ~ 18 k: 2 splits)
     if (tiles >= slots && nprob > 8) splits = 1;
-    // deterministic mode: every split of a bias tile adds its column sums with one atomic per column -- with ONE split that is a single
-    // adder per address (ordered); the weight gradients themselves go through slabs + an ordered reduce either way
-    if (mmb_deterministic()) splits = 1;
     if (g_tn_splits.load() > 0) splits = g_tn_splits.load();       // the forced count wins (tests, A/B runs)
     if (splits > max_splits) splits = max_splits;
     if (splits < 1) splits = 1;
@@ -1306,9 +1321,10 @@ size_t mmbert_gemm_tn_grouped_workspace(int nprob, const int* N, const int* K, i
     tn_plan(nprob, N, K, M, &splits, &tiles);
     if (splits_out) *splits_out = splits;
     if (splits == 1) return 0;
-    size_t elems = 0;
-    for (int i = 0; i < nprob; ++i) elems += (size_t)N[i] * K[i];
-    return (size_t)(splits - 1) * elems * sizeof(float);
+    size_t elems = 0, cols = 0;
+    for (int i = 0; i < nprob; ++i) { elems += (size_t)N[i] * K[i]; cols += (size_t)N[i]; }
+    // (+ one row of bias sums per problem and extra split: deterministic mode stores them instead of adding them with atomics)
+    return (size_t)(splits - 1) * (elems + cols) * sizeof(float);
 }
 
 size_t mmbert_gemm_tn_workspace(int M, int N, int K, int* splits_out) {
@@ -1324,7 +1340,7 @@ int mmbert_gemm_tn_grouped(hipStream_t stream, int nprob, const void* const* A, 
     GemmTNG g;
     int splits, tiles;
     tn_plan(nprob, N, K, M, &splits, &tiles);
-    long long off = 0;
+    long long off = 0, boff = 0;
     int tile0 = 0;
     TNReduce r;
     for (int i = 0; i < nprob; ++i) {
@@ -1332,15 +1348,21 @@ int mmbert_gemm_tn_grouped(hipStream_t stream, int nprob, const void* const* A, 
         TNProb& q = g.pr[i];
         q.A = (const bf16_t*)A[i]; q.B = (const bf16_t*)B[i]; q.W = W[i]; q.bias = bias ? bias[i] : nullptr;
         q.N = N[i]; q.K = K[i]; q.lda = lda[i]; q.ldb = ldb[i];
-        q.tiles_k = (K[i] + 255) / 256; q.tile0 = tile0; q.slab_off = off;
-        r.W[i] = W[i]; r.off[i] = off;
+        q.tiles_k = (K[i] + 255) / 256; q.tile0 = tile0; q.slab_off = off; q.bias_off = boff;
+        r.W[i] = W[i]; r.off[i] = off; r.bias[i] = q.bias; r.boff[i] = boff;
+        boff += N[i];
         tile0 += ((N[i] + 255) / 256) * q.tiles_k;
         off += (long long)N[i] * K[i];
     }
-    for (int i = nprob; i < TN_MAXP; ++i) { g.pr[i] = g.pr[0]; g.pr[i].tile0 = 0x7fffffff; r.W[i] = nullptr; }
-    for (int i = nprob; i <= TN_MAXP; ++i) r.off[i] = off;
+    for (int i = nprob; i < TN_MAXP; ++i) { g.pr[i] = g.pr[0]; g.pr[i].tile0 = 0x7fffffff; r.W[i] = nullptr; r.bias[i] = nullptr; }
+    for (int i = nprob; i <= TN_MAXP; ++i) { r.off[i] = off; r.boff[i] = boff; }
     if (splits > 1 && !slab) return -3;
-    g.slab = (float*)slab; g.alpha_dev = alpha_dev; g.slab_stride = off; g.nprob = nprob; g.total_tiles = tiles; g.M = M;
+    g.slab = (float*)slab; g.alpha_dev = alpha_dev; g.slab_stride = off;
+    // deterministic mode, token axis split: the bias sums of splits >= 1 go through the tail of the slab
+    const bool det_bias = splits > 1 && mmb_deterministic();
+    g.bias_slab = det_bias ? (float*)slab + (size_t)(splits - 1) * off : nullptr;
+    g.bias_stride = boff;
+    r.bias_slab = g.bias_slab; r.bias_stride = boff; g.nprob = nprob; g.total_tiles = tiles; g.M = M;
     g.splits = splits; g.rows_per_split = (((M + splits - 1) / splits) + 31) / 32 * 32; g.accumulate = accumulate; g.alpha = alpha;
     static std::atomic<unsigned long long> attr_done8{0};
     if (int e = mmb_allow_lds((const void*)gemm_tn8_kernel, 131072, attr_done8)) return e;

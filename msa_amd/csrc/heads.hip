@@ -425,7 +425,13 @@ __global__ __launch_bounds__(256) void skinny_mm_fold_kernel(const SkArgs a) {
     const int row = (int)(r / op.N), n = (int)(r - (long long)row * op.N);
     float t = op.bias ? op.bias[n] : 0.f;
     const float* w = a.ws + a.ws_off[oi] + (size_t)row * op.N + n;
-    for (int c = 0; c < op.pad_; ++c) t += w[(size_t)c * op.M * op.N];
+    const size_t pitch = (size_t)op.M * op.N;
+    int c = 0;
+    for (; c + 4 <= op.pad_; c += 4) {                               // four chunks' loads together, added in ascending order
+        const float w0 = w[(size_t)c * pitch], w1 = w[(size_t)(c + 1) * pitch], w2 = w[(size_t)(c + 2) * pitch], w3 = w[(size_t)(c + 3) * pitch];
+        t += w0; t += w1; t += w2; t += w3;
+    }
+    for (; c < op.pad_; ++c) t += w[(size_t)c * pitch];
     op.Y[(size_t)row * op.ldy + n] += t;
 }
 

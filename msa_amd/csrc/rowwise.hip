@@ -1076,35 +1076,25 @@ __global__ void ce_count_kernel(const int64_t* __restrict__ labels, int M, int V
     }
 }
 
-// Deterministic mode: loss_sum[seg] = sum over the labelled rows of (row_lse - logit[label]) * inv_count[seg] in a FIXED order (thread t
-// takes rows t, t + 1024, ... ascending; then a fixed-shape tree over the 1024 partial sums) instead of one atomic per row in arrival order.
-template <bool F32>
-__global__ __launch_bounds__(1024) void ce_loss_sum_ordered_kernel(const void* __restrict__ logits_, int ldv, int V, const int64_t* __restrict__ labels, int M,
-                                                                   const int* __restrict__ seg_bounds, int nseg, const float* __restrict__ inv_count,
-                                                                   const float* __restrict__ row_lse, float* __restrict__ loss_sum) {
+// Deterministic mode: loss_sum[seg] = the sum of the rows' loss terms (ce_row_kernel left them in row_loss, 0 for unlabelled rows) in a FIXED
+// order -- thread t takes rows t, t + 1024, ... ascending, then a fixed-shape tree over the 1024 partial sums -- instead of one atomic per
+// row in arrival order.
+__global__ __launch_bounds__(1024) void ce_loss_sum_ordered_kernel(const float* __restrict__ row_loss, int M, const int* __restrict__ seg_bounds, int nseg,
+                                                                   float* __restrict__ loss_sum) {
     __shared__ float red[4][1024];
     const int b1 = nseg > 1 ? seg_bounds[1] : 0x7fffffff, b2 = nseg > 2 ? seg_bounds[2] : 0x7fffffff, b3 = nseg > 3 ? seg_bounds[3] : 0x7fffffff;
     float c[4] = {0.f, 0.f, 0.f, 0.f};
-    for (int i0 = threadIdx.x; i0 < M; i0 += 1024 * 8) {            // eight rows per thread and trip: their label loads go out together
-        int64_t lab[8];
+    for (int i0 = threadIdx.x; i0 < M; i0 += 1024 * 8) {            // eight rows per thread and trip: their loads go out together
+        float v[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) lab[u] = labels[min(i0 + u * 1024, M - 1)];
-        float lg[8], ls[8];
+        for (int u = 0; u < 8; ++u) v[u] = row_loss[min(i0 + u * 1024, M - 1)];
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
-            const int i = min(i0 + u * 1024, M - 1);
-            const int64_t l = (lab[u] >= 0 && lab[u] < V) ? lab[u] : 0;     // (clamped: always a valid address; unlabelled rows are masked below)
-            lg[u] = F32 ? bf2f(f2bf(((const float*)logits_)[(size_t)i * ldv + l])) : bf2f(((const bf16_t*)logits_)[(size_t)i * ldv + l]);
-            ls[u] = row_lse[i];
-        }
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {                                // ascending rows: the order of a thread's sum is fixed
             const int i = i0 + u * 1024;
-            const bool ok = i < M && lab[u] >= 0 && lab[u] < V;
             const int sg = (i >= b1 ? 1 : 0) + (i >= b2 ? 1 : 0) + (i >= b3 ? 1 : 0);
-            const float v = ok ? (ls[u] - lg[u]) * inv_count[sg] : 0.f;
+            const float x = i < M ? v[u] : 0.f;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) c[q] += (sg == q) ? v : 0.f;
+            for (int q = 0; q < 4; ++q) c[q] += (sg == q) ? x : 0.f;
         }
     }
 #pragma unroll
@@ -1219,7 +1209,7 @@ template <int MODE, bool F32>
 __global__ __launch_bounds__(256) void ce_row_kernel(const void* __restrict__ logits_, int ldv, int V, const int64_t* __restrict__ labels,
                                                      const int* __restrict__ seg_bounds, int nseg, const float* __restrict__ inv_count,
                                                      float* __restrict__ loss_sum, float* __restrict__ row_lse, const float* __restrict__ gscale,
-                                                     bf16_t* __restrict__ dlogits, int ldd, const int* __restrict__ rows) {
+                                                     bf16_t* __restrict__ dlogits, int ldd, const int* __restrict__ rows, float* __restrict__ row_loss) {
     __shared__ float red[4];
     __shared__ float lab_logit;
     const int i = rows ? rows[blockIdx.x] : blockIdx.x;        // backward over a compact row list: output row = blockIdx.x
@@ -1227,7 +1217,7 @@ __global__ __launch_bounds__(256) void ce_row_kernel(const void* __restrict__ lo
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int nchunk = ldv >> 3;
     if (lab < 0 || lab >= V) {
-        if (MODE == 0) { if (tid == 0) row_lse[i] = 0.f; }
+        if (MODE == 0) { if (tid == 0) { row_lse[i] = 0.f; if (row_loss) row_loss[i] = 0.f; } }
         else {
             bf16_t* drow = dlogits + (size_t)(rows ? blockIdx.x : i) * ldd;
             const bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -1287,7 +1277,8 @@ __global__ __launch_bounds__(256) void ce_row_kernel(const void* __restrict__ lo
         if (tid == 0) {
             const float lse = mx + __logf(red[0] + red[1] + red[2] + red[3]);
             row_lse[i] = lse;
-            if (loss_sum) atomicAdd(loss_sum + s, (lse - lab_logit) * inv_count[s]);      // (null: deterministic mode, ce_loss_sum_ordered_kernel)
+            if (row_loss) row_loss[i] = (lse - lab_logit) * inv_count[s];                 // deterministic mode: summed in order by ce_loss_sum_ordered_kernel
+            else atomicAdd(loss_sum + s, (lse - lab_logit) * inv_count[s]);
         }
     } else {
         const float lse = row_lse[i];
@@ -1915,23 +1906,23 @@ int mmbert_pair_proj_bwd(hipStream_t stream, const float* feat, int B, int P, in
 }
 
 int mmbert_ce_fwd(hipStream_t stream, const void* logits, int ldv, int V, const int64_t* labels, int M,
-                  const int* seg_bounds, int nseg, float* inv_count, float* loss_sum, float* row_lse, int logits_f32) {
+                  const int* seg_bounds, int nseg, float* inv_count, float* loss_sum, float* row_lse, int logits_f32, float* row_loss) {
     if (M <= 0) return 0;
     if (nseg < 1 || nseg > 4 || (ldv & 7) || ldv > CE_MAXC * 256 * 8 || V > ldv) return -1;
+    const bool det = mmb_deterministic();
+    if (det && !row_loss) return -4;                              // deterministic mode needs the per-row loss buffer (M floats)
+    if (!det) row_loss = nullptr;
     hipLaunchKernelGGL(ce_count_kernel, dim3(1), dim3(1024), 0, stream, labels, M, V, seg_bounds, nseg, inv_count, loss_sum);
     MMB_CHECK_LAUNCH();
-    const bool det = mmb_deterministic();
-    float* ls = det ? nullptr : loss_sum;
     if (logits_f32)
-        hipLaunchKernelGGL((ce_row_kernel<0, true>), dim3(M), dim3(256), 0, stream, logits, ldv, V, labels, seg_bounds, nseg, inv_count, ls,
-                           row_lse, (const float*)nullptr, (bf16_t*)nullptr, 0, (const int*)nullptr);
+        hipLaunchKernelGGL((ce_row_kernel<0, true>), dim3(M), dim3(256), 0, stream, logits, ldv, V, labels, seg_bounds, nseg, inv_count, loss_sum,
+                           row_lse, (const float*)nullptr, (bf16_t*)nullptr, 0, (const int*)nullptr, row_loss);
     else
-        hipLaunchKernelGGL((ce_row_kernel<0, false>), dim3(M), dim3(256), 0, stream, logits, ldv, V, labels, seg_bounds, nseg, inv_count, ls,
-                           row_lse, (const float*)nullptr, (bf16_t*)nullptr, 0, (const int*)nullptr);
+        hipLaunchKernelGGL((ce_row_kernel<0, false>), dim3(M), dim3(256), 0, stream, logits, ldv, V, labels, seg_bounds, nseg, inv_count, loss_sum,
+                           row_lse, (const float*)nullptr, (bf16_t*)nullptr, 0, (const int*)nullptr, row_loss);
     MMB_CHECK_LAUNCH();
     if (det) {
-        if (logits_f32) hipLaunchKernelGGL((ce_loss_sum_ordered_kernel<true>), dim3(1), dim3(1024), 0, stream, logits, ldv, V, labels, M, seg_bounds, nseg, inv_count, row_lse, loss_sum);
-        else hipLaunchKernelGGL((ce_loss_sum_ordered_kernel<false>), dim3(1), dim3(1024), 0, stream, logits, ldv, V, labels, M, seg_bounds, nseg, inv_count, row_lse, loss_sum);
+        hipLaunchKernelGGL(ce_loss_sum_ordered_kernel, dim3(1), dim3(1024), 0, stream, (const float*)row_loss, M, seg_bounds, nseg, loss_sum);
         MMB_CHECK_LAUNCH();
     }
     return 0;
@@ -1959,10 +1950,10 @@ int mmbert_ce_bwd(hipStream_t stream, const void* logits, int ldv, int V, const 
     if (nseg < 1 || nseg > 4 || (ldv & 7) || (ldd & 7) || ldv > CE_MAXC * 256 * 8 || V > ldv) return -1;
     if (logits_f32)
         hipLaunchKernelGGL((ce_row_kernel<1, true>), dim3(rows ? nrows : M), dim3(256), 0, stream, logits, ldv, V, labels, seg_bounds, nseg, inv_count,
-                           (float*)nullptr, (float*)row_lse, gscale, (bf16_t*)dlogits, ldd, rows);
+                           (float*)nullptr, (float*)row_lse, gscale, (bf16_t*)dlogits, ldd, rows, (float*)nullptr);
     else
         hipLaunchKernelGGL((ce_row_kernel<1, false>), dim3(rows ? nrows : M), dim3(256), 0, stream, logits, ldv, V, labels, seg_bounds, nseg, inv_count,
-                           (float*)nullptr, (float*)row_lse, gscale, (bf16_t*)dlogits, ldd, rows);
+                           (float*)nullptr, (float*)row_lse, gscale, (bf16_t*)dlogits, ldd, rows, (float*)nullptr);
     MMB_CHECK_LAUNCH();
     return 0;
 }

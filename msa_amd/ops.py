@@ -797,8 +797,10 @@ def ce_fwd(logits, V, labels, seg_bounds, nseg):
     loss = torch.empty(nseg, device=logits.device, dtype=torch.float32)   # exactly nseg (<= 4) entries are written: returned as it is, not as a view
     lse = torch.empty(M, device=logits.device, dtype=torch.float32)
     assert logits.dtype in (torch.bfloat16, torch.float32)
+    row_loss = _ws_f32(M, logits.device) if deterministic() else None      # (deterministic mode: the rows' loss terms, summed in a fixed order)
     _lib.check(lib.mmbert_ce_fwd(_stream(), logits.data_ptr(), logits.stride(0), V, labels.data_ptr(), M, seg_bounds.data_ptr(), nseg,
-                                 inv.data_ptr(), loss.data_ptr(), lse.data_ptr(), 1 if logits.dtype == torch.float32 else 0), "mmbert_ce_fwd")
+                                 inv.data_ptr(), loss.data_ptr(), lse.data_ptr(), 1 if logits.dtype == torch.float32 else 0, _ptr(row_loss)),
+               "mmbert_ce_fwd")
     return loss, inv, lse
 
 

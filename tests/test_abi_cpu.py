@@ -40,7 +40,8 @@ def test_host_side_helpers_run_without_gpu():
     assert a != b and a == lib.mmbert_rng_stream(1, 2)
     splits = ctypes.c_int(0)
     need = lib.mmbert_gemm_tn_workspace(18400, 768, 768, ctypes.byref(splits))
-    assert splits.value > 1 and need == (splits.value - 1) * 768 * 768 * 4       # split 0 writes the gradient itself, the others slabs
+    # split 0 writes the gradient itself, the others slabs (+ one row of bias sums each: deterministic mode stores them there)
+    assert splits.value > 1 and need == (splits.value - 1) * (768 * 768 + 768) * 4
     assert lib.mmbert_gemm_tn_workspace(100, 4096, 4096, ctypes.byref(splits)) == 0 and splits.value == 1
 
 
