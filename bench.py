@@ -81,6 +81,7 @@ def main():
     ap.add_argument("--no-early-word", action="store_true", help="A/B: the word-embedding table's gradient reduced with the tail (round-2 form)")
     ap.add_argument("--sync-prologue", action="store_true", help="A/B: the step prologue on the compute stream (model.async_prologue = False)")
     ap.add_argument("--scores-fp32", action="store_true", help="return the prediction scores as fp32 (model.scores_dtype = torch.float32)")
+    ap.add_argument("--no-dp-reference-legs", action="store_true", help="skip the N > 1 readiness legs (paired weight gradients on the plain step; bf16 wire under the wrapper)")
     ap.add_argument("--no-deterministic", action="store_true", help="skip the secondary measurement in deterministic mode")
     ap.add_argument("--deterministic", action="store_true", help="run the HEADLINE in deterministic mode (model.deterministic = True)")
     ap.add_argument("--no-scores-fp32", action="store_true", help="skip the secondary measurement with fp32 prediction scores (the reference's dtype)")
@@ -311,6 +312,30 @@ def main():
         det_leg = leg_record(dl, note="model.deterministic = True (mmbert_set_deterministic): every fp32 sum in a schedule-independent order; "
                                       "bit-identical losses and gradients run to run")
 
+    # Secondary (N > 1 readiness): the weight gradients per layer PAIR instead of all layers in one call -- the form the data-parallel
+    # wrapper has to use (its hook needs a layer's gradient slice when the layer is done), measured on the plain step so that a SCALE
+    # point can be read against a world-1 number of the same code path.
+    paired = None
+    if not a.no_dp_reference_legs and dp is None:
+        was_defer = getattr(model, "defer_wgrads", None)
+        model.defer_wgrads = False
+        pel = timed_leg(step)
+        model.defer_wgrads = was_defer
+        paired = leg_record(pel, note="model.defer_wgrads = False: one weight-gradient launch per encoder-layer pair (what DataParallel's per-layer hooks need)")
+    # Secondary under the data-parallel wrapper: bf16 on the links (all-to-all + fp32 sum in rank order + all-gather instead of the fp32
+    # all-reduce: DataParallel(wire_dtype=torch.bfloat16)); at world size 1 the wire path is forced so that its kernels run
+    wire_leg = None
+    if not a.no_dp_reference_legs and dp is not None and a.dp_wire == "fp32":
+        bk = dp.bucketer
+        saved_wire = (bk.wire_dtype, bk.force_wire_path)
+        bk.wire_dtype, bk.force_wire_path = torch.bfloat16, world == 1
+        try:
+            wel = timed_leg(step)
+        finally:
+            bk.wire_dtype, bk.force_wire_path = saved_wire
+        wire_leg = leg_record(wel, note="DataParallel wire dtype bf16 (all-to-all + fp32 accumulation in rank order + all-gather); "
+                                        + ("forced through both stages at world size 1" if world == 1 else f"world size {world}"))
+
     # Secondary: the train step as trainer.py consumes it -- model.return_scores = False: the six prediction-score tensors that
     # the reference's forward returns and its trainer never reads are not produced, so the MLM head runs on the labelled rows
     # only (forward too) and the encoder leaves out the rows that only those scores would read.  Same losses and gradients
@@ -399,6 +424,10 @@ def main():
         res["scores_fp32"] = scores_fp32
     if det_leg is not None:
         res["deterministic"] = det_leg
+    if paired is not None:
+        res["paired_wgrads"] = paired
+    if wire_leg is not None:
+        res["dp_wire_bf16"] = wire_leg
     res["config"]["deterministic"] = bool(a.deterministic)
     if train_only is not None:
         res["train_only"] = train_only
@@ -427,10 +456,10 @@ def main():
                     kern[k] = (fl, ms, len(lst))
             fl, ms, n = kern["nt"]
             ach = fl / (ms * 1e-3) / 1e12
-            traffic, traffic_src = pmc_traffic_per_launch(("gemm_ntp_kernel", "gemm_nt8_kernel"))
-            res["roofline"] = {"bound": "mfma", "kernel": "the NT GEMM family behind mmbert_gemm_nt (bf16 MFMA 16x16x32, all fused epilogues): gemm_nt8_kernel (64-deep K tiles, "
-                                                          "8 phases, LDS-DMA half-tiles 3 ahead: one 192/224/256x256 tile per workgroup for single-round launches, a stream of 224x256 "
-                                                          "tiles for multi-round ones) + gemm_ntp_kernel (224/256x256 tile stream through a 4-slot LDS-DMA ring: data-parallel runs)",
+            traffic, traffic_src = pmc_traffic_per_launch("gemm_nt8_kernel")
+            res["roofline"] = {"bound": "mfma", "kernel": "the NT GEMM family behind mmbert_gemm_nt: gemm_nt8_kernel (bf16 MFMA 16x16x32, every fused epilogue; 64-deep K tiles in "
+                                                          "8 phases, LDS-DMA half-tiles 3 ahead: one 192/224/256x256 tile per workgroup for single-round launches, a stream of "
+                                                          "224x256 tiles per workgroup for multi-round ones)",
                                "achieved": round(ach, 1), "peak": 2500.0, "unit": "TFLOP/s", "frac": round(ach / 2500.0, 4),
                                "traffic": traffic, "traffic_source": traffic_src, "launches": n, "avg_launch_us": round(1e3 * ms / n, 2),
                                "share_of_step_time": round(ms * 1e-3 / elapsed_instr, 3),
@@ -559,7 +588,16 @@ def rccl_summary(path, limit=24):
             if seen[kind.group(1)] > 2:
                 continue
         brief.append(body)
-    out = {"log": path, "lines": len(lines), "channels": len({m.group(1) for l in lines for m in [re.search(r"Channel (\d+)/\d+", l)] if m}),
+    nch = len({m.group(1) for l in lines for m in [re.search(r"Channel (\d+)/\d+", l)] if m})
+    nranks = max([int(m.group(1)) for l in lines for m in [re.search(r"nranks (\d+)", l)] if m] or [1])
+    # xGMI is point-to-point (7 links x ~153 GB/s per GPU): a ring all-reduce over ONE channel moves a 32-MiB bucket over one link per hop
+    # (~5 ms for the step's 465 MB); RCCL spreads a collective over its channels, each routed over another link, so the
+    # fp32 buckets need >= 7 channels (or a non-ring algorithm) at 8 ranks to use the fabric.  Recorded, and loud on stderr -- not fatal:
+    # the bench line must still be printed.
+    multi_link = None if nranks <= 2 else bool(nch >= min(7, nranks - 1))
+    if multi_link is False:
+        print(f"[bench] WARNING: RCCL built {nch} channel(s) for {nranks} ranks: the gradient all-reduce is bound by {nch} xGMI link(s) per hop", file=sys.stderr, flush=True)
+    out = {"log": path, "lines": len(lines), "channels": nch, "nranks": nranks, "all_reduce_uses_all_links": multi_link,
            "p2p_links": sum("via P2P" in l for l in lines), "shm_links": sum("via SHM" in l for l in lines),
            "tree_ring_channel_lines": seen, "choices": tuning[:limit], "init": brief[:limit]}
     print("[bench] RCCL summary:", json.dumps(out)[:4000], file=sys.stderr, flush=True)
