@@ -137,6 +137,8 @@ __device__ __forceinline__ void mmb_keep4(uint32_t stream, uint64_t idx0, uint32
     k[2] = mmb_keep16(h1 & 0xFFFFu, thr16); k[3] = mmb_keep16(h1 >> 16, thr16);
 }
 
+typedef __attribute__((ext_vector_type(2))) float mmb_f2;
+
 // GELU, erf form (HF ACT2FN["gelu"]), with ONE transcendental per element.  The GEMM epilogues that apply it are VALU-bound
 // (112 elements per lane and tile), and v_exp_f32 / v_rcp_f32 issue at quarter rate, so the textbook erf (Abramowitz-Stegun
 // 7.1.26: rcp + exp + 6 FMA, used here until round 1) cost 14 VALU instructions per element.  Instead, with a = |x|:
@@ -146,18 +148,23 @@ __device__ __forceinline__ void mmb_keep4(uint32_t stream, uint64_t idx0, uint32
 // [0, 12]): |gelu error| <= 5.7e-7 absolute, |gelu' error| <= 4.1e-6 absolute -- three to four orders below the bf16 rounding
 // of the values they produce; the negative tail keeps its RELATIVE accuracy (no 1 - erf cancellation).  a is clamped to 12
 // (T, g < 1e-32 there), which also keeps the polynomials finite for any input.
+// (round 5) min(|x|, 12) and max(x, 0) through v_med3_f32: as fminf / fmaxf they each came with a canonicalising `v_max_f32 x, x` in front
+// (the library is built with -fno-finite-math-only, so LLVM keeps IEEE sNaN quieting) -- 3 of the 13 VALU instructions per element of the
+// FFN-up epilogue, which is VALU-issue bound (1 488 VALU + 115 exp per wave and 224 x 256 tile).  Same values for every finite x.
+__device__ __forceinline__ float mmb_clamp_abs12(float x) { return __builtin_amdgcn_fmed3f(fabsf(x), 0.0f, 12.0f); }
+__device__ __forceinline__ float mmb_relu(float x) { return __builtin_amdgcn_fmed3f(x, 0.0f, __builtin_inff()); }
 __device__ __forceinline__ float gelu_erf(float x) {
-    const float a = fminf(fabsf(x), 12.0f);
+    const float a = mmb_clamp_abs12(x);
     float q = 0.000488118665642307f;
     q = fmaf(q, a, -0.007198809871008205f);
     q = fmaf(q, a, 0.05214680078704519f);
     q = fmaf(q, a, 0.4595957249475095f);
     q = fmaf(q, a, 1.1510005681479196f);
     const float t = __builtin_amdgcn_exp2f(fmaf(-a, q, -1.0f));
-    return fmaf(-a, t, fmaxf(x, 0.0f));
+    return fmaf(-a, t, mmb_relu(x));
 }
 __device__ __forceinline__ float gelu_erf_grad(float x) {
-    const float a = fminf(fabsf(x), 12.0f);
+    const float a = mmb_clamp_abs12(x);
     float w = -0.00016849001371319273f;
     w = fmaf(w, a, 0.002318365387269111f);
     w = fmaf(w, a, -0.013920757956130972f);
@@ -168,4 +175,37 @@ __device__ __forceinline__ float gelu_erf_grad(float x) {
     w = fmaf(w, a, 0.49999600551278855f);
     const float g = __builtin_amdgcn_exp2f(-0.72134752044448170f * a * a) * w;
     return x > 0.0f ? 1.0f - g : g;
+}
+
+// Two elements at a time (round 5): the same Horner steps as v_pk_fma_f32 / v_pk_mul_f32 -- one instruction per step and PAIR where the
+// scalar forms spend one per element (hipcc's SLP pass packs the derivative's polynomial on its own, but not the forward's, whose steps
+// carry literal constants -- v_fmaak_f32 -- that the packed encoding cannot hold).  Every operation is the IEEE fma / mul of the scalar
+// form on each half: the results are BIT-identical to gelu_erf / gelu_erf_grad.  In the GEMM epilogues that apply them (224 x 256 tile:
+// 112 elements per lane, VALU-issue bound) the forward form goes from 8 + 1 exp to 5 + 1 exp instructions per element.
+__device__ __forceinline__ mmb_f2 gelu_erf2(mmb_f2 x) {
+    const mmb_f2 a = {mmb_clamp_abs12(x.x), mmb_clamp_abs12(x.y)};
+    mmb_f2 q = (mmb_f2){0.000488118665642307f, 0.000488118665642307f};
+    q = q * a + (mmb_f2){-0.007198809871008205f, -0.007198809871008205f};
+    q = q * a + (mmb_f2){0.05214680078704519f, 0.05214680078704519f};
+    q = q * a + (mmb_f2){0.4595957249475095f, 0.4595957249475095f};
+    q = q * a + (mmb_f2){1.1510005681479196f, 1.1510005681479196f};
+    const mmb_f2 e = -a * q + (mmb_f2){-1.0f, -1.0f};
+    const mmb_f2 t = {__builtin_amdgcn_exp2f(e.x), __builtin_amdgcn_exp2f(e.y)};
+    const mmb_f2 r = {mmb_relu(x.x), mmb_relu(x.y)};
+    return -a * t + r;
+}
+__device__ __forceinline__ mmb_f2 gelu_erf_grad2(mmb_f2 x) {
+    const mmb_f2 a = {mmb_clamp_abs12(x.x), mmb_clamp_abs12(x.y)};
+    mmb_f2 w = (mmb_f2){-0.00016849001371319273f, -0.00016849001371319273f};
+    w = w * a + (mmb_f2){0.002318365387269111f, 0.002318365387269111f};
+    w = w * a + (mmb_f2){-0.013920757956130972f, -0.013920757956130972f};
+    w = w * a + (mmb_f2){0.04993439894451681f, 0.04993439894451681f};
+    w = w * a + (mmb_f2){-0.1258212077485634f, -0.1258212077485634f};
+    w = w * a + (mmb_f2){0.2479567789223165f, 0.2479567789223165f};
+    w = w * a + (mmb_f2){-0.7976617799265314f, -0.7976617799265314f};
+    w = w * a + (mmb_f2){0.49999600551278855f, 0.49999600551278855f};
+    const mmb_f2 e = ((mmb_f2){-0.72134752044448170f, -0.72134752044448170f} * a) * a;
+    const mmb_f2 g = (mmb_f2){__builtin_amdgcn_exp2f(e.x), __builtin_amdgcn_exp2f(e.y)} * w;
+    const mmb_f2 og = (mmb_f2){1.0f, 1.0f} - g;
+    return (mmb_f2){x.x > 0.0f ? og.x : g.x, x.y > 0.0f ? og.y : g.y};
 }

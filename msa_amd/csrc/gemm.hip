@@ -623,11 +623,17 @@ __global__ __launch_bounds__(512, 2) void gemm_nt8_kernel(const GemmNT p) {
                         if (ok) *(bf16x8*)(q.aux + (size_t)m * q.ldaux + n) = u;
                     }
 #pragma unroll
-                    for (int r = 0; r < 8; ++r) vv[r] = gelu_erf(vv[r]);
+                    for (int r = 0; r < 8; r += 2) {                 // packed forms (common.h): bit-identical to gelu_erf, 5 instead of 8 VALU per element
+                        const mmb_f2 gv = gelu_erf2((mmb_f2){vv[r], vv[r + 1]});
+                        vv[r] = gv.x; vv[r + 1] = gv.y;
+                    }
                 }
                 if constexpr (EPI & EPI_GELU_BWD) {
 #pragma unroll
-                    for (int r = 0; r < 8; ++r) vv[r] *= gelu_erf_grad(bf2f(pre[i][h][r]));
+                    for (int r = 0; r < 8; r += 2) {
+                        const mmb_f2 gg = gelu_erf_grad2((mmb_f2){bf2f(pre[i][h][r]), bf2f(pre[i][h][r + 1])});
+                        vv[r] *= gg.x; vv[r + 1] *= gg.y;
+                    }
                 }
                 if constexpr (EPI & EPI_RESID) {
 #pragma unroll
