@@ -152,7 +152,8 @@ typedef __attribute__((ext_vector_type(2))) float mmb_f2;
 // (the library is built with -fno-finite-math-only, so LLVM keeps IEEE sNaN quieting) -- 3 of the 13 VALU instructions per element of the
 // FFN-up epilogue, which is VALU-issue bound (1 488 VALU + 115 exp per wave and 224 x 256 tile).  Same values for every finite x.
 __device__ __forceinline__ float mmb_clamp_abs12(float x) { return __builtin_amdgcn_fmed3f(fabsf(x), 0.0f, 12.0f); }
-__device__ __forceinline__ float mmb_relu(float x) { return __builtin_amdgcn_fmed3f(x, 0.0f, __builtin_inff()); }
+// (max(x, 0) as inline asm: hipcc folds med3(x, 0, inf) back into a max WITH the canonicalising v_max_f32 x, x in front)
+__device__ __forceinline__ float mmb_relu(float x) { float r; asm("v_max_f32 %0, 0, %1" : "=v"(r) : "v"(x)); return r; }
 __device__ __forceinline__ float gelu_erf(float x) {
     const float a = mmb_clamp_abs12(x);
     float q = 0.000488118665642307f;
@@ -208,4 +209,35 @@ __device__ __forceinline__ mmb_f2 gelu_erf_grad2(mmb_f2 x) {
     const mmb_f2 g = (mmb_f2){__builtin_amdgcn_exp2f(e.x), __builtin_amdgcn_exp2f(e.y)} * w;
     const mmb_f2 og = (mmb_f2){1.0f, 1.0f} - g;
     return (mmb_f2){x.x > 0.0f ? og.x : g.x, x.y > 0.0f ? og.y : g.y};
+}
+
+// Two pairs in lockstep: hipcc schedules one pair's chain after the other (register-pressure heuristics) and pads the v_exp_f32 -> use
+// and pk_fma -> v_exp_f32 wait states with s_nop; written side by side, each pair's waits are filled by the other pair's instructions.
+__device__ __forceinline__ void gelu_erf4(mmb_f2& x0, mmb_f2& x1) {
+    const mmb_f2 a0 = {mmb_clamp_abs12(x0.x), mmb_clamp_abs12(x0.y)}, a1 = {mmb_clamp_abs12(x1.x), mmb_clamp_abs12(x1.y)};
+    mmb_f2 q0 = (mmb_f2){0.000488118665642307f, 0.000488118665642307f}, q1 = q0;
+    q0 = q0 * a0 + (mmb_f2){-0.007198809871008205f, -0.007198809871008205f}; q1 = q1 * a1 + (mmb_f2){-0.007198809871008205f, -0.007198809871008205f};
+    q0 = q0 * a0 + (mmb_f2){0.05214680078704519f, 0.05214680078704519f};    q1 = q1 * a1 + (mmb_f2){0.05214680078704519f, 0.05214680078704519f};
+    q0 = q0 * a0 + (mmb_f2){0.4595957249475095f, 0.4595957249475095f};      q1 = q1 * a1 + (mmb_f2){0.4595957249475095f, 0.4595957249475095f};
+    q0 = q0 * a0 + (mmb_f2){1.1510005681479196f, 1.1510005681479196f};      q1 = q1 * a1 + (mmb_f2){1.1510005681479196f, 1.1510005681479196f};
+    const mmb_f2 e0 = -a0 * q0 + (mmb_f2){-1.0f, -1.0f}, e1 = -a1 * q1 + (mmb_f2){-1.0f, -1.0f};
+    const mmb_f2 r0 = {mmb_relu(x0.x), mmb_relu(x0.y)}, r1 = {mmb_relu(x1.x), mmb_relu(x1.y)};
+    const mmb_f2 t0 = {__builtin_amdgcn_exp2f(e0.x), __builtin_amdgcn_exp2f(e0.y)}, t1 = {__builtin_amdgcn_exp2f(e1.x), __builtin_amdgcn_exp2f(e1.y)};
+    x0 = -a0 * t0 + r0;
+    x1 = -a1 * t1 + r1;
+}
+__device__ __forceinline__ void gelu_erf_grad4(mmb_f2 x0, mmb_f2 x1, mmb_f2& d0, mmb_f2& d1) {
+    const mmb_f2 a0 = {mmb_clamp_abs12(x0.x), mmb_clamp_abs12(x0.y)}, a1 = {mmb_clamp_abs12(x1.x), mmb_clamp_abs12(x1.y)};
+    mmb_f2 w0 = (mmb_f2){-0.00016849001371319273f, -0.00016849001371319273f}, w1 = w0;
+#define MMB_W_STEP(C) w0 = w0 * a0 + (mmb_f2){C, C}; w1 = w1 * a1 + (mmb_f2){C, C};
+    MMB_W_STEP(0.002318365387269111f) MMB_W_STEP(-0.013920757956130972f) MMB_W_STEP(0.04993439894451681f) MMB_W_STEP(-0.1258212077485634f)
+    MMB_W_STEP(0.2479567789223165f) MMB_W_STEP(-0.7976617799265314f) MMB_W_STEP(0.49999600551278855f)
+#undef MMB_W_STEP
+    const mmb_f2 k = {-0.72134752044448170f, -0.72134752044448170f};
+    const mmb_f2 e0 = (k * a0) * a0, e1 = (k * a1) * a1;
+    const mmb_f2 t0 = {__builtin_amdgcn_exp2f(e0.x), __builtin_amdgcn_exp2f(e0.y)}, t1 = {__builtin_amdgcn_exp2f(e1.x), __builtin_amdgcn_exp2f(e1.y)};
+    const mmb_f2 g0 = t0 * w0, g1 = t1 * w1;
+    const mmb_f2 o0 = (mmb_f2){1.0f, 1.0f} - g0, o1 = (mmb_f2){1.0f, 1.0f} - g1;
+    d0 = (mmb_f2){x0.x > 0.0f ? o0.x : g0.x, x0.y > 0.0f ? o0.y : g0.y};
+    d1 = (mmb_f2){x1.x > 0.0f ? o1.x : g1.x, x1.y > 0.0f ? o1.y : g1.y};
 }

@@ -623,16 +623,18 @@ __global__ __launch_bounds__(512, 2) void gemm_nt8_kernel(const GemmNT p) {
                         if (ok) *(bf16x8*)(q.aux + (size_t)m * q.ldaux + n) = u;
                     }
 #pragma unroll
-                    for (int r = 0; r < 8; r += 2) {                 // packed forms (common.h): bit-identical to gelu_erf, 5 instead of 8 VALU per element
-                        const mmb_f2 gv = gelu_erf2((mmb_f2){vv[r], vv[r + 1]});
-                        vv[r] = gv.x; vv[r + 1] = gv.y;
+                    for (int r = 0; r < 8; r += 4) {                 // packed forms (common.h): bit-identical to gelu_erf, 5 instead of 8 VALU per element
+                        mmb_f2 g0 = {vv[r], vv[r + 1]}, g1 = {vv[r + 2], vv[r + 3]};
+                        gelu_erf4(g0, g1);
+                        vv[r] = g0.x; vv[r + 1] = g0.y; vv[r + 2] = g1.x; vv[r + 3] = g1.y;
                     }
                 }
                 if constexpr (EPI & EPI_GELU_BWD) {
 #pragma unroll
-                    for (int r = 0; r < 8; r += 2) {
-                        const mmb_f2 gg = gelu_erf_grad2((mmb_f2){bf2f(pre[i][h][r]), bf2f(pre[i][h][r + 1])});
-                        vv[r] *= gg.x; vv[r + 1] *= gg.y;
+                    for (int r = 0; r < 8; r += 4) {
+                        mmb_f2 d0, d1;
+                        gelu_erf_grad4((mmb_f2){bf2f(pre[i][h][r]), bf2f(pre[i][h][r + 1])}, (mmb_f2){bf2f(pre[i][h][r + 2]), bf2f(pre[i][h][r + 3])}, d0, d1);
+                        vv[r] *= d0.x; vv[r + 1] *= d0.y; vv[r + 2] *= d1.x; vv[r + 3] *= d1.y;
                     }
                 }
                 if constexpr (EPI & EPI_RESID) {
