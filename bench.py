@@ -325,7 +325,10 @@ def main():
     # Secondary under the data-parallel wrapper: bf16 on the links (all-to-all + fp32 sum in rank order + all-gather instead of the fp32
     # all-reduce: DataParallel(wire_dtype=torch.bfloat16)); at world size 1 the wire path is forced so that its kernels run
     wire_leg = None
-    if not a.no_dp_reference_legs and dp is not None and a.dp_wire == "fp32":
+    # (only in the forced single-process form by default: at N > 1 the headline's collectives are the ones to be measured, and a leg that
+    # switches the exchange protocol between timed regions is one more thing that could go wrong on the first real multi-GPU run;
+    # --dp-wire bf16 measures that protocol as the headline of its own run)
+    if not a.no_dp_reference_legs and dp is not None and a.dp_wire == "fp32" and world == 1:
         bk = dp.bucketer
         saved_wire = (bk.wire_dtype, bk.force_wire_path)
         bk.wire_dtype, bk.force_wire_path = torch.bfloat16, world == 1

@@ -299,6 +299,45 @@ size_t mmbert_skinny_mm_workspace(int nops, const mmbert_skinny_op* ops);
 int mmbert_skinny_mm_ordered(mmbert_stream_t stream, int nops, const mmbert_skinny_op* ops, void* workspace);
 int mmbert_skinny_wgrad(mmbert_stream_t stream, int nops, const mmbert_skinny_wgrad_op* ops);
 
+/* ---- composite encoder-layer calls (round 5): the launches of a layer's forward / of the dense part of its backward from ONE C call ----
+ * The same kernels through the same entry points, in the same order and with the same arguments as calling them one by one (bit-identical
+ * results); what they save is host time (HF:374-416 BertLayer).  All matrices contiguous bf16 unless a leading dimension is given;
+ * weights W* are [out, in], the transposed copies W*T [in, out]. */
+typedef struct { uint32_t stream, thr16; float scale; } mmbert_drop;          /* a dropout site: mmbert_rng_stream / mmbert_dropout_thr16 / 1 / (1 - p) */
+typedef struct {                                                             /* the attention kernels' view of the packed token matrix */
+    const float* key_bias; const int* bias_start; const int* seq_start; const int* seq_len; const unsigned* elem_base;
+    const int* ftile_seq; const int* ftile_r0; const int* ftile_qshift; const int* ftile_qend;      /* forward query tiles */
+    const int* qtile_seq; const int* qtile_r0; const int* qtile_qshift; const int* qtile_qend;      /* backward query tiles */
+    const int* tile_seq; const int* tile_r0;                                                        /* backward key tiles */
+    const int* kv_len;
+    int nftiles, nqtiles, ntiles, split, heads, pad_;
+} mmbert_attn_layout;
+typedef struct {
+    const void* x;                                                           /* layer input [rows, H], row pitch ldx */
+    const void* Wqkv; const void* Wo; const void* W1; const void* W2;
+    const float* bqkv; const float* bo; const float* b1; const float* b2; const float* ln1_g; const float* ln1_b; const float* ln2_g; const float* ln2_b;
+    void* qkv; void* actx; float* lse; void* z1; void* y1; float* m1; float* r1; void* u /* may be NULL */; void* g; void* z2; void* y2; float* m2; float* r2;
+    const int* y2_rows;                                                      /* LayerNorm 2 stores row i at y2[y2_rows[i]] (NULL: row i), pitch ldy2 */
+    int* tile_queue;
+    mmbert_drop att, h1, h2;                                                 /* attention probabilities, the two hidden dropouts */
+    int rows, H, I, ldx, ldy2; float ln_eps;
+} mmbert_layer_fwd_args;
+typedef struct {
+    const void* dy; const int* dy_rows;                                      /* gradient of the layer output (pitch lddy; read through dy_rows when given) */
+    const void* z2; const float* m2; const float* r2; const float* ln2_g; float* g_ln2_g; float* g_ln2_b; float* ln2_ws;   /* ln*_ws: mmbert_ln_bwd_workspace() floats, */
+    const void* z1; const float* m1; const float* r1; const float* ln1_g; float* g_ln1_g; float* g_ln1_b; float* ln1_ws;   /* folded later by mmbert_ln_bwd_reduce_rows  */
+    const void* u; const void* qkv; const void* actx; const float* lse;
+    const void* W2T; const void* W1T; const void* WoT; const void* WqkvT;
+    void* dz2; void* dz2d /* NULL without hidden dropout */; void* du; void* dy1; void* dz1; void* dz1d /* NULL without */; void* dctx; void* dqkv; float* delta; void* dx;
+    int* tile_queue;
+    mmbert_drop att, h1, h2;
+    int rows, H, I, lddy;
+} mmbert_layer_bwd_args;
+int mmbert_layer_fwd(mmbert_stream_t stream, const mmbert_attn_layout* layout, const mmbert_layer_fwd_args* a);
+/* dx = the gradient of the layer input; the caller then launches the layer's weight gradients from (du, y1), (dz2d, g), (dqkv, x), (dz1d, actx). */
+int mmbert_layer_bwd(mmbert_stream_t stream, const mmbert_attn_layout* layout, const mmbert_layer_bwd_args* a);
+int mmbert_layer_struct_sizes(int* out /* [3]: sizeof the three structures above, for a binding's self-check */);
+
 /* ---- deterministic mode (round 5) ----
  * mmbert_set_deterministic(1): every fp32 sum of the library is formed in an order that does not depend on how workgroups are scheduled --
  * the CE loss sums (an ordered one-workgroup sum instead of an atomic per row), the weight-gradient kernel (no token split: one adder per

@@ -64,6 +64,9 @@ SIGNATURES = {
     "mmbert_skinny_mm": (I, [P, I, P]),
     "mmbert_skinny_mm_workspace": (SZ, [I, P]),
     "mmbert_skinny_mm_ordered": (I, [P, I, P, P]),
+    "mmbert_layer_fwd": (I, [P, P, P]),
+    "mmbert_layer_bwd": (I, [P, P, P]),
+    "mmbert_layer_struct_sizes": (I, [P]),
     "mmbert_set_deterministic": (None, [I]),
     "mmbert_get_deterministic": (I, []),
     "mmbert_id_runs_sum_rows": (I, [P, P, I, I, P, I, I, I, P, I, P, I]),

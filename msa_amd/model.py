@@ -276,6 +276,49 @@ class _EncoderFn:
         ph = cfg.hidden_dropout_prob if train else 0.0
         pa = cfg.attention_probs_dropout_prob if train else 0.0
         saved = []
+        # One C call per layer (mmbert_layer_fwd: the same seven launches with the same arguments, bit-identical) unless somebody wrapped
+        # the per-launch functions (bench.py's event timing, tests that spy on launches) or switched it off (model.composite_layers)
+        composite = getattr(top, "composite_layers", True) and ops.launches_unwrapped() and top.debug_hidden is None
+        if composite:
+            AL = ops.attn_layout_struct(key_bias, layout, backward=False)
+            if kv_len is not None and not getattr(layout, "split", False):
+                AL.kv_len = kv_len.data_ptr()
+            I_, M_, dev = cfg.intermediate_size, x.shape[0], x.device
+            heads = layout.heads
+            bf, f32 = torch.bfloat16, torch.float32
+            tq = ops._tile_queue(dev)
+            for i in range(L):
+                lw = top._lw[i]
+                d_att, d_h1, d_h2 = (ops.make_drop(pa, seed, 8 * i), ops.make_drop(ph, seed, 8 * i + 1), ops.make_drop(ph, seed, 8 * i + 2))
+                last = i == L - 1 and y_out is not None
+                qkv, actx, z1, y1 = (torch.empty((M_, 3 * H), device=dev, dtype=bf), torch.empty((M_, H), device=dev, dtype=bf),
+                                     torch.empty((M_, H), device=dev, dtype=bf), torch.empty((M_, H), device=dev, dtype=bf))
+                g, z2 = torch.empty((M_, I_), device=dev, dtype=bf), torch.empty((M_, H), device=dev, dtype=bf)
+                lse = torch.empty((M_, heads), device=dev, dtype=f32)
+                u = torch.empty((M_, I_), device=dev, dtype=bf) if keep else None
+                if keep:
+                    m1, r1, m2, r2 = (torch.empty(M_, device=dev, dtype=f32) for _ in range(4))
+                else:
+                    m1 = r1 = m2 = r2 = None
+                y2 = y_out if last else torch.empty((M_, H), device=dev, dtype=bf)
+                a = lw.get("_fwd_args")
+                if a is None:                                        # the layer's constants, once
+                    a = lw["_fwd_args"] = ops._LayerFwd()
+                    for n in ("Wqkv", "Wo", "W1", "W2", "bqkv", "bo", "b1", "b2", "ln1_g", "ln1_b", "ln2_g", "ln2_b"):
+                        assert lw[n].is_contiguous()
+                        setattr(a, n, lw[n].data_ptr())
+                    a.H, a.I, a.ln_eps = H, I_, cfg.layer_norm_eps
+                a.x, a.ldx, a.rows = x.data_ptr(), x.stride(0), M_
+                a.qkv, a.actx, a.lse, a.z1, a.y1, a.g, a.z2 = qkv.data_ptr(), actx.data_ptr(), lse.data_ptr(), z1.data_ptr(), y1.data_ptr(), g.data_ptr(), z2.data_ptr()
+                a.u, a.m1, a.r1, a.m2, a.r2 = ops._ptr(u), ops._ptr(m1), ops._ptr(r1), ops._ptr(m2), ops._ptr(r2)
+                a.y2, a.ldy2, a.y2_rows = y2.data_ptr(), y2.stride(0), ops._ptr(y_rows) if last else None
+                a.tile_queue = tq
+                ops._set_drop(a.att, d_att); ops._set_drop(a.h1, d_h1); ops._set_drop(a.h2, d_h2)
+                ops.layer_fwd(AL, a)
+                if keep:
+                    saved.append((x, qkv, actx, lse, z1, m1, r1, y1, u, g, z2, m2, r2, d_att, d_h1, d_h2))
+                x = y2
+            return x, saved
         for i in range(L):
             lw = top._lw[i]
             d_att, d_h1, d_h2 = (ops.make_drop(pa, seed, 8 * i), ops.make_drop(ph, seed, 8 * i + 1), ops.make_drop(ph, seed, 8 * i + 2))
@@ -328,6 +371,8 @@ class _EncoderFn:
         if dw is None:
             dw = _auto_defer_wgrads(H, top.config.intermediate_size, L, x_dev=saved[0][0].device, rows=ra)
         defer_wgrads, deferred = (top.grad_hook is None and bool(dw)), []
+        composite_bwd = getattr(top, "composite_layers", True) and ops.launches_unwrapped()
+        AL = tq = None
         for i in reversed(range(L)):
             lw = top._lw[i]
             saved_i = saved[i]
@@ -361,23 +406,61 @@ class _EncoderFn:
                     continue
                 if compact is not None:
                     raise RuntimeError("compact output gradient without the sparse top-layer path")
-            # --- output sublayer: y2 = LN(dropout(g.W2^T + b2) + y1)      (b2 / bo gradients = column sums of dz2d / dz1d: they ride
-            # on the weight-gradient launch below, like b1 and bqkv, on an all-ones MFMA operand)
-            dz2d = torch.empty((ra, H), device=z2.device, dtype=torch.bfloat16) if d_h2[1] else None
-            dz2 = ops.ln_bwd(dy, z2, m2, r2, lw["ln2_g"], lw["g_ln2_g"], lw["g_ln2_b"], dx2=dz2d, pre_drop=d_h2, deferred=lnd, dy_rows=dy_rows)
-            dy_rows = None
-            if dz2d is None:
-                dz2d = dz2
-            du = ops.gemm_nt(dz2d, lw["W2T"], gelu_bwd_u=u)
-            dy1 = ops.gemm_nt(du, lw["W1T"], resid=dz2)
-            # --- attention sublayer: y1 = LN(dropout(ctx.Wo^T + bo) + x)
-            dz1d = torch.empty((ra, H), device=z2.device, dtype=torch.bfloat16) if d_h1[1] else None
-            dz1 = ops.ln_bwd(dy1, z1, m1, r1, lw["ln1_g"], lw["g_ln1_g"], lw["g_ln1_b"], dx2=dz1d, pre_drop=d_h1, deferred=lnd)
-            if dz1d is None:
-                dz1d = dz1
-            dctx = ops.gemm_nt(dz1d, lw["WoT"])
-            dqkv = ops.attn_bwd(qkv, actx, dctx, lse, key_bias, layout, H, drop=d_att, kv_len=kv_len)
-            dy = ops.gemm_nt(dqkv, lw["WqkvT"], resid=dz1)
+            if composite_bwd:
+                # the seven launches of the dense backward body from ONE C call (mmbert_layer_bwd: same kernels, same arguments, bit-identical)
+                dev, bf = z2.device, torch.bfloat16
+                I_ = top.config.intermediate_size
+                if AL is None:
+                    AL = ops.attn_layout_struct(key_bias, layout, backward=True)
+                    if kv_len is not None and not getattr(layout, "split", False):
+                        AL.kv_len = kv_len.data_ptr()
+                    tq = ops._tile_queue(dev)
+                dz2, dz1, dy1, dctx, dx_ = (torch.empty((ra, H), device=dev, dtype=bf) for _ in range(5))
+                dz2d = torch.empty((ra, H), device=dev, dtype=bf) if d_h2[1] else None
+                dz1d = torch.empty((ra, H), device=dev, dtype=bf) if d_h1[1] else None
+                du, dqkv = torch.empty((ra, I_), device=dev, dtype=bf), torch.empty((ra, 3 * H), device=dev, dtype=bf)
+                delta = torch.empty((ra, layout.heads), device=dev, dtype=torch.float32)
+                lnd.reserve(2, ra, H, dev)                           # (both slots are taken before their launches: no flush in between)
+                ws2 = lnd.slot(ra, H, dev, lw["g_ln2_g"], lw["g_ln2_b"], None)
+                ws1 = lnd.slot(ra, H, dev, lw["g_ln1_g"], lw["g_ln1_b"], None)
+                b = lw.get("_bwd_args")
+                if b is None:
+                    b = lw["_bwd_args"] = ops._LayerBwd()
+                    for n in ("W2T", "W1T", "WoT", "WqkvT", "ln2_g", "ln1_g", "g_ln2_g", "g_ln2_b", "g_ln1_g", "g_ln1_b"):
+                        assert lw[n].is_contiguous()
+                        setattr(b, n, lw[n].data_ptr())
+                    b.H, b.I = H, I_
+                b.dy, b.lddy, b.dy_rows, b.rows = dy.data_ptr(), dy.stride(0), ops._ptr(dy_rows), ra
+                b.z2, b.m2, b.r2, b.ln2_ws, b.z1, b.m1, b.r1, b.ln1_ws = z2.data_ptr(), m2.data_ptr(), r2.data_ptr(), ws2, z1.data_ptr(), m1.data_ptr(), r1.data_ptr(), ws1
+                b.u, b.qkv, b.actx, b.lse = u.data_ptr(), qkv.data_ptr(), actx.data_ptr(), lse.data_ptr()
+                b.dz2, b.dz2d, b.du, b.dy1, b.dz1, b.dz1d = dz2.data_ptr(), ops._ptr(dz2d), du.data_ptr(), dy1.data_ptr(), dz1.data_ptr(), ops._ptr(dz1d)
+                b.dctx, b.dqkv, b.delta, b.dx, b.tile_queue = dctx.data_ptr(), dqkv.data_ptr(), delta.data_ptr(), dx_.data_ptr(), tq
+                ops._set_drop(b.att, d_att); ops._set_drop(b.h1, d_h1); ops._set_drop(b.h2, d_h2)
+                ops.layer_bwd(AL, b)
+                dy_rows = None
+                dy = dx_
+                if dz2d is None:
+                    dz2d = dz2
+                if dz1d is None:
+                    dz1d = dz1
+            else:
+              # --- output sublayer: y2 = LN(dropout(g.W2^T + b2) + y1)      (b2 / bo gradients = column sums of dz2d / dz1d: they ride
+              # on the weight-gradient launch below, like b1 and bqkv, on an all-ones MFMA operand)
+              dz2d = torch.empty((ra, H), device=z2.device, dtype=torch.bfloat16) if d_h2[1] else None
+              dz2 = ops.ln_bwd(dy, z2, m2, r2, lw["ln2_g"], lw["g_ln2_g"], lw["g_ln2_b"], dx2=dz2d, pre_drop=d_h2, deferred=lnd, dy_rows=dy_rows)
+              dy_rows = None
+              if dz2d is None:
+                  dz2d = dz2
+              du = ops.gemm_nt(dz2d, lw["W2T"], gelu_bwd_u=u)
+              dy1 = ops.gemm_nt(du, lw["W1T"], resid=dz2)
+              # --- attention sublayer: y1 = LN(dropout(ctx.Wo^T + bo) + x)
+              dz1d = torch.empty((ra, H), device=z2.device, dtype=torch.bfloat16) if d_h1[1] else None
+              dz1 = ops.ln_bwd(dy1, z1, m1, r1, lw["ln1_g"], lw["g_ln1_g"], lw["g_ln1_b"], dx2=dz1d, pre_drop=d_h1, deferred=lnd)
+              if dz1d is None:
+                  dz1d = dz1
+              dctx = ops.gemm_nt(dz1d, lw["WoT"])
+              dqkv = ops.attn_bwd(qkv, actx, dctx, lse, key_bias, layout, H, drop=d_att, kv_len=kv_len)
+              dy = ops.gemm_nt(dqkv, lw["WqkvT"], resid=dz1)
             # --- all four weight gradients (+ b1, bqkv gradients on the ones-operand MFMA) of the layer in ONE launch.
             # They are off the critical path of backward; model.overlap_wgrad = True moves them to a side stream (measured: a loss).
             probs = [(du, y1, lw["g_W1"], lw["g_b1"]), (dz2d, g, lw["g_W2"], lw["g_b2"]),

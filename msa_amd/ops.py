@@ -38,17 +38,28 @@ def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
     return None if t is None else t.data_ptr()
 
 
+_rng_fn = None
+
+
 def rng_stream(seed: int, site: int) -> int:
-    return _lib.load().mmbert_rng_stream(seed & 0xFFFFFFFFFFFFFFFF, site & 0xFFFFFFFF)
+    global _rng_fn
+    if _rng_fn is None:
+        _rng_fn = _lib.load().mmbert_rng_stream
+    return _rng_fn(seed & 0xFFFFFFFFFFFFFFFF, site & 0xFFFFFFFF)
+
+
+_thr_cache = {}
 
 
 def make_drop(p: float, seed: int, site: int) -> Tuple[int, int, float]:
     """(stream, thr16, scale) of a dropout site; the effective drop probability is thr16/65536."""
     if p <= 0.0:
         return NO_DROP
-    lib = _lib.load()
-    thr = lib.mmbert_dropout_thr16(p)
-    return (rng_stream(seed, site), thr, 1.0 / (1.0 - thr / 65536.0))
+    t = _thr_cache.get(p)
+    if t is None:                                        # (the threshold of a probability never changes: one C call per distinct p)
+        thr = _lib.load().mmbert_dropout_thr16(p)
+        t = _thr_cache[p] = (thr, 1.0 / (1.0 - thr / 65536.0))
+    return (rng_stream(seed, site), t[0], t[1])
 
 
 _tile_queues = {}
@@ -291,6 +302,23 @@ class LnDeferred:
         self.used += per
         self.items.append((ptr, dgamma.data_ptr(), dbeta.data_ptr(), dbias2.data_ptr() if dbias2 is not None else None, int(M)))
         return ptr
+
+    def reserve(self, n, M, H, device):
+        """Make the next ``n`` ``slot(M, H, ...)`` calls flush-free.  A caller that takes several slots BEFORE launching their LayerNorm'
+        calls (the composite layer call takes two) must not have the second slot() fold the first one's partial sums before they exist:
+        whatever would make slot() flush within those calls -- another H, the slot count, a workspace that has to grow -- happens here,
+        while every slot taken so far has been launched."""
+        per = _lib.load().mmbert_ln_bwd_workspace(M, H)
+        if self.H is not None and (H != self.H or len(self.items) + n > self.slots):
+            self.flush()
+        ck = (device, _stream())
+        if not self.items:
+            self.ws, self.used = _lnd_cache.get(ck), 0
+        if self.ws is None or self.ws.numel() < self.used + n * per:
+            self.flush()
+            want = max(max(self.slots, n) * per, 2 * (self.ws.numel() if self.ws is not None else 0))
+            self.ws, self.used = torch.empty(want, device=device, dtype=torch.float32), 0
+            _lnd_cache[ck] = self.ws
 
     def drop(self):
         """Forget collected calls without folding them (the leftovers of a backward pass that raised half-way)."""
@@ -1088,3 +1116,91 @@ def skinny_wgrad(oplist):
         o.dY, o.X, o.dW, o.db = dY.data_ptr(), X.data_ptr(), dW.data_ptr(), _ptr(db)
         o.ldy, o.ldx, o.ldw, o.M, o.N, o.K = dY.stride(0), X.stride(0), dW.stride(0), dY.shape[0], dY.shape[1], X.shape[1]
     _lib.check(_lib.load().mmbert_skinny_wgrad(_stream(), n, ctypes.cast(arr, ctypes.c_void_p)), "mmbert_skinny_wgrad")
+
+
+# ------------------------------------------------------------------------------------ composite encoder-layer calls (mmbert_layer_fwd / _bwd)
+class _Drop(ctypes.Structure):
+    _fields_ = [("stream", ctypes.c_uint32), ("thr16", ctypes.c_uint32), ("scale", ctypes.c_float)]
+
+
+_VP, _CI = ctypes.c_void_p, ctypes.c_int
+
+
+class _AttnLayout(ctypes.Structure):
+    _fields_ = [(n, _VP) for n in ("key_bias", "bias_start", "seq_start", "seq_len", "elem_base", "ftile_seq", "ftile_r0", "ftile_qshift", "ftile_qend",
+                                    "qtile_seq", "qtile_r0", "qtile_qshift", "qtile_qend", "tile_seq", "tile_r0", "kv_len")] + \
+               [(n, _CI) for n in ("nftiles", "nqtiles", "ntiles", "split", "heads", "pad_")]
+
+
+class _LayerFwd(ctypes.Structure):
+    _fields_ = [(n, _VP) for n in ("x", "Wqkv", "Wo", "W1", "W2", "bqkv", "bo", "b1", "b2", "ln1_g", "ln1_b", "ln2_g", "ln2_b",
+                                    "qkv", "actx", "lse", "z1", "y1", "m1", "r1", "u", "g", "z2", "y2", "m2", "r2", "y2_rows", "tile_queue")] + \
+               [("att", _Drop), ("h1", _Drop), ("h2", _Drop)] + [(n, _CI) for n in ("rows", "H", "I", "ldx", "ldy2")] + [("ln_eps", ctypes.c_float)]
+
+
+class _LayerBwd(ctypes.Structure):
+    _fields_ = [(n, _VP) for n in ("dy", "dy_rows", "z2", "m2", "r2", "ln2_g", "g_ln2_g", "g_ln2_b", "ln2_ws", "z1", "m1", "r1", "ln1_g", "g_ln1_g", "g_ln1_b", "ln1_ws",
+                                    "u", "qkv", "actx", "lse", "W2T", "W1T", "WoT", "WqkvT",
+                                    "dz2", "dz2d", "du", "dy1", "dz1", "dz1d", "dctx", "dqkv", "delta", "dx", "tile_queue")] + \
+               [("att", _Drop), ("h1", _Drop), ("h2", _Drop)] + [(n, _CI) for n in ("rows", "H", "I", "lddy")]
+
+
+_layer_structs_checked = False
+
+
+def _check_layer_structs():
+    global _layer_structs_checked
+    if not _layer_structs_checked:
+        sz = (ctypes.c_int * 3)()
+        _lib.check(_lib.load().mmbert_layer_struct_sizes(sz), "mmbert_layer_struct_sizes")
+        got = (ctypes.sizeof(_AttnLayout), ctypes.sizeof(_LayerFwd), ctypes.sizeof(_LayerBwd))
+        if tuple(sz) != got:
+            raise RuntimeError(f"msa_amd.ops: structure layout differs from include/mmbert_hip.h: C {tuple(sz)} != ctypes {got}")
+        _layer_structs_checked = True
+
+
+def attn_layout_struct(key_bias, layout, backward: bool):
+    """The attention kernels' view of ``layout`` as the C structure of the composite layer calls (the same fields attn_fwd / attn_bwd pass
+    one by one; ``backward`` reads the split layout's lazily resolved tile counts)."""
+    _check_layer_structs()
+    if key_bias.numel() != layout.bias_len or layout.bias_len == layout.tokens:
+        key_bias = pad_key_bias(key_bias, layout) if key_bias.numel() == layout.tokens else key_bias
+    split = bool(getattr(layout, "split", False))
+    L = _AttnLayout()
+    L.key_bias, L.bias_start, L.seq_start, L.seq_len, L.elem_base = (key_bias.data_ptr(), layout.bias_start.data_ptr(), layout.seq_start.data_ptr(),
+                                                                     layout.seq_len.data_ptr(), layout.elem_base.data_ptr())
+    L.ftile_seq, L.ftile_r0, L.nftiles = layout.ftile_seq.data_ptr(), layout.ftile_r0.data_ptr(), layout.nftiles
+    L.ftile_qshift, L.ftile_qend = _ptr(getattr(layout, "ftile_qshift", None)), _ptr(getattr(layout, "ftile_qend", None))
+    L.kv_len = _ptr(layout.kv_len) if split else None
+    L.split, L.heads = 1 if split else 0, layout.heads
+    if backward:
+        if split:                    # backward covers region A only: its query tiles double as the key tiles (attn_bwd)
+            L.qtile_seq, L.qtile_r0, L.nqtiles = layout.tile_seq.data_ptr(), layout.tile_r0.data_ptr(), layout.ntiles
+        else:
+            L.qtile_seq, L.qtile_r0, L.nqtiles = layout.ftile_seq.data_ptr(), layout.ftile_r0.data_ptr(), layout.nftiles
+        L.tile_seq, L.tile_r0, L.ntiles = layout.tile_seq.data_ptr(), layout.tile_r0.data_ptr(), layout.ntiles
+        L.qtile_qshift, L.qtile_qend = _ptr(getattr(layout, "qtile_qshift", None)), _ptr(getattr(layout, "qtile_qend", None))
+    L._keep = (key_bias, layout)                                   # (the padded bias must outlive the launches)
+    return L
+
+
+def _set_drop(d: _Drop, drop: Drop):
+    d.stream, d.thr16, d.scale = drop or NO_DROP
+
+
+def layer_fwd(L: _AttnLayout, a: _LayerFwd):
+    _lib.check(_lib.load().mmbert_layer_fwd(_stream(), ctypes.addressof(L), ctypes.addressof(a)), "mmbert_layer_fwd")
+
+
+def layer_bwd(L: _AttnLayout, a: _LayerBwd):
+    _lib.check(_lib.load().mmbert_layer_bwd(_stream(), ctypes.addressof(L), ctypes.addressof(a)), "mmbert_layer_bwd")
+
+
+# the per-launch wrappers as defined here: model.py takes the composite path only while nobody has wrapped them (bench.py's per-launch
+# event timing, tests that spy on launches)
+_UNWRAPPED = dict(gemm_nt=gemm_nt, attn_fwd=attn_fwd, attn_bwd=attn_bwd, ln_fwd=ln_fwd, ln_bwd=ln_bwd)
+
+
+def launches_unwrapped() -> bool:
+    g = globals()
+    return all(g[k] is v for k, v in _UNWRAPPED.items())

@@ -709,6 +709,50 @@ def test_train_mode_step_at_the_timed_depth_matches_oracle_with_replayed_masks(s
     print("train-mode worst gradient cosine at L = 12", worst)
 
 
+@pytest.mark.parametrize("train", [False, True])
+def test_composite_layer_calls_are_bit_identical(train):
+    """Round 5: mmbert_layer_fwd / mmbert_layer_bwd issue a layer's forward (7 launches) and the dense part of its backward (7) from ONE C
+    call each -- the same kernels with the same arguments.  Against the per-launch path (model.composite_layers = False) in deterministic
+    mode (so that the loss sums do not depend on atomics' arrival order): losses, regression logits, prediction scores and the whole flat
+    gradient buffer BIT-identical, eval and train mode (dropout seeds handed through the structures), short cuts on (split layout, sparse
+    top layer: L - 1 composite backward calls) and off (L calls); and the composite path really ran."""
+    from msa_amd import ops as _ops
+    cfg = dict(hidden=256, layers=3, heads=4, intermediate=1024, vocab=4096, dataset="mosei", alpha=1.0, beta=1.0)
+    dbatch = batch_to(synthetic_batch(4, 24, 200, 130, dataset="mosei", vocab=cfg["vocab"], seed=61), DEV)
+    was = _ops.deterministic()
+    try:
+        _ops.set_deterministic(True)
+        for shortcuts in (True, False):
+            res = {}
+            for comp in (True, False):
+                m = build(cfg, train=train)
+                m.manual_seed(29)
+                m.composite_layers = comp
+                if not shortcuts:
+                    m.skip_padded_backward = m.sparse_top_layer_backward = False
+                calls = {"fwd": 0, "bwd": 0}
+                of, ob = _ops.layer_fwd, _ops.layer_bwd
+                _ops.layer_fwd = lambda *a, _o=of: (calls.__setitem__("fwd", calls["fwd"] + 1), _o(*a))[1]
+                _ops.layer_bwd = lambda *a, _o=ob: (calls.__setitem__("bwd", calls["bwd"] + 1), _o(*a))[1]
+                try:
+                    out, logits = m(**dbatch)
+                    out[0].mean().backward()
+                    torch.cuda.synchronize()
+                finally:
+                    _ops.layer_fwd, _ops.layer_bwd = of, ob
+                assert calls == ({"fwd": 3, "bwd": 2 if shortcuts else 3} if comp else {"fwd": 0, "bwd": 0}), (comp, shortcuts, calls)
+                res[comp] = ([out[i].detach().clone() for i in (0, 4, 5, 6)], logits.detach().clone(), [out[k].detach().clone() for k in (7, 9, 11)],
+                             m._flat.grads.clone())
+            for x, y in zip(res[True][0], res[False][0]):
+                assert torch.equal(x, y), (shortcuts, float(x), float(y))
+            assert torch.equal(res[True][1], res[False][1])
+            for x, y in zip(res[True][2], res[False][2]):
+                assert torch.equal(x, y)
+            assert torch.equal(res[True][3], res[False][3]), float((res[True][3] - res[False][3]).abs().max())
+    finally:
+        _ops.set_deterministic(was)
+
+
 def test_deferred_weight_gradients_equal_the_per_layer_launches():
     """Round 4: without a gradient hook (one GPU) every dense layer's weight gradients go out in ONE call at the end of backward
     (model.defer_wgrads, whole rounds of tiles) instead of per layer pair: the same products on the same operands -- every parameter
