@@ -68,7 +68,6 @@ def main():
     ap.add_argument("--no-fused", action="store_true", help="skip the secondary fused-sequence (S = T+V+A) measurement")
     ap.add_argument("--no-dense-reference", action="store_true", help="skip the secondary measurement with the exact-zero short cuts off")
     ap.add_argument("--no-train-only", action="store_true", help="skip the secondary measurement without the returned prediction scores")
-    ap.add_argument("--overlap-wgrad", action="store_true", help="weight-gradient GEMMs on a side stream (measured slower)")
     ap.add_argument("--eval-dropout-off", action="store_true", help="diagnostic only: not a valid headline number")
     ap.add_argument("--no-skip-masked-keys", action="store_true", help="A/B: attention also visits the key tiles that are entirely masked out")
     ap.add_argument("--no-skip-padded-backward", action="store_true", help="A/B: backward also runs on the rows whose gradients are exactly zero")
@@ -177,7 +176,6 @@ def main():
     model.to(dev)
     model.train(not a.eval_dropout_off)
     model.manual_seed(1234 + rank)
-    model.overlap_wgrad = a.overlap_wgrad
     # the batches of this benchmark are resident and complete before the timed region (the metric's definition): the step prologue may
     # read them on the model's input stream, ahead of the previous step's tail (model._prologue_stream)
     model.async_prologue = not a.sync_prologue

@@ -461,12 +461,11 @@ class _EncoderFn:
               dctx = ops.gemm_nt(dz1d, lw["WoT"])
               dqkv = ops.attn_bwd(qkv, actx, dctx, lse, key_bias, layout, H, drop=d_att, kv_len=kv_len)
               dy = ops.gemm_nt(dqkv, lw["WqkvT"], resid=dz1)
-            # --- all four weight gradients (+ b1, bqkv gradients on the ones-operand MFMA) of the layer in ONE launch.
-            # They are off the critical path of backward; model.overlap_wgrad = True moves them to a side stream (measured: a loss).
+            # --- all four weight gradients (+ their bias gradients) of the layer in ONE launch.  (They are off the critical path of backward;
+            # a side stream for them was measured a loss in rounds 1, 3 and 4 -- the chip's power envelope is shared -- and is gone.)
             probs = [(du, y1, lw["g_W1"], lw["g_b1"]), (dz2d, g, lw["g_W2"], lw["g_b2"]),
                      (dqkv, x, lw["g_Wqkv"], lw["g_bqkv"]), (dz1d, actx, lw["g_Wo"], lw["g_bo"])]
-            side = top._wgrad_stream()
-            if side is None and defer_wgrads:
+            if defer_wgrads:
                 # One GPU (no gradient hook): nothing needs this layer's weight gradients before the optimizer, so ALL dense layers'
                 # weight gradients can go out as ONE call at the end of backward, in whole rounds of 256 tiles (11 layers = 1188
                 # tiles = 4.64 rounds; the paired launches below fill 216 of 256 CUs each and layer 0, alone, splits the token axis
@@ -478,7 +477,7 @@ class _EncoderFn:
                 deferred.extend(probs)
                 top._layer_grads_done(i)
                 continue
-            if side is None and pair_wgrads:
+            if pair_wgrads:
                 # Two layers per launch: a layer's 108 tiles leave the chip half empty, so a single layer splits the token axis in two
                 # (fp32 slabs + a reduce launch, 12 us and 85 MB per layer); two layers' 216 tiles fill it in one round unsplit.  The
                 # upper layer of a pair just keeps its operands alive for one more layer (fresh buffers from the caching allocator)
@@ -493,17 +492,8 @@ class _EncoderFn:
                     held = None
                 else:
                     _wgrad(top, probs)
-            elif side is None:
-                _wgrad(top, probs)
             else:
-                main = torch.cuda.current_stream()
-                side.wait_stream(main)
-                with torch.cuda.stream(side):
-                    _wgrad(top, probs)
-                for t in (du, y1, dz2d, g, dqkv, x, dz1d, actx):
-                    t.record_stream(side)                  # the caching allocator must not hand these out while the side stream reads them
-                if top.grad_hook is not None:
-                    main.wait_stream(side)                 # DP: the layer's gradient slice is final only after its wgrad
+                _wgrad(top, probs)
             if top.grad_hook is not None:
                 lnd.flush()                                # ... and after its LayerNorm sums
             top._layer_grads_done(i)
@@ -511,9 +501,6 @@ class _EncoderFn:
             lnd.flush()
         for c in range(0, len(deferred), 48):                 # (mmbert_gemm_tn_grouped: up to 48 problems = 12 layers per launch)
             _wgrad(top, deferred[c:c + 48])
-        side = top._wgrad_stream()
-        if side is not None:
-            torch.cuda.current_stream().wait_stream(side)     # optimizer / all-reduce tail see complete gradients
         return dy
 
     @staticmethod
@@ -709,7 +696,6 @@ class _TrunkFn(torch.autograd.Function):
         npass = len(lens)
         layout = split if split is not None else plan["layout"]
         compact, t.compact = t.compact, None                      # (rows in the caller's order, their gradients): set by the MLM head
-        top._join_heads_backward()                                # (safety net: normally joined by the MLM head's backward)
         top._flat.settle([w["g_word_pad"]])                       # no MLM-head launch has overwritten a dropped table gradient (no labelled row):
                                                                   # zero it before the embedding rows are added / the slice is reduced
         # ONE collector for the LayerNorm' gamma / beta sums of the whole backward -- the MLM head's call (already in it), the sparse top
@@ -894,8 +880,6 @@ class _MLMHeadFn(torch.autograd.Function):
             sel, dy_all = res
             n = sel.numel()
             dyl = dy_all[:n]
-            if dfirst is not None:
-                ctx.top._join_heads_backward()
             if nf and _MLMHeadFn._compact_ok(ctx, t, n, dfirst):
                 first = t.top_rows[1]
                 df = dfirst if dfirst.shape[0] == first.numel() else dfirst.view(-1, first.numel(), dfirst.shape[1]).sum(0)   # ([CLS] rows repeated: fused)
@@ -908,7 +892,6 @@ class _MLMHeadFn(torch.autograd.Function):
         else:
             dy = res
         if dfirst is not None:                                # a [CLS] row may also carry a label: add, after the copy
-            ctx.top._join_heads_backward()
             if dy is None:
                 dy = torch.zeros((ctx.M, dfirst.shape[1]), device=dfirst.device, dtype=torch.bfloat16)
             dy.index_add_(0, ctx.first_rows, dfirst.to(dy.dtype))
@@ -998,30 +981,6 @@ class _GpuModelBase(nn.Module):
         # tests only: a dict here collects, per _encode() call, "emb" (text embeddings of all passes), "x" (encoder input) and
         # "layers" (every encoder layer's output), all [tokens, H] bf16 in the ORIGINAL packed row order (pass, sample, position)
         self.debug_hidden = None
-
-    def _wgrad_stream(self):
-        """Side stream for the weight-gradient GEMMs (None = run them in line, the default); see _EncoderFn.backward.
-        Measured on MI355X (round 1, same box, bench.py): 572 samples/s with the side stream vs 606 in line -- the TN
-        GEMM's two 72-KiB workgroups per CU leave no LDS for attention workgroups to co-reside, and capping it at one
-        workgroup per CU (padded LDS request) does not help either (577).  Kept as an opt-in switch only."""
-        if not getattr(self, "overlap_wgrad", False):
-            return None
-        s = getattr(self, "_side_stream", None)
-        if s is None:
-            s = self._side_stream = torch.cuda.Stream()
-        return s
-
-    def _heads_stream(self):
-        s = self.__dict__.get("_heads_side_stream")
-        if s is None:
-            s = self.__dict__["_heads_side_stream"] = torch.cuda.Stream()
-        return s
-
-    def _join_heads_backward(self):
-        """The current stream waits for the heads' backward chain if it ran on the side stream (overlap_heads_backward)."""
-        ev = self.__dict__.pop("_heads_join", None)
-        if ev is not None:
-            torch.cuda.current_stream().wait_event(ev)
 
     def _shared_lnd(self):
         """The one ``ops.LnDeferred`` collector of a backward pass (MLM head -> trunk: see ``_TrunkFn.backward``)."""
@@ -1574,25 +1533,8 @@ class _HeadsFn(torch.autograd.Function):
         dev = first.device
         d1 = d.reshape(1).float().contiguous()
         coef = (ctx.alpha / ctx.nmlm) if ctx.nmlm else 0.0
-        # (round 4, opt-in: model.overlap_heads_backward) The heads' backward -- ten launches of 5-30 us in a dependency chain -- and the MLM
-        # head's sparse backward -- eleven more -- are independent until the [CLS] rows' gradient joins the labelled rows': with the joint
-        # loss assembled here (mlm given) the MLM head's backward is the next node, so this chain can run on a side stream beside it.  Only
-        # the gradient of the per-pass MLM losses (d * alpha / passes) is produced on the current stream; the consumer of dfirst joins
-        # (_join_heads_backward: _MLMHeadFn.backward, and _TrunkFn.backward as a safety net).
-        side = top._heads_stream() if (ctx.nmlm and getattr(top, "overlap_heads_backward", False)) else None
-        if side is not None:
-            main = torch.cuda.current_stream()
-            _, _, dmlm = ops.heads_seed(seeds[:0], d1, 0, ctx.nmlm, coef)
-            side.wait_stream(main)
-            with torch.cuda.stream(side):
-                dfirst = _HeadsFn._backward_chain(ctx, top, first, P, Apre, g, Cc, T, seeds, d1, 0, 0.0)[0]
-            for t_ in (first, P, Apre, g, Cc, T, seeds, d1):
-                t_.record_stream(side)
-            dfirst.record_stream(main)
-            ev = torch.cuda.Event()
-            ev.record(side)
-            top.__dict__["_heads_join"] = ev
-            return dfirst, None, None, None, dmlm
+        # (the chain on a side stream beside the MLM head's sparse backward was measured -0.1 ... -0.3 % in round 4 -- two chains of 5-30-us
+        # launches hardly overlap -- and is gone)
         dfirst, dmlm = _HeadsFn._backward_chain(ctx, top, first, P, Apre, g, Cc, T, seeds, d1, ctx.nmlm, coef)
         return dfirst, None, None, None, dmlm
 
