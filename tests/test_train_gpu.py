@@ -174,6 +174,32 @@ def test_lazy_zero_of_the_dense_weight_gradients_is_invisible():
     assert not m2._flat.stale and float(m2._flat.grads.abs().max()) == 0.0
 
 
+def _dp_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)         # 1-GPU box: both ranks share cuda:0, gloo moves the bytes
+    from msa_amd import parallel
+    from msa_amd import trainer as T
+    torch.cuda.set_device(0)
+    m = build()
+    if rank == 1:                                                         # ranks start different: broadcast must fix it
+        with torch.no_grad():
+            for p in m.parameters():
+                p.add_(0.01)
+    opt, sched = T.build_optimizer(m, T.default_args(learning_rate=1e-3), 4)
+    dp = parallel.DataParallel(m, opt, bucket_mb=0.25)
+    m.eval()
+    batch = batch_to(synthetic_batch(2, 16, 40, 24, vocab=CFG["vocab"], seed=10 + rank), DEV)
+    out, _ = m(**batch)
+    out[0].mean().backward()
+    n_calls = dp.bucketer.calls
+    dp.finish_backward()
+    torch.cuda.synchronize()
+    if rank == 0:
+        q.put(dict(grads=m._flat.grads.cpu(), loss=float(out[0]), scale=opt.grad_scale, calls=n_calls))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
 def test_data_parallel_two_ranks_equals_mean_of_single_rank_grads():
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
