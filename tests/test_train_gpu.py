@@ -611,6 +611,42 @@ def _nccl_world1_worker(port, q):
         ops.dynamic_tile_queue = False
         assert staged >= 1, staged                                                    # buckets really went through the two-stage exchange
         werr = float((w - b).abs().max() / b.abs().max())
+        # round 5: differentiated forwards whose backward never comes (a validation pass with grad enabled) must not pile up
+        # unions -- the list is bounded, a cut list makes finish_backward rebuild the union, and the next real step is still right
+        m = build(cfg, dropout=0.1)
+        m.train()
+        m.manual_seed(5)
+        opt, sched = T.build_optimizer(m, T.default_args(train_batch_size=4, learning_rate=1e-3), 4)
+        dp = parallel.DataParallel(m, opt, bucket_mb=0.5, force_dynamic_queue=True)
+        for _ in range(12):
+            m(**batch)
+        assert len(dp._unions) <= 4 and dp._unions_cut, (len(dp._unions), dp._unions_cut)
+        m.manual_seed(5)
+        m._calls = 0                                                                   # (the same dropout seeds as the reference runs above)
+        out, _ = m(**batch)
+        out[0].mean().backward()
+        dp.finish_backward()
+        torch.cuda.synchronize()
+        cerr = float((m._flat.grads - b).abs().max() / b.abs().max())
+        assert cerr < 2e-3, cerr
+        assert not dp._unions and not dp._unions_cut
+        # ... and in deterministic mode the whole data-parallel step (row block through the ordered id-run sums) is bit-reproducible
+        ops.set_deterministic(True)
+        det = []
+        for _ in range(2):
+            m = build(cfg, dropout=0.1)
+            m.train()
+            m.manual_seed(5)
+            opt, sched = T.build_optimizer(m, T.default_args(train_batch_size=4, learning_rate=1e-3), 4)
+            dp = parallel.DataParallel(m, opt, bucket_mb=0.5, force_dynamic_queue=True)
+            out, _ = m(**batch)
+            out[0].mean().backward()
+            dp.finish_backward()
+            torch.cuda.synchronize()
+            det.append(m._flat.grads.clone())
+        ops.set_deterministic(False)
+        ops.dynamic_tile_queue = False
+        assert torch.equal(det[0], det[1])
         q.put(("ok", err, float(b.abs().max()), werr))
         dist.destroy_process_group()
     except Exception as e:                                                            # pragma: no cover
