@@ -365,9 +365,13 @@ def scatter_add_rows_ordered(keys, src, dst, vocab, union=None):
     association (ascending i) and land with one add per destination element.  row_of(key) = key, or its index in the ascending ``union``;
     keys outside (0, vocab) or not in the union are skipped.  One launch, nothing is sorted or read back by the host."""
     keys = keys.reshape(-1).long().contiguous()
-    _lib.check(_lib.load().mmbert_id_runs_sum_rows(_stream(), src.data_ptr(), 1 if src.dtype == torch.bfloat16 else 0, src.stride(0), keys.data_ptr(),
-                                                   keys.numel(), src.shape[1], int(vocab), _ptr(union), 0 if union is None else union.numel(),
-                                                   dst.data_ptr(), dst.stride(0)), "mmbert_id_runs_sum_rows")
+    fn, bf = _lib.load().mmbert_id_runs_sum_rows, 1 if src.dtype == torch.bfloat16 else 0
+    # (the kernel keeps an id's row list in LDS: 8192 rows per launch; longer batches go out in consecutive launches -- still ordered: the
+    # launches of a stream run one after the other, each adds its part of a run once)
+    for off in range(0, keys.numel(), 8192):
+        n = min(8192, keys.numel() - off)
+        _lib.check(fn(_stream(), src[off:off + n].data_ptr(), bf, src.stride(0), keys[off:off + n].data_ptr(), n, src.shape[1], int(vocab),
+                      _ptr(union), 0 if union is None else union.numel(), dst.data_ptr(), dst.stride(0)), "mmbert_id_runs_sum_rows")
     return dst
 
 

@@ -1277,5 +1277,15 @@ def test_deterministic_forms_equal_the_atomic_forms(ops):
             assert torch.equal(a, b), nm
             assert_close(a, r, 1e-5, 1e-4, nm)
         assert float(got[0].abs().sum()) > 0 and float(got[3].abs().sum()) > 0 and float(got[6].abs().sum()) > 0
+        # more rows than one launch of the ordered kernel holds in LDS (8192): consecutive launches, still one fixed order
+        big_ids = torch.randint(0, 300, (10000,), generator=g).to(DEV)
+        big_rows = rnd(10000, H, seed=509).to(DEV)
+        ops.set_deterministic(False)
+        ref_blk = ops.rows_to_block(big_ids, big_rows, union, 300, torch.zeros(union.numel(), H, device=DEV))
+        ops.set_deterministic(True)
+        b1 = ops.rows_to_block(big_ids, big_rows, union, 300, torch.zeros(union.numel(), H, device=DEV))
+        b2 = ops.rows_to_block(big_ids, big_rows, union, 300, torch.zeros(union.numel(), H, device=DEV))
+        assert torch.equal(b1, b2)
+        assert_close(b1, ref_blk, 1e-5, 2e-4, "row block, 10 000 rows")
     finally:
         ops.set_deterministic(was)
