@@ -616,7 +616,7 @@ def test_dropout_train_mode_is_seeded_and_unbiased():
 
 
 @pytest.mark.parametrize("shortcuts", [True, False])
-@pytest.mark.parametrize("case", ["cfg1", "base2", "deep4"])
+@pytest.mark.parametrize("case", ["cfg1", "base2", "deep4", "long2"])
 def test_train_mode_step_matches_oracle_with_replayed_masks(case, shortcuts):
     """The BENCHMARKED configuration -- model.train(), dropout 0.1 / 0.1 / 0.5 on, as REF:trainer.py:40,66,83 runs it -- end to end
     against the oracle: the HIP step's keep masks of every site (embeddings, JointEmbeddings, and per layer and pass the attention
@@ -624,7 +624,8 @@ def test_train_mode_step_matches_oracle_with_replayed_masks(case, shortcuts):
     (oracle._dropout), so the two sides compute the same function: the 4 losses at 3e-3, regression logits, prediction scores and
     EVERY parameter gradient at the eval-mode tolerances.  A wrong site or seed handed to a backward launch, a swapped h1 / h2 drop
     tuple or a mask indexed by the wrong row order gives gradients that fail here (and nowhere in eval mode).
-    cfg1 = BASELINE configs[0]'s model (B=2, T=50, P=64); base2 = two layers of configs[1] (d=768, T=50, A=V=500).  Both with the
+    cfg1 = BASELINE configs[0]'s model (B=2, T=50, P=64); base2 = two layers of configs[1] (d=768, T=50, A=V=500); long2 = two layers at
+    configs[3]'s lengths (A=V=1375).  All with the
     default exact-zero short cuts (valid-first packing: hidden-dropout masks follow the packed row order; sparse top-layer
     backward: masks of the ORIGINAL rows regenerated on gathered rows) and with them off (dense backward on every row).
     deep4 (round 4) = FOUR layers (d=256, B=2, T=24, unequal pair lengths 70 / 33): the only depth at which the dropout sites 8i + k
@@ -633,6 +634,11 @@ def test_train_mode_step_matches_oracle_with_replayed_masks(case, shortcuts):
     handed to the wrong layer's launch fails here and nowhere at L = 2."""
     if case == "cfg1":
         cfg, shape = CFG1, (2, 50, 64, 64)
+    elif case == "long2":
+        # round 5: BASELINE configs[3]'s sequence lengths (A = V = 1375: S = 1425 per joint pass, 23 key tiles, a 17-row last query tile)
+        # at two layers of the headline width and configs[3]'s batch 4, TRAIN mode -- the long-sequence ends of the dropout index arithmetic (12 x 1425 x 1428
+        # elements per sequence), of the attention tile lists and of the packed row maps, with every mask replayed in the oracle
+        cfg, shape = dict(hidden=768, layers=2, heads=12, intermediate=3072, vocab=30522, dataset="mosei", alpha=1.0, beta=1.0), (4, 50, 1375, 1375)
     elif case == "deep4":
         cfg, shape = dict(hidden=256, layers=4, heads=4, intermediate=1024, vocab=4096, dataset="mosei", alpha=1.0, beta=1.0), (2, 24, 70, 33)
     else:
@@ -645,7 +651,7 @@ def test_train_mode_step_matches_oracle_with_replayed_masks(case, shortcuts):
         from msa_amd import ops as _ops
         tn_calls, tn_orig = [], _ops.gemm_tn_grouped
         _ops.gemm_tn_grouped = lambda probs, *a, _o=tn_orig, _c=tn_calls, **k: (_c.append(len(probs)), _o(probs, *a, **k))[1]
-        m, out, worst = check_against_oracle(cfg, *shape, seed={"cfg1": 1, "base2": 5, "deep4": 6}[case], train=True, flags=flags)
+        m, out, worst = check_against_oracle(cfg, *shape, seed={"cfg1": 1, "base2": 5, "deep4": 6, "long2": 9}[case], train=True, flags=flags)
     finally:
         MM._EncoderFn._last_layer_sparse = staticmethod(orig)
         _ops.gemm_tn_grouped = tn_orig
