@@ -245,7 +245,7 @@ def main():
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(t)
-    loss = float(last)
+    loss = float(last.detach())
     # The roofline leg: the SAME K steps once more, bracketed the same way, with a HIP event pair around every GEMM / attention launch
     # on the launch stream.  Kept out of the headline region because the instrumentation is not free: ~340 event records per step
     # are ~340 extra packets in the queue between kernels (round 2 timed both in one pass: 16.4 ms per step against 15.9 without the
