@@ -549,13 +549,23 @@ __global__ __launch_bounds__(512, 2) void gemm_nt8_kernel(const GemmNT p) {
         const int ncol = n0 + wc * 64 + efq * 8;                     // 8 columns here (h = 0) and 8 at + 32 (h = 1)
         constexpr int PRE = 3;
         bf16x8 pre[NB][2];
+        // Epilogue operands as raw buffers: the per-lane byte offset of (mrow, ncol) once per operand and tile, row block i by ONE 32-bit add
+        // (16 i pitch: a scalar), the two column halves by the instruction's immediate -- where 64-bit pointers cost 3.5 VALU instructions
+        // per access (v_mad_i64_i32 + v_lshl_add_u64 + moves: 98 of FFN-up's 985 epilogue instructions).  Rows past M are past the
+        // descriptor's range: their loads return 0 and nothing of them is stored (`ok` below), so the row clamp is gone too.
+        constexpr uint32_t CSZ = (EPI & EPI_OUT_F32) ? 4u : 2u;
+        const uint32_t um = (uint32_t)q.M;
+        const auto rsC = __builtin_amdgcn_make_buffer_rsrc((void*)q.C, 0, (int)(um * (uint32_t)q.ldc * CSZ), 0x00020000);
+        const uint32_t voffC = ((uint32_t)mrow * (uint32_t)q.ldc + (uint32_t)ncol) * CSZ, rowC = 16u * (uint32_t)q.ldc * CSZ;
+        const bf16_t* presrc = (EPI & EPI_RESID) ? q.R : q.U;
+        const uint32_t preld = (uint32_t)((EPI & EPI_RESID) ? q.ldr : q.ldu);
+        const auto rsP = __builtin_amdgcn_make_buffer_rsrc((void*)presrc, 0, (int)((EPI & (EPI_RESID | EPI_GELU_BWD)) ? um * preld * 2u : 0u), 0x00020000);
+        const uint32_t voffP = ((uint32_t)mrow * preld + (uint32_t)ncol) * 2u, rowP = 32u * preld;
         auto load_pre = [&](int i) {
             if constexpr (EPI & (EPI_RESID | EPI_GELU_BWD)) {
-                const bf16_t* src = (EPI & EPI_RESID) ? q.R : q.U;
-                const int ld = (EPI & EPI_RESID) ? q.ldr : q.ldu;
-                const bf16_t* rp = src + (size_t)min(mrow + 16 * i, q.M - 1) * ld;   // clamped in range: a half that is out of range is never stored
-                pre[i][0] = *(const bf16x8*)(rp + min(ncol, q.N - 8));
-                pre[i][1] = *(const bf16x8*)(rp + min(ncol + 32, q.N - 8));
+                const uint32_t vo = voffP + (uint32_t)i * rowP;
+                pre[i][0] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rsP, vo, 0, 0));
+                pre[i][1] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rsP, vo + 64u, 0, 0));
             }
         };
 #pragma unroll
@@ -593,7 +603,9 @@ __global__ __launch_bounds__(512, 2) void gemm_nt8_kernel(const GemmNT p) {
                     if (dthr) {
 #pragma unroll
                         for (int k = 0; k < 4; ++k) {                // element pair k of the 8 columns: elements 2k, 2k + 1
-                            const uint32_t hb = mmb_pair_mix(seed0 + (uint32_t)i * seed_row + (uint32_t)(16 * h + k) * MMB_WEYL);
+                            uint32_t hb = mmb_pair_mix(seed0 + (uint32_t)i * seed_row + (uint32_t)(16 * h + k) * MMB_WEYL);
+                            asm("" : "+v"(hb));                      // the hash word as written (v_mul_lo + one SDWA fold): hipcc otherwise feeds the two 16-bit compares
+                                                                     // from y and y ^ (y << 16), i.e. a SECOND v_mul_lo_u32 by C << 16 and a v_xor per pair
                             f32x4& a4 = acc[i][2 * h + (k >> 1)];
                             const bool keep0 = (int16_t)(uint16_t)(hb & 0xFFFFu) >= (int16_t)(uint16_t)dthr_s;
                             const bool keep1 = (int16_t)(uint16_t)(hb >> 16) >= (int16_t)(uint16_t)dthr_s;
@@ -620,7 +632,9 @@ __global__ __launch_bounds__(512, 2) void gemm_nt8_kernel(const GemmNT p) {
                         bf16x8 u;
 #pragma unroll
                         for (int r = 0; r < 8; ++r) u[r] = f2bf(vv[r]);
-                        if (ok) *(bf16x8*)(q.aux + (size_t)m * q.ldaux + n) = u;
+                        const auto rsX = __builtin_amdgcn_make_buffer_rsrc((void*)q.aux, 0, (int)(um * (uint32_t)q.ldaux * 2u), 0x00020000);
+                        const uint32_t vo = ((uint32_t)mrow * (uint32_t)q.ldaux + (uint32_t)ncol) * 2u + (uint32_t)i * (32u * (uint32_t)q.ldaux) + (uint32_t)h * 64u;
+                        if (ok) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, u), rsX, vo, 0, 0);
                     }
 #pragma unroll
                     for (int r = 0; r < 8; r += 4) {                 // packed forms (common.h): bit-identical to gelu_erf, 5 instead of 8 VALU per element
@@ -645,13 +659,13 @@ __global__ __launch_bounds__(512, 2) void gemm_nt8_kernel(const GemmNT p) {
                 // -- the use of the prefetched residual row included -- into the predicated block, the prefetch loads stay "pending" on
                 // the path around it, and the NEXT tile's first fragment reads (which reuse those registers) get an s_waitcnt vmcnt(0):
                 // a drain of the previous epilogue's stores at every tile seam.
+                const uint32_t voC = voffC + (uint32_t)i * rowC + (uint32_t)h * (32u * CSZ);
                 if constexpr (EPI & EPI_OUT_F32) {
-                    float* c = (float*)q.C + (size_t)m * q.ldc + n;
                     f32x4 lo = {vv[0], vv[1], vv[2], vv[3]}, hi = {vv[4], vv[5], vv[6], vv[7]};
                     asm volatile("" : "+v"(lo), "+v"(hi));
                     if (ok) {
-                        *(f32x4*)c = lo;
-                        *(f32x4*)(c + 4) = hi;
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, lo), rsC, voC, 0, 0);
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, hi), rsC, voC + 16u, 0, 0);
                     }
                 } else {
                     bf16x8 o;
@@ -659,7 +673,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt8_kernel(const GemmNT p) {
                     for (int r = 0; r < 8; ++r) o[r] = f2bf(vv[r]);
                     u32x4 ow = __builtin_bit_cast(u32x4, o);
                     asm volatile("" : "+v"(ow));
-                    if (ok) *(u32x4*)((bf16_t*)q.C + (size_t)m * q.ldc + n) = ow;
+                    if (ok) __builtin_amdgcn_raw_buffer_store_b128(ow, rsC, voC, 0, 0);
                 }
             }
         }
@@ -719,8 +733,11 @@ enum { NTK_128 = 0, NTK_8PHASE = 3 };
 struct NTChoice { int kernel, bm, tiles, workgroups, group_m, use_queue; };
 
 // the 8-phase kernel: an even number (>= 4) of 64-deep K tiles, 32-bit buffer offsets
-static bool nt8_eligible(const GemmNT& p) {
-    return !(p.K & 127) && p.K >= 256 && (long long)p.M * p.lda < (1ll << 31) && (long long)p.N * p.ldb < (1ll << 31);
+static bool nt8_eligible(const GemmNT& p, int epi) {
+    // (the epilogue addresses C / R / U / aux as buffers too: M * pitch * element size below 2^32 bytes)
+    const long long m = p.M, esz = (epi & EPI_OUT_F32) ? 4 : 2;
+    return !(p.K & 127) && p.K >= 256 && m * p.lda < (1ll << 31) && (long long)p.N * p.ldb < (1ll << 31) && m * p.ldc * esz < (1ll << 32) &&
+           m * p.ldr * 2 < (1ll << 32) && m * p.ldaux * 2 < (1ll << 32) && m * p.ldu * 2 < (1ll << 32);
 }
 
 // Tile walk of the multi-tile form (ntp_tile_mn).  An XCD's 32 workgroups own a contiguous chunk of the walk (xcd_remap), i.e.
@@ -739,13 +756,13 @@ static int nt_group_m(int M, int N, int K, int bm, int tiles, int cus) {
     return ((M + bm - 1) / bm + 7) / 8;
 }
 
-static NTChoice nt_choose(const GemmNT& p, int /*epi*/) {
+static NTChoice nt_choose(const GemmNT& p, int epi) {
     NTChoice c = {NTK_128, 128, ((p.M + 127) / 128) * ((p.N + 127) / 128), 0, 1, 0};
     c.workgroups = c.tiles;
     const int force = g_nt_force.load();
     // the 256-wide pipeline needs enough rows and columns to fill its tiles, 16-byte epilogue accesses and an eligible K
     const bool big = (p.M >= 512) && (p.N >= 256) && !(p.N & 7) && !(p.ldc & 7) && !(p.ldr & 7) && !(p.ldaux & 7) && !(p.ldu & 7);
-    if (force == 1 || !nt8_eligible(p) || (p.N & 7) || (force == 0 && !big)) return c;
+    if (force == 1 || !nt8_eligible(p, epi) || (p.N & 7) || (force == 0 && !big)) return c;
     const int cus = device_cus(), tn = (p.N + 255) / 256;
     auto tiles_of = [&](int h) { return ((p.M + h - 1) / h) * tn; };
     const int t128 = tiles_of(128), t192 = tiles_of(192), t224 = tiles_of(224), t256 = tiles_of(256);
