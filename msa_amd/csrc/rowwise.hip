@@ -643,13 +643,40 @@ __global__ __launch_bounds__(WPB * 64) void ln_bwd_lean_kernel(const bf16_t* __r
 // passes of one launch sequence (same H, same block count) are folded into their gradients by ONE launch.
 // grid (ceil(H/64), items * 3, 8): a workgroup = 64 columns x 4 interleaved row groups over 1/8 of the partials, LDS-reduced, then
 // ONE atomic per column per workgroup (8 adders per address: no contention to speak of).
-struct LnReduceBatch { float* out[32][3]; const float* partial[32]; int nblocks[32]; int H, nq, items; };   // (nblocks per item: the calls of one launch may differ in rows)
+struct LnReduceBatch { float* out[32][3]; const float* partial[32]; int nblocks[32]; int H, nq, items, ordered; };   // (nblocks per item: the calls of one launch may differ in rows)
 __global__ __launch_bounds__(1024) void ln_bwd_reduce_batch_kernel(const LnReduceBatch b) {
     __shared__ float red[16][64];
     const int col = blockIdx.x * 64 + (threadIdx.x & 63), sub = threadIdx.x >> 6, nsub = (int)blockDim.x >> 6;
     const int item = blockIdx.y / b.nq, k = blockIdx.y - item * b.nq;
     float* out = b.out[item][k];
     if (out == nullptr) return;
+    if (b.ordered) {
+        // Deterministic mode (one z slice, 1024 threads).  Items that share a gradient (the joint embedding's LayerNorm runs once per pair
+        // modality, the MLM head's once per row chunk) are folded by the FIRST of them, in item order, and reach the gradient as ONE add:
+        // with one adder per item the arrival order decided the rounding as soon as the gradient held a value to accumulate onto
+        // (the second micro-batch of an accumulation step) or three items met.
+        for (int j = 0; j < item; ++j)
+            if (b.out[j][k] == out) return;                             // (workgroup-uniform)
+        float total = 0.f;
+        for (int it = item; it < b.items; ++it) {
+            if (b.out[it][k] != out) continue;
+            const float* partial = b.partial[it];
+            const int nblocks = b.nblocks[it];
+            float s = 0.f;
+            if (col < b.H)
+                for (int q = sub; q < nblocks; q += nsub) s += partial[((size_t)q * b.nq + k) * b.H + col];
+            red[sub][threadIdx.x & 63] = s;
+            __syncthreads();
+            if (sub == 0) {
+                float t = red[0][threadIdx.x];
+                for (int q = 1; q < nsub; ++q) t += red[q][threadIdx.x];
+                total += t;
+            }
+            __syncthreads();
+        }
+        if (sub == 0 && col < b.H) out[col] += total;                  // the only adder of this address
+        return;
+    }
     const float* partial = b.partial[item];
     const int nblocks = b.nblocks[item];
     const int per = (nblocks + gridDim.z - 1) / gridDim.z;
@@ -662,7 +689,7 @@ __global__ __launch_bounds__(1024) void ln_bwd_reduce_batch_kernel(const LnReduc
     if (sub == 0 && col < b.H) {
         float t = red[0][threadIdx.x];
         for (int q = 1; q < nsub; ++q) t += red[q][threadIdx.x];
-        atomicAdd(out + col, t);                                   // (deterministic mode: one z slice -- the only adder of this address)
+        atomicAdd(out + col, t);
     }
 }
 
@@ -1782,8 +1809,8 @@ int mmbert_ln_bwd(hipStream_t stream, const void* dy, int lddy, const int* dy_ro
     if (partial_ws && !defer_reduce) {
         LnReduceBatch b = {};
         b.out[0][0] = dgamma; b.out[0][1] = dbeta; b.out[0][2] = dbias2; b.partial[0] = partial_ws;
-        b.nblocks[0] = nblocks; b.H = H; b.nq = 3; b.items = 1;
-        hipLaunchKernelGGL(ln_bwd_reduce_batch_kernel, dim3((H + 63) / 64, 3, mmb_deterministic() ? 1 : 8), dim3(mmb_deterministic() ? 1024 : 256), 0, stream, b);
+        b.nblocks[0] = nblocks; b.H = H; b.nq = 3; b.items = 1; b.ordered = mmb_deterministic() ? 1 : 0;
+        hipLaunchKernelGGL(ln_bwd_reduce_batch_kernel, dim3((H + 63) / 64, 3, b.ordered ? 1 : 8), dim3(b.ordered ? 1024 : 256), 0, stream, b);
         MMB_CHECK_LAUNCH();
     }
     return 0;
@@ -1806,8 +1833,8 @@ static int ln_bwd_reduce_launch(hipStream_t stream, int items, const float* cons
         b.partial[i] = partial_ws[i];
         b.nblocks[i] = M > 0 ? ln_bwd_blocks(M, H) : 0;
     }
-    b.H = H; b.nq = 3; b.items = items;
-    hipLaunchKernelGGL(ln_bwd_reduce_batch_kernel, dim3((H + 63) / 64, items * 3, mmb_deterministic() ? 1 : 8), dim3(mmb_deterministic() ? 1024 : 256), 0, stream, b);
+    b.H = H; b.nq = 3; b.items = items; b.ordered = mmb_deterministic() ? 1 : 0;
+    hipLaunchKernelGGL(ln_bwd_reduce_batch_kernel, dim3((H + 63) / 64, items * 3, b.ordered ? 1 : 8), dim3(b.ordered ? 1024 : 256), 0, stream, b);
     MMB_CHECK_LAUNCH();
     return 0;
 }

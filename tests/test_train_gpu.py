@@ -470,6 +470,15 @@ def test_mosei_shape_trainer_loop_50_steps():
 
 
 def test_trained_state_gradients_match_oracle_without_calibrator():
+    from msa_amd import ops as _ops
+    was = _ops.deterministic()
+    try:
+        _trained_state_gradients()
+    finally:
+        _ops.set_deterministic(was)                              # (process-wide switch of the library)
+
+
+def _trained_state_gradients():
     """Round 4: every other oracle comparison runs at INITIALISATION weights (seeded N(0, 0.02)), where nce = 3 ln B exactly and the CPC
     gradients are residues of cancelling O(1) terms, softmax is flat and LayerNorm is (1, 0).  Here the comparison runs at a TRAINED
     state: 52 micro-batches = 26 optimizer steps of msa_amd.trainer.train_epoch (train mode, all dropouts, HF-AdamW, the reference's
@@ -488,6 +497,9 @@ def test_trained_state_gradients_match_oracle_without_calibrator():
     m = build(cfg, dropout=0.1)
     m.train()
     m.manual_seed(3)
+    # Deterministic mode (round 5): with fp32 atomics the 26-step trajectory is chaotic (see the alignment head's note below) and this
+    # test met a different trained state in every run -- one run in ~40 landed outside a bound.  Ordered sums make it ONE trajectory.
+    m.deterministic = True
     n_micro = 52
     args = T.default_args(train_batch_size=B, learning_rate=5e-4, mlm=True)
     opt, sched = T.build_optimizer(m, args, n_micro // 2, mode="hf")
@@ -516,7 +528,7 @@ def test_trained_state_gradients_match_oracle_without_calibrator():
     rep = {"moved_mean_abs": moved, "layernorm_off_one": ln_off, "losses": {}, "grads": {}}
     rel = lambda a, b: abs(float(a) - float(b)) / max(abs(float(b)), 1e-6)
     for i, name in ((0, "joint"), (4, "ap"), (5, "label"), (6, "nce")):
-        rep["losses"][name] = dict(ours=float(out[i]), oracle=float(oout[i]), rel=rel(out[i].detach(), oout[i].detach()))
+        rep["losses"][name] = dict(ours=float(out[i].detach()), oracle=float(oout[i].detach()), rel=rel(out[i].detach(), oout[i].detach()))
     rep["nce_minus_3lnB"] = float(oout[6]) - 3.0 * float(np.log(B))
     rep["logits_max_abs"] = float((logits.float().cpu() - ologits.detach()).abs().max())
     for n, g in ours.items():
@@ -776,8 +788,9 @@ def test_deterministic_mode_gives_bit_identical_steps(size):
     else:
         cfg, shape = dict(hidden=768, layers=12, heads=12, intermediate=3072, vocab=30522, dataset="mosei", alpha=1.0, beta=1.0), (4, 50, 500, 500)
     batch = batch_to(synthetic_batch(*shape, dataset="mosei", vocab=cfg["vocab"], seed=91), DEV)
+    batch2 = batch_to(synthetic_batch(*shape, dataset="mosei", vocab=cfg["vocab"], seed=92), DEV)
 
-    def run(flags=None, steps=0):
+    def run(flags=None, steps=0, accumulate=False):
         m = build(cfg, dropout=0.1)
         m.train()
         m.manual_seed(31)
@@ -786,6 +799,9 @@ def test_deterministic_mode_gives_bit_identical_steps(size):
                 m.train(v)
             else:
                 setattr(m, k, v)
+        if accumulate:                                            # a micro-batch whose gradients the timed one is accumulated onto
+            o0, _l0 = m(**batch2)
+            o0[0].mean().backward()
         out, logits = m(**batch)
         out[0].mean().backward()
         torch.cuda.synchronize()
@@ -812,6 +828,12 @@ def test_deterministic_mode_gives_bit_identical_steps(size):
         diff = [n for n in a["named"] if not torch.equal(a["named"][n], b["named"][n])]
         assert not diff, diff[:8]
         assert torch.equal(a["grads"], b["grads"]) and torch.equal(a["params"], b["params"])
+        # Gradient accumulation (the reference steps on every second micro-batch): adding onto NON-ZERO gradients is where several adders
+        # per address first show -- a + b == b + a, but (g + a) + b != (g + b) + a.  Round 5: the joint embedding's LayerNorm (one pass per
+        # pair modality, two items of one batched fold) differed in the last bit from the second micro-batch on.
+        c, d = run(accumulate=True), run(accumulate=True)
+        diff = [n for n in c["named"] if not torch.equal(c["named"][n], d["named"][n])]
+        assert not diff and torch.equal(c["grads"], d["grads"]), diff[:8]
         # same function, other launch paths, at the ORIGINAL tolerance: the weight gradients per layer pair instead of in one call (train
         # mode, the same masks), and -- in EVAL mode, where the packed row order does not select other dropout masks -- the exact-zero
         # short cuts off
