@@ -10,8 +10,8 @@ from msa_amd.data import synthetic_batch, batch_to
 from msa_amd import trainer as T, ops
 from msa_amd.model import MMBertConfig, MMBertForPretraining
 DEV = "cuda"
-cfg = dict(hidden=768, layers=2, heads=12, intermediate=3072, vocab=30522, dataset="mosei", alpha=1.0, beta=1.0)
-B = 8; n_micro = int(os.environ.get("N", 52)); REPS = int(os.environ.get("REPS", 4))
+cfg = dict(hidden=768, layers=int(os.environ.get("LAYERS", 2)), heads=12, intermediate=3072, vocab=30522, dataset="mosei", alpha=1.0, beta=1.0)
+B = int(os.environ.get("B", 8)); n_micro = int(os.environ.get("N", 52)); REPS = int(os.environ.get("REPS", 4))
 def build():
     c = MMBertConfig(vocab_size=cfg["vocab"], hidden_size=cfg["hidden"], num_hidden_layers=cfg["layers"], num_attention_heads=cfg["heads"],
                      intermediate_size=cfg["intermediate"], hidden_dropout_prob=0.1, attention_probs_dropout_prob=0.1)
