@@ -1,4 +1,4 @@
-"""Opcode mix of a kernel's hot loop, priced with the issue costs tools/ubench_valu.hip measured on MI355X (profiles/r5_ubench_valu.txt).
+"""Opcode mix of a kernel's hot loop, priced with the issue costs tools/ubench/ubench_valu.hip measured on MI355X (profiles/r5_ubench_valu.txt).
 
     python tools/isa_mix.py attention.hip attn_fwd_kernelILb1       # the loop with the most MFMAs of every kernel whose mangled name matches
     python tools/isa_mix.py gemm.hip 'gemm_nt8_kernelILi5ELb0ELi7' tail   # the code after the last MFMA (the epilogue)

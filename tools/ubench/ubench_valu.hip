@@ -1,7 +1,7 @@
 // VALU issue-cost microbenchmark (gfx950): shader cycles per instruction of the opcodes the GEMM epilogues and the attention kernels lean on.
 // 1, 2 and 4 waves per SIMD, 8 independent dependency chains per wave, so the figure is issue cost, not latency.  Cycles are s_memtime
 // (clock64) deltas of one wave, checked against the event time.
-//   hipcc --offload-arch=gfx950 -O3 -w tools/ubench_valu.hip -o /tmp/ubench_valu && /tmp/ubench_valu
+//   hipcc --offload-arch=gfx950 -O3 -w tools/ubench/ubench_valu.hip -o /tmp/ubench_valu && /tmp/ubench_valu
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdint>
