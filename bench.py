@@ -524,7 +524,7 @@ def reference_default_leg(a, dev, ops, wrap_state):
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
     rec = {"value": round(steps * B / el, 2), "unit": "samples/s", "ms_per_step": round(1e3 * el / steps, 3), "steps": steps,
-           "final_loss": round(float(last), 4),
+           "final_loss": round(float(last.detach()), 4),
            "workload": f"REF:train.py:28,32,38 defaults: bert-large ({L}-layer d={H} heads={heads} I={I}), T=P={T} (S = {T}/{2 * T}/{2 * T}), batch {B}, "
                        "train mode (dropout on), AdamW; pair-position MLM labels = copy of the text labels (REF:trainer.py:50,53)"}
     from msa_amd.model import _auto_defer_wgrads
