@@ -160,8 +160,13 @@ __device__ unsigned long long* g_attn_stamps = nullptr;
 #define ATT_STAMP(var)
 #endif
 
+// Four waves per SIMD (round 5): 122 VGPRs.  The kernel sat at 156-164 (three waves) because all 16 transposed V reads of a tile were issued in front
+// of the softmax block, 32 registers held across it beside the 32 score registers; read one 32-key slice at a time in front of its products
+// (the score registers are dead by then) it fits 128 without a spill, and the fourth wave is worth more than the hidden LDS latency:
+// forward -6 ... -7 % at the step's layout, bit-identical (profiles/r5_ab_attention_forward_4waves.log).  (Forcing the old body to 128 registers
+// spilled 20 and cost 25 %: r5_ab_attention_occupancy.log.)
 template <bool DROP>
-__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnArgs a) {
+__global__ __launch_bounds__(256, 4) void attn_fwd_kernel(const AttnArgs a) {
     __shared__ __attribute__((aligned(16))) char smem[2 * FWD_BUF];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -267,13 +272,6 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnArgs a) {
                 s[qb][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k1, qf[qb][1], s[qb][kt], 0, 0, 0);
             }
         }
-        // issue all transposed V reads of this tile now; they land while the softmax VALU work runs
-        u32x2 vlo[2][4], vhi[2][4];
-#pragma unroll
-        for (int d = 0; d < 4; ++d) {
-            tr_read<buf * FWD_BUF>(vlo[0][d], vaddr[d]); tr_read<buf * FWD_BUF + 16 * 128>(vhi[0][d], vaddr[d]);
-            tr_read<buf * FWD_BUF + 32 * 128>(vlo[1][d], vaddr[d]); tr_read<buf * FWD_BUF + 48 * 128>(vhi[1][d], vaddr[d]);
-        }
         bf16x8 pf[2][2];
         ATT_STAMP(st2)
 #pragma unroll
@@ -320,18 +318,26 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnArgs a) {
             }
         }
         ATT_STAMP(st3)
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the asm V reads
         __builtin_amdgcn_sched_barrier(0);
-        typedef __attribute__((ext_vector_type(8))) short s16x8;
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
+        for (int ks = 0; ks < 2; ++ks) {
+            // the transposed V reads of this 32-key slice (asm: see tr_read), then its products
+            u32x2 vlo[4], vhi[4];
 #pragma unroll
             for (int d = 0; d < 4; ++d) {
-                const bf16x8 vf = frag_of(vlo[ks][d], vhi[ks][d]);
+                if (ks == 0) { tr_read<buf * FWD_BUF>(vlo[d], vaddr[d]); tr_read<buf * FWD_BUF + 16 * 128>(vhi[d], vaddr[d]); }
+                else { tr_read<buf * FWD_BUF + 32 * 128>(vlo[d], vaddr[d]); tr_read<buf * FWD_BUF + 48 * 128>(vhi[d], vaddr[d]); }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+                const bf16x8 vf = frag_of(vlo[d], vhi[d]);
 #pragma unroll
                 for (int qb = 0; qb < 2; ++qb)
                     o[qb][d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[qb][ks], o[qb][d], 0, 0, 0);
             }
+        }
 #ifdef MMB_STAMPS
         ATT_STAMP(st4)
         t_wait += st1 - st0; t_qk += st2 - st1; t_soft += st3 - st2; t_pv += st4 - st3;
