@@ -38,7 +38,7 @@ for name, m, n, k, epi in shapes:
         outs[key] = out.float().clone()
     ts = {key: [] for key in LIBS}
     for r in range(rounds):
-        for key, lib in LIBS.items():
+        for key, lib in (list(LIBS.items()) if r % 2 == 0 else list(LIBS.items())[::-1]):     # alternating order: see ab_attn.py
             _lib._lib = lib
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
