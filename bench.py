@@ -51,7 +51,96 @@ def flops_per_sample(L, H, I, V, T, Pv, Pa, dv=35, ds=74):
     return sum(flop_parts(L, H, I, V, T, Pv, Pa, dv, ds).values())
 
 
+def smi_readings():
+    """sclk / mclk / power cap of GPU 0 as `rocm-smi` reports them, or the reason it did not answer.  Called at the very start of main(), BEFORE
+    this process touches the GPU: the tool is a child process, and a process that has initialised HIP must not spawn-and-exec on this pool."""
+    import re
+    import shutil
+    import subprocess
+    exe = shutil.which("rocm-smi") or "/opt/rocm/bin/rocm-smi"
+    if not os.path.exists(exe):
+        return {"error": "rocm-smi not found"}
+    try:
+        r = subprocess.run([exe, "-d", "0", "--showclocks", "--showmaxpower", "--showpower", "--showperflevel", "--json"], capture_output=True, text=True, timeout=8)
+        card = next(iter(json.loads(r.stdout).values()))
+    except Exception as e:                                         # no permission, a timeout, text instead of JSON: recorded, never fatal
+        return {"error": f"{type(e).__name__}: {str(e)[:120]}"}
+    pick = {}
+    for k, v in card.items():
+        kl = k.lower()
+        for tag, name in (("sclk", "sclk"), ("mclk", "mclk"), ("fclk", "fclk"), ("max graphics package power", "power_cap_w"), ("package power", "power_w"),
+                          ("performance level", "perf_level")):
+            if tag in kl and name not in pick:
+                m = re.search(r"[-+]?\d+(\.\d+)?", str(v))
+                pick[name] = v if name == "perf_level" else (float(m.group(0)) if m else str(v))
+    return pick or {"error": "no clock fields in rocm-smi's answer", "keys": list(card)[:8]}
+
+
+def box_probe(dev, ops, smi):
+    """Which box is this?  The boxes of the pool differ by 4-5 % on the train step and by ~10 % on attention backward, so
+    a driver line read against last round's means nothing without a yardstick taken on the same box.  Stand-alone microseconds (median of 5 after
+    2 warm-up launches, HIP events on the launch stream) of three FIXED launches -- the ones that separated the box classes in
+    profiles/r4_bench_final_profile_box.json against r4_bench_final.json -- on seeded operands, before anything else runs:
+      vocab_nt_us   the vocabulary NT GEMM of the step: [18400, 768] x [30592, 768]^T + bias -> bf16                 (0.865 TFLOP)
+      wgrad_tn44_us the 44-problem weight-gradient call: 11 layers x (W1, W2, Wqkv, Wo) at 13 850 rows               (2.15 TFLOP)
+      attn_bwd_us   attention backward at the step's layout: 16 x 50 + 32 x 550 tokens, 12 heads, dropout 0.1, all keys
+    `index` = the geometric mean of (reference microseconds / measured) over the three, reference = the FAST class of round 5
+    (REF_US below): 1.00 on such a box, ~0.95 on the slow class; `value_normalised` on the bench line is value / index."""
+    REF_US = {"vocab_nt_us": 800.0, "wgrad_tn44_us": 1880.0, "attn_bwd_us": 137.0}
+    H, I, heads, Vp, M, ra = 768, 3072, 12, 30592, 18400, 13850
+    g = torch.Generator(device=dev)
+    g.manual_seed(20260601)
+    bf = torch.bfloat16
+    rnd = lambda *s, scale=1.0: (torch.randn(*s, device=dev, generator=g) * scale).to(bf)
+
+    def med_us(fn, warm=2, reps=5):
+        for _ in range(warm):
+            fn()
+        ts = []
+        for _ in range(reps):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(); fn(); e1.record()
+            e1.synchronize()
+            ts.append(1e3 * e0.elapsed_time(e1))
+        return round(sorted(ts)[len(ts) // 2], 1)
+    out = {}
+    t0 = time.perf_counter()
+    A, W, bias = rnd(M, H), rnd(Vp, H, scale=0.02), torch.zeros(Vp, device=dev)
+    C = torch.empty((M, Vp), device=dev, dtype=bf)
+    out["vocab_nt_us"] = med_us(lambda: ops.gemm_nt(A, W, bias=bias, out=C))
+    del C, W
+    probs = []
+    for _ in range(11):
+        du, y1, dz, gg, dqkv, x = rnd(ra, I, scale=0.01), rnd(ra, H), rnd(ra, H, scale=0.01), rnd(ra, I), rnd(ra, 3 * H, scale=0.01), rnd(ra, H)
+        f32 = lambda *s: torch.empty(s, device=dev, dtype=torch.float32)
+        probs += [(du, y1, f32(I, H), f32(I)), (dz, gg, f32(H, I), f32(H)), (dqkv, x, f32(3 * H, H), f32(3 * H)), (dz, y1, f32(H, H), f32(H))]
+    out["wgrad_tn44_us"] = med_us(lambda: ops.gemm_tn_grouped(probs, accumulate=False), warm=1, reps=3)
+    del probs
+    lay = ops.SeqLayout([50] * 16 + [550] * 32, heads, dev)
+    qkv, dctx = rnd(lay.tokens, 3 * H), rnd(lay.tokens, H, scale=0.01)
+    kb = ops.pad_key_bias(torch.zeros(lay.tokens, device=dev), lay)
+    drop = ops.make_drop(0.1, 1234, 7)
+    ctx, lse = ops.attn_fwd(qkv, kb, lay, H, drop=drop)
+    dqkv = torch.empty_like(qkv)
+    out["attn_bwd_us"] = med_us(lambda: ops.attn_bwd(qkv, ctx, dctx, lse, kb, lay, H, drop=drop, dqkv=dqkv))
+    idx = 1.0
+    for k, ref in REF_US.items():
+        idx *= ref / out[k]
+    out["index"] = round(idx ** (1.0 / 3.0), 4)
+    out["reference_us"] = REF_US
+    out["note"] = ("stand-alone us of three fixed launches taken before the headline (median of 3-5, HIP events); index = geometric mean of reference / measured, "
+                   "reference = the fast box class of round 5")
+    props = torch.cuda.get_device_properties(dev)
+    out["device"] = {"name": props.name, "cus": props.multi_processor_count, "clock_rate_khz": getattr(props, "clock_rate", None)}
+    out["smi"] = smi
+    torch.cuda.synchronize()
+    out["probe_seconds"] = round(time.perf_counter() - t0, 3)
+    torch.cuda.empty_cache()
+    return out
+
+
 def main():
+    smi = smi_readings() if int(os.environ.get("RANK", 0)) == 0 else None      # (a child process: before anything here initialises HIP)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -88,6 +177,7 @@ def main():
                     "(bert-large: 24-layer d=1024, T=P=40, batch 32: REF:train.py:28,32,38)")
     ap.add_argument("--preset", choices=["headline", "reference-default"], default="headline",
                     help="reference-default: measure ONLY the reference's default model and print its record (tools; never the driver's line)")
+    ap.add_argument("--no-box-probe", action="store_true", help="skip the three fixed yardstick launches in front of the headline (the `box` object)")
     ap.add_argument("--rank-report", action="store_true", help="N > 1 diagnostics even on one process: per-rank step times, exposed tail (on by default for N > 1)")
     a = ap.parse_args()
 
@@ -116,6 +206,8 @@ def main():
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {a.gpus}")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+
+    box = box_probe(dev, ops, smi) if (rank == 0 and not a.no_box_probe) else None
 
     timing = {"nt": [], "tn": [], "attn_fwd": [], "attn_bwd": []}
     record = [False]
@@ -226,6 +318,7 @@ def main():
     last = None
     for i in range(a.steps):
         last = step(a.warmup + i)
+    host_enqueued = time.perf_counter() - t0              # every call of the K steps has RETURNED: the host's side of the region (queue busy)
     torch.cuda.synchronize()
     own_done = time.perf_counter() - t0                   # this rank's GPU is done (the contract's value is taken behind the barrier)
     barrier()
@@ -307,7 +400,7 @@ def main():
                                            "(REF:MMBertForPretraining.py:445-449); same losses and gradients as the headline step")
 
     # Secondary: model.deterministic = True -- ordered sums instead of fp32 atomics (CE loss sums, the heads' skinny products, bias /
-    # LayerNorm partial sums, the embedding scatter through sorted keys): bit-identical losses and gradients run to run
+    # LayerNorm partial sums, the embedding scatter through per-id run sums): bit-identical losses and gradients run to run
     # (tests/test_train_gpu.py::test_deterministic_mode_gives_bit_identical_steps); what it costs in the step is this leg against the headline.
     det_leg = None
     if not a.no_deterministic:
@@ -415,6 +508,10 @@ def main():
                    "backward_row_fraction": round(f, 4),
                    "backward_rows": "rows behind a sequence's last unmasked key and without a label have zero gradients in every layer: backward skips them (exact)"},
         "final_loss": round(loss, 4),
+        # the host's share of the headline region: wall time until the last step() call returned (the GPU still has queued work then);
+        # ms_per_step - host_enqueue_ms = how far ahead of the GPU the host runs.  Under the data-parallel wrapper this includes its hooks
+        # and RCCL's host calls (config.dp.host_enqueue_ms: VERDICT r5 item 8)
+        "host_enqueue_ms": round(1e3 * host_enqueued / a.steps, 3),
         "step_mfma_frac": round(fps_exec * value / world / 2.5e15, 4),
     }
     if dp is not None:
@@ -424,9 +521,13 @@ def main():
                                                         if dp.early_word else "with the tail"),
                                "all_reduce_calls_per_step": dp.bucketer.calls_per_step if hasattr(dp.bucketer, "calls_per_step") else None,
                                "per_rank_ms_per_step": per_rank_ms,
+                               "host_enqueue_ms": round(1e3 * host_enqueued / a.steps, 3),
                                "exposed_tail_us": exposed_tail(tail_events, world, dev),
                                "exposed_tail_note": "GPU time of the compute stream inside finish_backward() (instrumented leg): what of the "
                                                     "gradient exchange is NOT hidden under backward -- the last bucket, the compact row exchange, the waits"}
+    if box is not None:
+        res["box"] = box
+        res["value_normalised"] = round(value / box["index"], 2)      # what this step would read on the reference (fast) box class
     if dense_ref is not None:
         res["dense_backward_reference"] = dense_ref
     if dense_ref is not None:

@@ -53,7 +53,8 @@ static inline int mmb_device_cus() {
 // mmbert_set_deterministic (rowwise.hip defines the flag; one .so): 1 = every fp32 sum of the library is formed in an order that does not
 // depend on how workgroups are scheduled -- slabs + ordered reduces (or a single adder per address) instead of fp32 atomics whose arrival
 // order varies: the CE loss sums, the heads' skinny products, the weight-gradient kernel's bias sums (no token split), the LayerNorm
-// partial-sum fold, column sums; the embedding scatter and the data-parallel row block go through mmbert_segment_sum_rows.
+// partial-sum fold, column sums; the embedding scatter and the data-parallel row block go through mmbert_id_runs_sum_rows
+// (no sort: one workgroup per row, the first row of an id collects the id's rows in ascending order and adds them once).
 extern std::atomic<int> g_mmb_deterministic;
 static inline bool mmb_deterministic() { return g_mmb_deterministic.load(std::memory_order_relaxed) != 0; }
 

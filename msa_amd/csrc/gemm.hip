@@ -554,12 +554,14 @@ __global__ __launch_bounds__(512, 2) void gemm_nt8_kernel(const GemmNT p) {
         // per access (v_mad_i64_i32 + v_lshl_add_u64 + moves: 98 of FFN-up's 985 epilogue instructions).  Rows past M are past the
         // descriptor's range: their loads return 0 and nothing of them is stored (`ok` below), so the row clamp is gone too.
         constexpr uint32_t CSZ = (EPI & EPI_OUT_F32) ? 4u : 2u;
-        const uint32_t um = (uint32_t)q.M;
-        const auto rsC = __builtin_amdgcn_make_buffer_rsrc((void*)q.C, 0, (int)(um * (uint32_t)q.ldc * CSZ), 0x00020000);
+        // (descriptor range = up to the LAST VALID element, (M - 1) ld + N: with a strided view (ld > N) nothing behind row M - 1's N columns
+        // is readable -- a view that ends at its parent allocation's end must not be read past it)
+        const uint32_t um = (uint32_t)q.M, um1 = um ? um - 1u : 0u, un = um ? (uint32_t)q.N : 0u;
+        const auto rsC = __builtin_amdgcn_make_buffer_rsrc((void*)q.C, 0, (int)((um1 * (uint32_t)q.ldc + un) * CSZ), 0x00020000);
         const uint32_t voffC = ((uint32_t)mrow * (uint32_t)q.ldc + (uint32_t)ncol) * CSZ, rowC = 16u * (uint32_t)q.ldc * CSZ;
         const bf16_t* presrc = (EPI & EPI_RESID) ? q.R : q.U;
         const uint32_t preld = (uint32_t)((EPI & EPI_RESID) ? q.ldr : q.ldu);
-        const auto rsP = __builtin_amdgcn_make_buffer_rsrc((void*)presrc, 0, (int)((EPI & (EPI_RESID | EPI_GELU_BWD)) ? um * preld * 2u : 0u), 0x00020000);
+        const auto rsP = __builtin_amdgcn_make_buffer_rsrc((void*)presrc, 0, (int)((EPI & (EPI_RESID | EPI_GELU_BWD)) ? (um1 * preld + un) * 2u : 0u), 0x00020000);
         const uint32_t voffP = ((uint32_t)mrow * preld + (uint32_t)ncol) * 2u, rowP = 32u * preld;
         auto load_pre = [&](int i) {
             if constexpr (EPI & (EPI_RESID | EPI_GELU_BWD)) {
@@ -632,7 +634,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt8_kernel(const GemmNT p) {
                         bf16x8 u;
 #pragma unroll
                         for (int r = 0; r < 8; ++r) u[r] = f2bf(vv[r]);
-                        const auto rsX = __builtin_amdgcn_make_buffer_rsrc((void*)q.aux, 0, (int)(um * (uint32_t)q.ldaux * 2u), 0x00020000);
+                        const auto rsX = __builtin_amdgcn_make_buffer_rsrc((void*)q.aux, 0, (int)((um1 * (uint32_t)q.ldaux + un) * 2u), 0x00020000);
                         const uint32_t vo = ((uint32_t)mrow * (uint32_t)q.ldaux + (uint32_t)ncol) * 2u + (uint32_t)i * (32u * (uint32_t)q.ldaux) + (uint32_t)h * 64u;
                         if (ok) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, u), rsX, vo, 0, 0);
                     }
@@ -1356,7 +1358,7 @@ size_t mmbert_gemm_tn_workspace(int M, int N, int K, int* splits_out) {
     return mmbert_gemm_tn_grouped_workspace(1, &N, &K, M, splits_out);
 }
 
-// up to TN_MAXP (8) problems sharing M:  W_i[N_i,K_i] (+)= alpha * A_i^T . B_i ;  bias_i[N_i] += alpha * colsum(A_i) (bias_i may be null)
+// up to TN_MAXP (48) problems sharing M:  W_i[N_i,K_i] (+)= alpha * A_i^T . B_i ;  bias_i[N_i] += alpha * colsum(A_i) (bias_i may be null)
 int mmbert_gemm_tn_grouped(hipStream_t stream, int nprob, const void* const* A, const int* lda, const void* const* B, const int* ldb,
                            float* const* W, float* const* bias, const int* N, const int* K, int M,
                            int accumulate, float alpha, const float* alpha_dev, void* slab) {

@@ -1863,7 +1863,7 @@ int mmbert_embed_scatter(hipStream_t stream, const int64_t* ids, const int64_t* 
     if (n <= 0) return 0;
     if (H > LN_MAXV * 256 || (H & 3) || (ldd & 3) || T <= 0) return -1;
     // deterministic mode: the word rows cannot come from this kernel (a word at several positions: atomics in arrival order -- the caller
-    // uses mmbert_sorted_runs_sum_rows) and the token-type sums need the slab (2 * T * H floats)
+    // uses mmbert_id_runs_sum_rows) and the token-type sums need the slab (2 * T * H floats)
     if (mmb_deterministic() && (gword != nullptr || type_slab == nullptr)) return -4;
     constexpr int slices = 1;   // grid.y slices of the sequences; measured at the headline shape: 1 / 2 / 4 / 8 = 37.8 / 39.1 / 49.0 / 59.2 us (same-address atomics on the two token-type rows)
     hipLaunchKernelGGL(embed_scatter_kernel, dim3(T < n ? T : n, slices), dim3(256), 0, stream, ids, tts, (const bf16_t*)d, ldd, n, T, H, V, gword, gtype, gpos, type_slab);

@@ -233,8 +233,8 @@ def _auto_defer_wgrads(H, I, L, x_dev, rows=None) -> bool:
     The price is memory: the eight operands of every dense layer -- rows x (2 I + 8 H) bf16, 0.34 GB per layer at the headline shape, 3.7 GB
     for eleven layers -- stay alive until the end of backward.  ``rows`` (the backward's row count) given: the deferral is taken only
     while that fits into HALF of what the device still has (the driver's free memory + torch's cached-but-free blocks; one query per
-    (shape, depth), cached) -- a configuration that fits with the paired launches must not run out of memory because of a 0.7 %
-    scheduling gain.  MMBERT_DEFER_WGRADS=0/1 (read at import) and model.defer_wgrads = True / False override the rule."""
+    (shape, depth, 2048-row class), cached for 256 queries) -- a configuration that fits with the paired launches must not run out of
+    memory because of a 0.7 % scheduling gain.  In deterministic mode the rule is the shape alone.  MMBERT_DEFER_WGRADS=0/1 (read at import) and model.defer_wgrads = True / False override the rule."""
     key = str(x_dev)
     cus = _cu_count.get(key)
     if cus is None:
@@ -243,16 +243,19 @@ def _auto_defer_wgrads(H, I, L, x_dev, rows=None) -> bool:
     t = 2 * c(I) * c(H) + c(3 * H) * c(H) + c(H) * c(H)            # 256 x 256 tiles of a layer's four weight gradients
     if not (L > 2 and (L - 1) * t >= cus):
         return False
-    if rows is None:
+    if rows is None or ops.deterministic():
+        # deterministic mode: the two forms differ in fp32 summation order (the paired form splits layer 0's token axis), so the choice must
+        # not depend on how much memory happens to be free at the first query -- by shape only (model.defer_wgrads overrides)
         return True
     fk = (key, H, I, L, -(-int(rows) // 2048))                       # (row counts vary from batch to batch: 2048-row classes)
-    fits = _defer_fits.get(fk)
-    if fits is None:
+    ent = _defer_fits.get(fk)
+    if ent is None or ent[1] <= 0:                                    # (the answer is re-taken every 256 queries: memory fills up and empties over a run)
         need = L * (fk[4] * 2048) * (2 * I + 8 * H) * 2
         free, _total = torch.cuda.mem_get_info(x_dev)
         cached = torch.cuda.memory_reserved(x_dev) - torch.cuda.memory_allocated(x_dev)
-        fits = _defer_fits[fk] = need <= 0.5 * (free + cached)
-    return fits
+        ent = _defer_fits[fk] = [need <= 0.5 * (free + cached), 256]
+    ent[1] -= 1
+    return ent[0]
 
 
 def _wgrad(top, probs):
@@ -1610,7 +1613,7 @@ class MMBertForPretraining(_GpuModelBase):
         self.cls.predictions.decoder.weight = self.bert.embeddings.word_embeddings.weight
 
     # ``model.deterministic = True``: every fp32 sum of the step is formed in an order that does not depend on how workgroups are
-    # scheduled (slabs + ordered reduces, sorted-key segment sums, a single adder per address) instead of fp32 atomics in arrival order:
+    # scheduled (slabs + ordered reduces, per-id run sums in ascending row order (mmbert_id_runs_sum_rows), a single adder per address) instead of fp32 atomics in arrival order:
     # the same seeded step gives bit-identical losses and gradients run to run, and two launch paths of the same function agree more
     # tightly (tests/test_train_gpu.py).  Process-global (the library's mmbert_set_deterministic; MMBERT_DETERMINISTIC=1 sets it at
     # import); costs ~ a dozen small launches per step.

@@ -309,6 +309,8 @@ class LnDeferred:
         whatever would make slot() flush within those calls -- another H, the slot count, a workspace that has to grow -- happens here,
         while every slot taken so far has been launched."""
         per = _lib.load().mmbert_ln_bwd_workspace(M, H)
+        self.slots = min(32, max(self.slots, int(n)))            # (n > slots would make the n-th slot() flush the first ones: ADVICE r5)
+        assert n <= self.slots, "LnDeferred.reserve: at most 32 slots per reduce launch"
         if self.H is not None and (H != self.H or len(self.items) + n > self.slots):
             self.flush()
         ck = (device, _stream())
@@ -348,7 +350,8 @@ def embed_gather(ids, tts, word, type_, pos, T, out=None):
 
 def set_deterministic(on: bool) -> None:
     """Process-global (mmbert_set_deterministic): ordered sums instead of fp32 atomics everywhere in the library; the scatter-adds with
-    data-dependent collisions (embed_scatter's word / token-type rows, rows_to_block) switch to sorted keys + segment_sum_rows here."""
+    data-dependent collisions (embed_scatter's word / token-type rows, rows_to_block) go through mmbert_id_runs_sum_rows here (no sort: the first row of an id
+    collects the id's rows in ascending order and adds them once; O(n^2) id compares per launch, n <= 8192)."""
     _lib.load().mmbert_set_deterministic(1 if on else 0)
 
 
@@ -398,7 +401,7 @@ def embed_scatter(ids, tts, d, T, gword, gtype, gpos, vocab=None):
     slab = None
     if deterministic():
         # position sums: a single adder per address in the kernel; token-type sums: per-position partials in a slab, folded in position
-        # order; word rows (a word at several positions would be atomics in arrival order): sorted keys + ordered run sums
+        # order; word rows (a word at several positions would be atomics in arrival order): per-id run sums (mmbert_id_runs_sum_rows)
         slab = _ws_f32(2 * T * H, d.device)
         if gword is not None:
             scatter_add_rows_ordered(ids, d, gword, V)

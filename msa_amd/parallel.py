@@ -307,8 +307,26 @@ class DataParallel:
         return self.model(*a, **k)
 
 
+def _ordered_scatter(rows: torch.Tensor) -> bool:
+    """Deterministic mode (model.deterministic / mmbert_set_deterministic) on GPU rows: duplicate ids must not go through
+    ``index_add_`` (fp32 atomics in arrival order on HIP) -- the ordered kernel (mmbert_id_runs_sum_rows) takes them."""
+    if not rows.is_cuda:
+        return False
+    from . import ops
+    if not ops.deterministic():
+        return False
+    if rows.dtype not in (torch.bfloat16, torch.float32) or rows.stride(1) != 1:
+        raise RuntimeError("deterministic mode: the row gradients must be contiguous bf16 / fp32 rows for the ordered scatter")
+    return True
+
+
 def _scatter_rows(table: torch.Tensor, ids: torch.Tensor, rows: torch.Tensor):
     """table[ids[i]] += rows[i] for ids in (0, V) -- row 0 is the padding row of the lookup (HF:58, no gradient)."""
+    ids = ids.reshape(-1)
+    if _ordered_scatter(rows):
+        from . import ops
+        ops.scatter_add_rows_ordered(ids, rows, table, table.shape[0])
+        return
     keep = (ids > 0) & (ids < table.shape[0])
     table.index_add_(0, ids.clamp(0, table.shape[0] - 1), rows.to(table.dtype) * keep[:, None].to(table.dtype))
 
@@ -352,6 +370,7 @@ def exchange_rows(ids: torch.Tensor, rows: torch.Tensor, vocab: int, group=None,
             from . import ops                                  # one kernel (mmbert_rows_to_block) for the eleven launches of the torch form
             ops.rows_to_block(ids, rows, union, vocab, block)
         else:
+            _ordered_scatter(rows)                             # deterministic mode: GPU rows the ordered kernel cannot take raise here
             mine = (ids > 0) & (ids < vocab)
             pos = torch.searchsorted(union, ids.clamp(0, vocab - 1)).clamp(max=union.numel() - 1)
             block.index_add_(0, pos, rows.to(torch.float32) * mine[:, None].to(torch.float32))

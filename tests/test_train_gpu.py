@@ -643,22 +643,31 @@ def _nccl_world1_worker(port, q):
         assert cerr < 2e-3, cerr
         assert not dp._unions and not dp._unions_cut
         # ... and in deterministic mode the whole data-parallel step (row block through the ordered id-run sums) is bit-reproducible
+        # -- also through the two paths that scatter the lookup's rows LOCALLY (round 6, ADVICE r5: they called index_add_ with duplicate ids,
+        # fp32 atomics in arrival order): a no_sync() accumulation micro-step in front of the exchanged one (DataParallel._fold_rows_locally),
+        # and finish_backward() without an early word exchange (early_word_embedding=False)
         ops.set_deterministic(True)
-        det = []
-        for _ in range(2):
-            m = build(cfg, dropout=0.1)
-            m.train()
-            m.manual_seed(5)
-            opt, sched = T.build_optimizer(m, T.default_args(train_batch_size=4, learning_rate=1e-3), 4)
-            dp = parallel.DataParallel(m, opt, bucket_mb=0.5, force_dynamic_queue=True)
-            out, _ = m(**batch)
-            out[0].mean().backward()
-            dp.finish_backward()
-            torch.cuda.synchronize()
-            det.append(m._flat.grads.clone())
+        batch_b = batch_to(synthetic_batch(4, 24, 200, 130, dataset="mosei", vocab=cfg["vocab"], seed=32), "cuda")
+        for variant in ("plain", "no_sync_then_step", "no_early_word"):
+            det = []
+            for _ in range(2):
+                m = build(cfg, dropout=0.1)
+                m.train()
+                m.manual_seed(5)
+                opt, sched = T.build_optimizer(m, T.default_args(train_batch_size=4, learning_rate=1e-3), 4)
+                dp = parallel.DataParallel(m, opt, bucket_mb=0.5, force_dynamic_queue=True, early_word_embedding=variant != "no_early_word")
+                if variant == "no_sync_then_step":
+                    with dp.no_sync():
+                        o0, _ = m(**batch_b)
+                        o0[0].mean().backward()
+                out, _ = m(**batch)
+                out[0].mean().backward()
+                dp.finish_backward()
+                torch.cuda.synchronize()
+                det.append(m._flat.grads.clone())
+            assert torch.equal(det[0], det[1]), variant
         ops.set_deterministic(False)
         ops.dynamic_tile_queue = False
-        assert torch.equal(det[0], det[1])
         q.put(("ok", err, float(b.abs().max()), werr))
         dist.destroy_process_group()
     except Exception as e:                                                            # pragma: no cover
