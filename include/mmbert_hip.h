@@ -32,9 +32,10 @@ typedef struct ihipStream_t* mmbert_stream_t;   /* == hipStream_t */
 
 /* ---- GEMM epilogue flags (mmbert_gemm_nt.epi) ---- */
 #define MMBERT_EPI_BIAS 1      /* + bias[N] (fp32)                                             */
-#define MMBERT_EPI_GELU 2      /* out = gelu_erf(v); aux (optional) = v      HF:334-337         */
+#define MMBERT_EPI_GELU 2      /* out = gelu_erf(v); aux (optional) = gelu_erf'(v), bf16 -- the factor the backward multiplies by   HF:334-337 */
 #define MMBERT_EPI_RESID 4     /* out = dropout(v) + R                       HF:289-293,347-351 */
-#define MMBERT_EPI_GELU_BWD 8  /* out = v * gelu'(U)   (dgrad of the FFN down projection)       */
+#define MMBERT_EPI_GELU_BWD 8  /* out = v * U, U = the forward launch's aux (dgrad of the FFN down projection; round 6: aux / U hold
+                                  gelu' of the pre-activation, not the pre-activation -- the backward epilogue is one multiply) */
 #define MMBERT_EPI_OUT_F32 16  /* C is fp32 instead of bf16                                     */
 
 /* C[M,N] = epi(alpha * alpha_dev[0] * A[M,K] . B[N,K]^T).  Replaces nn.Linear forward (HF:175-177,
@@ -141,10 +142,12 @@ int mmbert_embed_scatter(mmbert_stream_t stream, const int64_t* ids, const int64
                          float* gword, float* gtype, float* gpos, float* type_slab);
 
 /* JointEmbeddings pair projection relu(W.feat + b) written after the text rows of each sample:
- * out[(b*(T+P) + T + p)] (REF:MMBertEmbedding.py:61-68); bwd accumulates dW, db. */
-int mmbert_pair_proj_fwd(mmbert_stream_t stream, const float* feat, int B, int P, int D, const float* W, const float* bias, int H,
+ * out[(b*(T+P) + T + p)] (REF:MMBertEmbedding.py:61-68); bwd accumulates dW, db.
+ * feat: [B*P, D] contiguous, fp32 -- or float64 with feat_f64 != 0: the reference's collate produces float64 features
+ * (REF:model_utils.py:94-99) and JointEmbeddings casts them with .float() (REF:MMBertEmbedding.py:62,64); the kernels round on load. */
+int mmbert_pair_proj_fwd(mmbert_stream_t stream, const void* feat, int feat_f64, int B, int P, int D, const float* W, const float* bias, int H,
                          void* out, int ldo, int T);
-int mmbert_pair_proj_bwd(mmbert_stream_t stream, const float* feat, int B, int P, int D, const void* J, const void* dJ, int ld, int T,
+int mmbert_pair_proj_bwd(mmbert_stream_t stream, const void* feat, int feat_f64, int B, int P, int D, const void* J, const void* dJ, int ld, int T,
                          float* dW, float* db, int H, void* workspace /* mmbert_pair_proj_bwd_workspace() bytes */);
 size_t mmbert_pair_proj_bwd_workspace(int B, int P, int D, int H);
 
@@ -364,7 +367,8 @@ int mmbert_id_runs_sum_rows(mmbert_stream_t stream, const void* src, int src_bf1
 int mmbert_adamw(mmbert_stream_t stream, float* p, float* g, float* m, float* v, void* p_bf16, const uint8_t* flags, size_t n,
                  double lr, double beta1, double beta2, double eps, double wd, int step, double gscale, int mode, int zero_grad);
 
-/* du = dy * gelu_erf'(u), contiguous bf16 (BertPredictionHeadTransform backward, HF:476-480) */
+/* du = dy * u, u = the aux output (gelu_erf' of the pre-activation) of the forward MMBERT_EPI_GELU launch; contiguous bf16
+ * (BertPredictionHeadTransform backward, HF:476-480) */
 int mmbert_gelu_bwd(mmbert_stream_t stream, const void* dy, const void* u, void* du, size_t n);
 
 int mmbert_cast_f32_bf16(mmbert_stream_t stream, const float* x, void* y, size_t n);

@@ -39,8 +39,8 @@ SIGNATURES = {
     "mmbert_ln_bwd_workspace": (SZ, [I, I]),
     "mmbert_embed_gather": (I, [P, P, P, P, P, P, I, I, I, I, P, I]),
     "mmbert_embed_scatter": (I, [P, P, P, P, I, I, I, I, I, P, P, P, P]),
-    "mmbert_pair_proj_fwd": (I, [P, P, I, I, I, P, P, I, P, I, I]),
-    "mmbert_pair_proj_bwd": (I, [P, P, I, I, I, P, P, I, I, P, P, I, P]),
+    "mmbert_pair_proj_fwd": (I, [P, P, I, I, I, I, P, P, I, P, I, I]),
+    "mmbert_pair_proj_bwd": (I, [P, P, I, I, I, I, P, P, I, I, P, P, I, P]),
     "mmbert_pair_proj_bwd_workspace": (SZ, [I, I, I, I]),
     "mmbert_attn_tile_rows": (I, [I]),
     "mmbert_attn_kv_len": (I, [P, P, P, P, I, P]),

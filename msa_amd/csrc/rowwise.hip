@@ -780,8 +780,10 @@ __global__ __launch_bounds__(256) void embed_scatter_kernel(const int64_t* __res
 // round 2: 64 x 64 tile with scalar LDS reads, 28 / 43 us; round 4: 128 x 64 tile, K-major LDS, three ds_read_b128 per 32 FMAs,
 // 23 / 35 us stand-alone, 30 / 43 us in the step's trace, against a scalar-FMA floor of 5.5 / 11.6 us; this form: 15 / 25 us by
 // rocprofv3 (tools/r4_s3_pairprof.sh, profiles/r4_pair_proj.log).)
-template <int KSHIFT>
-__global__ __launch_bounds__(256) void pair_proj_fwd_kernel(const float* __restrict__ feat, int n_rows, int P, int D,
+// FT = float, or double: the reference's collate hands the pair features over as float64 (REF:model_utils.py:94-99) and casts them in
+// JointEmbeddings.forward (REF:MMBertEmbedding.py:62,64: `.float()`): read as they are and rounded on load, the cast launches are gone.
+template <int KSHIFT, typename FT>
+__global__ __launch_bounds__(256) void pair_proj_fwd_kernel(const FT* __restrict__ feat, int n_rows, int P, int D,
                                                             const float* __restrict__ W, const float* __restrict__ bias, int H,
                                                             bf16_t* __restrict__ out, int ldo, int T, int KC, int pitch) {
 #if defined(__gfx950__)
@@ -813,11 +815,11 @@ __global__ __launch_bounds__(256) void pair_proj_fwd_kernel(const float* __restr
         const float kmask = kl < kc ? 1.f : 0.f;
         const int kg = min(k0 + kl, D - 1);                             // always in range: the load is not predicated (a product, not a
         const bool kst = kl < kc4;                                       // select, zeroes the padding: see pair_wgrad_kernel)
-        auto stage = [&](const float* __restrict__ base, int g0, int lim, int lrow0, auto nrows_c) {
+        auto stage = [&](auto base, int g0, int lim, int lrow0, auto nrows_c) {
             constexpr int N = decltype(nrows_c)::value / rstep, NB = N < 32 ? N : 32;
 #pragma unroll 1
             for (int ub = 0; ub < N; ub += NB) {
-                float v[NB];
+                std::remove_cv_t<std::remove_reference_t<decltype(base[0])>> v[NB];       // (float, or double: converted behind the last load)
 #pragma unroll
                 for (int u = 0; u < NB; ++u) {
                     const int gr = g0 + rsub + (ub + u) * rstep;
@@ -827,7 +829,7 @@ __global__ __launch_bounds__(256) void pair_proj_fwd_kernel(const float* __restr
 #pragma unroll
                     for (int u = 0; u < NB; ++u) {
                         const int r = rsub + (ub + u) * rstep;
-                        pair_sm[(lrow0 + r) * pitch + kl] = v[u] * (g0 + r < lim ? kmask : 0.f);
+                        pair_sm[(lrow0 + r) * pitch + kl] = (float)v[u] * (g0 + r < lim ? kmask : 0.f);
                     }
                 }
             }
@@ -920,9 +922,10 @@ __global__ __launch_bounds__(256) void pair_proj_fwd_kernel(const float* __restr
 //     (deterministic: no atomics).
 // (Round 1: a scalar-FMA kernel with one atomicAdd per weight and row chunk, 300 us for D = 74 at 8000 rows; rounds 2-4: a bf16 hi / lo
 // split of the features through the grouped TN kernel, four launches and 49 us; this form: two launches, 26 + 4.5 us.)
-struct PairBwdArgs { const float* feat; const bf16_t* J; const bf16_t* dJ; float* slab; int n, P, D, T, H, ld, rows_per_wg, ntiles; };
+struct PairBwdArgs { const void* feat; const bf16_t* J; const bf16_t* dJ; float* slab; int n, P, D, T, H, ld, rows_per_wg, ntiles; };
 constexpr int PAIR_NT = 5;                       // feature-column tiles (16 columns) per workgroup: D + 1 <= 80 in one pass, more on grid.z
 
+template <typename FT>
 __global__ __launch_bounds__(256) void pair_wgrad_kernel(const PairBwdArgs a) {
 #if defined(__gfx950__)
     __shared__ float red[3][PAIR_NT * 16][64];
@@ -941,14 +944,14 @@ __global__ __launch_bounds__(256) void pair_wgrad_kernel(const PairBwdArgs a) {
         const size_t off = (size_t)(b_ * (a.T + a.P) + a.T + p_) * a.ld + (hok ? hcol : 0);
         st.j = *(const bf16x4*)(a.J + off);
         st.d = *(const bf16x4*)(a.dJ + off);
-        const float* fr = a.feat + (size_t)rc * a.D;
+        const FT* fr = (const FT*)a.feat + (size_t)rc * a.D;
 #pragma unroll
         for (int j = 0; j < PAIR_NT; ++j) {
             const int k = (jt0 + j) * 16 + c;
             // (arithmetic, not a select, on the loaded value: hipcc sinks a load whose only use is one arm of a select into a branch
             // of its own, and every such branch ends in s_waitcnt vmcnt(0) -- the ring would hold one load at a time)
             const float live = (ok && j < njt) ? 1.0f : 0.0f;
-            st.f[j] = fmaf(fr[min(k, a.D - 1)], k < a.D ? live : 0.0f, k == a.D ? live : 0.0f);
+            st.f[j] = fmaf((float)fr[min(k, a.D - 1)], k < a.D ? live : 0.0f, k == a.D ? live : 0.0f);
         }
         if (!(ok && hok)) { st.d = (bf16x4){(bf16_t)0.0f, (bf16_t)0.0f, (bf16_t)0.0f, (bf16_t)0.0f}; }
     };
@@ -1390,13 +1393,14 @@ __global__ void cast_bf16_f32_kernel(const bf16_t* __restrict__ x, float* __rest
     }
 }
 
-// du = dy * gelu'(u)   (MLM head transform, HF:476-480; the encoder's FFN fuses this into its dgrad GEMM)
+// du = dy * d, d = gelu'(pre-activation) as the forward GEMM's EPI_GELU epilogue stored it   (MLM head transform, HF:476-480; the
+// encoder's FFN fuses this product into its dgrad GEMM)
 __global__ void gelu_bwd_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ u, bf16_t* __restrict__ du, size_t n) {
     for (size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n; i += (size_t)gridDim.x * blockDim.x * 4) {
         const bf16x4 a = *(const bf16x4*)(dy + i), b = *(const bf16x4*)(u + i);
         bf16x4 o;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) o[r] = f2bf(bf2f(a[r]) * gelu_erf_grad(bf2f(b[r])));
+        for (int r = 0; r < 4; ++r) o[r] = f2bf(bf2f(a[r]) * bf2f(b[r]));
         *(bf16x4*)(du + i) = o;
     }
 }
@@ -1704,6 +1708,22 @@ __global__ __launch_bounds__(256) void rows_to_block_kernel(const int64_t* __res
     }
 }
 
+template <typename FT>
+static int pair_proj_fwd_launch(hipStream_t stream, const FT* feat, int n, int P, int D, const float* W, const float* bias, int H, void* out, int ldo, int T,
+                                int KC, int pitch, int lds) {
+    static std::atomic<unsigned long long> attr_done{0};
+    if (KC <= 64) {                                                // 64 lanes of k per row (four rows per wave-instruction pair) or 128
+        hipLaunchKernelGGL((pair_proj_fwd_kernel<6, FT>), dim3((n + 63) / 64, (H + 127) / 128), dim3(256), lds, stream, feat, n, P, D, W, bias, H, (bf16_t*)out, ldo, T,
+                           KC, pitch);
+    } else {
+        if (int e = mmb_allow_lds((const void*)pair_proj_fwd_kernel<7, FT>, 192 * 130 * (int)sizeof(float), attr_done)) return e;
+        hipLaunchKernelGGL((pair_proj_fwd_kernel<7, FT>), dim3((n + 63) / 64, (H + 127) / 128), dim3(256), lds, stream, feat, n, P, D, W, bias, H, (bf16_t*)out, ldo, T,
+                           KC, pitch);
+    }
+    MMB_CHECK_LAUNCH();
+    return 0;
+}
+
 extern "C" {
 
 uint32_t mmbert_rng_stream(uint64_t seed, uint32_t site) {
@@ -1875,7 +1895,7 @@ int mmbert_embed_scatter(hipStream_t stream, const int64_t* ids, const int64_t* 
     return 0;
 }
 
-int mmbert_pair_proj_fwd(hipStream_t stream, const float* feat, int B, int P, int D, const float* W, const float* bias, int H,
+int mmbert_pair_proj_fwd(hipStream_t stream, const void* feat, int feat_f64, int B, int P, int D, const float* W, const float* bias, int H,
                          void* out, int ldo, int T) {
     const int n = B * P;
     if (n <= 0) return 0;
@@ -1883,17 +1903,8 @@ int mmbert_pair_proj_fwd(hipStream_t stream, const float* feat, int B, int P, in
     const int KC = D < 128 ? (D + 3) & ~3 : 128;                 // k chunk in LDS (a multiple of 4); row pitch = 2 mod 16 floats
     const int pitch = KC + ((18 - (KC & 15)) & 15);
     const int lds = 192 * pitch * (int)sizeof(float);             // <= 99 840 bytes
-    static std::atomic<unsigned long long> attr_done{0};
-    if (KC <= 64) {                                                // 64 lanes of k per row (four rows per wave-instruction pair) or 128
-        hipLaunchKernelGGL(pair_proj_fwd_kernel<6>, dim3((n + 63) / 64, (H + 127) / 128), dim3(256), lds, stream, feat, n, P, D, W, bias, H, (bf16_t*)out, ldo, T,
-                           KC, pitch);
-    } else {
-        if (int e = mmb_allow_lds((const void*)pair_proj_fwd_kernel<7>, 192 * 130 * (int)sizeof(float), attr_done)) return e;
-        hipLaunchKernelGGL(pair_proj_fwd_kernel<7>, dim3((n + 63) / 64, (H + 127) / 128), dim3(256), lds, stream, feat, n, P, D, W, bias, H, (bf16_t*)out, ldo, T,
-                           KC, pitch);
-    }
-    MMB_CHECK_LAUNCH();
-    return 0;
+    return feat_f64 ? pair_proj_fwd_launch(stream, (const double*)feat, n, P, D, W, bias, H, out, ldo, T, KC, pitch, lds)
+                    : pair_proj_fwd_launch(stream, (const float*)feat, n, P, D, W, bias, H, out, ldo, T, KC, pitch, lds);
 }
 
 // workspace: the slab [S][H][D + 1] fp32 of per-row-range partial products.  S row ranges (a multiple of 16 rows each) so that the
@@ -1914,7 +1925,7 @@ size_t mmbert_pair_proj_bwd_workspace(int B, int P, int D, int H) {
     return (size_t)S * H * (D + 1) * sizeof(float);
 }
 
-int mmbert_pair_proj_bwd(hipStream_t stream, const float* feat, int B, int P, int D, const void* J, const void* dJ, int ld, int T,
+int mmbert_pair_proj_bwd(hipStream_t stream, const void* feat, int feat_f64, int B, int P, int D, const void* J, const void* dJ, int ld, int T,
                          float* dW, float* db, int H, void* workspace) {
     const int n = B * P;
     if (n <= 0) return 0;
@@ -1925,7 +1936,9 @@ int mmbert_pair_proj_bwd(hipStream_t stream, const float* feat, int B, int P, in
     int S;
     pair_bwd_split(n, D, H, &a.rows_per_wg, &S);
     a.ntiles = (D + 1 + 15) / 16;
-    hipLaunchKernelGGL(pair_wgrad_kernel, dim3((H + 63) / 64, S, (a.ntiles + PAIR_NT - 1) / PAIR_NT), dim3(256), 0, stream, a);
+    const dim3 grid((H + 63) / 64, S, (a.ntiles + PAIR_NT - 1) / PAIR_NT);
+    if (feat_f64) hipLaunchKernelGGL(pair_wgrad_kernel<double>, grid, dim3(256), 0, stream, a);
+    else hipLaunchKernelGGL(pair_wgrad_kernel<float>, grid, dim3(256), 0, stream, a);
     MMB_CHECK_LAUNCH();
     hipLaunchKernelGGL(pair_wgrad_reduce_kernel, dim3((H * (D + 1) + 255) / 256), dim3(256), 0, stream, (const float*)workspace, S, H, D, dW, db);
     MMB_CHECK_LAUNCH();

@@ -175,7 +175,7 @@ class JointEmbeddings(nn.Module):
         B, T, H = input_embs.shape
         e1 = input_embs.reshape(B * T, H).to(torch.bfloat16)
         drop = ops.make_drop(self.dropout_prob if self.training else 0.0, top._next_seed(), 1001)
-        out = _JointFn.apply(e1, self.LayerNorm.weight, top, (pair_ids.float().contiguous(),), (self.which(pair_ids),), B, T, drop)
+        out = _JointFn.apply(e1, self.LayerNorm.weight, top, (_pair_features(pair_ids, e1.device),), (self.which(pair_ids),), B, T, drop)
         return out.view(B, -1, H).float()
 
 
@@ -201,7 +201,7 @@ class _JointFn(torch.autograd.Function):
             off += feat.shape[1]
         x, mean, rstd = ops.ln_fwd(j0, w["joint_ln_g"], w["joint_ln_b"], LN_EPS_JOINT, drop=drop)
         ctx.top, ctx.whichs, ctx.B, ctx.T, ctx.drop, ctx.nf = top, whichs, B, T, drop, len(feats)
-        ctx.save_for_backward(j0, mean, rstd, *feats)
+        ctx.save_for_backward(j0, mean, rstd, *feats)              # (feats: the caller's tensors; autograd's version check covers them)
         return x
 
     @staticmethod
@@ -217,6 +217,24 @@ class _JointFn(torch.autograd.Function):
             off += feat.shape[1]
         de1 = dj0.view(B, -1, H)[:, :T].reshape(B * T, H)
         return de1, None, None, None, None, None, None, None
+
+
+def _pair_features(f, dev):
+    """The pair features as the projection kernels take them: contiguous fp32 or float64 on the device.  The reference's collate hands over
+    float64 (REF:model_utils.py:94-99) and JointEmbeddings casts with ``.float()`` (REF:MMBertEmbedding.py:62,64); the kernels read float64
+    directly and round on load (same values, no cast launch, no fp32 copy).  The tensor is the CALLER's: it is read again by backward
+    (weight gradient of the projection), so an in-place change between forward and backward raises there, as a saved tensor would."""
+    f = f.to(dev)
+    if f.dtype not in (torch.float32, torch.float64):
+        f = f.float()
+    return f.contiguous()
+
+
+def _check_unchanged(feats, versions):
+    for f, v in zip(feats, versions):
+        if f._version != v:
+            raise RuntimeError("a pair-feature tensor needed for gradient computation has been modified by an inplace operation "
+                               "between forward and backward (the projection's weight gradient reads the caller's tensor)")
 
 
 _cu_count = {}
@@ -591,7 +609,7 @@ def _trunk_static(plan, B, T, lens, joff, dev):
 
 class _Trunk:
     """What one _TrunkFn call works on (plain attributes; built by _encode)."""
-    __slots__ = ("ids", "tts", "B", "T", "lens", "pair_info", "feats", "plan", "layout", "split", "key_bias", "kv_len", "seed", "top_rows",
+    __slots__ = ("ids", "tts", "B", "T", "lens", "pair_info", "feats", "feat_versions", "plan", "layout", "split", "key_bias", "kv_len", "seed", "top_rows",
                  "d_emb", "d_joint", "infer", "late_split", "compact")
 
 
@@ -739,6 +757,7 @@ class _TrunkFn(torch.autograd.Function):
             S = lens[k]
             lo = ctx.joff[k]
             off = T
+            _check_unchanged(t.feats[k], t.feat_versions[k])
             for feat, which in zip(t.feats[k], t.pair_info[k][1]):
                 ops.pair_proj_bwd(feat, J[lo:lo + B * S], dJ[lo:lo + B * S], T, w["g_" + which + "_w"], w["g_" + which + "_b"], seq_len=S, offset=off)
                 off += feat.shape[1]
@@ -790,6 +809,34 @@ def _active_row_count(rows) -> int:
     if int(host[2]) != 0:
         raise IndexError(f"masked_labels: {int(host[2])} label(s) are neither -100 nor in [0, vocab_size) -- Target out of bounds")
     return int(host[0])
+
+
+_ones = {}
+
+
+class _ScalarLoss(torch.Tensor):
+    """The 0-dim joint loss as ``forward()`` returns it.  The reference's loop differentiates ``outputs[0].mean()`` (REF:trainer.py:83); on a
+    0-dim tensor ``mean()`` is the identity, yet torch launches a reduction for it, a fill for the implicit unit gradient and a division in
+    ``MeanBackward`` -- three ATen launches per step in front of the heads' backward.  Here ``mean()`` of the scalar returns the scalar and
+    ``backward()`` without a gradient seeds a cached device-side 1.0: the same graph, the same values, no launch.  Everything else is
+    ``torch.Tensor`` (``.item()``, arithmetic, ``.detach()``, a ``mean`` with arguments)."""
+
+    def mean(self, *args, **kwargs):
+        if self.dim() == 0 and not args and not kwargs:
+            return self
+        return super().mean(*args, **kwargs)
+
+    def backward(self, gradient=None, retain_graph=None, create_graph=False, inputs=None):
+        if gradient is None and self.dim() == 0 and not create_graph:
+            key = (self.dtype, self.device)
+            gradient = _ones.get(key)
+            if gradient is None:
+                gradient = _ones[key] = torch.ones((), dtype=self.dtype, device=self.device)
+        return torch.autograd.backward(self, gradient, retain_graph, create_graph, inputs=inputs)
+
+
+def _scalar_loss(loss):
+    return loss.as_subclass(_ScalarLoss) if (torch.is_tensor(loss) and loss.dim() == 0 and type(loss) is torch.Tensor) else loss
 
 
 _dummies = {}
@@ -1267,7 +1314,8 @@ class _GpuModelBase(nn.Module):
         t = _Trunk()
         t.compact = None
         t.ids, t.tts, t.B, t.T, t.lens, t.pair_info, t.plan = ids, tts, B, T, lens, pair_info, plan
-        t.feats = [None if info is None else tuple(f.to(dev).float().contiguous() for f in info[0]) for info in pair_info]
+        t.feats = [None if info is None else tuple(_pair_features(f, dev) for f in info[0]) for info in pair_info]
+        t.feat_versions = [None if fs is None else tuple(f._version for f in fs) for fs in t.feats]
         t.key_bias, t.kv_len, t.seed, t.infer = key_bias, kv_len, seed, infer
         t.d_emb = ops.make_drop(p_emb, seed, 1000)
         t.d_joint = [ops.make_drop(p_joint, seed, 1001 + k) for k in range(len(lens))]
@@ -1821,7 +1869,7 @@ class MMBertForPretraining(_GpuModelBase):
             scores = tuple(logits[b[k]:b[k + 1]].view(B, lens[k], -1)[:, :, :V] for k in range(3))
             if self.scores_dtype != logits.dtype:
                 scores = tuple(sc.to(self.scores_dtype) for sc in scores)
-        self.outputs = (joint_loss, None, None, None, ap_loss, label_loss, nce,
+        self.outputs = (_scalar_loss(joint_loss), None, None, None, ap_loss, label_loss, nce,
                         scores[0], t_rel, scores[1], v_rel, scores[2], s_rel)
         return self.outputs, logits_out
 
@@ -1867,5 +1915,5 @@ class MMBertForPretraining(_GpuModelBase):
         scores = None if logits is None else logits.view(B, lens[0], -1)[:, :, :V]
         if scores is not None and self.scores_dtype != scores.dtype:
             scores = scores.to(self.scores_dtype)
-        self.outputs = (joint_loss, None, None, None, ap_loss, label_loss, nce, scores, v_rel)
+        self.outputs = (_scalar_loss(joint_loss), None, None, None, ap_loss, label_loss, nce, scores, v_rel)
         return self.outputs, logits_out

@@ -421,13 +421,14 @@ def _pair_rows(T, Pn, ld, seq_len, offset):
 
 
 def pair_proj_fwd(feat, W, bias, out, T, *, seq_len=None, offset=None):
-    """feat fp32 [B,P,D]; writes relu(W.feat+b) into rows b*(T+P)+T+p of ``out`` (bf16 [B*(T+P), H]); with ``seq_len`` /
+    """feat fp32 or float64 [B,P,D] contiguous; writes relu(W.feat+b) into rows b*(T+P)+T+p of ``out`` (bf16 [B*(T+P), H]); with ``seq_len`` /
     ``offset``: into rows b*seq_len + offset + p."""
     lib = _lib.load()
     B, Pn, D = feat.shape
+    assert feat.dtype in (torch.float32, torch.float64) and feat.is_contiguous()
     H = W.shape[0]
     Tp, shift = _pair_rows(T, Pn, out.stride(0), seq_len, offset)
-    _lib.check(lib.mmbert_pair_proj_fwd(_stream(), feat.data_ptr(), B, Pn, D, W.data_ptr(), bias.data_ptr(), H,
+    _lib.check(lib.mmbert_pair_proj_fwd(_stream(), feat.data_ptr(), 1 if feat.dtype == torch.float64 else 0, B, Pn, D, W.data_ptr(), bias.data_ptr(), H,
                                         out.data_ptr() + shift, out.stride(0), Tp), "mmbert_pair_proj_fwd")
 
 
@@ -435,10 +436,10 @@ def pair_proj_bwd(feat, J, dJ, T, dW, db, *, seq_len=None, offset=None):
     lib = _lib.load()
     B, Pn, D = feat.shape
     H = dW.shape[0]
-    assert J.stride(0) == dJ.stride(0)
+    assert J.stride(0) == dJ.stride(0) and feat.dtype in (torch.float32, torch.float64) and feat.is_contiguous()
     Tp, shift = _pair_rows(T, Pn, J.stride(0), seq_len, offset)
     ws = _ws_f32((lib.mmbert_pair_proj_bwd_workspace(B, Pn, D, H) + 3) // 4, feat.device)
-    _lib.check(lib.mmbert_pair_proj_bwd(_stream(), feat.data_ptr(), B, Pn, D, J.data_ptr() + shift, dJ.data_ptr() + shift, J.stride(0), Tp,
+    _lib.check(lib.mmbert_pair_proj_bwd(_stream(), feat.data_ptr(), 1 if feat.dtype == torch.float64 else 0, B, Pn, D, J.data_ptr() + shift, dJ.data_ptr() + shift, J.stride(0), Tp,
                                         dW.data_ptr(), db.data_ptr(), H, ws.data_ptr()), "mmbert_pair_proj_bwd")
 
 

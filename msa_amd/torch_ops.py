@@ -62,7 +62,8 @@ def _linear(x, weight, bias=None, act="none"):
 
 
 def _linear_pre(x, weight, bias=None):
-    """GELU form that also returns the pre-activation (what backward needs): one launch, two outputs."""
+    """GELU form that also returns what backward needs -- gelu'(pre-activation), bf16 (named ``pre`` for the slot it fills) --: one launch,
+    two outputs."""
     xb = _bf(x)
     pre = torch.empty((xb.shape[0], weight.shape[0]), device=x.device, dtype=torch.bfloat16)
     y = ops.gemm_nt(xb, _bf(weight), bias=None if bias is None else bias.float(), gelu=True, aux=pre)
@@ -70,13 +71,13 @@ def _linear_pre(x, weight, bias=None):
 
 
 def _linear_bwd(dy, x, weight, pre, has_bias):
-    """dx = (dy * gelu'(pre)) W  (NT against W^T, GELU' fused in the epilogue when pre is given); dW = dy^T x (TN, fp32);
+    """dx = (dy * pre) W with pre = gelu'(pre-activation) as linear_pre returned it  (NT against W^T); dW = dy^T x (TN, fp32);
     db = column sums riding on the TN launch."""
     dyb, xb = _bf(dy), _bf(x)
     N, K = weight.shape
     wt = _bf(weight).t().contiguous()                                 # [K, N]: dgrad as an NT product
     if pre is not None:
-        g = ops.gelu_bwd(dyb, pre.contiguous())                       # dy * gelu'(pre), bf16
+        g = ops.gelu_bwd(dyb, pre.contiguous())                       # dy * gelu'(pre-activation), bf16
     else:
         g = dyb
     dx = ops.gemm_nt(g, wt)
@@ -239,6 +240,11 @@ def _emb_bwd(dy, ids, token_types, e0, mean, rstd, gamma, vocab, types, position
     return dword, dtype_, dpos, dg, db
 
 
+def _pairf(pair):
+    """fp32 or float64 features as they are (the kernels round float64 on load: REF:MMBertEmbedding.py:62,64's ``.float()``)."""
+    return (pair if pair.dtype in (torch.float32, torch.float64) else pair.float()).contiguous()
+
+
 def _joint_fwd(text_emb, pair, weight, bias, gamma, beta, eps=1e-5, dropout_p=0.0, seed=0):
     """JointEmbeddings (REF:MMBertEmbedding.py:57-72): cat(text_emb, relu(W pair + b)) -> LayerNorm -> dropout.
     text_emb [B,T,H], pair [B,P,D] -> (y [B,T+P,H] bf16, j0 (pre-LN) [B*(T+P),H], mean, rstd)."""
@@ -246,7 +252,7 @@ def _joint_fwd(text_emb, pair, weight, bias, gamma, beta, eps=1e-5, dropout_p=0.
     P = pair.shape[1]
     j0 = torch.empty((B * (T + P), H), device=text_emb.device, dtype=torch.bfloat16)
     j0.view(B, T + P, H)[:, :T].copy_(text_emb)
-    ops.pair_proj_fwd(pair.float().contiguous(), weight.float().contiguous(), bias.float().contiguous(), j0, T)
+    ops.pair_proj_fwd(_pairf(pair), weight.float().contiguous(), bias.float().contiguous(), j0, T)
     drop = ops.make_drop(float(dropout_p), int(seed), _DROP_SITE_JOINT) if dropout_p > 0.0 else None
     y, mean, rstd = ops.ln_fwd(j0, gamma.float().contiguous(), beta.float().contiguous(), eps, drop=drop)
     return y.view(B, T + P, H), j0, mean, rstd
@@ -264,7 +270,7 @@ def _joint_bwd(dy, pair, j0, mean, rstd, gamma, text_len, dropout_p=0.0, seed=0)
     dW, dbias = torch.zeros((H, D), device=dev, dtype=torch.float32), torch.zeros(H, device=dev, dtype=torch.float32)
     drop = ops.make_drop(float(dropout_p), int(seed), _DROP_SITE_JOINT) if dropout_p > 0.0 else None
     dj0 = ops.ln_bwd(_bf(dy.reshape(-1, H)), j0, mean, rstd, gamma.float().contiguous(), dg, db, post_drop=drop)
-    ops.pair_proj_bwd(pair.float().contiguous(), j0, dj0, text_len, dW, dbias)
+    ops.pair_proj_bwd(_pairf(pair), j0, dj0, text_len, dW, dbias)
     dtext = dj0.view(B, text_len + P, H)[:, :text_len].contiguous()
     return dtext, dW, dbias, dg, db
 

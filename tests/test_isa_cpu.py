@@ -27,7 +27,8 @@ def _find(table, prefix):
 def test_rowwise_kernels_keep_their_loads_in_flight(scan):
     t = scan("rowwise.hip")
     # (only "no load waits alone" is pinned: the LOAD COUNT of a kernel is hipcc's business and moves with ROCm versions -- ADVICE r4)
-    for prefix in ("pair_proj_fwd_kernel<6>", "pair_proj_fwd_kernel<7>", "pair_wgrad_kernel", "ce_count_kernel", "split_layout_kernel"):
+    for prefix in ("pair_proj_fwd_kernel<6, float>", "pair_proj_fwd_kernel<7, float>", "pair_proj_fwd_kernel<6, double>", "pair_proj_fwd_kernel<7, double>",
+                   "pair_wgrad_kernel<float>", "pair_wgrad_kernel<double>", "ce_count_kernel", "split_layout_kernel"):
         for loads, drains, serialized in _find(t, prefix):
             assert loads > 0 and serialized == 0, (prefix, loads, drains, serialized)
     for prefix in ("transpose_cast_kernel<float>", "transpose_cast_kernel<__bf16>", "_Z21transpose_cast_kernelIDF16b"):

@@ -124,7 +124,7 @@ def hip_dropout_masks(m, B, lens, split):
 
 
 def check_against_oracle(cfg, B, T, Pv, Pa, seed, loss_tol=3e-3, train=False, flags=None, model_seed=7, score_tol=3e-2, logit_tol=2e-2,
-                         grad_tol=0.045, score_mean_tol=None, head_grad_tol=None):
+                         grad_tol=0.045, score_mean_tol=None, head_grad_tol=None, report=None):
     """``train``: the whole step in TRAIN mode (all three dropouts on, REF:trainer.py:40,66,83) -- the HIP model runs first, its masks
     are rebuilt (hip_dropout_masks) and the oracle replays them.  ``flags``: model switches set before the call.  The default
     tolerances are the L = 2 ones of the file header; deep models pass the bounds re-derived at depth (test_bert_base_12_layers_match_oracle)."""
@@ -166,11 +166,15 @@ def check_against_oracle(cfg, B, T, Pv, Pa, seed, loss_tol=3e-3, train=False, fl
         assert float((out[k].float().cpu() - oout[k].detach()).abs().max()) < logit_tol
     out[0].mean().backward()
     torch.cuda.synchronize()
-    worst = compare_gradients(m, p, pe, grad_tol, head_grad_tol)
+    devs = {} if report else None
+    worst = compare_gradients(m, p, pe, grad_tol, head_grad_tol, devs)
+    if report:                                                    # every parameter's measured deviation -> gpurun_out/<report>.json (_report)
+        _report(report, dict(losses={name: dict(hip=float(out[i].detach()), oracle=float(oout[i].detach())) for i, name in ((0, "joint"), (4, "ap"), (5, "label"), (6, "nce"))},
+                             grads=devs, worst_cosine=worst))
     return m, out, worst
 
 
-def compare_gradients(m, p, pe, grad_tol=0.045, head_grad_tol=None):
+def compare_gradients(m, p, pe, grad_tol=0.045, head_grad_tol=None, devs=None):
     """Every parameter gradient of the HIP model ``m`` against the oracle's (``p``; ``pe`` = the oracle under bf16 storage emulation,
     the calibrator for the ill-conditioned head gradients).  Returns (worst cosine, its name)."""
     worst = (1.0, None)
@@ -188,6 +192,8 @@ def compare_gradients(m, p, pe, grad_tol=0.045, head_grad_tol=None):
             continue
         dev = float((g - og).norm() / og.norm())
         dev_emul = float((pe[n].grad - og).norm() / og.norm())
+        if devs is not None:
+            devs[n] = dict(rel_err=dev, emulated_oracle_rel_err=dev_emul, norm=float(og.norm()))
         # 4.5 % relative error == cosine 0.999; ill-conditioned head gradients (CPC, pooler, gates at
         # init) are allowed 3x what bf16 storage alone does to the ORACLE's gradient
         # ... and a gradient whose norm is three orders below the other head gradients (the CPC biases at initialisation: ~5e-5
@@ -694,7 +700,8 @@ def test_train_mode_step_at_the_timed_depth_matches_oracle_with_replayed_masks(s
         # score of magnitude >= 8 carries 3e-2 of rounding alone), regression logits 3e-2, encoder-side gradients max(6 %, 3 x the bf16-storage
         # calibrator), the [B, H]-sized head gradients max(12 %, 3 x calibrator) as in the eval-mode L = 12 batch-8 test
         m, out, worst = check_against_oracle(cfg, 8, 50, 500, 500, seed=8, train=True, flags=flags, loss_tol=4e-3, score_tol=8e-2,
-                                             score_mean_tol=8e-3, logit_tol=3e-2, grad_tol=0.06, head_grad_tol=0.12)
+                                             score_mean_tol=8e-3, logit_tol=3e-2, grad_tol=0.06, head_grad_tol=0.12,
+                                             report="parity_train_L12_B8" + ("" if shortcuts else "_shortcuts_off"))
     finally:
         MM._EncoderFn._last_layer_sparse = staticmethod(orig)
         _ops.gemm_tn_grouped = tn_orig
@@ -889,6 +896,52 @@ def test_fused_heads_equal_eager_heads(num_labels):
         # 3e-7 absolute: the CPC / classifier gradients at initialisation are differences of nearly equal 1e-3-sized terms
         # (norm ~1e-6, see DESIGN numerics): their last digits depend on the summation order on BOTH sides
         assert err <= 3e-4 * scale + 3e-7, f"{n}: err {err:.3e} scale {scale:.3e}"
+
+
+def test_loss_mean_backward_is_the_reference_call_without_aten_launches():
+    """Round 6.  The reference differentiates ``outputs[0].mean()`` (REF:trainer.py:83).  outputs[0] is a 0-dim
+    ``_ScalarLoss``: ``mean()`` of it is the tensor itself and ``backward()`` seeds a cached device-side 1.0 -- the reduction, the fill and
+    the division torch launches for that line are gone, the graph and the values are the same: gradients BIT-identical (deterministic mode)
+    to the plain-tensor path (``torch.Tensor.mean`` on the same scalar, implicit ones gradient), ``.item()`` / arithmetic / ``mean(dim)``
+    behave as on any tensor, and the pair features are read as float64 (the reference's dtype, rounded on load) -- modifying them in place
+    between forward and backward raises like a saved tensor would."""
+    from msa_amd import ops as _ops
+    from msa_amd.model import _ScalarLoss
+    cfg = dict(hidden=256, layers=2, heads=4, intermediate=1024, vocab=4096, dataset="mosei", alpha=1.0, beta=1.0)
+    batch = batch_to(synthetic_batch(4, 24, 90, 70, dataset="mosei", vocab=cfg["vocab"], seed=77), DEV)
+    assert batch["input_ids"][1].dtype == torch.float64 and batch["input_ids"][2].dtype == torch.float64      # collate's contract
+    was = _ops.deterministic()
+    grads = []
+    try:
+        _ops.set_deterministic(True)
+        for plain in (False, True):
+            m = build(cfg, train=True)
+            m.manual_seed(3)
+            out, _ = m(**batch)
+            loss = out[0]
+            assert isinstance(loss, _ScalarLoss) and loss.dim() == 0 and loss.mean() is loss
+            assert isinstance(float(loss), float) and float(loss + 1.0) == pytest.approx(float(loss) + 1.0)
+            assert loss.mean(dim=None).shape == () and float(loss.detach().mean()) == float(loss)
+            if plain:
+                torch.Tensor.mean(loss.as_subclass(torch.Tensor)).backward()        # what torch does for REF:trainer.py:83 on a plain tensor
+            else:
+                loss.mean().backward()
+            torch.cuda.synchronize()
+            grads.append(m._flat.grads.clone())
+    finally:
+        _ops.set_deterministic(was)
+    assert torch.equal(grads[0], grads[1]) and float(grads[0].abs().sum()) > 0.0
+    # fp32 features (DeviceBatchBuilder's dtype) give the same step as float64 ones whose values are fp32-representable
+    m = build(cfg)
+    o64, _ = m(**batch)
+    b32 = dict(batch, input_ids=tuple(t.float() if t.dtype == torch.float64 else t for t in batch["input_ids"]))
+    o32, _ = m(**b32)
+    assert abs(float(o64[0]) - float(o32[0])) <= 1e-6 * abs(float(o64[0]))
+    # the caller's feature tensor is read again in backward: an in-place change in between is an error, not a silently wrong gradient
+    out, _ = m(**batch)
+    batch["input_ids"][1].mul_(2.0)
+    with pytest.raises(RuntimeError, match="modified by an inplace operation"):
+        out[0].mean().backward()
 
 
 def test_submodule_api_matches_oracle():
