@@ -32,10 +32,9 @@ typedef struct ihipStream_t* mmbert_stream_t;   /* == hipStream_t */
 
 /* ---- GEMM epilogue flags (mmbert_gemm_nt.epi) ---- */
 #define MMBERT_EPI_BIAS 1      /* + bias[N] (fp32)                                             */
-#define MMBERT_EPI_GELU 2      /* out = gelu_erf(v); aux (optional) = gelu_erf'(v), bf16 -- the factor the backward multiplies by   HF:334-337 */
+#define MMBERT_EPI_GELU 2      /* out = gelu_erf(v); aux (optional) = v      HF:334-337         */
 #define MMBERT_EPI_RESID 4     /* out = dropout(v) + R                       HF:289-293,347-351 */
-#define MMBERT_EPI_GELU_BWD 8  /* out = v * U, U = the forward launch's aux (dgrad of the FFN down projection; round 6: aux / U hold
-                                  gelu' of the pre-activation, not the pre-activation -- the backward epilogue is one multiply) */
+#define MMBERT_EPI_GELU_BWD 8  /* out = v * gelu'(U)   (dgrad of the FFN down projection)       */
 #define MMBERT_EPI_OUT_F32 16  /* C is fp32 instead of bf16                                     */
 
 /* C[M,N] = epi(alpha * alpha_dev[0] * A[M,K] . B[N,K]^T).  Replaces nn.Linear forward (HF:175-177,
@@ -367,8 +366,7 @@ int mmbert_id_runs_sum_rows(mmbert_stream_t stream, const void* src, int src_bf1
 int mmbert_adamw(mmbert_stream_t stream, float* p, float* g, float* m, float* v, void* p_bf16, const uint8_t* flags, size_t n,
                  double lr, double beta1, double beta2, double eps, double wd, int step, double gscale, int mode, int zero_grad);
 
-/* du = dy * u, u = the aux output (gelu_erf' of the pre-activation) of the forward MMBERT_EPI_GELU launch; contiguous bf16
- * (BertPredictionHeadTransform backward, HF:476-480) */
+/* du = dy * gelu_erf'(u), contiguous bf16 (BertPredictionHeadTransform backward, HF:476-480) */
 int mmbert_gelu_bwd(mmbert_stream_t stream, const void* dy, const void* u, void* du, size_t n);
 
 int mmbert_cast_f32_bf16(mmbert_stream_t stream, const float* x, void* y, size_t n);

@@ -212,46 +212,6 @@ __device__ __forceinline__ mmb_f2 gelu_erf_grad2(mmb_f2 x) {
     return (mmb_f2){x.x > 0.0f ? og.x : g.x, x.y > 0.0f ? og.y : g.y};
 }
 
-// gelu'(x) from the T(a) the forward form has in hand anyway (round 6): g(a) = gelu'(-a) = T(a) - a phi(a), phi(a) = 2^(-a^2 / (2 ln 2)) / sqrt(2 pi) --
-// one more transcendental and 4 packed operations per element instead of the degree-7 polynomial; |error| <= 2.6e-6 absolute on every bf16
-// argument of [-14, 14] and on a 2e6-point fp32 grid (the W form: 4.1e-6).  The FFN-up epilogue stores THIS (bf16) as its second output: the
-// input-gradient launch then multiplies by a loaded value instead of evaluating gelu_erf_grad per element.
-__device__ __forceinline__ float gelu_erf_with_grad(float x, float& d) {
-    const float a = mmb_clamp_abs12(x);
-    float q = 0.000488118665642307f;
-    q = fmaf(q, a, -0.007198809871008205f);
-    q = fmaf(q, a, 0.05214680078704519f);
-    q = fmaf(q, a, 0.4595957249475095f);
-    q = fmaf(q, a, 1.1510005681479196f);
-    const float t = __builtin_amdgcn_exp2f(fmaf(-a, q, -1.0f));
-    const float ph = __builtin_amdgcn_exp2f((-0.72134752044448170f * a) * a);
-    const float g = fmaf(-0.3989422804014327f * a, ph, t);
-    d = x > 0.0f ? 1.0f - g : g;
-    return fmaf(-a, t, mmb_relu(x));
-}
-// ... two pairs in lockstep (gelu values BIT-identical to gelu_erf4 / gelu_erf; derivatives bit-identical to gelu_erf_with_grad)
-__device__ __forceinline__ void gelu_erf4_with_grad(mmb_f2& x0, mmb_f2& x1, mmb_f2& d0, mmb_f2& d1) {
-    const mmb_f2 a0 = {mmb_clamp_abs12(x0.x), mmb_clamp_abs12(x0.y)}, a1 = {mmb_clamp_abs12(x1.x), mmb_clamp_abs12(x1.y)};
-    mmb_f2 q0 = (mmb_f2){0.000488118665642307f, 0.000488118665642307f}, q1 = q0;
-    q0 = q0 * a0 + (mmb_f2){-0.007198809871008205f, -0.007198809871008205f}; q1 = q1 * a1 + (mmb_f2){-0.007198809871008205f, -0.007198809871008205f};
-    q0 = q0 * a0 + (mmb_f2){0.05214680078704519f, 0.05214680078704519f};    q1 = q1 * a1 + (mmb_f2){0.05214680078704519f, 0.05214680078704519f};
-    q0 = q0 * a0 + (mmb_f2){0.4595957249475095f, 0.4595957249475095f};      q1 = q1 * a1 + (mmb_f2){0.4595957249475095f, 0.4595957249475095f};
-    q0 = q0 * a0 + (mmb_f2){1.1510005681479196f, 1.1510005681479196f};      q1 = q1 * a1 + (mmb_f2){1.1510005681479196f, 1.1510005681479196f};
-    const mmb_f2 e0 = -a0 * q0 + (mmb_f2){-1.0f, -1.0f}, e1 = -a1 * q1 + (mmb_f2){-1.0f, -1.0f};
-    const mmb_f2 k = {-0.72134752044448170f, -0.72134752044448170f};
-    const mmb_f2 s0 = (k * a0) * a0, s1 = (k * a1) * a1;
-    const mmb_f2 r0 = {mmb_relu(x0.x), mmb_relu(x0.y)}, r1 = {mmb_relu(x1.x), mmb_relu(x1.y)};
-    const mmb_f2 t0 = {__builtin_amdgcn_exp2f(e0.x), __builtin_amdgcn_exp2f(e0.y)}, t1 = {__builtin_amdgcn_exp2f(e1.x), __builtin_amdgcn_exp2f(e1.y)};
-    const mmb_f2 p0 = {__builtin_amdgcn_exp2f(s0.x), __builtin_amdgcn_exp2f(s0.y)}, p1 = {__builtin_amdgcn_exp2f(s1.x), __builtin_amdgcn_exp2f(s1.y)};
-    const mmb_f2 c = {-0.3989422804014327f, -0.3989422804014327f};
-    const mmb_f2 g0 = (c * a0) * p0 + t0, g1 = (c * a1) * p1 + t1;
-    const mmb_f2 o0 = (mmb_f2){1.0f, 1.0f} - g0, o1 = (mmb_f2){1.0f, 1.0f} - g1;
-    d0 = (mmb_f2){x0.x > 0.0f ? o0.x : g0.x, x0.y > 0.0f ? o0.y : g0.y};
-    d1 = (mmb_f2){x1.x > 0.0f ? o1.x : g1.x, x1.y > 0.0f ? o1.y : g1.y};
-    x0 = -a0 * t0 + r0;
-    x1 = -a1 * t1 + r1;
-}
-
 // Two pairs in lockstep: hipcc schedules one pair's chain after the other (register-pressure heuristics) and pads the v_exp_f32 -> use
 // and pk_fma -> v_exp_f32 wait states with s_nop; written side by side, each pair's waits are filled by the other pair's instructions.
 __device__ __forceinline__ void gelu_erf4(mmb_f2& x0, mmb_f2& x1) {

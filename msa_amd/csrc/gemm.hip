@@ -24,9 +24,9 @@ typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
 
 #define EPI_BIAS 1
-#define EPI_GELU 2       // out = gelu(v); optional aux = gelu'(v) (bf16: what EPI_GELU_BWD / mmbert_gelu_bwd multiply by)
+#define EPI_GELU 2       // out = gelu(v); optional aux = v (pre-activation, bf16)
 #define EPI_RESID 4      // out = dropout(v) + R
-#define EPI_GELU_BWD 8   // out = v * U, U = the aux output of the forward EPI_GELU launch (gelu' of the pre-activation)
+#define EPI_GELU_BWD 8   // out = v * gelu'(U)
 #define EPI_OUT_F32 16
 
 struct GemmNT {
@@ -71,20 +71,16 @@ __device__ __forceinline__ void epi_store(const GemmNT& p, int m, int n, float (
     }
     if constexpr (EPI & EPI_GELU) {
         if (p.aux) {
-            float d[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = gelu_erf_with_grad(v[r], d[r]);
-            bf16x4 u = {f2bf(d[0]), f2bf(d[1]), f2bf(d[2]), f2bf(d[3])};
+            bf16x4 u = {f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
             *(bf16x4*)(p.aux + (size_t)m * p.ldaux + n) = u;
-        } else {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
         }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
     }
     if constexpr (EPI & EPI_GELU_BWD) {
         const bf16x4 u = *(const bf16x4*)(p.U + (size_t)m * p.ldu + n);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] *= bf2f(u[r]);
+        for (int r = 0; r < 4; ++r) v[r] *= gelu_erf_grad(bf2f(u[r]));
     }
     if constexpr (EPI & EPI_RESID) {
         if (p.drop_thr16) {
@@ -116,17 +112,16 @@ __device__ __forceinline__ void epi_store8(const GemmNT& p, int m, int n, float 
         if (p.aux) {
             bf16x8 u;
 #pragma unroll
-            for (int r = 0; r < 8; ++r) { float d; v[r] = gelu_erf_with_grad(v[r], d); u[r] = f2bf(d); }
+            for (int r = 0; r < 8; ++r) u[r] = f2bf(v[r]);
             *(bf16x8*)(p.aux + (size_t)m * p.ldaux + n) = u;
-        } else {
-#pragma unroll
-            for (int r = 0; r < 8; ++r) v[r] = gelu_erf(v[r]);
         }
+#pragma unroll
+        for (int r = 0; r < 8; ++r) v[r] = gelu_erf(v[r]);
     }
     if constexpr (EPI & EPI_GELU_BWD) {
         const bf16x8 u = *(const bf16x8*)(p.U + (size_t)m * p.ldu + n);
 #pragma unroll
-        for (int r = 0; r < 8; ++r) v[r] *= bf2f(u[r]);
+        for (int r = 0; r < 8; ++r) v[r] *= gelu_erf_grad(bf2f(u[r]));
     }
     if constexpr (EPI & EPI_RESID) {
         if (p.drop_thr16) {
@@ -636,31 +631,27 @@ __global__ __launch_bounds__(512, 2) void gemm_nt8_kernel(const GemmNT p) {
                 const bool ok = interior || (m < q.M && n + 8 <= q.N);
                 if constexpr (EPI & EPI_GELU) {
                     if (q.aux) {
-                        // gelu AND gelu' from one a = |v| and one T(a) (gelu_erf4_with_grad): the second output is the DERIVATIVE, so that the
-                        // input-gradient launch (EPI_GELU_BWD) multiplies by a loaded value (round 6; it evaluated gelu' per element before)
                         bf16x8 u;
 #pragma unroll
-                        for (int r = 0; r < 8; r += 4) {
-                            mmb_f2 g0 = {vv[r], vv[r + 1]}, g1 = {vv[r + 2], vv[r + 3]}, d0, d1;
-                            gelu_erf4_with_grad(g0, g1, d0, d1);
-                            vv[r] = g0.x; vv[r + 1] = g0.y; vv[r + 2] = g1.x; vv[r + 3] = g1.y;
-                            u[r] = f2bf(d0.x); u[r + 1] = f2bf(d0.y); u[r + 2] = f2bf(d1.x); u[r + 3] = f2bf(d1.y);
-                        }
+                        for (int r = 0; r < 8; ++r) u[r] = f2bf(vv[r]);
                         const auto rsX = __builtin_amdgcn_make_buffer_rsrc((void*)q.aux, 0, (int)((um1 * (uint32_t)q.ldaux + un) * 2u), 0x00020000);
                         const uint32_t vo = ((uint32_t)mrow * (uint32_t)q.ldaux + (uint32_t)ncol) * 2u + (uint32_t)i * (32u * (uint32_t)q.ldaux) + (uint32_t)h * 64u;
                         if (ok) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, u), rsX, vo, 0, 0);
-                    } else {
+                    }
 #pragma unroll
-                        for (int r = 0; r < 8; r += 4) {             // packed forms (common.h): bit-identical to gelu_erf, 5 instead of 8 VALU per element
-                            mmb_f2 g0 = {vv[r], vv[r + 1]}, g1 = {vv[r + 2], vv[r + 3]};
-                            gelu_erf4(g0, g1);
-                            vv[r] = g0.x; vv[r + 1] = g0.y; vv[r + 2] = g1.x; vv[r + 3] = g1.y;
-                        }
+                    for (int r = 0; r < 8; r += 4) {                 // packed forms (common.h): bit-identical to gelu_erf, 5 instead of 8 VALU per element
+                        mmb_f2 g0 = {vv[r], vv[r + 1]}, g1 = {vv[r + 2], vv[r + 3]};
+                        gelu_erf4(g0, g1);
+                        vv[r] = g0.x; vv[r + 1] = g0.y; vv[r + 2] = g1.x; vv[r + 3] = g1.y;
                     }
                 }
                 if constexpr (EPI & EPI_GELU_BWD) {
 #pragma unroll
-                    for (int r = 0; r < 8; ++r) vv[r] *= bf2f(pre[i][h][r]);
+                    for (int r = 0; r < 8; r += 4) {
+                        mmb_f2 d0, d1;
+                        gelu_erf_grad4((mmb_f2){bf2f(pre[i][h][r]), bf2f(pre[i][h][r + 1])}, (mmb_f2){bf2f(pre[i][h][r + 2]), bf2f(pre[i][h][r + 3])}, d0, d1);
+                        vv[r] *= d0.x; vv[r + 1] *= d0.y; vv[r + 2] *= d1.x; vv[r + 3] *= d1.y;
+                    }
                 }
                 if constexpr (EPI & EPI_RESID) {
 #pragma unroll

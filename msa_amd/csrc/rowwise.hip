@@ -1393,14 +1393,13 @@ __global__ void cast_bf16_f32_kernel(const bf16_t* __restrict__ x, float* __rest
     }
 }
 
-// du = dy * d, d = gelu'(pre-activation) as the forward GEMM's EPI_GELU epilogue stored it   (MLM head transform, HF:476-480; the
-// encoder's FFN fuses this product into its dgrad GEMM)
+// du = dy * gelu'(u)   (MLM head transform, HF:476-480; the encoder's FFN fuses this into its dgrad GEMM)
 __global__ void gelu_bwd_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ u, bf16_t* __restrict__ du, size_t n) {
     for (size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n; i += (size_t)gridDim.x * blockDim.x * 4) {
         const bf16x4 a = *(const bf16x4*)(dy + i), b = *(const bf16x4*)(u + i);
         bf16x4 o;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) o[r] = f2bf(bf2f(a[r]) * bf2f(b[r]));
+        for (int r = 0; r < 4; ++r) o[r] = f2bf(bf2f(a[r]) * gelu_erf_grad(bf2f(b[r])));
         *(bf16x4*)(du + i) = o;
     }
 }

@@ -62,8 +62,7 @@ def _linear(x, weight, bias=None, act="none"):
 
 
 def _linear_pre(x, weight, bias=None):
-    """GELU form that also returns what backward needs -- gelu'(pre-activation), bf16 (named ``pre`` for the slot it fills) --: one launch,
-    two outputs."""
+    """GELU form that also returns the pre-activation (what backward needs): one launch, two outputs."""
     xb = _bf(x)
     pre = torch.empty((xb.shape[0], weight.shape[0]), device=x.device, dtype=torch.bfloat16)
     y = ops.gemm_nt(xb, _bf(weight), bias=None if bias is None else bias.float(), gelu=True, aux=pre)
@@ -71,13 +70,13 @@ def _linear_pre(x, weight, bias=None):
 
 
 def _linear_bwd(dy, x, weight, pre, has_bias):
-    """dx = (dy * pre) W with pre = gelu'(pre-activation) as linear_pre returned it  (NT against W^T); dW = dy^T x (TN, fp32);
+    """dx = (dy * gelu'(pre)) W  (NT against W^T, GELU' fused in the epilogue when pre is given); dW = dy^T x (TN, fp32);
     db = column sums riding on the TN launch."""
     dyb, xb = _bf(dy), _bf(x)
     N, K = weight.shape
     wt = _bf(weight).t().contiguous()                                 # [K, N]: dgrad as an NT product
     if pre is not None:
-        g = ops.gelu_bwd(dyb, pre.contiguous())                       # dy * gelu'(pre-activation), bf16
+        g = ops.gelu_bwd(dyb, pre.contiguous())                       # dy * gelu'(pre), bf16
     else:
         g = dyb
     dx = ops.gemm_nt(g, wt)
