@@ -281,6 +281,40 @@ int mmbert_heads_tanh(mmbert_stream_t stream, float* x, size_t n);            /*
 int mmbert_heads_tanh_bwd(mmbert_stream_t stream, const float* dP, const float* P, float* dpre, size_t n);
 int mmbert_heads_colsum(mmbert_stream_t stream, int nseg, const float* const* src, float* const* dst, const int* rows, const int* cols, const int* ld);
 
+/* ---- the pretraining heads, one launch per dependency level (round 6; csrc/heads_coop.hip) ----
+ * Everything downstream of the [CLS] rows (pooler HF:457-463; REF:MMBertForPretraining.py:293-301 align / seq_relationship, :399-443 gates,
+ * gated concatenation, classifier1_1 / 1_2, losses; CPC REF:MMBertEmbedding.py:21-32) from ONE call that issues seven launches, and its whole
+ * backward -- the gradient of the [CLS] rows and of every head parameter -- from one more call (six launches).
+ * fp32 throughout (products on the fp32 MFMA), no data atomics: results do not depend on scheduling.
+ * Row order of every [3B, H] array: modality-major (text, visual, speech).  B <= 128, H % 16 == 0, the regression head (one output).
+ *   first      fp32 [3B, H] (ld H) -- or NULL: row i is row first_rows[i] of the bf16 matrix y (ldy elements per row; ldy % 4 == 0)
+ *   ap         int64 [2B] alignment labels (visual rows, then speech rows) -- or ap [B] (visual) and ap2 [B] (speech) when ap2 != NULL; sent fp32 [B]; mlm fp32 [nmlm] per-pass MLM losses (nmlm may be 0)
+ *   parameters fp32 in PyTorch's Linear layout [out, in]: Wp (pooler), Wal (align [2,H]), Wsr (seq_relationship [2,H]), Wat (attn [H,2H]),
+ *              vw[m] / vb[m] (vt, vv, vs: [H] / [1]), Wc1 (classifier1_1 [H,3H]), Wc2 (classifier1_2 [1,H]), Wq[m] (cpc_z{t,v,a}.net [H,H])
+ *   forward    loss[1] = alpha * mean(mlm) + ap_loss + label_loss - beta * nce (REF :427,:443), aux[3] = {ap_loss, label_loss, nce},
+ *              out5[5] = {ap, label, nce, heads, joint}, logits[B] (tanh applied when tanh_lo), t_rel [B,2], rel [2B,2]
+ *   ws         mmbert_heads_step_workspace(B, H) bytes; written by forward, read and extended by backward (same B, H)
+ *   backward   dloss: device scalar (upstream gradient of `loss`); dfirst fp32 [3B, H]; dmlm [nmlm] = dloss * alpha / nmlm;
+ *              g*: the parameters' gradients, ACCUMULATED (+=); gWat has row pitch 2H like Wat
+ *   sync       4 zero-initialised uint32 in device memory (the loss level's "last workgroup assembles the losses" counter); left zeroed;
+ *              one buffer per stream in flight */
+typedef struct {
+    int B, H, tanh_lo, nmlm;
+    float alpha, beta;
+    const float* first; const void* y; const int64_t* first_rows; int ldy, pad0_;
+    const int64_t* ap; const int64_t* ap2; const float* sent; const float* mlm;
+    const float *Wp, *bp, *Wal, *bal, *Wsr, *bsr, *Wat, *bat, *vw[3], *vb[3], *Wc1, *bc1, *Wc2, *bc2, *Wq[3], *bq[3];
+    float *loss, *aux, *out5, *logits, *t_rel, *rel;
+    float* ws;
+    const float* dloss; float* dfirst; float* dmlm;
+    float *gWp, *gbp, *gWal, *gbal, *gWat, *gbat, *gvw[3], *gvb[3], *gWc1, *gbc1, *gWc2, *gbc2, *gWq[3], *gbq[3];
+    unsigned* sync;
+} mmbert_heads_step;
+int mmbert_heads_step_struct_size(void);          /* sizeof(mmbert_heads_step): bindings check their mirror of the struct against it */
+size_t mmbert_heads_step_workspace(int B, int H);
+int mmbert_heads_step_fwd(mmbert_stream_t stream, const mmbert_heads_step* p);
+int mmbert_heads_step_bwd(mmbert_stream_t stream, const mmbert_heads_step* p);
+
 /* ---- the heads' dense layers: lists of fp32 products with at most 64 rows, one launch per dependency level ----
  * mmbert_skinny_mm: for every op, Y[M, N] += bias + sum_j X_j . op(W_j) -- the sum is split over workgroups and added with fp32
  * atomics, so Y must hold zeros (or the value to add to) before the call; `act` must be 0 and `accumulate` is informational

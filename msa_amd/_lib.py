@@ -64,6 +64,10 @@ SIGNATURES = {
     "mmbert_skinny_mm": (I, [P, I, P]),
     "mmbert_skinny_mm_workspace": (SZ, [I, P]),
     "mmbert_skinny_mm_ordered": (I, [P, I, P, P]),
+    "mmbert_heads_step_struct_size": (I, []),
+    "mmbert_heads_step_workspace": (SZ, [I, I]),
+    "mmbert_heads_step_fwd": (I, [P, P]),
+    "mmbert_heads_step_bwd": (I, [P, P]),
     "mmbert_layer_fwd": (I, [P, P, P]),
     "mmbert_layer_bwd": (I, [P, P, P]),
     "mmbert_layer_struct_sizes": (I, [P]),

@@ -12,7 +12,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libmmbert_hip.so")
-SOURCES = ["gemm.hip", "attention.hip", "rowwise.hip", "heads.hip", "layer.hip"]
+SOURCES = ["gemm.hip", "attention.hip", "rowwise.hip", "heads.hip", "heads_coop.hip", "layer.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffast-math", "-fno-finite-math-only"]
 EXTRA = os.environ.get("MMBERT_HIPCC_FLAGS", "").split()

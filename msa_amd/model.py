@@ -873,7 +873,15 @@ class _MLMHeadFn(torch.autograd.Function):
         y = y.contiguous()
         ctx.compact = False
         ctx.first_rows = first_rows
-        first = y.index_select(0, first_rows).float() if first_rows is not None else None
+        first = None
+        if first_rows is not None:
+            if getattr(top, "_heads_read_rows", False):
+                # the level-launch heads (_HeadsStepFn) read rows first_rows of y themselves: `first` only carries the autograd edge (an
+                # uninitialised buffer: no gather, no cast); the real operand travels beside the graph, like the trunk's compact gradient
+                first = torch.empty((first_rows.numel(), H), device=y.device, dtype=torch.float32)
+                top.__dict__["_heads_src"] = (y, first_rows, first.data_ptr())
+            else:
+                first = y.index_select(0, first_rows).float()
         if (not want_scores) and keep and rows is not None and getattr(top, "sparse_mlm_backward", True):
             # the caller does not want the prediction scores: the whole head runs on the labelled rows only (the loss is a mean
             # over them; trainer.py never reads the scores) -- forward included
@@ -1520,6 +1528,93 @@ class MMBertPreTrainingHeads(nn.Module):
         return scores, self.seq_relationship(pooled_output)
 
 
+class _HeadsStepFn(torch.autograd.Function):
+    """The heads, one launch per dependency level (csrc/heads_coop.hip, round 6): ``mmbert_heads_step_fwd`` (ONE C call, seven launches) evaluates
+    everything downstream of the [CLS] rows -- pooler, align / seq_relationship scores, gates, gated concatenation, classifier1_1 / 1_2, the
+    three CPC terms, the losses and the joint loss -- and ``mmbert_heads_step_bwd`` (one call, six launches) its whole hand-derived backward
+    (the gradient of the [CLS] rows, every head parameter's gradient accumulated into ``p.grad``, the gradient of the per-pass MLM losses).
+    Same arithmetic and interface as ``_HeadsFn`` (19 launches + ~8 ATen launches around them: gather / cast of the rows, zero fills, cat),
+    which stays as ``model.coop_heads = False`` and as this path's reference in the tests; no atomics, so no separate deterministic form.
+    ``first``: fp32 [3B, H]; or, with ``src = (y bf16 [tokens, H], rows int64 [3B])``, a placeholder whose rows the kernel reads from y."""
+
+    @staticmethod
+    def forward(ctx, first, top, ap, sent, mlm=None, src=None):
+        B, H = first.shape[0] // 3, first.shape[1]
+        dev = first.device
+        a = ops.heads_step_struct()
+        a.B, a.H, a.tanh_lo = B, H, 1 if top.num_labels == 1 else 0
+        a.alpha, a.beta = float(top.alpha), float(top.beta)
+        keep = []
+        if src is not None:
+            y, rows = src
+            assert y.dtype == torch.bfloat16 and y.stride(1) == 1 and rows.dtype == torch.int64 and rows.is_contiguous() and rows.numel() == 3 * B
+            a.first, a.y, a.first_rows, a.ldy = None, y.data_ptr(), rows.data_ptr(), y.stride(0)
+        else:
+            first = first.contiguous()
+            assert first.dtype == torch.float32
+            a.first = first.data_ptr()
+        if mlm is not None:
+            mlm = mlm.detach().float().contiguous()
+            a.mlm, a.nmlm = mlm.data_ptr(), mlm.numel()
+            keep.append(mlm)
+        pool, al, sr, at = top.bert.pooler.dense, top.cls.align, top.cls.seq_relationship, top.attn
+        vs3 = (top.vt, top.vv, top.vs)
+        c1, c2 = top.classifier1_1, top.classifier1_2
+        qs = (top.cpc_zt.net, top.cpc_zv.net, top.cpc_za.net)
+        assert c2.weight.shape[0] == 1 and at.weight.is_contiguous()
+        a.Wp, a.bp, a.Wal, a.bal, a.Wsr, a.bsr = (t.data_ptr() for t in (pool.weight, pool.bias, al.weight, al.bias, sr.weight, sr.bias))
+        a.Wat, a.bat, a.Wc1, a.bc1, a.Wc2, a.bc2 = (t.data_ptr() for t in (at.weight, at.bias, c1.weight, c1.bias, c2.weight, c2.bias))
+        for m in range(3):
+            a.vw[m], a.vb[m], a.Wq[m], a.bq[m] = vs3[m].weight.data_ptr(), vs3[m].bias.data_ptr(), qs[m].weight.data_ptr(), qs[m].bias.data_ptr()
+        if isinstance(ap, tuple):                              # (visual labels [B], speech labels [B]): no concatenation launch
+            ap = tuple(t.contiguous() for t in ap)
+            assert all(t.dtype == torch.int64 and t.numel() == B for t in ap)
+            a.ap, a.ap2 = ap[0].data_ptr(), ap[1].data_ptr()
+        else:
+            ap = ap.contiguous()
+            assert ap.dtype == torch.int64 and ap.numel() == 2 * B
+            a.ap = ap.data_ptr()
+        sent = sent.contiguous()
+        assert sent.dtype == torch.float32 and sent.numel() == B
+        f32 = torch.float32
+        loss, aux, out5 = torch.empty((), device=dev, dtype=f32), torch.empty(3, device=dev, dtype=f32), torch.empty(5, device=dev, dtype=f32)
+        logits, t_rel, rel = torch.empty((B, 1), device=dev, dtype=f32), torch.empty((B, 2), device=dev, dtype=f32), torch.empty((2 * B, 2), device=dev, dtype=f32)
+        ws = ops.heads_step_workspace(B, H, dev)
+        a.sent = sent.data_ptr()
+        a.loss, a.aux, a.out5, a.logits, a.t_rel, a.rel, a.ws = (t.data_ptr() for t in (loss, aux, out5, logits, t_rel, rel, ws))
+        a.sync = ops.heads_step_sync(dev).data_ptr()
+        ops.heads_step_fwd(a)
+        ctx.top, ctx.a, ctx.B, ctx.H, ctx.keep = top, a, B, H, (keep, ap, sent, ws, out5)
+        ctx.save_for_backward(*([] if src is not None else [first]))
+        ctx.mark_non_differentiable(aux, logits, t_rel, rel)
+        ctx.set_materialize_grads(False)
+        return loss, aux, logits, t_rel, rel
+
+    @staticmethod
+    def backward(ctx, d, *_unused):
+        if d is None:
+            return None, None, None, None, None, None
+        top, a, B, H = ctx.top, ctx.a, ctx.B, ctx.H
+        dev = d.device
+        d1 = d.reshape(1).float().contiguous()
+        dfirst = torch.empty((3 * B, H), device=dev, dtype=torch.float32)
+        dmlm = torch.empty(a.nmlm, device=dev, dtype=torch.float32) if a.nmlm else None
+        pool, al, at = top.bert.pooler.dense, top.cls.align, top.attn
+        vs3 = (top.vt, top.vv, top.vs)
+        c1, c2 = top.classifier1_1, top.classifier1_2
+        qs = (top.cpc_zt.net, top.cpc_zv.net, top.cpc_za.net)
+        a.dloss, a.dfirst, a.dmlm = d1.data_ptr(), dfirst.data_ptr(), ops._ptr(dmlm)
+        a.gWp, a.gbp, a.gWal, a.gbal = (t.grad.data_ptr() for t in (pool.weight, pool.bias, al.weight, al.bias))
+        a.gWat, a.gbat, a.gWc1, a.gbc1, a.gWc2, a.gbc2 = (t.grad.data_ptr() for t in (at.weight, at.bias, c1.weight, c1.bias, c2.weight, c2.bias))
+        for m in range(3):
+            a.gvw[m], a.gvb[m], a.gWq[m], a.gbq[m] = (vs3[m].weight.grad.data_ptr(), vs3[m].bias.grad.data_ptr(), qs[m].weight.grad.data_ptr(),
+                                                      qs[m].bias.grad.data_ptr())
+        assert at.weight.grad.is_contiguous()
+        a.sync = ops.heads_step_sync(dev).data_ptr()
+        ops.heads_step_bwd(a)
+        return dfirst, None, None, None, dmlm, None
+
+
 class _HeadsFn(torch.autograd.Function):
     """heads_loss = ap_loss + label_loss - beta * nce and the auxiliary outputs from the [CLS] rows, with a hand-written
     backward, entirely in csrc/heads.hip: the dense layers as lists of <= 128-row fp32 products (batch <= 32: the reference's default, REF:train.py:38; mmbert_skinny_mm / _wgrad, one
@@ -1808,15 +1903,39 @@ class MMBertForPretraining(_GpuModelBase):
         heads_loss = ap_loss + label_loss - self.beta * nce
         return heads_loss, ap_loss, label_loss, nce, logits_out, t_rel, v_rel, s_rel
 
+    def _coop_heads_apply(self, sentiment, B) -> bool:
+        """Whether the level-launch heads (_HeadsStepFn) will run this step: then the MLM head leaves the [CLS] rows in the encoder output for
+        that kernel to read (no gather / cast launch)."""
+        return bool(self.fused_heads and getattr(self, "coop_heads", True) and sentiment is not None and self.num_labels in (1, 7) and B <= 128
+                    and self.config.hidden_size % 16 == 0
+                    and all(q.grad is not None for q in (self.attn.weight, self.vt.weight, self.classifier1_1.weight)))
+
     def _run_heads(self, first, ap_v, ap_s, sentiment, dev, B, mlm=None):
         """The heads on the [3B, H] [CLS] rows: the fused kernels (csrc/heads.hip) where they apply, else the eager form.
         (A captured hipGraph of the eager [B,H]-sized glue -- forward and backward, ~200 dependent launches -- was built and
         measured in round 1: no gain; the device time of the tiny kernels, not their dispatch, is the cost.)"""
-        fused = (self.fused_heads and sentiment is not None and first.is_cuda and self.num_labels in (1, 7) and B <= 32
-                 and all(q.grad is not None for q in (self.attn.weight, self.vt.weight, self.classifier1_1.weight)))
+        src = self.__dict__.pop("_heads_src", None)
+        grads_ok = all(q.grad is not None for q in (self.attn.weight, self.vt.weight, self.classifier1_1.weight))
+        fused = self.fused_heads and sentiment is not None and first.is_cuda and self.num_labels in (1, 7) and grads_ok
+        coop = fused and getattr(self, "coop_heads", True) and B <= 128 and first.shape[1] % 16 == 0
+        if src is not None and not (coop and src[2] == first.data_ptr()):
+            first = src[0].index_select(0, src[1]).float()      # (the rows were left to a path that does not run after all: gather them now)
+            src = None
+        if fused and not coop and B > 32:
+            fused = False
+            if not self.__dict__.get("_warned_heads_batch"):
+                import warnings
+                self.__dict__["_warned_heads_batch"] = True
+                warnings.warn(f"msa_amd: per-GPU batch {B} is beyond the fused heads' limit (128 samples on the level-launch path, 32 on "
+                              "the 19-launch path): the heads run in eager PyTorch (~250 small launches per step)")
         if fused:
-            ap = torch.cat((ap_v.to(dev).view(-1), ap_s.to(dev).view(-1))).long()
-            loss, aux, logits_out, t_rel, rel = _HeadsFn.apply(first, self, ap, sentiment.to(dev).view(-1).float(), mlm)
+            sent = sentiment.to(dev).view(-1).float()
+            if coop:
+                ap = (ap_v.to(dev).view(-1).long(), ap_s.to(dev).view(-1).long())
+                loss, aux, logits_out, t_rel, rel = _HeadsStepFn.apply(first, self, ap, sent, mlm, None if src is None else (src[0], src[1]))
+            else:
+                ap = torch.cat((ap_v.to(dev).view(-1), ap_s.to(dev).view(-1))).long()
+                loss, aux, logits_out, t_rel, rel = _HeadsFn.apply(first, self, ap, sent, mlm)
             return loss, aux[0], aux[1], aux[2], logits_out, t_rel, rel[:B], rel[B:]
         out = self._heads(first, ap_v.to(dev), ap_s.to(dev), None if sentiment is None else sentiment.to(dev))
         if mlm is not None:                                   # joint loss, eager form   (:427, :443)
@@ -1859,6 +1978,7 @@ class MMBertForPretraining(_GpuModelBase):
         want_rows = torch.is_grad_enabled() and getattr(self, "sparse_mlm_backward", True) and labels.is_cuda
         y, plan, lens, rows = self._encode(passes, labels, want_rows, packed=pk)
         trunk, self._last_trunk = self._last_trunk, None
+        self._heads_read_rows = self._coop_heads_apply(sentiment, B)
         # first = [3B, H]: the [CLS] rows of every sequence; joint_loss = alpha * (mlm_t + mlm_v + mlm_s) / 3 + heads_loss  (:427, :443)
         mlm, logits, first = _MLMHeadFn.apply(y, self.cls.predictions.transform.LayerNorm.weight, self, labels, plan["bounds"], plan["bounds_dev"],
                                               self.return_scores, rows, plan["first"], trunk)
@@ -1909,6 +2029,7 @@ class MMBertForPretraining(_GpuModelBase):
         # the visual padding sits in the MIDDLE of the fused sequence: valid-first packing over the row set, not over a prefix
         y, plan, lens, rows = self._encode(passes, labels, want_rows, rowset=getattr(self, "fused_rowset_packing", True), packed=pk)
         trunk, self._last_trunk = self._last_trunk, None
+        self._heads_read_rows = self._coop_heads_apply(sentiment, B)
         mlm, logits, first = _MLMHeadFn.apply(y, self.cls.predictions.transform.LayerNorm.weight, self, labels, plan["bounds"], plan["bounds_dev"],
                                               self.return_scores, rows, plan["first"].repeat(3), trunk)   # the one [CLS] row in the t / v / s slots
         joint_loss, ap_loss, label_loss, nce, logits_out, _t_rel, v_rel, _s_rel = self._run_heads(first, ap_v, ap_s, sentiment, dev, B, mlm=mlm)

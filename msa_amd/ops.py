@@ -1067,6 +1067,56 @@ def heads_colsum(pairs):
                                                IA(*[s.stride(0) for s, _ in pairs])), "mmbert_heads_colsum")
 
 
+# ------------------------------------------------------------------------------------ the heads, one launch per dependency level (csrc/heads_coop.hip)
+_VP, _VP3 = ctypes.c_void_p, ctypes.c_void_p * 3
+
+
+class _HeadsStep(ctypes.Structure):
+    """Mirror of ``mmbert_heads_step`` (include/mmbert_hip.h), field for field."""
+    _fields_ = ([("B", ctypes.c_int), ("H", ctypes.c_int), ("tanh_lo", ctypes.c_int), ("nmlm", ctypes.c_int), ("alpha", ctypes.c_float), ("beta", ctypes.c_float),
+                 ("first", _VP), ("y", _VP), ("first_rows", _VP), ("ldy", ctypes.c_int), ("pad0_", ctypes.c_int), ("ap", _VP), ("ap2", _VP), ("sent", _VP), ("mlm", _VP)]
+                + [(n, _VP) for n in ("Wp", "bp", "Wal", "bal", "Wsr", "bsr", "Wat", "bat")] + [("vw", _VP3), ("vb", _VP3)]
+                + [(n, _VP) for n in ("Wc1", "bc1", "Wc2", "bc2")] + [("Wq", _VP3), ("bq", _VP3)]
+                + [(n, _VP) for n in ("loss", "aux", "out5", "logits", "t_rel", "rel", "ws", "dloss", "dfirst", "dmlm")]
+                + [(n, _VP) for n in ("gWp", "gbp", "gWal", "gbal", "gWat", "gbat")] + [("gvw", _VP3), ("gvb", _VP3)]
+                + [(n, _VP) for n in ("gWc1", "gbc1", "gWc2", "gbc2")] + [("gWq", _VP3), ("gbq", _VP3)] + [("sync", _VP)])
+
+
+_heads_sync = {}
+_heads_struct_checked = False
+
+
+def heads_step_struct() -> "_HeadsStep":
+    global _heads_struct_checked
+    if not _heads_struct_checked:
+        n = _lib.load().mmbert_heads_step_struct_size()
+        if n != ctypes.sizeof(_HeadsStep):
+            raise RuntimeError(f"mmbert_heads_step: the library's struct has {n} bytes, the binding's {ctypes.sizeof(_HeadsStep)}")
+        _heads_struct_checked = True
+    return _HeadsStep()
+
+
+def heads_step_sync(device) -> torch.Tensor:
+    """The four zeroed counter words of the heads' loss level for the current stream (the kernel leaves them zeroed)."""
+    key = (device, _stream())
+    t = _heads_sync.get(key)
+    if t is None:
+        t = _heads_sync[key] = torch.zeros(4, device=device, dtype=torch.int32)
+    return t
+
+
+def heads_step_workspace(B: int, H: int, device) -> torch.Tensor:
+    return torch.empty(_lib.load().mmbert_heads_step_workspace(int(B), int(H)) // 4, device=device, dtype=torch.float32)
+
+
+def heads_step_fwd(a: "_HeadsStep"):
+    _lib.check(_lib.load().mmbert_heads_step_fwd(_stream(), ctypes.addressof(a)), "mmbert_heads_step_fwd")
+
+
+def heads_step_bwd(a: "_HeadsStep"):
+    _lib.check(_lib.load().mmbert_heads_step_bwd(_stream(), ctypes.addressof(a)), "mmbert_heads_step_bwd")
+
+
 # ------------------------------------------------------------------------------------ the heads' dense layers (skinny fp32 products)
 class _SkSrc(ctypes.Structure):
     _fields_ = [("X", ctypes.c_void_p), ("W", ctypes.c_void_p), ("ldx", ctypes.c_int), ("ldw", ctypes.c_int), ("inner", ctypes.c_int),

@@ -8,7 +8,7 @@ python -m msa_amd.build >/dev/null
 mkdir -p tools/_ab
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffast-math -fno-finite-math-only -Imsa_amd/csrc -c "$src" -o /tmp/_ab_variant.o
 objs=""
-for f in gemm attention rowwise heads layer; do
+for f in gemm attention rowwise heads heads_coop layer; do
     if [ "$f" = "$which" ]; then objs="$objs /tmp/_ab_variant.o"; else objs="$objs msa_amd/_obj/$f.o"; fi
 done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o "$out" $objs

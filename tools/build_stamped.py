@@ -7,7 +7,7 @@ OUT = os.path.join(ROOT, "tools", "_stamp")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffast-math", "-fno-finite-math-only", "-DMMB_STAMPS"]
 os.makedirs(OUT, exist_ok=True)
 procs, objs = [], []
-for f in ("gemm", "attention", "rowwise", "heads", "layer"):
+for f in ("gemm", "attention", "rowwise", "heads", "heads_coop", "layer"):
     o = os.path.join(OUT, f + "_stamps.o")
     objs.append(o)
     procs.append(subprocess.Popen(["/opt/rocm/bin/hipcc", *FLAGS, "-c", os.path.join(ROOT, "msa_amd", "csrc", f + ".hip"), "-o", o]))
