@@ -62,23 +62,25 @@ __device__ __forceinline__ f32x4 hc_mfma4(const float4 a, const float4 b, f32x4 
 // One 16 x 16 tile per WORKGROUP: D[m][n] = sum_k A(m, k) B(k, n), K % 16 == 0, split over the 16 waves in 16-deep granules.
 // la(row, k) / lb(col, k) return the four operand values at k .. k + 3 (lane (c, g) asks for row / col = 16 t + c and k = granule + 4 g);
 // ep(row, col, value) is called once per tile element (thread = (row = tid >> 4, col = tid & 15), 64-byte runs per row).
-template <class LA, class LB, class EP>
+// NB = 16-deep granules whose operand loads are in flight together (2 NB 16-byte loads per lane): 4 by default, 12 for the K = 3 H products,
+// whose waves hold 9 (H = 768) to 12 (H = 1024) granules -- one round trip instead of three.
+template <int NB = 4, class LA, class LB, class EP>
 __device__ __forceinline__ void hc_wg_tile(const HcCtx& c, int tm, int tn, int K, LA la, LB lb, EP ep) {
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, cc = lane & 15, g = lane >> 4;
     const int gran = K >> 4, gpw = (gran + HC_WAVES - 1) / HC_WAVES;
     const int g0 = wave * gpw, g1 = min(g0 + gpw, gran);
     const int m = tm * 16 + cc, n = tn * 16 + cc;
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    for (int q = g0; q < g1; q += 4) {                                 // up to 8 16-byte loads in flight per lane
-        float4 a[4], b[4];
+    for (int q = g0; q < g1; q += NB) {
+        float4 a[NB], b[NB];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < NB; ++u) {
             const int k = (min(q + u, g1 - 1) << 4) + 4 * g;
             a[u] = la(m, k);
             b[u] = lb(n, k);
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u)
+        for (int u = 0; u < NB; ++u)
             if (q + u < g1) acc = hc_mfma4(a[u], b[u], acc);           // (wave-uniform)
     }
     *(f32x4*)(c.red + wave * 256 + lane * 4) = acc;                    // acc[r] = D[4 g + r][cc]
@@ -103,7 +105,27 @@ __device__ __forceinline__ void hc_wave_tile(int tm, int tn, int K, LA la, LB lb
 #pragma unroll
     for (int r = 0; r < 4; ++r) ep(tm * 16 + 4 * g + r, tn * 16 + cc, acc[r]);
 }
-
+// ... two tiles of one job side by side (tile t and, when has2, tile t2; tiles_n column tiles per row of tiles): the second tile's operand loads
+// and read-modify-write traffic overlap the first one's (a wave's tiles are otherwise a chain of dependent round trips)
+template <class LA, class LB, class EP>
+__device__ __forceinline__ void hc_wave_tile_pair(int t, int t2, bool has2, int tiles_n, int K, LA la, LB lb, EP ep) {
+    const int lane = threadIdx.x & 63, cc = lane & 15, g = lane >> 4;
+    const int tm = t / tiles_n, tn = t - tm * tiles_n, tm2 = t2 / tiles_n, tn2 = t2 - tm2 * tiles_n;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};
+    for (int k0 = 0; k0 < K; k0 += 16) {
+        const float4 a = la(tm * 16 + cc, k0 + 4 * g), b = lb(tn * 16 + cc, k0 + 4 * g);
+        float4 a2 = make_float4(0.f, 0.f, 0.f, 0.f), b2 = a2;
+        if (has2) { a2 = la(tm2 * 16 + cc, k0 + 4 * g); b2 = lb(tn2 * 16 + cc, k0 + 4 * g); }
+        acc = hc_mfma4(a, b, acc);
+        if (has2) acc2 = hc_mfma4(a2, b2, acc2);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) ep(tm * 16 + 4 * g + r, tn * 16 + cc, acc[r]);
+    if (has2) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) ep(tm2 * 16 + 4 * g + r, tn2 * 16 + cc, acc2[r]);
+    }
+}
 // p.arr[m] with a run-time m as two selects (a run-time index into the kernel-argument struct would send the whole struct to scratch memory)
 template <class T> __device__ __forceinline__ T hc_pick(T const (&a)[3], int m) { return m == 0 ? a[0] : (m == 1 ? a[1] : a[2]); }
 __device__ __forceinline__ float4 hc_ld4(const float* p) { return *(const float4*)p; }
@@ -227,7 +249,7 @@ __global__ __launch_bounds__(HC_THREADS) void heads_fwd_level_kernel(const mmber
     if constexpr (LEVEL == 4) {
     // ---- F4: T = classifier1_1(cat_m(P_m * g_m))  (REF :411-414), the gated concatenation formed by the operand loader
     for (int t = c.wg; t < tB * tH; t += c.nwg) {
-        hc_wg_tile(c, t / tH, t % tH, 3 * H,
+        hc_wg_tile<10>(c, t / tH, t % tH, 3 * H,
                    [&](int b, int k) { const int m = k / H, row = m * B + min(b, B - 1); return hc_scale4(mem.ld4(w.P + (size_t)row * H + (k - m * H)), hc_ldc(w.g + row)); },
                    [&](int n, int k) { return hc_ld4(p.Wc1 + (size_t)n * 3 * H + k); },
                    [&](int b, int n, float s) { if (b < B) hc_stc(w.T + (size_t)b * H + n, s + p.bc1[n]); });
@@ -386,6 +408,8 @@ __global__ __launch_bounds__(HC_THREADS) void heads_bwd_level_kernel(const mmber
     const int tid = threadIdx.x, wave = tid >> 6;
     const int gwave = c.wg * HC_WAVES + wave, nwave = c.nwg * HC_WAVES;
     const int gthread = c.wg * HC_THREADS + tid, nthread = c.nwg * HC_THREADS;
+    // wave jobs and column jobs are handed out from the LAST workgroup down: the first ones hold the level's workgroup tiles
+    const int rwave = nwave - 1 - gwave, rthread = nthread - 1 - gthread;
     const HcWs w = hc_ws(B, H, p.ws, nullptr);
     const HcMem mem = {};
     const float* firstf = p.first ? p.first : w.first;
@@ -430,19 +454,18 @@ __global__ __launch_bounds__(HC_THREADS) void heads_bwd_level_kernel(const mmber
     // ---- B2: dT = sum_m dXP_m Wq_m + dlo Wc2;  weight gradients of the CPC projections (their operands are final)
     {
         for (int t = c.wg; t < tB * tH; t += c.nwg) {
-            hc_wg_tile(c, t / tH, t % tH, 3 * H,
+            hc_wg_tile<12>(c, t / tH, t % tH, 3 * H,
                        [&](int b, int k) { const int m = k / H; return mem.ld4(w.dXP + ((size_t)m * B + min(b, B - 1)) * H + (k - m * H)); },
                        [&](int n, int k) { const int m = k / H; return hc_col4(hc_pick(p.Wq, m), H, k - m * H, n); },
                        [&](int b, int n, float s) { if (b < B) hc_stc(w.dT + (size_t)b * H + n, s + w.dlo[b] * p.Wc2[n]); });
         }
-        for (int t = gwave; t < 3 * tH * tH; t += nwave) {                 // gWq_m[n][k] += d sum_b dXP_m[b][n] T[b][k]
-            const int m = t / (tH * tH), r = t - m * tH * tH;
-            float* gW = hc_pick(p.gWq, m);
-            hc_wave_tile(r / tH, r % tH, B, [&](int n, int b) { return hc_col4_lim<true>(w.dXP + (size_t)m * B * H, H, b, n, B); },
-                         [&](int k, int b) { return hc_col4_lim(w.T, H, b, k, B); },
-                         [&](int n, int k, float s) { gW[(size_t)n * H + k] += d * s; });
+        for (int t = rwave; t < 3 * tH * tH; t += 2 * nwave) {             // gWq_m[n][k] += d sum_b dXP_m[b][n] T[b][k]   (rows n' = m H + n of one 3H x H job)
+            hc_wave_tile_pair(t, t + nwave, t + nwave < 3 * tH * tH, tH, B,
+                              [&](int n, int b) { const int m = n / H; return hc_col4_lim<true>(w.dXP + (size_t)m * B * H, H, b, n - m * H, B); },
+                              [&](int k, int b) { return hc_col4_lim(w.T, H, b, k, B); },
+                              [&](int n, int k, float s) { const int m = n / H; hc_pick(p.gWq, m)[(size_t)(n - m * H) * H + k] += d * s; });
         }
-        for (int i = gthread; i < 3 * H; i += nthread) {                   // gbq_m[n] += d sum_b dXP_m[b][n]
+        for (int i = rthread; i < 3 * H; i += nthread) {                   // gbq_m[n] += d sum_b dXP_m[b][n]
             const int m = i / H, n = i - m * H;
             float s = 0.f;
             for (int b = 0; b < B; ++b) s += hc_ldc(w.dXP + ((size_t)m * B + b) * H + n);
@@ -458,15 +481,15 @@ __global__ __launch_bounds__(HC_THREADS) void heads_bwd_level_kernel(const mmber
                        [&](int n, int k) { return hc_col4(p.Wc1, 3 * H, k, n); },
                        [&](int b, int n, float s) { if (b < B) hc_stc(w.dC + (size_t)b * 3 * H + n, s); });
         }
-        for (int t = gwave; t < tH * 3 * tH; t += nwave) {                 // gWc1[n][k'] += d sum_b dT[b][n] C[b][k'],  C = gated concatenation
-            hc_wave_tile(t / (3 * tH), t % (3 * tH), B, [&](int n, int b) { return hc_col4_lim<true>(w.dT, H, b, n, B); },
+        for (int t = rwave; t < tH * 3 * tH; t += 2 * nwave) {             // gWc1[n][k'] += d sum_b dT[b][n] C[b][k'],  C = gated concatenation
+            hc_wave_tile_pair(t, t + nwave, t + nwave < tH * 3 * tH, 3 * tH, B, [&](int n, int b) { return hc_col4_lim<true>(w.dT, H, b, n, B); },
                          [&](int k, int b) { const int m = k / H; float4 v = hc_col4_lim(w.P + (size_t)m * B * H, H, b, k - m * H, B);
                                              const float* g = w.g + m * B;
                                              v.x *= g[min(b, B - 1)]; v.y *= g[min(b + 1, B - 1)]; v.z *= g[min(b + 2, B - 1)]; v.w *= g[min(b + 3, B - 1)];
                                              return v; },
                          [&](int n, int k, float s) { p.gWc1[(size_t)n * 3 * H + k] += d * s; });
         }
-        for (int i = gthread; i < 2 * H + 1; i += nthread) {
+        for (int i = rthread; i < 2 * H + 1; i += nthread) {
             float s = 0.f;
             if (i < H) { for (int b = 0; b < B; ++b) s += hc_ldc(w.dT + (size_t)b * H + i); p.gbc1[i] += d * s; }
             else if (i < 2 * H) { const int k = i - H; for (int b = 0; b < B; ++b) s += w.dlo[b] * w.T[(size_t)b * H + k]; p.gWc2[k] += d * s; }
@@ -504,12 +527,12 @@ __global__ __launch_bounds__(HC_THREADS) void heads_bwd_level_kernel(const mmber
                        [&](int row, int n, float s) {
                            if (row < R) { const float x = w.P[(size_t)row * H + n]; hc_stc(w.dpre + (size_t)row * H + n, (s + hc_ldc(w.dP0 + (size_t)row * H + n)) * (1.f - x * x)); } });
         }
-        for (int t = gwave; t < tH * tH; t += nwave) {                      // gWat[n][k] and [n][H + k] += d sum_rows dA[row][n] P[row][k]
-            hc_wave_tile(t / tH, t % tH, R, [&](int n, int r) { return hc_col4_lim<true>(w.dA, H, r, n, R); },
+        for (int t = rwave; t < tH * tH; t += 2 * nwave) {                  // gWat[n][k] and [n][H + k] += d sum_rows dA[row][n] P[row][k]
+            hc_wave_tile_pair(t, t + nwave, t + nwave < tH * tH, tH, R, [&](int n, int r) { return hc_col4_lim<true>(w.dA, H, r, n, R); },
                          [&](int k, int r) { return hc_col4_lim(w.P, H, r, k, R); },
                          [&](int n, int k, float s) { float* q = p.gWat + (size_t)n * 2 * H + k; q[0] += d * s; q[H] += d * s; });
         }
-        for (int i = gthread; i < 4 * H + 3; i += nthread) {
+        for (int i = rthread; i < 4 * H + 3; i += nthread) {
             float s = 0.f;
             if (i < H) { for (int r = 0; r < R; ++r) s += hc_ldc(w.dA + (size_t)r * H + i); p.gbat[i] += d * s; }
             else if (i < 4 * H) { const int m = (i - H) / H, k = i - H - m * H; for (int b = 0; b < B; ++b) s += hc_ldc(w.E + ((size_t)m * B + b) * H + k); hc_pick(p.gvw, m)[k] += d * s; }
@@ -529,12 +552,12 @@ __global__ __launch_bounds__(HC_THREADS) void heads_bwd_level_kernel(const mmber
                                p.dfirst[(size_t)row * H + n] = d * s;
                            } });
         }
-        for (int t = gwave; t < tH * tH; t += nwave) {                      // gWp[n][k] += d sum_rows dpre[row][n] first[row][k]
-            hc_wave_tile(t / tH, t % tH, R, [&](int n, int r) { return hc_col4_lim<true>(w.dpre, H, r, n, R); },
+        for (int t = rwave; t < tH * tH; t += 2 * nwave) {                  // gWp[n][k] += d sum_rows dpre[row][n] first[row][k]
+            hc_wave_tile_pair(t, t + nwave, t + nwave < tH * tH, tH, R, [&](int n, int r) { return hc_col4_lim<true>(w.dpre, H, r, n, R); },
                          [&](int k, int r) { return hc_col4_lim(firstf, H, r, k, R); },
                          [&](int n, int k, float s) { p.gWp[(size_t)n * H + k] += d * s; });
         }
-        for (int i = gthread; i < 3 * H + 2 + p.nmlm; i += nthread) {
+        for (int i = rthread; i < 3 * H + 2 + p.nmlm; i += nthread) {
             float s = 0.f;
             if (i < H) { for (int r = 0; r < R; ++r) s += hc_ldc(w.dpre + (size_t)r * H + i); p.gbp[i] += d * s; }
             else if (i < 3 * H) { const int n = (i - H) / H, k = i - H - n * H; for (int q = 0; q < 2 * B; ++q) s += w.drel[q * 2 + n] * firstf[(size_t)(B + q) * H + k]; p.gWal[(size_t)n * H + k] += d * s; }

@@ -124,7 +124,7 @@ def hip_dropout_masks(m, B, lens, split):
 
 
 def check_against_oracle(cfg, B, T, Pv, Pa, seed, loss_tol=3e-3, train=False, flags=None, model_seed=7, score_tol=3e-2, logit_tol=2e-2,
-                         grad_tol=0.045, score_mean_tol=None, head_grad_tol=None, report=None):
+                         grad_tol=0.045, score_mean_tol=None, head_grad_tol=None, report=None, calibrate=True):
     """``train``: the whole step in TRAIN mode (all three dropouts on, REF:trainer.py:40,66,83) -- the HIP model runs first, its masks
     are rebuilt (hip_dropout_masks) and the oracle replays them.  ``flags``: model switches set before the call.  The default
     tolerances are the L = 2 ones of the file header; deep models pass the bounds re-derived at depth (test_bert_base_12_layers_match_oracle)."""
@@ -147,12 +147,15 @@ def check_against_oracle(cfg, B, T, Pv, Pa, seed, loss_tol=3e-3, train=False, fl
         assert 0.85 < keep < 0.95 and 0.4 < float(masks["v.joint"].float().mean()) < 0.6, keep       # dropout really was on
         m.last_split = seen[0]
     p, oout, ologits = oracle_run(cfg, batch, train=train, masks=masks, probs=probs)
-    # calibrator: what bf16 storage alone does to each loss / gradient
-    pe, eout, _ = oracle_run(cfg, batch, train=train, masks=masks, probs=probs, emulate_bf16=True)
+    # calibrator: what bf16 storage alone does to each loss / gradient.  ``calibrate=False`` (the batch-16 run at the timed depth: a second
+    # fp32 oracle pass there is another ~70 s and ~45 GB): fixed bounds only -- the ones the eval-mode batch-16 test states
+    pe, eout = (None, None)
+    if calibrate:
+        pe, eout, _ = oracle_run(cfg, batch, train=train, masks=masks, probs=probs, emulate_bf16=True)
     for i, name in ((0, "joint"), (4, "ap"), (5, "label"), (6, "nce")):
         # 3e-3 relative, or 3x the deviation bf16 STORAGE alone causes in the oracle where that is larger (the 2-way alignment
         # CE of a 2-sample batch at H = 1024 moves by 1.9e-3 under storage rounding alone)
-        tol = max(loss_tol, 3.0 * rel(eout[i].detach(), oout[i].detach()))
+        tol = max(loss_tol, 3.0 * rel(eout[i].detach(), oout[i].detach())) if calibrate else loss_tol
         assert rel(out[i].detach(), oout[i].detach()) < tol, (name, float(out[i].detach()), float(oout[i].detach()), tol)
     assert out[1] is None and out[2] is None and out[3] is None
     assert float((logits.detach().float().cpu() - ologits.detach()).abs().max()) < logit_tol
@@ -191,6 +194,21 @@ def compare_gradients(m, p, pe, grad_tol=0.045, head_grad_tol=None, devs=None):
             assert float(og.norm()) < 1e-6 and float(g.norm()) < 2e-3, (n, float(g.norm()))
             continue
         dev = float((g - og).norm() / og.norm())
+        if pe is None:
+            # no calibrator (check_against_oracle(calibrate=False)): the fixed bounds of test_bert_base_12_layers_batch8_gradients_without_calibrator --
+            # encoder side grad_tol, [B, H] heads head_grad_tol, the three CPC projections (differences of nearly equal unit vectors: see there)
+            # 50 % AND 1e-3 absolute
+            if devs is not None:
+                devs[n] = dict(rel_err=dev, norm=float(og.norm()))
+            enc = n.startswith(("bert.embeddings", "bert.encoder", "bert.jointEmbeddings", "cls.predictions"))
+            if n.startswith("cpc_"):
+                assert dev < 0.5 and dev * float(og.norm()) < 1e-3, (n, dev, float(og.norm()))
+            else:
+                assert dev < (grad_tol if enc or head_grad_tol is None else head_grad_tol), (n, dev, float(og.norm()))
+            cos = float(torch.nn.functional.cosine_similarity(g.reshape(1, -1), og.reshape(1, -1)))
+            if cos < worst[0]:
+                worst = (cos, n)
+            continue
         dev_emul = float((pe[n].grad - og).norm() / og.norm())
         if devs is not None:
             devs[n] = dict(rel_err=dev, emulated_oracle_rel_err=dev_emul, norm=float(og.norm()))
@@ -670,13 +688,14 @@ def test_train_mode_step_matches_oracle_with_replayed_masks(case, shortcuts):
 
 @pytest.mark.parametrize("shortcuts", [True, False])
 def test_train_mode_step_at_the_timed_depth_matches_oracle_with_replayed_masks(shortcuts):
-    """Round 5: the replay test above at the configuration bench.py TIMES -- 12 layers, d = 768, 12 heads, I = 3072, vocabulary 30 522,
-    T = 50, A = V = 500, model.train() with dropout 0.1 / 0.1 / 0.5 (REF:trainer.py:40,66,83) -- at batch 8 (9 200 packed rows: the
-    smallest batch at which nt_choose's cost rule sends FFN-up + GELU and the GELU' input gradient to the MULTI-TILE 8-phase form on
-    224-row tiles, the form that carries the timed step; at batch 2 every launch is single-round, at batch 6 the rule takes 192-row
-    tiles).  Every
-    dropout site 8i + k for i < 12 is replayed in the oracle; asserted besides the numbers: the weight gradients of all dense layers
-    went out in ONE call (model._auto_defer_wgrads: 11 layers x 4 problems behind the sparse top layer, 12 x 4 with the short cuts
+    """Rounds 5-6: the replay test above at the configuration bench.py TIMES -- 12 layers, d = 768, 12 heads, I = 3072, vocabulary 30 522,
+    T = 50, A = V = 500, model.train() with dropout 0.1 / 0.1 / 0.5 (REF:trainer.py:40,66,83).  With the short cuts ON (the timed step) at the
+    TIMED BATCH, 16 (round 6: 18 400 packed rows, 2.75 attention rounds, the 44-problem weight-gradient call at full height; one fp32 oracle
+    pass with fixed bounds; batch 8 on hosts below 70 GiB); with them OFF at batch 8 (9 200 packed rows: the smallest batch at which
+    nt_choose's cost rule sends FFN-up + GELU and the GELU' input gradient to the MULTI-TILE 8-phase form on 224-row tiles, the form that
+    carries the timed step; at batch 2 every launch is single-round, at batch 6 the rule takes 192-row tiles) with the bf16-storage
+    calibrator.  Every dropout site 8i + k for i < 12 is replayed in the oracle; asserted besides the numbers: the weight gradients of all
+    dense layers went out in ONE call (model._auto_defer_wgrads: 11 layers x 4 problems behind the sparse top layer, 12 x 4 with the short cuts
     off) and mmbert_gemm_nt dispatched a forward and a backward shape to the multi-tile 8-phase form on 224-row tiles."""
     cfg = dict(hidden=768, layers=12, heads=12, intermediate=3072, vocab=30522, dataset="mosei", alpha=1.0, beta=1.0)
     flags = {} if shortcuts else dict(skip_padded_backward=False, sparse_top_layer_backward=False)
@@ -699,9 +718,17 @@ def test_train_mode_step_at_the_timed_depth_matches_oracle_with_replayed_masks(s
         # tolerances at L = 12 (re-derived at depth, test_bert_base_12_layers_match_oracle): losses 4e-3, scores 8e-2 max / 8e-3 mean (a bf16
         # score of magnitude >= 8 carries 3e-2 of rounding alone), regression logits 3e-2, encoder-side gradients max(6 %, 3 x the bf16-storage
         # calibrator), the [B, H]-sized head gradients max(12 %, 3 x calibrator) as in the eval-mode L = 12 batch-8 test
-        m, out, worst = check_against_oracle(cfg, 8, 50, 500, 500, seed=8, train=True, flags=flags, loss_tol=4e-3, score_tol=8e-2,
-                                             score_mean_tol=8e-3, logit_tol=3e-2, grad_tol=0.06, head_grad_tol=0.12,
-                                             report="parity_train_L12_B8" + ("" if shortcuts else "_shortcuts_off"))
+        # round 6: with the short cuts ON -- the step bench.py times -- at the TIMED BATCH, 16 (18 400 packed rows: 2.75
+        # attention rounds, the 44-problem weight-gradient call at full height), one fp32 oracle pass, the fixed bounds of the eval-mode
+        # batch-16 test (encoder side 8 %, heads 12 %, CPC 50 % and 1e-3 absolute); with them OFF at batch 8 with the bf16-storage calibrator
+        if shortcuts and _host_mem_gib() >= 70:
+            m, out, worst = check_against_oracle(cfg, 16, 50, 500, 500, seed=8, train=True, flags=flags, loss_tol=4e-3, score_tol=8e-2,
+                                                 score_mean_tol=8e-3, logit_tol=3e-2, grad_tol=0.08, head_grad_tol=0.12,
+                                                 report="parity_train_L12_B16", calibrate=False)
+        else:
+            m, out, worst = check_against_oracle(cfg, 8, 50, 500, 500, seed=8, train=True, flags=flags, loss_tol=4e-3, score_tol=8e-2,
+                                                 score_mean_tol=8e-3, logit_tol=3e-2, grad_tol=0.06, head_grad_tol=0.12,
+                                                 report="parity_train_L12_B8" + ("" if shortcuts else "_shortcuts_off"))
     finally:
         MM._EncoderFn._last_layer_sparse = staticmethod(orig)
         _ops.gemm_tn_grouped = tn_orig
@@ -1017,6 +1044,15 @@ def test_cpu_tensors_are_rejected_loudly():
 BASE12 = dict(hidden=768, layers=12, heads=12, intermediate=3072, vocab=30522, dataset="mosei", alpha=1.0, beta=1.0)
 
 
+def _host_mem_gib():
+    """MemAvailable of the host in GiB (the fp32 CPU oracle at the timed batch needs ~45 GB); a large number when it cannot be read."""
+    try:
+        with open("/proc/meminfo") as fh:
+            return {l.split(":")[0]: int(l.split()[1]) for l in fh}.get("MemAvailable", 0) // (1 << 20)
+    except OSError:
+        return 1 << 20
+
+
 def _report(name, payload):
     """Measured deviations go to gpurun_out/ (when it exists) so that the stated tolerances can be read against them."""
     import json
@@ -1187,10 +1223,11 @@ def test_reference_default_bert_large_full_size_train_step_properties():
     assert moved >= len(allp) - 6 - 24, moved                        # (key biases: zero true gradient, may or may not move)
 
 
-@pytest.mark.parametrize("B", [8, 16])
+@pytest.mark.parametrize("B", [16])
 def test_bert_base_12_layers_batch8_gradients_without_calibrator(B):
     """(B = 16, round 4: the bench's own batch -- BASELINE configs[1] exactly as benchmarked, in eval mode; ~40 GB and about three
-    minutes of fp32 CPU oracle, skipped below 70 GiB of available host memory; deviations -> gpurun_out/parity_L12_B16.json.)
+    minutes of fp32 CPU oracle, falling back to batch 8 below 70 GiB of available host memory; deviations -> gpurun_out/parity_L12_B16.json.
+    Round 6: the batch-8 case of this test went with the GPU-suite budget -- it is implied by this one plus the batch-8 TRAIN-mode replay.)
     The headline depth again at batch 8 (half the bench's batch; the fp32 CPU oracle needs about a minute and ~20 GB for it), with NO
     calibrator: the [B,H]-sized head gradients are sums over the batch of per-sample terms that partly cancel -- 17-26 % off at
     batch 2, where only the bf16-emulation calibrator bounds them -- and are better conditioned here.  Stated at L = 12, B = 8:
@@ -1201,14 +1238,8 @@ def test_bert_base_12_layers_batch8_gradients_without_calibrator(B):
       cancel to a norm of 2e-3 .. 4e-3 -- three orders below the other head gradients (0.1 .. 2.4) -- so one bf16 rounding of the
       pooled vectors (2^-9 relative) is an absolute error of that size whatever the kernel.  Deviations go to
       gpurun_out/parity_L12_B8.json (-> profiles/r3_parity_L12_B8.json)."""
-    avail = 0
-    try:
-        with open("/proc/meminfo") as fh:
-            avail = {l.split(":")[0]: int(l.split()[1]) for l in fh}.get("MemAvailable", 0) // (1 << 20)
-    except OSError:
-        pass
-    if avail and avail < (40 if B == 8 else 70):
-        pytest.skip(f"needs ~{20 * B // 8} GB of host memory for the fp32 oracle at batch {B} (MemAvailable {avail} GiB)")
+    if B == 16 and _host_mem_gib() < 70:
+        B = 8                                                            # (a small host: the batch-8 form of the same check, never a skip)
     cfg = BASE12
     batch = synthetic_batch(B, 50, 500, 500, dataset=cfg["dataset"], vocab=cfg["vocab"], seed=5)
     m = build(cfg)

@@ -707,7 +707,10 @@ def test_async_prologue_gives_the_same_training_run():
     assert float((lc - la).abs().max()) <= 3.0 * noise + 1e-3, (lc, la, noise)       # (a wrong key bias or row list moves the loss by > 0.1)
     pn = max(float((runs["a"][1][n] - runs["b"][1][n]).abs().max()) for n in runs["a"][1])
     pa = max(float((runs["async"][1][n] - runs["a"][1][n]).abs().max()) for n in runs["a"][1])
-    assert pa <= 3.0 * pn + 1e-4, (pa, pn)
+    # (round 6: the heads no longer use fp32 atomics, two identical runs now agree to ~1e-7 and are no yardstick any more for runs whose FIRST
+    # step already differs in rounding -- the packing is built before the embedding kernels in one and behind them in the other (2e-6 on the
+    # loss above); ten Adam steps at lr 3e-4 move a parameter by up to 3e-3 and turn such a difference into ~2e-4: bounded at 5e-4)
+    assert pa <= 3.0 * pn + 5e-4, (pa, pn)
 
 
 def test_data_parallel_over_rccl_world1_equals_plain_step():
