@@ -147,7 +147,6 @@ def box_probe(dev, ops, smi):
 
 
 def main():
-    smi = smi_readings() if int(os.environ.get("RANK", 0)) == 0 else None      # (a child process: before anything here initialises HIP)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -187,6 +186,8 @@ def main():
     ap.add_argument("--no-box-probe", action="store_true", help="skip the three fixed yardstick launches in front of the headline (the `box` object)")
     ap.add_argument("--rank-report", action="store_true", help="N > 1 diagnostics even on one process: per-rank step times, exposed tail (on by default for N > 1)")
     a = ap.parse_args()
+    # (rocm-smi is a child process: started before anything here initialises HIP, and only with the box yardstick)
+    smi = smi_readings() if (int(os.environ.get("RANK", 0)) == 0 and not a.no_box_probe) else None
 
     from msa_amd import ops, parallel
     from msa_amd.data import synthetic_batch, batch_to, to_fused

@@ -558,31 +558,19 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnArgs a) {
 
 // =============================================================================================
 // backward, part 2: dK, dV per 128-key tile.  4 waves x 32 keys (two 16-key blocks per wave); the
-// 64-query tiles (Q and dO, ONE LDS image each -- the transposed-read layout, row fragments read out of it --, plus the LSE / delta
-// slices) stream through two LDS buffers.
-// Round 6: scores in the SAME orientation as forward and the dQ kernel -- S^T = K.Q^T, key on the accumulator ROW, query on the lane:
-//   S^T  = K.Q^T  (+ (bias[key] - lse[q]) / scale as initial accumulator)     p = exp2(S^T*c)
-//   dP^T = V.dO^T            Pd^T = keep*p            dS^T = p*(keep*dscale*dP^T - delta[q])
-// so that a lane holds FOUR CONSECUTIVE KEYS of one query row: the two dropout hash words of a (row, 4 keys) group serve the lane
-// alone (the round-1..5 form -- S = Q.K^T, key on the lane -- held one key of four rows: four words per lane, each shared with the
-// neighbour lane: two hashes + two DPP swaps + eight selects per four scores, 15.9 VALU instructions per score against the dQ
-// kernel's 9.1).  The products that contract over the QUERY need it on the k index, i.e. in registers:
-//   dV^T += dO^T.Pd        dK^T += Q^T.dS       (B operand [k = query][n = key])
-// Pd^T / dS^T therefore go through a wave-private LDS scratch: one ds_write_b64 per 16 x 16 block as they leave the accumulator
-// (row = query, 4 consecutive keys), read back TRANSPOSED by ds_read_b64_tr_b16 -- 16 writes + 16 reads per 64-query tile and wave
-// instead of ~125 VALU instructions; no barrier (a wave's LDS operations execute in order).  dscale is applied once, to dV.
+// 64-query tiles (Q and dO, each as a row image and a transposed-read image, plus the LSE / delta
+// slices) stream through two LDS buffers.  Products, all with the key on the lane:
+//   S  = Q.K^T  (+ (bias[key] - lse[q]) / scale as initial accumulator)     p = exp2(S*c)
+//   dP = dO.V^T            Pd = keep*dscale*p            dS = p*(keep*dscale*dP - delta[q])
+//   dV^T += dO^T.Pd        dK^T += Q^T.dS       (dO^T / Q^T by transposed LDS reads)
+// The dropout hash is per (query row, key PAIR): the two lanes that hold the keys of a pair split the
+// four query rows of an accumulator register group between them and swap results with one DPP move.
 // =============================================================================================
-#define DKV_BUF 16896          // Q image 8192 | dO image 8192 | lse 256 | delta 256
-#define DKV_SCR 4096           // per wave: Pd^T block column [64 q][16 keys] bf16 (2 KiB) | dS^T (2 KiB)
-
-// row fragment (16-byte chunk `chunk` of row `row`) out of a transposed-read image (stage_tile<1>'s swizzle)
-__device__ __forceinline__ bf16x8 lds_row_frag_t(const char* tile, int row, int chunk) {
-    return *(const bf16x8*)(tile + row * 128 + ((chunk ^ (((row >> 1) & 3) << 1)) << 4));
-}
+#define DKV_BUF 33280          // Q row 8192 | Q tr 8192 | dO row 8192 | dO tr 8192 | lse 256 | delta 256
 
 template <bool DROP>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnArgs a) {
-    __shared__ __attribute__((aligned(16))) char smem[2 * DKV_BUF + 4 * DKV_SCR];
+    __shared__ __attribute__((aligned(16))) char smem[2 * DKV_BUF];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int tix = a.head_fast ? blockIdx.y : blockIdx.x, head = a.head_fast ? blockIdx.x : blockIdx.y;       // see AttnArgs::head_fast
@@ -618,33 +606,34 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnArgs a) 
     const float* lbase = a.lse + (size_t)start * a.heads + head;
     const float* dbase = a.delta + (size_t)start * a.heads + head;
     const float c2 = a.scale * LOG2E, inv_scale = 1.0f / a.scale;
-    int ki[2];
+    int ki[2], kc[2];
     bf16x8 kf[2][2], vf[2][2];
-    f32x4 kb4[2];                                            // bias / scale of the lane's four keys (accumulator rows 4g .. 4g + 3) per key block
+    float kb[2];
 #pragma unroll
     for (int kb_ = 0; kb_ < 2; ++kb_) {
         ki[kb_] = r0 + wave * 32 + kb_ * 16 + fr;
-        const int kc = min(ki[kb_], Skv - 1);
+        kc[kb_] = min(ki[kb_], Skv - 1);
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
-            kf[kb_][kk] = *(const bf16x8*)(base + a.H + (size_t)kc * a.ld_qkv + kk * 32 + 8 * g);
-            vf[kb_][kk] = *(const bf16x8*)(base + 2 * a.H + (size_t)kc * a.ld_qkv + kk * 32 + 8 * g);
+            kf[kb_][kk] = *(const bf16x8*)(base + a.H + (size_t)kc[kb_] * a.ld_qkv + kk * 32 + 8 * g);
+            vf[kb_][kk] = *(const bf16x8*)(base + 2 * a.H + (size_t)kc[kb_] * a.ld_qkv + kk * 32 + 8 * g);
         }
-        // padded array (ceil128(S) entries): keys past the end read -1e30 -> p = 0
-        kb4[kb_] = *(const f32x4*)(a.key_bias + a.bias_start[seq] + r0 + wave * 32 + kb_ * 16 + 4 * g) * inv_scale;
+        kb[kb_] = a.key_bias[a.bias_start[seq] + ki[kb_]] * inv_scale;    // padded array: keys past the end read -1e30 -> p = 0
     }
-    // dropout hash seed of (query row fr of a tile's 16-row block, the lane's first key pair of key block 0); rows and key blocks further
-    // on are wave-uniform offsets away.  Element (q, key) has index elem_base + (head S + q) Spad + key; all of these terms are multiples
-    // of 4 here, so the lane's four keys are the element pairs p, p + 1 with p even.
-    const uint32_t hseed = ((a.elem_base[seq] + (uint32_t)(head * S + fr) * (uint32_t)Spad + (uint32_t)(r0 + wave * 32 + 4 * g)) >> 1) * MMB_WEYL + a.dstream;
+    const unsigned ebase = a.elem_base[seq] + (unsigned)(head * S) * Spad;
+    // dropout hash seed of (row 4g + (lane & 1), this lane's key pair of key block 0); the other rows / key block are
+    // wave-uniform offsets away (keys past the end hash out of range: their p is 0 through the -1e30 bias)
+    const uint32_t hseed = (((ebase + (uint32_t)(4 * g + (lane & 1)) * (uint32_t)Spad) >> 1) + ((uint32_t)ki[0] >> 1)) * MMB_WEYL + a.dstream;
 
     auto stage = [&](int buf, int q0) {
         char* B = smem + buf * DKV_BUF;
-        stage_tile<1>(B, base, a.ld_qkv, q0, Sq, wave, lane);
-        stage_tile<1>(B + 8192, dob, a.H, q0, Sq, wave, lane);
+        stage_tile<0>(B, base, a.ld_qkv, q0, Sq, wave, lane);
+        stage_tile<1>(B + 8192, base, a.ld_qkv, q0, Sq, wave, lane);
+        stage_tile<0>(B + 16384, dob, a.H, q0, Sq, wave, lane);
+        stage_tile<1>(B + 24576, dob, a.H, q0, Sq, wave, lane);
         const size_t qoff = (size_t)min(q0 + lane, Sq - 1) * a.heads;
-        __builtin_amdgcn_global_load_lds(GPTR(lbase + qoff), LPTR(B + 16384), 4, 0, 0);
-        __builtin_amdgcn_global_load_lds(GPTR(dbase + qoff), LPTR(B + 16640), 4, 0, 0);
+        __builtin_amdgcn_global_load_lds(GPTR(lbase + qoff), LPTR(B + 32768), 4, 0, 0);
+        __builtin_amdgcn_global_load_lds(GPTR(dbase + qoff), LPTR(B + 33024), 4, 0, 0);
     };
 
     f32x4 dk[2][4], dv[2][4];
@@ -655,23 +644,20 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnArgs a) 
 
     const unsigned lds0 = (unsigned)(uintptr_t)LPTR(smem);
     const int tq = (lane >> 2) & 3, tp = lane & 3;
-    unsigned taddr2[2][4];                                   // transposed reads of the Q / dO images, per buffer and d-tile
+    unsigned taddr2[2][4];                                   // per buffer (ds offsets are 16-bit: the second buffer needs its own base)
 #pragma unroll
     for (int d = 0; d < 4; ++d) {
         const int r = 4 * g + tq;
         taddr2[0][d] = lds0 + r * 128 + ((d ^ ((r >> 1) & 3)) << 5) + tp * 8;
         taddr2[1][d] = taddr2[0][d] + DKV_BUF;
     }
-    const unsigned saddr2[2] = {lds0 + 16384 + 4 * fr, lds0 + 16384 + 4 * fr + DKV_BUF};     // lse / delta of query fr of a 16-row block
-    // the wave's transposition scratch: blocks of [16 queries][16 keys] bf16 (32-byte rows).  Written row-wise (lane = query fr, its
-    // four keys 4g .. 4g + 3 = 8 bytes), read transposed: lane (i, g) receives key column i of query rows 4g .. 4g + 3 (+ 16).
-    const unsigned scr0 = lds0 + 2 * DKV_BUF + wave * DKV_SCR;
-    const unsigned waddr = scr0 + fr * 32 + g * 8;           // + qt * 512 (+ 2048 for dS)
-    const unsigned raddr = scr0 + (4 * g + tq) * 32 + tp * 8;   // + ks * 1024 (rows 32 ks ..), + 512 for rows + 16 (+ 2048 for dS)
+    const unsigned saddr2[2] = {lds0 + 16 * g, lds0 + 16 * g + DKV_BUF};   // lse / delta: 4 consecutive query rows per lane group
+    const bool odd = lane & 1;
     const int ntile = (Sq + 63) >> 6;
     if (ntile > 0) stage(0, 0);                              // (q_limit may leave a sequence without any query: zeros are stored below)
     auto tile_body = [&](auto buf_c, int t) {
         constexpr int buf = decltype(buf_c)::value;
+        constexpr int BO = 0;                                // buffer base lives in the address registers
         const unsigned saddr = saddr2[buf];
         const unsigned (&taddr)[4] = taddr2[buf];
         const int q0 = t << 6;
@@ -680,79 +666,83 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnArgs a) 
         if (t + 1 < ntile) stage(buf ^ 1, q0 + 64);
         if (!wave_active) return;                            // a wave whose 32 keys lie past the sequence end only helps staging
         const char* Qs = smem + buf * DKV_BUF;
-        const char* Ds = Qs + 8192;
-        float lq[4], dq_[4];
-        {
-            float l0, l1, l2, l3, e0, e1, e2, e3;
-            asm volatile("ds_read_b32 %0, %8\n\tds_read_b32 %1, %8 offset:64\n\tds_read_b32 %2, %8 offset:128\n\tds_read_b32 %3, %8 offset:192\n\t"
-                         "ds_read_b32 %4, %8 offset:256\n\tds_read_b32 %5, %8 offset:320\n\tds_read_b32 %6, %8 offset:384\n\tds_read_b32 %7, %8 offset:448\n\t"
-                         "s_waitcnt lgkmcnt(0)"
-                         : "=&v"(l0), "=&v"(l1), "=&v"(l2), "=&v"(l3), "=&v"(e0), "=&v"(e1), "=&v"(e2), "=&v"(e3) : "v"(saddr) : "memory");
-            lq[0] = l0; lq[1] = l1; lq[2] = l2; lq[3] = l3; dq_[0] = e0; dq_[1] = e1; dq_[2] = e2; dq_[3] = e3;
-        }
+        const char* Ds = Qs + 16384;
+        f32x4 l4[4], d4[4];
+        lds_read16<BO + 32768>(l4[0], saddr); lds_read16<BO + 32768 + 64>(l4[1], saddr);
+        lds_read16<BO + 32768 + 128>(l4[2], saddr); lds_read16<BO + 32768 + 192>(l4[3], saddr);
+        lds_read16<BO + 33024>(d4[0], saddr); lds_read16<BO + 33024 + 64>(d4[1], saddr);
+        lds_read16<BO + 33024 + 128>(d4[2], saddr); lds_read16<BO + 33024 + 192>(d4[3], saddr);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
+        const bool qtail = q0 + 64 > Sq;
 #pragma unroll
         for (int qt = 0; qt < 4; ++qt) {
-            lq[qt] = lq[qt] * (-inv_scale);                  // -lse[q]/scale  (natural-log lse: exp2(S*c) with c = scale*log2e)
-            if (q0 + qt * 16 + fr >= Sq) lq[qt] = -INFINITY; // query rows past the end: p = 0
+            l4[qt] = l4[qt] * (-inv_scale);                  // -lse[q]/scale  (natural-log lse: exp2(S*c) with c = scale*log2e)
+            if (qtail) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) if (q0 + qt * 16 + 4 * g + r >= Sq) l4[qt][r] = -INFINITY;   // query rows past the end: p = 0
+            }
         }
 #pragma unroll
         for (int kb_ = 0; kb_ < 2; ++kb_) {
             f32x4 s[4], dp[4];
 #pragma unroll
             for (int qt = 0; qt < 4; ++qt) {
-                s[qt] = kb4[kb_] + lq[qt];
+                s[qt] = l4[qt] + kb[kb_];
                 dp[qt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                const bf16x8 q0f = lds_row_frag_t(Qs, qt * 16 + fr, g), q1f = lds_row_frag_t(Qs, qt * 16 + fr, 4 + g);
-                const bf16x8 o0f = lds_row_frag_t(Ds, qt * 16 + fr, g), o1f = lds_row_frag_t(Ds, qt * 16 + fr, 4 + g);
-                // D[row <-> key (A operand rows = this lane's K / V row)][col <-> query (B operand)]
-                s[qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[kb_][0], q0f, s[qt], 0, 0, 0);
-                s[qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[kb_][1], q1f, s[qt], 0, 0, 0);
-                dp[qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[kb_][0], o0f, dp[qt], 0, 0, 0);
-                dp[qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[kb_][1], o1f, dp[qt], 0, 0, 0);
+                const bf16x8 q0f = lds_row_frag(Qs, qt * 16 + fr, g), q1f = lds_row_frag(Qs, qt * 16 + fr, 4 + g);
+                const bf16x8 o0f = lds_row_frag(Ds, qt * 16 + fr, g), o1f = lds_row_frag(Ds, qt * 16 + fr, 4 + g);
+                // D[row <-> query (A operand rows)][col <-> key (B operand = this lane's K / V row)]
+                s[qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(q0f, kf[kb_][0], s[qt], 0, 0, 0);
+                s[qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(q1f, kf[kb_][1], s[qt], 0, 0, 0);
+                dp[qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(o0f, vf[kb_][0], dp[qt], 0, 0, 0);
+                dp[qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(o1f, vf[kb_][1], dp[qt], 0, 0, 0);
             }
+            f32x4 pm[4];
 #pragma unroll
             for (int qt = 0; qt < 4; ++qt) {
-                bool keep[4] = {true, true, true, true};
+                float ksc[4] = {1.f, 1.f, 1.f, 1.f};
                 if constexpr (DROP) {
-                    const uint32_t sv = ((uint32_t)(q0 + qt * 16) * ((uint32_t)Spad >> 1) + (uint32_t)kb_ * 8u) * MMB_WEYL;   // wave-uniform
-                    const uint32_t h0 = mmb_pair_mix(hseed + sv), h1 = mmb_pair_mix(hseed + sv + MMB_WEYL);
-                    keep[0] = mmb_keep16(h0 & 0xFFFFu, a.dthr); keep[1] = mmb_keep16(h0 >> 16, a.dthr);
-                    keep[2] = mmb_keep16(h1 & 0xFFFFu, a.dthr); keep[3] = mmb_keep16(h1 >> 16, a.dthr);
+                    // pair index of (row q, keys {2j,2j+1}); even lane hashes rows r = 0,2, odd lane rows 1,3, then swap.  The
+                    // seed is linear in the row: per-lane part hseed[][] (set up once), wave-uniform part by scalar arithmetic
+                    // (rows past the sequence end hash whatever they hash: their contributions are zero anyway)
+                    const uint32_t sv = ((uint32_t)(q0 + qt * 16) * ((uint32_t)Spad >> 1) + (uint32_t)kb_ * 8u) * MMB_WEYL;
+                    const uint32_t ha = mmb_pair_mix(hseed + sv);
+                    const uint32_t hb = mmb_pair_mix(hseed + sv + (uint32_t)Spad * MMB_WEYL);      // rows + 2
+                    const uint32_t xa = __builtin_amdgcn_mov_dpp(ha, 0xB1, 0xF, 0xF, true);    // quad_perm [1,0,3,2]: neighbour lane's value
+                    const uint32_t xb = __builtin_amdgcn_mov_dpp(hb, 0xB1, 0xF, 0xF, true);
+                    const uint32_t h0 = odd ? xa : ha, h1 = odd ? ha : xa, h2 = odd ? xb : hb, h3 = odd ? hb : xb;
+                    const int sh = (kc[kb_] & 1) * 16;
+                    ksc[0] = mmb_keep16((h0 >> sh) & 0xFFFFu, a.dthr) ? a.dscale : 0.f;
+                    ksc[1] = mmb_keep16((h1 >> sh) & 0xFFFFu, a.dthr) ? a.dscale : 0.f;
+                    ksc[2] = mmb_keep16((h2 >> sh) & 0xFFFFu, a.dthr) ? a.dscale : 0.f;
+                    ksc[3] = mmb_keep16((h3 >> sh) & 0xFFFFu, a.dthr) ? a.dscale : 0.f;
                 }
-                float pm[4], ds[4];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const float p = __builtin_amdgcn_exp2f(s[qt][r] * c2);
-                    pm[r] = keep[r] ? p : 0.f;                                          // dropped P, unscaled   -> dV (dscale at the end)
-                    const float dpm = keep[r] ? dp[qt][r] * a.dscale : 0.f;
-                    ds[r] = p * (dpm - dq_[qt]);                                        // dS                    -> dK
+                    pm[qt][r] = p * ksc[r];                                  // dropped P   -> dV
+                    s[qt][r] = p * (dp[qt][r] * ksc[r] - d4[qt][r]);         // dS          -> dK
                 }
-                const bf16x4 pb = {f2bf(pm[0]), f2bf(pm[1]), f2bf(pm[2]), f2bf(pm[3])};
-                const bf16x4 db = {f2bf(ds[0]), f2bf(ds[1]), f2bf(ds[2]), f2bf(ds[3])};
-                const u32x2 pw = __builtin_bit_cast(u32x2, pb), dw = __builtin_bit_cast(u32x2, db);
-                const unsigned wa = waddr + (unsigned)qt * 512u;                        // query block qt of the scratch column
-                asm volatile("ds_write_b64 %0, %1\n\tds_write_b64 %0, %2 offset:2048" :: "v"(wa), "v"(pw), "v"(dw) : "memory");
             }
-            // the wave's own writes, read back transposed (LDS operations of one wave execute in order: no barrier)
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
-                u32x2 plo, phi, slo, shi, dlo[4], dhi[4], qlo[4], qhi[4];
-                if (ks == 0) { tr_read<0>(plo, raddr); tr_read<512>(phi, raddr); tr_read<2048>(slo, raddr); tr_read<2048 + 512>(shi, raddr); }
-                else { tr_read<1024>(plo, raddr); tr_read<1536>(phi, raddr); tr_read<2048 + 1024>(slo, raddr); tr_read<2048 + 1536>(shi, raddr); }
+                const bf16x8 pf = pack8(pm[2 * ks], pm[2 * ks + 1]);
+                const bf16x8 dsf = pack8(s[2 * ks], s[2 * ks + 1]);
+                u32x2 dlo[4], dhi[4], qlo[4], qhi[4];
 #pragma unroll
                 for (int d = 0; d < 4; ++d) {
                     if (ks == 0) {
-                        tr_read<8192>(dlo[d], taddr[d]); tr_read<8192 + 16 * 128>(dhi[d], taddr[d]);
-                        tr_read<0>(qlo[d], taddr[d]); tr_read<16 * 128>(qhi[d], taddr[d]);
+                        tr_read<BO + 24576>(dlo[d], taddr[d]); tr_read<BO + 24576 + 16 * 128>(dhi[d], taddr[d]);
+                        tr_read<BO + 8192>(qlo[d], taddr[d]); tr_read<BO + 8192 + 16 * 128>(qhi[d], taddr[d]);
                     } else {
-                        tr_read<8192 + 32 * 128>(dlo[d], taddr[d]); tr_read<8192 + 48 * 128>(dhi[d], taddr[d]);
-                        tr_read<32 * 128>(qlo[d], taddr[d]); tr_read<48 * 128>(qhi[d], taddr[d]);
+                        tr_read<BO + 24576 + 32 * 128>(dlo[d], taddr[d]); tr_read<BO + 24576 + 48 * 128>(dhi[d], taddr[d]);
+                        tr_read<BO + 8192 + 32 * 128>(qlo[d], taddr[d]); tr_read<BO + 8192 + 48 * 128>(qhi[d], taddr[d]);
                     }
                 }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_sched_barrier(0);
-                const bf16x8 pf = frag_of(plo, phi), dsf = frag_of(slo, shi);
+                typedef __attribute__((ext_vector_type(8))) short s16x8;
 #pragma unroll
                 for (int d = 0; d < 4; ++d) {
                     dv[kb_][d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_of(dlo[d], dhi[d]), pf, dv[kb_][d], 0, 0, 0);
@@ -772,7 +762,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnArgs a) 
 #pragma unroll
             for (int d = 0; d < 4; ++d) {
                 bf16x4 kvv = {f2bf(dk[kb_][d][0] * a.scale), f2bf(dk[kb_][d][1] * a.scale), f2bf(dk[kb_][d][2] * a.scale), f2bf(dk[kb_][d][3] * a.scale)};
-                bf16x4 vvv = {f2bf(dv[kb_][d][0] * a.dscale), f2bf(dv[kb_][d][1] * a.dscale), f2bf(dv[kb_][d][2] * a.dscale), f2bf(dv[kb_][d][3] * a.dscale)};
+                bf16x4 vvv = {f2bf(dv[kb_][d][0]), f2bf(dv[kb_][d][1]), f2bf(dv[kb_][d][2]), f2bf(dv[kb_][d][3])};
                 *(bf16x4*)(drow + a.H + d * 16 + 4 * g) = kvv;
                 *(bf16x4*)(drow + 2 * a.H + d * 16 + 4 * g) = vvv;
             }
