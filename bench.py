@@ -84,9 +84,10 @@ def box_probe(dev, ops, smi):
       vocab_nt_us   the vocabulary NT GEMM of the step: [18400, 768] x [30592, 768]^T + bias -> bf16                 (0.865 TFLOP)
       wgrad_tn44_us the 44-problem weight-gradient call: 11 layers x (W1, W2, Wqkv, Wo) at 13 850 rows               (2.15 TFLOP)
       attn_bwd_us   attention backward at the step's layout: 16 x 50 + 32 x 550 tokens, 12 heads, dropout 0.1, all keys
-    `index` = the geometric mean of (reference microseconds / measured) over the three, reference = the FAST class of round 5
+    `index` = the geometric mean of (reference microseconds / measured) over the three, reference = a FAST-class box of round 6
     (REF_US below): 1.00 on such a box, ~0.95 on the slow class; `value_normalised` on the bench line is value / index."""
-    REF_US = {"vocab_nt_us": 800.0, "wgrad_tn44_us": 1880.0, "attn_bwd_us": 137.0}
+    # (round 6, gpurun_out/r6_bench_mid.json: a box on which the round-5 tree reads 1 262 samples/s -- the fast class; the slow class reads ~1 195-1 220)
+    REF_US = {"vocab_nt_us": 731.0, "wgrad_tn44_us": 1893.0, "attn_bwd_us": 257.0}
     H, I, heads, Vp, M, ra = 768, 3072, 12, 30592, 18400, 13850
     g = torch.Generator(device=dev)
     g.manual_seed(20260601)
@@ -136,7 +137,7 @@ def box_probe(dev, ops, smi):
     out["index"] = round(idx ** (1.0 / 3.0), 4)
     out["reference_us"] = REF_US
     out["note"] = ("stand-alone us of three fixed launches taken before the headline (median of 3-5, HIP events); index = geometric mean of reference / measured, "
-                   "reference = the fast box class of round 5")
+                   "reference = a fast-class box of round 6 (the round-5 tree reads 1 262 samples/s there)")
     props = torch.cuda.get_device_properties(dev)
     out["device"] = {"name": props.name, "cus": props.multi_processor_count, "clock_rate_khz": getattr(props, "clock_rate", None)}
     out["smi"] = smi

@@ -586,10 +586,10 @@ static int hc_check(const mmbert_heads_step* p, int* cus) {
     *cus = mmb_device_cus();
     return 0;
 }
-// a level's grid: its 16 x 16 workgroup tiles, or enough 16-wave workgroups for its wave jobs, at most one round of the chip
+// a level's grid: its 16 x 16 workgroup tiles PLUS enough 16-wave workgroups for its wave jobs (handed out from the last workgroup down, so that
+// a workgroup holds a tile or wave jobs, not both in a row), at most one round of the chip
 static inline int hc_grid(int wg_tiles, int wave_jobs, int cus, int floor_) {
-    int g = wg_tiles, w = (wave_jobs + HC_WAVES - 1) / HC_WAVES;
-    if (w > g) g = w;
+    int g = wg_tiles + (wave_jobs + HC_WAVES - 1) / HC_WAVES;
     if (g < floor_) g = floor_;
     return g > cus ? cus : (g < 1 ? 1 : g);
 }
