@@ -1472,9 +1472,12 @@ class MMBertModel(_GpuModelBase):
         if input_ids is not None and inputs_embeds is not None:
             raise ValueError("You cannot specify both input_ids and inputs_embeds at the same time")
         if input_ids is None and inputs_embeds is not None:
-            # REF:MMBertForPretraining.py:231-241 accepts pre-computed embeddings; no caller in the reference passes them and the
-            # embedding lookup is fused into the trunk here ("MMBertModel on its own")
-            raise NotImplementedError("MMBertModel: inputs_embeds is not supported on the HIP path (pass input_ids)")
+            # REF:MMBertForPretraining.py:231-235 lets the argument through its checks, but REF :264 then calls ``input_ids.long()``
+            # unconditionally: with inputs_embeds alone the REFERENCE raises AttributeError ('NoneType' object has no attribute 'long') --
+            # the path does not work there, no caller passes it, and the embedding lookup is fused into the trunk here.  Same outcome
+            # (an exception before any arithmetic), with a message that says why.
+            raise NotImplementedError("MMBertModel: inputs_embeds without input_ids is not a working path of the reference either "
+                                      "(REF:MMBertForPretraining.py:264 calls input_ids.long()); pass input_ids")
         if input_ids is None:
             raise ValueError("You have to specify either input_ids or inputs_embeds")
         top = self._owner() if self._owner is not None else self._standalone_top(
@@ -1751,6 +1754,9 @@ class MMBertForPretraining(_GpuModelBase):
         # heads through _HeadsFn (hand-written backward, csrc/heads.hip); False = the eager autograd form (_heads), in which
         # ap_loss / label_loss / nce and the relationship scores stay differentiable outputs
         self.fused_heads = os.environ.get("MMBERT_FUSED_HEADS", "1") != "0"
+        # which fused form: True = one launch per dependency level (csrc/heads_coop.hip, _HeadsStepFn: 7 + 6 launches, up to 128 samples, no
+        # atomics), False = the 19-launch form (csrc/heads.hip, _HeadsFn: up to 32 samples); beyond the limit the eager form runs, with a warning
+        self.coop_heads = True
         _hf_init(self, config.initializer_range, skip=_bert)
         # weight tying (HF:728-731): decoder.weight IS the word embedding, decoder.bias IS predictions.bias
         self.cls.predictions.decoder.weight = self.bert.embeddings.word_embeddings.weight

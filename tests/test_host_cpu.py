@@ -476,3 +476,20 @@ def test_from_pretrained_reads_legacy_and_prefixless_checkpoints_and_is_loud(tmp
     alias["cls.predictions.decoder.bias"] = hf["cls.predictions.bias"]
     m = MMBertForPretraining.from_pretrained(_write_ckpt(tmp_path / "alias", conf, alias))
     assert m.load_report["missing"] == [] and torch.equal(m.state_dict()["cls.predictions.bias"], hf["cls.predictions.bias"])
+
+
+def test_inputs_embeds_alone_raises_like_the_reference_does():
+    """REF:MMBertForPretraining.py:264 calls ``input_ids.long()`` whatever was passed: with ``inputs_embeds`` alone the reference raises
+    (AttributeError) before any arithmetic; so does this model (NotImplementedError naming that line), and both refuse ids + embeds together
+    with the reference's ValueError (REF :231)."""
+    import pytest
+    from msa_amd.model import MMBertConfig, MMBertModel
+    m = MMBertModel(MMBertConfig(vocab_size=64, hidden_size=64, num_hidden_layers=1, num_attention_heads=1, intermediate_size=128))
+    m.set_joint_embeddings("mosei")
+    x = torch.zeros(2, 5, 64)
+    with pytest.raises(NotImplementedError, match="input_ids.long"):
+        m(inputs_embeds=x)
+    with pytest.raises(ValueError, match="both input_ids and inputs_embeds"):
+        m(input_ids=torch.zeros(2, 5, dtype=torch.long), inputs_embeds=x)
+    with pytest.raises(ValueError, match="either input_ids or inputs_embeds"):
+        m()
