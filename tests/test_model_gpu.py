@@ -196,12 +196,14 @@ def compare_gradients(m, p, pe, grad_tol=0.045, head_grad_tol=None, devs=None):
         dev = float((g - og).norm() / og.norm())
         if pe is None:
             # no calibrator (check_against_oracle(calibrate=False)): the fixed bounds of test_bert_base_12_layers_batch8_gradients_without_calibrator --
-            # encoder side grad_tol, [B, H] heads head_grad_tol, the three CPC projections (differences of nearly equal unit vectors: see there)
-            # 50 % AND 1e-3 absolute
+            # encoder side grad_tol, [B, H] heads head_grad_tol; a CPC projection whose gradient is orders below the pooler's (differences of nearly
+            # equal unit vectors: see there) 50 % AND 1e-3 absolute, otherwise the heads' bound (train mode: dropout decorrelates the [CLS] rows)
             if devs is not None:
                 devs[n] = dict(rel_err=dev, norm=float(og.norm()))
             enc = n.startswith(("bert.embeddings", "bert.encoder", "bert.jointEmbeddings", "cls.predictions"))
-            if n.startswith("cpc_"):
+            pool_n = float(p["bert.pooler.dense.weight"].grad.norm())
+            if n.startswith("cpc_") and float(og.norm()) < 1e-2 * pool_n:
+                # (the eval-at-initialisation case: a difference of nearly equal unit vectors, orders below the other head gradients)
                 assert dev < 0.5 and dev * float(og.norm()) < 1e-3, (n, dev, float(og.norm()))
             else:
                 assert dev < (grad_tol if enc or head_grad_tol is None else head_grad_tol), (n, dev, float(og.norm()))

@@ -5,7 +5,7 @@
 cd "$(dirname "$0")/.."
 R=${1:-rX}
 export TMPDIR=/tmp
-BENCH="python3 bench.py --no-cpu-baseline --no-kernel-timing --no-fused --no-dense-reference --no-train-only --no-reference-default --no-scores-fp32 --no-deterministic --no-dp-reference-legs"
+BENCH="python3 bench.py --no-cpu-baseline --no-kernel-timing --no-fused --no-dense-reference --no-train-only --no-reference-default --no-scores-fp32 --no-deterministic --no-dp-reference-legs --no-box-probe"
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_$R -o $R -- $BENCH --steps 20 --warmup 5 > gpurun_out/prof_$R.log 2>&1
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $c --kernel-trace --output-format csv -d gpurun_out/pmc_${R}_$c -o pmc -- $BENCH --steps 2 --warmup 1 > gpurun_out/pmc_${R}_$c.log 2>&1
