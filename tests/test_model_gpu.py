@@ -641,8 +641,9 @@ def test_dropout_train_mode_is_seeded_and_unbiased():
     assert all(torch.isfinite(q.grad).all() for q in m.parameters())
 
 
-@pytest.mark.parametrize("shortcuts", [True, False])
-@pytest.mark.parametrize("case", ["cfg1", "base2", "deep4", "long2"])
+# (long2 with the short cuts OFF went with the GPU-suite budget, round 6: 32 s of fp32 oracle for the dense backward at S = 1425, which
+# test_full_size_long_fusion_step_is_finite_and_seeded and the dense cases of the three other shapes cover)
+@pytest.mark.parametrize("case,shortcuts", [(c_, s_) for c_ in ("cfg1", "base2", "deep4", "long2") for s_ in (True, False) if not (c_ == "long2" and not s_)])
 def test_train_mode_step_matches_oracle_with_replayed_masks(case, shortcuts):
     """The BENCHMARKED configuration -- model.train(), dropout 0.1 / 0.1 / 0.5 on, as REF:trainer.py:40,66,83 runs it -- end to end
     against the oracle: the HIP step's keep masks of every site (embeddings, JointEmbeddings, and per layer and pass the attention
