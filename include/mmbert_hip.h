@@ -76,7 +76,7 @@ void mmbert_gemm_tn_force_splits(int splits);
  *   W[N,K] (fp32, contiguous: ldw == K) = (accumulate ? W : 0) + alpha * alpha_dev[0] * A[M,N]^T . B[M,K]
  *   bias_out[N] (optional)             += alpha * alpha_dev[0] * column sums of A      (the bias gradient)
  * The token axis may be split into fp32 slabs (deterministic reduce): `slab` must hold *_workspace() bytes.
- * The grouped form runs up to 48 problems that share M in ONE call (the four dense layers of one, two or -- round 4, when nothing needs a
+ * The grouped form runs up to 52 problems that share M in ONE call (the four dense layers of one, two or -- round 4, when nothing needs a
  * layer's weight gradients before the optimizer -- up to twelve encoder layers); host arrays of length nprob.  A call of more than 8
  * problems and more tiles than CUs never splits the token axis and goes out as whole rounds of CUs-many tiles, one launch per round. */
 size_t mmbert_gemm_tn_workspace(int M, int N, int K, int* splits_out);
@@ -86,6 +86,14 @@ size_t mmbert_gemm_tn_grouped_workspace(int nprob, const int* N, const int* K, i
 int mmbert_gemm_tn_grouped(mmbert_stream_t stream, int nprob, const void* const* A, const int* lda, const void* const* B, const int* ldb,
                            float* const* W, float* const* bias, const int* N, const int* K, int M,
                            int accumulate, float alpha, const float* alpha_dev, void* slab);
+/* ... with a row count per problem (round 6): the problems of M[0] rows first, problems of FEWER rows behind them -- the weight gradients
+ * of the few hundred rows that carry a loss (tied decoder, MLM transform: HF:466-496; the top encoder layer's row-sparse sublayers), which
+ * autograd computes like all others (REF:trainer.py:83).  Their tiles ride behind the long tiles of the call's LAST launch (its idle CUs
+ * work through them); the token axis is not split in such a call.  accumulate_each (may be null: `accumulate` for all): per problem,
+ * whether it adds to W or overwrites it. */
+int mmbert_gemm_tn_grouped_rows(mmbert_stream_t stream, int nprob, const void* const* A, const int* lda, const void* const* B, const int* ldb,
+                                float* const* W, float* const* bias, const int* N, const int* K, const int* M,
+                                int accumulate, const int* accumulate_each, float alpha, const float* alpha_dev, void* slab);
 
 /* out[n] += alpha * alpha_dev[0] * sum_m X[m][n]   (bias gradients) */
 int mmbert_colsum(mmbert_stream_t stream, const void* X, int ldx, int M, int N, float* out, float alpha, const float* alpha_dev);

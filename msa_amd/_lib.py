@@ -27,6 +27,7 @@ SIGNATURES = {
     "mmbert_gemm_tn": (I, [P, P, I, P, I, P, I, I, I, I, I, F, P, P, P]),
     "mmbert_gemm_tn_grouped_workspace": (SZ, [I, P, P, I, P]),
     "mmbert_gemm_tn_grouped": (I, [P, I, P, P, P, P, P, P, P, P, I, I, F, P, P]),
+    "mmbert_gemm_tn_grouped_rows": (I, [P, I, P, P, P, P, P, P, P, P, P, I, P, F, P, P]),
     "mmbert_colsum": (I, [P, P, I, I, I, P, F, P]),
     "mmbert_rng_stream": (U32, [U64, U32]),
     "mmbert_dropout_thr16": (U32, [F]),

@@ -821,13 +821,16 @@ static int dispatch_nt(hipStream_t s, const GemmNT& p) {
 // Workgroup = 512 threads, output tile 256(n) x 256(k), one workgroup per CU: a CU issues a 16-byte-per-lane LDS-DMA every ~30-37 clk at
 // best, and a 256 x 128 tile (rounds 1-2) needed 48 of them per 1024 MFMA clocks -- load-issue bound at 58 % of the MFMA rate.
 // -------------------------------------------------------------------------------------------------
-struct TNProb { const bf16_t* A; const bf16_t* B; float* W; float* bias; int N, K, lda, ldb, tiles_k, tile0; long long slab_off; long long bias_off; };
+// (M: the problem's own token rows -- round 6: problems of FEW rows ride in the last launch of the deferred call, see mmbert_gemm_tn_grouped_rows;
+//  slab_off / bias_off in elements: int, so that 52 records stay inside the 4 KiB of kernel arguments; acc: this problem adds to W instead of
+//  overwriting it)
+struct TNProb { const bf16_t* A; const bf16_t* B; float* W; float* bias; int N, K, lda, ldb, tiles_k, tile0, M, slab_off, bias_off, acc; };
 // up to TN_MAXP problems per launch: the four dense layers of an encoder layer -- or of TWO layers (model._EncoderFn pairs them: 216
 // tiles fill the chip in one round without splitting the token axis, so no fp32 slabs and no reduce launch) -- or, round 4, of up to
 // TWELVE layers at once: without a gradient hook (one GPU) nothing needs a layer's weight gradients before the optimizer, so the model
 // defers them all to ONE call at the end of backward, which goes out as whole rounds of CUs-many tiles (11 layers = 1188 tiles = 4 full
-// launches + one of 164, against 5 paired launches at 216 of 256 CUs plus a split single layer).  48 x 64 B = 3 KiB of kernel arguments.
-#define TN_MAXP 48
+// launches + one of 164, against 5 paired launches at 216 of 256 CUs plus a split single layer).  52 x 72 B = 3.7 KiB of kernel arguments.
+#define TN_MAXP 52
 struct GemmTNG {
     TNProb pr[TN_MAXP];
     float* slab; const float* alpha_dev;
@@ -836,6 +839,7 @@ struct GemmTNG {
     int nprob, total_tiles, M, splits, rows_per_split, accumulate;
     float alpha;
     int tile_base;
+    int remap_n;                                // the launch's first remap_n workgroups take their tiles in the XCD-contiguous order; the rest (few-row tiles) in index order
 };
 
 __device__ __forceinline__ int tn_swz(int row) { return ((row & 3) | ((row >> 1) & 4)) << 1; }
@@ -874,7 +878,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn8_kernel(const GemmTNG g) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 2, wc = wave & 3;
-    int t_lin = g.tile_base + xcd_remap(blockIdx.x, gridDim.x);
+    int t_lin = g.tile_base + ((int)blockIdx.x < g.remap_n ? xcd_remap(blockIdx.x, g.remap_n) : (int)blockIdx.x);
     const __attribute__((address_space(4))) GemmTNG& gq = *(const __attribute__((address_space(4))) GemmTNG*)__builtin_amdgcn_kernarg_segment_ptr();
     int pi = 0;
     {
@@ -885,12 +889,12 @@ __global__ __launch_bounds__(512, 2) void gemm_tn8_kernel(const GemmTNG g) {
     const __attribute__((address_space(4))) TNProb& pr = gq.pr[pi];
     const bf16_t* Ap = pr.A; const bf16_t* Bp = pr.B; float* Wp = pr.W; float* biasp = pr.bias;
     const int N = pr.N, K = pr.K, lda = pr.lda, ldb = pr.ldb, tiles_k = pr.tiles_k;
-    const long long slab_off = pr.slab_off, bias_off = pr.bias_off;
+    const int slab_off = pr.slab_off, bias_off = pr.bias_off;
     t_lin -= pr.tile0;
     const int n0 = (t_lin / tiles_k) << 8, k0 = (t_lin % tiles_k) << 8;
     const int split = blockIdx.y;
     const int mbeg = split * g.rows_per_split;
-    const int mend = min(g.M, mbeg + g.rows_per_split);
+    const int mend = min(pr.M, mbeg + g.rows_per_split);
     const int nt = (mend - mbeg + 63) >> 6;                        // K tiles of 64 tokens; <= 0 for a trailing empty split
     const bool do_bias = (biasp != nullptr) && (k0 == 0);
 
@@ -1051,7 +1055,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn8_kernel(const GemmTNG g) {
     const float alpha = g.alpha * (g.alpha_dev ? *g.alpha_dev : 1.0f);
     const int fr = lane & 15, fq = lane >> 4;
     float* out = split > 0 ? g.slab + (size_t)(split - 1) * g.slab_stride + slab_off : Wp;
-    const bool accum = (split == 0) && g.accumulate;
+    const bool accum = (split == 0) && pr.acc;
 #pragma unroll
     for (int ib = 0; ib < 8; ib += 2) {                            // two k blocks at a time: their eight accumulate reads are issued together
         float4 old[2][4];
@@ -1358,15 +1362,27 @@ size_t mmbert_gemm_tn_workspace(int M, int N, int K, int* splits_out) {
     return mmbert_gemm_tn_grouped_workspace(1, &N, &K, M, splits_out);
 }
 
-// up to TN_MAXP (48) problems sharing M:  W_i[N_i,K_i] (+)= alpha * A_i^T . B_i ;  bias_i[N_i] += alpha * colsum(A_i) (bias_i may be null)
-int mmbert_gemm_tn_grouped(hipStream_t stream, int nprob, const void* const* A, const int* lda, const void* const* B, const int* ldb,
-                           float* const* W, float* const* bias, const int* N, const int* K, int M,
-                           int accumulate, float alpha, const float* alpha_dev, void* slab) {
-    if (nprob <= 0 || M <= 0) return 0;
+// up to TN_MAXP (52) problems:  W_i[N_i,K_i] (+)= alpha * A_i^T . B_i over M_i token rows;  bias_i[N_i] += alpha * colsum(A_i) (bias_i may be null).
+// The problems of M_0 rows ("long": M_i == M_0) come first; problems of FEWER rows may follow (round 6: the tied-decoder, MLM-transform and
+// top-layer weight gradients of the few hundred rows that carry a loss).  With more long tiles than CUs -- the deferred multi-layer call --
+// the long tiles go out in whole rounds of CUs-many, and the few-row tiles ride behind the LAST round's long tiles in the same launch: its
+// idle CUs (65 of 256 at the headline shape) work through them while the long tiles run, where they took four launches of their own on the
+// serial tail of backward.  The token axis is never split when few-row problems are present.
+int mmbert_gemm_tn_grouped_rows(hipStream_t stream, int nprob, const void* const* A, const int* lda, const void* const* B, const int* ldb,
+                                float* const* W, float* const* bias, const int* N, const int* K, const int* Mrows,
+                                int accumulate, const int* accumulate_each, float alpha, const float* alpha_dev, void* slab) {
+    if (nprob <= 0) return 0;
     if (nprob > TN_MAXP) return -1;
+    const int M = Mrows[0];
+    if (M <= 0) return 0;
+    int nlong = 0;
+    while (nlong < nprob && Mrows[nlong] == M) ++nlong;
+    for (int i = nlong; i < nprob; ++i)
+        if (Mrows[i] >= M || Mrows[i] <= 0) return -1;             // long problems first, then the shorter ones
     GemmTNG g;
-    int splits, tiles;
-    tn_plan(nprob, N, K, M, &splits, &tiles);
+    int splits, tiles_long, tiles_all;
+    tn_plan(nlong, N, K, M, &splits, &tiles_long);
+    if (nlong < nprob) splits = 1;
     long long off = 0, boff = 0;
     int tile0 = 0;
     TNReduce r;
@@ -1374,13 +1390,15 @@ int mmbert_gemm_tn_grouped(hipStream_t stream, int nprob, const void* const* A, 
         if ((N[i] & 7) || (K[i] & 7) || (lda[i] & 7) || (ldb[i] & 7) || N[i] < 8 || K[i] < 8) return -1;
         TNProb& q = g.pr[i];
         q.A = (const bf16_t*)A[i]; q.B = (const bf16_t*)B[i]; q.W = W[i]; q.bias = bias ? bias[i] : nullptr;
-        q.N = N[i]; q.K = K[i]; q.lda = lda[i]; q.ldb = ldb[i];
-        q.tiles_k = (K[i] + 255) / 256; q.tile0 = tile0; q.slab_off = off; q.bias_off = boff;
+        q.N = N[i]; q.K = K[i]; q.lda = lda[i]; q.ldb = ldb[i]; q.M = Mrows[i]; q.acc = accumulate_each ? accumulate_each[i] : accumulate;
+        q.tiles_k = (K[i] + 255) / 256; q.tile0 = tile0; q.slab_off = (int)off; q.bias_off = (int)boff;
         r.W[i] = W[i]; r.off[i] = off; r.bias[i] = q.bias; r.boff[i] = boff;
         boff += N[i];
         tile0 += ((N[i] + 255) / 256) * q.tiles_k;
         off += (long long)N[i] * K[i];
     }
+    tiles_all = tile0;
+    if (splits > 1 && off > 0x7fffffffLL) return -1;               // (slab offsets are ints; an unsplit launch does not read them)
     for (int i = nprob; i < TN_MAXP; ++i) { g.pr[i] = g.pr[0]; g.pr[i].tile0 = 0x7fffffff; r.W[i] = nullptr; r.bias[i] = nullptr; }
     for (int i = nprob; i <= TN_MAXP; ++i) { r.off[i] = off; r.boff[i] = boff; }
     if (splits > 1 && !slab) return -3;
@@ -1389,22 +1407,26 @@ int mmbert_gemm_tn_grouped(hipStream_t stream, int nprob, const void* const* A, 
     const bool det_bias = splits > 1 && mmb_deterministic();
     g.bias_slab = det_bias ? (float*)slab + (size_t)(splits - 1) * off : nullptr;
     g.bias_stride = boff;
-    r.bias_slab = g.bias_slab; r.bias_stride = boff; g.nprob = nprob; g.total_tiles = tiles; g.M = M;
+    r.bias_slab = g.bias_slab; r.bias_stride = boff; g.nprob = nprob; g.total_tiles = tiles_all; g.M = M;
     g.splits = splits; g.rows_per_split = (((M + splits - 1) / splits) + 31) / 32 * 32; g.accumulate = accumulate; g.alpha = alpha;
     static std::atomic<unsigned long long> attr_done8{0};
     if (int e = mmb_allow_lds((const void*)gemm_tn8_kernel, 131072, attr_done8)) return e;
     auto kern = gemm_tn8_kernel;
-    // more tiles than CUs (only the deferred multi-layer launches; never split): whole rounds of CUs-many tiles, one launch per round
     const int cus_ = device_cus();
-    if (splits == 1 && tiles > cus_) {
-        for (int base = 0; base < tiles; base += cus_) {
-            g.tile_base = base;
-            hipLaunchKernelGGL(kern, dim3(tiles - base < cus_ ? tiles - base : cus_, 1), dim3(512), 131072, stream, g);
+    const int tiles_short = tiles_all - tiles_long;
+    if (splits == 1 && (tiles_long > cus_ || tiles_short > 0)) {
+        // whole rounds of CUs-many long tiles, one launch per round (only the deferred multi-layer launches have more tiles than CUs; never
+        // split); the few-row tiles behind the last round's
+        for (int base = 0; base < tiles_long; base += cus_) {
+            const int n = tiles_long - base < cus_ ? tiles_long - base : cus_;
+            const bool last = base + cus_ >= tiles_long;
+            g.tile_base = base; g.remap_n = n;
+            hipLaunchKernelGGL(kern, dim3(n + (last ? tiles_short : 0), 1), dim3(512), 131072, stream, g);
             MMB_CHECK_LAUNCH();
         }
     } else {
-        g.tile_base = 0;
-        hipLaunchKernelGGL(kern, dim3(tiles, splits), dim3(512), 131072, stream, g);
+        g.tile_base = 0; g.remap_n = tiles_long;
+        hipLaunchKernelGGL(kern, dim3(tiles_long, splits), dim3(512), 131072, stream, g);
     }
     MMB_CHECK_LAUNCH();
     if (splits > 1) {
@@ -1415,6 +1437,17 @@ int mmbert_gemm_tn_grouped(hipStream_t stream, int nprob, const void* const* A, 
         MMB_CHECK_LAUNCH();
     }
     return 0;
+}
+
+// ... all problems over the same M token rows
+int mmbert_gemm_tn_grouped(hipStream_t stream, int nprob, const void* const* A, const int* lda, const void* const* B, const int* ldb,
+                           float* const* W, float* const* bias, const int* N, const int* K, int M,
+                           int accumulate, float alpha, const float* alpha_dev, void* slab) {
+    if (nprob <= 0 || M <= 0) return 0;
+    if (nprob > TN_MAXP) return -1;
+    int Ms[TN_MAXP];
+    for (int i = 0; i < nprob; ++i) Ms[i] = M;
+    return mmbert_gemm_tn_grouped_rows(stream, nprob, A, lda, B, ldb, W, bias, N, K, Ms, accumulate, nullptr, alpha, alpha_dev, slab);
 }
 
 int mmbert_gemm_tn(hipStream_t stream, const void* A, int lda, const void* B, int ldb, float* W, int ldw,

@@ -279,7 +279,50 @@ def _auto_defer_wgrads(H, I, L, x_dev, rows=None) -> bool:
 def _wgrad(top, probs):
     """One weight-gradient launch for ``probs`` = [(dY, X, gW (view of the flat gradient buffer), gb)]: it OVERWRITES gradients the
     optimizer has dropped (lazy zero, flat.FlatParams.take_accumulate) and accumulates otherwise."""
-    ops.gemm_tn_grouped(probs, accumulate=top._flat.take_accumulate([q[2] for q in probs]))
+    f = top._flat
+    if not f.stale:
+        ops.gemm_tn_grouped(probs, accumulate=True)
+    else:
+        # per problem: a gradient outside the lazy set (the MLM transform's: zeroed by the optimizer) in one call with dropped ones must not
+        # make take_accumulate settle those with zero fills
+        ops.gemm_tn_grouped(probs, accumulate=[f.take_accumulate([q[2]]) for q in probs])
+
+
+def _late_wgrad(top, prob, defer: bool):
+    """A weight gradient of the FEW rows that carry a loss (tied decoder, MLM transform, the top layer's row-sparse sublayers).  ``defer``:
+    it waits in ``top._late_wgrads`` for the end of the trunk's backward, where _EncoderFn.run_backward hands it to the deferred
+    multi-layer call -- its tiles then run on the CUs the call's last round leaves idle (mmbert_gemm_tn_grouped_rows) instead of as a launch
+    of 9 - 360 short tiles on the serial tail of backward.  Otherwise (a gradient hook wants final gradients early, or no trunk backward
+    follows): launched here."""
+    if defer:
+        pend = top.__dict__.setdefault("_late_wgrads", [])
+        if any(q[2] is prob[2] for q in pend):                  # a second backward stage writing the same gradient: never two writers in one launch
+            _flush_late_wgrads(top)
+            pend = top.__dict__.setdefault("_late_wgrads", [])
+        pend.append(prob)
+    else:
+        _wgrad(top, [prob])
+
+
+def _flush_late_wgrads(top, long_probs=(), deferred=False):
+    """The deferred dense problems (``long_probs``, all of the backward's row count) and whatever waits in ``top._late_wgrads``: as ONE
+    call per 12 layers when ``deferred`` (the few-row problems behind the last one's), else the few-row problems one launch each."""
+    late = top.__dict__.pop("_late_wgrads", None) or []
+    long_probs = list(long_probs)
+    if not deferred or not long_probs:
+        for c in range(0, len(long_probs), 48):
+            _wgrad(top, long_probs[c:c + 48])
+        for q in late:
+            _wgrad(top, [q])
+        return
+    chunks = [long_probs[c:c + 48] for c in range(0, len(long_probs), 48)]    # (12 layers per call: whole rounds, as measured in round 4)
+    if late and len(chunks[-1]) + len(late) <= ops.TN_MAX_PROBLEMS:
+        chunks[-1] = chunks[-1] + late
+        late = []
+    for c in chunks:
+        _wgrad(top, c)
+    for q in late:
+        _wgrad(top, [q])
 
 
 class _EncoderFn:
@@ -419,7 +462,7 @@ class _EncoderFn:
                         (dy_c,) = ops.gather_rows([dy], src_rows.int())
                 if R is not None:
                     dy = _EncoderFn._last_layer_sparse(top, lw, layout, key_bias, kv_len, saved_i, dy_c, R, H, ra, R32, lnd,
-                                                       rinv if compact is not None else None)
+                                                       rinv if compact is not None else None, deferred if defer_wgrads else None)
                     if top.grad_hook is not None:
                         lnd.flush()
                     dy_rows = None
@@ -520,8 +563,9 @@ class _EncoderFn:
             top._layer_grads_done(i)
         if own_lnd:
             lnd.flush()
-        for c in range(0, len(deferred), 48):                 # (mmbert_gemm_tn_grouped: up to 48 problems = 12 layers per launch)
-            _wgrad(top, deferred[c:c + 48])
+        # (mmbert_gemm_tn_grouped_rows: 12 layers per call; round 6: the few-row weight gradients of the MLM head and of the sparse top layer
+        # ride behind the last call's tiles)
+        _flush_late_wgrads(top, deferred, deferred=defer_wgrads)
         return dy
 
     @staticmethod
@@ -539,7 +583,7 @@ class _EncoderFn:
         return R
 
     @staticmethod
-    def _last_layer_sparse(top, lw, layout, key_bias, kv_len, saved_i, dy_c, R, H, ra, R32=None, lnd=None, rinv=None):
+    def _last_layer_sparse(top, lw, layout, key_bias, kv_len, saved_i, dy_c, R, H, ra, R32=None, lnd=None, rinv=None, deferred=None):
         """Backward of the top encoder layer when only the rows R of its output carry a gradient: the output sublayer (LayerNorm',
         FFN-down and FFN-up input gradients, their weight gradients), LayerNorm' and the output projection of the attention
         sublayer run on those rows only (gathered operands, the dropout masks of the ORIGINAL rows); attention's backward is
@@ -580,8 +624,16 @@ class _EncoderFn:
             dz1.index_copy_(0, R, dz1_c)
         out = ops.gemm_nt(dqkv, lw["WqkvT"], resid=dz1)
         # (bias gradients b1 / b2 / bo: column sums of the bf16 gradients on the ones-operand MFMA, as in the dense layers)
-        _wgrad(top, [(du_c, y1_c, lw["g_W1"], lw["g_b1"]), (dz2d_c, g_c, lw["g_W2"], lw["g_b2"]), (dz1d_c, actx_c, lw["g_Wo"], lw["g_bo"])])
-        _wgrad(top, [(dqkv, x, lw["g_Wqkv"], lw["g_bqkv"])])
+        few = [(du_c, y1_c, lw["g_W1"], lw["g_b1"]), (dz2d_c, g_c, lw["g_W2"], lw["g_b2"]), (dz1d_c, actx_c, lw["g_Wo"], lw["g_bo"])]
+        if deferred is not None and getattr(top, "late_wgrads", True):
+            # the deferred multi-layer call takes them: the QKV gradient (all rows of the backward) as one more of its problems -- it was a
+            # launch of 27 tiles with the token axis split 8 ways + a reduce launch --, the three few-row ones behind its tiles
+            deferred.append((dqkv, x, lw["g_Wqkv"], lw["g_bqkv"]))
+            for q in few:
+                _late_wgrad(top, q, True)
+        else:
+            _wgrad(top, few)
+            _wgrad(top, [(dqkv, x, lw["g_Wqkv"], lw["g_bqkv"])])
         return out
 
 
@@ -717,8 +769,10 @@ class _TrunkFn(torch.autograd.Function):
         npass = len(lens)
         layout = split if split is not None else plan["layout"]
         compact, t.compact = t.compact, None                      # (rows in the caller's order, their gradients): set by the MLM head
-        top._flat.settle([w["g_word_pad"]])                       # no MLM-head launch has overwritten a dropped table gradient (no labelled row):
-                                                                  # zero it before the embedding rows are added / the slice is reduced
+        # no MLM-head launch has overwritten a dropped table gradient (no labelled row): zero it before the embedding rows are added / the
+        # slice is reduced -- unless that launch waits in the deferred call (then after the encoder's backward, below: a no-op)
+        if not any(q[2] is w["g_word_pad"] for q in (top.__dict__.get("_late_wgrads") or ())):
+            top._flat.settle([w["g_word_pad"]])
         # ONE collector for the LayerNorm' gamma / beta sums of the whole backward -- the MLM head's call (already in it), the sparse top
         # layer's two, the dense layers', the embedding stage's: one reduce launch at the end instead of seven (a data-parallel hook
         # flushes it wherever it needs final gradients)
@@ -734,6 +788,7 @@ class _TrunkFn(torch.autograd.Function):
         dx = _EncoderFn.run_backward(top, layout, t.key_bias, None if split is not None else t.kv_len, ctx.saved, dy, dy_rows, t.top_rows,
                                      compact, lnd)
         ctx.saved = None
+        top._flat.settle([w["g_word_pad"]])
         if split is not None:
             top.last_backward_row_fraction = float(split.rows_a) / split.tokens
         # ---- embedding stage: dx holds the leading rows_a rows of the packed order (all rows without the packing)
@@ -977,14 +1032,19 @@ class _MLMHeadFn(torch.autograd.Function):
         # the transform LayerNorm's gamma / beta sums join the trunk's collector when the trunk's backward follows (it flushes), else
         # they are folded right here
         lnd = ctx.top._shared_lnd() if (ctx.trunk is not None and ctx.needs_input_grad[0]) else None
+        # the few-row weight gradients wait for the trunk's backward (which follows in this pass) unless a hook wants them final before it
+        late = (ctx.trunk is not None and ctx.needs_input_grad[0] and ctx.top.grad_hook is None and ctx.top.head_grad_hook is None
+                and getattr(ctx.top, "late_wgrads", True))
+        if ctx.top.__dict__.get("_late_wgrads"):                 # (left by a backward whose trunk stage never ran)
+            _flush_late_wgrads(ctx.top)
         if ctx.compact:
             y_c, pre_c, t0_c, mean_c, rstd_c, t_c, logits_c, labels_c, bounds_c, inv, lse, sel = ctx.saved_tensors
             dl = ops.ce_bwd(logits_c, V, labels_c, bounds_c, ctx.nseg, inv, gs, lse, logits_c)       # in place: the scores go nowhere
-            ops.gemm_tn(dl, t_c, w["g_word_pad"], bias_out=w["g_pred_bias"], accumulate=ctx.top._flat.take_accumulate([w["g_word_pad"]]))
+            _late_wgrad(ctx.top, (dl, t_c, w["g_word_pad"], w["g_pred_bias"]), late)
             dt = ops.gemm_nt_splitk(dl, w["wordT"])
             dt0 = ops.ln_bwd(dt, t0_c, mean_c, rstd_c, w["mlm_ln_g"], w["g_mlm_ln_g"], w["g_mlm_ln_b"], deferred=lnd)
             dpre = ops.gelu_bwd(dt0, pre_c)
-            ops.gemm_tn(dpre, y_c, w["g_Wt"], bias_out=w["g_bt"])
+            _late_wgrad(ctx.top, (dpre, y_c, w["g_Wt"], w["g_bt"]), late)
             dy_all = torch.empty((sel.numel() + extra_rows, y_c.shape[1]), device=y_c.device, dtype=torch.bfloat16)
             ops.gemm_nt(dpre, w["WtT"], out=dy_all[:sel.numel()])
             return sel, dy_all
@@ -1000,11 +1060,11 @@ class _MLMHeadFn(torch.autograd.Function):
                 dl = torch.empty((n, logits.shape[1]), device=y.device, dtype=torch.bfloat16)
                 ops.ce_bwd(logits, V, labels, seg_bounds, ctx.nseg, inv, gs, lse, dl, rows=idx)
                 t_c, t0_c, pre_c, y_c, mean_c, rstd_c = ops.gather_rows([t, t0, pre, y, mean, rstd], idx)      # one launch
-                ops.gemm_tn(dl, t_c, w["g_word_pad"], bias_out=w["g_pred_bias"], accumulate=ctx.top._flat.take_accumulate([w["g_word_pad"]]))
+                _late_wgrad(ctx.top, (dl, t_c, w["g_word_pad"], w["g_pred_bias"]), late)
                 dt = ops.gemm_nt_splitk(dl, w["wordT"])                     # K = vocabulary, a few hundred rows: split-K
                 dt0 = ops.ln_bwd(dt, t0_c, mean_c, rstd_c, w["mlm_ln_g"], w["g_mlm_ln_g"], w["g_mlm_ln_b"], deferred=lnd)
                 dpre = ops.gelu_bwd(dt0, pre_c)
-                ops.gemm_tn(dpre, y_c, w["g_Wt"], bias_out=w["g_bt"])
+                _late_wgrad(ctx.top, (dpre, y_c, w["g_Wt"], w["g_bt"]), late)
                 dy_all = torch.empty((n + extra_rows, y.shape[1]), device=y.device, dtype=torch.bfloat16)
                 ops.gemm_nt(dpre, w["WtT"], out=dy_all[:n])
                 return idx, dy_all
@@ -1757,6 +1817,10 @@ class MMBertForPretraining(_GpuModelBase):
         # which fused form: True = one launch per dependency level (csrc/heads_coop.hip, _HeadsStepFn: 7 + 6 launches, up to 128 samples, no
         # atomics), False = the 19-launch form (csrc/heads.hip, _HeadsFn: up to 32 samples); beyond the limit the eager form runs, with a warning
         self.coop_heads = True
+        # round 6: without a gradient hook, the weight gradients of the few rows that carry a loss (tied decoder, MLM transform, the sparse top
+        # layer's sublayers) wait for the deferred multi-layer call at the end of backward and run on the CUs its last round leaves idle
+        # (_late_wgrad); False = launched where they arise, on the serial tail of backward (the round-5 order)
+        self.late_wgrads = True
         _hf_init(self, config.initializer_range, skip=_bert)
         # weight tying (HF:728-731): decoder.weight IS the word embedding, decoder.bias IS predictions.bias
         self.cls.predictions.decoder.weight = self.bert.embeddings.word_embeddings.weight

@@ -177,26 +177,45 @@ def gemm_tn(A, B, W, *, accumulate=True, alpha=1.0, alpha_dev=None, bias_out=Non
     return W
 
 
-_PtrArr = {n: (ctypes.c_void_p * n) for n in range(1, 49)}
-_IntArr = {n: (ctypes.c_int * n) for n in range(1, 49)}
+TN_MAX_PROBLEMS = 52                      # (gemm.hip: TN_MAXP)
+_PtrArr = {n: (ctypes.c_void_p * n) for n in range(1, TN_MAX_PROBLEMS + 1)}
+_IntArr = {n: (ctypes.c_int * n) for n in range(1, TN_MAX_PROBLEMS + 1)}
 
 
 def gemm_tn_grouped(problems, *, accumulate=True, alpha=1.0):
-    """problems: up to 48 tuples (round 4: the deferred weight gradients of up to 12 layers; 8 before) (A[M,N] bf16, B[M,K] bf16, W[N,K] fp32, bias[N] fp32 or None) sharing M:
-    one launch computes every W (+)= A^T @ B and bias += colsum(A)  (see mmbert_gemm_tn_grouped)."""
+    """problems: up to 52 tuples (A[M,N] bf16, B[M,K] bf16, W[N,K] fp32, bias[N] fp32 or None) -- the deferred weight gradients of up to 12
+    layers (round 4), and behind them (round 6) problems of FEWER rows, whose tiles ride in the call's last launch: one call computes every
+    W (+)= A^T @ B and bias += colsum(A)  (see mmbert_gemm_tn_grouped_rows).  Problems are taken longest first (a stable sort by rows).
+    ``accumulate``: one flag, or one per problem."""
     lib = _lib.load()
     n = len(problems)
-    M = problems[0][0].shape[0]
+    each = None
+    if isinstance(accumulate, (list, tuple)):                 # one flag per problem
+        each = [1 if a else 0 for a in accumulate]
+        accumulate = all(each)
+        if accumulate or not any(each):
+            each = None
+    rows = [p[0].shape[0] for p in problems]
+    if any(rows[i] < rows[i + 1] for i in range(n - 1)):
+        order = sorted(range(n), key=lambda i: -rows[i])
+        problems = [problems[i] for i in order]
+        rows = [rows[i] for i in order]
+        if each is not None:
+            each = [each[i] for i in order]
+    M = rows[0]
     PA, IA = _PtrArr[n], _IntArr[n]
     Ns = IA(*[p[0].shape[1] for p in problems])
     Ks = IA(*[p[1].shape[1] for p in problems])
-    need = lib.mmbert_gemm_tn_grouped_workspace(n, Ns, Ks, M, None)
-    slab = _slab(need, problems[0][0].device)
-    _lib.check(lib.mmbert_gemm_tn_grouped(
+    mixed = rows[-1] != M
+    slab = None
+    if not mixed:
+        need = lib.mmbert_gemm_tn_grouped_workspace(n, Ns, Ks, M, None)
+        slab = _slab(need, problems[0][0].device)
+    _lib.check(lib.mmbert_gemm_tn_grouped_rows(
         _stream(), n, PA(*[p[0].data_ptr() for p in problems]), IA(*[p[0].stride(0) for p in problems]),
         PA(*[p[1].data_ptr() for p in problems]), IA(*[p[1].stride(0) for p in problems]),
         PA(*[p[2].data_ptr() for p in problems]), PA(*[(p[3].data_ptr() if p[3] is not None else None) for p in problems]),
-        Ns, Ks, M, 1 if accumulate else 0, float(alpha), None, _ptr(slab)), "mmbert_gemm_tn_grouped")
+        Ns, Ks, IA(*rows), 1 if accumulate else 0, IA(*each) if each is not None else None, float(alpha), None, _ptr(slab)), "mmbert_gemm_tn_grouped_rows")
 
 
 def colsum(X, out, *, alpha=1.0, alpha_dev=None):

@@ -443,6 +443,36 @@ def test_gemm_tn_grouped_many_layers_in_whole_rounds(ops):
             assert torch.equal(bias.cpu(), rb), i
 
 
+@pytest.mark.parametrize("layers", [1, 3])
+def test_gemm_tn_grouped_few_row_problems_ride_behind_the_long_tiles(ops, layers):
+    """Round 6 (mmbert_gemm_tn_grouped_rows): problems of FEWER token rows behind the long ones in one call -- the tied decoder's, the MLM
+    transform's and the sparse top layer's weight gradients in the deferred multi-layer call.  One "layer" (108 long tiles: a single launch,
+    the few-row tiles behind them) and three (324: a full round, then 68 long tiles + the few-row ones); small-integer operands, so every
+    fp32 sum is EXACT whatever the order; per-problem accumulate flags (an overwritten gradient starts from garbage); problems handed over
+    in mixed order (ops sorts by rows); ragged row counts."""
+    M = 1184
+    shapes = [(3072, 768, M), (768, 3072, M), (2304, 768, M), (768, 768, M)] * layers
+    shapes += [(30592, 768, 368), (768, 768, 368), (3072, 768, 391), (768, 3072, 391), (768, 768, 391), (520, 136, 7)]
+    probs, refs, flags = [], [], []
+    for i, (N, K, m) in enumerate(shapes):
+        A = ((torch.arange(m)[:, None] * (3 + i) + torch.arange(N)[None, :] * 5) % 3 - 1.0)          # {-1, 0, 1}
+        B = ((torch.arange(m)[:, None] * 2 + torch.arange(K)[None, :] * (7 + i)) % 2).float()        # {0, 1}
+        acc = (i % 3 != 1)
+        W0 = torch.full((N, K), float(i + 1))
+        b0 = torch.full((N,), -2.0) if i % 2 == 0 else None
+        Wd = W0.clone().to(DEV) if acc else torch.full((N, K), float("nan"), device=DEV)
+        probs.append((bf(A).to(DEV), bf(B).to(DEV), Wd, b0.clone().to(DEV) if b0 is not None else None))
+        flags.append(acc)
+        refs.append(((W0 if acc else 0) + A.t() @ B, (b0 + A.sum(0)) if b0 is not None else None))
+    order = list(range(len(probs)))
+    order = order[-3:] + order[:-3]                                # three few-row problems in front: the call takes them longest first
+    ops.gemm_tn_grouped([probs[i] for i in order], accumulate=[flags[i] for i in order])
+    for i, ((A, B, W, bias), (rw, rb)) in enumerate(zip(probs, refs)):
+        assert torch.equal(W.cpu(), rw), (i, shapes[i])
+        if bias is not None:
+            assert torch.equal(bias.cpu(), rb), (i, shapes[i])
+
+
 @pytest.mark.parametrize("M,splits", [(1700, 0), (1700, 3), (70, 0), (4129, 2), (33, 0)])
 def test_gemm_tn_ragged_tokens_forced_splits_and_accumulate(ops, M, splits):
     """The weight-gradient kernel (gemm_tn8_kernel: 64-token K tiles, half-tile stream, transposed fragment reads) on ragged token counts

@@ -699,7 +699,7 @@ def test_train_mode_step_at_the_timed_depth_matches_oracle_with_replayed_masks(s
     carries the timed step; at batch 2 every launch is single-round, at batch 6 the rule takes 192-row tiles) with the bf16-storage
     calibrator.  Every dropout site 8i + k for i < 12 is replayed in the oracle; asserted besides the numbers: the weight gradients of all
     dense layers went out in ONE call (model._auto_defer_wgrads: 11 layers x 4 problems behind the sparse top layer, 12 x 4 with the short cuts
-    off) and mmbert_gemm_nt dispatched a forward and a backward shape to the multi-tile 8-phase form on 224-row tiles."""
+    off; the few-row weight gradients behind them: 50 problems) and mmbert_gemm_nt dispatched a forward and a backward shape to the multi-tile 8-phase form on 224-row tiles."""
     cfg = dict(hidden=768, layers=12, heads=12, intermediate=3072, vocab=30522, dataset="mosei", alpha=1.0, beta=1.0)
     flags = {} if shortcuts else dict(skip_padded_backward=False, sparse_top_layer_backward=False)
     from msa_amd import model as MM
@@ -737,7 +737,9 @@ def test_train_mode_step_at_the_timed_depth_matches_oracle_with_replayed_masks(s
         _ops.gemm_tn_grouped = tn_orig
         _ops.gemm_nt = nt_orig
     assert (m.last_split is not None) == shortcuts and len(calls) == (1 if shortcuts else 0), (m.last_split, calls)
-    assert (44 if shortcuts else 48) in tn_calls and 8 not in tn_calls, tn_calls           # one call for all dense layers, no paired launches
+    # one call for all dense layers, no paired launches; round 6: the few-row weight gradients ride in it (the tied decoder's and the MLM
+    # transform's; with the sparse top layer its three few-row ones and its QKV gradient as a 45th long problem): 50 problems either way
+    assert tn_calls == [50], tn_calls
     multi = {}
     for (M, N, K, epi) in nt_shapes:
         d = _ops.gemm_nt_describe(M, N, K, epi)
@@ -818,7 +820,8 @@ def test_deferred_weight_gradients_equal_the_per_layer_launches():
         finally:
             _ops.gemm_tn_grouped = orig
         grads[defer], calls[defer] = {n: q.grad.float().clone() for n, q in m.named_parameters()}, seen
-    assert 16 in calls[True] and 8 in calls[False] and 16 not in calls[False], calls       # 4 dense layers behind the sparse top layer: one call of 16
+    # 4 dense layers behind the sparse top layer: one call of 16 + (round 6) the top layer's QKV gradient, its three few-row ones and the MLM head's two
+    assert calls[True] == [22] and 8 in calls[False] and 22 not in calls[False], calls
     for n in grads[True]:
         if "attention.self.key.bias" in n:
             continue
