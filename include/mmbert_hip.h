@@ -71,6 +71,8 @@ void mmbert_gemm_nt_force(int mode);
 int mmbert_gemm_nt_describe(int M, int N, int K, int epi, int with_queue, int* out);
 /* Split count of the token axis in mmbert_gemm_tn / _grouped: 0 = by shape (default), > 0 forced.  Tests and A/B benchmarking. */
 void mmbert_gemm_tn_force_splits(int splits);
+/* 1: a grouped call of more long tiles than CUs goes out as ONE launch instead of one launch per round of CUs-many tiles.  A/B benchmarking. */
+void mmbert_gemm_tn_force_one_launch(int on);
 
 /* Weight gradients autograd computes for nn.Linear (REF:trainer.py:83):
  *   W[N,K] (fp32, contiguous: ldw == K) = (accumulate ? W : 0) + alpha * alpha_dev[0] * A[M,N]^T . B[M,K]
@@ -322,6 +324,12 @@ int mmbert_heads_step_struct_size(void);          /* sizeof(mmbert_heads_step): 
 size_t mmbert_heads_step_workspace(int B, int H);
 int mmbert_heads_step_fwd(mmbert_stream_t stream, const mmbert_heads_step* p);
 int mmbert_heads_step_bwd(mmbert_stream_t stream, const mmbert_heads_step* p);
+/* levels lo .. hi only (forward 1 .. 7, backward 1 .. 6; the calls above = all of them): the heads of REF:MMBertForPretraining.py:293-443 run
+ * beside the MLM head's launches on a side stream; forward level 7 (the losses; the only one that reads `mlm`) behind both. */
+int mmbert_heads_step_fwd_levels(mmbert_stream_t stream, const mmbert_heads_step* p, int lo, int hi);
+int mmbert_heads_step_bwd_levels(mmbert_stream_t stream, const mmbert_heads_step* p, int lo, int hi);
+/* dmlm[i] = dloss * alpha / nmlm alone (backward level 6 writes the same): the MLM head's backward needs nothing else of the heads' to start */
+int mmbert_heads_step_dmlm(mmbert_stream_t stream, const mmbert_heads_step* p);
 
 /* ---- the heads' dense layers: lists of fp32 products with at most 64 rows, one launch per dependency level ----
  * mmbert_skinny_mm: for every op, Y[M, N] += bias + sum_j X_j . op(W_j) -- the sum is split over workgroups and added with fp32

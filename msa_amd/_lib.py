@@ -23,6 +23,7 @@ SIGNATURES = {
     "mmbert_gemm_nt_splitk": (I, [P, P, I, P, I, P, I, I, I, I, P, P, I]),
     "mmbert_gemm_nt_splitk_workspace": (SZ, [I, I, I]),
     "mmbert_gemm_tn_force_splits": (None, [I]),
+    "mmbert_gemm_tn_force_one_launch": (None, [I]),
     "mmbert_gemm_tn_workspace": (SZ, [I, I, I, P]),
     "mmbert_gemm_tn": (I, [P, P, I, P, I, P, I, I, I, I, I, F, P, P, P]),
     "mmbert_gemm_tn_grouped_workspace": (SZ, [I, P, P, I, P]),
@@ -69,6 +70,9 @@ SIGNATURES = {
     "mmbert_heads_step_workspace": (SZ, [I, I]),
     "mmbert_heads_step_fwd": (I, [P, P]),
     "mmbert_heads_step_bwd": (I, [P, P]),
+    "mmbert_heads_step_fwd_levels": (I, [P, P, I, I]),
+    "mmbert_heads_step_bwd_levels": (I, [P, P, I, I]),
+    "mmbert_heads_step_dmlm": (I, [P, P]),
     "mmbert_layer_fwd": (I, [P, P, P]),
     "mmbert_layer_bwd": (I, [P, P, P]),
     "mmbert_layer_struct_sizes": (I, [P]),

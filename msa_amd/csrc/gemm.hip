@@ -1310,6 +1310,8 @@ void mmbert_gemm_nt_force(int mode) {
 
 static std::atomic<int> g_tn_splits{0};   // 0 = by shape; > 0 forces the split count of the token axis (A/B benchmarking)
 void mmbert_gemm_tn_force_splits(int splits) { g_tn_splits.store(splits); }
+static std::atomic<int> g_tn_one_launch{0};   // 1: a call of more long tiles than CUs goes out as ONE launch instead of one per round (A/B benchmarking)
+void mmbert_gemm_tn_force_one_launch(int on) { g_tn_one_launch.store(on ? 1 : 0); }
 static int tn_plan(int nprob, const int* N, const int* K, int M, int* splits_out, int* tiles_out) {
     int tiles = 0;
     double elems = 0;
@@ -1417,9 +1419,10 @@ int mmbert_gemm_tn_grouped_rows(hipStream_t stream, int nprob, const void* const
     if (splits == 1 && (tiles_long > cus_ || tiles_short > 0)) {
         // whole rounds of CUs-many long tiles, one launch per round (only the deferred multi-layer launches have more tiles than CUs; never
         // split); the few-row tiles behind the last round's
-        for (int base = 0; base < tiles_long; base += cus_) {
-            const int n = tiles_long - base < cus_ ? tiles_long - base : cus_;
-            const bool last = base + cus_ >= tiles_long;
+        const int step_ = g_tn_one_launch.load() ? (tiles_long > 0 ? tiles_long : 1) : cus_;
+        for (int base = 0; base < tiles_long; base += step_) {
+            const int n = tiles_long - base < step_ ? tiles_long - base : step_;
+            const bool last = base + step_ >= tiles_long;
             g.tile_base = base; g.remap_n = n;
             hipLaunchKernelGGL(kern, dim3(n + (last ? tiles_short : 0), 1), dim3(512), 131072, stream, g);
             MMB_CHECK_LAUNCH();

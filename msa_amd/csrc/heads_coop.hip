@@ -586,6 +586,10 @@ static int hc_check(const mmbert_heads_step* p, int* cus) {
     *cus = mmb_device_cus();
     return 0;
 }
+__global__ void heads_dmlm_kernel(const float* __restrict__ dloss, float* __restrict__ dmlm, int nmlm, float alpha) {
+    const float d = *dloss;
+    for (int i = threadIdx.x; i < nmlm; i += blockDim.x) dmlm[i] = d * (alpha / (float)nmlm);      // (the expression of backward level 6)
+}
 // a level's grid: its 16 x 16 workgroup tiles PLUS enough 16-wave workgroups for its wave jobs (handed out from the last workgroup down, so that
 // a workgroup holds a tile or wave jobs, not both in a row), at most one round of the chip
 static inline int hc_grid(int wg_tiles, int wave_jobs, int cus, int floor_) {
@@ -595,35 +599,53 @@ static inline int hc_grid(int wg_tiles, int wave_jobs, int cus, int floor_) {
 }
 #define HC_LAUNCH(K, L, GRID, LDS) do { hipLaunchKernelGGL((K<L>), dim3(GRID), dim3(HC_THREADS), (LDS), stream, *p); MMB_CHECK_LAUNCH(); } while (0)
 
-int mmbert_heads_step_fwd(hipStream_t stream, const mmbert_heads_step* p) {
+// levels lo .. hi of the forward (1 .. 7) / backward (1 .. 6): the model runs the heads beside the MLM head's launches on a side stream and
+// only the loss level (which reads the MLM losses) behind both
+int mmbert_heads_step_fwd_levels(hipStream_t stream, const mmbert_heads_step* p, int lo, int hi) {
     int cus;
     if (hc_check(p, &cus)) return -1;
-    if (!p->loss || !p->aux || !p->out5 || !p->logits || !p->t_rel || !p->rel || !p->ap || !p->sent || (p->nmlm > 0 && !p->mlm)) return -1;
+    if (lo < 1 || hi > 7 || lo > hi) return -1;
+    if (!p->loss || !p->aux || !p->out5 || !p->logits || !p->t_rel || !p->rel || !p->ap || !p->sent || (hi == 7 && p->nmlm > 0 && !p->mlm)) return -1;
     const int B = p->B, H = p->H, R = 3 * B, tH = H >> 4, tB = (B + 15) >> 4, tR = (R + 15) >> 4, t2B = (2 * B + 15) >> 4;
     const int red = HC_WAVES * 256 * (int)sizeof(float);
-    HC_LAUNCH(heads_fwd_level_kernel, 1, hc_grid(tR * tH + t2B, p->first ? 0 : R, cus, 1), red);
-    HC_LAUNCH(heads_fwd_level_kernel, 2, hc_grid(tR * tH + tB, 0, cus, 1), red);
-    HC_LAUNCH(heads_fwd_level_kernel, 3, hc_grid(0, R, cus, 1), red);
-    HC_LAUNCH(heads_fwd_level_kernel, 4, hc_grid(tB * tH, 0, cus, 1), red);
-    HC_LAUNCH(heads_fwd_level_kernel, 5, hc_grid(tB * 3 * tH + tB, 0, cus, 1), red);
-    HC_LAUNCH(heads_fwd_level_kernel, 6, hc_grid(3 * tB * tB, R, cus, 1), red);
-    HC_LAUNCH(heads_fwd_level_kernel, 7, 4, red + (int)((HC_WAVES * (size_t)B + 2 * HC_WAVES) * sizeof(float)));
+    if (lo <= 1 && 1 <= hi) HC_LAUNCH(heads_fwd_level_kernel, 1, hc_grid(tR * tH + t2B, p->first ? 0 : R, cus, 1), red);
+    if (lo <= 2 && 2 <= hi) HC_LAUNCH(heads_fwd_level_kernel, 2, hc_grid(tR * tH + tB, 0, cus, 1), red);
+    if (lo <= 3 && 3 <= hi) HC_LAUNCH(heads_fwd_level_kernel, 3, hc_grid(0, R, cus, 1), red);
+    if (lo <= 4 && 4 <= hi) HC_LAUNCH(heads_fwd_level_kernel, 4, hc_grid(tB * tH, 0, cus, 1), red);
+    if (lo <= 5 && 5 <= hi) HC_LAUNCH(heads_fwd_level_kernel, 5, hc_grid(tB * 3 * tH + tB, 0, cus, 1), red);
+    if (lo <= 6 && 6 <= hi) HC_LAUNCH(heads_fwd_level_kernel, 6, hc_grid(3 * tB * tB, R, cus, 1), red);
+    if (lo <= 7 && 7 <= hi) HC_LAUNCH(heads_fwd_level_kernel, 7, 4, red + (int)((HC_WAVES * (size_t)B + 2 * HC_WAVES) * sizeof(float)));
     return 0;
 }
 
-int mmbert_heads_step_bwd(hipStream_t stream, const mmbert_heads_step* p) {
+int mmbert_heads_step_fwd(hipStream_t stream, const mmbert_heads_step* p) { return mmbert_heads_step_fwd_levels(stream, p, 1, 7); }
+
+int mmbert_heads_step_bwd_levels(hipStream_t stream, const mmbert_heads_step* p, int lo, int hi) {
     int cus;
     if (hc_check(p, &cus)) return -1;
+    if (lo < 1 || hi > 6 || lo > hi) return -1;
     if (!p->dloss || !p->dfirst || (p->nmlm > 0 && !p->dmlm)) return -1;
     const int B = p->B, H = p->H, R = 3 * B, tH = H >> 4, tB = (B + 15) >> 4, tR = (R + 15) >> 4;
     const int red = HC_WAVES * 256 * (int)sizeof(float);
     const int cols = (4 * H + 3 + HC_THREADS - 1) / HC_THREADS;         // workgroups that cover the widest column-sum job with one thread per column
-    HC_LAUNCH(heads_bwd_level_kernel, 1, hc_grid(0, 6 * tB * tH, cus, 1), red);
-    HC_LAUNCH(heads_bwd_level_kernel, 2, hc_grid(tB * tH, 3 * tH * tH, cus, cols), red);
-    HC_LAUNCH(heads_bwd_level_kernel, 3, hc_grid(tB * 3 * tH, tH * 3 * tH, cus, cols), red);
-    HC_LAUNCH(heads_bwd_level_kernel, 4, hc_grid(0, R, cus, 1), red);
-    HC_LAUNCH(heads_bwd_level_kernel, 5, hc_grid(tR * tH, tH * tH, cus, cols), red);
-    HC_LAUNCH(heads_bwd_level_kernel, 6, hc_grid(tR * tH, tH * tH, cus, cols), red);
+    if (lo <= 1 && 1 <= hi) HC_LAUNCH(heads_bwd_level_kernel, 1, hc_grid(0, 6 * tB * tH, cus, 1), red);
+    if (lo <= 2 && 2 <= hi) HC_LAUNCH(heads_bwd_level_kernel, 2, hc_grid(tB * tH, 3 * tH * tH, cus, cols), red);
+    if (lo <= 3 && 3 <= hi) HC_LAUNCH(heads_bwd_level_kernel, 3, hc_grid(tB * 3 * tH, tH * 3 * tH, cus, cols), red);
+    if (lo <= 4 && 4 <= hi) HC_LAUNCH(heads_bwd_level_kernel, 4, hc_grid(0, R, cus, 1), red);
+    if (lo <= 5 && 5 <= hi) HC_LAUNCH(heads_bwd_level_kernel, 5, hc_grid(tR * tH, tH * tH, cus, cols), red);
+    if (lo <= 6 && 6 <= hi) HC_LAUNCH(heads_bwd_level_kernel, 6, hc_grid(tR * tH, tH * tH, cus, cols), red);
+    return 0;
+}
+
+int mmbert_heads_step_bwd(hipStream_t stream, const mmbert_heads_step* p) { return mmbert_heads_step_bwd_levels(stream, p, 1, 6); }
+
+// the gradient of the per-pass MLM losses alone (what backward level 6 also writes): d(joint) / d(mlm[i]) = alpha / nmlm, times the upstream
+// gradient -- one tiny launch, so that the MLM head's backward can start on the current stream while the six levels run on another
+int mmbert_heads_step_dmlm(hipStream_t stream, const mmbert_heads_step* p) {
+    if (!p || p->nmlm <= 0) return 0;
+    if (!p->dloss || !p->dmlm) return -1;
+    hipLaunchKernelGGL(heads_dmlm_kernel, dim3(1), dim3(64), 0, stream, p->dloss, p->dmlm, p->nmlm, p->alpha);
+    MMB_CHECK_LAUNCH();
     return 0;
 }
 #undef HC_LAUNCH

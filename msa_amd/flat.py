@@ -240,12 +240,33 @@ class FlatParams:
 
     def refresh(self):
         """fp32 masters -> bf16 copy and transposed copies (after any out-of-band parameter change)."""
+        self.wait_transposes()                # (a side-stream transposed-copy launch may still read the bf16 copy rewritten here)
         ops.cast_f32_bf16(self.params, self.half)
         self.refresh_transposes()
         self._version = self._param_versions()
 
-    def refresh_transposes(self):
+    def refresh_transposes(self, side: bool = False):
+        """``side`` (the optimizer's call, round 6): on the storage's own side stream, behind the work queued on the current stream so far.
+        The transposed copies are read by BACKWARD only (the input gradients' W^T operands), the launch is a 0.4-GB copy at HBM rate
+        (92 us) and what follows an optimizer step on the current stream is the next step's prologue -- ten launches of 5-30 us that
+        leave the chip empty: the two run side by side.  Readers call wait_transposes() (model._MLMHeadFn / _EncoderFn backward; the
+        next optimizer step, which rewrites the bf16 copy this launch reads)."""
+        if side and ops.SIDE_TRANSPOSES and self.halfT.is_cuda:
+            self.wait_transposes()
+            s = ops.side_stream("transposes", self.halfT.device)
+            s.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(s):
+                ops.transpose_cast(self.half, self.halfT, self._descs, self._ndesc, self._ntiles)
+                self.__dict__["_t_event"] = s.record_event()
+            return
+        self.wait_transposes()
         ops.transpose_cast(self.half, self.halfT, self._descs, self._ndesc, self._ntiles)      # from the bf16 copy: half the bytes, same values
+
+    def wait_transposes(self):
+        """The current stream waits for a transposed-copy launch still running on the side stream (no-op otherwise)."""
+        ev = self.__dict__.pop("_t_event", None)
+        if ev is not None:
+            torch.cuda.current_stream().wait_event(ev)
 
     def mark_synced(self):
         """The bf16 copies were just refreshed by the optimizer kernel itself."""

@@ -319,10 +319,42 @@ def _flush_late_wgrads(top, long_probs=(), deferred=False):
     if late and len(chunks[-1]) + len(late) <= ops.TN_MAX_PROBLEMS:
         chunks[-1] = chunks[-1] + late
         late = []
+    side = getattr(top, "wgrad_side_stream", True) and long_probs[0][0].is_cuda
+    if side:
+        # on the model's side stream, behind everything queued so far: nothing reads these gradients before the optimizer, and what the
+        # caller (_TrunkFn.backward) queues next -- the embedding stage: LayerNorm', the pair projections' weight gradients, the reduce
+        # launches; 110 us of launches that leave most of the chip empty -- runs beside the call's 1.8 ms instead of behind them.  The caller
+        # joins (_join_wgrads) before anything else writes the tied table's gradient; the operands stay referenced until then (their
+        # blocks belong to the current stream's pool)
+        _join_wgrads(top)
+        s = ops.side_stream("wgrads", long_probs[0][0].device)
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            for c in chunks:
+                _wgrad(top, c)
+            for q in late:
+                _wgrad(top, [q])
+            top.__dict__["_wgrad_join"] = (s.record_event(), chunks, late)
+        return
     for c in chunks:
         _wgrad(top, c)
     for q in late:
         _wgrad(top, [q])
+
+
+def _join_heads(top):
+    """The current stream waits for the heads' backward levels queued on the side stream (_HeadsStepFn.backward; no-op otherwise)."""
+    j = top.__dict__.pop("_heads_join", None)
+    if j is not None:
+        torch.cuda.current_stream().wait_event(j[0])
+
+
+def _join_wgrads(top):
+    """The current stream waits for the deferred weight-gradient call queued on the side stream (no-op otherwise); its operands are
+    released behind the wait."""
+    j = top.__dict__.pop("_wgrad_join", None)
+    if j is not None:
+        torch.cuda.current_stream().wait_event(j[0])
 
 
 class _EncoderFn:
@@ -413,6 +445,9 @@ class _EncoderFn:
         L = top.config.num_hidden_layers
         top._flat.grads_dirty = True
         top._flat.attach_lazy()
+        top._flat.wait_transposes()                               # (the optimizer's transposed-copy launch runs on a side stream)
+        _join_wgrads(top)                                         # (left by a backward that raised)
+        _join_heads(top)
         # split (valid-first) layout: the rows behind rows_a have exactly-zero gradients in every layer (see _encode), so the
         # whole backward -- dgrads, weight gradients, LayerNorm', attention -- runs on the leading rows_a rows only
         M_all = saved[0][0].shape[0]
@@ -827,6 +862,7 @@ class _TrunkFn(torch.autograd.Function):
             else:
                 ops.ln_bwd(dx[bounds[k0]:bounds[k1]], e0[rows], mean0[rows], rstd0[rows], w["emb_ln_g"], w["g_emb_ln_g"], w["g_emb_ln_b"], **kw)
         lnd.flush()
+        _join_wgrads(top)                                         # (the deferred call writes the tied table's gradient whole; the rows below add to it)
         if top.defer_embed_rows:
             ops.embed_scatter(t.ids, t.tts, de0, T, None, w["g_type"], w["g_pos"], vocab=cfg.vocab_size)
             # a LIST: every differentiated trunk backward between two finish_backward() calls hands over its rows (a second
@@ -988,6 +1024,7 @@ class _MLMHeadFn(torch.autograd.Function):
         # without a cat (the rows' gradients are written in place by the last product, the [CLS] rows by one converting copy)
         nf = t.top_rows[1].numel() if (t is not None and t.top_rows is not None and dfirst is not None) else 0
         res = _MLMHeadFn._backward(ctx, dloss, extra_rows=nf)
+        _join_heads(ctx.top)                                  # (the heads' backward may still run on its side stream: dfirst is read from here on)
         nones = (None,) * 9
         if isinstance(res, tuple):                            # (labelled rows int32 or int64, their gradients [n (+ nf), H] bf16): the sparse paths
             sel, dy_all = res
@@ -1028,6 +1065,7 @@ class _MLMHeadFn(torch.autograd.Function):
             return None
         ctx.top._flat.grads_dirty = True
         ctx.top._flat.attach_lazy()
+        ctx.top._flat.wait_transposes()                           # (the optimizer's transposed-copy launch runs on a side stream)
         gs = dloss.contiguous().float()
         # the transform LayerNorm's gamma / beta sums join the trunk's collector when the trunk's backward follows (it flushes), else
         # they are folded right here
@@ -1601,25 +1639,18 @@ class _HeadsStepFn(torch.autograd.Function):
     ``first``: fp32 [3B, H]; or, with ``src = (y bf16 [tokens, H], rows int64 [3B])``, a placeholder whose rows the kernel reads from y."""
 
     @staticmethod
-    def forward(ctx, first, top, ap, sent, mlm=None, src=None):
-        B, H = first.shape[0] // 3, first.shape[1]
-        dev = first.device
+    def _setup(top, B, H, dev, ap, sent, first=None, src=None):
+        """The argument record of a forward pass (everything but the MLM losses) and its output tensors: (a, outs, keep)."""
         a = ops.heads_step_struct()
         a.B, a.H, a.tanh_lo = B, H, 1 if top.num_labels == 1 else 0
         a.alpha, a.beta = float(top.alpha), float(top.beta)
-        keep = []
         if src is not None:
             y, rows = src
             assert y.dtype == torch.bfloat16 and y.stride(1) == 1 and rows.dtype == torch.int64 and rows.is_contiguous() and rows.numel() == 3 * B
             a.first, a.y, a.first_rows, a.ldy = None, y.data_ptr(), rows.data_ptr(), y.stride(0)
         else:
-            first = first.contiguous()
-            assert first.dtype == torch.float32
+            assert first.dtype == torch.float32 and first.is_contiguous()
             a.first = first.data_ptr()
-        if mlm is not None:
-            mlm = mlm.detach().float().contiguous()
-            a.mlm, a.nmlm = mlm.data_ptr(), mlm.numel()
-            keep.append(mlm)
         pool, al, sr, at = top.bert.pooler.dense, top.cls.align, top.cls.seq_relationship, top.attn
         vs3 = (top.vt, top.vv, top.vs)
         c1, c2 = top.classifier1_1, top.classifier1_2
@@ -1646,8 +1677,47 @@ class _HeadsStepFn(torch.autograd.Function):
         a.sent = sent.data_ptr()
         a.loss, a.aux, a.out5, a.logits, a.t_rel, a.rel, a.ws = (t.data_ptr() for t in (loss, aux, out5, logits, t_rel, rel, ws))
         a.sync = ops.heads_step_sync(dev).data_ptr()
-        ops.heads_step_fwd(a)
-        ctx.top, ctx.a, ctx.B, ctx.H, ctx.keep = top, a, B, H, (keep, ap, sent, ws, out5)
+        return a, (loss, aux, logits, t_rel, rel), (ap, sent, ws, out5)
+
+    @staticmethod
+    def prelaunch(top, y, rows, ap, sent):
+        """Round 6: forward levels 1 - 6 (everything but the losses) on the heads' side stream, queued BEFORE the MLM head's forward: they
+        need the encoder output's [CLS] rows and nothing of the MLM head, whose launches (transform, the vocabulary GEMM, cross-entropy)
+        then run beside them instead of in front of them.  ``forward`` picks the record up, joins, and runs level 7."""
+        B, H, dev = rows.numel() // 3, y.shape[1], y.device
+        a, outs, keep = _HeadsStepFn._setup(top, B, H, dev, ap, sent, src=(y, rows))
+        s = ops.side_stream("heads", dev)
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            ops.heads_step_fwd(a, 1, 6)
+            ev = s.record_event()
+        top.__dict__["_heads_pre"] = (y.data_ptr(), rows.data_ptr(), a, outs, keep, ev)
+
+    @staticmethod
+    def forward(ctx, first, top, ap, sent, mlm=None, src=None):
+        B, H = first.shape[0] // 3, first.shape[1]
+        dev = first.device
+        pre = top.__dict__.pop("_heads_pre", None)
+        if pre is not None and not (src is not None and pre[0] == src[0].data_ptr() and pre[1] == src[1].data_ptr() and pre[2].B == B):
+            pre = None                                          # (a record some other forward pass left behind)
+        if pre is not None:
+            _, _, a, outs, keep3, ev = pre
+            torch.cuda.current_stream().wait_event(ev)
+            lo = 7
+        else:
+            if src is None:
+                first = first.contiguous()
+            a, outs, keep3 = _HeadsStepFn._setup(top, B, H, dev, ap, sent, first=first, src=src)
+            lo = 1
+        keep = []
+        if mlm is not None:
+            mlm = mlm.detach().float().contiguous()
+            a.mlm, a.nmlm = mlm.data_ptr(), mlm.numel()
+            keep.append(mlm)
+        ops.heads_step_fwd(a, lo, 7)
+        loss, aux, logits, t_rel, rel = outs
+        ctx.top, ctx.a, ctx.B, ctx.H, ctx.keep = top, a, B, H, (keep,) + tuple(keep3)
+        ctx.side = src is not None          # (the gradient of the [CLS] rows then goes to _MLMHeadFn.backward and nowhere else: it joins the side stream)
         ctx.save_for_backward(*([] if src is not None else [first]))
         ctx.mark_non_differentiable(aux, logits, t_rel, rel)
         ctx.set_materialize_grads(False)
@@ -1674,6 +1744,20 @@ class _HeadsStepFn(torch.autograd.Function):
                                                       qs[m].bias.grad.data_ptr())
         assert at.weight.grad.is_contiguous()
         a.sync = ops.heads_step_sync(dev).data_ptr()
+        if ctx.side and dmlm is not None and getattr(top, "heads_side_stream", True) and top.grad_hook is None and top.head_grad_hook is None:
+            # round 6: the six levels on a side stream, beside the MLM head's sparse backward (which needs nothing of the heads' but the
+            # gradient of its per-pass losses: one tiny launch here) -- two chains of small dependent launches that leave the chip empty,
+            # 82 and 97 us, side by side.  _MLMHeadFn.backward joins before it reads dfirst (_join_heads)
+            ops.heads_step_dmlm(a)
+            scratch = torch.empty_like(dmlm)
+            a.dmlm = scratch.data_ptr()                            # (level 6 writes the same values: into its own words)
+            s = ops.side_stream("heads", dev)
+            s.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(s):
+                ops.heads_step_bwd(a)
+                top.__dict__["_heads_join"] = (s.record_event(), scratch, d1, ctx.keep)
+            a.dmlm = dmlm.data_ptr()
+            return dfirst, None, None, None, dmlm, None
         ops.heads_step_bwd(a)
         return dfirst, None, None, None, dmlm, None
 
@@ -1821,6 +1905,10 @@ class MMBertForPretraining(_GpuModelBase):
         # layer's sublayers) wait for the deferred multi-layer call at the end of backward and run on the CUs its last round leaves idle
         # (_late_wgrad); False = launched where they arise, on the serial tail of backward (the round-5 order)
         self.late_wgrads = True
+        # ... and that call goes out on a side stream, beside the embedding stage's backward (_flush_late_wgrads); False = on the current stream
+        self.wgrad_side_stream = True
+        # the level-launch heads' backward on a side stream beside the MLM head's sparse backward (_HeadsStepFn.backward); False = in line
+        self.heads_side_stream = True
         _hf_init(self, config.initializer_range, skip=_bert)
         # weight tying (HF:728-731): decoder.weight IS the word embedding, decoder.bias IS predictions.bias
         self.cls.predictions.decoder.weight = self.bert.embeddings.word_embeddings.weight
@@ -2049,6 +2137,10 @@ class MMBertForPretraining(_GpuModelBase):
         y, plan, lens, rows = self._encode(passes, labels, want_rows, packed=pk)
         trunk, self._last_trunk = self._last_trunk, None
         self._heads_read_rows = self._coop_heads_apply(sentiment, B)
+        if self._heads_read_rows and getattr(self, "heads_side_stream", True) and y.is_cuda and y.is_contiguous():
+            # the heads' forward levels below the losses go out NOW, on the side stream, beside the MLM head's launches (_HeadsStepFn.prelaunch)
+            _HeadsStepFn.prelaunch(self, y, plan["first"], (ap_v.to(dev).view(-1).long(), ap_s.to(dev).view(-1).long()),
+                                   sentiment.to(dev).view(-1).float())
         # first = [3B, H]: the [CLS] rows of every sequence; joint_loss = alpha * (mlm_t + mlm_v + mlm_s) / 3 + heads_loss  (:427, :443)
         mlm, logits, first = _MLMHeadFn.apply(y, self.cls.predictions.transform.LayerNorm.weight, self, labels, plan["bounds"], plan["bounds_dev"],
                                               self.return_scores, rows, plan["first"], trunk)

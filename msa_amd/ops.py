@@ -17,6 +17,27 @@ from . import _lib
 
 EPI_BIAS, EPI_GELU, EPI_RESID, EPI_GELU_BWD, EPI_OUT_F32 = 1, 2, 4, 8, 16
 
+# round 6: the optimizer's transposed-copy launch on a side stream (flat.FlatParams.refresh_transposes); False = on the current stream (A/B)
+SIDE_TRANSPOSES = True
+# priority of the side streams: "low" = the lowest the device offers (the current stream's small launches get their CUs first), "default"
+SIDE_STREAM_PRIORITY = "low"
+_side_streams = {}
+
+
+def side_stream(tag: str, device) -> "torch.cuda.Stream":
+    """One cached side stream per (purpose, device, priority setting)."""
+    key = (tag, str(device), SIDE_STREAM_PRIORITY)
+    s = _side_streams.get(key)
+    if s is None:
+        prio = 0
+        if SIDE_STREAM_PRIORITY == "low":
+            try:
+                prio = max(torch.cuda.Stream.priority_range())
+            except Exception:
+                prio = 0
+        s = _side_streams[key] = torch.cuda.Stream(device=device, priority=prio)
+    return s
+
 Drop = Optional[Tuple[int, int, float]]      # (rng stream, thr16, scale)
 NO_DROP = (0, 0, 1.0)
 
@@ -1128,12 +1149,16 @@ def heads_step_workspace(B: int, H: int, device) -> torch.Tensor:
     return torch.empty(_lib.load().mmbert_heads_step_workspace(int(B), int(H)) // 4, device=device, dtype=torch.float32)
 
 
-def heads_step_fwd(a: "_HeadsStep"):
-    _lib.check(_lib.load().mmbert_heads_step_fwd(_stream(), ctypes.addressof(a)), "mmbert_heads_step_fwd")
+def heads_step_fwd(a: "_HeadsStep", lo: int = 1, hi: int = 7):
+    _lib.check(_lib.load().mmbert_heads_step_fwd_levels(_stream(), ctypes.addressof(a), lo, hi), "mmbert_heads_step_fwd_levels")
 
 
-def heads_step_bwd(a: "_HeadsStep"):
-    _lib.check(_lib.load().mmbert_heads_step_bwd(_stream(), ctypes.addressof(a)), "mmbert_heads_step_bwd")
+def heads_step_dmlm(a: "_HeadsStep"):
+    _lib.check(_lib.load().mmbert_heads_step_dmlm(_stream(), ctypes.addressof(a)), "mmbert_heads_step_dmlm")
+
+
+def heads_step_bwd(a: "_HeadsStep", lo: int = 1, hi: int = 6):
+    _lib.check(_lib.load().mmbert_heads_step_bwd_levels(_stream(), ctypes.addressof(a), lo, hi), "mmbert_heads_step_bwd_levels")
 
 
 # ------------------------------------------------------------------------------------ the heads' dense layers (skinny fp32 products)

@@ -109,12 +109,13 @@ class AdamW:
             self._bind()
         flat = self._flat
         self._steps += 1
+        flat.wait_transposes()               # (a step without a backward in between: the last step's transposed copies still read the bf16 copy)
         flat.settle()                        # a lazy gradient no backward has written since the last step counts as zero
         flat.attach_lazy()
         ops.adamw(flat.params, flat.grads, self._m, self._v, flat.half, self._flags, lr=self.lr, beta1=self.betas[0],
                   beta2=self.betas[1], eps=self.eps, wd=self.wd, step=self._steps, gscale=self.grad_scale, mode=self.mode,
                   zero_grad=True)
-        flat.refresh_transposes()
+        flat.refresh_transposes(side=True)
         flat.mark_synced()
         flat.grads_dirty = False
         if self.lazy_zero:

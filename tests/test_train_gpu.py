@@ -713,6 +713,51 @@ def test_async_prologue_gives_the_same_training_run():
     assert pa <= 3.0 * pn + 5e-4, (pa, pn)
 
 
+def test_side_streams_and_late_weight_gradients_give_bit_identical_training_runs():
+    """Round 6: (a) the weight gradients of the few loss-carrying rows ride in the deferred multi-layer call (model.late_wgrads), (b) that
+    call goes out on a side stream beside the embedding stage's backward (model.wgrad_side_stream), (c) the optimizer's transposed-copy
+    launch runs on a side stream beside the next step's prologue (ops.SIDE_TRANSPOSES).  None of them changes what is computed: in
+    deterministic mode (ordered sums everywhere) six seeded train steps -- dropout on, AdamW, four ragged batches, no host synchronisation
+    in between, and a forced deferred call (five layers) -- give the SAME BITS with every one of them switched off: losses and every
+    parameter.  A missing wait (a backward reading transposed weights of the step before, a gradient added before the call overwrote
+    it) shows up here as a difference."""
+    from msa_amd import trainer as T
+    from msa_amd import ops as _ops
+    cfg = dict(hidden=256, layers=5, heads=4, intermediate=1024, vocab=4096, dataset="mosei", alpha=1.0, beta=1.0)
+    pool = [batch_to(synthetic_batch(6, 30, 200, 170, dataset="mosei", vocab=cfg["vocab"], seed=700 + i), DEV) for i in range(4)]
+    runs = {}
+    was, was_side = _ops.deterministic(), _ops.SIDE_TRANSPOSES
+    try:
+        _ops.set_deterministic(True)
+        for tag, late, side_w, side_t in (("all", True, True, True), ("no_side_wgrads", True, False, True), ("no_side_transposes", True, True, False),
+                                          ("none", False, False, False)):
+            _ops.SIDE_TRANSPOSES = side_t
+            m = build(cfg, dropout=0.1)
+            m.train()
+            m.manual_seed(13)
+            m.defer_wgrads, m.late_wgrads, m.wgrad_side_stream = True, late, side_w
+            opt, sched = T.build_optimizer(m, T.default_args(train_batch_size=6, learning_rate=3e-4), 10, mode="hf")
+            losses = []
+            for i in range(6):
+                out, _ = m(**pool[i % 4])
+                out[0].mean().backward()
+                opt.step(); sched.step(); opt.zero_grad()
+                losses.append(out[0].detach())
+            torch.cuda.synchronize()
+            runs[tag] = (torch.stack(losses).cpu(), {n: q.detach().clone().cpu() for n, q in m.named_parameters()})
+    finally:
+        _ops.set_deterministic(was)
+        _ops.SIDE_TRANSPOSES = was_side
+    ref_l, ref_p = runs["all"]
+    assert bool(torch.isfinite(ref_l).all())
+    for tag in ("no_side_wgrads", "no_side_transposes"):
+        assert torch.equal(runs[tag][0], ref_l), (tag, runs[tag][0], ref_l)
+        for n in ref_p:
+            assert torch.equal(runs[tag][1][n], ref_p[n]), (tag, n)
+    # with the few-row gradients launched where they arise, the top layer's QKV gradient splits its token axis (another fp32 order): close, not equal
+    assert float((runs["none"][0] - ref_l).abs().max()) <= 1e-3, (runs["none"][0], ref_l)
+
+
 def test_data_parallel_over_rccl_world1_equals_plain_step():
     """The DP code path on hardware with ONE GPU: torch.distributed "nccl" (= RCCL) initialised with world_size 1, the model
     wrapped in parallel.DataParallel (weight broadcast, bucketed all-reduce hooks fired from backward as layers finish, the

@@ -5,7 +5,7 @@ ratios measured in one process count).
     python tools/ab_step.py base: paired:attr.defer_wgrads=False nt256:nt_mode=256      # each variant = name:KEY=VAL[,KEY=VAL...]
 
 Keys: attr.NAME=<python literal> (a model attribute), ops.NAME=<literal> (a msa_amd.ops module attribute), nt_mode=<mmbert_gemm_nt_force
-mode>, tn_splits=<mmbert_gemm_tn_force_splits>.  The library reads no environment variable (round 5); two BUILDS of it are compared with
+mode>, tn_splits=<mmbert_gemm_tn_force_splits>, tn_one=<mmbert_gemm_tn_force_one_launch>.  The library reads no environment variable (round 5); two BUILDS of it are compared with
 alternating processes (tools/ab_lib.sh, MMBERT_LIB_PATH)."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -66,9 +66,10 @@ def setenv(env):
         setattr(model, k, v)
     for k, v in ops_defaults.items():
         setattr(_ops, k, v)
-    os.environ.update({k: v for k, v in env.items() if not k.startswith(("attr.", "ops.")) and k not in ("tn_splits", "nt_mode")})
+    os.environ.update({k: v for k, v in env.items() if not k.startswith(("attr.", "ops.")) and k not in ("tn_splits", "nt_mode", "tn_one")})
     from msa_amd import _lib as _l
     _l.load().mmbert_gemm_tn_force_splits(int(env.get("tn_splits", 0)))
+    _l.load().mmbert_gemm_tn_force_one_launch(int(env.get("tn_one", 0)))
     _l.load().mmbert_gemm_nt_force(int(env.get("nt_mode", 0)))
     for k, v in env.items():
         if k.startswith("attr."):                      # model attribute toggles: attr.NAME=python-literal

@@ -22,6 +22,7 @@ python3 tools/pmc_mfma.py gpurun_out/pmcm_${R}_ > gpurun_out/${R}_pmc_mfma_util.
 python3 tools/pmc_sq.py gpurun_out/pmcs_$R/pmc_counter_collection.csv > gpurun_out/${R}_pmc_sq_gemm.csv
 python3 tools/trace_gaps.py gpurun_out/prof_$R/${R}_kernel_trace.csv > gpurun_out/${R}_step_timeline.txt
 python3 tools/tail_sequence.py gpurun_out/prof_$R/${R}_kernel_trace.csv > gpurun_out/${R}_tail_sequence.txt
+python3 tools/tail_sequence.py gpurun_out/prof_$R/${R}_kernel_trace.csv --step > gpurun_out/${R}_step_sequence.txt
 cp gpurun_out/prof_$R/${R}_kernel_stats.csv gpurun_out/${R}_kernel_stats.csv
 bash tools/pmc_attn.sh > gpurun_out/pmc_attn_$R.log 2>&1
 python3 tools/pmc_attn.py gpurun_out/pmc_attn_g > gpurun_out/${R}_pmc_attention.csv
