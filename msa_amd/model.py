@@ -697,7 +697,7 @@ def _trunk_static(plan, B, T, lens, joff, dev):
 class _Trunk:
     """What one _TrunkFn call works on (plain attributes; built by _encode)."""
     __slots__ = ("ids", "tts", "B", "T", "lens", "pair_info", "feats", "feat_versions", "plan", "layout", "split", "key_bias", "kv_len", "seed", "top_rows",
-                 "d_emb", "d_joint", "infer", "late_split", "compact")
+                 "d_emb", "d_joint", "infer", "late_split", "compact", "J_pre")
 
 
 class _TrunkFn(torch.autograd.Function):
@@ -732,8 +732,15 @@ class _TrunkFn(torch.autograd.Function):
         dropped = split is not None and getattr(split, "dropped", False)
         Mx = split.rows_packed if early else tokens
         pad = 1 if (early and dropped) else 0                   # left-out rows (inv = rows_a) land in one scratch row behind X
-        buf = torch.empty((Mx + pad + jtot, H), device=dev, dtype=torch.bfloat16)
-        X, J = buf[:Mx], buf[Mx + pad:]
+        pre = t.J_pre                                             # (J, events): the pair rows of J are being written on side streams (_encode)
+        t.J_pre = None
+        if pre is not None and pre[0].shape[0] == jtot:
+            buf = torch.empty((Mx + pad, H), device=dev, dtype=torch.bfloat16)
+            X, J = buf[:Mx], pre[0]
+        else:
+            pre = None
+            buf = torch.empty((Mx + pad + jtot, H), device=dev, dtype=torch.bfloat16)
+            X, J = buf[:Mx], buf[Mx + pad:]
         st = _trunk_static(plan, B, T, lens, joff, dev)
         # ---- embeddings: e0 = word + type + pos for the text rows of all passes, LayerNorm + dropout stored where the rows are needed
         e0 = ops.embed_gather(t.ids, t.tts, w["word"], w["type"], w["pos"], T)
@@ -750,13 +757,16 @@ class _TrunkFn(torch.autograd.Function):
             ops.ln_fwd(e0[rows], w["emb_ln_g"], w["emb_ln_b"], cfg.layer_norm_eps, out=out, out_rows=orows, drop=t.d_emb, drop_row0=k0 * B * T,
                        stats=(mean0[rows], rstd0[rows]))
         jstats = {}
-        for k in joint:
+        for n, k in enumerate(joint):
             S = lens[k]
             Jk = J[joff[k]:joff[k] + B * S]
             off = T
-            for feat, which in zip(t.feats[k], t.pair_info[k][1]):
-                ops.pair_proj_fwd(feat, w[which + "_w"], w[which + "_b"], Jk, T, seq_len=S, offset=off)
-                off += feat.shape[1]
+            if pre is not None:
+                torch.cuda.current_stream().wait_event(pre[1][n])
+            else:
+                for feat, which in zip(t.feats[k], t.pair_info[k][1]):
+                    ops.pair_proj_fwd(feat, w[which + "_w"], w[which + "_b"], Jk, T, seq_len=S, offset=off)
+                    off += feat.shape[1]
             if early:
                 out, orows = X, split.inv32[bounds[k]:bounds[k + 1]]
             else:
@@ -862,7 +872,9 @@ class _TrunkFn(torch.autograd.Function):
             else:
                 ops.ln_bwd(dx[bounds[k0]:bounds[k1]], e0[rows], mean0[rows], rstd0[rows], w["emb_ln_g"], w["g_emb_ln_g"], w["g_emb_ln_b"], **kw)
         lnd.flush()
-        _join_wgrads(top)                                         # (the deferred call writes the tied table's gradient whole; the rows below add to it)
+        # the deferred call writes the tied table's gradient whole; the rows below add to it.  (Measured: that gradient on a side stream of
+        # its own at the start of backward, so that embed_scatter could run beside the deferred call: +0.1 %, profiles/r6_ab_side_streams.log)
+        _join_wgrads(top)
         if top.defer_embed_rows:
             ops.embed_scatter(t.ids, t.tts, de0, T, None, w["g_type"], w["g_pos"], vocab=cfg.vocab_size)
             # a LIST: every differentiated trunk backward between two finish_backward() calls hands over its rows (a second
@@ -1422,6 +1434,29 @@ class _GpuModelBase(nn.Module):
         t.ids, t.tts, t.B, t.T, t.lens, t.pair_info, t.plan = ids, tts, B, T, lens, pair_info, plan
         t.feats = [None if info is None else tuple(_pair_features(f, dev) for f in info[0]) for info in pair_info]
         t.feat_versions = [None if fs is None else tuple(f._version for f in fs) for fs in t.feats]
+        # round 6: the pair projections of the joint passes (relu(W.pair + b) into the pair rows of the joint pre-LayerNorm matrix: 17 + 28 us
+        # at the headline shape) need nothing of this step but the features: queued NOW, one side stream per joint pass, beside the packing
+        # and embedding launches that follow on the current stream (36 us of small dependent launches); _TrunkFn.forward joins in front
+        # of the joint LayerNorm
+        t.J_pre = None
+        if getattr(self, "pairs_side_stream", True) and dev.type == "cuda" and any(info is not None for info in pair_info):
+            w_ = self._w
+            jtot = sum(B * lens[k] for k in range(len(lens)) if pair_info[k] is not None)
+            J = torch.empty((jtot, cfg.hidden_size), device=dev, dtype=torch.bfloat16)
+            evs, lo = [], 0
+            main = torch.cuda.current_stream()
+            for n, k in enumerate(k for k in range(len(lens)) if pair_info[k] is not None):
+                S = lens[k]
+                s_ = ops.side_stream("pairs%d" % n, dev)
+                s_.wait_stream(main)
+                with torch.cuda.stream(s_):
+                    off = T
+                    for feat, which in zip(t.feats[k], pair_info[k][1]):
+                        ops.pair_proj_fwd(feat, w_[which + "_w"], w_[which + "_b"], J[lo:lo + B * S], T, seq_len=S, offset=off)
+                        off += feat.shape[1]
+                    evs.append(s_.record_event())
+                lo += B * S
+            t.J_pre = (J, evs)
         t.key_bias, t.kv_len, t.seed, t.infer = key_bias, kv_len, seed, infer
         t.d_emb = ops.make_drop(p_emb, seed, 1000)
         t.d_joint = [ops.make_drop(p_joint, seed, 1001 + k) for k in range(len(lens))]
@@ -1909,6 +1944,8 @@ class MMBertForPretraining(_GpuModelBase):
         self.wgrad_side_stream = True
         # the level-launch heads' backward on a side stream beside the MLM head's sparse backward (_HeadsStepFn.backward); False = in line
         self.heads_side_stream = True
+        # the joint passes' pair projections on side streams beside the packing and embedding launches (_encode); False = in line
+        self.pairs_side_stream = True
         _hf_init(self, config.initializer_range, skip=_bert)
         # weight tying (HF:728-731): decoder.weight IS the word embedding, decoder.bias IS predictions.bias
         self.cls.predictions.decoder.weight = self.bert.embeddings.word_embeddings.weight

@@ -716,7 +716,9 @@ def test_async_prologue_gives_the_same_training_run():
 def test_side_streams_and_late_weight_gradients_give_bit_identical_training_runs():
     """Round 6: (a) the weight gradients of the few loss-carrying rows ride in the deferred multi-layer call (model.late_wgrads), (b) that
     call goes out on a side stream beside the embedding stage's backward (model.wgrad_side_stream), (c) the optimizer's transposed-copy
-    launch runs on a side stream beside the next step's prologue (ops.SIDE_TRANSPOSES).  None of them changes what is computed: in
+    launch runs on a side stream beside the next step's prologue (ops.SIDE_TRANSPOSES), (d) the heads' forward levels and backward run on
+    a side stream beside the MLM head (model.heads_side_stream), (e) the pair projections on side streams beside the packing and embedding
+    launches (model.pairs_side_stream).  None of them changes what is computed: in
     deterministic mode (ordered sums everywhere) six seeded train steps -- dropout on, AdamW, four ragged batches, no host synchronisation
     in between, and a forced deferred call (five layers) -- give the SAME BITS with every one of them switched off: losses and every
     parameter.  A missing wait (a backward reading transposed weights of the step before, a gradient added before the call overwrote
@@ -729,13 +731,14 @@ def test_side_streams_and_late_weight_gradients_give_bit_identical_training_runs
     was, was_side = _ops.deterministic(), _ops.SIDE_TRANSPOSES
     try:
         _ops.set_deterministic(True)
-        for tag, late, side_w, side_t in (("all", True, True, True), ("no_side_wgrads", True, False, True), ("no_side_transposes", True, True, False),
-                                          ("none", False, False, False)):
+        for tag, late, side_w, side_t, side_h, side_p in (("all", True, True, True, True, True), ("no_side_wgrads", True, False, True, True, True),
+                                                          ("no_side_transposes", True, True, False, True, True), ("no_side_heads", True, True, True, False, True),
+                                                          ("no_side_pairs", True, True, True, True, False), ("none", False, False, False, False, False)):
             _ops.SIDE_TRANSPOSES = side_t
             m = build(cfg, dropout=0.1)
             m.train()
             m.manual_seed(13)
-            m.defer_wgrads, m.late_wgrads, m.wgrad_side_stream = True, late, side_w
+            m.defer_wgrads, m.late_wgrads, m.wgrad_side_stream, m.heads_side_stream, m.pairs_side_stream = True, late, side_w, side_h, side_p
             opt, sched = T.build_optimizer(m, T.default_args(train_batch_size=6, learning_rate=3e-4), 10, mode="hf")
             losses = []
             for i in range(6):
@@ -750,7 +753,7 @@ def test_side_streams_and_late_weight_gradients_give_bit_identical_training_runs
         _ops.SIDE_TRANSPOSES = was_side
     ref_l, ref_p = runs["all"]
     assert bool(torch.isfinite(ref_l).all())
-    for tag in ("no_side_wgrads", "no_side_transposes"):
+    for tag in ("no_side_wgrads", "no_side_transposes", "no_side_heads", "no_side_pairs"):
         assert torch.equal(runs[tag][0], ref_l), (tag, runs[tag][0], ref_l)
         for n in ref_p:
             assert torch.equal(runs[tag][1][n], ref_p[n]), (tag, n)
