@@ -1782,10 +1782,11 @@ class _HeadsStepFn(torch.autograd.Function):
                                                       qs[m].bias.grad.data_ptr())
         assert at.weight.grad.is_contiguous()
         a.sync = ops.heads_step_sync(dev).data_ptr()
-        if ctx.side and dmlm is not None and getattr(top, "heads_side_stream", True) and top.grad_hook is None and top.head_grad_hook is None:
+        if ctx.side and dmlm is not None and getattr(top, "heads_side_stream", True):
             # round 6: the six levels on a side stream, beside the MLM head's sparse backward (which needs nothing of the heads' but the
             # gradient of its per-pass losses: one tiny launch here) -- two chains of small dependent launches that leave the chip empty,
-            # 82 and 97 us, side by side.  _MLMHeadFn.backward joins before it reads dfirst (_join_heads)
+            # 82 and 97 us, side by side.  _MLMHeadFn.backward joins before it reads dfirst (_join_heads) -- that is BEFORE the trunk's
+            # backward starts, where a data-parallel wrapper's head_grad_hook reads the heads' gradients: the hook needs nothing extra
             ops.heads_step_dmlm(a)
             scratch = torch.empty_like(dmlm)
             a.dmlm = scratch.data_ptr()                            # (level 6 writes the same values: into its own words)
