@@ -348,8 +348,8 @@ def _flush_late_wgrads(top, long_probs=(), deferred=False):
 def _join_heads(top):
     """The current stream waits for the heads' backward levels queued on the side stream (_HeadsStepFn.backward; no-op otherwise)."""
     j = top.__dict__.pop("_heads_join", None)
-    if j is not None:
-        torch.cuda.current_stream().wait_event(j[0])
+    if j:
+        torch.cuda.current_stream().wait_event(j[-1][0])
 
 
 def _join_wgrads(top):
@@ -1794,7 +1794,9 @@ class _HeadsStepFn(torch.autograd.Function):
             s.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(s):
                 ops.heads_step_bwd(a)
-                top.__dict__["_heads_join"] = (s.record_event(), scratch, d1, ctx.keep)
+                # (a list: a second graph's backward may fork before the first one's MLM head has joined -- one in-order stream, so the
+                # LAST event covers all of them; every record keeps its operands alive until then)
+                top.__dict__.setdefault("_heads_join", []).append((s.record_event(), scratch, d1, ctx.keep))
             a.dmlm = dmlm.data_ptr()
             return dfirst, None, None, None, dmlm, None
         ops.heads_step_bwd(a)

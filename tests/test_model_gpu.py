@@ -828,6 +828,38 @@ def test_deferred_weight_gradients_equal_the_per_layer_launches():
         same_grads(grads[True][n], grads[False][n], n)
 
 
+def test_two_graphs_in_flight_one_backward_equals_two_backward_passes():
+    """Round 6: two forward passes, then ONE backward of the sum of their losses.  autograd then runs both heads' and both MLM heads' backward
+    stages before either trunk's: the heads' side stream forks twice before the first join, and the few-row weight gradients of BOTH graphs
+    wait for the deferred call -- two writers of the tied decoder's, the MLM transform's and the top layer's gradients, which must never
+    share a launch (model._late_wgrad flushes the first set).  Against the same two forward passes differentiated one after the other (the
+    second accumulates): the same gradients up to fp32 summation order.  Train mode, forced deferred call, five layers."""
+    cfg = dict(hidden=256, layers=5, heads=4, intermediate=1024, vocab=4096, dataset="mosei", alpha=1.0, beta=1.0)
+    b1 = batch_to(synthetic_batch(4, 24, 200, 130, dataset="mosei", vocab=cfg["vocab"], seed=61), DEV)
+    b2 = batch_to(synthetic_batch(4, 24, 200, 130, dataset="mosei", vocab=cfg["vocab"], seed=62), DEV)
+    grads = {}
+    for mode in ("sum", "apart"):
+        m = build(cfg, train=True)
+        m.manual_seed(21)
+        m.defer_wgrads = True
+        o1, _ = m(**b1)
+        if mode == "apart":
+            o1[0].mean().backward()
+        o2, _ = m(**b2)
+        if mode == "apart":
+            o2[0].mean().backward()
+        else:
+            (o1[0] + o2[0]).backward()
+        torch.cuda.synchronize()
+        assert not m.__dict__.get("_late_wgrads") and not m.__dict__.get("_heads_join") and m.__dict__.get("_wgrad_join") is None
+        grads[mode] = {n: q.grad.float().clone() for n, q in m.named_parameters() if q.grad is not None}
+    assert grads["sum"].keys() == grads["apart"].keys()
+    for n in grads["sum"]:
+        if "attention.self.key.bias" in n:
+            continue
+        same_grads(grads["sum"][n], grads["apart"][n], n)
+
+
 def test_one_layernorm_reduce_per_backward_and_no_leftovers_after_a_failed_one():
     """Round 4: every LayerNorm' of a backward pass (MLM head, sparse top layer, dense layers, embedding stage) shares ONE collector:
     ONE mmbert_ln_bwd_reduce_rows launch per backward (the trunk's flush at its end) instead of one per call, the
