@@ -515,7 +515,13 @@ def main():
                    "scores_dtype": {torch.bfloat16: "bf16", torch.float32: "fp32"}[model.scores_dtype],
                    "mlm_backward": "labelled rows only (exact: unlabelled rows have zero CE gradient)",
                    "backward_row_fraction": round(f, 4),
-                   "backward_rows": "rows behind a sequence's last unmasked key and without a label have zero gradients in every layer: backward skips them (exact)"},
+                   "backward_rows": "rows behind a sequence's last unmasked key and without a label have zero gradients in every layer: backward skips them (exact)",
+                   # round 6: how the step is scheduled (the work itself is unchanged: bit-identical with every one of these off, tests/test_train_gpu.py)
+                   "scheduling": {"few_row_weight_gradients_in_the_deferred_call": bool(getattr(model, "late_wgrads", False) and dp is None),
+                                  "side_streams": {"heads": bool(getattr(model, "heads_side_stream", False)),
+                                                   "deferred_weight_gradient_call": bool(getattr(model, "wgrad_side_stream", False) and dp is None),
+                                                   "pair_projections": bool(getattr(model, "pairs_side_stream", False)),
+                                                   "transposed_weight_copies": bool(getattr(ops, "SIDE_TRANSPOSES", False))}}},
         "final_loss": round(loss, 4),
         # the host's share of the headline region: wall time until the last step() call returned (the GPU still has queued work then);
         # ms_per_step - host_enqueue_ms = how far ahead of the GPU the host runs.  Under the data-parallel wrapper this includes its hooks
